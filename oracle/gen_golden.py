@@ -1,0 +1,160 @@
+"""Generate tests/golden/*.npz -- run in the BUILD container only (needs /root/reference for the model
+fixture and /opt/conda/bin/h5dump).  TEST INFRASTRUCTURE ONLY.
+
+    python -m oracle.gen_golden
+
+Expected outputs come from the numpy/scipy restatement (oracle/np_oracle.py); before anything is
+written, each is checked against the C oracle (oracle/vc_oracle.c) -- the two independent
+restatements must agree (bit-exact for DTW, <=1e-9 relative for floating-point paths).  The only data
+taken from the reference tree are the trained-model tensors of
+test/models/clb_to_slt_gmm32_order40_diff.jld (the model test/gmmmap.jl:3-8 loads) and the DTW
+known-answer vectors of test/dtw.jl:7-31.
+"""
+import os
+import subprocess
+import tempfile
+
+import numpy as np
+
+from . import c_oracle as co
+from . import np_oracle as npo
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(ROOT, "tests", "golden")
+REF_MODEL = "/root/reference/test/models/clb_to_slt_gmm32_order40_diff.jld"
+H5DUMP = "/opt/conda/bin/h5dump"
+
+
+def _relmax(a, b):
+    return float(np.max(np.abs(a - b)) / max(np.max(np.abs(a)), 1e-300))
+
+
+def extract_model():
+    """raw HDF5 buffers are the Julia memory image."""
+    with tempfile.TemporaryDirectory() as td:
+        arrs = {}
+        for name in ("weights", "means", "covars"):
+            p = os.path.join(td, name + ".bin")
+            subprocess.check_call([H5DUMP, "-d", "/" + name, "-b", "LE", "-o", p, REF_MODEL], stdout=subprocess.DEVNULL)
+            arrs[name] = np.fromfile(p, dtype="<f8")
+    w = arrs["weights"]
+    M = len(w)
+    mu = arrs["means"].reshape(M, -1)
+    Dj = mu.shape[1]
+    sig = arrs["covars"].reshape(M, Dj, Dj)      # [m][col][row]
+    return w, mu, sig
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    w, mu, sig = extract_model()
+    M, Dj = mu.shape
+    D = Dj // 2
+    np.savez(os.path.join(OUT, "model_clb_to_slt_gmm32_order40_diff.npz"), weights=w, means=mu, covars=sig)
+
+    # ---- (2) frame conversion on the fixture model, both directions
+    out = {}
+    for swap in (False, True):
+        gn, gc = npo.GMMMap(w, mu, sig, swap=swap), co.GMMMap(w, mu, sig, swap=swap)
+        lo = D if swap else 0
+        X = npo.sample_frames(20261 + swap, w, mu, sig, 256, lo, lo + D)
+        Y, P, idx = gn.fvconvert(X), gn.predict_proba(X), gn.predict(X)
+        assert _relmax(Y, gc.fvconvert(X)) < 1e-9 and np.max(np.abs(P - gc.predict_proba(X))) < 1e-9
+        assert np.array_equal(idx, gc.predict(X))
+        assert _relmax(gn.A, gc.A) < 1e-9
+        k = "swap" if swap else "fwd"
+        out.update({f"X_{k}": X, f"Y_{k}": Y, f"P_{k}": P, f"idx_{k}": idx})
+    # vc(): power row passthrough
+    fm = np.concatenate([np.linspace(-3, 3, 64)[:, None], out["X_fwd"][:64]], axis=1)
+    gn = npo.GMMMap(w, mu, sig)
+    out["vc_fm"], out["vc_out"] = fm, npo.vc_frames(gn, fm)
+    np.savez(os.path.join(OUT, "gmmmap_fixture_model.npz"), **out)
+
+    # ---- config 1 of BASELINE.json: D=24, M=8, T=1000 synthetic (plumbing case)
+    w1, mu1, sig1 = npo.synth_model(1001, 48, 8)
+    X1 = npo.sample_frames(1001, w1, mu1, sig1, 1000, 0, 24)
+    g1n, g1c = npo.GMMMap(w1, mu1, sig1), co.GMMMap(w1, mu1, sig1)
+    Y1 = g1n.fvconvert(X1)
+    assert _relmax(Y1, g1c.fvconvert(X1)) < 1e-9
+    np.savez(os.path.join(OUT, "gmmmap_cfg1_D24_M8_T1000.npz"), weights=w1, means=mu1, covars=sig1, X=X1, Y=Y1,
+             idx=g1n.predict(X1))
+
+    # ---- (3) DTW: the reference's two KATs + random pairs
+    dt = {}
+    v1 = np.array([[1., 2, 3], [1, 2, 4], [1, 8, 5], [10, 3, 6]])
+    v2 = np.array([[1., 2, 3], [1, 2, 4], [1, 2, 5], [1, 8, 5], [10, 3, 6]])
+    a1 = np.array([[0.], [1], [2], [3], [4], [5]])
+    a2 = np.array([[0.], [0], [1], [2], [3], [4], [4], [5]])
+    kats = [(v1, v2, 0, 1, [1, 2, 2, 3, 4]), (a1, a2, 0, 1, [1, 1, 2, 3, 4, 5, 5, 6])]   # test/dtw.jl:17,29
+    for k, (t, s, fs, bs, exp) in enumerate(kats):
+        p, c, b = npo.dtw_fit(t, s, fs, bs)
+        assert p.tolist() == exp and co.dtw_fit(t, s, fs, bs)[0].tolist() == exp
+        dt.update({f"kat{k}_tmpl": t, f"kat{k}_seq": s, f"kat{k}_path": np.array(exp, dtype=np.int64),
+                   f"kat{k}_cost": c, f"kat{k}_bp": b, f"kat{k}_steps": np.array([fs, bs])})
+    rng = np.random.default_rng(424242)
+    n = 0
+    for Dd in (1, 3, 40):
+        for bs, fs in ((1, 0), (2, 0), (2, 1), (3, 2)):
+            for rep in range(2):
+                S, T = int(rng.integers(5, 61)), int(rng.integers(5, 61))
+                t = rng.standard_normal((S, Dd))
+                # sequence: time-warped noisy copy of the template so that paths are non-trivial
+                src_idx = np.clip(np.sort(rng.integers(0, S, T)), 0, S - 1)
+                s = t[src_idx] + 0.3 * rng.standard_normal((T, Dd))
+                if rep == 1:
+                    s = np.round(s * 2) / 2      # coarse values -> exact cost ties exercise the strict '<' rule
+                    t = np.round(t * 2) / 2
+                p, c, b = npo.dtw_fit(t, s, fs, bs)
+                p2, c2, b2 = co.dtw_fit(t, s, fs, bs)
+                assert np.array_equal(p, p2) and np.array_equal(c, c2) and np.array_equal(b, b2)
+                nt, ap = npo.align(t, s)
+                nt2, ap2 = co.align(t, s)
+                assert np.array_equal(nt, nt2) and np.array_equal(ap, ap2)
+                dt.update({f"r{n}_tmpl": t, f"r{n}_seq": s, f"r{n}_path": p, f"r{n}_cost": c, f"r{n}_bp": b,
+                           f"r{n}_steps": np.array([fs, bs]), f"r{n}_align_newtgt": nt, f"r{n}_align_path": ap})
+                n += 1
+    dt["n_random"] = np.array(n)
+    np.savez_compressed(os.path.join(OUT, "dtw_cases.npz"), **dt)
+
+    # ---- (4) trajectory: W pattern (test/trajectory_gmmmap.jl:53) + a solve with the fixture model read as
+    #      static D=20 + delta D=20 (the *_with_delta model is missing from the reference tree)
+    tr = {}
+    r, c, v = co.constructW(30, 40)
+    Wn = npo.constructW(30, 40).tocoo()
+    import scipy.sparse as sp
+    assert abs(sp.coo_matrix((v, (r - 1, c - 1)), shape=Wn.shape).tocsc() - Wn.tocsc()).max() == 0
+    tr.update(W_rows=r, W_cols=c, W_vals=v)
+    gn, gc = npo.GMMMap(w, mu, sig), co.GMMMap(w, mu, sig)
+    tn, tc = npo.TrajectoryGMMMap(gn), co.TrajectoryGMMMap(gc)
+    static = npo.sample_frames(777, w, mu, sig, 100, 0, D // 2)
+    # smooth the static track so that delta features are speech-like, then push_delta
+    static = np.cumsum(static, axis=0) / np.sqrt(np.arange(1, 101))[:, None]
+    Xd = npo.push_delta(static)
+    assert np.array_equal(Xd, co.push_delta(static))
+    Y, mh, Ey = tn.fvconvert(Xd)
+    Yc, mhc, Eyc = tc.fvconvert(Xd)
+    assert np.array_equal(mh, mhc) and _relmax(Y, Yc) < 1e-6 and _relmax(Ey, Eyc) < 1e-9, (_relmax(Y, Yc))
+    fmt = np.concatenate([np.linspace(0, 1, 100)[:, None], Xd], axis=1)
+    vco = npo.vc_traj(tn, fmt, 30)
+    assert _relmax(vco, tc.vc(fmt, 30)) < 1e-6
+    tr.update(static=static, X=Xd, Y=Y, mhat=mh, Ey=Ey, vc_fm=fmt, vc_out_L30=vco)
+    np.savez(os.path.join(OUT, "trajectory_fixture_model.npz"), **tr)
+
+    # ---- (5) diagonal E-step, N=2000, Dj=80, M=16
+    wd, mud, _ = npo.synth_model(3003, 80, 16)
+    rg = np.random.default_rng(3003)
+    var = np.exp(rg.uniform(np.log(1e-3), 0.0, (16, 80)))
+    comp = rg.choice(16, size=2000, p=wd)
+    Xe = mud[comp] + rg.standard_normal((2000, 80)) * np.sqrt(var[comp])
+    S0, S1, S2, ll = npo.estep_diag(Xe, wd, mud, var)
+    c0, c1, c2, cl = co.estep_diag(Xe, wd, mud, var)
+    assert _relmax(S0, c0) < 1e-10 and _relmax(S1, c1) < 1e-10 and _relmax(S2, c2) < 1e-10 and abs(ll - cl) < 1e-8 * abs(ll)
+    np.savez(os.path.join(OUT, "estep_diag_N2000_D80_M16.npz"), X=Xe, w=wd, mu=mud, var=var, S0=S0, S1=S1, S2=S2,
+             loglik=np.array(ll))
+    print("golden fixtures written to", OUT)
+    for f in sorted(os.listdir(OUT)):
+        print(f"  {f}: {os.path.getsize(os.path.join(OUT, f)) / 1e6:.2f} MB")
+
+
+if __name__ == "__main__":
+    main()

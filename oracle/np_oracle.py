@@ -1,0 +1,241 @@
+"""numpy/scipy restatement of the VoiceConversion.jl hot path -- TEST INFRASTRUCTURE ONLY.
+
+Second, independent restatement of the reference algorithm (the first is oracle/vc_oracle.c).  It is
+written the way the Julia source is written (explicit sparse W, scipy Cholesky / LU, explicit
+posterior vector), so that agreement between the two restatements is evidence for both.  Used by
+oracle/gen_golden.py to produce tests/golden/*.npz and by the CPU tests.  The product never imports it.
+
+Arrays follow numpy convention [frame, feature] = the Julia (feature, frame) column-major memory image,
+so `X.ravel()` is byte-for-byte what Julia would hand to ccall.  Indices returned are 1-based (Julia).
+
+Pinning: DTW by test/dtw.jl:7-31, constructW by test/trajectory_gmmmap.jl:1-34 of the reference;
+fvconvert / trajectory / E-step numerics are PARITY UNPINNED by the reference's tests (isfinite only).
+"""
+import numpy as np
+import scipy.linalg as sla
+import scipy.sparse as sp
+import scipy.sparse.linalg as spla
+
+LOG2PI = float(np.log(2.0 * np.pi))
+
+
+class GMMMap:
+    """src/gmmmap.jl:57-96.  w (M,), mu (M,Dj) [= Julia (Dj,M)], sigma (M,Dj,Dj) indexed [m][col][row]."""
+
+    def __init__(self, w, mu, sigma, swap=False):
+        w = np.asarray(w, dtype=np.float64)
+        mu = np.asarray(mu, dtype=np.float64)
+        sigma = np.asarray(sigma, dtype=np.float64)
+        M, Dj = mu.shape
+        D = Dj >> 1                                               # src/gmmmap.jl:70
+        S = np.transpose(sigma, (0, 2, 1))                        # S[m][row][col]
+        mux, muy = mu[:, :D], mu[:, D:]                           # split_joint_gmm, src/gmmmap.jl:41-52
+        Sxx, Sxy, Syx, Syy = S[:, :D, :D], S[:, :D, D:], S[:, D:, :D], S[:, D:, D:]
+        if swap:                                                  # src/gmmmap.jl:74-78
+            mux, muy = muy, mux
+            Sxx, Syy = Syy, Sxx
+            Sxy, Syx = Syx, Sxy
+        self.D, self.M, self.w = D, M, w
+        self.mux, self.muy = mux.copy(), muy.copy()
+        self.Sxx, self.Sxy, self.Syx, self.Syy = (a.copy() for a in (Sxx, Sxy, Syx, Syy))
+        # src/gmmmap.jl:33-36: Syx * Sxx^-1 (general inverse of the raw block)
+        self.A = np.stack([self.Syx[m] @ np.linalg.inv(self.Sxx[m]) for m in range(M)])
+        # src/gmm.jl:16-17: Hermitian() mirrors the upper triangle; MvNormal Cholesky-factorises it
+        self.chol = []
+        for m in range(M):
+            U = np.triu(self.Sxx[m])
+            Ssym = U + np.triu(self.Sxx[m], 1).T
+            self.chol.append(np.linalg.cholesky(Ssym))            # raises LinAlgError if not PD
+        self.logdet = np.array([2.0 * np.sum(np.log(np.diag(L))) for L in self.chol])
+
+    def log_weighted(self, x):
+        """lpr_m = logpdf(N(mux_m, Sxx_m), x) + log w_m  (src/gmm.jl:25-27)."""
+        lpr = np.full(self.M, -np.inf)
+        for m in range(self.M):
+            if not self.w[m] > 0.0:
+                continue
+            z = sla.solve_triangular(self.chol[m], x - self.mux[m], lower=True)
+            lpr[m] = -(self.D * LOG2PI + self.logdet[m]) / 2.0 - (z @ z) / 2.0 + np.log(self.w[m])
+        return lpr
+
+    def predict_proba1(self, x):
+        lpr = self.log_weighted(x)
+        u = np.max(lpr)
+        lse = u + np.log(np.sum(np.exp(lpr - u)))                 # StatsFuns.logsumexp, src/gmm.jl:28
+        return np.exp(lpr - lse)                                  # src/gmm.jl:29
+
+    def predict_proba(self, X):
+        return np.stack([self.predict_proba1(x) for x in X])     # (T,M) = Julia (M,T)
+
+    def predict(self, X):
+        return np.array([int(np.argmax(self.predict_proba1(x))) + 1 for x in X], dtype=np.int64)
+
+    def fvconvert1(self, x):
+        """src/gmmmap.jl:101-118."""
+        E = np.stack([self.muy[m] + self.A[m] @ (x - self.mux[m]) for m in range(self.M)], axis=1)  # (D,M)
+        return E @ self.predict_proba1(x)
+
+    def fvconvert(self, X):
+        return np.stack([self.fvconvert1(x) for x in X])
+
+
+def vc_frames(g, fm):
+    """vc(c::FrameByFrameConverter, fm), src/common.jl:7-26; fm is (T, D+1) here."""
+    out = np.empty_like(fm)
+    out[:, 1:] = g.fvconvert(fm[:, 1:])
+    out[:, 0] = fm[:, 0]
+    return out
+
+
+# ---------------------------------------------------------------------------------------------- DTW
+def dtw_fit(tmpl, seq, fstep=0, bstep=1):
+    """fit!(d, template, sequence), src/dtw.jl:93-145.  tmpl (S,D), seq (T,D).
+    Returns path (T,), costtable (T+1,S) [= Julia (S,T+1)], backpointer (T+1,S) int64; all 1-based."""
+    S, T = tmpl.shape[0], seq.shape[0]
+    D = tmpl.shape[1]
+    cost = np.zeros((T + 1, S))
+    bp = np.ones((T + 1, S), dtype=np.int64)
+    cost[0] = np.arange(1, S + 1)
+    bp[0] = np.arange(1, S + 1)
+    for t in range(1, T + 1):
+        v = seq[t - 1]
+        for i in range(1, S + 1):
+            o = 0.0
+            for d in range(D):                                    # sequential, unfused (oracle's association)
+                df = v[d] - tmpl[i - 1, d]
+                o = o + df * df
+            minindex = i
+            mincost = cost[t - 1, i - 1] + o + 1.0
+            for j in range(i - bstep, i + fstep + 1):
+                if j < 1 or j > S:
+                    continue
+                tr = 0.0 if i == j + 1 else (1.0 if i == j else 2.0)
+                c = cost[t - 1, j - 1] + o + tr
+                if c < mincost:
+                    mincost, minindex = c, j
+            cost[t, i - 1] = mincost
+            bp[t, i - 1] = minindex
+    path = np.zeros(T, dtype=np.int64)
+    if T > 0:
+        path[T - 1] = int(np.argmin(cost[T])) + 1
+        for i in range(T, 1, -1):
+            path[i - 2] = bp[i, path[i - 1] - 1]
+    return path, cost, bp
+
+
+def align(src, tgt):
+    """align(src, tgt), src/align.jl:8-35.  src (S,D), tgt (T,D) -> newtgt (S,D), path."""
+    path, _, _ = dtw_fit(src, tgt, fstep=0, bstep=2)
+    newtgt = np.zeros_like(src)
+    for k in range(len(path)):
+        newtgt[path[k] - 1] = tgt[k]
+    S = src.shape[0]
+    if len(path):
+        have = set(path.tolist())
+        for i in range(path[0], path[-1] + 1):
+            if i in have:
+                continue
+            if 1 < i < S:
+                newtgt[i - 1] = (newtgt[i - 2] + newtgt[i]) / 2.0
+    return newtgt, path
+
+
+# ---------------------------------------------------------------------------------------- trajectory
+def constructW(D, T):
+    """src/trajectory_gmmmap.jl:39-61, as a scipy CSC matrix (2DT x DT)."""
+    W = sp.lil_matrix((2 * D * T, D * T))
+    I = np.arange(D)
+    for t in range(T):
+        W[2 * D * t + I, t * D + I] = 1.0
+        if t >= 1:
+            W[2 * D * t + D + I, (t - 1) * D + I] = -0.5
+        if t < T - 1:
+            W[2 * D * t + D + I, (t + 1) * D + I] = 0.5
+    return W.tocsc()
+
+
+def push_delta(src):
+    """src/datasets.jl:6-13; src (T,D) -> (T,2D); first/last frames keep the static copy in the delta rows."""
+    T, D = src.shape
+    out = np.concatenate([src, src], axis=1)
+    for t in range(1, T - 1):
+        out[t, D:] = -0.5 * src[t - 1] + 0.5 * src[t + 1]
+    return out
+
+
+class TrajectoryGMMMap:
+    """src/trajectory_gmmmap.jl:3-37."""
+
+    def __init__(self, g):
+        self.g = g
+        self.Dy = np.stack([np.linalg.inv(g.Syy[m] - g.A[m] @ g.Sxy[m]) for m in range(g.M)])   # :24-28
+
+    def fvconvert(self, X):
+        """src/trajectory_gmmmap.jl:65-110.  X (T,2D) -> (T,D); also returns mhat, Ey."""
+        g = self.g
+        T, D2 = X.shape
+        D = D2 >> 1
+        W = constructW(D, T)
+        mhat = g.predict(X)                                               # :82
+        Ey = np.stack([g.muy[m - 1] + g.A[m - 1] @ (X[t] - g.mux[m - 1]) for t, m in enumerate(mhat)])  # :85-89
+        Dinv = sp.block_diag([sp.csc_matrix(self.Dy[m - 1]) for m in mhat], format="csc")             # :95
+        WtD = W.T @ Dinv                                                  # :103
+        y = spla.spsolve((WtD @ W).tocsc(), WtD @ Ey.ravel())             # :105
+        return y.reshape(T, D), mhat, Ey
+
+
+def vc_traj(tj, fm, L):
+    """vc(c::TrajectoryConverter, fm), src/common.jl:31-63; fm (T, 2D+1) -> (T, D+1); chunks of L frames."""
+    T = fm.shape[0]
+    D = (fm.shape[1] - 1) >> 1
+    out = np.empty((T, D + 1))
+    b = 0
+    while b < T:
+        e = min(b + L, T)
+        out[b:e, 1:] = tj.fvconvert(fm[b:e, 1:])[0]
+        b = e
+    out[:, 0] = fm[:, 0]
+    return out
+
+
+# ------------------------------------------------------------------------------------------ E-step
+def estep_diag(X, w, mu, var):
+    """Diagonal E-step.  X (N,Dj); w (M,); mu,var (M,Dj).  Returns S0,S1,S2,loglik."""
+    Dj = X.shape[1]
+    cst = np.log(w) - 0.5 * (Dj * LOG2PI + np.sum(np.log(var), axis=1))
+    q = np.sum((X[:, None, :] - mu[None, :, :]) ** 2 / var[None, :, :], axis=2)       # (N,M)
+    lpr = cst[None, :] - 0.5 * q
+    u = lpr.max(axis=1, keepdims=True)
+    lse = u[:, 0] + np.log(np.sum(np.exp(lpr - u), axis=1))
+    gam = np.exp(lpr - lse[:, None])
+    return gam.sum(0), gam.T @ X, gam.T @ (X * X), float(lse.sum())
+
+
+# ------------------------------------------------------------------- synthetic generators
+def synth_model(seed, Dj, M, lam_lo=1e-5, lam_hi=1.0):
+    """Synthetic joint GMM: Dirichlet(2) weights, N(0,1) means, covariances Q diag(lam) Q' with lam
+    log-uniform in [lam_lo, lam_hi] (cond ~ fixture's 1e6-1e7), exactly symmetrised."""
+    rng = np.random.default_rng(seed)
+    w = rng.dirichlet(2.0 * np.ones(M))
+    mu = rng.standard_normal((M, Dj))
+    sig = np.empty((M, Dj, Dj))
+    for m in range(M):
+        Q, _ = np.linalg.qr(rng.standard_normal((Dj, Dj)))
+        lam = np.exp(rng.uniform(np.log(lam_lo), np.log(lam_hi), Dj))
+        S = (Q * lam) @ Q.T
+        sig[m] = (S + S.T) / 2.0
+    return w, mu, sig
+
+
+def sample_frames(seed, w, mu, sig, T, lo, hi):
+    """Frames drawn from the model's own marginal over dims [lo,hi): component ~ w, then mu + L z."""
+    rng = np.random.default_rng(seed)
+    M = len(w)
+    comp = rng.choice(M, size=T, p=w / w.sum())
+    Ls = [np.linalg.cholesky((sig[m][lo:hi, lo:hi] + sig[m][lo:hi, lo:hi].T) / 2.0) for m in range(M)]
+    Z = rng.standard_normal((T, hi - lo))
+    X = np.empty((T, hi - lo))
+    for m in range(M):
+        sel = comp == m
+        X[sel] = mu[m, lo:hi] + Z[sel] @ Ls[m].T
+    return X
