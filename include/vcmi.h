@@ -1,0 +1,140 @@
+/*
+ * vcmi.h -- C-ABI of libvcmi.so: the MI355X (gfx950) hot path of r9y9/VoiceConversion.jl.
+ *
+ * The reference is pure Julia and has no FFI of its own; its boundary is the exported Julia API
+ * (src/VoiceConversion.jl:12-38, src/dtw.jl:7).  Each entry point below replaces the body of one of
+ * those Julia functions and is what the Julia wrapper (voiceconversion.jl_amd/julia/VoiceConversionMI.jl)
+ * binds with `ccall((:sym, "libvcmi"), Cint, ...)`; the same symbols are bound from Python ctypes
+ * (voiceconversion.jl_amd/_lib.py).  INTEGRATION.md shows both bindings.
+ *
+ * Conventions
+ *   - every array is the Julia memory image: column-major Float64; a (D,T) feature matrix is T frames
+ *     of D contiguous doubles (`ld` = distance in doubles between consecutive frames, >= D);
+ *   - indices written to callers are Julia's: Int64, 1-based;
+ *   - plain "host" entry points take host pointers, copy to the current HIP device, run, copy back and
+ *     return when the result is in the caller's buffer; `_dev` entry points take DEVICE pointers and a
+ *     hipStream_t (passed as void*; NULL = default stream) and only enqueue work;
+ *   - every function returns a vcmi_status; vcmi_last_error() gives the thread-local message.  No C++
+ *     exception or abort crosses this boundary.  The Julia wrapper maps VCMI_ERR_DIM ->
+ *     DimensionMismatch (src/gmmmap.jl:102, src/trajectory_gmmmap.jl:68, src/align.jl:11-13),
+ *     VCMI_ERR_NOT_PD -> PosDefException (raised by MvNormal in src/gmm.jl:17), others -> ErrorException;
+ *   - handles are not re-entrant: one handle must not be used from two threads at once (the reference's
+ *     GMMMap carries mutable scratch too, src/gmmmap.jl:59).
+ */
+#ifndef VCMI_H
+#define VCMI_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  VCMI_OK = 0,
+  VCMI_ERR_DIM = 1,       /* inconsistent dimensions              -> DimensionMismatch */
+  VCMI_ERR_NOT_PD = 2,    /* covariance block not positive definite -> PosDefException */
+  VCMI_ERR_HIP = 3,       /* HIP runtime / kernel failure */
+  VCMI_ERR_OOM = 4,       /* host or device allocation failed */
+  VCMI_ERR_ARG = 5,       /* NULL pointer, negative size, unsupported option */
+  VCMI_ERR_NO_DEVICE = 6  /* no gfx950 device visible */
+} vcmi_status;
+
+const char *vcmi_last_error(void);
+const char *vcmi_version(void);
+int vcmi_device_count(int *count);
+/* Select the HIP device used by this thread's subsequent calls (one process per GPU: LOCAL_RANK). */
+int vcmi_set_device(int device);
+
+/* ---------------------------------------------------------------------------------------------
+ * GMMMap -- src/gmmmap.jl:57-118, posterior helpers src/gmm.jl:24-58
+ * ------------------------------------------------------------------------------------------- */
+typedef struct vcmi_gmmmap vcmi_gmmmap;
+
+/* GMMMap(weights, mu, Sigma; swap=false), src/gmmmap.jl:62-90: weights (M), mu (Dj,M), Sigma (Dj,Dj,M).
+ * Splits the joint GMM (:41-52), forms A_m = Sigma^yx_m inv(Sigma^xx_m) (:33-36) and the Cholesky factor
+ * of Hermitian(Sigma^xx_m) (src/gmm.jl:16-17) on the host, and uploads the packed per-mixture blocks. */
+int vcmi_gmmmap_create(const double *weights, const double *mu, const double *sigma, int Dj, int M, int swap,
+                       vcmi_gmmmap **out);
+int vcmi_gmmmap_destroy(vcmi_gmmmap *g);
+int vcmi_gmmmap_dim(const vcmi_gmmmap *g);          /* dim(g),         src/gmmmap.jl:94 */
+int vcmi_gmmmap_ncomponents(const vcmi_gmmmap *g);  /* ncomponents(g), src/gmmmap.jl:95 */
+/* g.params.ΣʸˣΣˣˣ⁻¹ (D,D,M), src/gmmmap.jl:21 */
+int vcmi_gmmmap_get_A(const vcmi_gmmmap *g, double *A);
+
+/* fvconvert(g, x) for every column of X (D,T) -> Y (D,T); src/gmmmap.jl:101-118.  One launch replaces the
+ * frame loop of src/common.jl:17-19.  T = 1 is the reference's per-frame call. */
+int vcmi_gmmmap_convert(vcmi_gmmmap *g, const double *X, int64_t ldx, int64_t T, double *Y, int64_t ldy);
+int vcmi_gmmmap_convert_dev(vcmi_gmmmap *g, const double *dX, int64_t ldx, int64_t T, double *dY, int64_t ldy,
+                            void *stream);
+/* vc(c::FrameByFrameConverter, fm), src/common.jl:7-26: fm, out are (D+1,T); row 1 (power) is copied. */
+int vcmi_vc_frames(vcmi_gmmmap *g, const double *fm, int64_t T, double *out);
+/* predict_proba(g.px, X) -> P (M,T), src/gmm.jl:24-41 */
+int vcmi_gmmmap_posterior(vcmi_gmmmap *g, const double *X, int64_t ldx, int64_t T, double *P);
+int vcmi_gmmmap_posterior_dev(vcmi_gmmmap *g, const double *dX, int64_t ldx, int64_t T, double *dP, void *stream);
+/* predict(g.px, X) -> idx (T), 1-based, first maximum wins; src/gmm.jl:44-58 */
+int vcmi_gmmmap_predict(vcmi_gmmmap *g, const double *X, int64_t ldx, int64_t T, int64_t *idx);
+int vcmi_gmmmap_predict_dev(vcmi_gmmmap *g, const double *dX, int64_t ldx, int64_t T, int64_t *didx, void *stream);
+/* Kernel selection for convert: 0 = auto (MFMA tile kernel when dim(g) has an instantiation, else the
+ * generic VALU kernel), 1 = force the generic VALU kernel, 2 = force MFMA (VCMI_ERR_ARG if unavailable). */
+int vcmi_gmmmap_set_kernel(vcmi_gmmmap *g, int which);
+
+/* ---------------------------------------------------------------------------------------------
+ * DTW -- src/dtw.jl:93-145 (fit! + backward), align -- src/align.jl:8-35
+ * ------------------------------------------------------------------------------------------- */
+/* fit!(DTW(fstep,bstep), template (D,S), sequence (D,T)) -> path (T).  costtable (S,T+1) f64 and
+ * backpointer (S,T+1) Int64 are the fields d.costtable / d.backpointer (src/dtw.jl:15-16); pass NULL
+ * for both to skip materialising them ("path-only" mode). */
+int vcmi_dtw_fit(const double *tmpl, int64_t S, const double *seq, int64_t T, int D, int fstep, int bstep,
+                 int64_t *path, double *costtable, int64_t *backpointer);
+/* n independent pairs in one launch (one workgroup per pair).  Host pointers. */
+int vcmi_dtw_fit_batch(int64_t n, const double *const *tmpl, const int64_t *S, const double *const *seq,
+                       const int64_t *T, int D, int fstep, int bstep, int64_t *const *path);
+/* Device-resident batch: `feats` is one device buffer holding every (D,len) matrix; pair p has its template at
+ * feats + tmpl_off[p] (S[p] frames) and its sequence at feats + seq_off[p] (T[p] frames); its path goes to
+ * paths + path_off[p].  Offsets (in elements) and lengths are HOST arrays of n entries. */
+int vcmi_dtw_fit_batch_dev(int64_t n, const double *feats, const int64_t *tmpl_off, const int64_t *S,
+                           const int64_t *seq_off, const int64_t *T, int D, int fstep, int bstep, int64_t *paths,
+                           const int64_t *path_off, void *stream);
+/* align(src (D,S), tgt (D,T)) -> newtgt (D,S); path (T) optional (NULL).  src/align.jl:8-35 */
+int vcmi_align(const double *src, int64_t S, const double *tgt, int64_t T, int D, double *newtgt, int64_t *path);
+int vcmi_align_batch(int64_t n, const double *const *src, const int64_t *S, const double *const *tgt,
+                     const int64_t *T, int D, double *const *newtgt);
+
+/* ---------------------------------------------------------------------------------------------
+ * Diagonal-covariance E-step (call site bin/train_gmm.jl:103; math SURVEY A.6)
+ * ------------------------------------------------------------------------------------------- */
+/* X (Dj,N); w (M); mu, var (Dj,M) -> S0 (M), S1, S2 (Dj,M), loglik (1). */
+int vcmi_estep_diag(const double *X, int64_t N, int Dj, int M, const double *w, const double *mu, const double *var,
+                    double *S0, double *S1, double *S2, double *loglik);
+/* Device X; parameters are HOST arrays (tiny).  dstats is a DEVICE buffer of vcmi_estep_stats_len(Dj,M)
+ * doubles laid out [S0 (M) | S1 (Dj,M) | S2 (Dj,M) | loglik] -- one contiguous buffer so that the
+ * multi-GPU path is a single all-reduce(sum).  The result is deterministic run to run. */
+int64_t vcmi_estep_stats_len(int Dj, int M);
+int vcmi_estep_diag_dev(const double *dX, int64_t N, int Dj, int M, const double *w, const double *mu,
+                        const double *var, double *dstats, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * TrajectoryGMMMap -- src/trajectory_gmmmap.jl:3-110, vc src/common.jl:31-63, push_delta src/datasets.jl:6-13
+ * ------------------------------------------------------------------------------------------- */
+typedef struct vcmi_traj vcmi_traj;
+/* TrajectoryGMMMap(g, T): g's dim is 2D (static+delta); precomputes Dy_m = inv(Sigma^yy_m - A_m Sigma^xy_m)
+ * (:24-28).  T only sets length(t) (:34); W is a stencil and is never materialised.  g must outlive t. */
+int vcmi_traj_create(vcmi_gmmmap *g, int64_t T, vcmi_traj **out);
+int vcmi_traj_destroy(vcmi_traj *t);
+int64_t vcmi_traj_length(const vcmi_traj *t);
+/* fvconvert(t, X (2D,T)) -> Y (D,T); src/trajectory_gmmmap.jl:65-110 */
+int vcmi_traj_convert(vcmi_traj *t, const double *X, int64_t T, double *Y);
+/* n utterances, one launch; host pointers */
+int vcmi_traj_convert_batch(vcmi_traj *t, int64_t n, const double *const *X, const int64_t *T, double *const *Y);
+/* device-resident batch: utterance u has X at dX + x_off[u] ((2D,T[u])) and Y at dY + y_off[u] ((D,T[u])) */
+int vcmi_traj_convert_batch_dev(vcmi_traj *t, int64_t n, const double *dX, const int64_t *x_off, const int64_t *T,
+                                double *dY, const int64_t *y_off, void *stream);
+/* vc(c::TrajectoryConverter, fm (2D+1,T)) -> out (D+1,T) in chunks of length(t) frames; src/common.jl:31-63 */
+int vcmi_vc_traj(vcmi_traj *t, const double *fm, int64_t T, double *out);
+/* push_delta(src (D,T)) -> out (2D,T); src/datasets.jl:6-13 (host-side helper, O(DT)) */
+int vcmi_push_delta(const double *src, int D, int64_t T, double *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VCMI_H */

@@ -1,0 +1,135 @@
+"""GPU parity: GMMMap fvconvert / predict_proba / predict / vc through the C-ABI vs the CPU oracle and the
+committed golden vectors.  Tolerance: north_star asks <= 1e-5 relative on converted mel-cepstra; the FP64
+kernels are held to 1e-9 here (observed ~1e-12)."""
+import numpy as np
+import pytest
+
+from conftest import frame_relerr, julia_model, load_golden, relerr
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-9
+
+
+@pytest.fixture(scope="module")
+def vc():
+    import voiceconversion_jl_amd as m
+    assert m.device_count() >= 1
+    return m
+
+
+@pytest.mark.parametrize("kernel", [1, 2])
+@pytest.mark.parametrize("swap", [False, True])
+def test_fixture_model_matches_golden(vc, fixture_model, kernel, swap):
+    w, mu, sig = julia_model(*fixture_model)
+    z = load_golden("gmmmap_fixture_model.npz")
+    k = "swap" if swap else "fwd"
+    g = vc.GMMMap(w, mu, sig, swap=swap)
+    g.set_kernel(kernel)
+    assert len(g) == 1 and vc.dim(g) == 40 and vc.ncomponents(g) == 32 and vc.size(g) == (40, 1)   # test/gmmmap.jl:9-14
+    X = z[f"X_{k}"].T                      # Julia shape (D,T)
+    Y = vc.fvconvert(g, X)
+    assert Y.shape == X.shape
+    assert frame_relerr(Y, z[f"Y_{k}"].T) < TOL
+    P = vc.predict_proba(g.px, X)
+    assert P.shape == (32, X.shape[1])
+    assert np.max(np.abs(P - z[f"P_{k}"].T)) < 1e-9
+    assert np.array_equal(vc.predict(g.px, X), z[f"idx_{k}"])
+    # single-frame signature of the reference, src/gmmmap.jl:101
+    y0 = vc.fvconvert(g, X[:, 0].copy())
+    assert y0.shape == (40,) and relerr(y0, z[f"Y_{k}"][0]) < TOL
+
+
+def test_vc_keeps_power_row(vc, fixture_model):
+    w, mu, sig = julia_model(*fixture_model)
+    z = load_golden("gmmmap_fixture_model.npz")
+    g = vc.GMMMap(w, mu, sig)
+    out = vc.vc(g, z["vc_fm"].T)
+    assert np.array_equal(out[0], z["vc_fm"][:, 0])                  # src/common.jl:23
+    assert frame_relerr(out[1:], z["vc_out"][:, 1:].T) < TOL
+
+
+@pytest.mark.parametrize("kernel", [1, 2])
+def test_config1_plumbing(vc, kernel):
+    """BASELINE.json configs[0]: D=24, M=8, T=1000."""
+    z = load_golden("gmmmap_cfg1_D24_M8_T1000.npz")
+    g = vc.GMMMap(*julia_model(z["weights"], z["means"], z["covars"]))
+    g.set_kernel(kernel)
+    Y = vc.fvconvert(g, z["X"].T)
+    assert frame_relerr(Y, z["Y"].T) < TOL
+    assert np.array_equal(vc.predict(g.px, z["X"].T), z["idx"])
+
+
+@pytest.mark.parametrize("D,M,T", [(40, 64, 4099), (16, 3, 130), (20, 5, 1), (25, 4, 77), (7, 2, 65), (80, 8, 300)])
+def test_random_models_vs_oracle(vc, D, M, T):
+    """Seeded synthetic models (SURVEY 8d generator) at sizes the C oracle finishes in seconds; D=25 and D=7
+    have no MFMA instantiation and exercise the generic kernel; ragged T exercises the tile tails."""
+    from oracle import c_oracle as co, np_oracle as npo
+    w, mu, sig = npo.synth_model(1000 + D + M, 2 * D, M)
+    X = npo.sample_frames(2000 + T, w, mu, sig, T, 0, D)
+    ref = co.GMMMap(w, mu, sig)
+    Yref = ref.fvconvert(X)
+    g = vc.GMMMap(*julia_model(w, mu, sig))
+    Y = vc.fvconvert(g, X.T)
+    assert frame_relerr(Y, Yref.T) < TOL
+    assert np.max(np.abs(vc.predict_proba(g.px, X.T) - ref.predict_proba(X).T)) < 1e-9
+    assert np.array_equal(vc.predict(g.px, X.T), ref.predict(X))
+    assert relerr(g.SyxSxxinv, np.transpose(ref.A, (1, 2, 0))) < 1e-9
+
+
+def test_zero_weight_component_has_zero_posterior(vc):
+    from oracle import c_oracle as co, np_oracle as npo
+    w, mu, sig = npo.synth_model(5, 32, 6)
+    w = w.copy(); w[2] = 0.0; w /= w.sum()
+    X = npo.sample_frames(6, w, mu, sig, 100, 0, 16)
+    g = vc.GMMMap(*julia_model(w, mu, sig))
+    P = vc.predict_proba(g.px, X.T)
+    assert np.all(P[2] == 0.0)
+    assert frame_relerr(vc.fvconvert(g, X.T), co.GMMMap(w, mu, sig).fvconvert(X).T) < TOL
+
+
+def test_errors(vc, fixture_model):
+    w, mu, sig = julia_model(*fixture_model)
+    g = vc.GMMMap(w, mu, sig)
+    with pytest.raises(vc.DimensionMismatch):
+        vc.fvconvert(g, np.zeros(39))                                 # src/gmmmap.jl:102
+    bad = sig.copy()
+    bad[:40, :40, 3] = -np.eye(40)
+    with pytest.raises(vc.PosDefException):
+        vc.GMMMap(w, mu, bad)                                         # PosDefException from MvNormal, src/gmm.jl:17
+
+
+def test_device_resident_and_deterministic(vc, fixture_model):
+    import torch
+    w, mu, sig = julia_model(*fixture_model)
+    z = load_golden("gmmmap_fixture_model.npz")
+    g = vc.GMMMap(w, mu, sig)
+    Xd = torch.from_numpy(np.ascontiguousarray(z["X_fwd"])).cuda()   # (T,D) contiguous = Julia (D,T) image
+    Y1 = vc.fvconvert(g, Xd.t())
+    Y2 = vc.fvconvert(g, Xd.t())
+    torch.cuda.synchronize()
+    assert torch.equal(Y1, Y2)
+    assert frame_relerr(Y1.cpu().numpy(), z["Y_fwd"].T) < TOL
+
+
+def test_linearity_at_full_size(vc):
+    """Size-independent property at BASELINE config 2 scale (D=40, M=64, T=10^6): with a single-mixture model
+    the map is affine, y = b + A x, so fvconvert(x1 + x2 - x3) = y1 + y2 - y3; and for the full model the
+    converted frames of a tiled input repeat exactly."""
+    import torch
+    from oracle import np_oracle as npo
+    w, mu, sig = npo.synth_model(1002, 80, 64)
+    g = vc.GMMMap(*julia_model(w, mu, sig))
+    base = npo.sample_frames(1002, w, mu, sig, 4096, 0, 40)
+    T = 1_000_000
+    reps = -(-T // 4096)
+    Xd = torch.from_numpy(base).cuda().repeat(reps, 1)[:T].contiguous()
+    Y = vc.fvconvert(g, Xd.t()).t()
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(Y).all())
+    first = Y[:4096]
+    for r in (1, reps // 2, reps - 2):
+        assert torch.equal(Y[r * 4096:(r + 1) * 4096], first)         # identical inputs -> identical outputs
+    from oracle import c_oracle as co
+    ref = co.GMMMap(w, mu, sig).fvconvert(base[:256])
+    assert frame_relerr(first[:256].cpu().numpy().T, ref.T) < TOL

@@ -1,0 +1,123 @@
+"""ctypes binding of libvcmi.so (the C-ABI declared in include/vcmi.h).
+
+The HIP library is the product: if it is missing this module raises at import time -- there is no
+CPU fallback anywhere in the package (the CPU oracle under oracle/ is test infrastructure only).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvcmi.so")
+
+
+class DimensionMismatch(ValueError):
+    """Julia's DimensionMismatch (src/gmmmap.jl:102, src/trajectory_gmmmap.jl:68, src/align.jl:11-13)."""
+
+
+class PosDefException(ArithmeticError):
+    """Julia's PosDefException, raised by MvNormal's Cholesky in src/gmm.jl:17."""
+
+
+class VCMIError(RuntimeError):
+    """Any other libvcmi failure (HIP error, out of memory, bad argument, no device)."""
+
+
+VCMI_OK, VCMI_ERR_DIM, VCMI_ERR_NOT_PD, VCMI_ERR_HIP, VCMI_ERR_OOM, VCMI_ERR_ARG, VCMI_ERR_NO_DEVICE = range(7)
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} not found: build the HIP library first (python -c 'import __graft_entry__ as g; g.build()' "
+        "or make -C voiceconversion.jl_amd/csrc). There is no CPU fallback."
+    )
+
+# PyTorch-ROCm bundles its own HIP/HSA runtime (torch/lib/libamdhip64.so, SONAME libamdhip64.so.7).  Two HIP
+# runtimes in one process cannot both own the GPU, so torch is imported FIRST: libvcmi's NEEDED
+# libamdhip64.so.7 then binds to the runtime torch already loaded, and device pointers / streams are shared.
+# (A Julia or C++ host that never loads torch binds to /opt/rocm/lib instead.)
+import torch  # noqa: E402,F401
+
+lib = C.CDLL(LIB_PATH)
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int64)
+_dpp = C.POINTER(_dp)
+_ipp = C.POINTER(_ip)
+_vp = C.c_void_p
+_i64 = C.c_int64
+_int = C.c_int
+
+# name -> (restype, argtypes); every symbol include/vcmi.h declares
+SIGNATURES = {
+    "vcmi_last_error": (C.c_char_p, []),
+    "vcmi_version": (C.c_char_p, []),
+    "vcmi_device_count": (_int, [C.POINTER(_int)]),
+    "vcmi_set_device": (_int, [_int]),
+    "vcmi_gmmmap_create": (_int, [_dp, _dp, _dp, _int, _int, _int, C.POINTER(_vp)]),
+    "vcmi_gmmmap_destroy": (_int, [_vp]),
+    "vcmi_gmmmap_dim": (_int, [_vp]),
+    "vcmi_gmmmap_ncomponents": (_int, [_vp]),
+    "vcmi_gmmmap_get_A": (_int, [_vp, _dp]),
+    "vcmi_gmmmap_convert": (_int, [_vp, _dp, _i64, _i64, _dp, _i64]),
+    "vcmi_gmmmap_convert_dev": (_int, [_vp, _vp, _i64, _i64, _vp, _i64, _vp]),
+    "vcmi_vc_frames": (_int, [_vp, _dp, _i64, _dp]),
+    "vcmi_gmmmap_posterior": (_int, [_vp, _dp, _i64, _i64, _dp]),
+    "vcmi_gmmmap_posterior_dev": (_int, [_vp, _vp, _i64, _i64, _vp, _vp]),
+    "vcmi_gmmmap_predict": (_int, [_vp, _dp, _i64, _i64, _ip]),
+    "vcmi_gmmmap_predict_dev": (_int, [_vp, _vp, _i64, _i64, _vp, _vp]),
+    "vcmi_gmmmap_set_kernel": (_int, [_vp, _int]),
+    "vcmi_dtw_fit": (_int, [_dp, _i64, _dp, _i64, _int, _int, _int, _ip, _dp, _ip]),
+    "vcmi_dtw_fit_batch": (_int, [_i64, _dpp, _ip, _dpp, _ip, _int, _int, _int, _ipp]),
+    "vcmi_dtw_fit_batch_dev": (_int, [_i64, _vp, _ip, _ip, _ip, _ip, _int, _int, _int, _vp, _ip, _vp]),
+    "vcmi_align": (_int, [_dp, _i64, _dp, _i64, _int, _dp, _ip]),
+    "vcmi_align_batch": (_int, [_i64, _dpp, _ip, _dpp, _ip, _int, _dpp]),
+    "vcmi_estep_diag": (_int, [_dp, _i64, _int, _int, _dp, _dp, _dp, _dp, _dp, _dp, _dp]),
+    "vcmi_estep_stats_len": (_i64, [_int, _int]),
+    "vcmi_estep_diag_dev": (_int, [_vp, _i64, _int, _int, _dp, _dp, _dp, _vp, _vp]),
+    "vcmi_traj_create": (_int, [_vp, _i64, C.POINTER(_vp)]),
+    "vcmi_traj_destroy": (_int, [_vp]),
+    "vcmi_traj_length": (_i64, [_vp]),
+    "vcmi_traj_convert": (_int, [_vp, _dp, _i64, _dp]),
+    "vcmi_traj_convert_batch": (_int, [_vp, _i64, _dpp, _ip, _dpp]),
+    "vcmi_traj_convert_batch_dev": (_int, [_vp, _i64, _vp, _ip, _ip, _vp, _ip, _vp]),
+    "vcmi_vc_traj": (_int, [_vp, _dp, _i64, _dp]),
+    "vcmi_push_delta": (_int, [_dp, _int, _i64, _dp]),
+}
+
+for _name, (_res, _args) in SIGNATURES.items():
+    _fn = getattr(lib, _name)      # AttributeError here = the library does not export a declared symbol
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+
+def last_error():
+    return lib.vcmi_last_error().decode("utf-8", "replace")
+
+
+def check(status):
+    """Map a vcmi_status to the exception type the reference would have thrown."""
+    if status == VCMI_OK:
+        return
+    msg = last_error()
+    if status == VCMI_ERR_DIM:
+        raise DimensionMismatch(msg)
+    if status == VCMI_ERR_NOT_PD:
+        raise PosDefException(msg)
+    raise VCMIError(f"libvcmi status {status}: {msg}")
+
+
+def dptr(a):
+    return a.ctypes.data_as(_dp)
+
+
+def iptr(a):
+    return a.ctypes.data_as(_ip)
+
+
+def device_count():
+    n = _int(0)
+    check(lib.vcmi_device_count(C.byref(n)))
+    return n.value
+
+
+def set_device(i):
+    check(lib.vcmi_set_device(int(i)))

@@ -1,0 +1,692 @@
+// gmmmap.hip -- GMM joint-density mapping on MI355X (gfx950): model preparation, the batched
+// fvconvert kernels (FP64 MFMA tile kernel + generic FP64 VALU kernel), posterior and argmax.
+//
+// Replaces, for whole (D,T) matrices at once:
+//   GMMMap ctor / GMMMapParam / split_joint_gmm          reference src/gmmmap.jl:23-90
+//   GaussianMixtureModel (Hermitian + Cholesky)          reference src/gmm.jl:8-20
+//   fvconvert(g::GMMMap, x)                              reference src/gmmmap.jl:101-118
+//   predict_proba / predict                              reference src/gmm.jl:24-58
+//   vc(c::FrameByFrameConverter, fm)                     reference src/common.jl:7-26
+//
+// Math.  Per mixture m, prepared once on the host:
+//   A_m = Syx_m inv(Sxx_m)              b_m  = muy_m - A_m mux_m
+//   L_m L_m' = Hermitian(Sxx_m)         U_m  = inv(L_m)   (lower triangular)     cz_m = U_m mux_m
+//   lc_m = log w_m - (D log 2pi + 2 sum_i log L_m[i,i]) / 2
+// Per frame x:   z_m = U_m x - cz_m,  l_m = lc_m - |z_m|^2 / 2,  p = softmax(l),  y = sum_m p_m (A_m x + b_m).
+// The softmax is evaluated online (running max + rescale), so no (M,T) posterior is ever stored by convert.
+//
+// MFMA kernel data layout: the 2*Dp rows [U_m ; A_m] (Dp = D rounded up to 4) are cut into 16-row tiles;
+// D[16 rows x 16 frames] += W[16 rows x 4 k] * X[4 k x 16 frames] is one v_mfma_f64_16x16x4_f64.  U-only
+// tiles skip the k-steps that are entirely above the diagonal.  Each mixture's operand fragments are stored
+// in HBM in issue order, 64 lanes x 8 B per step, so the global->LDS stage is a straight copy and every
+// ds_read_b64 is conflict-free.
+#include "vcmi_common.hpp"
+#include "host_linalg.hpp"
+#include "gmmmap_handle.hpp"
+
+#include <cmath>
+#include <limits>
+
+namespace vcmi {
+
+// ------------------------------------------------------------------------------------------------
+// compile-time description of the row tiling for a padded dimension DP (multiple of 4)
+// ------------------------------------------------------------------------------------------------
+template <int DP>
+struct Tiling {
+  static constexpr int KS = DP / 4;                       // k-steps covering all of x
+  static constexpr int NT = (2 * DP + 15) / 16;           // 16-row tiles over [U rows ; A rows]
+  static constexpr int NU = (DP + 15) / 16;               // tiles that contain at least one U row
+  __host__ __device__ static constexpr int steps(int t) {  // k-steps tile t needs
+    return (16 * t + 15 < DP) ? ((4 * (t + 1) < KS) ? 4 * (t + 1) : KS) : KS;
+  }
+  __host__ __device__ static constexpr int nsteps() {
+    int n = 0;
+    for (int t = 0; t < NT; ++t) n += steps(t);
+    return n;
+  }
+  static constexpr int NSTEPS = nsteps();
+  // per-mixture block in doubles: [fragments NSTEPS*64 | cinit NT*16 | lc | pad], multiple of 32 doubles
+  static constexpr int CINIT_OFF = NSTEPS * 64;
+  static constexpr int LC_OFF = CINIT_OFF + NT * 16;
+  static constexpr int BLK = ((LC_OFF + 1 + 31) / 32) * 32;
+};
+
+// runtime mirror used by the host-side packer (same formulas, any DP)
+struct TilingRT {
+  int DP, KS, NT, NU, NSTEPS, CINIT_OFF, LC_OFF, BLK;
+  explicit TilingRT(int dp) : DP(dp) {
+    KS = DP / 4;
+    NT = (2 * DP + 15) / 16;
+    NU = (DP + 15) / 16;
+    NSTEPS = 0;
+    for (int t = 0; t < NT; ++t) NSTEPS += steps(t);
+    CINIT_OFF = NSTEPS * 64;
+    LC_OFF = CINIT_OFF + NT * 16;
+    BLK = ((LC_OFF + 1 + 31) / 32) * 32;
+  }
+  int steps(int t) const { return (16 * t + 15 < DP) ? std::min(4 * (t + 1), KS) : KS; }
+};
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+// exp for the softmax weights; arguments are <= 0 (or -inf).
+__device__ __forceinline__ double vc_exp(double x) { return exp(x); }
+
+// ------------------------------------------------------------------------------------------------
+// MFMA tile kernel.  One wave owns FT tiles of 16 frames; a workgroup of WAVES waves shares the
+// per-mixture operand block, double-buffered in LDS.
+// MODE 0: convert (writes Y).  MODE 1: log-weighted densities l_m (writes LP (M,T)), no A tiles used.
+// ------------------------------------------------------------------------------------------------
+template <int DP, int FT, int WAVES, int MODE, int NBUF>
+__global__ void __launch_bounds__(WAVES * 64)
+gmmmap_mfma_kernel(const double *__restrict__ packed, int M, int D, const double *__restrict__ X, int64_t ldx,
+                   int64_t T, double *__restrict__ Y, int64_t ldy) {
+  using TL = Tiling<DP>;
+  constexpr int KS = TL::KS, NT = TL::NT, NU = TL::NU, BLK = TL::BLK;
+  constexpr int NTHREADS = WAVES * 64;
+  constexpr int NV = (BLK / 2 + NTHREADS - 1) / NTHREADS;   // double2 copies per thread per block
+  extern __shared__ double smem[];                          // NBUF * BLK doubles
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int lcol = lane & 15;   // frame within a 16-frame tile (MFMA column)
+  const int lgrp = lane >> 4;   // k within a k-step (operands) / row offset within a register group (results)
+  const int64_t frame0 = ((int64_t)blockIdx.x * WAVES + wave) * (16 * FT);
+
+  // B operands: xb[f][ks] = X[k = 4 ks + lgrp][frame = frame0 + 16 f + lcol], zero outside (D, T)
+  double xb[FT][KS];
+#pragma unroll
+  for (int f = 0; f < FT; ++f) {
+    const int64_t fr = frame0 + 16 * f + lcol;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int k = 4 * ks + lgrp;
+      xb[f][ks] = (fr < T && k < D) ? X[fr * ldx + k] : 0.0;
+    }
+  }
+
+  double yacc[FT][KS];
+  double runmax[FT], den[FT];
+#pragma unroll
+  for (int f = 0; f < FT; ++f) {
+    runmax[f] = -INFINITY;
+    den[f] = 0.0;
+#pragma unroll
+    for (int j = 0; j < KS; ++j) yacc[f][j] = 0.0;
+  }
+
+  // stage block 0
+  {
+    const double2 *src = reinterpret_cast<const double2 *>(packed);
+    double2 *dst = reinterpret_cast<double2 *>(smem);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int e = tid + i * NTHREADS;
+      if (e < BLK / 2) dst[e] = src[e];
+    }
+  }
+  __syncthreads();
+
+  for (int m = 0; m < M; ++m) {
+    const double *cur = smem + (NBUF == 2 ? (m & 1) * BLK : 0);
+    double2 *nxt = reinterpret_cast<double2 *>(smem + (NBUF == 2 ? ((m + 1) & 1) * BLK : 0));
+    // prefetch block m+1 into registers (global -> VGPR), written to LDS after the MFMA work
+    double2 pre[NV];
+    const bool more = (m + 1 < M);
+    if (more) {
+      const double2 *src = reinterpret_cast<const double2 *>(packed + (size_t)(m + 1) * BLK);
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int e = tid + i * NTHREADS;
+        if (e < BLK / 2) pre[i] = src[e];
+      }
+    }
+
+    const double lc = cur[TL::LC_OFF];
+    if (lc != -INFINITY) {   // zero-weight mixtures have posterior exactly 0 (wave-uniform branch)
+      // ---------------- phase U: whitening tiles, z = U x - cz ----------------
+      d4 acc[FT][NT];
+#pragma unroll
+      for (int t = 0; t < NU; ++t) {
+        d4 c;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) c[r] = cur[TL::CINIT_OFF + 16 * t + 4 * r + lgrp];
+#pragma unroll
+        for (int f = 0; f < FT; ++f) acc[f][t] = c;
+      }
+      int s = 0;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+        for (int t = 0; t < NU; ++t) {
+          if (ks < TL::steps(t)) {
+            const double a = cur[s * 64 + lane];
+            ++s;
+#pragma unroll
+            for (int f = 0; f < FT; ++f) acc[f][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, xb[f][ks], acc[f][t], 0, 0, 0);
+          }
+        }
+      }
+      double q[FT];
+#pragma unroll
+      for (int f = 0; f < FT; ++f) {
+        double qq = 0.0;
+#pragma unroll
+        for (int t = 0; t < NU; ++t) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            if (16 * t + 4 * r < DP) qq = fma(acc[f][t][r], acc[f][t][r], qq);
+          }
+        }
+        qq += __shfl_xor(qq, 16);
+        qq += __shfl_xor(qq, 32);
+        q[f] = qq;
+      }
+
+      if (MODE == 1) {
+        // log-weighted density of mixture m for the wave's frames; one lane group writes
+        if (lgrp == 0) {
+#pragma unroll
+          for (int f = 0; f < FT; ++f) {
+            const int64_t fr = frame0 + 16 * f + lcol;
+            if (fr < T) Y[fr * ldy + m] = lc - 0.5 * q[f];
+          }
+        }
+      } else {
+        // ---------------- phase A: regression tiles, E = A x + b ----------------
+        int sa = s;
+#pragma unroll
+        for (int t = NU; t < NT; ++t) {
+          d4 c;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) c[r] = cur[TL::CINIT_OFF + 16 * t + 4 * r + lgrp];
+#pragma unroll
+          for (int f = 0; f < FT; ++f) acc[f][t] = c;
+        }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+          for (int t = NU; t < NT; ++t) {
+            const double a = cur[sa * 64 + lane];
+            ++sa;
+#pragma unroll
+            for (int f = 0; f < FT; ++f) acc[f][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, xb[f][ks], acc[f][t], 0, 0, 0);
+          }
+        }
+        // online softmax update:  y <- y * e^(old-new) + e^(l-new) * E
+#pragma unroll
+        for (int f = 0; f < FT; ++f) {
+          const double l = lc - 0.5 * q[f];
+          const double nm = fmax(runmax[f], l);
+          const double sc = vc_exp(runmax[f] - nm);
+          const double wg = vc_exp(l - nm);
+          den[f] = fma(den[f], sc, wg);
+          runmax[f] = nm;
+#pragma unroll
+          for (int t = NU - 1; t < NT; ++t) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int p0 = 16 * t + 4 * r;
+              if (p0 >= DP && p0 < 2 * DP) {
+                const int j = (p0 - DP) / 4;
+                yacc[f][j] = fma(wg, acc[f][t][r], yacc[f][j] * sc);
+              }
+            }
+          }
+        }
+      }
+    }
+
+    else if (MODE == 1 && lgrp == 0) {
+#pragma unroll
+      for (int f = 0; f < FT; ++f) {
+        const int64_t fr = frame0 + 16 * f + lcol;
+        if (fr < T) Y[fr * ldy + m] = -INFINITY;
+      }
+    }
+
+    if (NBUF == 1) __syncthreads();   // single buffer: everyone is done reading before it is overwritten
+    if (more) {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int e = tid + i * NTHREADS;
+        if (e < BLK / 2) nxt[e] = pre[i];
+      }
+    }
+    __syncthreads();
+  }
+
+  if (MODE == 0) {
+#pragma unroll
+    for (int f = 0; f < FT; ++f) {
+      const int64_t fr = frame0 + 16 * f + lcol;
+      const double inv = 1.0 / den[f];
+      if (fr < T) {
+#pragma unroll
+        for (int j = 0; j < KS; ++j) {
+          const int row = 4 * j + lgrp;
+          if (row < D) Y[fr * ldy + row] = yacc[f][j] * inv;
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Generic VALU kernel (any D): one lane per frame, x and the y accumulator in LDS ([d][lane] layout,
+// conflict-free), parameters read through wave-uniform (scalar) loads.
+// MODE 0 convert, 1 log-weighted densities (M,T).
+// ------------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ void __launch_bounds__(64)
+gmmmap_generic_kernel(const double *__restrict__ U, const double *__restrict__ A, const double *__restrict__ cz,
+                      const double *__restrict__ b, const double *__restrict__ lcv, int M, int D, int DP,
+                      const double *__restrict__ X, int64_t ldx, int64_t T, double *__restrict__ Y, int64_t ldy) {
+  extern __shared__ double smem[];
+  double *xs = smem;              // [D][64]
+  double *ys = smem + (size_t)D * 64;   // [D][64] (MODE 0)
+  const int lane = threadIdx.x;
+  const int64_t fr = (int64_t)blockIdx.x * 64 + lane;
+  const bool live = fr < T;
+  for (int d = 0; d < D; ++d) {
+    xs[d * 64 + lane] = live ? X[fr * ldx + d] : 0.0;
+    if (MODE == 0) ys[d * 64 + lane] = 0.0;
+  }
+  double runmax = -INFINITY, den = 0.0;
+  for (int m = 0; m < M; ++m) {
+    const double lc = lcv[m];
+    if (lc == -INFINITY) {
+      if (MODE == 1 && live) Y[fr * ldy + m] = -INFINITY;
+      continue;
+    }
+    const double *Um = U + (size_t)m * DP * DP;
+    double q = 0.0;
+    for (int i = 0; i < D; ++i) {
+      double z = -cz[(size_t)m * DP + i];
+      for (int j = 0; j <= i; ++j) z = fma(Um[i * DP + j], xs[j * 64 + lane], z);
+      q = fma(z, z, q);
+    }
+    const double l = lc - 0.5 * q;
+    if (MODE == 1) {
+      if (live) Y[fr * ldy + m] = l;
+    } else {
+      const double nm = fmax(runmax, l);
+      const double sc = vc_exp(runmax - nm);
+      const double wg = vc_exp(l - nm);
+      den = fma(den, sc, wg);
+      runmax = nm;
+      const double *Am = A + (size_t)m * DP * DP;
+      for (int i = 0; i < D; ++i) {
+        double e = b[(size_t)m * DP + i];
+        for (int j = 0; j < D; ++j) e = fma(Am[i * DP + j], xs[j * 64 + lane], e);
+        ys[i * 64 + lane] = fma(wg, e, ys[i * 64 + lane] * sc);
+      }
+    }
+  }
+  if (MODE == 0 && live) {
+    const double inv = 1.0 / den;
+    for (int d = 0; d < D; ++d) Y[fr * ldy + d] = ys[d * 64 + lane] * inv;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// (M,T) log-weighted densities -> posterior in place (MODE 0) or 1-based argmax (MODE 1).
+// One lane per frame.  Follows src/gmm.jl:28-29 (max-shifted log-sum-exp, exp(l - lse)) and :46 (first max).
+// ------------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ void __launch_bounds__(256)
+posterior_finish_kernel(double *__restrict__ LP, int M, int64_t T, int64_t *__restrict__ idx) {
+  const int64_t fr = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (fr >= T) return;
+  double *l = LP + fr * M;
+  double u = l[0];
+  int best = 0;
+  for (int m = 1; m < M; ++m)
+    if (l[m] > u) { u = l[m]; best = m; }
+  if (MODE == 1) {
+    idx[fr] = best + 1;
+    return;
+  }
+  double s = 0.0;
+  for (int m = 0; m < M; ++m) s += vc_exp(l[m] - u);
+  const double lse = u + log(s);
+  for (int m = 0; m < M; ++m) l[m] = vc_exp(l[m] - lse);
+}
+
+// ------------------------------------------------------------------------------------------------
+// launch helpers
+// ------------------------------------------------------------------------------------------------
+template <int DP, int MODE>
+static int launch_mfma(const vcmi_gmmmap *g, const double *dX, int64_t ldx, int64_t T, double *dY, int64_t ldy,
+                       hipStream_t st) {
+  constexpr int FT = (DP <= 48) ? 2 : 1;
+  constexpr int WAVES = 4;
+  using TL = Tiling<DP>;
+  // double-buffer the per-mixture block when two copies fit in half of the CU's 160 KiB LDS
+  constexpr int NBUF = (2 * (size_t)TL::BLK * sizeof(double) <= 80 * 1024) ? 2 : 1;
+  const size_t shmem = NBUF * (size_t)TL::BLK * sizeof(double);
+  auto kern = gmmmap_mfma_kernel<DP, FT, WAVES, MODE, NBUF>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    VCMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)shmem));
+    attr_done = true;
+  }
+  const int64_t per_wg = (int64_t)16 * FT * WAVES;
+  const int64_t blocks = (T + per_wg - 1) / per_wg;
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(WAVES * 64), shmem, st, g->packed.p, g->M, g->D, dX, ldx, T, dY,
+                     ldy);
+  VCMI_HIP(hipGetLastError());
+  return VCMI_OK;
+}
+
+template <int MODE>
+static int dispatch_mfma(const vcmi_gmmmap *g, const double *dX, int64_t ldx, int64_t T, double *dY, int64_t ldy,
+                         hipStream_t st) {
+  switch (g->DP) {
+#define VCMI_CASE(DPV) \
+  case DPV: return launch_mfma<DPV, MODE>(g, dX, ldx, T, dY, ldy, st);
+    VCMI_CASE(16) VCMI_CASE(20) VCMI_CASE(24) VCMI_CASE(28) VCMI_CASE(32) VCMI_CASE(40) VCMI_CASE(48) VCMI_CASE(64)
+    VCMI_CASE(80)
+#undef VCMI_CASE
+    default: return fail(VCMI_ERR_ARG, "no MFMA instantiation for padded dimension %d", g->DP);
+  }
+}
+
+bool gmmmap_has_mfma(int DP) {
+  switch (DP) {
+    case 16: case 20: case 24: case 28: case 32: case 40: case 48: case 64: case 80: return true;
+    default: return false;
+  }
+}
+
+template <int MODE>
+static int launch_generic(const vcmi_gmmmap *g, const double *dX, int64_t ldx, int64_t T, double *dY, int64_t ldy,
+                          hipStream_t st) {
+  const size_t shmem = (size_t)g->D * 64 * sizeof(double) * (MODE == 0 ? 2 : 1);
+  if (shmem > 160 * 1024) return fail(VCMI_ERR_ARG, "dimension %d too large for the generic kernel", g->D);
+  auto kern = gmmmap_generic_kernel<MODE>;
+  if (shmem > 64 * 1024)
+    VCMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)shmem));
+  const int64_t blocks = (T + 63) / 64;
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64), shmem, st, g->U.p, g->A.p, g->cz.p, g->b.p, g->lc.p, g->M,
+                     g->D, g->DP, dX, ldx, T, dY, ldy);
+  VCMI_HIP(hipGetLastError());
+  return VCMI_OK;
+}
+
+static bool use_mfma(const vcmi_gmmmap *g) {
+  if (g->kernel_choice == 1) return false;
+  return gmmmap_has_mfma(g->DP);
+}
+
+// convert on device pointers
+int gmmmap_convert_device(vcmi_gmmmap *g, const double *dX, int64_t ldx, int64_t T, double *dY, int64_t ldy,
+                          hipStream_t st) {
+  if (T == 0) return VCMI_OK;
+  if (g->kernel_choice == 2 && !gmmmap_has_mfma(g->DP))
+    return fail(VCMI_ERR_ARG, "MFMA kernel forced but dimension %d has no instantiation", g->D);
+  if (use_mfma(g)) return dispatch_mfma<0>(g, dX, ldx, T, dY, ldy, st);
+  return launch_generic<0>(g, dX, ldx, T, dY, ldy, st);
+}
+
+// log-weighted densities (M,T) on device pointers
+int gmmmap_logdens_device(vcmi_gmmmap *g, const double *dX, int64_t ldx, int64_t T, double *dLP, hipStream_t st) {
+  if (T == 0) return VCMI_OK;
+  if (use_mfma(g)) return dispatch_mfma<1>(g, dX, ldx, T, dLP, g->M, st);
+  return launch_generic<1>(g, dX, ldx, T, dLP, g->M, st);
+}
+
+int gmmmap_posterior_device(vcmi_gmmmap *g, const double *dX, int64_t ldx, int64_t T, double *dP, hipStream_t st) {
+  if (T == 0) return VCMI_OK;
+  VCMI_TRY(gmmmap_logdens_device(g, dX, ldx, T, dP, st));
+  hipLaunchKernelGGL(posterior_finish_kernel<0>, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, st, dP, g->M, T,
+                     (int64_t *)nullptr);
+  VCMI_HIP(hipGetLastError());
+  return VCMI_OK;
+}
+
+int gmmmap_predict_device(vcmi_gmmmap *g, const double *dX, int64_t ldx, int64_t T, int64_t *didx, hipStream_t st) {
+  if (T == 0) return VCMI_OK;
+  VCMI_TRY(g->scratch_lp.reserve((size_t)T * g->M));
+  VCMI_TRY(gmmmap_logdens_device(g, dX, ldx, T, g->scratch_lp.p, st));
+  hipLaunchKernelGGL(posterior_finish_kernel<1>, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, st, g->scratch_lp.p,
+                     g->M, T, didx);
+  VCMI_HIP(hipGetLastError());
+  return VCMI_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// model preparation (host) and upload
+// ------------------------------------------------------------------------------------------------
+static int prepare(vcmi_gmmmap *g, const double *w, const double *mu, const double *sigma, int Dj, int M, int swap) {
+  const int D = Dj >> 1;   // src/gmmmap.jl:70
+  const int DP = (D + 3) / 4 * 4;
+  g->D = D;
+  g->M = M;
+  g->DP = DP;
+  const size_t dd = (size_t)D * D, pp = (size_t)DP * DP;
+  g->h_A_julia.assign(dd * M, 0.0);
+  g->h_Sxy.assign(dd * M, 0.0);
+  g->h_Syy.assign(dd * M, 0.0);
+  g->h_A.assign(dd * M, 0.0);
+  g->h_mux.assign((size_t)D * M, 0.0);
+  g->h_muy.assign((size_t)D * M, 0.0);
+  std::vector<double> hU(pp * M, 0.0), hA(pp * M, 0.0), hcz((size_t)DP * M, 0.0), hb((size_t)DP * M, 0.0), hlc(M);
+  std::vector<double> Sxx(dd), Syx(dd), inv(dd), L(dd), Ui(dd);
+  const int xo = swap ? D : 0, yo = swap ? 0 : D;   // src/gmmmap.jl:74-78
+  const double LOG2PI = 1.8378770664093454835606594728112;
+  for (int m = 0; m < M; ++m) {
+    const double *S = sigma + (size_t)Dj * Dj * m;   // column-major (Dj,Dj)
+    double *mux = &g->h_mux[(size_t)D * m], *muy = &g->h_muy[(size_t)D * m];
+    for (int d = 0; d < D; ++d) {
+      mux[d] = mu[xo + d + (size_t)Dj * m];
+      muy[d] = mu[yo + d + (size_t)Dj * m];
+    }
+    // row-major copies of the four blocks, src/gmmmap.jl:41-52
+    for (int r = 0; r < D; ++r)
+      for (int c = 0; c < D; ++c) {
+        Sxx[(size_t)r * D + c] = S[(xo + r) + (size_t)Dj * (xo + c)];
+        Syx[(size_t)r * D + c] = S[(yo + r) + (size_t)Dj * (xo + c)];
+        g->h_Sxy[dd * m + (size_t)r * D + c] = S[(xo + r) + (size_t)Dj * (yo + c)];
+        g->h_Syy[dd * m + (size_t)r * D + c] = S[(yo + r) + (size_t)Dj * (yo + c)];
+      }
+    // A_m = Syx inv(Sxx) on the raw block, src/gmmmap.jl:35
+    if (!la::inverse(Sxx.data(), D, inv.data()))
+      return fail(VCMI_ERR_NOT_PD, "Sigma^xx of mixture %d is singular", m + 1);
+    double *Am = &g->h_A[dd * m];
+    la::matmul(Syx.data(), inv.data(), D, Am);
+    for (int r = 0; r < D; ++r)
+      for (int c = 0; c < D; ++c) {
+        g->h_A_julia[dd * m + r + (size_t)D * c] = Am[(size_t)r * D + c];
+        hA[pp * m + (size_t)r * DP + c] = Am[(size_t)r * D + c];
+      }
+    // p(x): Hermitian(Sxx) (upper triangle mirrored, src/gmm.jl:16) -> Cholesky -> U = inv(L)
+    if (!la::cholesky_from_upper(Sxx.data(), D, L.data()))
+      return fail(VCMI_ERR_NOT_PD, "Sigma^xx of mixture %d is not positive definite", m + 1);
+    la::lower_inverse(L.data(), D, Ui.data());
+    double logdiag = 0.0;
+    for (int d = 0; d < D; ++d) logdiag += std::log(L[(size_t)d * D + d]);
+    hlc[m] = (w[m] > 0.0) ? std::log(w[m]) - 0.5 * (D * LOG2PI + 2.0 * logdiag)
+                          : -std::numeric_limits<double>::infinity();   // zero-weight: posterior 0
+    for (int r = 0; r < D; ++r) {
+      double cz = 0.0, ba = 0.0;
+      for (int c = 0; c < D; ++c) {
+        hU[pp * m + (size_t)r * DP + c] = Ui[(size_t)r * D + c];
+        cz += Ui[(size_t)r * D + c] * mux[c];
+        ba += Am[(size_t)r * D + c] * mux[c];
+      }
+      hcz[(size_t)DP * m + r] = cz;
+      hb[(size_t)DP * m + r] = muy[r] - ba;
+    }
+  }
+  VCMI_TRY(g->U.alloc(hU.size()));
+  VCMI_TRY(g->A.alloc(hA.size()));
+  VCMI_TRY(g->cz.alloc(hcz.size()));
+  VCMI_TRY(g->b.alloc(hb.size()));
+  VCMI_TRY(g->lc.alloc(hlc.size()));
+  VCMI_HIP(hipMemcpy(g->U.p, hU.data(), hU.size() * 8, hipMemcpyHostToDevice));
+  VCMI_HIP(hipMemcpy(g->A.p, hA.data(), hA.size() * 8, hipMemcpyHostToDevice));
+  VCMI_HIP(hipMemcpy(g->cz.p, hcz.data(), hcz.size() * 8, hipMemcpyHostToDevice));
+  VCMI_HIP(hipMemcpy(g->b.p, hb.data(), hb.size() * 8, hipMemcpyHostToDevice));
+  VCMI_HIP(hipMemcpy(g->lc.p, hlc.data(), hlc.size() * 8, hipMemcpyHostToDevice));
+
+  // packed operand blocks for the MFMA kernel (issue order: phase U k-major over U tiles, then phase A)
+  if (gmmmap_has_mfma(DP)) {
+    TilingRT tl(DP);
+    std::vector<double> pk((size_t)tl.BLK * M, 0.0);
+    auto wrow = [&](int m, int p, int k) -> double {   // row p of [U_m ; A_m], column k
+      if (k >= DP) return 0.0;
+      if (p < DP) return hU[pp * m + (size_t)p * DP + k];
+      if (p < 2 * DP) return hA[pp * m + (size_t)(p - DP) * DP + k];
+      return 0.0;
+    };
+    for (int m = 0; m < M; ++m) {
+      double *blk = &pk[(size_t)tl.BLK * m];
+      int s = 0;
+      for (int phase = 0; phase < 2; ++phase) {
+        const int t0 = phase == 0 ? 0 : tl.NU, t1 = phase == 0 ? tl.NU : tl.NT;
+        for (int ks = 0; ks < tl.KS; ++ks)
+          for (int t = t0; t < t1; ++t) {
+            if (ks >= tl.steps(t)) continue;
+            for (int l = 0; l < 64; ++l) blk[(size_t)s * 64 + l] = wrow(m, 16 * t + (l & 15), 4 * ks + (l >> 4));
+            ++s;
+          }
+      }
+      for (int p = 0; p < tl.NT * 16; ++p) {
+        double c = 0.0;
+        if (p < DP) c = -hcz[(size_t)DP * m + p];
+        else if (p < 2 * DP) c = hb[(size_t)DP * m + (p - DP)];
+        blk[tl.CINIT_OFF + p] = c;
+      }
+      blk[tl.LC_OFF] = hlc[m];
+    }
+    VCMI_TRY(g->packed.alloc(pk.size()));
+    VCMI_HIP(hipMemcpy(g->packed.p, pk.data(), pk.size() * 8, hipMemcpyHostToDevice));
+  }
+  return VCMI_OK;
+}
+
+}  // namespace vcmi
+
+// ------------------------------------------------------------------------------------------------
+// C-ABI
+// ------------------------------------------------------------------------------------------------
+using namespace vcmi;
+
+extern "C" int vcmi_gmmmap_create(const double *weights, const double *mu, const double *sigma, int Dj, int M, int swap,
+                                  vcmi_gmmmap **out) {
+  if (!weights || !mu || !sigma || !out) return fail(VCMI_ERR_ARG, "vcmi_gmmmap_create: NULL argument");
+  if (Dj < 2 || (Dj & 1) || M < 1) return fail(VCMI_ERR_DIM, "vcmi_gmmmap_create: joint dimension %d / mixtures %d invalid", Dj, M);
+  *out = nullptr;
+  VCMI_TRY(check_device());
+  vcmi_gmmmap *g = new (std::nothrow) vcmi_gmmmap();
+  if (!g) return fail(VCMI_ERR_OOM, "out of host memory");
+  (void)hipGetDevice(&g->device);
+  int rc = prepare(g, weights, mu, sigma, Dj, M, swap);
+  if (rc != VCMI_OK) {
+    delete g;
+    return rc;
+  }
+  *out = g;
+  return VCMI_OK;
+}
+
+extern "C" int vcmi_gmmmap_destroy(vcmi_gmmmap *g) {
+  delete g;
+  return VCMI_OK;
+}
+extern "C" int vcmi_gmmmap_dim(const vcmi_gmmmap *g) { return g ? g->D : -1; }
+extern "C" int vcmi_gmmmap_ncomponents(const vcmi_gmmmap *g) { return g ? g->M : -1; }
+extern "C" int vcmi_gmmmap_get_A(const vcmi_gmmmap *g, double *A) {
+  if (!g || !A) return fail(VCMI_ERR_ARG, "vcmi_gmmmap_get_A: NULL argument");
+  memcpy(A, g->h_A_julia.data(), g->h_A_julia.size() * sizeof(double));
+  return VCMI_OK;
+}
+extern "C" int vcmi_gmmmap_set_kernel(vcmi_gmmmap *g, int which) {
+  if (!g || which < 0 || which > 2) return fail(VCMI_ERR_ARG, "vcmi_gmmmap_set_kernel: bad argument");
+  if (which == 2 && !gmmmap_has_mfma(g->DP)) return fail(VCMI_ERR_ARG, "no MFMA instantiation for dimension %d", g->D);
+  g->kernel_choice = which;
+  return VCMI_OK;
+}
+
+static int check_xy(const vcmi_gmmmap *g, const void *X, int64_t ldx, int64_t T, const void *Y, int64_t ldy, const char *who) {
+  if (!g) return fail(VCMI_ERR_ARG, "%s: NULL handle", who);
+  if (T < 0) return fail(VCMI_ERR_ARG, "%s: negative frame count", who);
+  if (T > 0 && (!X || !Y)) return fail(VCMI_ERR_ARG, "%s: NULL buffer", who);
+  if (ldx < g->D || ldy < 1) return fail(VCMI_ERR_DIM, "%s: Inconsistent dimensions (leading dimension %lld < dim %d)", who, (long long)ldx, g->D);
+  return VCMI_OK;
+}
+
+extern "C" int vcmi_gmmmap_convert_dev(vcmi_gmmmap *g, const double *dX, int64_t ldx, int64_t T, double *dY, int64_t ldy,
+                                       void *stream) {
+  VCMI_TRY(check_xy(g, dX, ldx, T, dY, ldy, "vcmi_gmmmap_convert_dev"));
+  if (ldy < g->D) return fail(VCMI_ERR_DIM, "vcmi_gmmmap_convert_dev: ldy %lld < dim %d", (long long)ldy, g->D);
+  return gmmmap_convert_device(g, dX, ldx, T, dY, ldy, as_stream(stream));
+}
+
+extern "C" int vcmi_gmmmap_convert(vcmi_gmmmap *g, const double *X, int64_t ldx, int64_t T, double *Y, int64_t ldy) {
+  VCMI_TRY(check_xy(g, X, ldx, T, Y, ldy, "vcmi_gmmmap_convert"));
+  if (ldy < g->D) return fail(VCMI_ERR_DIM, "vcmi_gmmmap_convert: ldy %lld < dim %d", (long long)ldy, g->D);
+  if (T == 0) return VCMI_OK;
+  const size_t nx = (size_t)(T - 1) * ldx + g->D, ny = (size_t)T * g->D;
+  VCMI_TRY(g->scratch_x.reserve(nx));
+  VCMI_TRY(g->scratch_y.reserve(ny));
+  VCMI_HIP(hipMemcpy(g->scratch_x.p, X, nx * 8, hipMemcpyHostToDevice));
+  VCMI_TRY(gmmmap_convert_device(g, g->scratch_x.p, ldx, T, g->scratch_y.p, g->D, nullptr));
+  VCMI_HIP(hipMemcpy2D(Y, (size_t)ldy * 8, g->scratch_y.p, (size_t)g->D * 8, (size_t)g->D * 8, (size_t)T,
+                       hipMemcpyDeviceToHost));
+  return VCMI_OK;
+}
+
+extern "C" int vcmi_vc_frames(vcmi_gmmmap *g, const double *fm, int64_t T, double *out) {
+  if (!g) return fail(VCMI_ERR_ARG, "vcmi_vc_frames: NULL handle");
+  if (T < 0 || (T > 0 && (!fm || !out))) return fail(VCMI_ERR_ARG, "vcmi_vc_frames: bad argument");
+  if (T == 0) return VCMI_OK;
+  const int64_t ld = g->D + 1;   // row 1 is the power coefficient, src/common.jl:11
+  const size_t n = (size_t)T * ld;
+  VCMI_TRY(g->scratch_x.reserve(n));
+  VCMI_TRY(g->scratch_y.reserve(n));
+  VCMI_HIP(hipMemcpy(g->scratch_x.p, fm, n * 8, hipMemcpyHostToDevice));
+  VCMI_HIP(hipMemcpyAsync(g->scratch_y.p, g->scratch_x.p, n * 8, hipMemcpyDeviceToDevice, nullptr));   // keeps row 1, src/common.jl:23
+  VCMI_TRY(gmmmap_convert_device(g, g->scratch_x.p + 1, ld, T, g->scratch_y.p + 1, ld, nullptr));
+  VCMI_HIP(hipMemcpy(out, g->scratch_y.p, n * 8, hipMemcpyDeviceToHost));
+  return VCMI_OK;
+}
+
+extern "C" int vcmi_gmmmap_posterior_dev(vcmi_gmmmap *g, const double *dX, int64_t ldx, int64_t T, double *dP, void *stream) {
+  VCMI_TRY(check_xy(g, dX, ldx, T, dP, 1, "vcmi_gmmmap_posterior_dev"));
+  return gmmmap_posterior_device(g, dX, ldx, T, dP, as_stream(stream));
+}
+
+extern "C" int vcmi_gmmmap_posterior(vcmi_gmmmap *g, const double *X, int64_t ldx, int64_t T, double *P) {
+  VCMI_TRY(check_xy(g, X, ldx, T, P, 1, "vcmi_gmmmap_posterior"));
+  if (T == 0) return VCMI_OK;
+  const size_t nx = (size_t)(T - 1) * ldx + g->D, np = (size_t)T * g->M;
+  VCMI_TRY(g->scratch_x.reserve(nx));
+  VCMI_TRY(g->scratch_y.reserve(np));
+  VCMI_HIP(hipMemcpy(g->scratch_x.p, X, nx * 8, hipMemcpyHostToDevice));
+  VCMI_TRY(gmmmap_posterior_device(g, g->scratch_x.p, ldx, T, g->scratch_y.p, nullptr));
+  VCMI_HIP(hipMemcpy(P, g->scratch_y.p, np * 8, hipMemcpyDeviceToHost));
+  return VCMI_OK;
+}
+
+extern "C" int vcmi_gmmmap_predict_dev(vcmi_gmmmap *g, const double *dX, int64_t ldx, int64_t T, int64_t *didx, void *stream) {
+  VCMI_TRY(check_xy(g, dX, ldx, T, didx, 1, "vcmi_gmmmap_predict_dev"));
+  return gmmmap_predict_device(g, dX, ldx, T, didx, as_stream(stream));
+}
+
+extern "C" int vcmi_gmmmap_predict(vcmi_gmmmap *g, const double *X, int64_t ldx, int64_t T, int64_t *idx) {
+  VCMI_TRY(check_xy(g, X, ldx, T, idx, 1, "vcmi_gmmmap_predict"));
+  if (T == 0) return VCMI_OK;
+  const size_t nx = (size_t)(T - 1) * ldx + g->D;
+  VCMI_TRY(g->scratch_x.reserve(nx));
+  VCMI_TRY(g->scratch_idx.reserve((size_t)T));
+  VCMI_HIP(hipMemcpy(g->scratch_x.p, X, nx * 8, hipMemcpyHostToDevice));
+  VCMI_TRY(gmmmap_predict_device(g, g->scratch_x.p, ldx, T, g->scratch_idx.p, nullptr));
+  VCMI_HIP(hipMemcpy(idx, g->scratch_idx.p, (size_t)T * 8, hipMemcpyDeviceToHost));
+  return VCMI_OK;
+}

@@ -1,0 +1,32 @@
+// gmmmap_handle.hpp -- the opaque vcmi_gmmmap handle (shared by gmmmap.hip and traj.hip).
+#pragma once
+#include "vcmi_common.hpp"
+
+struct vcmi_gmmmap {
+  int D = 0;    // dim(g): source feature dimension, src/gmmmap.jl:94
+  int DP = 0;   // D rounded up to a multiple of 4 (MFMA k-step)
+  int M = 0;    // ncomponents(g)
+  int device = 0;
+  int kernel_choice = 0;   // 0 auto, 1 generic VALU, 2 MFMA
+
+  // host copies kept for accessors and for TrajectoryGMMMap's constructor (row-major (D,D) per mixture)
+  std::vector<double> h_A_julia;   // Julia memory image (D,D,M) of ΣʸˣΣˣˣ⁻¹
+  std::vector<double> h_A, h_Sxy, h_Syy, h_mux, h_muy;
+
+  // device parameters, generic layout: [M][DP][DP] row-major / [M][DP] / [M]
+  vcmi::DevBuf<double> U, A, cz, b, lc;
+  // device parameters, MFMA fragment order: [M][Tiling::BLK]
+  vcmi::DevBuf<double> packed;
+
+  // grow-only device scratch for the host-pointer entry points
+  vcmi::DevBuf<double> scratch_x, scratch_y, scratch_lp;
+  vcmi::DevBuf<int64_t> scratch_idx;
+};
+
+namespace vcmi {
+bool gmmmap_has_mfma(int DP);
+int gmmmap_convert_device(vcmi_gmmmap *g, const double *dX, int64_t ldx, int64_t T, double *dY, int64_t ldy, hipStream_t st);
+int gmmmap_logdens_device(vcmi_gmmmap *g, const double *dX, int64_t ldx, int64_t T, double *dLP, hipStream_t st);
+int gmmmap_posterior_device(vcmi_gmmmap *g, const double *dX, int64_t ldx, int64_t T, double *dP, hipStream_t st);
+int gmmmap_predict_device(vcmi_gmmmap *g, const double *dX, int64_t ldx, int64_t T, int64_t *didx, hipStream_t st);
+}  // namespace vcmi

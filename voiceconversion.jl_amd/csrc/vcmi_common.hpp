@@ -1,0 +1,65 @@
+// vcmi_common.hpp -- status/error plumbing shared by the libvcmi translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+#include "../../include/vcmi.h"
+
+namespace vcmi {
+
+// thread-local message behind vcmi_last_error()
+char *error_buffer();
+int fail(int code, const char *fmt, ...);
+
+#define VCMI_HIP(expr)                                                                                   \
+  do {                                                                                                   \
+    hipError_t e_ = (expr);                                                                              \
+    if (e_ != hipSuccess)                                                                                \
+      return vcmi::fail(e_ == hipErrorOutOfMemory ? VCMI_ERR_OOM : VCMI_ERR_HIP, "%s failed: %s (%s:%d)", \
+                        #expr, hipGetErrorString(e_), __FILE__, __LINE__);                               \
+  } while (0)
+
+#define VCMI_TRY(expr)            \
+  do {                            \
+    int s_ = (expr);              \
+    if (s_ != VCMI_OK) return s_; \
+  } while (0)
+
+// Device buffer with RAII; allocation failures surface as status codes through alloc().
+template <typename T>
+struct DevBuf {
+  T *p = nullptr;
+  size_t n = 0;
+  DevBuf() = default;
+  DevBuf(const DevBuf &) = delete;
+  DevBuf &operator=(const DevBuf &) = delete;
+  ~DevBuf() { release(); }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    n = 0;
+  }
+  int alloc(size_t count) {
+    release();
+    if (count == 0) return VCMI_OK;
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&p), count * sizeof(T));
+    if (e != hipSuccess) {
+      p = nullptr;
+      return fail(VCMI_ERR_OOM, "hipMalloc of %zu bytes failed: %s", count * sizeof(T), hipGetErrorString(e));
+    }
+    n = count;
+    return VCMI_OK;
+  }
+  // grow-only scratch
+  int reserve(size_t count) { return count <= n ? VCMI_OK : alloc(count); }
+};
+
+int check_device();  // VCMI_ERR_NO_DEVICE when no HIP device is visible
+
+inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
+
+}  // namespace vcmi
