@@ -31,6 +31,11 @@ FP64_PEAK_TFLOPS = 78.6
 HBM_PEAK_GBS = 8000.0
 
 
+def julia_model(w, mu, sig):
+    """numpy [m][d] / [m][col][row] buffers -> Julia-shaped (Dj,M) / (Dj,Dj,M) Fortran arrays (same bytes)."""
+    return w, np.asfortranarray(mu.T), np.asfortranarray(np.transpose(sig, (2, 1, 0)))
+
+
 def convert_flops_per_frame(D, M):
     """Algorithmic FP64 flop per converted frame: M(3D^2 + 6D) + 25M."""
     return M * (3 * D * D + 6 * D) + 25 * M
@@ -100,7 +105,6 @@ def bench_convert(args, world, rank):
 
     import voiceconversion_jl_amd as vc
     from oracle import np_oracle as npo
-    from tests.conftest import julia_model
 
     D, M, T = 40, 64, args.frames
     w, mu, sig = npo.synth_model(1002, 2 * D, M)

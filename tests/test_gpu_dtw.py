@@ -1,0 +1,111 @@
+"""GPU parity: DTW fit!/backward and align through the C-ABI -- BIT-EXACT against the reference's KATs
+(test/dtw.jl:7-31), the committed golden tables and the C oracle."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def vc():
+    import voiceconversion_jl_amd as m
+    assert m.device_count() >= 1
+    return m
+
+
+def test_reference_kat_3dim(vc):
+    """test/dtw.jl:7-19"""
+    v1 = np.array([[1., 2, 3], [1, 2, 4], [1, 8, 5], [10, 3, 6]]).T
+    v2 = np.array([[1., 2, 3], [1, 2, 4], [1, 2, 5], [1, 8, 5], [10, 3, 6]]).T
+    d = vc.DTW(bstep=1, fstep=0)
+    indices = vc.fit_(d, v1, v2)
+    assert indices.tolist() == [1, 2, 2, 3, 4]
+    assert d.costtable.shape == (4, 6) and d.backpointer.shape == (4, 6)
+    assert vc.backward(d).tolist() == [1, 2, 2, 3, 4]
+
+
+def test_reference_kat_1dim(vc):
+    """test/dtw.jl:21-31"""
+    v1 = np.array([[0., 1, 2, 3, 4, 5]])
+    v2 = np.array([[0., 0, 1, 2, 3, 4, 4, 5]])
+    d = vc.DTW(bstep=1, fstep=0)
+    assert vc.fit_(d, v1, v2).tolist() == [1, 1, 2, 3, 4, 5, 5, 6]
+
+
+def test_golden_tables_bit_exact(vc):
+    z = load_golden("dtw_cases.npz")
+    names = [f"kat{k}" for k in range(2)] + [f"r{k}" for k in range(int(z["n_random"]))]
+    for nm in names:
+        fs, bs = (int(x) for x in z[f"{nm}_steps"])
+        d = vc.DTW(fstep=fs, bstep=bs)
+        path = vc.fit_(d, z[f"{nm}_tmpl"].T, z[f"{nm}_seq"].T)
+        assert np.array_equal(path, z[f"{nm}_path"]), nm
+        assert np.array_equal(d.costtable, z[f"{nm}_cost"].T), nm          # bit-exact Float64
+        assert np.array_equal(d.backpointer, z[f"{nm}_bp"].T), nm
+        assert np.array_equal(vc.fit_(d, z[f"{nm}_tmpl"].T, z[f"{nm}_seq"].T, tables=False), z[f"{nm}_path"]), nm
+        if nm.startswith("r"):
+            src, newtgt, apath = vc.align(z[f"{nm}_tmpl"].T, z[f"{nm}_seq"].T, return_path=True)
+            assert np.array_equal(newtgt, z[f"{nm}_align_newtgt"].T), nm
+            assert np.array_equal(apath, z[f"{nm}_align_path"]), nm
+
+
+def _warped_pair(rng, S, T, D):
+    t = rng.standard_normal((S, D))
+    idx = np.clip(np.sort(rng.integers(0, S, T)), 0, S - 1)
+    return t, t[idx] + 0.2 * rng.standard_normal((T, D))
+
+
+@pytest.mark.parametrize("S,T,D,fs,bs", [(500, 500, 40, 0, 2), (450, 550, 40, 0, 1), (1024, 300, 13, 0, 2), (130, 700, 40, 2, 3),
+                                         (1, 7, 3, 0, 1), (9, 1, 2, 0, 2), (1500, 200, 5, 0, 2), (300, 100, 150, 0, 2)])
+def test_vs_oracle_bit_exact(vc, S, T, D, fs, bs):
+    """Config-4-sized pairs and the edge shapes: S=1, T=1, S>1024 and D>128 (generic kernel), wide step
+    windows (byte codes), LDS-resident and HBM-resident step codes."""
+    from oracle import c_oracle as co
+    rng = np.random.default_rng(S * 7 + T)
+    t, s = _warped_pair(rng, S, T, D)
+    p_ref, c_ref, b_ref = co.dtw_fit(t, s, fs, bs)
+    d = vc.DTW(fstep=fs, bstep=bs)
+    path = vc.fit_(d, t.T, s.T)
+    assert np.array_equal(path, p_ref)
+    assert np.array_equal(d.costtable, c_ref.T)
+    assert np.array_equal(d.backpointer, b_ref.T)
+    assert np.array_equal(vc.fit_(d, t.T, s.T, tables=False), p_ref)
+
+
+def test_batch_ragged_and_align(vc):
+    from oracle import c_oracle as co
+    rng = np.random.default_rng(99)
+    pairs = [_warped_pair(rng, int(rng.integers(40, 300)), int(rng.integers(40, 300)), 40) for _ in range(37)]
+    d = vc.DTW(fstep=0, bstep=2)
+    paths = vc.fit_batch(d, [t.T for t, _ in pairs], [s.T for _, s in pairs])
+    outs = vc.align_batch([t.T for t, _ in pairs], [s.T for _, s in pairs])
+    for (t, s), p, (src, newtgt) in zip(pairs, paths, outs):
+        assert np.array_equal(p, co.dtw_fit(t, s, 0, 2, tables=False))
+        nt_ref, _ = co.align(t, s)
+        assert np.array_equal(newtgt, nt_ref.T)
+        assert src.shape == newtgt.shape
+
+
+def test_empty_sequence_and_errors(vc):
+    d = vc.DTW()
+    p = vc.fit_(d, np.ones((3, 4)), np.zeros((3, 0)))
+    assert p.shape == (0,) and d.costtable.shape == (4, 1) and d.costtable[:, 0].tolist() == [1, 2, 3, 4]
+    assert vc.fit_batch(d, [], []) == []
+    with pytest.raises(vc.DimensionMismatch):
+        vc.align(np.zeros((3, 5)), np.zeros((4, 5)))           # src/align.jl:11-13
+
+
+def test_online_update_matches_fit(vc):
+    """update! (src/dtw.jl:61-90) column by column reproduces fit!'s tables."""
+    rng = np.random.default_rng(5)
+    t, s = _warped_pair(rng, 12, 9, 4)
+    d1 = vc.DTW(bstep=2)
+    vc.fit_(d1, t.T, s.T)
+    d2 = vc.DTW(bstep=2)
+    vc.set_template_(d2, t.T)
+    for k in range(s.shape[0]):
+        vc.update_(d2, s[k])
+    assert np.array_equal(d1.costtable, d2.costtable) and np.array_equal(d1.backpointer, d2.backpointer)
+    assert np.array_equal(vc.backward(d2), vc.backward(d1))

@@ -8,3 +8,5 @@ from .common import (AbstractConverter, FrameByFrameConverter, TrajectoryConvert
                      ncomponents, size, vc)
 from .gmm import GMM, predict, predict_proba  # noqa: F401
 from .gmmmap import GMMMap  # noqa: F401
+from .dtw import DTW, backward, fit_, fit_batch, set_template_, update_  # noqa: F401,E402
+from .align import align, align_batch  # noqa: F401,E402
