@@ -1,6 +1,398 @@
-// estep.hip -- placeholder translation unit (filled in below in this round)
+// estep.hip -- E-step of EM for a diagonal-covariance GMM on joint features, MI355X (gfx950).
+//
+// Call site in the reference: bin/train_gmm.jl:103 `gmm[:fit](dataset.X')` (scikit-learn through PyCall); the
+// joint feature matrix is built by src/datasets.jl:52-77.  The arithmetic itself is third-party (sklearn.mixture);
+// what is implemented here is its published definition:
+//   l_nm = log w_m - (Dj log 2pi + sum_d log var_md + sum_d (x_nd - mu_md)^2 / var_md) / 2
+//   lse_n = logsumexp_m l_nm,   gamma_nm = exp(l_nm - lse_n)
+//   S0_m = sum_n gamma_nm,  S1_md = sum_n gamma_nm x_nd,  S2_md = sum_n gamma_nm x_nd^2,  loglik = sum_n lse_n
+// Output buffer layout (device): [S0 (M) | S1 (Dj,M) | S2 (Dj,M) | loglik] -- contiguous so that the multi-GPU
+// path is ONE all-reduce(sum) of M(1+2Dj)+1 doubles over RCCL.
+//
+// Two implementations:
+//  * MFMA kernel (Dj = 80, M <= 128 here; v_mfma_f64_16x16x4_f64): both the log-density
+//    l = [x^2, x] . [-iv/2 ; mu iv] + c  and the statistics  gamma' [x, x^2]  are dense FP64 contractions.
+//    A workgroup of 8 waves owns a strided set of 64-frame blocks; wave w owns mixtures 16w..16w+15: their
+//    weight fragments (80 VGPRs) and their 16 x 160 statistics accumulators (80 VGPRs) stay in registers for
+//    the whole kernel.  Per-workgroup partial statistics are reduced in a fixed order by a second kernel,
+//    so results are bit-identical run to run (no FP64 atomics).
+//  * generic kernels (any Dj, M): gamma to an HBM workspace in chunks, then per-(m,d) sequential accumulation
+//    over fixed frame segments, then a fixed-order reduction.
 #include "vcmi_common.hpp"
+
+#include <cmath>
+
+namespace vcmi {
+
+static constexpr double kLog2Pi = 1.8378770664093454835606594728112;
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------------------------------------------
+// generic path
+// ------------------------------------------------------------------------------------------------
+static constexpr int kChunk = 1 << 16;   // frames per workspace chunk
+static constexpr int kSeg = 512;         // frames per deterministic accumulation segment
+
+// one lane per frame: responsibilities gamma (chunk-local (n,M) row-major) and lse
+__global__ void __launch_bounds__(64)
+estep_gamma_kernel(const double *__restrict__ X, int64_t n0, int64_t nfr, int Dj, int M, const double *__restrict__ mu,
+                   const double *__restrict__ iv, const double *__restrict__ cst, double *__restrict__ G,
+                   double *__restrict__ LSE) {
+  extern __shared__ double xs[];   // [Dj][64]
+  const int lane = threadIdx.x;
+  const int64_t nl = (int64_t)blockIdx.x * 64 + lane;
+  const bool live = nl < nfr;
+  for (int d = 0; d < Dj; ++d) xs[d * 64 + lane] = live ? X[(n0 + nl) * Dj + d] : 0.0;
+  double *g = G + nl * M;
+  double u = -INFINITY;
+  for (int m = 0; m < M; ++m) {
+    double q = 0.0;
+    for (int d = 0; d < Dj; ++d) {
+      const double df = xs[d * 64 + lane] - mu[(size_t)m * Dj + d];
+      q = fma(df * df, iv[(size_t)m * Dj + d], q);
+    }
+    const double l = cst[m] - 0.5 * q;
+    if (live) g[m] = l;
+    u = fmax(u, l);
+  }
+  if (!live) return;
+  double s = 0.0;
+  for (int m = 0; m < M; ++m) s += exp(g[m] - u);
+  const double lse = u + log(s);
+  for (int m = 0; m < M; ++m) g[m] = exp(g[m] - lse);
+  LSE[nl] = lse;
+}
+
+// thread per statistic element e = m*Dj + d, sequential over the frames of one segment
+__global__ void __launch_bounds__(256)
+estep_stats_kernel(const double *__restrict__ X, int64_t n0, int64_t nfr, int Dj, int M, const double *__restrict__ G,
+                   const double *__restrict__ LSE, double *__restrict__ part, int64_t plen) {
+  const int seg = blockIdx.x;
+  const int e = blockIdx.y * 256 + threadIdx.x;
+  const int64_t f0 = (int64_t)seg * kSeg, f1 = (f0 + kSeg < nfr) ? f0 + kSeg : nfr;
+  double *P = part + (size_t)seg * plen;
+  if (e < M * Dj) {
+    const int m = e / Dj, d = e % Dj;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+    for (int64_t f = f0; f < f1; ++f) {
+      const double g = G[f * M + m], x = X[(n0 + f) * Dj + d];
+      s0 += g;
+      s1 = fma(g, x, s1);
+      s2 = fma(g * x, x, s2);
+    }
+    if (d == 0) P[m] = s0;
+    P[M + e] = s1;
+    P[M + (size_t)M * Dj + e] = s2;
+  }
+  if (e == 0) {
+    double ll = 0.0;
+    for (int64_t f = f0; f < f1; ++f) ll += LSE[f];
+    P[plen - 1] = ll;
+  }
+}
+
+// stats[e] += sum over partial rows, in row order (deterministic)
+__global__ void __launch_bounds__(256)
+estep_reduce_kernel(const double *__restrict__ part, int nrows, int64_t plen, double *__restrict__ stats) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= plen) return;
+  double s = stats[e];
+  for (int r = 0; r < nrows; ++r) s += part[(size_t)r * plen + e];
+  stats[e] = s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// MFMA path, Dj = 80 (K = 160 = [x^2 | x], 40 k-steps; 10 statistic column tiles [x | x^2])
+// ------------------------------------------------------------------------------------------------
+template <int DJ>
+struct EstepCfg {
+  static constexpr int KS = 2 * DJ / 4;          // k-steps of the log-density contraction
+  static constexpr int NDT = 2 * DJ / 16;        // 16-wide column tiles of the statistics [x | x^2]
+  static constexpr int FB = 64;                  // frames per block
+  static constexpr int RSX = DJ + 1;             // LDS row stride of x (doubles), odd -> conflict-free column reads
+  static constexpr int MMAX = 128;               // 8 waves x 16 mixtures
+  static constexpr int RSG = MMAX + 16;          // LDS row stride of gamma; == 16 mod 32 -> f-groups land 32 banks apart
+  static constexpr size_t LDS_BYTES = ((size_t)FB * RSX + (size_t)FB * RSG + 8 * 64) * sizeof(double);
+};
+
+// Wpack: [mt (8)][ks (KS)][lane (64)] A-operand fragments of W = [-iv/2 | mu*iv] (rows = mixtures), zero rows for m >= M
+// cinit: [128] log-density constants c_m (-inf rows for m >= M so that their gamma is exactly 0)
+template <int DJ>
+__global__ void __launch_bounds__(512)
+estep_mfma_kernel(const double *__restrict__ X, int64_t N, int M, const double *__restrict__ Wpack,
+                  const double *__restrict__ cinit, double *__restrict__ part, int64_t plen) {
+  using C = EstepCfg<DJ>;
+  constexpr int KS = C::KS, NDT = C::NDT, FB = C::FB, RSX = C::RSX, RSG = C::RSG;
+  extern __shared__ double smem[];
+  double *xs = smem;                       // [FB][RSX]
+  double *lg = smem + FB * RSX;            // [FB][RSG]   l, then gamma
+  double *red = lg + FB * RSG;             // [8][64] scratch for the log-likelihood reduction
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lcol = lane & 15, lgrp = lane >> 4;
+
+  // this wave's weight fragments and log-density constants stay in registers for the whole kernel
+  double wfrag[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) wfrag[ks] = Wpack[((size_t)wave * KS + ks) * 64 + lane];
+  d4 cin;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) cin[r] = cinit[16 * wave + 4 * r + lgrp];
+
+  d4 sacc[NDT];   // statistics tiles: rows = this wave's 16 mixtures, cols = 16 of the 2*DJ columns [x | x^2]
+  double s0l = 0.0;   // sum over this lane's frames of gamma[f][m = 16 wave + lcol]
+#pragma unroll
+  for (int j = 0; j < NDT; ++j) sacc[j] = d4{0, 0, 0, 0};
+  double llacc = 0.0;
+
+  const int64_t nblocks = (N + FB - 1) / FB;
+  for (int64_t blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
+    const int64_t f0 = blk * FB;
+    // ---- stage x: FB frames x DJ doubles, coalesced, zero beyond N ----
+    for (int e = tid; e < FB * DJ; e += 512) {
+      const int f = e / DJ, d = e % DJ;
+      xs[f * RSX + d] = (f0 + f < N) ? X[(f0 + f) * DJ + d] : 0.0;
+    }
+    __syncthreads();
+    // ---- step A: l[m][f] = c_m + sum_k W[m][k] Xe[k][f],  Xe = [x^2 ; x] ----
+#pragma unroll
+    for (int ft = 0; ft < FB / 16; ++ft) {
+      d4 acc = cin;
+      const double *xr = xs + (16 * ft + lcol) * RSX + lgrp;
+#pragma unroll
+      for (int ks = 0; ks < KS / 2; ++ks) {
+        const double x = xr[4 * ks];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(wfrag[ks], x * x, acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int ks = 0; ks < KS / 2; ++ks) {
+        const double x = xr[4 * ks];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(wfrag[KS / 2 + ks], x, acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) lg[(16 * ft + lcol) * RSG + 16 * wave + 4 * r + lgrp] = acc[r];
+    }
+    __syncthreads();
+    // ---- softmax over the 128 mixture slots of each frame: 8 lanes per frame, 16 slots per lane ----
+    {
+      const int f = tid >> 3, part8 = tid & 7;
+      double *row = lg + f * RSG + 16 * part8;
+      double v[16];
+      double u = -INFINITY;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        v[i] = row[i];
+        u = fmax(u, v[i]);
+      }
+      u = fmax(u, __shfl_xor(u, 1));
+      u = fmax(u, __shfl_xor(u, 2));
+      u = fmax(u, __shfl_xor(u, 4));
+      double s = 0.0;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        v[i] = exp(v[i] - u);
+        s += v[i];
+      }
+      s += __shfl_xor(s, 1);
+      s += __shfl_xor(s, 2);
+      s += __shfl_xor(s, 4);
+      const bool livef = (f0 + f < N);
+      const double inv = livef ? 1.0 / s : 0.0;          // frames beyond N contribute gamma = 0
+#pragma unroll
+      for (int i = 0; i < 16; ++i) row[i] = v[i] * inv;
+      if (part8 == 0 && livef) llacc += u + log(s);
+    }
+    __syncthreads();
+    // ---- step B: S[m][c] += sum_f gamma[f][m] Xe[f][c],  Xe = [x | x^2];  S0[m] += sum_f gamma[f][m] ----
+#pragma unroll 4
+    for (int ks = 0; ks < FB / 4; ++ks) {
+      const int f = 4 * ks + lgrp;
+      const double gm = lg[f * RSG + 16 * wave + lcol];
+      const double *xr = xs + f * RSX + lcol;
+#pragma unroll
+      for (int j = 0; j < NDT / 2; ++j) {
+        const double x = xr[16 * j];
+        sacc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(gm, x, sacc[j], 0, 0, 0);
+        sacc[NDT / 2 + j] = __builtin_amdgcn_mfma_f64_16x16x4f64(gm, x * x, sacc[NDT / 2 + j], 0, 0, 0);
+      }
+      s0l += gm;
+    }
+    __syncthreads();
+  }
+
+  // ---- write this workgroup's partial statistics: rows m = 16 wave + lgrp + 4 r, cols = 16 j + lcol ----
+  double *P = part + (size_t)blockIdx.x * plen;
+  s0l += __shfl_xor(s0l, 16);
+  s0l += __shfl_xor(s0l, 32);
+  if (lgrp == 0 && 16 * wave + lcol < M) P[16 * wave + lcol] = s0l;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int m = 16 * wave + 4 * r + lgrp;
+    if (m < M) {
+#pragma unroll
+      for (int j = 0; j < NDT; ++j) {
+        const int c = 16 * j + lcol;   // column of [x | x^2]
+        if (c < DJ) P[M + (size_t)m * DJ + c] = sacc[j][r];
+        else P[M + (size_t)M * DJ + (size_t)m * DJ + (c - DJ)] = sacc[j][r];
+      }
+    }
+  }
+  // log-likelihood: fixed-order reduction inside the workgroup
+  red[tid] = llacc;
+  __syncthreads();
+  if (tid == 0) {
+    double ll = 0.0;
+    for (int i = 0; i < 512; ++i) ll += red[i];
+    P[plen - 1] = ll;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+struct EstepScratch {
+  DevBuf<double> mu, iv, cst, G, LSE, part, Wpack, cinit, X, stats;
+};
+static EstepScratch &scratch() {
+  static thread_local EstepScratch s;
+  return s;
+}
+
+static int g_estep_force_generic = 0;
+
+static int estep_device(const double *dX, int64_t N, int Dj, int M, const double *w, const double *mu, const double *var,
+                        double *dstats, hipStream_t st) {
+  if (N < 0 || Dj < 1 || M < 1) return fail(VCMI_ERR_DIM, "E-step: N=%lld Dj=%d M=%d invalid", (long long)N, Dj, M);
+  if (!w || !mu || !var || !dstats || (N > 0 && !dX)) return fail(VCMI_ERR_ARG, "E-step: NULL argument");
+  EstepScratch &sc = scratch();
+  const int64_t plen = (int64_t)M * (1 + 2 * Dj) + 1;
+  std::vector<double> hiv((size_t)M * Dj), hc(M);
+  for (int m = 0; m < M; ++m) {
+    double sl = 0.0;
+    for (int d = 0; d < Dj; ++d) {
+      const double v = var[d + (size_t)Dj * m];
+      if (!(v > 0.0)) return fail(VCMI_ERR_NOT_PD, "E-step: variance (%d,%d) is not positive", d + 1, m + 1);
+      sl += std::log(v);
+      hiv[(size_t)m * Dj + d] = 1.0 / v;
+    }
+    hc[m] = (w[m] > 0.0 ? std::log(w[m]) : -INFINITY) - 0.5 * (Dj * kLog2Pi + sl);
+  }
+  VCMI_HIP(hipMemsetAsync(dstats, 0, plen * sizeof(double), st));
+  if (N == 0) return VCMI_OK;
+
+  const bool mfma = (Dj == 80 && M <= EstepCfg<80>::MMAX && !g_estep_force_generic);
+  if (mfma) {
+    using C = EstepCfg<80>;
+    // A-operand fragments of W[m][k]: k < Dj -> -iv/2 (multiplies x^2), k >= Dj -> mu*iv (multiplies x)
+    std::vector<double> hW((size_t)8 * C::KS * 64, 0.0), hci(C::MMAX, -INFINITY);
+    for (int mt = 0; mt < 8; ++mt)
+      for (int ks = 0; ks < C::KS; ++ks)
+        for (int l = 0; l < 64; ++l) {
+          const int m = 16 * mt + (l & 15), k = 4 * ks + (l >> 4);
+          double v = 0.0;
+          if (m < M) {
+            const int d = k < Dj ? k : k - Dj;
+            const double ivv = hiv[(size_t)m * Dj + d];
+            v = k < Dj ? -0.5 * ivv : mu[d + (size_t)Dj * m] * ivv;
+          }
+          hW[((size_t)mt * C::KS + ks) * 64 + l] = v;
+        }
+    // c_m absorbs the constant term -sum_d mu^2 iv / 2 of the expanded square
+    for (int m = 0; m < M; ++m) {
+      double t = 0.0;
+      for (int d = 0; d < Dj; ++d) t += mu[d + (size_t)Dj * m] * mu[d + (size_t)Dj * m] * hiv[(size_t)m * Dj + d];
+      hci[m] = hc[m] - 0.5 * t;
+    }
+    int dev = 0, cus = 256;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const int64_t nblocks = (N + C::FB - 1) / C::FB;
+    const int grid = (int)std::min<int64_t>(nblocks, cus);
+    VCMI_TRY(sc.Wpack.reserve(hW.size()));
+    VCMI_TRY(sc.cinit.reserve(hci.size()));
+    VCMI_TRY(sc.part.reserve((size_t)grid * plen));
+    VCMI_HIP(hipMemcpyAsync(sc.Wpack.p, hW.data(), hW.size() * 8, hipMemcpyHostToDevice, st));
+    VCMI_HIP(hipMemcpyAsync(sc.cinit.p, hci.data(), hci.size() * 8, hipMemcpyHostToDevice, st));
+    VCMI_HIP(hipStreamSynchronize(st));   // host vectors die at return
+    auto kern = estep_mfma_kernel<80>;
+    VCMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)C::LDS_BYTES));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), C::LDS_BYTES, st, dX, N, M, sc.Wpack.p, sc.cinit.p, sc.part.p, plen);
+    VCMI_HIP(hipGetLastError());
+    hipLaunchKernelGGL(estep_reduce_kernel, dim3((unsigned)((plen + 255) / 256)), dim3(256), 0, st, sc.part.p, grid, plen,
+                       dstats);
+    VCMI_HIP(hipGetLastError());
+    return VCMI_OK;
+  }
+
+  // generic path
+  std::vector<double> hmu((size_t)M * Dj);
+  for (int m = 0; m < M; ++m)
+    for (int d = 0; d < Dj; ++d) hmu[(size_t)m * Dj + d] = mu[d + (size_t)Dj * m];
+  const size_t shmem = (size_t)Dj * 64 * sizeof(double);
+  if (shmem > 150 * 1024) return fail(VCMI_ERR_ARG, "E-step: joint dimension %d too large", Dj);
+  VCMI_TRY(sc.mu.reserve(hmu.size()));
+  VCMI_TRY(sc.iv.reserve(hiv.size()));
+  VCMI_TRY(sc.cst.reserve(hc.size()));
+  const int64_t ch = std::min<int64_t>(N, kChunk);
+  const int maxseg = (int)((ch + kSeg - 1) / kSeg);
+  VCMI_TRY(sc.G.reserve((size_t)ch * M));
+  VCMI_TRY(sc.LSE.reserve((size_t)ch));
+  VCMI_TRY(sc.part.reserve((size_t)maxseg * plen));
+  VCMI_HIP(hipMemcpyAsync(sc.mu.p, hmu.data(), hmu.size() * 8, hipMemcpyHostToDevice, st));
+  VCMI_HIP(hipMemcpyAsync(sc.iv.p, hiv.data(), hiv.size() * 8, hipMemcpyHostToDevice, st));
+  VCMI_HIP(hipMemcpyAsync(sc.cst.p, hc.data(), hc.size() * 8, hipMemcpyHostToDevice, st));
+  VCMI_HIP(hipStreamSynchronize(st));
+  if (shmem > 64 * 1024)
+    VCMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(estep_gamma_kernel),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+  for (int64_t n0 = 0; n0 < N; n0 += kChunk) {
+    const int64_t nfr = std::min<int64_t>(kChunk, N - n0);
+    const int nseg = (int)((nfr + kSeg - 1) / kSeg);
+    hipLaunchKernelGGL(estep_gamma_kernel, dim3((unsigned)((nfr + 63) / 64)), dim3(64), shmem, st, dX, n0, nfr, Dj, M,
+                       sc.mu.p, sc.iv.p, sc.cst.p, sc.G.p, sc.LSE.p);
+    hipLaunchKernelGGL(estep_stats_kernel, dim3(nseg, (M * Dj + 255) / 256), dim3(256), 0, st, dX, n0, nfr, Dj, M, sc.G.p,
+                       sc.LSE.p, sc.part.p, plen);
+    hipLaunchKernelGGL(estep_reduce_kernel, dim3((unsigned)((plen + 255) / 256)), dim3(256), 0, st, sc.part.p, nseg, plen,
+                       dstats);
+    VCMI_HIP(hipGetLastError());
+  }
+  return VCMI_OK;
+}
+
+}  // namespace vcmi
+
 using namespace vcmi;
-extern "C" int vcmi_estep_diag(const double *, int64_t, int, int, const double *, const double *, const double *, double *, double *, double *, double *) { return fail(VCMI_ERR_ARG, "not implemented"); }
+
 extern "C" int64_t vcmi_estep_stats_len(int Dj, int M) { return (int64_t)M * (1 + 2 * Dj) + 1; }
-extern "C" int vcmi_estep_diag_dev(const double *, int64_t, int, int, const double *, const double *, const double *, double *, void *) { return fail(VCMI_ERR_ARG, "not implemented"); }
+
+extern "C" int vcmi_estep_diag_dev(const double *dX, int64_t N, int Dj, int M, const double *w, const double *mu,
+                                   const double *var, double *dstats, void *stream) {
+  return estep_device(dX, N, Dj, M, w, mu, var, dstats, as_stream(stream));
+}
+
+extern "C" int vcmi_estep_diag(const double *X, int64_t N, int Dj, int M, const double *w, const double *mu,
+                               const double *var, double *S0, double *S1, double *S2, double *loglik) {
+  if (!S0 || !S1 || !S2 || !loglik) return fail(VCMI_ERR_ARG, "vcmi_estep_diag: NULL output");
+  if (N < 0 || Dj < 1 || M < 1) return fail(VCMI_ERR_DIM, "E-step: N=%lld Dj=%d M=%d invalid", (long long)N, Dj, M);
+  VCMI_TRY(check_device());
+  EstepScratch &sc = scratch();
+  const int64_t plen = vcmi_estep_stats_len(Dj, M);
+  VCMI_TRY(sc.X.reserve((size_t)std::max<int64_t>(N, 1) * Dj));
+  VCMI_TRY(sc.stats.reserve((size_t)plen));
+  if (N > 0) VCMI_HIP(hipMemcpy(sc.X.p, X, (size_t)N * Dj * 8, hipMemcpyHostToDevice));
+  VCMI_TRY(estep_device(sc.X.p, N, Dj, M, w, mu, var, sc.stats.p, nullptr));
+  std::vector<double> h((size_t)plen);
+  VCMI_HIP(hipMemcpy(h.data(), sc.stats.p, (size_t)plen * 8, hipMemcpyDeviceToHost));
+  memcpy(S0, h.data(), sizeof(double) * M);
+  memcpy(S1, h.data() + M, sizeof(double) * M * Dj);
+  memcpy(S2, h.data() + M + (size_t)M * Dj, sizeof(double) * M * Dj);
+  *loglik = h[(size_t)plen - 1];
+  return VCMI_OK;
+}
+
+// test hook (not part of include/vcmi.h): 1 forces the generic kernels so that both paths are parity-tested
+extern "C" int vcmi_estep_debug_force_generic(int on) {
+  g_estep_force_generic = on;
+  return VCMI_OK;
+}

@@ -1,0 +1,91 @@
+"""Diagonal-covariance E-step -- the arithmetic behind `gmm[:fit](dataset.X')` in the reference's
+bin/train_gmm.jl:103 (scikit-learn through PyCall; joint features from src/datasets.jl:52-77).
+
+estep_diag(X (Dj,N), w (M,), mu (Dj,M), var (Dj,M)) -> S0 (M,), S1 (Dj,M), S2 (Dj,M), loglik.
+With a torch.distributed process group (one process per GPU) every rank passes its own shard of frames and
+the sufficient statistics are summed with ONE all-reduce over RCCL (`estep_diag_allreduce`)."""
+import numpy as np
+
+from . import _lib
+from ._arrays import current_stream_ptr, dev_matrix, is_torch, jl_matrix, jl_vector
+
+
+def stats_len(Dj, M):
+    return int(_lib.lib.vcmi_estep_stats_len(int(Dj), int(M)))
+
+
+def _params(w, mu, var):
+    w = jl_vector(w)
+    mu = jl_matrix(mu, "mu")
+    var = jl_matrix(var, "var")
+    Dj, M = mu.shape
+    if var.shape != (Dj, M) or w.shape != (M,):
+        raise _lib.DimensionMismatch(f"w {w.shape}, mu {mu.shape}, var {var.shape} are inconsistent")
+    return w, mu, var, Dj, M
+
+
+def unpack_stats(stats, Dj, M):
+    """[S0 | S1 | S2 | loglik] -> (S0 (M,), S1 (Dj,M), S2 (Dj,M), loglik); works for numpy and torch buffers."""
+    S0 = stats[:M]
+    S1 = stats[M:M + M * Dj].reshape(M, Dj).T
+    S2 = stats[M + M * Dj:M + 2 * M * Dj].reshape(M, Dj).T
+    return S0, S1, S2, stats[M + 2 * M * Dj]
+
+
+def estep_diag_dev(X, w, mu, var, out=None):
+    """Device-resident E-step: X is a (Dj,N) torch tensor (unit stride along Dj, dense: ld == Dj).
+    Returns the packed statistics as a device tensor of stats_len(Dj,M) doubles."""
+    import torch
+
+    w, mu, var, Dj, M = _params(w, mu, var)
+    ptr, D, N, ld = dev_matrix(X, "X")
+    if D != Dj or (N > 1 and ld != Dj):
+        raise _lib.DimensionMismatch("X must be a dense (Dj,N) matrix matching the model dimension")
+    if out is None:
+        out = torch.empty(stats_len(Dj, M), dtype=torch.float64, device=X.device)
+    _lib.check(_lib.lib.vcmi_estep_diag_dev(ptr, N, Dj, M, _lib.dptr(w), _lib.dptr(mu), _lib.dptr(var), out.data_ptr(),
+                                            current_stream_ptr()))
+    return out
+
+
+def estep_diag(X, w, mu, var):
+    if is_torch(X):
+        w_, mu_, var_, Dj, M = _params(w, mu, var)
+        st = estep_diag_dev(X, w_, mu_, var_).cpu().numpy()
+        S0, S1, S2, ll = unpack_stats(st, Dj, M)
+        return S0.copy(), np.asfortranarray(S1), np.asfortranarray(S2), float(ll)
+    w, mu, var, Dj, M = _params(w, mu, var)
+    X = jl_matrix(X, "X")
+    if X.shape[0] != Dj:
+        raise _lib.DimensionMismatch("X must be (Dj,N)")
+    N = X.shape[1]
+    S0 = np.empty(M)
+    S1 = np.empty((Dj, M), order="F")
+    S2 = np.empty((Dj, M), order="F")
+    ll = np.zeros(1)
+    _lib.check(_lib.lib.vcmi_estep_diag(_lib.dptr(X), N, Dj, M, _lib.dptr(w), _lib.dptr(mu), _lib.dptr(var),
+                                        _lib.dptr(S0), _lib.dptr(S1), _lib.dptr(S2), _lib.dptr(ll)))
+    return S0, S1, S2, float(ll[0])
+
+
+def estep_diag_allreduce(X_shard, w, mu, var, group=None):
+    """Multi-GPU E-step: local statistics of this rank's frame shard, then one all-reduce(sum) of the packed
+    M(1+2Dj)+1 doubles (RCCL when the group's backend is "nccl").  Returns the packed global statistics."""
+    import torch.distributed as dist
+
+    st = estep_diag_dev(X_shard, w, mu, var)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(st, op=dist.ReduceOp.SUM, group=group)
+    return st
+
+
+def mstep_diag(S0, S1, S2, min_covar=1e-7):
+    """M-step of the old sklearn.mixture.GMM the reference configures (bin/train_gmm.jl:84-89, min_covar :18),
+    from the E-step statistics (informative -- the E-step is what the parity tests pin)."""
+    eps = np.finfo(np.float64).eps
+    S0 = np.asarray(S0)
+    w = S0 / (S0.sum() + 10 * eps) + eps
+    inv = 1.0 / (S0 + 10 * eps)
+    mu = S1 * inv[None, :]
+    var = S2 * inv[None, :] - 2 * mu * S1 * inv[None, :] + mu * mu + min_covar
+    return w, mu, var
