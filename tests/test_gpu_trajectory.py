@@ -1,0 +1,87 @@
+"""GPU parity: TrajectoryGMMMap fvconvert / vc / push_delta vs golden vectors and the C oracle.
+Tolerance: the reference solves (W'D^-1W) y = W'D^-1E with a sparse direct solver, the GPU with a banded
+Cholesky; cond(P) ~ 1e6, so the two agree to ~1e-9; the test holds 1e-6 relative (north_star: 1e-5)."""
+import numpy as np
+import pytest
+
+from conftest import julia_model, load_golden, relerr
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-6
+
+
+@pytest.fixture(scope="module")
+def vc():
+    import voiceconversion_jl_amd as m
+    assert m.device_count() >= 1
+    return m
+
+
+def test_accessors(vc, fixture_model):
+    """test/trajectory_gmmmap.jl:36-50 (with the 80-dim fixture read as static 20 + delta 20)"""
+    g = vc.GMMMap(*julia_model(*fixture_model))
+    t = vc.TrajectoryGMMMap(g, 100)
+    assert len(t) == 100 and vc.dim(t) == 40 and vc.ncomponents(t) == 32 and vc.size(t) == (40, 100)
+
+
+def test_golden_fixture_model(vc, fixture_model):
+    z = load_golden("trajectory_fixture_model.npz")
+    g = vc.GMMMap(*julia_model(*fixture_model))
+    t = vc.TrajectoryGMMMap(g, 100)
+    assert np.array_equal(vc.push_delta(z["static"].T), z["X"].T)
+    Y = vc.fvconvert(t, z["X"].T)
+    assert Y.shape == (20, 100)
+    assert relerr(Y, z["Y"].T) < TOL
+    assert np.array_equal(vc.predict(g.px, z["X"].T), z["mhat"])
+    # vc(): chunks of length(t) = 30 frames, power row kept (src/common.jl:31-63)
+    t30 = vc.TrajectoryGMMMap(g, 30)
+    out = vc.vc(t30, z["vc_fm"].T)
+    assert out.shape == (21, 100)
+    assert np.array_equal(out[0], z["vc_fm"][:, 0])
+    assert relerr(out[1:], z["vc_out_L30"][:, 1:].T) < TOL
+    with pytest.raises(vc.DimensionMismatch):
+        vc.fvconvert(t, np.zeros((38, 10)))                          # src/trajectory_gmmmap.jl:68
+
+
+@pytest.mark.parametrize("D,M,Ts", [(40, 8, [300]), (12, 4, [1, 2, 3, 4, 5, 50]), (20, 6, [64, 7, 129])])
+def test_vs_oracle_batch(vc, D, M, Ts):
+    """Config-5 shape (static D=40, X dim 80) at a length the oracle finishes in seconds, plus the short-utterance
+    edge cases T = 1..5 where the stencil loses neighbours."""
+    from oracle import c_oracle as co, np_oracle as npo
+    w, mu, sig = npo.synth_model(500 + D, 4 * D, M, lam_lo=1e-3)
+    ref = co.TrajectoryGMMMap(co.GMMMap(w, mu, sig))
+    g = vc.GMMMap(*julia_model(w, mu, sig))
+    t = vc.TrajectoryGMMMap(g, max(Ts))
+    rng = np.random.default_rng(D)
+    Xs = []
+    for T in Ts:
+        static = npo.sample_frames(int(rng.integers(1 << 30)), w, mu, sig, T, 0, D)
+        static = np.cumsum(static, axis=0) / np.sqrt(np.arange(1, T + 1))[:, None]
+        Xs.append(npo.push_delta(static))
+    Ys = t.fvconvert_batch([x.T for x in Xs])
+    for x, y in zip(Xs, Ys):
+        yref, mh, _ = ref.fvconvert(x)
+        assert relerr(y, yref.T) < TOL
+    y0 = vc.fvconvert(t, Xs[0].T)
+    assert np.array_equal(y0, Ys[0])                                 # batch == single, bit for bit
+
+
+def test_constructW_structure(vc):
+    """test/trajectory_gmmmap.jl:1-34, 53: constructW(30, 40)"""
+    import scipy.sparse as sp
+    D, T = 30, 40
+    W = vc.constructW(D, T)
+    assert sp.issparse(W) and W.shape == (2 * D * T, D * T)
+    z = load_golden("trajectory_fixture_model.npz")
+    ref = sp.coo_matrix((z["W_vals"], (z["W_rows"] - 1, z["W_cols"] - 1)), shape=W.shape).tocsc()
+    assert abs(W - ref).max() == 0
+    Wd = W.toarray()
+    I = np.eye(D)
+    for t in range(T):
+        s = 2 * D * t
+        assert np.array_equal(Wd[s:s + D, t * D:(t + 1) * D], I)
+        if t >= 1:
+            assert np.array_equal(Wd[s + D:s + 2 * D, (t - 1) * D:t * D], -0.5 * I)
+        if t < T - 1:
+            assert np.array_equal(Wd[s + D:s + 2 * D, (t + 1) * D:(t + 2) * D], 0.5 * I)
+    assert W.nnz == D * T + 2 * D * (T - 1)

@@ -11,3 +11,4 @@ from .gmmmap import GMMMap  # noqa: F401
 from .dtw import DTW, backward, fit_, fit_batch, set_template_, update_  # noqa: F401,E402
 from .align import align, align_batch  # noqa: F401,E402
 from .estep import estep_diag, estep_diag_allreduce, estep_diag_dev, mstep_diag, stats_len, unpack_stats  # noqa: F401,E402
+from .trajectory_gmmmap import TrajectoryGMMMap, constructW, push_delta  # noqa: F401,E402

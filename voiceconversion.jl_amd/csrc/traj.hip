@@ -1,11 +1,451 @@
-// traj.hip -- placeholder translation unit (filled in below in this round)
+// traj.hip -- trajectory (MLPG) conversion with a GMM on static+delta features, MI355X (gfx950).
+//
+// Replaces   TrajectoryGMMMap ctor (Dy_m = inv(Syy_m - A_m Sxy_m))      reference src/trajectory_gmmmap.jl:11-31
+//            constructW / compute_wt (never materialised: W is a stencil) reference src/trajectory_gmmmap.jl:39-61
+//            fvconvert(tgmm, X)                                          reference src/trajectory_gmmmap.jl:65-110
+//            vc(c::TrajectoryConverter, fm)                              reference src/common.jl:31-63
+//            push_delta                                                  reference src/datasets.jl:6-13
+//
+// Math.  With mhat_t = argmax_m p(m | X_t), E_t = mu^y_m + A_m (X_t - mu^x_m), Q_t = Dy_mhat_t cut
+// into DxD blocks [[Qss,Qsd],[Qds,Qdd]] and g_t = Q_t E_t = [gs; gd], the normal equations
+// (W' Dy^-1 W) y = W' Dy^-1 E of :103-105 are block-pentadiagonal:
+//   P[t,t]   = Qss(t) + Qdd(t-1)/4 + Qdd(t+1)/4        r[t] = gs(t) + gd(t-1)/2 - gd(t+1)/2
+//   P[t,t-1] = Qds(t-1)/2 - Qsd(t)/2                   (terms with t-1 < 1 or t+1 > T dropped, as W drops them)
+//   P[t,t-2] = -Qdd(t-1)/4
+// One workgroup per utterance factorises P = L L' with a right-looking Cholesky on a sliding 3D x 3D window held
+// in LDS (the right-hand side rides along as an extra row, so z = L^-1 r falls out of the same updates), streams
+// the D-column panels of L to an HBM workspace, and back-substitutes L' y = z reading the panels in reverse.
 #include "vcmi_common.hpp"
+#include "host_linalg.hpp"
+#include "gmmmap_handle.hpp"
+
+#include <algorithm>
+
+struct vcmi_traj {
+  vcmi_gmmmap *g = nullptr;
+  int D2 = 0;          // dim(t) = 2D (static + delta), src/trajectory_gmmmap.jl:35
+  int D = 0;           // static dimension
+  int M = 0;
+  int64_t length = 0;  // length(t), src/trajectory_gmmmap.jl:34
+  vcmi::DevBuf<double> AT, QT, bvec, Q;   // [M][k][r] transposed A and Q (coalesced gemv), b [M][2D], Q row-major [M][2D][2D]
+  vcmi::DevBuf<double> gbuf, ws, xbuf, ybuf;
+  vcmi::DevBuf<int64_t> mhat;
+  vcmi::DevBuf<int> status;
+  vcmi::DevBuf<unsigned char> uttbuf;
+};
+
+namespace vcmi {
+
+struct TrajUtt {
+  const double *X;   // (2D,T) dense
+  double *Y;         // (D,T) dense
+  int64_t frame0;    // offset of this utterance in the packed per-frame scratch (mhat, g)
+  int32_t T;
+};
+
+// ------------------------------------------------------------------------------------------------
+// g_t = Q_mhat (A_mhat x_t + b_mhat): one workgroup per frame, thread r owns output row r
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(128)
+traj_g_kernel(const double *__restrict__ X, int64_t nframes, int D2, const int64_t *__restrict__ mhat,
+              const double *__restrict__ AT, const double *__restrict__ QT, const double *__restrict__ bvec,
+              double *__restrict__ G) {
+  extern __shared__ double sm[];   // x[D2], e[D2]
+  double *xs = sm, *es = sm + D2;
+  const int64_t fr = blockIdx.x;
+  const int m = (int)mhat[fr] - 1;
+  for (int r = threadIdx.x; r < D2; r += blockDim.x) xs[r] = X[fr * D2 + r];
+  __syncthreads();
+  const double *A = AT + (size_t)m * D2 * D2, *Q = QT + (size_t)m * D2 * D2;
+  for (int r = threadIdx.x; r < D2; r += blockDim.x) {
+    double e = bvec[(size_t)m * D2 + r];                       // E = mu^y + A (x - mu^x), src/trajectory_gmmmap.jl:88
+    for (int k = 0; k < D2; ++k) e = fma(A[(size_t)k * D2 + r], xs[k], e);
+    es[r] = e;
+  }
+  __syncthreads();
+  for (int r = threadIdx.x; r < D2; r += blockDim.x) {
+    double s = 0.0;
+    for (int k = 0; k < D2; ++k) s = fma(Q[(size_t)k * D2 + r], es[k], s);
+    G[fr * D2 + r] = s;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// banded Cholesky solve, one workgroup (256 threads) per utterance
+// ------------------------------------------------------------------------------------------------
+// LDS window: 3x3 blocks of DxD with circular block slots (global block a lives in slot a % 3), row stride LD.
+__device__ __forceinline__ int wslot(int a) { return a % 3; }
+
+__global__ void __launch_bounds__(256)
+traj_solve_kernel(const TrajUtt *__restrict__ utts, int n, int D, const double *__restrict__ Qall,
+                  const int64_t *__restrict__ mhat_all, const double *__restrict__ g_all, double *__restrict__ ws_all,
+                  int64_t ws_stride, int *__restrict__ status) {
+  const int D2 = 2 * D, W3 = 3 * D, LD = W3 + 1;
+  extern __shared__ double sm[];
+  double *Wd = sm;                       // [W3][LD]
+  double *rr = Wd + (size_t)W3 * LD;     // [W3] right-hand-side row (circular slots like the window)
+  double *yring = rr + W3;               // [2][D]  y_{t+1}, y_{t+2} during back-substitution
+  double *wv = yring + 2 * D;            // [D]
+  __shared__ int bad;
+  const int tid = threadIdx.x;
+  const size_t PAN = (size_t)(W3 + 1) * D;   // panel: rows 0..3D-1 of L[:, block t] (relative to t) + z row
+
+  for (int u = blockIdx.x; u < n; u += gridDim.x) {
+    const TrajUtt U = utts[u];
+    const int T = U.T;
+    if (T == 0) continue;
+    const int64_t *mh = mhat_all + U.frame0;
+    const double *g = g_all + U.frame0 * D2;
+    double *ws = ws_all + (size_t)blockIdx.x * ws_stride;
+    if (tid == 0) bad = 0;
+
+    // assemble block row a of P (and r) into the window; blocks (a, a-2), (a, a-1), (a, a)
+    auto add_block_row = [&](int a) {
+      const int sa = wslot(a);
+      const double *Qa = Qall + (size_t)(mh[a] - 1) * D2 * D2;
+      const double *Qm = (a >= 1) ? Qall + (size_t)(mh[a - 1] - 1) * D2 * D2 : nullptr;
+      const double *Qp = (a + 1 < T) ? Qall + (size_t)(mh[a + 1] - 1) * D2 * D2 : nullptr;
+      for (int e = tid; e < D * D; e += 256) {
+        const int i = e / D, j = e % D;
+        double v = Qa[(size_t)i * D2 + j];                                        // Qss(a)
+        if (Qm) v += 0.25 * Qm[(size_t)(D + i) * D2 + (D + j)];                   // + Qdd(a-1)/4
+        if (Qp) v += 0.25 * Qp[(size_t)(D + i) * D2 + (D + j)];                   // + Qdd(a+1)/4
+        Wd[(size_t)(sa * D + i) * LD + sa * D + j] = v;
+        if (a >= 1) {
+          const int sb = wslot(a - 1);
+          Wd[(size_t)(sa * D + i) * LD + sb * D + j] =
+              0.5 * Qm[(size_t)(D + i) * D2 + j] - 0.5 * Qa[(size_t)i * D2 + (D + j)];   // Qds(a-1)/2 - Qsd(a)/2
+        }
+        if (a >= 2) {
+          const int sc = wslot(a - 2);
+          Wd[(size_t)(sa * D + i) * LD + sc * D + j] = -0.25 * Qm[(size_t)(D + i) * D2 + (D + j)];   // -Qdd(a-1)/4
+        }
+      }
+      for (int i = tid; i < D; i += 256) {
+        double v = g[(size_t)a * D2 + i];
+        if (a >= 1) v += 0.5 * g[(size_t)(a - 1) * D2 + D + i];
+        if (a + 1 < T) v -= 0.5 * g[(size_t)(a + 1) * D2 + D + i];
+        rr[sa * D + i] = v;
+      }
+    };
+
+    for (int a = 0; a < 3 && a < T; ++a) add_block_row(a);
+    __syncthreads();
+
+    // ---------------- factorisation + forward substitution ----------------
+    for (int t = 0; t < T; ++t) {
+      const int nb = (T - t < 3) ? T - t : 3;      // block rows alive in the window
+      const int nrows = nb * D;
+      const int s0 = wslot(t);
+      // local row lr (0..nrows-1) -> LDS row index
+      auto rowidx = [&](int lr) { return wslot(t + lr / D) * D + lr % D; };
+      for (int c = 0; c < D; ++c) {
+        const int pc = s0 * D + c;                 // LDS index of pivot row/column
+        const double piv = Wd[(size_t)pc * LD + pc];
+        if (!(piv > 0.0)) {
+          if (tid == 0) bad = 1;
+        }
+        const double dinv = 1.0 / sqrt(piv);
+        __syncthreads();                           // everyone has read the pivot before it is overwritten
+        // scale column c below the pivot (and the rhs entry)
+        for (int lr = c + tid; lr < nrows; lr += 256) {
+          const int ri = rowidx(lr);
+          Wd[(size_t)ri * LD + pc] = (lr == c) ? piv * dinv : Wd[(size_t)ri * LD + pc] * dinv;
+        }
+        if (tid == 255) rr[pc] *= dinv;
+        __syncthreads();
+        // rank-1 update of the trailing lower triangle and of the rhs row
+        const int rem = nrows - c - 1;
+        {
+          const int ti = tid >> 4, tj = tid & 15;
+          for (int a = ti; a < rem; a += 16) {
+            const int lr = c + 1 + a, ri = rowidx(lr);
+            const double lic = Wd[(size_t)ri * LD + pc];
+            for (int b = tj; b <= a; b += 16) {
+              const int lcq = c + 1 + b, rj = rowidx(lcq);
+              Wd[(size_t)ri * LD + rj] = fma(-lic, Wd[(size_t)rj * LD + pc], Wd[(size_t)ri * LD + rj]);
+            }
+          }
+        }
+        const double zc = rr[pc];
+        for (int b = tid; b < rem; b += 256) {
+          const int rj = rowidx(c + 1 + b);
+          rr[rj] = fma(-zc, Wd[(size_t)rj * LD + pc], rr[rj]);
+        }
+        __syncthreads();
+      }
+      // stream the finished panel: rows lr = 0..3D-1 (zero beyond nrows), columns of block t; then the z row
+      double *pan = ws + (size_t)t * PAN;
+      for (int e = tid; e < W3 * D; e += 256) {
+        const int lr = e / D, c = e % D;
+        pan[e] = (lr < nrows) ? Wd[(size_t)rowidx(lr) * LD + s0 * D + c] : 0.0;
+      }
+      for (int c = tid; c < D; c += 256) pan[(size_t)W3 * D + c] = rr[s0 * D + c];
+      __syncthreads();
+      if (t + 3 < T) add_block_row(t + 3);
+      __syncthreads();
+    }
+
+    // ---------------- back substitution  L' y = z ----------------
+    for (int i = tid; i < 2 * D; i += 256) yring[i] = 0.0;
+    __syncthreads();
+    for (int t = T - 1; t >= 0; --t) {
+      const double *pan = ws + (size_t)t * PAN;
+      double *y1 = yring + ((t + 1) & 1) * D, *y2 = yring + (t & 1) * D;   // y_{t+1}, y_{t+2}
+      // stage the diagonal block (needed row-wise by the triangular solve) in LDS
+      for (int e = tid; e < D * D; e += 256) Wd[e] = pan[e];
+      // w = z - E' y1 - F' y2  (thread j owns column j; panel rows D..3D-1 hold E then F)
+      if (tid < D) {
+        double s = pan[(size_t)W3 * D + tid];
+        for (int i = 0; i < D; ++i) s = fma(-pan[(size_t)(D + i) * D + tid], y1[i], s);
+        for (int i = 0; i < D; ++i) s = fma(-pan[(size_t)(2 * D + i) * D + tid], y2[i], s);
+        wv[tid] = s;
+      }
+      __syncthreads();
+      // Dg' y = w : sequential in k, one wave
+      if (tid < 64) {
+        double w = (tid < D) ? wv[tid] : 0.0;
+        for (int k = D - 1; k >= 0; --k) {
+          const double yk = __shfl(w, k) / Wd[(size_t)k * D + k];
+          if (tid == k) w = yk;
+          else if (tid < k) w = fma(-Wd[(size_t)k * D + tid], yk, w);
+        }
+        if (tid < D) {
+          y2[tid] = w;                       // becomes y_t; the slot of y_{t+2} is free now
+          U.Y[(size_t)t * D + tid] = w;      // reshape(y, D, T), src/trajectory_gmmmap.jl:109
+        }
+      }
+      __syncthreads();
+    }
+    if (tid == 0 && bad) status[0] = 1;
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+static size_t solve_lds_bytes(int D) {
+  const size_t W3 = 3 * (size_t)D;
+  return (W3 * (W3 + 1) + W3 + 2 * D + D) * sizeof(double);
+}
+
+static int traj_run(vcmi_traj *t, std::vector<TrajUtt> &utts, int64_t nframes, bool contiguous, const double *dX0,
+                    hipStream_t st) {
+  const int n = (int)utts.size();
+  if (n == 0 || nframes == 0) return VCMI_OK;
+  const int D = t->D, D2 = t->D2;
+  VCMI_TRY(t->mhat.reserve((size_t)nframes));
+  VCMI_TRY(t->gbuf.reserve((size_t)nframes * D2));
+  // (1) mhat = predict(g.px, X), src/trajectory_gmmmap.jl:82
+  if (contiguous) {
+    VCMI_TRY(gmmmap_predict_device(t->g, dX0, D2, nframes, t->mhat.p, st));
+    hipLaunchKernelGGL(traj_g_kernel, dim3((unsigned)nframes), dim3(128), 2 * D2 * sizeof(double), st, dX0, nframes, D2,
+                       t->mhat.p, t->AT.p, t->QT.p, t->bvec.p, t->gbuf.p);
+  } else {
+    for (auto &u : utts) {
+      if (u.T == 0) continue;
+      VCMI_TRY(gmmmap_predict_device(t->g, u.X, D2, u.T, t->mhat.p + u.frame0, st));
+      hipLaunchKernelGGL(traj_g_kernel, dim3((unsigned)u.T), dim3(128), 2 * D2 * sizeof(double), st, u.X, (int64_t)u.T, D2,
+                         t->mhat.p + u.frame0, t->AT.p, t->QT.p, t->bvec.p, t->gbuf.p + (size_t)u.frame0 * D2);
+    }
+  }
+  VCMI_HIP(hipGetLastError());
+  // (2) banded solve
+  int Tmax = 0;
+  for (auto &u : utts) Tmax = std::max(Tmax, (int)u.T);
+  int dev = 0, cus = 256;
+  (void)hipGetDevice(&dev);
+  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  const int grid = std::min(n, cus);
+  const int64_t ws_stride = (int64_t)Tmax * (3 * D + 1) * D;
+  VCMI_TRY(t->ws.reserve((size_t)grid * ws_stride));
+  VCMI_TRY(t->status.reserve(1));
+  VCMI_TRY(t->uttbuf.reserve(sizeof(TrajUtt) * n));
+  VCMI_HIP(hipMemsetAsync(t->status.p, 0, sizeof(int), st));
+  // longest utterances first
+  std::stable_sort(utts.begin(), utts.end(), [](const TrajUtt &a, const TrajUtt &b) { return a.T > b.T; });
+  VCMI_HIP(hipMemcpy(t->uttbuf.p, utts.data(), sizeof(TrajUtt) * n, hipMemcpyHostToDevice));
+  const size_t shmem = solve_lds_bytes(D);
+  VCMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(traj_solve_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)shmem));
+  hipLaunchKernelGGL(traj_solve_kernel, dim3(grid), dim3(256), shmem, st, reinterpret_cast<const TrajUtt *>(t->uttbuf.p), n, D,
+                     t->Q.p, t->mhat.p, t->gbuf.p, t->ws.p, ws_stride, t->status.p);
+  VCMI_HIP(hipGetLastError());
+  return VCMI_OK;
+}
+
+static int traj_check_status(vcmi_traj *t, hipStream_t st) {
+  int h = 0;
+  VCMI_HIP(hipMemcpyAsync(&h, t->status.p, sizeof(int), hipMemcpyDeviceToHost, st));
+  VCMI_HIP(hipStreamSynchronize(st));
+  if (h) return fail(VCMI_ERR_NOT_PD, "trajectory normal matrix W'D^-1W is not positive definite");
+  return VCMI_OK;
+}
+
+// host-pointer batch: pack, run, unpack
+static int traj_host_batch(vcmi_traj *t, int64_t n, const double *const *X, const int64_t *T, double *const *Y) {
+  if (!t) return fail(VCMI_ERR_ARG, "trajectory: NULL handle");
+  if (n < 0) return fail(VCMI_ERR_ARG, "trajectory: negative batch size");
+  if (n == 0) return VCMI_OK;
+  if (!X || !T || !Y) return fail(VCMI_ERR_ARG, "trajectory: NULL argument");
+  int64_t nframes = 0;
+  for (int64_t u = 0; u < n; ++u) {
+    if (T[u] < 0 || T[u] > INT32_MAX) return fail(VCMI_ERR_DIM, "trajectory: bad utterance length");
+    if (T[u] > 0 && (!X[u] || !Y[u])) return fail(VCMI_ERR_ARG, "trajectory: NULL matrix");
+    nframes += T[u];
+  }
+  if (nframes == 0) return VCMI_OK;
+  const int D = t->D, D2 = t->D2;
+  VCMI_TRY(t->xbuf.reserve((size_t)nframes * D2));
+  VCMI_TRY(t->ybuf.reserve((size_t)nframes * D));
+  std::vector<double> hx((size_t)nframes * D2);
+  std::vector<TrajUtt> utts(n);
+  int64_t f0 = 0;
+  for (int64_t u = 0; u < n; ++u) {
+    if (T[u] > 0) memcpy(&hx[(size_t)f0 * D2], X[u], sizeof(double) * D2 * T[u]);
+    utts[u] = TrajUtt{t->xbuf.p + (size_t)f0 * D2, t->ybuf.p + (size_t)f0 * D, f0, (int32_t)T[u]};
+    f0 += T[u];
+  }
+  VCMI_HIP(hipMemcpy(t->xbuf.p, hx.data(), hx.size() * 8, hipMemcpyHostToDevice));
+  VCMI_TRY(traj_run(t, utts, nframes, true, t->xbuf.p, nullptr));
+  VCMI_TRY(traj_check_status(t, nullptr));
+  std::vector<double> hy((size_t)nframes * D);
+  VCMI_HIP(hipMemcpy(hy.data(), t->ybuf.p, hy.size() * 8, hipMemcpyDeviceToHost));
+  f0 = 0;
+  for (int64_t u = 0; u < n; ++u) {
+    if (T[u] > 0) memcpy(Y[u], &hy[(size_t)f0 * D], sizeof(double) * D * T[u]);
+    f0 += T[u];
+  }
+  return VCMI_OK;
+}
+
+}  // namespace vcmi
+
 using namespace vcmi;
-extern "C" int vcmi_traj_create(vcmi_gmmmap *, int64_t, vcmi_traj **) { return fail(VCMI_ERR_ARG, "not implemented"); }
-extern "C" int vcmi_traj_destroy(vcmi_traj *) { return VCMI_OK; }
-extern "C" int64_t vcmi_traj_length(const vcmi_traj *) { return 0; }
-extern "C" int vcmi_traj_convert(vcmi_traj *, const double *, int64_t, double *) { return fail(VCMI_ERR_ARG, "not implemented"); }
-extern "C" int vcmi_traj_convert_batch(vcmi_traj *, int64_t, const double *const *, const int64_t *, double *const *) { return fail(VCMI_ERR_ARG, "not implemented"); }
-extern "C" int vcmi_traj_convert_batch_dev(vcmi_traj *, int64_t, const double *, const int64_t *, const int64_t *, double *, const int64_t *, void *) { return fail(VCMI_ERR_ARG, "not implemented"); }
-extern "C" int vcmi_vc_traj(vcmi_traj *, const double *, int64_t, double *) { return fail(VCMI_ERR_ARG, "not implemented"); }
-extern "C" int vcmi_push_delta(const double *, int, int64_t, double *) { return fail(VCMI_ERR_ARG, "not implemented"); }
+
+extern "C" int vcmi_traj_create(vcmi_gmmmap *g, int64_t T, vcmi_traj **out) {
+  if (!g || !out) return fail(VCMI_ERR_ARG, "vcmi_traj_create: NULL argument");
+  *out = nullptr;
+  if (g->D & 1) return fail(VCMI_ERR_DIM, "TrajectoryGMMMap: dim(g) = %d must be even (static + delta)", g->D);
+  if (T < 0) return fail(VCMI_ERR_ARG, "TrajectoryGMMMap: negative length");
+  const int D2 = g->D, D = D2 / 2, M = g->M;
+  if (solve_lds_bytes(D) > 160 * 1024 - 64)
+    return fail(VCMI_ERR_ARG, "TrajectoryGMMMap: static dimension %d exceeds the LDS-window solver's limit (46)", D);
+  vcmi_traj *t = new (std::nothrow) vcmi_traj();
+  if (!t) return fail(VCMI_ERR_OOM, "out of host memory");
+  t->g = g;
+  t->D2 = D2;
+  t->D = D;
+  t->M = M;
+  t->length = T;
+  const size_t nn = (size_t)D2 * D2;
+  std::vector<double> Q(nn * M), QT(nn * M), AT(nn * M), bv((size_t)D2 * M), tmp(nn), S(nn);
+  for (int m = 0; m < M; ++m) {
+    // Dy_m = inv(Syy_m - A_m Sxy_m), src/trajectory_gmmmap.jl:24-28
+    la::matmul(&g->h_A[nn * m], &g->h_Sxy[nn * m], D2, tmp.data());
+    for (size_t k = 0; k < nn; ++k) S[k] = g->h_Syy[nn * m + k] - tmp[k];
+    if (!la::inverse(S.data(), D2, &Q[nn * m])) {
+      delete t;
+      return fail(VCMI_ERR_NOT_PD, "TrajectoryGMMMap: conditional covariance of mixture %d is singular", m + 1);
+    }
+    for (int r = 0; r < D2; ++r) {
+      double ba = 0.0;
+      for (int k = 0; k < D2; ++k) {
+        QT[nn * m + (size_t)k * D2 + r] = Q[nn * m + (size_t)r * D2 + k];
+        AT[nn * m + (size_t)k * D2 + r] = g->h_A[nn * m + (size_t)r * D2 + k];
+        ba += g->h_A[nn * m + (size_t)r * D2 + k] * g->h_mux[(size_t)D2 * m + k];
+      }
+      bv[(size_t)D2 * m + r] = g->h_muy[(size_t)D2 * m + r] - ba;
+    }
+  }
+  int rc = VCMI_OK;
+  if ((rc = t->Q.alloc(Q.size())) || (rc = t->QT.alloc(QT.size())) || (rc = t->AT.alloc(AT.size())) ||
+      (rc = t->bvec.alloc(bv.size()))) {
+    delete t;
+    return rc;
+  }
+  hipError_t e = hipMemcpy(t->Q.p, Q.data(), Q.size() * 8, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(t->QT.p, QT.data(), QT.size() * 8, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(t->AT.p, AT.data(), AT.size() * 8, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(t->bvec.p, bv.data(), bv.size() * 8, hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    delete t;
+    return fail(VCMI_ERR_HIP, "TrajectoryGMMMap: upload failed: %s", hipGetErrorString(e));
+  }
+  *out = t;
+  return VCMI_OK;
+}
+
+extern "C" int vcmi_traj_destroy(vcmi_traj *t) {
+  delete t;
+  return VCMI_OK;
+}
+extern "C" int64_t vcmi_traj_length(const vcmi_traj *t) { return t ? t->length : -1; }
+
+extern "C" int vcmi_traj_convert(vcmi_traj *t, const double *X, int64_t T, double *Y) {
+  const double *xs[1] = {X};
+  double *ys[1] = {Y};
+  return traj_host_batch(t, 1, xs, &T, ys);
+}
+
+extern "C" int vcmi_traj_convert_batch(vcmi_traj *t, int64_t n, const double *const *X, const int64_t *T, double *const *Y) {
+  return traj_host_batch(t, n, X, T, Y);
+}
+
+extern "C" int vcmi_traj_convert_batch_dev(vcmi_traj *t, int64_t n, const double *dX, const int64_t *x_off, const int64_t *T,
+                                           double *dY, const int64_t *y_off, void *stream) {
+  if (!t) return fail(VCMI_ERR_ARG, "vcmi_traj_convert_batch_dev: NULL handle");
+  if (n < 0) return fail(VCMI_ERR_ARG, "vcmi_traj_convert_batch_dev: negative batch size");
+  if (n == 0) return VCMI_OK;
+  if (!dX || !x_off || !T || !dY || !y_off) return fail(VCMI_ERR_ARG, "vcmi_traj_convert_batch_dev: NULL argument");
+  std::vector<TrajUtt> utts(n);
+  int64_t f0 = 0;
+  bool contiguous = true;
+  for (int64_t u = 0; u < n; ++u) {
+    if (T[u] < 0 || T[u] > INT32_MAX) return fail(VCMI_ERR_DIM, "trajectory: bad utterance length");
+    if (x_off[u] != x_off[0] + f0 * t->D2) contiguous = false;
+    utts[u] = TrajUtt{dX + x_off[u], dY + y_off[u], f0, (int32_t)T[u]};
+    f0 += T[u];
+  }
+  VCMI_TRY(traj_run(t, utts, f0, contiguous, dX + x_off[0], as_stream(stream)));
+  return traj_check_status(t, as_stream(stream));
+}
+
+extern "C" int vcmi_vc_traj(vcmi_traj *t, const double *fm, int64_t T, double *out) {
+  if (!t) return fail(VCMI_ERR_ARG, "vcmi_vc_traj: NULL handle");
+  if (T < 0 || (T > 0 && (!fm || !out))) return fail(VCMI_ERR_ARG, "vcmi_vc_traj: bad argument");
+  if (T == 0) return VCMI_OK;
+  if (t->length < 1) return fail(VCMI_ERR_ARG, "vcmi_vc_traj: length(t) must be positive");
+  const int D = t->D, D2 = t->D2;
+  const int64_t L = t->length, nch = (T + L - 1) / L;   // chunks [kL+1, min((k+1)L, T)], src/common.jl:42-57
+  std::vector<double> x((size_t)T * D2), y((size_t)T * D);
+  for (int64_t f = 0; f < T; ++f) memcpy(&x[(size_t)f * D2], fm + (size_t)f * (D2 + 1) + 1, sizeof(double) * D2);
+  std::vector<const double *> xs(nch);
+  std::vector<double *> ys(nch);
+  std::vector<int64_t> Ts(nch);
+  for (int64_t k = 0; k < nch; ++k) {
+    xs[k] = &x[(size_t)k * L * D2];
+    ys[k] = &y[(size_t)k * L * D];
+    Ts[k] = std::min<int64_t>(L, T - k * L);
+  }
+  VCMI_TRY(traj_host_batch(t, nch, xs.data(), Ts.data(), ys.data()));
+  for (int64_t f = 0; f < T; ++f) {
+    out[(size_t)f * (D + 1)] = fm[(size_t)f * (D2 + 1)];   // power row kept, src/common.jl:60
+    memcpy(out + (size_t)f * (D + 1) + 1, &y[(size_t)f * D], sizeof(double) * D);
+  }
+  return VCMI_OK;
+}
+
+extern "C" int vcmi_push_delta(const double *src, int D, int64_t T, double *out) {
+  if (!src || !out || D < 1 || T < 0) return fail(VCMI_ERR_ARG, "vcmi_push_delta: bad argument");
+  for (int64_t t = 0; t < T; ++t)
+    for (int d = 0; d < D; ++d) {   // repmat(src, 2), src/datasets.jl:8
+      out[d + (size_t)2 * D * t] = src[d + (size_t)D * t];
+      out[D + d + (size_t)2 * D * t] = src[d + (size_t)D * t];
+    }
+  for (int64_t t = 1; t + 1 < T; ++t)   // t = 2:T-1, src/datasets.jl:9-11
+    for (int d = 0; d < D; ++d)
+      out[D + d + (size_t)2 * D * t] = -0.5 * src[d + (size_t)D * (t - 1)] + 0.5 * src[d + (size_t)D * (t + 1)];
+  return VCMI_OK;
+}

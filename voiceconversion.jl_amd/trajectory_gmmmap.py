@@ -1,0 +1,106 @@
+"""Trajectory-based (MLPG) conversion -- reference src/trajectory_gmmmap.jl:1-110, push_delta src/datasets.jl:6-13."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._arrays import jl_matrix
+from .common import TrajectoryConverter
+
+
+def constructW(D, T):
+    """constructW(D, T): the (2DT x DT) sparse window matrix of src/trajectory_gmmmap.jl:39-61 -- identity for the
+    static rows, -1/2 / +1/2 on the neighbouring frames for the delta rows (missing neighbours dropped).
+    Host-side helper for API parity (test/trajectory_gmmmap.jl:1-34); the GPU solver applies W as a stencil and
+    never materialises it."""
+    import scipy.sparse as sp
+
+    t = np.arange(T)
+    d = np.arange(D)
+    rows = [(2 * D * t[:, None] + d[None, :]).ravel()]
+    cols = [(D * t[:, None] + d[None, :]).ravel()]
+    vals = [np.ones(D * T)]
+    if T >= 2:
+        tt = t[1:]
+        rows.append((2 * D * tt[:, None] + D + d[None, :]).ravel())
+        cols.append((D * (tt[:, None] - 1) + d[None, :]).ravel())
+        vals.append(np.full(D * (T - 1), -0.5))
+        tt = t[:-1]
+        rows.append((2 * D * tt[:, None] + D + d[None, :]).ravel())
+        cols.append((D * (tt[:, None] + 1) + d[None, :]).ravel())
+        vals.append(np.full(D * (T - 1), 0.5))
+    return sp.csc_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(2 * D * T, D * T))
+
+
+def push_delta(src):
+    """push_delta(src (D,T)) -> (2D,T), src/datasets.jl:6-13: delta_t = (x_{t+1} - x_{t-1})/2 for 2 <= t <= T-1;
+    the first and last frame keep a copy of the static features in the delta rows (repmat artefact)."""
+    src = jl_matrix(src, "src")
+    D, T = src.shape
+    out = np.empty((2 * D, T), order="F")
+    _lib.check(_lib.lib.vcmi_push_delta(_lib.dptr(src), D, T, _lib.dptr(out)))
+    return out
+
+
+class TrajectoryGMMMap(TrajectoryConverter):
+    """TrajectoryGMMMap(g::GMMMap, T) -- src/trajectory_gmmmap.jl:3-37.  `g` is a GMMMap over static+delta
+    features (dim(g) = 2D).  The constructor precomputes Dy_m = inv(Sigma^yy_m - A_m Sigma^xy_m) (:24-28)."""
+
+    def __init__(self, g, T):
+        self.gmmmap = g
+        h = C.c_void_p()
+        _lib.check(_lib.lib.vcmi_traj_create(g._h, int(T), C.byref(h)))
+        self._h = h
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            _lib.lib.vcmi_traj_destroy(h)
+            self._h = None
+
+    def __len__(self):                      # Base.length(t) = size(W,2) / (dim/2) = T, src/trajectory_gmmmap.jl:34
+        return int(_lib.lib.vcmi_traj_length(self._h))
+
+    def _dim(self):                         # src/trajectory_gmmmap.jl:35
+        return self.gmmmap._dim()
+
+    def _ncomponents(self):                 # src/trajectory_gmmmap.jl:36
+        return self.gmmmap._ncomponents()
+
+    def _fvconvert(self, X):
+        """fvconvert(tgmm, X (2D,T)) -> (D,T); src/trajectory_gmmmap.jl:65-110"""
+        X = jl_matrix(X, "X")
+        D2, T = X.shape
+        if D2 != self._dim():               # src/trajectory_gmmmap.jl:68
+            raise _lib.DimensionMismatch("Inconsistent dimentions.")
+        Y = np.empty((D2 // 2, T), order="F")
+        _lib.check(_lib.lib.vcmi_traj_convert(self._h, _lib.dptr(X), T, _lib.dptr(Y)))
+        return Y
+
+    def fvconvert_batch(self, Xs):
+        """Batch extension: independent utterances in one launch (one workgroup per utterance)."""
+        n = len(Xs)
+        if n == 0:
+            return []
+        Xs = [jl_matrix(x, "X") for x in Xs]
+        D2 = self._dim()
+        for x in Xs:
+            if x.shape[0] != D2:
+                raise _lib.DimensionMismatch("Inconsistent dimentions.")
+        T = np.array([x.shape[1] for x in Xs], dtype=np.int64)
+        Ys = [np.empty((D2 // 2, int(t)), order="F") for t in T]
+        dpp = C.POINTER(C.c_double) * n
+        _lib.check(_lib.lib.vcmi_traj_convert_batch(self._h, n, dpp(*[_lib.dptr(x) for x in Xs]), _lib.iptr(T),
+                                                    dpp(*[_lib.dptr(y) for y in Ys])))
+        return Ys
+
+    def _vc(self, fm):
+        """vc(c::TrajectoryConverter, fm (2D+1,T)) -> (D+1,T) in chunks of length(c) frames; src/common.jl:31-63"""
+        fm = jl_matrix(fm, "fm")
+        D2 = self._dim()
+        if fm.shape[0] != D2 + 1:
+            raise _lib.DimensionMismatch("Inconsistent dimentions.")
+        T = fm.shape[1]
+        out = np.empty((D2 // 2 + 1, T), order="F")
+        _lib.check(_lib.lib.vcmi_vc_traj(self._h, _lib.dptr(fm), T, _lib.dptr(out)))
+        return out
