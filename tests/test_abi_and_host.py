@@ -1,0 +1,127 @@
+"""CPU: the C-ABI library loads and exports every symbol include/vcmi.h declares; status/exception mapping;
+host-side logic of the mirror (no compute calls that need a GPU)."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+@pytest.fixture(scope="module")
+def vc():
+    import __graft_entry__ as ge
+    ge.build()
+    import voiceconversion_jl_amd as m
+    return m
+
+
+def _declared():
+    header = open(os.path.join(ROOT, "include", "vcmi.h")).read()
+    return sorted(set(re.findall(r"\b(vcmi_[A-Za-z0-9_]+)\s*\(", header)))
+
+
+def test_every_declared_symbol_is_exported_and_bound(vc):
+    from voiceconversion_jl_amd import _lib
+    names = _declared()
+    assert len(names) >= 30
+    for n in names:
+        assert hasattr(_lib.lib, n), n
+        assert n in _lib.SIGNATURES, f"{n} declared in vcmi.h but not bound in _lib.py"
+    assert set(_lib.SIGNATURES) == set(names)
+    assert b"gfx950" in _lib.lib.vcmi_version()
+
+
+def test_no_device_is_reported_not_crashed(vc):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    assert vc.device_count() == 0
+    with pytest.raises(vc.VCMIError, match="no HIP device"):
+        vc.GMMMap(np.ones(2) / 2, np.zeros((4, 2)), np.stack([np.eye(4)] * 2, axis=2))
+    with pytest.raises(vc.VCMIError):
+        vc.fit_(vc.DTW(), np.zeros((2, 3)), np.zeros((2, 3)))
+
+
+def test_argument_errors_map_to_reference_exceptions(vc):
+    with pytest.raises(vc.DimensionMismatch):
+        vc.GMMMap(np.ones(3), np.zeros((4, 2)), np.zeros((4, 4, 2)))
+    with pytest.raises(vc.DimensionMismatch):
+        vc.align(np.zeros((3, 5)), np.zeros((4, 5)))                        # src/align.jl:11-13
+    with pytest.raises(vc.DimensionMismatch):
+        vc.fit_(vc.DTW(), np.zeros((3, 5)), np.zeros((4, 5)))
+    with pytest.raises(vc.DimensionMismatch):
+        vc.estep_diag(np.zeros((5, 10)), np.ones(2) / 2, np.zeros((4, 2)), np.ones((4, 2)))
+
+
+def test_product_does_not_touch_the_oracle():
+    """The product package must not import, load or link anything under oracle/."""
+    pkg = os.path.join(ROOT, "voiceconversion.jl_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".hpp", ".jl")) or f == "Makefile":
+                text = open(os.path.join(dirpath, f), errors="replace").read()
+                assert "vc_oracle" not in text and "np_oracle" not in text and "c_oracle" not in text, os.path.join(dirpath, f)
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", text, re.M), os.path.join(dirpath, f)
+
+
+def test_push_delta_and_constructW_host_helpers(vc):
+    from oracle import c_oracle as co
+    rng = np.random.default_rng(1)
+    for T in (1, 2, 3, 17):
+        s = rng.standard_normal((T, 5))
+        assert np.array_equal(vc.push_delta(s.T), co.push_delta(s).T)
+    import scipy.sparse as sp
+    r, c, v = co.constructW(4, 6)
+    ref = sp.coo_matrix((v, (r - 1, c - 1)), shape=(48, 24)).tocsc()
+    assert abs(vc.constructW(4, 6) - ref).max() == 0
+    assert vc.constructW(3, 1).nnz == 3
+
+
+def test_dtw_online_update_and_backward_host_logic(vc):
+    """update!/set_template!/backward (src/dtw.jl:53-90,133-145) are host-side in the mirror: check them against
+    the oracle's fit! tables."""
+    from oracle import c_oracle as co
+    rng = np.random.default_rng(2)
+    t = rng.standard_normal((9, 3))
+    s = rng.standard_normal((7, 3))
+    for fs, bs in ((0, 1), (0, 2), (1, 2)):
+        p, c, b = co.dtw_fit(t, s, fs, bs)
+        d = vc.DTW(fstep=fs, bstep=bs)
+        vc.set_template_(d, t.T)
+        assert d.costtable.shape == (9, 1) and d.costtable[:, 0].tolist() == list(range(1, 10))
+        for k in range(7):
+            vc.update_(d, s[k])
+        assert np.array_equal(d.costtable, c.T) and np.array_equal(d.backpointer, b.T)
+        assert np.array_equal(vc.backward(d), p)
+
+
+def test_sharding_helpers(vc):
+    from voiceconversion_jl_amd import dist as vd
+    for n, world in ((10, 3), (1_000_000, 8), (5, 8), (0, 2)):
+        spans = [vd.shard_range(n, r, world) for r in range(world)]
+        assert spans[0][0] == 0 and spans[-1][1] == n
+        assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+        sizes = [hi - lo for lo, hi in spans]
+        assert max(sizes) - min(sizes) <= 1
+    costs = [500 * 500, 100, 450 * 520, 300 * 300, 7, 550 * 550, 480 * 500]
+    parts = vd.shard_by_cost(costs, 3)
+    assert sorted(i for p in parts for i in p) == list(range(len(costs)))
+    loads = [sum(costs[i] for i in p) for p in parts]
+    assert max(loads) <= 1.5 * (sum(costs) / 3)
+    S0, S1, S2 = np.arange(3.), np.arange(12.).reshape(4, 3), -np.arange(12.).reshape(4, 3)
+    packed = vd.pack_stats(S0, S1, S2, 7.5)
+    a0, a1, a2, ll = vc.unpack_stats(packed, 4, 3)
+    assert np.array_equal(a0, S0) and np.array_equal(a1, S1) and np.array_equal(a2, S2) and ll == 7.5
+    assert len(packed) == vc.stats_len(4, 3)
+
+
+def test_mstep_formulas(vc):
+    rng = np.random.default_rng(3)
+    X = rng.standard_normal((500, 4)) * 0.5 + 2.0
+    S0 = np.array([500.0])
+    S1 = X.sum(0)[:, None]
+    S2 = (X * X).sum(0)[:, None]
+    w, mu, var = vc.mstep_diag(S0, S1, S2, min_covar=0.0)
+    assert np.allclose(w, 1.0) and np.allclose(mu[:, 0], X.mean(0)) and np.allclose(var[:, 0], X.var(0), rtol=1e-9)

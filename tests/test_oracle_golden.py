@@ -1,0 +1,114 @@
+"""CPU: the C oracle (oracle/vc_oracle.c) against the committed golden vectors and the reference's own KATs;
+numpy restatement spot checks.  No GPU, no /root/reference."""
+import numpy as np
+import scipy.sparse as sp
+
+from conftest import load_golden, relerr
+from oracle import c_oracle as co
+from oracle import np_oracle as npo
+
+
+def test_dtw_reference_kats():
+    """test/dtw.jl:7-31 of the reference"""
+    v1 = np.array([[1., 2, 3], [1, 2, 4], [1, 8, 5], [10, 3, 6]])
+    v2 = np.array([[1., 2, 3], [1, 2, 4], [1, 2, 5], [1, 8, 5], [10, 3, 6]])
+    assert co.dtw_fit(v1, v2, 0, 1)[0].tolist() == [1, 2, 2, 3, 4]
+    assert npo.dtw_fit(v1, v2, 0, 1)[0].tolist() == [1, 2, 2, 3, 4]
+    a = np.arange(6.)[:, None]
+    b = np.array([0., 0, 1, 2, 3, 4, 4, 5])[:, None]
+    assert co.dtw_fit(a, b, 0, 1)[0].tolist() == [1, 1, 2, 3, 4, 5, 5, 6]
+    assert npo.dtw_fit(a, b, 0, 1)[0].tolist() == [1, 1, 2, 3, 4, 5, 5, 6]
+
+
+def test_dtw_golden_bit_exact():
+    z = load_golden("dtw_cases.npz")
+    names = ["kat0", "kat1"] + [f"r{k}" for k in range(int(z["n_random"]))]
+    for nm in names:
+        fs, bs = (int(x) for x in z[f"{nm}_steps"])
+        p, c, b = co.dtw_fit(z[f"{nm}_tmpl"], z[f"{nm}_seq"], fs, bs)
+        assert np.array_equal(p, z[f"{nm}_path"]) and np.array_equal(c, z[f"{nm}_cost"]) and np.array_equal(b, z[f"{nm}_bp"])
+        assert np.array_equal(co.dtw_fit(z[f"{nm}_tmpl"], z[f"{nm}_seq"], fs, bs, tables=False), z[f"{nm}_path"])
+        if nm.startswith("r"):
+            nt, ap = co.align(z[f"{nm}_tmpl"], z[f"{nm}_seq"])
+            assert np.array_equal(nt, z[f"{nm}_align_newtgt"]) and np.array_equal(ap, z[f"{nm}_align_path"])
+    # one case through the pure-numpy restatement as well
+    p, c, b = npo.dtw_fit(z["r3_tmpl"], z["r3_seq"], *(int(x) for x in z["r3_steps"]))
+    assert np.array_equal(c, z["r3_cost"]) and np.array_equal(b, z["r3_bp"])
+
+
+def test_constructW_pattern():
+    """test/trajectory_gmmmap.jl:1-34 of the reference: constructW(30, 40)"""
+    D, T = 30, 40
+    r, c, v = co.constructW(D, T)
+    W = sp.coo_matrix((v, (r - 1, c - 1)), shape=(2 * D * T, D * T)).toarray()
+    I = np.eye(D)
+    for t in range(T):
+        s = 2 * D * t
+        for i in range(T):
+            blk = W[s:s + D, i * D:(i + 1) * D]
+            assert np.array_equal(blk, I if i == t else np.zeros((D, D)))
+            blk = W[s + D:s + 2 * D, i * D:(i + 1) * D]
+            want = -0.5 * I if i == t - 1 else (0.5 * I if i == t + 1 else np.zeros((D, D)))
+            assert np.array_equal(blk, want)
+    z = load_golden("trajectory_fixture_model.npz")
+    assert np.array_equal(r, z["W_rows"]) and np.array_equal(c, z["W_cols"]) and np.array_equal(v, z["W_vals"])
+    assert abs(npo.constructW(D, T) - sp.csc_matrix(W)).max() == 0
+
+
+def test_gmmmap_fixture_model(fixture_model):
+    w, mu, sig = fixture_model
+    z = load_golden("gmmmap_fixture_model.npz")
+    for swap, k in ((False, "fwd"), (True, "swap")):
+        g = co.GMMMap(w, mu, sig, swap=swap)
+        assert g.D == 40 and g.M == 32                                  # test/gmmmap.jl:9-14
+        assert relerr(g.fvconvert(z[f"X_{k}"]), z[f"Y_{k}"]) < 1e-9
+        assert np.max(np.abs(g.predict_proba(z[f"X_{k}"]) - z[f"P_{k}"])) < 1e-9
+        assert np.array_equal(g.predict(z[f"X_{k}"]), z[f"idx_{k}"])
+    g = co.GMMMap(w, mu, sig)
+    out = g.vc(z["vc_fm"])
+    assert np.array_equal(out[:, 0], z["vc_fm"][:, 0]) and relerr(out[:, 1:], z["vc_out"][:, 1:]) < 1e-9
+    P = g.predict_proba(z["X_fwd"][:8])
+    assert np.allclose(P.sum(axis=1), 1.0, atol=1e-12)
+    # numpy restatement on a few frames
+    gn = npo.GMMMap(w, mu, sig)
+    assert relerr(gn.fvconvert(z["X_fwd"][:5]), z["Y_fwd"][:5]) < 1e-12
+
+
+def test_gmmmap_config1():
+    z = load_golden("gmmmap_cfg1_D24_M8_T1000.npz")
+    g = co.GMMMap(z["weights"], z["means"], z["covars"])
+    assert relerr(g.fvconvert(z["X"]), z["Y"]) < 1e-9
+    assert np.array_equal(g.predict(z["X"]), z["idx"])
+
+
+def test_not_positive_definite_is_reported(fixture_model):
+    w, mu, sig = fixture_model
+    bad = sig.copy()
+    bad[3, :40, :40] = -np.eye(40)
+    try:
+        co.GMMMap(w, mu, bad)
+        assert False, "expected LinAlgError"
+    except np.linalg.LinAlgError:
+        pass
+
+
+def test_trajectory_fixture_model(fixture_model):
+    w, mu, sig = fixture_model
+    z = load_golden("trajectory_fixture_model.npz")
+    assert np.array_equal(co.push_delta(z["static"]), z["X"])
+    assert np.array_equal(npo.push_delta(z["static"]), z["X"])
+    t = co.TrajectoryGMMMap(co.GMMMap(w, mu, sig))
+    Y, mh, Ey = t.fvconvert(z["X"])
+    assert np.array_equal(mh, z["mhat"]) and relerr(Ey, z["Ey"]) < 1e-9 and relerr(Y, z["Y"]) < 1e-6
+    assert relerr(t.vc(z["vc_fm"], 30), z["vc_out_L30"]) < 1e-6
+    # chunk length is part of the contract (src/common.jl:42-57): another chunking gives another answer
+    assert relerr(t.vc(z["vc_fm"], 100)[:, 1:], z["Y"]) < 1e-6
+    assert relerr(t.vc(z["vc_fm"], 30), t.vc(z["vc_fm"], 100)) > 1e-6
+
+
+def test_estep_golden():
+    z = load_golden("estep_diag_N2000_D80_M16.npz")
+    S0, S1, S2, ll = co.estep_diag(z["X"], z["w"], z["mu"], z["var"])
+    assert relerr(S0, z["S0"]) < 1e-10 and relerr(S1, z["S1"]) < 1e-10 and relerr(S2, z["S2"]) < 1e-10
+    assert abs(ll - float(z["loglik"])) < 1e-10 * abs(float(z["loglik"]))
+    assert abs(S0.sum() - 2000) < 1e-8

@@ -12,3 +12,4 @@ from .dtw import DTW, backward, fit_, fit_batch, set_template_, update_  # noqa:
 from .align import align, align_batch  # noqa: F401,E402
 from .estep import estep_diag, estep_diag_allreduce, estep_diag_dev, mstep_diag, stats_len, unpack_stats  # noqa: F401,E402
 from .trajectory_gmmmap import TrajectoryGMMMap, constructW, push_delta  # noqa: F401,E402
+from . import dist  # noqa: F401,E402

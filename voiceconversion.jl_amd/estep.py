@@ -71,12 +71,9 @@ def estep_diag(X, w, mu, var):
 def estep_diag_allreduce(X_shard, w, mu, var, group=None):
     """Multi-GPU E-step: local statistics of this rank's frame shard, then one all-reduce(sum) of the packed
     M(1+2Dj)+1 doubles (RCCL when the group's backend is "nccl").  Returns the packed global statistics."""
-    import torch.distributed as dist
+    from .dist import allreduce_sum_
 
-    st = estep_diag_dev(X_shard, w, mu, var)
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(st, op=dist.ReduceOp.SUM, group=group)
-    return st
+    return allreduce_sum_(estep_diag_dev(X_shard, w, mu, var), group)
 
 
 def mstep_diag(S0, S1, S2, min_covar=1e-7):
