@@ -162,20 +162,197 @@ def bench_convert(args, world, rank):
     return out
 
 
+# --------------------------------------------------------------------------------------------- E-step
+def bench_estep(args, world, rank):
+    """BASELINE configs[2]: diagonal E-step, Dj=80, M=128, N=10^7 frames over 8 GPUs -> 1.25e6 frames per GPU
+    (weak scaling), followed by ONE all-reduce of the packed statistics over RCCL."""
+    import torch
+
+    import voiceconversion_jl_amd as vc
+    from oracle import np_oracle as npo
+
+    Dj, M, N = 80, 128, args.frames if args.frames != 1_000_000 else 1_250_000
+    w, mu, _ = npo.synth_model(1003, Dj, M)
+    rg = np.random.default_rng(1003 + rank)
+    var = np.exp(rg.uniform(np.log(1e-3), 0.0, (M, Dj)))
+    comp = rg.choice(M, size=N, p=w)
+    X = mu[comp] + rg.standard_normal((N, Dj)) * np.sqrt(var[comp])
+    Xd = torch.from_numpy(X).cuda()
+    out_t = torch.empty(vc.stats_len(Dj, M), dtype=torch.float64, device="cuda")
+    muT, varT = np.asfortranarray(mu.T), np.asfortranarray(var.T)
+
+    def step():
+        vc.estep_diag_dev(Xd.t(), w, muT, varT, out=out_t)
+        vc.dist.allreduce_sum_(out_t)
+
+    wall, kernel_ms = timed_steps(step, args.steps, args.warmup, world)
+    fps = world * N * args.steps / wall
+    achieved = estep_flops_per_frame(Dj, M) * N / (kernel_ms * 1e-3) / 1e12
+    out = {"metric": "diag-GMM E-step frames/sec (Dj=80, M=128)", "value": fps, "unit": "frames/s", "n_gpus": world,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+           "config": {"workload": "diag E-step (BASELINE configs[2])", "Dj": Dj, "M": M, "frames_per_gpu": N,
+                      "collective": "all-reduce(sum) of %d doubles per step" % vc.stats_len(Dj, M)},
+           "roofline": {"bound": "mfma", "kernel": "estep_mfma_kernel<80> (+ all-reduce)", "achieved": achieved,
+                        "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS, "traffic": None,
+                        "flop_per_frame": estep_flops_per_frame(Dj, M), "kernel_ms": kernel_ms}}
+    if rank == 0:
+        from oracle import c_oracle as co
+
+        n = 20000
+        t0 = time.perf_counter()
+        r0, r1, r2, rl = co.estep_diag(X[:n], w, mu, var)
+        dt = time.perf_counter() - t0
+        S0, S1, S2, ll = vc.estep_diag(X[:n].T, w, muT, varT)
+        out["cpu_baseline"] = {"value": n / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+                               "sample": f"first {n} frames, C oracle, {dt:.1f} s on 1 of {os.cpu_count()} host cores"}
+        out["parity_max_rel_err_vs_oracle"] = float(np.max(np.abs(S1 - r1.T)) / np.max(np.abs(r1)))
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ DTW
+def _dtw_pairs(seed, n, D):
+    rng = np.random.default_rng(seed)
+    pairs = []
+    for _ in range(n):
+        S, T = int(rng.integers(450, 551)), int(rng.integers(450, 551))
+        t = rng.standard_normal((S, D))
+        idx = np.clip(np.sort(rng.integers(0, S, T)), 0, S - 1)
+        pairs.append((t, t[idx] + 0.2 * rng.standard_normal((T, D))))
+    return pairs
+
+
+def bench_dtw(args, world, rank):
+    """BASELINE configs[3]: DTW alignment of ~500x500-frame pairs, D=40, bstep=2/fstep=0 (what align uses);
+    `--pairs` pairs per GPU (weak scaling, pairs independent, no collective); path-only mode, device-resident."""
+    import ctypes as C
+
+    import torch
+
+    import voiceconversion_jl_amd as vc
+    from voiceconversion_jl_amd import _lib
+
+    D, n = 40, args.pairs
+    pairs = _dtw_pairs(1004 + rank, n, D)
+    feats, toff, soff, poff, S, T = [], [], [], [], [], []
+    fo = po = 0
+    for t, s in pairs:
+        toff.append(fo); feats.append(t.ravel()); fo += t.size
+        soff.append(fo); feats.append(s.ravel()); fo += s.size
+        poff.append(po); po += s.shape[0]
+        S.append(t.shape[0]); T.append(s.shape[0])
+    fd = torch.from_numpy(np.concatenate(feats)).cuda()
+    pd = torch.empty(po, dtype=torch.int64, device="cuda")
+    arr = lambda a: np.asarray(a, dtype=np.int64)  # noqa: E731
+    toff, soff, poff, S, T = arr(toff), arr(soff), arr(poff), arr(S), arr(T)
+
+    def step():
+        _lib.check(_lib.lib.vcmi_dtw_fit_batch_dev(n, fd.data_ptr(), _lib.iptr(toff), _lib.iptr(S), _lib.iptr(soff), _lib.iptr(T),
+                                                   D, 0, 2, pd.data_ptr(), _lib.iptr(poff), torch.cuda.current_stream().cuda_stream))
+
+    wall, kernel_ms = timed_steps(step, args.steps, args.warmup, world)
+    cells = float(np.sum(S * T))
+    flops = cells * (3 * D + 10)
+    achieved = flops / (kernel_ms * 1e-3) / 1e12
+    out = {"metric": "DTW aligned pairs/sec (~500x500 frames, D=40)", "value": world * n * args.steps / wall, "unit": "pairs/s",
+           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+           "config": {"workload": "DTW fit!+backward, path-only (BASELINE configs[3])", "D": D, "pairs_per_gpu": n,
+                      "fstep": 0, "bstep": 2},
+           "roofline": {"bound": "mfma", "kernel": "dtw_kernel<40,2,true>", "achieved": achieved, "peak": FP64_PEAK_TFLOPS,
+                        "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS, "traffic": None,
+                        "note": "FP64 VALU work (unfused sub/mul/add, bit-exact contract) priced against the FP64 roof; "
+                                "the T-step column dependency chain is the real limiter",
+                        "cells_per_s": cells / (kernel_ms * 1e-3), "kernel_ms": kernel_ms}}
+    if rank == 0:
+        from oracle import c_oracle as co
+
+        k = min(n, 40)
+        t0 = time.perf_counter()
+        refs = [co.dtw_fit(t, s, 0, 2, tables=False) for t, s in pairs[:k]]
+        dt = time.perf_counter() - t0
+        got = pd.cpu().numpy()
+        ok = all(np.array_equal(got[poff[i]:poff[i] + T[i]], refs[i]) for i in range(k))
+        out["cpu_baseline"] = {"value": k / dt, "unit": "pairs/s", "cores": 1, "kind": "port",
+                               "sample": f"first {k} pairs, C oracle, {dt:.1f} s on 1 of {os.cpu_count()} host cores"}
+        out["parity_bit_exact_vs_oracle"] = bool(ok)
+    return out
+
+
+# ----------------------------------------------------------------------------------------- trajectory
+def bench_traj(args, world, rank):
+    """BASELINE configs[4]: TrajectoryGMMMap, static D=40 (X dim 80), M=64, T=2000 per utterance, `--utts`
+    utterances per GPU (weak scaling, utterance-parallel, no collective); device-resident."""
+    import torch
+
+    import voiceconversion_jl_amd as vc
+    from oracle import np_oracle as npo
+    from voiceconversion_jl_amd import _lib
+
+    D, M, T, n = 40, 64, 2000, args.utts
+    w, mu, sig = npo.synth_model(1005, 4 * D, M, lam_lo=1e-3)
+    g = vc.GMMMap(*julia_model(w, mu, sig))
+    tj = vc.TrajectoryGMMMap(g, T)
+    rng = np.random.default_rng(1005 + rank)
+    base = []
+    for _ in range(min(n, 8)):
+        st = npo.sample_frames(int(rng.integers(1 << 30)), w, mu, sig, T, 0, D)
+        st = np.cumsum(st, axis=0) / np.sqrt(np.arange(1, T + 1))[:, None]
+        base.append(npo.push_delta(st))
+    X = np.concatenate([base[i % len(base)] for i in range(n)])                  # (n*T, 2D)
+    Xd = torch.from_numpy(X).cuda()
+    Yd = torch.empty((n * T, D), dtype=torch.float64, device="cuda")
+    xoff = np.arange(n, dtype=np.int64) * T * 2 * D
+    yoff = np.arange(n, dtype=np.int64) * T * D
+    Ts = np.full(n, T, dtype=np.int64)
+
+    def step():
+        _lib.check(_lib.lib.vcmi_traj_convert_batch_dev(tj._h, n, Xd.data_ptr(), _lib.iptr(xoff), _lib.iptr(Ts), Yd.data_ptr(),
+                                                        _lib.iptr(yoff), torch.cuda.current_stream().cuda_stream))
+
+    wall, kernel_ms = timed_steps(step, args.steps, args.warmup, world)
+    flops_per_utt = 2.0e9
+    achieved = flops_per_utt * n / (kernel_ms * 1e-3) / 1e12
+    out = {"metric": "trajectory-converted frames/sec (static D=40, M=64, T=2000)", "value": world * n * T * args.steps / wall,
+           "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "f64", "data": "synthetic",
+           "config": {"workload": "TrajectoryGMMMap fvconvert (BASELINE configs[4])", "static_D": D, "M": M, "T": T,
+                      "utterances_per_gpu": n},
+           "roofline": {"bound": "mfma", "kernel": "predict + traj_g_kernel + traj_solve_kernel", "achieved": achieved,
+                        "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS, "traffic": None,
+                        "flop_per_utterance": flops_per_utt, "kernel_ms": kernel_ms,
+                        "note": "whole pipeline (3 kernels); the banded solve is a 2000-step sequential block recurrence"}}
+    if rank == 0:
+        from oracle import c_oracle as co
+
+        ref = co.TrajectoryGMMMap(co.GMMMap(w, mu, sig))
+        t0 = time.perf_counter()
+        Yref, _, _ = ref.fvconvert(base[0])
+        dt = time.perf_counter() - t0
+        err = float(np.max(np.abs(Yd[:T].cpu().numpy() - Yref)) / np.max(np.abs(Yref)))
+        out["cpu_baseline"] = {"value": T / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+                               "sample": f"1 utterance of {T} frames, C oracle, {dt:.1f} s on 1 of {os.cpu_count()} host cores"}
+        out["parity_max_rel_err_vs_oracle"] = err
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="convert", choices=["convert"])
+    ap.add_argument("--workload", default="convert", choices=["convert", "estep", "dtw", "traj"])
     ap.add_argument("--frames", type=int, default=1_000_000, help="frames per GPU (BASELINE: 10^6)")
+    ap.add_argument("--pairs", type=int, default=1000, help="DTW pairs per GPU")
+    ap.add_argument("--utts", type=int, default=256, help="trajectory utterances per GPU")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU time budget of the cpu_baseline sample")
     args = ap.parse_args()
 
     world, rank, _ = dist_setup(args.gpus)
     if world != args.gpus and rank == 0:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
-    out = {"convert": bench_convert}[args.workload](args, world, rank)
+    out = {"convert": bench_convert, "estep": bench_estep, "dtw": bench_dtw, "traj": bench_traj}[args.workload](args, world, rank)
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

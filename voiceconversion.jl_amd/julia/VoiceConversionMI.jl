@@ -1,0 +1,243 @@
+# VoiceConversionMI.jl -- drop-in Julia host side for the MI355X hot path of VoiceConversion.jl.
+#
+# Thin, logic-free `ccall` wrapper over libvcmi.so (include/vcmi.h).  It keeps the reference's exported names
+# and signatures (reference src/VoiceConversion.jl:12-38, src/dtw.jl:7) for the hot path:
+#   GMMMap, fvconvert, vc, dim, ncomponents, TrajectoryGMMMap, DTW, fit!, update!, set_template!, backward,
+#   align, push_delta
+# and adds the batch methods the reference lacks (fvconvert(g, X::Matrix), fit!(d, templates, sequences),
+# align(srcs, tgts), estep_diag).
+#
+# NOTE: no Julia binary exists in the build image or on the GPU box, so this file has never been executed; it
+# is kept mechanical on purpose -- every method is one ccall plus the status check.  The identical ABI is
+# exercised from Python ctypes (voiceconversion.jl_amd/_lib.py) by the parity tests.
+# Written for Julia >= 1.0; for the reference's Julia 0.5 replace `mutable struct` by `type`,
+# `finalizer(f, obj)` by `finalizer(obj, f)` and `Cvoid` by `Void`.
+module VoiceConversionMI
+
+export GMMMap, TrajectoryGMMMap, fvconvert, vc, dim, ncomponents,
+       DTW, fit!, update!, set_template!, backward, align, push_delta,
+       predict_proba, predict, estep_diag
+
+const libvcmi = get(ENV, "LIBVCMI", "libvcmi")
+
+# vcmi_status -> the exception the reference would have thrown
+function check(status::Cint)
+    status == 0 && return
+    msg = unsafe_string(ccall((:vcmi_last_error, libvcmi), Cstring, ()))
+    status == 1 && throw(DimensionMismatch(msg))                       # src/gmmmap.jl:102
+    status == 2 && throw(LinearAlgebra.PosDefException(0))             # MvNormal in src/gmm.jl:17
+    error("libvcmi status $status: $msg")
+end
+import LinearAlgebra
+
+abstract type AbstractConverter end                                    # src/common.jl:2-4
+abstract type FrameByFrameConverter <: AbstractConverter end
+abstract type TrajectoryConverter <: AbstractConverter end
+
+# ---------------------------------------------------------------------------------------------- GMMMap
+mutable struct GMMMap <: FrameByFrameConverter                        # src/gmmmap.jl:57
+    h::Ptr{Cvoid}
+    function GMMMap(weights::Vector{Float64}, μ::Matrix{Float64}, Σ::Array{Float64,3}; swap::Bool=false)
+        h = Ref{Ptr{Cvoid}}(C_NULL)
+        check(ccall((:vcmi_gmmmap_create, libvcmi), Cint,
+                    (Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Cint, Cint, Cint, Ref{Ptr{Cvoid}}),
+                    weights, μ, Σ, size(μ, 1), length(weights), swap ? 1 : 0, h))
+        g = new(h[])
+        finalizer(x -> ccall((:vcmi_gmmmap_destroy, libvcmi), Cint, (Ptr{Cvoid},), x.h), g)
+        g
+    end
+end
+
+Base.length(g::GMMMap) = 1                                             # src/gmmmap.jl:93
+dim(g::GMMMap) = Int(ccall((:vcmi_gmmmap_dim, libvcmi), Cint, (Ptr{Cvoid},), g.h))
+ncomponents(g::GMMMap) = Int(ccall((:vcmi_gmmmap_ncomponents, libvcmi), Cint, (Ptr{Cvoid},), g.h))
+Base.size(g::GMMMap) = (dim(g), length(g))
+
+# fvconvert(g, x) -- src/gmmmap.jl:101-118
+function fvconvert(g::GMMMap, x::Vector{Float64})
+    y = Vector{Float64}(undef, dim(g))
+    length(x) == dim(g) || throw(DimensionMismatch("Inconsistent dimentions."))
+    check(ccall((:vcmi_gmmmap_convert, libvcmi), Cint,
+                (Ptr{Cvoid}, Ptr{Float64}, Int64, Int64, Ptr{Float64}, Int64), g.h, x, dim(g), 1, y, dim(g)))
+    y
+end
+
+# batch method: every column of X in one launch
+function fvconvert(g::GMMMap, X::Matrix{Float64})
+    size(X, 1) == dim(g) || throw(DimensionMismatch("Inconsistent dimentions."))
+    Y = similar(X)
+    check(ccall((:vcmi_gmmmap_convert, libvcmi), Cint,
+                (Ptr{Cvoid}, Ptr{Float64}, Int64, Int64, Ptr{Float64}, Int64),
+                g.h, X, size(X, 1), size(X, 2), Y, size(Y, 1)))
+    Y
+end
+
+# vc(c::FrameByFrameConverter, fm) -- src/common.jl:7-26 (row 1 = power, kept)
+function vc(g::GMMMap, fm::Matrix{Float64})
+    size(fm, 1) == dim(g) + 1 || throw(DimensionMismatch("Inconsistent dimentions."))
+    out = similar(fm)
+    check(ccall((:vcmi_vc_frames, libvcmi), Cint, (Ptr{Cvoid}, Ptr{Float64}, Int64, Ptr{Float64}),
+                g.h, fm, size(fm, 2), out))
+    out
+end
+
+# predict_proba / predict on g.px -- src/gmm.jl:24-58 (here methods of the mapper itself)
+function predict_proba(g::GMMMap, X::Matrix{Float64})
+    P = Matrix{Float64}(undef, ncomponents(g), size(X, 2))
+    check(ccall((:vcmi_gmmmap_posterior, libvcmi), Cint, (Ptr{Cvoid}, Ptr{Float64}, Int64, Int64, Ptr{Float64}),
+                g.h, X, size(X, 1), size(X, 2), P))
+    P
+end
+function predict(g::GMMMap, X::Matrix{Float64})
+    idx = Vector{Int64}(undef, size(X, 2))
+    check(ccall((:vcmi_gmmmap_predict, libvcmi), Cint, (Ptr{Cvoid}, Ptr{Float64}, Int64, Int64, Ptr{Int64}),
+                g.h, X, size(X, 1), size(X, 2), idx))
+    idx
+end
+
+# ---------------------------------------------------------------------------------- TrajectoryGMMMap
+mutable struct TrajectoryGMMMap <: TrajectoryConverter                 # src/trajectory_gmmmap.jl:3
+    gmmmap::GMMMap
+    h::Ptr{Cvoid}
+    function TrajectoryGMMMap(g::GMMMap, T::Int)
+        h = Ref{Ptr{Cvoid}}(C_NULL)
+        check(ccall((:vcmi_traj_create, libvcmi), Cint, (Ptr{Cvoid}, Int64, Ref{Ptr{Cvoid}}), g.h, T, h))
+        t = new(g, h[])
+        finalizer(x -> ccall((:vcmi_traj_destroy, libvcmi), Cint, (Ptr{Cvoid},), x.h), t)
+        t
+    end
+end
+Base.length(t::TrajectoryGMMMap) = Int(ccall((:vcmi_traj_length, libvcmi), Int64, (Ptr{Cvoid},), t.h))
+dim(t::TrajectoryGMMMap) = dim(t.gmmmap)
+ncomponents(t::TrajectoryGMMMap) = ncomponents(t.gmmmap)
+Base.size(t::TrajectoryGMMMap) = (dim(t), length(t))
+
+# fvconvert(tgmm, X) -- src/trajectory_gmmmap.jl:65-110
+function fvconvert(t::TrajectoryGMMMap, X::Matrix{Float64})
+    size(X, 1) == dim(t) || throw(DimensionMismatch("Inconsistent dimentions."))
+    Y = Matrix{Float64}(undef, size(X, 1) >> 1, size(X, 2))
+    check(ccall((:vcmi_traj_convert, libvcmi), Cint, (Ptr{Cvoid}, Ptr{Float64}, Int64, Ptr{Float64}),
+                t.h, X, size(X, 2), Y))
+    Y
+end
+
+# vc(c::TrajectoryConverter, fm) -- src/common.jl:31-63
+function vc(t::TrajectoryGMMMap, fm::Matrix{Float64})
+    out = Matrix{Float64}(undef, (size(fm, 1) - 1) >> 1 + 1, size(fm, 2))
+    check(ccall((:vcmi_vc_traj, libvcmi), Cint, (Ptr{Cvoid}, Ptr{Float64}, Int64, Ptr{Float64}),
+                t.h, fm, size(fm, 2), out))
+    out
+end
+
+function push_delta(src::Matrix{Float64})                              # src/datasets.jl:6-13
+    out = Matrix{Float64}(undef, 2size(src, 1), size(src, 2))
+    check(ccall((:vcmi_push_delta, libvcmi), Cint, (Ptr{Float64}, Cint, Int64, Ptr{Float64}),
+                src, size(src, 1), size(src, 2), out))
+    out
+end
+
+# ------------------------------------------------------------------------------------------------ DTW
+mutable struct DTW                                                     # src/dtw.jl:11-17
+    fstep::Int
+    bstep::Int
+    template::Matrix{Float64}
+    costtable::Matrix{Float64}
+    backpointer::Matrix{Int}
+end
+DTW(; fstep=0, bstep=1) = DTW(fstep, bstep, zeros(1, 1), zeros(1, 1), zeros(Int, 1, 1))   # src/dtw.jl:19-21
+
+# fit!(d, template, sequence) -- src/dtw.jl:93-128 (+ backward :133-145); fills d.costtable / d.backpointer
+function fit!(d::DTW, template::Matrix{Float64}, sequence::Matrix{Float64})
+    S, T = size(template, 2), size(sequence, 2)
+    size(template, 1) == size(sequence, 1) || throw(DimensionMismatch("feature dimension"))
+    d.template = template
+    d.costtable = Matrix{Float64}(undef, S, T + 1)
+    d.backpointer = Matrix{Int}(undef, S, T + 1)
+    path = Vector{Int}(undef, T)
+    check(ccall((:vcmi_dtw_fit, libvcmi), Cint,
+                (Ptr{Float64}, Int64, Ptr{Float64}, Int64, Cint, Cint, Cint, Ptr{Int64}, Ptr{Float64}, Ptr{Int64}),
+                template, S, sequence, T, size(template, 1), d.fstep, d.bstep, path, d.costtable, d.backpointer))
+    path
+end
+fit!(d::DTW, sequence::Matrix{Float64}) = fit!(d, d.template, sequence)               # src/dtw.jl:130
+
+# batch method: n pairs, one workgroup each, path-only
+function fit!(d::DTW, templates::Vector{Matrix{Float64}}, sequences::Vector{Matrix{Float64}})
+    n = length(templates)
+    S = Int64[size(t, 2) for t in templates]; T = Int64[size(s, 2) for s in sequences]
+    paths = [Vector{Int}(undef, t) for t in T]
+    GC.@preserve templates sequences paths begin
+        check(ccall((:vcmi_dtw_fit_batch, libvcmi), Cint,
+                    (Int64, Ptr{Ptr{Float64}}, Ptr{Int64}, Ptr{Ptr{Float64}}, Ptr{Int64}, Cint, Cint, Cint, Ptr{Ptr{Int64}}),
+                    n, pointer.(templates), S, pointer.(sequences), T, size(templates[1], 1), d.fstep, d.bstep,
+                    pointer.(paths)))
+    end
+    paths
+end
+
+function set_template!(d::DTW, template::Matrix{Float64})              # src/dtw.jl:38-42,53-56
+    d.template = template
+    S = size(template, 2)
+    d.costtable = reshape(collect(1.0:S), S, 1)
+    d.backpointer = reshape(collect(1:S), S, 1)
+end
+
+# update!(d, v): one on-line column -- src/dtw.jl:61-90; stays on the host (one S-cell column is not GPU work)
+function update!(d::DTW, v::AbstractVector)
+    S, T = size(d.costtable)
+    last = d.costtable[:, T]
+    cur = zeros(S); curbp = zeros(Int, S)
+    for i = 1:S
+        obs = 0.0
+        for k = 1:length(v)
+            obs += (v[k] - d.template[k, i])^2
+        end
+        minindex = i
+        mincost = last[i] + obs + 1.0
+        for j = i-d.bstep:i+d.fstep
+            (j < 1 || j > S) && continue
+            c = last[j] + obs + (i == j + 1 ? 0.0 : (i == j ? 1.0 : 2.0))
+            if c < mincost
+                mincost, minindex = c, j
+            end
+        end
+        cur[i] = mincost; curbp[i] = minindex
+    end
+    d.costtable = [d.costtable cur]
+    d.backpointer = [d.backpointer curbp]
+end
+
+function backward(d::DTW)                                              # src/dtw.jl:133-145
+    T = size(d.costtable, 2) - 1
+    minpath = zeros(Int, T)
+    minpath[end] = argmin(d.costtable[:, T+1])
+    for i = reverse(2:T)
+        minpath[i-1] = d.backpointer[minpath[i], i+1]
+    end
+    minpath
+end
+
+# align(src, tgt) -- src/align.jl:8-35
+function align(src::Matrix{Float64}, tgt::Matrix{Float64})
+    size(src, 1) == size(tgt, 1) || throw(DimensionMismatch("order of feature vector must be equal"))
+    newtgt = similar(src)
+    check(ccall((:vcmi_align, libvcmi), Cint,
+                (Ptr{Float64}, Int64, Ptr{Float64}, Int64, Cint, Ptr{Float64}, Ptr{Int64}),
+                src, size(src, 2), tgt, size(tgt, 2), size(src, 1), newtgt, C_NULL))
+    src, newtgt
+end
+
+# ---------------------------------------------------------------------------------------------- E-step
+# sufficient statistics of a diagonal GMM on joint features X (Dj,N); replaces the E-step inside
+# `gmm[:fit](dataset.X')` of bin/train_gmm.jl:103
+function estep_diag(X::Matrix{Float64}, w::Vector{Float64}, μ::Matrix{Float64}, σ²::Matrix{Float64})
+    Dj, M = size(μ)
+    S0 = Vector{Float64}(undef, M); S1 = similar(μ); S2 = similar(μ); ll = Ref{Float64}(0.0)
+    check(ccall((:vcmi_estep_diag, libvcmi), Cint,
+                (Ptr{Float64}, Int64, Cint, Cint, Ptr{Float64}, Ptr{Float64}, Ptr{Float64},
+                 Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ref{Float64}),
+                X, size(X, 2), Dj, M, w, μ, σ², S0, S1, S2, ll))
+    S0, S1, S2, ll[]
+end
+
+end # module
