@@ -25,6 +25,7 @@
 #include "gmmmap_handle.hpp"
 
 #include <cmath>
+#include <cstdlib>
 #include <limits>
 
 namespace vcmi {
@@ -49,7 +50,7 @@ struct Tiling {
   // per-mixture block in doubles: [fragments NSTEPS*64 | cinit NT*16 | lc | pad], multiple of 32 doubles
   static constexpr int CINIT_OFF = NSTEPS * 64;
   static constexpr int LC_OFF = CINIT_OFF + NT * 16;
-  static constexpr int BLK = ((LC_OFF + 1 + 31) / 32) * 32;
+  static constexpr int BLK = ((LC_OFF + 1 + 1023) / 1024) * 1024;   // whole double2 per thread for 256- and 512-thread groups
 };
 
 // runtime mirror used by the host-side packer (same formulas, any DP)
@@ -63,7 +64,7 @@ struct TilingRT {
     for (int t = 0; t < NT; ++t) NSTEPS += steps(t);
     CINIT_OFF = NSTEPS * 64;
     LC_OFF = CINIT_OFF + NT * 16;
-    BLK = ((LC_OFF + 1 + 31) / 32) * 32;
+    BLK = ((LC_OFF + 1 + 1023) / 1024) * 1024;
   }
   int steps(int t) const { return (16 * t + 15 < DP) ? std::min(4 * (t + 1), KS) : KS; }
 };
@@ -79,13 +80,14 @@ __device__ __forceinline__ double vc_exp(double x) { return exp(x); }
 // MODE 0: convert (writes Y).  MODE 1: log-weighted densities l_m (writes LP (M,T)), no A tiles used.
 // ------------------------------------------------------------------------------------------------
 template <int DP, int FT, int WAVES, int MODE, int NBUF>
-__global__ void __launch_bounds__(WAVES * 64)
+__global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(DP <= 40 ? (FT == 2 ? 3 : 4) : 2)))
 gmmmap_mfma_kernel(const double *__restrict__ packed, int M, int D, const double *__restrict__ X, int64_t ldx,
                    int64_t T, double *__restrict__ Y, int64_t ldy) {
   using TL = Tiling<DP>;
   constexpr int KS = TL::KS, NT = TL::NT, NU = TL::NU, BLK = TL::BLK;
   constexpr int NTHREADS = WAVES * 64;
-  constexpr int NV = (BLK / 2 + NTHREADS - 1) / NTHREADS;   // double2 copies per thread per block
+  constexpr int NV = BLK / 2 / NTHREADS;   // double2 copies per thread per block (BLK is a multiple of 1024)
+  static_assert(BLK % (2 * NTHREADS) == 0, "block size must be a whole number of double2 per thread");
   extern __shared__ double smem[];                          // NBUF * BLK doubles
 
   const int tid = threadIdx.x;
@@ -124,7 +126,7 @@ gmmmap_mfma_kernel(const double *__restrict__ packed, int M, int D, const double
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int e = tid + i * NTHREADS;
-      if (e < BLK / 2) dst[e] = src[e];
+      dst[e] = src[e];
     }
   }
   __syncthreads();
@@ -133,15 +135,14 @@ gmmmap_mfma_kernel(const double *__restrict__ packed, int M, int D, const double
     const double *cur = smem + (NBUF == 2 ? (m & 1) * BLK : 0);
     double2 *nxt = reinterpret_cast<double2 *>(smem + (NBUF == 2 ? ((m + 1) & 1) * BLK : 0));
     // prefetch block m+1 into registers (global -> VGPR), written to LDS after the MFMA work
+    // (unconditional: the last iteration re-reads its own block, which keeps `pre` in registers and the loop
+    // body free of exec-mask branches)
     double2 pre[NV];
-    const bool more = (m + 1 < M);
-    if (more) {
-      const double2 *src = reinterpret_cast<const double2 *>(packed + (size_t)(m + 1) * BLK);
+    {
+      const int mn = (m + 1 < M) ? m + 1 : m;
+      const double2 *src = reinterpret_cast<const double2 *>(packed + (size_t)mn * BLK);
 #pragma unroll
-      for (int i = 0; i < NV; ++i) {
-        const int e = tid + i * NTHREADS;
-        if (e < BLK / 2) pre[i] = src[e];
-      }
+      for (int i = 0; i < NV; ++i) pre[i] = src[tid + i * NTHREADS];
     }
 
     const double lc = cur[TL::LC_OFF];
@@ -219,11 +220,19 @@ gmmmap_mfma_kernel(const double *__restrict__ packed, int M, int D, const double
 #pragma unroll
         for (int f = 0; f < FT; ++f) {
           const double l = lc - 0.5 * q[f];
-          const double nm = fmax(runmax[f], l);
-          const double sc = vc_exp(runmax[f] - nm);
-          const double wg = vc_exp(l - nm);
-          den[f] = fma(den[f], sc, wg);
-          runmax[f] = nm;
+#ifndef VCMI_LAZY
+#define VCMI_LAZY 1
+#endif
+          if (!VCMI_LAZY || __builtin_amdgcn_ballot_w64(l > runmax[f]) != 0) {   // wave-uniform: some frame has a new maximum
+            const double nm = fmax(runmax[f], l);
+            const double sc = vc_exp(runmax[f] - nm);
+            den[f] *= sc;
+            runmax[f] = nm;
+#pragma unroll
+            for (int j = 0; j < KS; ++j) yacc[f][j] *= sc;
+          }
+          const double wg = vc_exp(l - runmax[f]);
+          den[f] += wg;
 #pragma unroll
           for (int t = NU - 1; t < NT; ++t) {
 #pragma unroll
@@ -231,7 +240,7 @@ gmmmap_mfma_kernel(const double *__restrict__ packed, int M, int D, const double
               const int p0 = 16 * t + 4 * r;
               if (p0 >= DP && p0 < 2 * DP) {
                 const int j = (p0 - DP) / 4;
-                yacc[f][j] = fma(wg, acc[f][t][r], yacc[f][j] * sc);
+                yacc[f][j] = fma(wg, acc[f][t][r], yacc[f][j]);
               }
             }
           }
@@ -248,13 +257,8 @@ gmmmap_mfma_kernel(const double *__restrict__ packed, int M, int D, const double
     }
 
     if (NBUF == 1) __syncthreads();   // single buffer: everyone is done reading before it is overwritten
-    if (more) {
 #pragma unroll
-      for (int i = 0; i < NV; ++i) {
-        const int e = tid + i * NTHREADS;
-        if (e < BLK / 2) nxt[e] = pre[i];
-      }
-    }
+    for (int i = 0; i < NV; ++i) nxt[tid + i * NTHREADS] = pre[i];
     __syncthreads();
   }
 
@@ -358,11 +362,11 @@ posterior_finish_kernel(double *__restrict__ LP, int M, int64_t T, int64_t *__re
 // ------------------------------------------------------------------------------------------------
 // launch helpers
 // ------------------------------------------------------------------------------------------------
-template <int DP, int MODE>
+template <int DP, int MODE, int FTV, int WV>
 static int launch_mfma(const vcmi_gmmmap *g, const double *dX, int64_t ldx, int64_t T, double *dY, int64_t ldy,
                        hipStream_t st) {
-  constexpr int FT = (DP <= 48) ? 2 : 1;
-  constexpr int WAVES = 4;
+  constexpr int FT = FTV;
+  constexpr int WAVES = WV;
   using TL = Tiling<DP>;
   // double-buffer the per-mixture block when two copies fit in half of the CU's 160 KiB LDS
   constexpr int NBUF = (2 * (size_t)TL::BLK * sizeof(double) <= 80 * 1024) ? 2 : 1;
@@ -385,9 +389,15 @@ static int launch_mfma(const vcmi_gmmmap *g, const double *dX, int64_t ldx, int6
 template <int MODE>
 static int dispatch_mfma(const vcmi_gmmmap *g, const double *dX, int64_t ldx, int64_t T, double *dY, int64_t ldy,
                          hipStream_t st) {
+  if (g->DP == 40 && MODE == 0) {   // tuning variants (VCMI_VARIANT), experiments only
+    static const int variant = getenv("VCMI_VARIANT") ? atoi(getenv("VCMI_VARIANT")) : 0;
+    if (variant == 1) return launch_mfma<40, 0, 1, 4>(g, dX, ldx, T, dY, ldy, st);
+    if (variant == 2) return launch_mfma<40, 0, 1, 8>(g, dX, ldx, T, dY, ldy, st);
+    if (variant == 3) return launch_mfma<40, 0, 2, 8>(g, dX, ldx, T, dY, ldy, st);
+  }
   switch (g->DP) {
 #define VCMI_CASE(DPV) \
-  case DPV: return launch_mfma<DPV, MODE>(g, dX, ldx, T, dY, ldy, st);
+  case DPV: return launch_mfma<DPV, MODE, ((DPV) <= 48 ? 2 : 1), 4>(g, dX, ldx, T, dY, ldy, st);
     VCMI_CASE(16) VCMI_CASE(20) VCMI_CASE(24) VCMI_CASE(28) VCMI_CASE(32) VCMI_CASE(40) VCMI_CASE(48) VCMI_CASE(64)
     VCMI_CASE(80)
 #undef VCMI_CASE
