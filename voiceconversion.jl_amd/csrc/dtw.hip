@@ -24,13 +24,15 @@
 namespace vcmi {
 
 struct DtwPair {
-  const double *tmpl;   // (D,S)
-  const double *seq;    // (D,T)
+  int64_t tmpl_off;     // template (D,S) at feats + tmpl_off
+  int64_t seq_off;      // sequence (D,T) at feats + seq_off
   int64_t *path;        // (T) 1-based, may be null when only newtgt is wanted
   double *cost;         // (S,T+1) or null
   int64_t *bp;          // (S,T+1) or null
   double *newtgt;       // (D,S) or null: align() output
   unsigned char *codes; // (S,T) bytes in HBM, used only when the step codes do not fit in LDS
+  double *obs;          // (S,T) observation costs (fast path workspace)
+  int64_t spad_off;     // offset of the zero-padded sequence copy (fast path, D != DMAX)
   int32_t S, T;
 };
 
@@ -40,7 +42,7 @@ __device__ __forceinline__ double dtw_transition(int j, int i) {   // transition
 
 // shared epilogue: argmin of the last column, backward pass, path output, align post-processing.
 template <bool LDSCODES, int BITS>
-__device__ void dtw_finish(const DtwPair &P, int D, int fstep, const double *clast, int32_t *path32, int32_t *owner,
+__device__ void dtw_finish(const DtwPair &P, const double *__restrict__ seq, int D, int fstep, const double *clast, int32_t *path32, int32_t *owner,
                            int32_t *holes, const uint32_t *codes_lds, int Smax) {
   constexpr int CPW = 32 / BITS;
   const int S = P.S, T = P.T, tid = threadIdx.x, nthr = blockDim.x;
@@ -72,7 +74,7 @@ __device__ void dtw_finish(const DtwPair &P, int D, int fstep, const double *cla
   for (int64_t e = tid; e < (int64_t)S * D; e += nthr) {
     const int i = (int)(e / D), d = (int)(e % D);
     const int k = owner[i];
-    P.newtgt[e] = (k >= 0) ? P.seq[(size_t)D * k + d] : 0.0;
+    P.newtgt[e] = (k >= 0) ? seq[(size_t)D * k + d] : 0.0;
   }
   __shared__ int nholes;
   if (tid == 0) {                                   // hole = setdiff(path[1]:path[end], path), increasing order
@@ -91,12 +93,75 @@ __device__ void dtw_finish(const DtwPair &P, int D, int fstep, const double *cla
 }
 
 // ------------------------------------------------------------------------------------------------
-// Fast kernel: S <= blockDim (<= 1024), D <= DMAX; template frame in registers.
+// Fast path = two kernels.
+//
+// (1) dtw_obs_kernel<DMAX>: the observation costs O[i,t] = sum_d (seq[d,t] - tmpl[d,i])^2 of every cell, which do
+//     not depend on the recurrence, are computed with NO barrier: lane = template frame (its D values in VGPRs),
+//     the sequence column is wave-uniform and arrives through scalar loads (`feats` is a read-only, non-aliased
+//     kernel argument), i.e. as SGPR operands of the FP64 ALU -- no LDS traffic, no per-lane loads.  (64-bit
+//     same-address LDS reads were measured to serialise per lane on gfx950, which ruled out an LDS broadcast.)
+//     Arithmetic order: sequential in d, unfused sub / mul / add (bit-exact contract).  O goes to an HBM workspace
+//     in the cost table's (S,T) column-major order, so writes and the later reads are coalesced.
+// (2) dtw_rec_kernel<STEPS,CODES>: one workgroup per pair, thread r = template frame r: per column a handful of
+//     instructions (candidate costs, strict '<' selection in the reference's scan order), previous column
+//     double-buffered in LDS, one barrier per column, O prefetched PF columns ahead in registers.
+//     STEPS: 1 = (bstep 1, fstep 0), 2 = (bstep 2, fstep 0) -- candidate window unrolled; 0 = run-time window.
+//     CODES: 0 = 2-bit step codes in LDS, 1 = byte codes in LDS, 2 = byte codes in HBM.
 // ------------------------------------------------------------------------------------------------
-template <int DMAX, int BITS, bool LDSCODES>
+static constexpr int kObsRows = 256;    // template frames per obs workgroup (4 waves)
+static constexpr int kObsCols = 128;    // sequence frames per obs workgroup
+
+// zero-pads the sequence of every pair to DMAX doubles per frame (only launched when D != DMAX), so that the
+// observation loop below is branch-free: (0 - 0)^2 = +0.0 added to a non-negative sum leaves it bit-identical.
+__global__ void __launch_bounds__(256)
+dtw_pad_kernel(const double *__restrict__ feats, const DtwPair *__restrict__ pairs, int D, int DMAX, double *__restrict__ spad) {
+  const DtwPair P = pairs[blockIdx.x];
+  const int64_t n = (int64_t)P.T * DMAX;
+  for (int64_t e = (int64_t)blockIdx.y * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.y * 256) {
+    const int64_t t = e / DMAX;
+    const int d = (int)(e % DMAX);
+    spad[P.spad_off + e] = (d < D) ? feats[P.seq_off + t * D + d] : 0.0;
+  }
+}
+
+// sbase + P.<off>: sequence with exactly DMAX doubles per frame (the caller's buffer when D == DMAX, else the padded copy)
+template <int DMAX>
+__global__ void __launch_bounds__(kObsRows)
+dtw_obs_kernel(const double *__restrict__ feats, const double *__restrict__ sbase, int padded,
+               const DtwPair *__restrict__ pairs, int D) {
+  const DtwPair P = pairs[blockIdx.x];
+  const int S = P.S, T = P.T;
+  const int r = blockIdx.y * kObsRows + threadIdx.x;
+  const int t0 = blockIdx.z * kObsCols;
+  if (blockIdx.y * kObsRows >= S || t0 >= T) return;      // workgroup-uniform
+  const bool active = r < S;
+  const double *__restrict__ seq = sbase + (padded ? P.spad_off : P.seq_off);
+  double tm[DMAX];
+#pragma unroll
+  for (int d = 0; d < DMAX; ++d) tm[d] = (active && d < D) ? feats[P.tmpl_off + (int64_t)D * r + d] : 0.0;
+  const int t1 = (t0 + kObsCols < T) ? t0 + kObsCols : T;
+  double *__restrict__ O = P.obs;
+  for (int t = t0; t < t1; ++t) {
+    const double *__restrict__ v = seq + (size_t)DMAX * t;   // wave-uniform -> scalar loads
+    double o = 0.0;                                       // observation(d, v, i), src/dtw.jl:33-35
+#pragma unroll
+    for (int d = 0; d < DMAX; ++d) {
+      const double df = v[d] - tm[d];
+      const double sq = df * df;
+      o = o + sq;
+    }
+    if (active) O[(size_t)S * t + r] = o;
+  }
+}
+
+template <int STEPS, int CODES>
 __global__ void __launch_bounds__(1024)
-dtw_kernel(const DtwPair *__restrict__ pairs, int D, int fstep, int bstep, int Smax, int Tmax) {
+dtw_rec_kernel(const double *__restrict__ feats, const DtwPair *__restrict__ pairs, int D, int fstep, int bstep, int Smax,
+               int Tmax) {
+  constexpr bool LDSCODES = (CODES != 2);
+  constexpr int BITS = (CODES == 0) ? 2 : 8;
   constexpr int CPW = 32 / BITS;
+  constexpr int PF = 4;                                   // columns of O in flight per thread
   const DtwPair P = pairs[blockIdx.x];
   const int S = P.S, T = P.T;
   const int r = threadIdx.x;
@@ -108,10 +173,7 @@ dtw_kernel(const DtwPair *__restrict__ pairs, int D, int fstep, int bstep, int S
   int32_t *holes = owner + Smax;                                  // [Smax]
   uint32_t *codes = reinterpret_cast<uint32_t *>(holes + Smax);   // [ceil(Tmax/CPW)][Smax] when LDSCODES
   if (T == 0) return;
-
-  double tm[DMAX];
-#pragma unroll
-  for (int d = 0; d < DMAX; ++d) tm[d] = (active && d < D) ? P.tmpl[(size_t)D * r + d] : 0.0;
+  const double *__restrict__ O = P.obs;
 
   // lazy_init!: costtable[:,1] = 1:S, backpointer[:,1] = 1:S  (src/dtw.jl:49-50)
   double cprev = (double)(r + 1);
@@ -120,52 +182,63 @@ dtw_kernel(const DtwPair *__restrict__ pairs, int D, int fstep, int bstep, int S
     if (P.cost) P.cost[r] = cprev;
     if (P.bp) P.bp[r] = r + 1;
   }
+  double opf[PF];
+#pragma unroll
+  for (int k = 0; k < PF; ++k) opf[k] = (active && k < T) ? O[(size_t)S * k + r] : 0.0;
   __syncthreads();
 
   uint32_t word = 0;
-  for (int t = 0; t < T; ++t) {
-    const double *cp = cbuf + (t & 1) * Smax;
-    double *cn = cbuf + ((t + 1) & 1) * Smax;
-    if (active) {
-      const double *__restrict__ v = P.seq + (size_t)D * t;
-      double o = 0.0;                                   // observation(d, v, i), src/dtw.jl:33-35
+  for (int t0 = 0; t0 < T; t0 += PF) {
 #pragma unroll
-      for (int d = 0; d < DMAX; ++d) {
-        if (d < D) {
-          const double df = v[d] - tm[d];
-          const double sq = df * df;
-          o = o + sq;
+    for (int k = 0; k < PF; ++k) {
+      const int t = t0 + k;
+      if (t < T) {                                        // wave-uniform
+        const double *cp = cbuf + (t & 1) * Smax;
+        double *cn = cbuf + ((t + 1) & 1) * Smax;
+        if (active) {
+          const double o = opf[k];
+          opf[k] = (t + PF < T) ? O[(size_t)S * (t + PF) + r] : 0.0;   // refill this slot PF columns ahead
+          int arg = r;                                    // minindex = i, src/dtw.jl:106-110
+          double best = (cprev + o) + 1.0;
+          if (STEPS == 0) {
+            for (int j = r - bstep; j <= r + fstep; ++j) {  // src/dtw.jl:113-121
+              if (j < 0 || j >= S) continue;
+              const double c = (cp[j] + o) + dtw_transition(j, r);
+              if (c < best) { best = c; arg = j; }
+            }
+          } else {
+            // window j = r-STEPS .. r, increasing j; j == r repeats the start value and never wins the strict '<'
+            if (STEPS == 2) {
+              const double c2 = (cp[r >= 2 ? r - 2 : r] + o) + 2.0;
+              if (r >= 2 && c2 < best) { best = c2; arg = r - 2; }
+            }
+            const double c1 = (cp[r >= 1 ? r - 1 : r] + o) + 0.0;
+            if (r >= 1 && c1 < best) { best = c1; arg = r - 1; }
+          }
+          cn[r] = best;
+          cprev = best;
+          if (P.cost) P.cost[(size_t)S * (t + 1) + r] = best;
+          if (P.bp) P.bp[(size_t)S * (t + 1) + r] = arg + 1;
+          const uint32_t code = (uint32_t)(r - arg + fstep);
+          if (LDSCODES) {
+            word |= code << (BITS * (t % CPW));
+            if ((t % CPW) == CPW - 1 || t == T - 1) {
+              codes[(t / CPW) * Smax + r] = word;
+              word = 0;
+            }
+          } else {
+            P.codes[(size_t)S * t + r] = (unsigned char)code;
+          }
         }
-      }
-      int arg = r;                                      // minindex = i, src/dtw.jl:106-110
-      double best = (cprev + o) + 1.0;
-      for (int j = r - bstep; j <= r + fstep; ++j) {    // src/dtw.jl:113-121
-        if (j < 0 || j >= S) continue;
-        const double c = (cp[j] + o) + dtw_transition(j, r);
-        if (c < best) { best = c; arg = j; }
-      }
-      cn[r] = best;
-      cprev = best;
-      if (P.cost) P.cost[(size_t)S * (t + 1) + r] = best;
-      if (P.bp) P.bp[(size_t)S * (t + 1) + r] = arg + 1;
-      const uint32_t code = (uint32_t)(r - arg + fstep);
-      if (LDSCODES) {
-        word |= code << (BITS * (t % CPW));
-        if ((t % CPW) == CPW - 1 || t == T - 1) {
-          codes[(t / CPW) * Smax + r] = word;
-          word = 0;
-        }
-      } else {
-        P.codes[(size_t)S * t + r] = (unsigned char)code;
+        __syncthreads();
       }
     }
-    __syncthreads();
   }
   if (!LDSCODES) {
     __threadfence();
     __syncthreads();
   }
-  dtw_finish<LDSCODES, BITS>(P, D, fstep, cbuf + (T & 1) * Smax, path32, owner, holes, codes, Smax);
+  dtw_finish<LDSCODES, BITS>(P, feats + P.seq_off, D, fstep, cbuf + (T & 1) * Smax, path32, owner, holes, codes, Smax);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -173,7 +246,7 @@ dtw_kernel(const DtwPair *__restrict__ pairs, int D, int fstep, int bstep, int S
 // template read from HBM/L2, step codes as bytes in HBM.
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(1024)
-dtw_generic_kernel(const DtwPair *__restrict__ pairs, int D, int fstep, int bstep, int Smax, int Tmax) {
+dtw_generic_kernel(const double *__restrict__ feats, const DtwPair *__restrict__ pairs, int D, int fstep, int bstep, int Smax, int Tmax) {
   const DtwPair P = pairs[blockIdx.x];
   const int S = P.S, T = P.T, tid = threadIdx.x, nthr = blockDim.x;
   extern __shared__ unsigned char smem_raw[];
@@ -191,9 +264,9 @@ dtw_generic_kernel(const DtwPair *__restrict__ pairs, int D, int fstep, int bste
   for (int t = 0; t < T; ++t) {
     const double *cp = cbuf + (t & 1) * Smax;
     double *cn = cbuf + ((t + 1) & 1) * Smax;
-    const double *__restrict__ v = P.seq + (size_t)D * t;
+    const double *__restrict__ v = feats + P.seq_off + (size_t)D * t;
     for (int r = tid; r < S; r += nthr) {
-      const double *__restrict__ tc = P.tmpl + (size_t)D * r;
+      const double *__restrict__ tc = feats + P.tmpl_off + (size_t)D * r;
       double o = 0.0;
       for (int d = 0; d < D; ++d) {
         const double df = v[d] - tc[d];
@@ -216,7 +289,7 @@ dtw_generic_kernel(const DtwPair *__restrict__ pairs, int D, int fstep, int bste
   }
   __threadfence();
   __syncthreads();
-  dtw_finish<false, 8>(P, D, fstep, cbuf + (T & 1) * Smax, path32, owner, holes, nullptr, Smax);
+  dtw_finish<false, 8>(P, feats + P.seq_off, D, fstep, cbuf + (T & 1) * Smax, path32, owner, holes, nullptr, Smax);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -229,27 +302,53 @@ struct DtwLaunch {
   int D, fstep, bstep;
 };
 
-template <int DMAX>
-static int launch_fast(const DtwPair *dpairs, int n, int D, int fstep, int bstep, int Smax, int Tmax, int bits,
-                       bool ldscodes, size_t shmem, int threads, hipStream_t st) {
-#define VCMI_DTW_LAUNCH(B, L)                                                                                  \
+static int launch_rec(const double *feats, const DtwPair *dpairs, int n, int D, int fstep, int bstep, int Smax, int Tmax,
+                      int steps, int codes, size_t shmem, int threads, hipStream_t st) {
+#define VCMI_DTW_LAUNCH(ST, CO)                                                                                \
   do {                                                                                                         \
-    auto kern = dtw_kernel<DMAX, B, L>;                                                                        \
+    auto kern = dtw_rec_kernel<ST, CO>;                                                                        \
     VCMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
                                  (int)shmem));                                                                 \
-    hipLaunchKernelGGL(kern, dim3(n), dim3(threads), shmem, st, dpairs, D, fstep, bstep, Smax, Tmax);          \
+    hipLaunchKernelGGL(kern, dim3(n), dim3(threads), shmem, st, feats, dpairs, D, fstep, bstep, Smax, Tmax);   \
   } while (0)
-  if (!ldscodes) VCMI_DTW_LAUNCH(8, false);
-  else if (bits == 2) VCMI_DTW_LAUNCH(2, true);
-  else VCMI_DTW_LAUNCH(8, true);
+  if (steps == 1 && codes == 0) VCMI_DTW_LAUNCH(1, 0);
+  else if (steps == 1) VCMI_DTW_LAUNCH(1, 2);
+  else if (steps == 2 && codes == 0) VCMI_DTW_LAUNCH(2, 0);
+  else if (steps == 2) VCMI_DTW_LAUNCH(2, 2);
+  else if (codes == 0) VCMI_DTW_LAUNCH(0, 0);
+  else if (codes == 1) VCMI_DTW_LAUNCH(0, 1);
+  else VCMI_DTW_LAUNCH(0, 2);
 #undef VCMI_DTW_LAUNCH
+  VCMI_HIP(hipGetLastError());
+  return VCMI_OK;
+}
+
+static int dtw_dmax(int D) {
+  return D <= 8 ? 8 : D <= 16 ? 16 : D <= 24 ? 24 : D <= 32 ? 32 : D <= 40 ? 40 : D <= 48 ? 48 : D <= 64 ? 64 : 96;
+}
+
+static int launch_obs(const double *feats, const double *spad, const DtwPair *dpairs, int n, int D, int Smax, int Tmax,
+                      hipStream_t st) {
+  const dim3 grid(n, (Smax + kObsRows - 1) / kObsRows, (Tmax + kObsCols - 1) / kObsCols);
+  const int dmax = dtw_dmax(D);
+  const int padded = (D != dmax);
+  const double *sbase = padded ? spad : feats;
+  if (padded) hipLaunchKernelGGL(dtw_pad_kernel, dim3(n, 8), dim3(256), 0, st, feats, dpairs, D, dmax, const_cast<double *>(spad));
+  switch (dmax) {
+#define VCMI_OBS_CASE(DM) \
+  case DM: hipLaunchKernelGGL(dtw_obs_kernel<DM>, grid, dim3(kObsRows), 0, st, feats, sbase, padded, dpairs, D); break;
+    VCMI_OBS_CASE(8) VCMI_OBS_CASE(16) VCMI_OBS_CASE(24) VCMI_OBS_CASE(32) VCMI_OBS_CASE(40) VCMI_OBS_CASE(48)
+    VCMI_OBS_CASE(64) VCMI_OBS_CASE(96)
+#undef VCMI_OBS_CASE
+  }
   VCMI_HIP(hipGetLastError());
   return VCMI_OK;
 }
 
 // Launch one workgroup per pair.  `pairs` holds DEVICE pointers (codes filled in here when needed).
 // codes_ws: grow-only device scratch for HBM step codes.
-static int dtw_run(std::vector<DtwPair> &pairs, int D, int fstep, int bstep, DevBuf<unsigned char> &codes_ws,
+static int dtw_run(const double *feats, std::vector<DtwPair> &pairs, int D, int fstep, int bstep, DevBuf<unsigned char> &codes_ws,
+                   DevBuf<double> &obs_ws, DevBuf<double> &spad_ws,
                    DevBuf<DtwPair> &dpairs, hipStream_t st) {
   const int n = (int)pairs.size();
   if (n == 0) return VCMI_OK;
@@ -267,9 +366,10 @@ static int dtw_run(std::vector<DtwPair> &pairs, int D, int fstep, int bstep, Dev
     return (int64_t)a.S * a.T > (int64_t)b.S * b.T;
   });
   const int bits = (fstep + bstep + 1 <= 4) ? 2 : 8;
+  const bool fast = (Smax <= 1024 && D <= 96);
   const size_t base = (size_t)2 * Smax * 8 + (size_t)Tmax * 4 + (size_t)2 * Smax * 4;
+  const size_t base_generic = base;
   const size_t codes_lds = (size_t)((Tmax + (32 / bits) - 1) / (32 / bits)) * Smax * 4;
-  const bool fast = (Smax <= 1024 && D <= 128);
   const bool ldscodes = fast && (base + codes_lds <= kLdsLimit);
   if (base > kLdsLimit) return fail(VCMI_ERR_ARG, "DTW: template of %d frames exceeds the supported length", Smax);
   if (!ldscodes) {
@@ -283,20 +383,52 @@ static int dtw_run(std::vector<DtwPair> &pairs, int D, int fstep, int bstep, Dev
     }
   }
   VCMI_TRY(dpairs.reserve(n));
-  VCMI_HIP(hipMemcpy(dpairs.p, pairs.data(), sizeof(DtwPair) * n, hipMemcpyHostToDevice));   // tiny, synchronous: `pairs` may die after return
   if (fast) {
-    const int threads = std::min(1024, (Smax + 63) / 64 * 64);
+    // observation-cost workspace: S*T doubles per pair; large batches run in slices of at most ~4 GiB
+    const int threads = (Smax + 63) / 64 * 64;
     const size_t shmem = base + (ldscodes ? codes_lds : 0);
-    if (D <= 8) return launch_fast<8>(dpairs.p, n, D, fstep, bstep, Smax, Tmax, bits, ldscodes, shmem, threads, st);
-    if (D <= 16) return launch_fast<16>(dpairs.p, n, D, fstep, bstep, Smax, Tmax, bits, ldscodes, shmem, threads, st);
-    if (D <= 32) return launch_fast<32>(dpairs.p, n, D, fstep, bstep, Smax, Tmax, bits, ldscodes, shmem, threads, st);
-    if (D <= 40) return launch_fast<40>(dpairs.p, n, D, fstep, bstep, Smax, Tmax, bits, ldscodes, shmem, threads, st);
-    if (D <= 64) return launch_fast<64>(dpairs.p, n, D, fstep, bstep, Smax, Tmax, bits, ldscodes, shmem, threads, st);
-    return launch_fast<128>(dpairs.p, n, D, fstep, bstep, Smax, Tmax, bits, ldscodes, shmem, threads, st);
+    const int steps = (fstep == 0 && bstep == 1) ? 1 : (fstep == 0 && bstep == 2) ? 2 : 0;
+    const int codes = !ldscodes ? 2 : (bits == 2 ? 0 : 1);
+    const size_t kMaxCells = (size_t)1 << 29;
+    int lo = 0;
+    while (lo < n) {
+      size_t cells = 0;
+      int hi = lo;
+      while (hi < n && (hi == lo || cells + (size_t)pairs[hi].S * pairs[hi].T <= kMaxCells)) {
+        cells += (size_t)pairs[hi].S * pairs[hi].T;
+        ++hi;
+      }
+      VCMI_TRY(obs_ws.reserve(cells));
+      const int dmax = dtw_dmax(D);
+      if (D != dmax) {
+        size_t padn = 0;
+        for (int k = lo; k < hi; ++k) padn += (size_t)pairs[k].T * dmax;
+        VCMI_TRY(spad_ws.reserve(padn));
+      }
+      size_t off = 0, poff = 0;
+      int smax = 0, tmax = 0;
+      for (int k = lo; k < hi; ++k) {
+        pairs[k].obs = obs_ws.p + off;
+        off += (size_t)pairs[k].S * pairs[k].T;
+        pairs[k].spad_off = (int64_t)poff;
+        poff += (size_t)pairs[k].T * dmax;
+        smax = std::max(smax, pairs[k].S);
+        tmax = std::max(tmax, pairs[k].T);
+      }
+      VCMI_HIP(hipMemcpy(dpairs.p + lo, pairs.data() + lo, sizeof(DtwPair) * (hi - lo), hipMemcpyHostToDevice));
+      if (tmax > 0) {
+        VCMI_TRY(launch_obs(feats, spad_ws.p, dpairs.p + lo, hi - lo, D, smax, tmax, st));
+        VCMI_TRY(launch_rec(feats, dpairs.p + lo, hi - lo, D, fstep, bstep, Smax, Tmax, steps, codes, shmem, threads, st));
+      }
+      if (hi < n) VCMI_HIP(hipStreamSynchronize(st));   // the next slice reuses the workspace
+      lo = hi;
+    }
+    return VCMI_OK;
   }
+  VCMI_HIP(hipMemcpy(dpairs.p, pairs.data(), sizeof(DtwPair) * n, hipMemcpyHostToDevice));   // tiny, synchronous: `pairs` may die after return
   VCMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(dtw_generic_kernel),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)base));
-  hipLaunchKernelGGL(dtw_generic_kernel, dim3(n), dim3(1024), base, st, dpairs.p, D, fstep, bstep, Smax, Tmax);
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)base_generic));
+  hipLaunchKernelGGL(dtw_generic_kernel, dim3(n), dim3(1024), base_generic, st, feats, dpairs.p, D, fstep, bstep, Smax, Tmax);
   VCMI_HIP(hipGetLastError());
   return VCMI_OK;
 }
@@ -305,7 +437,7 @@ static int dtw_run(std::vector<DtwPair> &pairs, int D, int fstep, int bstep, Dev
 struct DtwScratch {
   DevBuf<unsigned char> codes;
   DevBuf<DtwPair> dpairs;
-  DevBuf<double> feats, cost, newtgt;
+  DevBuf<double> feats, cost, newtgt, obs, spad;
   DevBuf<int64_t> paths, bp;
 };
 static DtwScratch &scratch() {
@@ -345,10 +477,10 @@ static int dtw_host_batch(int64_t n, const double *const *tmpl, const int64_t *S
   for (int64_t p = 0; p < n; ++p) {
     DtwPair &q = pairs[p];
     memcpy(&hfeat[fo], tmpl[p], sizeof(double) * D * S[p]);
-    q.tmpl = sc.feats.p + fo;
+    q.tmpl_off = (int64_t)fo;
     fo += (size_t)D * S[p];
     if (T[p] > 0) memcpy(&hfeat[fo], seq[p], sizeof(double) * D * T[p]);
-    q.seq = sc.feats.p + fo;
+    q.seq_off = (int64_t)fo;
     fo += (size_t)D * T[p];
     q.path = sc.paths.p + po;
     po += (size_t)T[p];
@@ -357,6 +489,8 @@ static int dtw_host_batch(int64_t n, const double *const *tmpl, const int64_t *S
     q.newtgt = newtgt ? sc.newtgt.p + to : nullptr;
     to += (size_t)D * S[p];
     q.codes = nullptr;
+    q.obs = nullptr;
+    q.spad_off = 0;
     q.S = (int32_t)S[p];
     q.T = (int32_t)T[p];
   }
@@ -368,7 +502,7 @@ static int dtw_host_batch(int64_t n, const double *const *tmpl, const int64_t *S
     }
   }
   std::vector<DtwPair> order = pairs;   // dtw_run sorts its argument; keep `pairs` in caller order for the copy-back
-  VCMI_TRY(dtw_run(order, D, fstep, bstep, sc.codes, sc.dpairs, nullptr));
+  VCMI_TRY(dtw_run(sc.feats.p, order, D, fstep, bstep, sc.codes, sc.obs, sc.spad, sc.dpairs, nullptr));
   VCMI_HIP(hipDeviceSynchronize());
   std::vector<int64_t> hpath(std::max<size_t>(npath, 1));
   VCMI_HIP(hipMemcpy(hpath.data(), sc.paths.p, npath * 8, hipMemcpyDeviceToHost));
@@ -417,11 +551,11 @@ extern "C" int vcmi_dtw_fit_batch_dev(int64_t n, const double *feats, const int6
   std::vector<DtwPair> pairs(n);
   for (int64_t p = 0; p < n; ++p) {
     if (S[p] < 1 || T[p] < 0 || S[p] > INT32_MAX || T[p] > INT32_MAX) return fail(VCMI_ERR_DIM, "DTW: bad sequence length");
-    pairs[p] = DtwPair{feats + tmpl_off[p], feats + seq_off[p], paths + path_off[p], nullptr, nullptr, nullptr, nullptr,
+    pairs[p] = DtwPair{tmpl_off[p], seq_off[p], paths + path_off[p], nullptr, nullptr, nullptr, nullptr, nullptr, 0,
                        (int32_t)S[p], (int32_t)T[p]};
   }
   DtwScratch &sc = scratch();
-  return dtw_run(pairs, D, fstep, bstep, sc.codes, sc.dpairs, as_stream(stream));
+  return dtw_run(feats, pairs, D, fstep, bstep, sc.codes, sc.obs, sc.spad, sc.dpairs, as_stream(stream));
 }
 
 extern "C" int vcmi_align(const double *src, int64_t S, const double *tgt, int64_t T, int D, double *newtgt,
