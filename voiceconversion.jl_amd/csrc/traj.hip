@@ -73,8 +73,10 @@ traj_g_kernel(const double *__restrict__ X, int64_t nframes, int D2, const int64
 // ------------------------------------------------------------------------------------------------
 // banded Cholesky solve, one workgroup (256 threads) per utterance
 // ------------------------------------------------------------------------------------------------
-// LDS window: 3x3 blocks of DxD with circular block slots (global block a lives in slot a % 3), row stride LD.
-__device__ __forceinline__ int wslot(int a) { return a % 3; }
+// LDS window: rows/cols 0..3D-1 = global rows t*D .. t*D+3D-1 of the band (row stride LD); after block column t is
+// finished the lower-right 2D x 2D part is shifted up-left by D (through registers) and block row t+3 is assembled
+// into the freed rows.  No index arithmetic beyond adds in the hot loops.
+static constexpr int kShiftRegs = 36;   // ceil(4*46^2 / 256) doubles per thread for the window shift
 
 __global__ void __launch_bounds__(256)
 traj_solve_kernel(const TrajUtt *__restrict__ utts, int n, int D, const double *__restrict__ Qall,
@@ -83,11 +85,14 @@ traj_solve_kernel(const TrajUtt *__restrict__ utts, int n, int D, const double *
   const int D2 = 2 * D, W3 = 3 * D, LD = W3 + 1;
   extern __shared__ double sm[];
   double *Wd = sm;                       // [W3][LD]
-  double *rr = Wd + (size_t)W3 * LD;     // [W3] right-hand-side row (circular slots like the window)
-  double *yring = rr + W3;               // [2][D]  y_{t+1}, y_{t+2} during back-substitution
+  double *rr = Wd + (size_t)W3 * LD;     // [W3] right-hand side riding along as an extra row
+  double *lcol = rr + W3;                // [W3] scaled pivot column of the current elimination step
+  double *yring = lcol + W3;             // [2][D]  y_{t+1}, y_{t+2} during back-substitution
   double *wv = yring + 2 * D;            // [D]
   __shared__ int bad;
+  __shared__ double zc_s;
   const int tid = threadIdx.x;
+  const int ti = tid >> 4, tj = tid & 15;
   const size_t PAN = (size_t)(W3 + 1) * D;   // panel: rows 0..3D-1 of L[:, block t] (relative to t) + z row
 
   for (int u = blockIdx.x; u < n; u += gridDim.x) {
@@ -99,90 +104,108 @@ traj_solve_kernel(const TrajUtt *__restrict__ utts, int n, int D, const double *
     double *ws = ws_all + (size_t)blockIdx.x * ws_stride;
     if (tid == 0) bad = 0;
 
-    // assemble block row a of P (and r) into the window; blocks (a, a-2), (a, a-1), (a, a)
-    auto add_block_row = [&](int a) {
-      const int sa = wslot(a);
+    // assemble global block row a of P (and r) into local block row la of the window: blocks (a,a-2), (a,a-1), (a,a)
+    auto add_block_row = [&](int a, int la) {
       const double *Qa = Qall + (size_t)(mh[a] - 1) * D2 * D2;
       const double *Qm = (a >= 1) ? Qall + (size_t)(mh[a - 1] - 1) * D2 * D2 : nullptr;
       const double *Qp = (a + 1 < T) ? Qall + (size_t)(mh[a + 1] - 1) * D2 * D2 : nullptr;
+      int i = tid / D, j = tid - i * D;                      // one division per call, then incremental
+      const int di = 256 / D, dj = 256 - di * D;
       for (int e = tid; e < D * D; e += 256) {
-        const int i = e / D, j = e % D;
+        double *row = Wd + (size_t)(la * D + i) * LD;
         double v = Qa[(size_t)i * D2 + j];                                        // Qss(a)
         if (Qm) v += 0.25 * Qm[(size_t)(D + i) * D2 + (D + j)];                   // + Qdd(a-1)/4
         if (Qp) v += 0.25 * Qp[(size_t)(D + i) * D2 + (D + j)];                   // + Qdd(a+1)/4
-        Wd[(size_t)(sa * D + i) * LD + sa * D + j] = v;
-        if (a >= 1) {
-          const int sb = wslot(a - 1);
-          Wd[(size_t)(sa * D + i) * LD + sb * D + j] =
-              0.5 * Qm[(size_t)(D + i) * D2 + j] - 0.5 * Qa[(size_t)i * D2 + (D + j)];   // Qds(a-1)/2 - Qsd(a)/2
-        }
-        if (a >= 2) {
-          const int sc = wslot(a - 2);
-          Wd[(size_t)(sa * D + i) * LD + sc * D + j] = -0.25 * Qm[(size_t)(D + i) * D2 + (D + j)];   // -Qdd(a-1)/4
-        }
+        row[la * D + j] = v;
+        if (la >= 1 && a >= 1)
+          row[(la - 1) * D + j] = 0.5 * Qm[(size_t)(D + i) * D2 + j] - 0.5 * Qa[(size_t)i * D2 + (D + j)];   // Qds(a-1)/2 - Qsd(a)/2
+        if (la >= 2 && a >= 2)
+          row[(la - 2) * D + j] = -0.25 * Qm[(size_t)(D + i) * D2 + (D + j)];     // -Qdd(a-1)/4
+        i += di;
+        j += dj;
+        if (j >= D) { j -= D; ++i; }
       }
-      for (int i = tid; i < D; i += 256) {
-        double v = g[(size_t)a * D2 + i];
-        if (a >= 1) v += 0.5 * g[(size_t)(a - 1) * D2 + D + i];
-        if (a + 1 < T) v -= 0.5 * g[(size_t)(a + 1) * D2 + D + i];
-        rr[sa * D + i] = v;
+      for (int k = tid; k < D; k += 256) {
+        double v = g[(size_t)a * D2 + k];
+        if (a >= 1) v += 0.5 * g[(size_t)(a - 1) * D2 + D + k];
+        if (a + 1 < T) v -= 0.5 * g[(size_t)(a + 1) * D2 + D + k];
+        rr[la * D + k] = v;
       }
     };
 
-    for (int a = 0; a < 3 && a < T; ++a) add_block_row(a);
+    for (int a = 0; a < 3 && a < T; ++a) add_block_row(a, a);
     __syncthreads();
 
     // ---------------- factorisation + forward substitution ----------------
     for (int t = 0; t < T; ++t) {
       const int nb = (T - t < 3) ? T - t : 3;      // block rows alive in the window
       const int nrows = nb * D;
-      const int s0 = wslot(t);
-      // local row lr (0..nrows-1) -> LDS row index
-      auto rowidx = [&](int lr) { return wslot(t + lr / D) * D + lr % D; };
       for (int c = 0; c < D; ++c) {
-        const int pc = s0 * D + c;                 // LDS index of pivot row/column
-        const double piv = Wd[(size_t)pc * LD + pc];
-        if (!(piv > 0.0)) {
-          if (tid == 0) bad = 1;
-        }
+        // (a) pivot and scaled column into lcol (the window column itself is left untouched until (b))
+        const double piv = Wd[(size_t)c * LD + c];
+        if (!(piv > 0.0) && tid == 0) bad = 1;
         const double dinv = 1.0 / sqrt(piv);
-        __syncthreads();                           // everyone has read the pivot before it is overwritten
-        // scale column c below the pivot (and the rhs entry)
-        for (int lr = c + tid; lr < nrows; lr += 256) {
-          const int ri = rowidx(lr);
-          Wd[(size_t)ri * LD + pc] = (lr == c) ? piv * dinv : Wd[(size_t)ri * LD + pc] * dinv;
-        }
-        if (tid == 255) rr[pc] *= dinv;
+        for (int lr = c + tid; lr < nrows; lr += 256) lcol[lr] = (lr == c) ? piv * dinv : Wd[(size_t)lr * LD + c] * dinv;
+        if (tid == 255) zc_s = rr[c] * dinv;
         __syncthreads();
-        // rank-1 update of the trailing lower triangle and of the rhs row
+        // (b) rank-1 update of the trailing lower triangle and of the rhs; the finished column goes back to the window
         const int rem = nrows - c - 1;
-        {
-          const int ti = tid >> 4, tj = tid & 15;
-          for (int a = ti; a < rem; a += 16) {
-            const int lr = c + 1 + a, ri = rowidx(lr);
-            const double lic = Wd[(size_t)ri * LD + pc];
-            for (int b = tj; b <= a; b += 16) {
-              const int lcq = c + 1 + b, rj = rowidx(lcq);
-              Wd[(size_t)ri * LD + rj] = fma(-lic, Wd[(size_t)rj * LD + pc], Wd[(size_t)ri * LD + rj]);
-            }
-          }
+        for (int a = ti; a < rem; a += 16) {
+          const int ri = c + 1 + a;
+          const double lic = lcol[ri];
+          double *row = Wd + (size_t)ri * LD + c + 1;
+          for (int b = tj; b <= a; b += 16) row[b] = fma(-lic, lcol[c + 1 + b], row[b]);
         }
-        const double zc = rr[pc];
-        for (int b = tid; b < rem; b += 256) {
-          const int rj = rowidx(c + 1 + b);
-          rr[rj] = fma(-zc, Wd[(size_t)rj * LD + pc], rr[rj]);
+        const double zc = zc_s;
+        for (int lr = c + tid; lr < nrows; lr += 256) {
+          Wd[(size_t)lr * LD + c] = lcol[lr];
+          if (lr > c) rr[lr] = fma(-zc, lcol[lr], rr[lr]);
+          else rr[lr] = zc;
         }
         __syncthreads();
       }
-      // stream the finished panel: rows lr = 0..3D-1 (zero beyond nrows), columns of block t; then the z row
+      // stream the finished panel: rows 0..3D-1 (zero beyond nrows), columns of block t; then the z row
       double *pan = ws + (size_t)t * PAN;
-      for (int e = tid; e < W3 * D; e += 256) {
-        const int lr = e / D, c = e % D;
-        pan[e] = (lr < nrows) ? Wd[(size_t)rowidx(lr) * LD + s0 * D + c] : 0.0;
+      {
+        int lr = tid / D, cc = tid - lr * D;
+        const int dl = 256 / D, dc = 256 - dl * D;
+        for (int e = tid; e < W3 * D; e += 256) {
+          pan[e] = (lr < nrows) ? Wd[(size_t)lr * LD + cc] : 0.0;
+          lr += dl;
+          cc += dc;
+          if (cc >= D) { cc -= D; ++lr; }
+        }
       }
-      for (int c = tid; c < D; c += 256) pan[(size_t)W3 * D + c] = rr[s0 * D + c];
+      for (int cc = tid; cc < D; cc += 256) pan[(size_t)W3 * D + cc] = rr[cc];
+      // shift the window up-left by D (through registers), then assemble block row t+3
+      double sh[kShiftRegs];
+      double rsh = 0.0;
+      {
+        int i = tid / D2, j = tid - i * D2;
+        const int di = 256 / D2, dj = 256 - di * D2;
+#pragma unroll
+        for (int k = 0; k < kShiftRegs; ++k) {
+          sh[k] = (i < D2) ? Wd[(size_t)(i + D) * LD + (j + D)] : 0.0;
+          i += di;
+          j += dj;
+          if (j >= D2) { j -= D2; ++i; }
+        }
+        if (tid < D2) rsh = rr[tid + D];
+      }
       __syncthreads();
-      if (t + 3 < T) add_block_row(t + 3);
+      {
+        int i = tid / D2, j = tid - i * D2;
+        const int di = 256 / D2, dj = 256 - di * D2;
+#pragma unroll
+        for (int k = 0; k < kShiftRegs; ++k) {
+          if (i < D2) Wd[(size_t)i * LD + j] = sh[k];
+          i += di;
+          j += dj;
+          if (j >= D2) { j -= D2; ++i; }
+        }
+        if (tid < D2) rr[tid] = rsh;
+      }
+      if (t + 3 < T) add_block_row(t + 3, 2);
       __syncthreads();
     }
 
@@ -227,7 +250,7 @@ traj_solve_kernel(const TrajUtt *__restrict__ utts, int n, int D, const double *
 // ------------------------------------------------------------------------------------------------
 static size_t solve_lds_bytes(int D) {
   const size_t W3 = 3 * (size_t)D;
-  return (W3 * (W3 + 1) + W3 + 2 * D + D) * sizeof(double);
+  return (W3 * (W3 + 1) + 2 * W3 + 2 * D + D) * sizeof(double);
 }
 
 static int traj_run(vcmi_traj *t, std::vector<TrajUtt> &utts, int64_t nframes, bool contiguous, const double *dX0,
