@@ -20,6 +20,7 @@
 #include "gmmmap_handle.hpp"
 
 #include <algorithm>
+#include <cstdlib>
 
 struct vcmi_traj {
   vcmi_gmmmap *g = nullptr;
@@ -73,9 +74,231 @@ traj_g_kernel(const double *__restrict__ X, int64_t nframes, int D2, const int64
 // ------------------------------------------------------------------------------------------------
 // banded Cholesky solve, one workgroup (256 threads) per utterance
 // ------------------------------------------------------------------------------------------------
+// 1/sqrt(x) in FP64: hardware v_rsq_f64 seed + two Newton steps (each roughly doubles the correct bits; the seed
+// has >= 26) -- a short dependent chain instead of the IEEE sqrt + divide expansion on the per-column critical path.
+__device__ __forceinline__ double traj_rsqrt(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  y = y * fma(-0.5 * x * y, y, 1.5);
+  y = y * fma(-0.5 * x * y, y, 1.5);
+  return y;
+}
+
+// back substitution  L' y = z  from the panels in the HBM workspace (shared by both solve kernels).
+// Panels are double-buffered in LDS (`buf`, 2 x PAN doubles): panel t-1 is fetched (coalesced, through registers)
+// while step t computes.  The sequential part -- the D-step triangular solve -- runs in one wave with the needed
+// row entries and reciprocal diagonal preloaded, so its chain is one shuffle + one FMA per step.
+template <int NPRE>
+__device__ void traj_backsub(const double *__restrict__ ws, size_t PAN, int D, int T, double *buf, double *yring, double *wv,
+                             double *rdiag, double *__restrict__ Y) {
+  const int tid = threadIdx.x, W3 = 3 * D;
+#ifdef TRAJ_NO_BACKSUB
+  return;
+#endif
+  for (int i = tid; i < 2 * D; i += 256) yring[i] = 0.0;
+  {
+    const double *pan = ws + (size_t)(T - 1) * PAN;
+    for (size_t e = tid; e < PAN; e += 256) buf[((T - 1) & 1) * PAN + e] = pan[e];
+  }
+  __syncthreads();
+  for (int t = T - 1; t >= 0; --t) {
+    const double *pb = buf + (size_t)(t & 1) * PAN;
+    double *pn = buf + (size_t)((t + 1) & 1) * PAN;       // receives panel t-1
+    double pre[NPRE];
+    if (t > 0) {
+      const double *pan = ws + (size_t)(t - 1) * PAN;
+#pragma unroll
+      for (int k = 0; k < NPRE; ++k) {
+        const size_t e = tid + (size_t)k * 256;
+        pre[k] = (e < PAN) ? pan[e] : 0.0;
+      }
+    }
+    double *y1 = yring + ((t + 1) & 1) * D, *y2 = yring + (t & 1) * D;   // y_{t+1}, y_{t+2}
+    // w = z - E' y1 - F' y2  (thread j owns column j; panel rows D..3D-1 hold E then F)
+    if (tid < D) {
+      double s = pb[(size_t)W3 * D + tid];
+      for (int i = 0; i < D; ++i) s = fma(-pb[(size_t)(D + i) * D + tid], y1[i], s);
+      for (int i = 0; i < D; ++i) s = fma(-pb[(size_t)(2 * D + i) * D + tid], y2[i], s);
+      wv[tid] = s;
+    } else if (tid >= 64 && tid < 64 + D) {
+      rdiag[tid - 64] = 1.0 / pb[(size_t)(tid - 64) * D + (tid - 64)];
+    }
+    __syncthreads();
+    // Dg' y = w : sequential in k, one wave
+    if (tid < 64) {
+      double w = (tid < D) ? wv[tid] : 0.0;
+      const double rd = (tid < D) ? rdiag[tid] : 0.0;
+      for (int k = D - 1; k >= 0; --k) {
+        const double lk = (tid < k) ? pb[(size_t)k * D + tid] : 0.0;   // independent of the chain: issued ahead
+        const double yk = __shfl(w * rd, k);
+        w = (tid == k) ? yk : fma(-lk, yk, w);
+      }
+      if (tid < D) {
+        y2[tid] = w;                       // becomes y_t; the slot of y_{t+2} is free now
+        Y[(size_t)t * D + tid] = w;        // reshape(y, D, T), src/trajectory_gmmmap.jl:109
+      }
+    }
+    if (t > 0) {
+#pragma unroll
+      for (int k = 0; k < NPRE; ++k) {
+        const size_t e = tid + (size_t)k * 256;
+        if (e < PAN) pn[e] = pre[k];
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// assemble global block row a of P (and r) into local block row la of the LDS window: blocks (a,a-2), (a,a-1), (a,a)
+__device__ void traj_add_block_row(double *Wd, double *rr, int LD, int D, int a, int la, int T,
+                                   const int64_t *__restrict__ mh, const double *__restrict__ g,
+                                   const double *__restrict__ Qall) {
+  const int tid = threadIdx.x, D2 = 2 * D;
+  const double *Qa = Qall + (size_t)(mh[a] - 1) * D2 * D2;
+  const double *Qm = (a >= 1) ? Qall + (size_t)(mh[a - 1] - 1) * D2 * D2 : nullptr;
+  const double *Qp = (a + 1 < T) ? Qall + (size_t)(mh[a + 1] - 1) * D2 * D2 : nullptr;
+  int i = tid / D, j = tid - i * D;                      // one division per call, then incremental
+  const int di = 256 / D, dj = 256 - di * D;
+  for (int e = tid; e < D * D; e += 256) {
+    double *row = Wd + (size_t)(la * D + i) * LD;
+    double v = Qa[(size_t)i * D2 + j];                                        // Qss(a)
+    if (Qm) v += 0.25 * Qm[(size_t)(D + i) * D2 + (D + j)];                   // + Qdd(a-1)/4
+    if (Qp) v += 0.25 * Qp[(size_t)(D + i) * D2 + (D + j)];                   // + Qdd(a+1)/4
+    row[la * D + j] = v;
+    if (la >= 1 && a >= 1)
+      row[(la - 1) * D + j] = 0.5 * Qm[(size_t)(D + i) * D2 + j] - 0.5 * Qa[(size_t)i * D2 + (D + j)];   // Qds(a-1)/2 - Qsd(a)/2
+    if (la >= 2 && a >= 2)
+      row[(la - 2) * D + j] = -0.25 * Qm[(size_t)(D + i) * D2 + (D + j)];     // -Qdd(a-1)/4
+    i += di;
+    j += dj;
+    if (j >= D) { j -= D; ++i; }
+  }
+  for (int k = tid; k < D; k += 256) {
+    double v = g[(size_t)a * D2 + k];
+    if (a >= 1) v += 0.5 * g[(size_t)(a - 1) * D2 + D + k];
+    if (a + 1 < T) v -= 0.5 * g[(size_t)(a + 1) * D2 + D + k];
+    rr[la * D + k] = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Register-resident solve kernel (static D).  The 3D x 3D window lives in REGISTERS, block-cyclically over a
+// 16 x 16 thread grid (thread (ti,tj) owns elements i = ti + 16 ka, j = tj + 16 kb, kb <= ka; register indices are
+// compile-time, the pivot column's tile is picked with a short select chain).  Per column: the owners of column c
+// publish it to LDS (double-buffered -> ONE barrier per column), every thread scales the entries it needs itself,
+// and the rank-1 update is pure register FMAs over all tiles (finished rows/columns are masked by zero
+// multipliers, no branches).  Between block steps the window is shifted by D
+// through LDS, where block row t+3 is assembled.
+// ------------------------------------------------------------------------------------------------
+template <int D>
+__global__ void __launch_bounds__(256)
+traj_solve_reg_kernel(const TrajUtt *__restrict__ utts, int n, const double *__restrict__ Qall,
+                      const int64_t *__restrict__ mhat_all, const double *__restrict__ g_all, double *__restrict__ ws_all,
+                      int64_t ws_stride, int *__restrict__ status) {
+  constexpr int D2 = 2 * D, W3 = 3 * D, LD = W3 + 1, NK = (W3 + 15) / 16;
+  extern __shared__ double sm[];
+  double *Wd = sm;                       // [W3][LD]  staging window (assembly, shift)
+  double *rr = Wd + (size_t)W3 * LD;     // [W3] right-hand side
+  double *colb = rr + W3;                // [2][NK*16] raw pivot column, double-buffered
+  double *yring = colb + 2 * NK * 16;    // [2][D]
+  double *wv = yring + 2 * D;            // [D]
+  __shared__ int bad;
+  const int tid = threadIdx.x;
+  const int ti = tid >> 4, tj = tid & 15;
+  constexpr size_t PAN = (size_t)(W3 + 1) * D;
+
+  for (int u = blockIdx.x; u < n; u += gridDim.x) {
+    const TrajUtt U = utts[u];
+    const int T = U.T;
+    if (T == 0) continue;
+    const int64_t *mh = mhat_all + U.frame0;
+    const double *g = g_all + U.frame0 * D2;
+    double *ws = ws_all + (size_t)blockIdx.x * ws_stride;
+    if (tid == 0) bad = 0;
+    for (int e = tid; e < W3 * LD; e += 256) Wd[e] = 0.0;
+    for (int e = tid; e < W3; e += 256) rr[e] = 0.0;
+    for (int e = tid; e < 2 * NK * 16; e += 256) colb[e] = 0.0;
+    __syncthreads();
+    for (int a = 0; a < 3 && a < T; ++a) traj_add_block_row(Wd, rr, LD, D, a, a, T, mh, g, Qall);
+    __syncthreads();
+
+    for (int t = 0; t < T; ++t) {
+      // window -> registers
+      double v[NK][NK];
+#pragma unroll
+      for (int ka = 0; ka < NK; ++ka)
+#pragma unroll
+        for (int kb = 0; kb <= ka; ++kb) {
+          const int i = ti + 16 * ka, j = tj + 16 * kb;
+          v[ka][kb] = (i < W3 && j < W3) ? Wd[(size_t)i * LD + j] : 0.0;
+        }
+      double *pan = ws + (size_t)t * PAN;
+      constexpr int NKC = (D + 15) / 16;             // tiles that can hold a pivot column of this block step
+      for (int c = 0; c < D; ++c) {
+        const int kc = c >> 4, oc = c & 15;
+        double *cb = colb + (c & 1) * NK * 16;
+        if (tj == oc) {                               // owners of column c publish it (rows above c are ignored later)
+#pragma unroll
+          for (int ka = 0; ka < NK; ++ka) {
+            double x = v[ka][0];
+#pragma unroll
+            for (int q = 1; q < NKC; ++q)
+              if (q <= ka) x = (kc == q) ? v[ka][q] : x;
+            cb[ti + 16 * ka] = x;
+          }
+        }
+        __syncthreads();
+        const double piv = cb[c];
+        if (!(piv > 0.0) && tid == 0) bad = 1;
+        const double dinv = traj_rsqrt(piv);
+        // scaled column entries this thread needs; zero multipliers mask finished rows (i <= c) and columns (j <= c)
+        double lr_[NK], lc_[NK];
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+          const double a = cb[ti + 16 * k] * dinv, b = cb[tj + 16 * k] * dinv;
+          lr_[k] = (ti + 16 * k > c) ? a : 0.0;
+          lc_[k] = (tj + 16 * k > c) ? b : 0.0;
+        }
+#pragma unroll
+        for (int ka = 0; ka < NK; ++ka)
+#pragma unroll
+          for (int kb = 0; kb <= ka; ++kb) v[ka][kb] = fma(-lr_[ka], lc_[kb], v[ka][kb]);
+        // finished column of L -> panel (rows c..3D-1; rows above the diagonal of this block column are never read)
+        const double zc = rr[c] * dinv;
+        if (tid < W3) {
+          const double l = (tid == c) ? piv * dinv : cb[tid] * dinv;
+          if (tid >= c) pan[(size_t)tid * D + c] = l;
+          if (tid > c) rr[tid] = fma(-zc, l, rr[tid]);
+        }
+        if (tid == 255) pan[(size_t)W3 * D + c] = zc;
+      }
+      __syncthreads();
+      // registers -> window shifted up-left by D; rows 2D..3D-1 are re-assembled (or zeroed at the tail)
+#pragma unroll
+      for (int ka = 0; ka < NK; ++ka)
+#pragma unroll
+        for (int kb = 0; kb <= ka; ++kb) {
+          const int i = ti + 16 * ka, j = tj + 16 * kb;
+          if (i >= D && j >= D && i < W3 && j < W3) Wd[(size_t)(i - D) * LD + (j - D)] = v[ka][kb];
+        }
+      double rsh = (tid < D2) ? rr[tid + D] : 0.0;
+      __syncthreads();
+      if (tid < D2) rr[tid] = rsh;
+      for (int e = tid; e < D * LD; e += 256) Wd[(size_t)D2 * LD + e] = 0.0;
+      if (tid < D) rr[D2 + tid] = 0.0;
+      __syncthreads();
+      if (t + 3 < T) traj_add_block_row(Wd, rr, LD, D, t + 3, 2, T, mh, g, Qall);
+      __syncthreads();
+    }
+    traj_backsub<((W3 + 1) * D + 255) / 256>(ws, PAN, D, T, Wd, yring, wv, colb, U.Y);
+    if (tid == 0 && bad) status[0] = 1;
+    __syncthreads();
+  }
+}
+
 // LDS window: rows/cols 0..3D-1 = global rows t*D .. t*D+3D-1 of the band (row stride LD); after block column t is
 // finished the lower-right 2D x 2D part is shifted up-left by D (through registers) and block row t+3 is assembled
 // into the freed rows.  No index arithmetic beyond adds in the hot loops.
+static constexpr int kBackPre = (139 * 46 + 255) / 256;   // panel doubles per thread for the largest supported D
 static constexpr int kShiftRegs = 36;   // ceil(4*46^2 / 256) doubles per thread for the window shift
 
 __global__ void __launch_bounds__(256)
@@ -104,34 +327,7 @@ traj_solve_kernel(const TrajUtt *__restrict__ utts, int n, int D, const double *
     double *ws = ws_all + (size_t)blockIdx.x * ws_stride;
     if (tid == 0) bad = 0;
 
-    // assemble global block row a of P (and r) into local block row la of the window: blocks (a,a-2), (a,a-1), (a,a)
-    auto add_block_row = [&](int a, int la) {
-      const double *Qa = Qall + (size_t)(mh[a] - 1) * D2 * D2;
-      const double *Qm = (a >= 1) ? Qall + (size_t)(mh[a - 1] - 1) * D2 * D2 : nullptr;
-      const double *Qp = (a + 1 < T) ? Qall + (size_t)(mh[a + 1] - 1) * D2 * D2 : nullptr;
-      int i = tid / D, j = tid - i * D;                      // one division per call, then incremental
-      const int di = 256 / D, dj = 256 - di * D;
-      for (int e = tid; e < D * D; e += 256) {
-        double *row = Wd + (size_t)(la * D + i) * LD;
-        double v = Qa[(size_t)i * D2 + j];                                        // Qss(a)
-        if (Qm) v += 0.25 * Qm[(size_t)(D + i) * D2 + (D + j)];                   // + Qdd(a-1)/4
-        if (Qp) v += 0.25 * Qp[(size_t)(D + i) * D2 + (D + j)];                   // + Qdd(a+1)/4
-        row[la * D + j] = v;
-        if (la >= 1 && a >= 1)
-          row[(la - 1) * D + j] = 0.5 * Qm[(size_t)(D + i) * D2 + j] - 0.5 * Qa[(size_t)i * D2 + (D + j)];   // Qds(a-1)/2 - Qsd(a)/2
-        if (la >= 2 && a >= 2)
-          row[(la - 2) * D + j] = -0.25 * Qm[(size_t)(D + i) * D2 + (D + j)];     // -Qdd(a-1)/4
-        i += di;
-        j += dj;
-        if (j >= D) { j -= D; ++i; }
-      }
-      for (int k = tid; k < D; k += 256) {
-        double v = g[(size_t)a * D2 + k];
-        if (a >= 1) v += 0.5 * g[(size_t)(a - 1) * D2 + D + k];
-        if (a + 1 < T) v -= 0.5 * g[(size_t)(a + 1) * D2 + D + k];
-        rr[la * D + k] = v;
-      }
-    };
+    auto add_block_row = [&](int a, int la) { traj_add_block_row(Wd, rr, LD, D, a, la, T, mh, g, Qall); };
 
     for (int a = 0; a < 3 && a < T; ++a) add_block_row(a, a);
     __syncthreads();
@@ -144,7 +340,7 @@ traj_solve_kernel(const TrajUtt *__restrict__ utts, int n, int D, const double *
         // (a) pivot and scaled column into lcol (the window column itself is left untouched until (b))
         const double piv = Wd[(size_t)c * LD + c];
         if (!(piv > 0.0) && tid == 0) bad = 1;
-        const double dinv = 1.0 / sqrt(piv);
+        const double dinv = traj_rsqrt(piv);
         for (int lr = c + tid; lr < nrows; lr += 256) lcol[lr] = (lr == c) ? piv * dinv : Wd[(size_t)lr * LD + c] * dinv;
         if (tid == 255) zc_s = rr[c] * dinv;
         __syncthreads();
@@ -209,37 +405,7 @@ traj_solve_kernel(const TrajUtt *__restrict__ utts, int n, int D, const double *
       __syncthreads();
     }
 
-    // ---------------- back substitution  L' y = z ----------------
-    for (int i = tid; i < 2 * D; i += 256) yring[i] = 0.0;
-    __syncthreads();
-    for (int t = T - 1; t >= 0; --t) {
-      const double *pan = ws + (size_t)t * PAN;
-      double *y1 = yring + ((t + 1) & 1) * D, *y2 = yring + (t & 1) * D;   // y_{t+1}, y_{t+2}
-      // stage the diagonal block (needed row-wise by the triangular solve) in LDS
-      for (int e = tid; e < D * D; e += 256) Wd[e] = pan[e];
-      // w = z - E' y1 - F' y2  (thread j owns column j; panel rows D..3D-1 hold E then F)
-      if (tid < D) {
-        double s = pan[(size_t)W3 * D + tid];
-        for (int i = 0; i < D; ++i) s = fma(-pan[(size_t)(D + i) * D + tid], y1[i], s);
-        for (int i = 0; i < D; ++i) s = fma(-pan[(size_t)(2 * D + i) * D + tid], y2[i], s);
-        wv[tid] = s;
-      }
-      __syncthreads();
-      // Dg' y = w : sequential in k, one wave
-      if (tid < 64) {
-        double w = (tid < D) ? wv[tid] : 0.0;
-        for (int k = D - 1; k >= 0; --k) {
-          const double yk = __shfl(w, k) / Wd[(size_t)k * D + k];
-          if (tid == k) w = yk;
-          else if (tid < k) w = fma(-Wd[(size_t)k * D + tid], yk, w);
-        }
-        if (tid < D) {
-          y2[tid] = w;                       // becomes y_t; the slot of y_{t+2} is free now
-          U.Y[(size_t)t * D + tid] = w;      // reshape(y, D, T), src/trajectory_gmmmap.jl:109
-        }
-      }
-      __syncthreads();
-    }
+    traj_backsub<kBackPre>(ws, PAN, D, T, Wd, yring, wv, lcol, U.Y);
     if (tid == 0 && bad) status[0] = 1;
     __syncthreads();
   }
@@ -250,7 +416,8 @@ traj_solve_kernel(const TrajUtt *__restrict__ utts, int n, int D, const double *
 // ------------------------------------------------------------------------------------------------
 static size_t solve_lds_bytes(int D) {
   const size_t W3 = 3 * (size_t)D;
-  return (W3 * (W3 + 1) + 2 * W3 + 2 * D + D) * sizeof(double);
+  const size_t NK = (W3 + 15) / 16;
+  return (W3 * (W3 + 1) + 2 * W3 + 2 * NK * 16 + 2 * D + D) * sizeof(double);   // covers both solve kernels
 }
 
 static int traj_run(vcmi_traj *t, std::vector<TrajUtt> &utts, int64_t nframes, bool contiguous, const double *dX0,
@@ -290,10 +457,31 @@ static int traj_run(vcmi_traj *t, std::vector<TrajUtt> &utts, int64_t nframes, b
   std::stable_sort(utts.begin(), utts.end(), [](const TrajUtt &a, const TrajUtt &b) { return a.T > b.T; });
   VCMI_HIP(hipMemcpy(t->uttbuf.p, utts.data(), sizeof(TrajUtt) * n, hipMemcpyHostToDevice));
   const size_t shmem = solve_lds_bytes(D);
-  VCMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(traj_solve_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)shmem));
-  hipLaunchKernelGGL(traj_solve_kernel, dim3(grid), dim3(256), shmem, st, reinterpret_cast<const TrajUtt *>(t->uttbuf.p), n, D,
-                     t->Q.p, t->mhat.p, t->gbuf.p, t->ws.p, ws_stride, t->status.p);
+  const TrajUtt *du = reinterpret_cast<const TrajUtt *>(t->uttbuf.p);
+  bool launched = false;
+  if (!getenv("VCMI_TRAJ_GENERIC")) {
+    switch (D) {
+#define VCMI_TRAJ_CASE(DV)                                                                                          \
+  case DV: {                                                                                                        \
+    auto kern = traj_solve_reg_kernel<DV>;                                                                          \
+    VCMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,  \
+                                 (int)shmem));                                                                      \
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), shmem, st, du, n, t->Q.p, t->mhat.p, t->gbuf.p, t->ws.p, ws_stride, \
+                       t->status.p);                                                                                \
+    launched = true;                                                                                                \
+  } break;
+      VCMI_TRAJ_CASE(12) VCMI_TRAJ_CASE(16) VCMI_TRAJ_CASE(20) VCMI_TRAJ_CASE(24) VCMI_TRAJ_CASE(25) VCMI_TRAJ_CASE(30)
+      VCMI_TRAJ_CASE(32) VCMI_TRAJ_CASE(40)
+#undef VCMI_TRAJ_CASE
+      default: break;
+    }
+  }
+  if (!launched) {
+    VCMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(traj_solve_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)shmem));
+    hipLaunchKernelGGL(traj_solve_kernel, dim3(grid), dim3(256), shmem, st, du, n, D, t->Q.p, t->mhat.p, t->gbuf.p, t->ws.p,
+                       ws_stride, t->status.p);
+  }
   VCMI_HIP(hipGetLastError());
   return VCMI_OK;
 }
