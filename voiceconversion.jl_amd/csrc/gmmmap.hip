@@ -33,10 +33,11 @@ namespace vcmi {
 // ------------------------------------------------------------------------------------------------
 // compile-time description of the row tiling for a padded dimension DP (multiple of 4)
 // ------------------------------------------------------------------------------------------------
-template <int DP>
+// UONLY: only the whitening rows U_m (log-density / posterior / argmax path: the regression rows are not staged)
+template <int DP, bool UONLY = false>
 struct Tiling {
   static constexpr int KS = DP / 4;                       // k-steps covering all of x
-  static constexpr int NT = (2 * DP + 15) / 16;           // 16-row tiles over [U rows ; A rows]
+  static constexpr int NT = UONLY ? (DP + 15) / 16 : (2 * DP + 15) / 16;   // 16-row tiles over [U rows ; A rows]
   static constexpr int NU = (DP + 15) / 16;               // tiles that contain at least one U row
   __host__ __device__ static constexpr int steps(int t) {  // k-steps tile t needs
     return (16 * t + 15 < DP) ? ((4 * (t + 1) < KS) ? 4 * (t + 1) : KS) : KS;
@@ -56,9 +57,9 @@ struct Tiling {
 // runtime mirror used by the host-side packer (same formulas, any DP)
 struct TilingRT {
   int DP, KS, NT, NU, NSTEPS, CINIT_OFF, LC_OFF, BLK;
-  explicit TilingRT(int dp) : DP(dp) {
+  explicit TilingRT(int dp, bool uonly = false) : DP(dp) {
     KS = DP / 4;
-    NT = (2 * DP + 15) / 16;
+    NT = uonly ? (DP + 15) / 16 : (2 * DP + 15) / 16;
     NU = (DP + 15) / 16;
     NSTEPS = 0;
     for (int t = 0; t < NT; ++t) NSTEPS += steps(t);
@@ -83,7 +84,7 @@ template <int DP, int FT, int WAVES, int MODE, int NBUF>
 __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(DP <= 40 ? (FT == 2 ? 3 : 4) : 2)))
 gmmmap_mfma_kernel(const double *__restrict__ packed, int M, int D, const double *__restrict__ X, int64_t ldx,
                    int64_t T, double *__restrict__ Y, int64_t ldy) {
-  using TL = Tiling<DP>;
+  using TL = Tiling<DP, MODE == 1>;
   constexpr int KS = TL::KS, NT = TL::NT, NU = TL::NU, BLK = TL::BLK;
   constexpr int NTHREADS = WAVES * 64;
   constexpr int NV = BLK / 2 / NTHREADS;   // double2 copies per thread per block (BLK is a multiple of 1024)
@@ -365,9 +366,9 @@ posterior_finish_kernel(double *__restrict__ LP, int M, int64_t T, int64_t *__re
 template <int DP, int MODE, int FTV, int WV>
 static int launch_mfma(const vcmi_gmmmap *g, const double *dX, int64_t ldx, int64_t T, double *dY, int64_t ldy,
                        hipStream_t st) {
-  constexpr int FT = FTV;
+  constexpr int FT = (MODE == 1) ? 2 : FTV;
   constexpr int WAVES = WV;
-  using TL = Tiling<DP>;
+  using TL = Tiling<DP, MODE == 1>;
   // double-buffer the per-mixture block when two copies fit in half of the CU's 160 KiB LDS
   constexpr int NBUF = (2 * (size_t)TL::BLK * sizeof(double) <= 80 * 1024) ? 2 : 1;
   const size_t shmem = NBUF * (size_t)TL::BLK * sizeof(double);
@@ -380,8 +381,8 @@ static int launch_mfma(const vcmi_gmmmap *g, const double *dX, int64_t ldx, int6
   }
   const int64_t per_wg = (int64_t)16 * FT * WAVES;
   const int64_t blocks = (T + per_wg - 1) / per_wg;
-  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(WAVES * 64), shmem, st, g->packed.p, g->M, g->D, dX, ldx, T, dY,
-                     ldy);
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(WAVES * 64), shmem, st, MODE == 1 ? g->packedU.p : g->packed.p, g->M,
+                     g->D, dX, ldx, T, dY, ldy);
   VCMI_HIP(hipGetLastError());
   return VCMI_OK;
 }
@@ -545,20 +546,20 @@ static int prepare(vcmi_gmmmap *g, const double *w, const double *mu, const doub
   VCMI_HIP(hipMemcpy(g->lc.p, hlc.data(), hlc.size() * 8, hipMemcpyHostToDevice));
 
   // packed operand blocks for the MFMA kernel (issue order: phase U k-major over U tiles, then phase A)
-  if (gmmmap_has_mfma(DP)) {
-    TilingRT tl(DP);
+  for (int uonly = 0; uonly < 2 && gmmmap_has_mfma(DP); ++uonly) {
+    TilingRT tl(DP, uonly != 0);
     std::vector<double> pk((size_t)tl.BLK * M, 0.0);
     auto wrow = [&](int m, int p, int k) -> double {   // row p of [U_m ; A_m], column k
       if (k >= DP) return 0.0;
       if (p < DP) return hU[pp * m + (size_t)p * DP + k];
-      if (p < 2 * DP) return hA[pp * m + (size_t)(p - DP) * DP + k];
+      if (p < 2 * DP && !uonly) return hA[pp * m + (size_t)(p - DP) * DP + k];
       return 0.0;
     };
     for (int m = 0; m < M; ++m) {
       double *blk = &pk[(size_t)tl.BLK * m];
       int s = 0;
       for (int phase = 0; phase < 2; ++phase) {
-        const int t0 = phase == 0 ? 0 : tl.NU, t1 = phase == 0 ? tl.NU : tl.NT;
+        const int t0 = phase == 0 ? 0 : tl.NU, t1 = phase == 0 ? std::min(tl.NU, tl.NT) : tl.NT;
         for (int ks = 0; ks < tl.KS; ++ks)
           for (int t = t0; t < t1; ++t) {
             if (ks >= tl.steps(t)) continue;
@@ -569,13 +570,14 @@ static int prepare(vcmi_gmmmap *g, const double *w, const double *mu, const doub
       for (int p = 0; p < tl.NT * 16; ++p) {
         double c = 0.0;
         if (p < DP) c = -hcz[(size_t)DP * m + p];
-        else if (p < 2 * DP) c = hb[(size_t)DP * m + (p - DP)];
+        else if (p < 2 * DP && !uonly) c = hb[(size_t)DP * m + (p - DP)];
         blk[tl.CINIT_OFF + p] = c;
       }
       blk[tl.LC_OFF] = hlc[m];
     }
-    VCMI_TRY(g->packed.alloc(pk.size()));
-    VCMI_HIP(hipMemcpy(g->packed.p, pk.data(), pk.size() * 8, hipMemcpyHostToDevice));
+    DevBuf<double> &dst = uonly ? g->packedU : g->packed;
+    VCMI_TRY(dst.alloc(pk.size()));
+    VCMI_HIP(hipMemcpy(dst.p, pk.data(), pk.size() * 8, hipMemcpyHostToDevice));
   }
   return VCMI_OK;
 }

@@ -16,7 +16,8 @@ struct vcmi_gmmmap {
   // device parameters, generic layout: [M][DP][DP] row-major / [M][DP] / [M]
   vcmi::DevBuf<double> U, A, cz, b, lc;
   // device parameters, MFMA fragment order: [M][Tiling::BLK]
-  vcmi::DevBuf<double> packed;
+  vcmi::DevBuf<double> packed;    // [U_m ; A_m] tiles (convert)
+  vcmi::DevBuf<double> packedU;   // U_m tiles only (log-density / posterior / argmax)
 
   // grow-only device scratch for the host-pointer entry points
   vcmi::DevBuf<double> scratch_x, scratch_y, scratch_lp;
