@@ -135,9 +135,10 @@ estep_mfma_kernel(const double *__restrict__ X, int64_t N, int M, const double *
   double wfrag[KS];
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) wfrag[ks] = Wpack[((size_t)wave * KS + ks) * 64 + lane];
-  d4 cin;
-#pragma unroll
-  for (int r = 0; r < 4; ++r) cin[r] = cinit[16 * wave + 4 * r + lgrp];
+  // step A computes the TRANSPOSED tile (rows = frames, cols = this wave's mixtures) by swapping the MFMA operands:
+  // the result then lands in LDS with lanes along consecutive mixtures -> conflict-free stores
+  const double cm = cinit[16 * wave + lcol];
+  const d4 cin = {cm, cm, cm, cm};
 
   d4 sacc[NDT];   // statistics tiles: rows = this wave's 16 mixtures, cols = 16 of the 2*DJ columns [x | x^2]
   double s0l = 0.0;   // sum over this lane's frames of gamma[f][m = 16 wave + lcol]
@@ -162,45 +163,46 @@ estep_mfma_kernel(const double *__restrict__ X, int64_t N, int M, const double *
 #pragma unroll
       for (int ks = 0; ks < KS / 2; ++ks) {
         const double x = xr[4 * ks];
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(wfrag[ks], x * x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x * x, wfrag[ks], acc, 0, 0, 0);
       }
 #pragma unroll
       for (int ks = 0; ks < KS / 2; ++ks) {
         const double x = xr[4 * ks];
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(wfrag[KS / 2 + ks], x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x, wfrag[KS / 2 + ks], acc, 0, 0, 0);
       }
 #pragma unroll
-      for (int r = 0; r < 4; ++r) lg[(16 * ft + lcol) * RSG + 16 * wave + 4 * r + lgrp] = acc[r];
+      for (int r = 0; r < 4; ++r) lg[(16 * ft + 4 * r + lgrp) * RSG + 16 * wave + lcol] = acc[r];
     }
     __syncthreads();
-    // ---- softmax over the 128 mixture slots of each frame: 8 lanes per frame, 16 slots per lane ----
-    {
-      const int f = tid >> 3, part8 = tid & 7;
-      double *row = lg + f * RSG + 16 * part8;
-      double v[16];
+    // ---- softmax over the 128 mixture slots of each frame.  16 lanes per frame, lane lcol owns slots lcol + 16 i:
+    //      per instruction a 32-lane group touches 2 frame rows x 16 consecutive doubles, which with RSG == 16 mod 32
+    //      is conflict-free (same pattern as step B's gamma reads) ----
+#pragma unroll
+    for (int ps = 0; ps < FB / 32; ++ps) {
+      const int f = 32 * ps + 4 * wave + lgrp;
+      double *row = lg + f * RSG + lcol;
+      double v[C::MMAX / 16];
       double u = -INFINITY;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        v[i] = row[i];
+      for (int i = 0; i < C::MMAX / 16; ++i) {
+        v[i] = row[16 * i];
         u = fmax(u, v[i]);
       }
-      u = fmax(u, __shfl_xor(u, 1));
-      u = fmax(u, __shfl_xor(u, 2));
-      u = fmax(u, __shfl_xor(u, 4));
+#pragma unroll
+      for (int sh = 1; sh < 16; sh <<= 1) u = fmax(u, __shfl_xor(u, sh));
       double s = 0.0;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
+      for (int i = 0; i < C::MMAX / 16; ++i) {
         v[i] = exp(v[i] - u);
         s += v[i];
       }
-      s += __shfl_xor(s, 1);
-      s += __shfl_xor(s, 2);
-      s += __shfl_xor(s, 4);
+#pragma unroll
+      for (int sh = 1; sh < 16; sh <<= 1) s += __shfl_xor(s, sh);
       const bool livef = (f0 + f < N);
       const double inv = livef ? 1.0 / s : 0.0;          // frames beyond N contribute gamma = 0
 #pragma unroll
-      for (int i = 0; i < 16; ++i) row[i] = v[i] * inv;
-      if (part8 == 0 && livef) llacc += u + log(s);
+      for (int i = 0; i < C::MMAX / 16; ++i) row[16 * i] = v[i] * inv;
+      if (lcol == 0 && livef) llacc += u + log(s);
     }
     __syncthreads();
     // ---- step B: S[m][c] += sum_f gamma[f][m] Xe[f][c],  Xe = [x | x^2];  S0[m] += sum_f gamma[f][m] ----
