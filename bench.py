@@ -140,6 +140,14 @@ def bench_convert(args, world, rank):
                      "traffic": None, "flop_per_frame": convert_flops_per_frame(D, M), "kernel_ms": kernel_ms,
                      "hbm_GBps_algorithmic": 2 * D * 8 * T / (kernel_ms * 1e-3) / 1e9},
     }
+    # HBM traffic of the kernel from the committed PMC passes (cannot be collected inside the timed run)
+    try:
+        tr = json.load(open(os.path.join(ROOT, "profiles", "r01b_pmc", "convert_traffic.json")))
+        if tr["frames"] == T:
+            out["roofline"]["traffic"] = tr["hbm_bytes_per_launch_raw"]
+            out["roofline"]["traffic_unit"] = "bytes per launch (rocprofv3 FETCH_SIZE+WRITE_SIZE, see profiles/r01b_pmc/)"
+    except (OSError, KeyError, ValueError):
+        pass
     if rank == 0:
         from oracle import c_oracle as co
 
