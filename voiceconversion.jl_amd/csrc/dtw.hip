@@ -98,8 +98,8 @@ __device__ void dtw_finish(const DtwPair &P, const double *__restrict__ seq, int
 // (1) dtw_obs_kernel<DMAX>: the observation costs O[i,t] = sum_d (seq[d,t] - tmpl[d,i])^2 of every cell, which do
 //     not depend on the recurrence, are computed with NO barrier: lane = template frame (its D values in VGPRs),
 //     the sequence column is wave-uniform and arrives through scalar loads (`feats` is a read-only, non-aliased
-//     kernel argument), i.e. as SGPR operands of the FP64 ALU -- no LDS traffic, no per-lane loads.  (64-bit
-//     same-address LDS reads were measured to serialise per lane on gfx950, which ruled out an LDS broadcast.)
+//     kernel argument), i.e. as SGPR operands of the FP64 ALU -- no LDS traffic, no per-lane loads.  (An LDS-staged
+//     broadcast variant measured 2x slower than per-lane loads: the LDS pipe, not the FP64 ALU, became the limiter.)
 //     Arithmetic order: sequential in d, unfused sub / mul / add (bit-exact contract).  O goes to an HBM workspace
 //     in the cost table's (S,T) column-major order, so writes and the later reads are coalesced.
 // (2) dtw_rec_kernel<STEPS,CODES>: one workgroup per pair, thread r = template frame r: per column a handful of
