@@ -52,10 +52,17 @@ def dist_setup(n_gpus):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local)
+    # VCMI_BENCH_DEVICE / VCMI_BENCH_BACKEND exist only to smoke-test the multi-rank code path on a 1-GPU box
+    # (all ranks on one device, gloo); the real launch is one rank per GPU over RCCL ("nccl").
+    dev = int(os.environ.get("VCMI_BENCH_DEVICE", local))
+    backend = os.environ.get("VCMI_BENCH_BACKEND", "nccl")
+    torch.cuda.set_device(dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+        else:
+            dist.init_process_group(backend)
     return world, rank, local
 
 
