@@ -31,7 +31,7 @@ struct DtwPair {
   int64_t *bp;          // (S,T+1) or null
   double *newtgt;       // (D,S) or null: align() output
   unsigned char *codes; // (S,T) bytes in HBM, used only when the step codes do not fit in LDS
-  double *obs;          // (S,T) observation costs (fast path workspace)
+  int64_t obs_off;      // (S,T) observation costs at obs_ws + obs_off (fast path workspace)
   int64_t spad_off;     // offset of the zero-padded sequence copy (fast path, D != DMAX)
   int32_t S, T;
 };
@@ -46,20 +46,38 @@ __device__ void dtw_finish(const DtwPair &P, const double *__restrict__ seq, int
                            int32_t *holes, const uint32_t *codes_lds, int Smax) {
   constexpr int CPW = 32 / BITS;
   const int S = P.S, T = P.T, tid = threadIdx.x, nthr = blockDim.x;
-  if (tid == 0) {
-    int best = 0;                                   // indmin: first minimum, src/dtw.jl:137
-    double bv = clast[0];
-    for (int i = 1; i < S; ++i) {
+  // indmin of the last column (first minimum wins, src/dtw.jl:137): per-thread scan of a strided slice, wave
+  // reduction on (value, index) with shuffles, then thread 0 combines the per-wave winners through LDS
+  {
+    double bv = INFINITY;
+    int bi = 0x7fffffff;
+    for (int i = tid; i < S; i += nthr) {
       const double c = clast[i];
-      if (c < bv) { bv = c; best = i; }
+      if (c < bv) { bv = c; bi = i; }                 // strided, increasing i: keeps the first minimum of the slice
     }
-    path32[T - 1] = best;
-    for (int t = T - 1; t >= 1; --t) {              // src/dtw.jl:140-142
-      const int row = path32[t];
-      int code;
-      if (LDSCODES) code = (codes_lds[(t / CPW) * Smax + row] >> (BITS * (t % CPW))) & ((1u << BITS) - 1u);
-      else code = P.codes[(size_t)S * t + row];
-      path32[t - 1] = row - (code - fstep);
+#pragma unroll
+    for (int sh = 1; sh < 64; sh <<= 1) {
+      const double ov = __shfl_xor(bv, sh);
+      const int oi = __shfl_xor(bi, sh);
+      if (ov < bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    __shared__ double wv_[16];
+    __shared__ int wi_[16];
+    if ((tid & 63) == 0) { wv_[tid >> 6] = bv; wi_[tid >> 6] = bi; }
+    __syncthreads();
+    if (tid == 0) {
+      const int nw = (nthr + 63) >> 6;
+      for (int w = 1; w < nw; ++w)
+        if (wv_[w] < bv || (wv_[w] == bv && wi_[w] < bi)) { bv = wv_[w]; bi = wi_[w]; }
+      int row = bi;
+      path32[T - 1] = row;
+      for (int t = T - 1; t >= 1; --t) {              // src/dtw.jl:140-142; `row` stays in a register
+        int code;
+        if (LDSCODES) code = (codes_lds[(t / CPW) * Smax + row] >> (BITS * (t % CPW))) & ((1u << BITS) - 1u);
+        else code = P.codes[(size_t)S * t + row];
+        row -= code - fstep;
+        path32[t - 1] = row;
+      }
     }
   }
   __syncthreads();
@@ -128,7 +146,7 @@ dtw_pad_kernel(const double *__restrict__ feats, const DtwPair *__restrict__ pai
 template <int DMAX>
 __global__ void __launch_bounds__(kObsRows)
 dtw_obs_kernel(const double *__restrict__ feats, const double *__restrict__ sbase, int padded,
-               const DtwPair *__restrict__ pairs, int D) {
+               const DtwPair *__restrict__ pairs, int D, double *__restrict__ obs_ws) {
   const DtwPair P = pairs[blockIdx.x];
   const int S = P.S, T = P.T;
   const int r = blockIdx.y * kObsRows + threadIdx.x;
@@ -140,7 +158,7 @@ dtw_obs_kernel(const double *__restrict__ feats, const double *__restrict__ sbas
 #pragma unroll
   for (int d = 0; d < DMAX; ++d) tm[d] = (active && d < D) ? feats[P.tmpl_off + (int64_t)D * r + d] : 0.0;
   const int t1 = (t0 + kObsCols < T) ? t0 + kObsCols : T;
-  double *__restrict__ O = P.obs;
+  double *__restrict__ O = obs_ws + P.obs_off;   // kernel-argument base: global (not flat) stores
   for (int t = t0; t < t1; ++t) {
     const double *__restrict__ v = seq + (size_t)DMAX * t;   // wave-uniform -> scalar loads
     double o = 0.0;                                       // observation(d, v, i), src/dtw.jl:33-35
@@ -157,11 +175,11 @@ dtw_obs_kernel(const double *__restrict__ feats, const double *__restrict__ sbas
 template <int STEPS, int CODES>
 __global__ void __launch_bounds__(1024)
 dtw_rec_kernel(const double *__restrict__ feats, const DtwPair *__restrict__ pairs, int D, int fstep, int bstep, int Smax,
-               int Tmax) {
+               int Tmax, const double *__restrict__ obs_ws) {
   constexpr bool LDSCODES = (CODES != 2);
   constexpr int BITS = (CODES == 0) ? 2 : 8;
   constexpr int CPW = 32 / BITS;
-  constexpr int PF = 4;                                   // columns of O in flight per thread
+  constexpr int PF = 8;                                   // columns of O per register set
   const DtwPair P = pairs[blockIdx.x];
   const int S = P.S, T = P.T;
   const int r = threadIdx.x;
@@ -173,7 +191,9 @@ dtw_rec_kernel(const double *__restrict__ feats, const DtwPair *__restrict__ pai
   int32_t *holes = owner + Smax;                                  // [Smax]
   uint32_t *codes = reinterpret_cast<uint32_t *>(holes + Smax);   // [ceil(Tmax/CPW)][Smax] when LDSCODES
   if (T == 0) return;
-  const double *__restrict__ O = P.obs;
+  // kernel-argument base -> global_load with counted vmcnt (a pointer loaded from the descriptor would be a FLAT
+  // load, which must be waited for with vmcnt(0) and would serialise the prefetch)
+  const double *__restrict__ O = obs_ws + P.obs_off;
 
   // lazy_init!: costtable[:,1] = 1:S, backpointer[:,1] = 1:S  (src/dtw.jl:49-50)
   double cprev = (double)(r + 1);
@@ -182,57 +202,70 @@ dtw_rec_kernel(const double *__restrict__ feats, const DtwPair *__restrict__ pai
     if (P.cost) P.cost[r] = cprev;
     if (P.bp) P.bp[r] = r + 1;
   }
-  double opf[PF];
-#pragma unroll
-  for (int k = 0; k < PF; ++k) opf[k] = (active && k < T) ? O[(size_t)S * k + r] : 0.0;
-  __syncthreads();
-
-  uint32_t word = 0;
-  for (int t0 = 0; t0 < T; t0 += PF) {
+  // O is read PF columns at a time into one of two register sets (ping-pong, unconditional clamped loads issued as
+  // a batch) while the other set is consumed, so HBM latency is covered by PF columns of recurrence work.
+  const int rl = active ? r : 0;
+  auto load_set = [&](double (&dst)[PF], int tbase) {
 #pragma unroll
     for (int k = 0; k < PF; ++k) {
-      const int t = t0 + k;
-      if (t < T) {                                        // wave-uniform
-        const double *cp = cbuf + (t & 1) * Smax;
-        double *cn = cbuf + ((t + 1) & 1) * Smax;
-        if (active) {
-          const double o = opf[k];
-          opf[k] = (t + PF < T) ? O[(size_t)S * (t + PF) + r] : 0.0;   // refill this slot PF columns ahead
-          int arg = r;                                    // minindex = i, src/dtw.jl:106-110
-          double best = (cprev + o) + 1.0;
-          if (STEPS == 0) {
-            for (int j = r - bstep; j <= r + fstep; ++j) {  // src/dtw.jl:113-121
-              if (j < 0 || j >= S) continue;
-              const double c = (cp[j] + o) + dtw_transition(j, r);
-              if (c < best) { best = c; arg = j; }
-            }
-          } else {
-            // window j = r-STEPS .. r, increasing j; j == r repeats the start value and never wins the strict '<'
-            if (STEPS == 2) {
-              const double c2 = (cp[r >= 2 ? r - 2 : r] + o) + 2.0;
-              if (r >= 2 && c2 < best) { best = c2; arg = r - 2; }
-            }
-            const double c1 = (cp[r >= 1 ? r - 1 : r] + o) + 0.0;
-            if (r >= 1 && c1 < best) { best = c1; arg = r - 1; }
-          }
-          cn[r] = best;
-          cprev = best;
-          if (P.cost) P.cost[(size_t)S * (t + 1) + r] = best;
-          if (P.bp) P.bp[(size_t)S * (t + 1) + r] = arg + 1;
-          const uint32_t code = (uint32_t)(r - arg + fstep);
-          if (LDSCODES) {
-            word |= code << (BITS * (t % CPW));
-            if ((t % CPW) == CPW - 1 || t == T - 1) {
-              codes[(t / CPW) * Smax + r] = word;
-              word = 0;
-            }
-          } else {
-            P.codes[(size_t)S * t + r] = (unsigned char)code;
-          }
+      int tc = tbase + k;
+      tc = tc < T ? tc : T - 1;
+      dst[k] = O[(size_t)S * tc + rl];
+    }
+  };
+  uint32_t word = 0;
+  auto column = [&](int t, double o) {
+    const double *cp = cbuf + (t & 1) * Smax;
+    double *cn = cbuf + ((t + 1) & 1) * Smax;
+    if (active) {
+      int arg = r;                                    // minindex = i, src/dtw.jl:106-110
+      double best = (cprev + o) + 1.0;
+      if (STEPS == 0) {
+        for (int j = r - bstep; j <= r + fstep; ++j) {  // src/dtw.jl:113-121
+          if (j < 0 || j >= S) continue;
+          const double c = (cp[j] + o) + dtw_transition(j, r);
+          if (c < best) { best = c; arg = j; }
         }
-        __syncthreads();
+      } else {
+        // window j = r-STEPS .. r, increasing j; j == r repeats the start value and never wins the strict '<'
+        if (STEPS == 2) {
+          const double c2 = (cp[r >= 2 ? r - 2 : r] + o) + 2.0;
+          if (r >= 2 && c2 < best) { best = c2; arg = r - 2; }
+        }
+        const double c1 = (cp[r >= 1 ? r - 1 : r] + o) + 0.0;
+        if (r >= 1 && c1 < best) { best = c1; arg = r - 1; }
+      }
+      cn[r] = best;
+      cprev = best;
+      if (P.cost) P.cost[(size_t)S * (t + 1) + r] = best;
+      if (P.bp) P.bp[(size_t)S * (t + 1) + r] = arg + 1;
+      const uint32_t code = (uint32_t)(r - arg + fstep);
+      if (LDSCODES) {
+        word |= code << (BITS * (t % CPW));
+        if ((t % CPW) == CPW - 1 || t == T - 1) {
+          codes[(t / CPW) * Smax + r] = word;
+          word = 0;
+        }
+      } else {
+        P.codes[(size_t)S * t + r] = (unsigned char)code;
       }
     }
+    // column barrier that waits for the LDS traffic only: __syncthreads() would also drain vmcnt, i.e. stall every
+    // column on the O prefetches that are meant to stay in flight
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  };
+  double oa[PF], ob[PF];
+  load_set(oa, 0);
+  __syncthreads();
+  for (int t0 = 0; t0 < T; t0 += 2 * PF) {
+    load_set(ob, t0 + PF);
+#pragma unroll
+    for (int k = 0; k < PF; ++k)
+      if (t0 + k < T) column(t0 + k, oa[k]);              // wave-uniform guard
+    load_set(oa, t0 + 2 * PF);
+#pragma unroll
+    for (int k = 0; k < PF; ++k)
+      if (t0 + PF + k < T) column(t0 + PF + k, ob[k]);
   }
   if (!LDSCODES) {
     __threadfence();
@@ -303,13 +336,13 @@ struct DtwLaunch {
 };
 
 static int launch_rec(const double *feats, const DtwPair *dpairs, int n, int D, int fstep, int bstep, int Smax, int Tmax,
-                      int steps, int codes, size_t shmem, int threads, hipStream_t st) {
+                      int steps, int codes, size_t shmem, int threads, const double *obs_ws, hipStream_t st) {
 #define VCMI_DTW_LAUNCH(ST, CO)                                                                                \
   do {                                                                                                         \
     auto kern = dtw_rec_kernel<ST, CO>;                                                                        \
     VCMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
                                  (int)shmem));                                                                 \
-    hipLaunchKernelGGL(kern, dim3(n), dim3(threads), shmem, st, feats, dpairs, D, fstep, bstep, Smax, Tmax);   \
+    hipLaunchKernelGGL(kern, dim3(n), dim3(threads), shmem, st, feats, dpairs, D, fstep, bstep, Smax, Tmax, obs_ws); \
   } while (0)
   if (steps == 1 && codes == 0) VCMI_DTW_LAUNCH(1, 0);
   else if (steps == 1) VCMI_DTW_LAUNCH(1, 2);
@@ -328,7 +361,7 @@ static int dtw_dmax(int D) {
 }
 
 static int launch_obs(const double *feats, const double *spad, const DtwPair *dpairs, int n, int D, int Smax, int Tmax,
-                      hipStream_t st) {
+                      double *obs_ws, hipStream_t st) {
   const dim3 grid(n, (Smax + kObsRows - 1) / kObsRows, (Tmax + kObsCols - 1) / kObsCols);
   const int dmax = dtw_dmax(D);
   const int padded = (D != dmax);
@@ -336,7 +369,7 @@ static int launch_obs(const double *feats, const double *spad, const DtwPair *dp
   if (padded) hipLaunchKernelGGL(dtw_pad_kernel, dim3(n, 8), dim3(256), 0, st, feats, dpairs, D, dmax, const_cast<double *>(spad));
   switch (dmax) {
 #define VCMI_OBS_CASE(DM) \
-  case DM: hipLaunchKernelGGL(dtw_obs_kernel<DM>, grid, dim3(kObsRows), 0, st, feats, sbase, padded, dpairs, D); break;
+  case DM: hipLaunchKernelGGL(dtw_obs_kernel<DM>, grid, dim3(kObsRows), 0, st, feats, sbase, padded, dpairs, D, obs_ws); break;
     VCMI_OBS_CASE(8) VCMI_OBS_CASE(16) VCMI_OBS_CASE(24) VCMI_OBS_CASE(32) VCMI_OBS_CASE(40) VCMI_OBS_CASE(48)
     VCMI_OBS_CASE(64) VCMI_OBS_CASE(96)
 #undef VCMI_OBS_CASE
@@ -408,7 +441,7 @@ static int dtw_run(const double *feats, std::vector<DtwPair> &pairs, int D, int 
       size_t off = 0, poff = 0;
       int smax = 0, tmax = 0;
       for (int k = lo; k < hi; ++k) {
-        pairs[k].obs = obs_ws.p + off;
+        pairs[k].obs_off = (int64_t)off;
         off += (size_t)pairs[k].S * pairs[k].T;
         pairs[k].spad_off = (int64_t)poff;
         poff += (size_t)pairs[k].T * dmax;
@@ -417,8 +450,8 @@ static int dtw_run(const double *feats, std::vector<DtwPair> &pairs, int D, int 
       }
       VCMI_HIP(hipMemcpy(dpairs.p + lo, pairs.data() + lo, sizeof(DtwPair) * (hi - lo), hipMemcpyHostToDevice));
       if (tmax > 0) {
-        VCMI_TRY(launch_obs(feats, spad_ws.p, dpairs.p + lo, hi - lo, D, smax, tmax, st));
-        VCMI_TRY(launch_rec(feats, dpairs.p + lo, hi - lo, D, fstep, bstep, Smax, Tmax, steps, codes, shmem, threads, st));
+        VCMI_TRY(launch_obs(feats, spad_ws.p, dpairs.p + lo, hi - lo, D, smax, tmax, obs_ws.p, st));
+        VCMI_TRY(launch_rec(feats, dpairs.p + lo, hi - lo, D, fstep, bstep, Smax, Tmax, steps, codes, shmem, threads, obs_ws.p, st));
       }
       if (hi < n) VCMI_HIP(hipStreamSynchronize(st));   // the next slice reuses the workspace
       lo = hi;
@@ -489,7 +522,7 @@ static int dtw_host_batch(int64_t n, const double *const *tmpl, const int64_t *S
     q.newtgt = newtgt ? sc.newtgt.p + to : nullptr;
     to += (size_t)D * S[p];
     q.codes = nullptr;
-    q.obs = nullptr;
+    q.obs_off = 0;
     q.spad_off = 0;
     q.S = (int32_t)S[p];
     q.T = (int32_t)T[p];
@@ -551,7 +584,7 @@ extern "C" int vcmi_dtw_fit_batch_dev(int64_t n, const double *feats, const int6
   std::vector<DtwPair> pairs(n);
   for (int64_t p = 0; p < n; ++p) {
     if (S[p] < 1 || T[p] < 0 || S[p] > INT32_MAX || T[p] > INT32_MAX) return fail(VCMI_ERR_DIM, "DTW: bad sequence length");
-    pairs[p] = DtwPair{tmpl_off[p], seq_off[p], paths + path_off[p], nullptr, nullptr, nullptr, nullptr, nullptr, 0,
+    pairs[p] = DtwPair{tmpl_off[p], seq_off[p], paths + path_off[p], nullptr, nullptr, nullptr, nullptr, 0, 0,
                        (int32_t)S[p], (int32_t)T[p]};
   }
   DtwScratch &sc = scratch();
