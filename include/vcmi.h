@@ -75,7 +75,8 @@ int vcmi_gmmmap_posterior_dev(vcmi_gmmmap *g, const double *dX, int64_t ldx, int
 int vcmi_gmmmap_predict(vcmi_gmmmap *g, const double *X, int64_t ldx, int64_t T, int64_t *idx);
 int vcmi_gmmmap_predict_dev(vcmi_gmmmap *g, const double *dX, int64_t ldx, int64_t T, int64_t *didx, void *stream);
 /* Kernel selection for convert: 0 = auto (MFMA tile kernel when dim(g) has an instantiation, else the
- * generic VALU kernel), 1 = force the generic VALU kernel, 2 = force MFMA (VCMI_ERR_ARG if unavailable). */
+ * generic VALU kernel), 1 = force the generic VALU kernel, 2 = force MFMA (VCMI_ERR_ARG if unavailable),
+ * 3 = MFMA kernel with 4-mixture row grouping (experimental alternative tiling; D = 24 or 40 only). */
 int vcmi_gmmmap_set_kernel(vcmi_gmmmap *g, int which);
 
 /* ---------------------------------------------------------------------------------------------

@@ -440,6 +440,7 @@ int gmmmap_convert_device(vcmi_gmmmap *g, const double *dX, int64_t ldx, int64_t
   if (T == 0) return VCMI_OK;
   if (g->kernel_choice == 2 && !gmmmap_has_mfma(g->DP))
     return fail(VCMI_ERR_ARG, "MFMA kernel forced but dimension %d has no instantiation", g->D);
+  if (g->kernel_choice == 3) return gmmmap_convert_g4_device(g, dX, ldx, T, dY, ldy, st);
   if (use_mfma(g)) return dispatch_mfma<0>(g, dX, ldx, T, dY, ldy, st);
   return launch_generic<0>(g, dX, ldx, T, dY, ldy, st);
 }
@@ -579,6 +580,7 @@ static int prepare(vcmi_gmmmap *g, const double *w, const double *mu, const doub
     VCMI_TRY(dst.alloc(pk.size()));
     VCMI_HIP(hipMemcpy(dst.p, pk.data(), pk.size() * 8, hipMemcpyHostToDevice));
   }
+  VCMI_TRY(gmmmap_pack_g4(g, hU, hA, hcz, hb, hlc));
   return VCMI_OK;
 }
 
@@ -619,7 +621,8 @@ extern "C" int vcmi_gmmmap_get_A(const vcmi_gmmmap *g, double *A) {
   return VCMI_OK;
 }
 extern "C" int vcmi_gmmmap_set_kernel(vcmi_gmmmap *g, int which) {
-  if (!g || which < 0 || which > 2) return fail(VCMI_ERR_ARG, "vcmi_gmmmap_set_kernel: bad argument");
+  if (!g || which < 0 || which > 3) return fail(VCMI_ERR_ARG, "vcmi_gmmmap_set_kernel: bad argument");
+  if (which == 3 && !gmmmap_has_g4(g->DP)) return fail(VCMI_ERR_ARG, "no grouped-tiling instantiation for dimension %d", g->D);
   if (which == 2 && !gmmmap_has_mfma(g->DP)) return fail(VCMI_ERR_ARG, "no MFMA instantiation for dimension %d", g->D);
   g->kernel_choice = which;
   return VCMI_OK;

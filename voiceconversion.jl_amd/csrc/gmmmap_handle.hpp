@@ -7,7 +7,7 @@ struct vcmi_gmmmap {
   int DP = 0;   // D rounded up to a multiple of 4 (MFMA k-step)
   int M = 0;    // ncomponents(g)
   int device = 0;
-  int kernel_choice = 0;   // 0 auto, 1 generic VALU, 2 MFMA
+  int kernel_choice = 0;   // 0 auto, 1 generic VALU, 2 MFMA, 3 MFMA with 4-mixture row grouping
 
   // host copies kept for accessors and for TrajectoryGMMMap's constructor (row-major (D,D) per mixture)
   std::vector<double> h_A_julia;   // Julia memory image (D,D,M) of ΣʸˣΣˣˣ⁻¹
@@ -18,6 +18,7 @@ struct vcmi_gmmmap {
   // device parameters, MFMA fragment order: [M][Tiling::BLK]
   vcmi::DevBuf<double> packed;    // [U_m ; A_m] tiles (convert)
   vcmi::DevBuf<double> packedU;   // U_m tiles only (log-density / posterior / argmax)
+  vcmi::DevBuf<double> packed4;   // 4-mixture row grouping (gmmmap_g4.hip, kernel choice 3)
 
   // grow-only device scratch for the host-pointer entry points
   vcmi::DevBuf<double> scratch_x, scratch_y, scratch_lp;
@@ -25,6 +26,10 @@ struct vcmi_gmmmap {
 };
 
 namespace vcmi {
+bool gmmmap_has_g4(int DP);
+int gmmmap_pack_g4(vcmi_gmmmap *g, const std::vector<double> &hU, const std::vector<double> &hA, const std::vector<double> &hcz,
+                   const std::vector<double> &hb, const std::vector<double> &hlc);
+int gmmmap_convert_g4_device(vcmi_gmmmap *g, const double *dX, int64_t ldx, int64_t T, double *dY, int64_t ldy, hipStream_t st);
 bool gmmmap_has_mfma(int DP);
 int gmmmap_convert_device(vcmi_gmmmap *g, const double *dX, int64_t ldx, int64_t T, double *dY, int64_t ldy, hipStream_t st);
 int gmmmap_logdens_device(vcmi_gmmmap *g, const double *dX, int64_t ldx, int64_t T, double *dLP, hipStream_t st);
