@@ -198,8 +198,8 @@ traj_solve_reg_kernel(const TrajUtt *__restrict__ utts, int n, const double *__r
   extern __shared__ double sm[];
   double *Wd = sm;                       // [W3][LD]  staging window (assembly, shift)
   double *rr = Wd + (size_t)W3 * LD;     // [W3] right-hand side
-  double *colb = rr + W3;                // [2][NK*16] raw pivot column, double-buffered
-  double *yring = colb + 2 * NK * 16;    // [2][D]
+  double *colb = rr + W3;                // [2][NK*16+1] masked pivot column (+ the pivot itself), double-buffered
+  double *yring = colb + 2 * (NK * 16 + 1);   // [2][D]
   double *wv = yring + 2 * D;            // [D]
   __shared__ int bad;
   const int tid = threadIdx.x;
@@ -216,7 +216,7 @@ traj_solve_reg_kernel(const TrajUtt *__restrict__ utts, int n, const double *__r
     if (tid == 0) bad = 0;
     for (int e = tid; e < W3 * LD; e += 256) Wd[e] = 0.0;
     for (int e = tid; e < W3; e += 256) rr[e] = 0.0;
-    for (int e = tid; e < 2 * NK * 16; e += 256) colb[e] = 0.0;
+    for (int e = tid; e < 2 * (NK * 16 + 1); e += 256) colb[e] = 0.0;
     __syncthreads();
     for (int a = 0; a < 3 && a < T; ++a) traj_add_block_row(Wd, rr, LD, D, a, a, T, mh, g, Qall);
     __syncthreads();
@@ -235,28 +235,28 @@ traj_solve_reg_kernel(const TrajUtt *__restrict__ utts, int n, const double *__r
       constexpr int NKC = (D + 15) / 16;             // tiles that can hold a pivot column of this block step
       for (int c = 0; c < D; ++c) {
         const int kc = c >> 4, oc = c & 15;
-        double *cb = colb + (c & 1) * NK * 16;
-        if (tj == oc) {                               // owners of column c publish it (rows above c are ignored later)
-#pragma unroll
-          for (int ka = 0; ka < NK; ++ka) {
+        double *cb = colb + (c & 1) * (NK * 16 + 1);
+        if (tj == oc) {                               // owners of column c publish it, already masked: rows i <= c
+#pragma unroll                                        // (finished rows / columns of the window) are written as 0 so that
+          for (int ka = 0; ka < NK; ++ka) {           // the readers need no compare/select at all; the pivot goes to cb[NK*16-1]
             double x = v[ka][0];
 #pragma unroll
             for (int q = 1; q < NKC; ++q)
               if (q <= ka) x = (kc == q) ? v[ka][q] : x;
-            cb[ti + 16 * ka] = x;
+            const int i = ti + 16 * ka;
+            cb[i] = (i > c) ? x : 0.0;
+            if (i == c) cb[NK * 16] = x;
           }
         }
         __syncthreads();
-        const double piv = cb[c];
+        const double piv = cb[NK * 16];
         if (!(piv > 0.0) && tid == 0) bad = 1;
         const double dinv = traj_rsqrt(piv);
-        // scaled column entries this thread needs; zero multipliers mask finished rows (i <= c) and columns (j <= c)
         double lr_[NK], lc_[NK];
 #pragma unroll
         for (int k = 0; k < NK; ++k) {
-          const double a = cb[ti + 16 * k] * dinv, b = cb[tj + 16 * k] * dinv;
-          lr_[k] = (ti + 16 * k > c) ? a : 0.0;
-          lc_[k] = (tj + 16 * k > c) ? b : 0.0;
+          lr_[k] = cb[ti + 16 * k] * dinv;
+          lc_[k] = cb[tj + 16 * k] * dinv;
         }
 #pragma unroll
         for (int ka = 0; ka < NK; ++ka)
@@ -417,7 +417,7 @@ traj_solve_kernel(const TrajUtt *__restrict__ utts, int n, int D, const double *
 static size_t solve_lds_bytes(int D) {
   const size_t W3 = 3 * (size_t)D;
   const size_t NK = (W3 + 15) / 16;
-  return (W3 * (W3 + 1) + 2 * W3 + 2 * NK * 16 + 2 * D + D) * sizeof(double);   // covers both solve kernels
+  return (W3 * (W3 + 1) + 2 * W3 + 2 * (NK * 16 + 1) + 2 * D + D) * sizeof(double);   // covers both solve kernels
 }
 
 static int traj_run(vcmi_traj *t, std::vector<TrajUtt> &utts, int64_t nframes, bool contiguous, const double *dX0,
