@@ -79,6 +79,29 @@ class GMMMap:
         return np.stack([self.fvconvert1(x) for x in X])
 
 
+def fvconvert_batched_gemm(g, X, chunk=65536):
+    """Same math as GMMMap.fvconvert but restructured as batched GEMMs over frame chunks (numpy -> multithreaded
+    BLAS): the 'strong CPU baseline' of SURVEY 8d(ii).  z = (X - mux_m) inv(L_m)', l_m = c_m - |z|^2/2,
+    softmax over m, y = sum_m p_m (muy_m + (X - mux_m) A_m')."""
+    Uinv = [sla.solve_triangular(L, np.eye(g.D), lower=True) for L in g.chol]
+    cst = np.array([np.log(g.w[m]) - (g.D * LOG2PI + g.logdet[m]) / 2.0 if g.w[m] > 0 else -np.inf for m in range(g.M)])
+    Y = np.empty_like(X)
+    for lo in range(0, X.shape[0], chunk):
+        Xc = X[lo:lo + chunk]
+        lpr = np.empty((Xc.shape[0], g.M))
+        for m in range(g.M):
+            Z = (Xc - g.mux[m]) @ Uinv[m].T
+            lpr[:, m] = cst[m] - 0.5 * np.einsum("ij,ij->i", Z, Z)
+        lpr -= lpr.max(axis=1, keepdims=True)
+        P = np.exp(lpr)
+        P /= P.sum(axis=1, keepdims=True)
+        acc = np.zeros_like(Xc)
+        for m in range(g.M):
+            acc += P[:, m:m + 1] * (g.muy[m] + (Xc - g.mux[m]) @ g.A[m].T)
+        Y[lo:lo + chunk] = acc
+    return Y
+
+
 def vc_frames(g, fm):
     """vc(c::FrameByFrameConverter, fm), src/common.jl:7-26; fm is (T, D+1) here."""
     out = np.empty_like(fm)
