@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload convert|estep|dtw|traj]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload convert|estep|estep_full|dtw|traj]
 
 Default workload = BASELINE.json configs[1]: GMMMap fvconvert, D=40, M=64, T=10^6 synthetic frames per GPU
 (weak scaling: every rank converts its own shard of T frames; frames are independent, so there is no
@@ -238,6 +238,53 @@ def bench_estep(args, world, rank):
     return out
 
 
+def bench_estep_full(args, world, rank):
+    """full-covariance E-step (what bin/train_gmm.jl:84-103 runs), Dj=80, M=64, 5e5 frames per
+    GPU (weak scaling) + ONE all-reduce of the packed statistics.  Algorithmic flops per frame: triangular
+    whitening M*Dj*(Dj+1) + symmetric-half second moments M*Dj*(Dj+1) + first moments 2*M*Dj."""
+    import torch
+
+    import voiceconversion_jl_amd as vc
+    from oracle import np_oracle as npo
+
+    Dj, M, N = 80, 64, args.frames if args.frames != 1_000_000 else 500_000
+    w, mu, sig = npo.synth_model(1005, Dj, M, lam_lo=1e-3)
+    X = npo.sample_frames(1005 + rank, w, mu, sig, N, 0, Dj)
+    Xd = torch.from_numpy(X).cuda()
+    out_t = torch.empty(vc.full_stats_len(Dj, M), dtype=torch.float64, device="cuda")
+    muT, sgT = np.asfortranarray(mu.T), np.asfortranarray(np.transpose(sig, (2, 1, 0)))
+
+    def step():
+        vc.estep_full_dev(Xd.t(), w, muT, sgT, out=out_t)
+        vc.dist.allreduce_sum_(out_t)
+
+    wall, kernel_ms = timed_steps(step, args.steps, args.warmup, world)
+    flop = 2 * M * Dj * (Dj + 1) + 2 * M * Dj
+    achieved = flop * N / (kernel_ms * 1e-3) / 1e12
+    out = {"metric": "full-covariance GMM E-step frames/sec (Dj=80, M=64)", "value": world * N * args.steps / wall,
+           "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "f64", "data": "synthetic",
+           "config": {"workload": "full-covariance E-step (SURVEY 8f rank 1; bin/train_gmm.jl:84-103)", "Dj": Dj, "M": M,
+                      "frames_per_gpu": N,
+                      "collective": "all-reduce(sum) of %d doubles per step" % vc.full_stats_len(Dj, M)},
+           "roofline": {"bound": "mfma", "kernel": "whole step: gmmmap_mfma_kernel<MODE 1> + estep_full_stats_kernel<80>",
+                        "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": achieved / FP64_PEAK_TFLOPS, "traffic": None, "flop_per_frame": flop, "kernel_ms": kernel_ms}}
+    if rank == 0:
+        from oracle import c_oracle as co
+
+        n = 40000
+        t0 = time.perf_counter()
+        r0, r1, r2, rl = co.estep_full(X[:n], w, mu, sig)
+        dt = time.perf_counter() - t0
+        S0, S1, S2, ll = vc.estep_full(X[:n].T, w, muT, sgT)
+        out["cpu_baseline"] = {"value": n / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+                               "sample": f"first {n} frames, C oracle, {dt:.1f} s on 1 of {os.cpu_count()} host cores"}
+        out["parity_max_rel_err_vs_oracle"] = float(np.max(np.abs(S2 - np.transpose(r2, (2, 1, 0)))) / np.max(np.abs(r2)))
+    return out
+
+
 # ------------------------------------------------------------------------------------------------ DTW
 def _dtw_pairs(seed, n, D):
     rng = np.random.default_rng(seed)
@@ -370,7 +417,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="convert", choices=["convert", "estep", "dtw", "traj"])
+    ap.add_argument("--workload", default="convert", choices=["convert", "estep", "estep_full", "dtw", "traj"])
     ap.add_argument("--frames", type=int, default=1_000_000, help="frames per GPU (BASELINE: 10^6)")
     ap.add_argument("--pairs", type=int, default=1000, help="DTW pairs per GPU")
     ap.add_argument("--utts", type=int, default=256, help="trajectory utterances per GPU")
@@ -380,7 +427,7 @@ def main():
     world, rank, _ = dist_setup(args.gpus)
     if world != args.gpus and rank == 0:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
-    out = {"convert": bench_convert, "estep": bench_estep, "dtw": bench_dtw, "traj": bench_traj}[args.workload](args, world, rank)
+    out = {"convert": bench_convert, "estep": bench_estep, "estep_full": bench_estep_full, "dtw": bench_dtw, "traj": bench_traj}[args.workload](args, world, rank)
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

@@ -114,6 +114,17 @@ int64_t vcmi_estep_stats_len(int Dj, int M);
 int vcmi_estep_diag_dev(const double *dX, int64_t N, int Dj, int M, const double *w, const double *mu,
                         const double *var, double *dstats, void *stream);
 
+/* Full-covariance E-step -- what the reference's training actually runs: bin/train_gmm.jl:84-89 builds
+ * sklearn.mixture.GMM(covariance_type="full") and :103 calls fit.  w (M); mu (Dj,M); sigma (Dj,Dj,M).
+ * Statistics S0 (M), S1 (Dj,M), S2 (Dj,Dj,M) = sum_n gamma_nm x_n x_n', loglik; device layout
+ * [S0 | S1 | S2 | loglik] of vcmi_estep_full_stats_len(Dj,M) doubles (one all-reduce).  VCMI_ERR_NOT_PD when a
+ * covariance is not positive definite. */
+int64_t vcmi_estep_full_stats_len(int Dj, int M);
+int vcmi_estep_full(const double *X, int64_t N, int Dj, int M, const double *w, const double *mu, const double *sigma,
+                    double *S0, double *S1, double *S2, double *loglik);
+int vcmi_estep_full_dev(const double *dX, int64_t N, int Dj, int M, const double *w, const double *mu,
+                        const double *sigma, double *dstats, void *stream);
+
 /* ---------------------------------------------------------------------------------------------
  * TrajectoryGMMMap -- src/trajectory_gmmmap.jl:3-110, vc src/common.jl:31-63, push_delta src/datasets.jl:6-13
  * ------------------------------------------------------------------------------------------- */

@@ -51,6 +51,7 @@ def lib():
         L.vco_traj_fvconvert.argtypes = [C.c_void_p, _dp, C.c_int64, _dp, _ip, _dp]
         L.vco_vc_traj.argtypes = [C.c_void_p, _dp, C.c_int64, C.c_int64, _dp]
         L.vco_estep_diag.argtypes = [_dp, C.c_int64, C.c_int, C.c_int, _dp, _dp, _dp, _dp, _dp, _dp, _dp]
+        L.vco_estep_full.argtypes = [_dp, C.c_int64, C.c_int, C.c_int, _dp, _dp, _dp, _dp, _dp, _dp, _dp]
         _lib = L
     return _lib
 
@@ -196,4 +197,19 @@ def estep_diag(X, w, mu, var):
     S2 = np.empty((M, Dj))
     ll = C.c_double(0.0)
     lib().vco_estep_diag(_d(X), N, Dj, M, _d(w), _d(mu), _d(var), _d(S0), _d(S1), _d(S2), C.byref(ll))
+    return S0, S1, S2, ll.value
+
+
+def estep_full(X, w, mu, sigma):
+    """X (N,Dj); w (M,); mu (M,Dj); sigma (M,Dj,Dj) [m][col][row].  Returns S0 (M,), S1 (M,Dj), S2 (M,Dj,Dj) [m][col][row], loglik."""
+    X, w, mu, sigma = _f64(X), _f64(w), _f64(mu), _f64(sigma)
+    N, Dj = X.shape
+    M = len(w)
+    S0 = np.empty(M)
+    S1 = np.empty((M, Dj))
+    S2 = np.empty((M, Dj, Dj))
+    ll = C.c_double(0.0)
+    rc = lib().vco_estep_full(_d(X), N, Dj, M, _d(w), _d(mu), _d(sigma), _d(S0), _d(S1), _d(S2), C.byref(ll))
+    if rc:
+        raise np.linalg.LinAlgError("covariance not positive definite")
     return S0, S1, S2, ll.value

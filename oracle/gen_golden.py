@@ -151,6 +151,23 @@ def main():
     assert _relmax(S0, c0) < 1e-10 and _relmax(S1, c1) < 1e-10 and _relmax(S2, c2) < 1e-10 and abs(ll - cl) < 1e-8 * abs(ll)
     np.savez(os.path.join(OUT, "estep_diag_N2000_D80_M16.npz"), X=Xe, w=wd, mu=mud, var=var, S0=S0, S1=S1, S2=S2,
              loglik=np.array(ll))
+    # ---- (6) full-covariance E-step (what bin/train_gmm.jl:84-103 runs), N=1000, Dj=80, M=8; the log-density
+    # is additionally checked against scikit-learn's own full-covariance routine when it is importable here.
+    wf, muf, sigf = npo.synth_model(3004, 80, 8, lam_lo=1e-3)
+    Xf = npo.sample_frames(3004, wf, muf, sigf, 1000, 0, 80)
+    S0, S1, S2, ll = npo.estep_full(Xf, wf, muf, sigf)
+    c0, c1, c2, cl = co.estep_full(Xf, wf, muf, sigf)
+    assert _relmax(S0, c0) < 1e-10 and _relmax(S1, c1) < 1e-10 and _relmax(S2, c2) < 1e-10 and abs(ll - cl) < 1e-8 * abs(ll)
+    try:
+        from scipy.special import logsumexp
+        from sklearn.mixture._gaussian_mixture import _compute_precision_cholesky, _estimate_log_gaussian_prob
+        lp = _estimate_log_gaussian_prob(Xf, muf, _compute_precision_cholesky(sigf, "full"), "full") + np.log(wf)
+        assert abs(logsumexp(lp, axis=1).sum() - ll) < 1e-9 * abs(ll)
+        print("full-covariance log-likelihood agrees with scikit-learn's _estimate_log_gaussian_prob")
+    except ImportError:
+        pass
+    np.savez(os.path.join(OUT, "estep_full_N1000_D80_M8.npz"), X=Xf, w=wf, mu=muf, sigma=sigf, S0=S0, S1=S1, S2=S2,
+             loglik=np.array(ll))
     print("golden fixtures written to", OUT)
     for f in sorted(os.listdir(OUT)):
         print(f"  {f}: {os.path.getsize(os.path.join(OUT, f)) / 1e6:.2f} MB")

@@ -234,6 +234,23 @@ def estep_diag(X, w, mu, var):
     return gam.sum(0), gam.T @ X, gam.T @ (X * X), float(lse.sum())
 
 
+def estep_full(X, w, mu, sigma):
+    """Full-covariance E-step (bin/train_gmm.jl:84-103 via sklearn).  X (N,Dj); w (M,); mu (M,Dj); sigma (M,Dj,Dj)
+    (symmetric).  Returns S0 (M,), S1 (M,Dj), S2 (M,Dj,Dj), loglik."""
+    N, Dj = X.shape
+    M = len(w)
+    lpr = np.empty((N, M))
+    for m in range(M):
+        L = np.linalg.cholesky((sigma[m] + sigma[m].T) / 2.0)
+        Z = sla.solve_triangular(L, (X - mu[m]).T, lower=True)
+        lpr[:, m] = np.log(w[m]) - 0.5 * (Dj * LOG2PI + 2.0 * np.sum(np.log(np.diag(L)))) - 0.5 * np.sum(Z * Z, axis=0)
+    u = lpr.max(axis=1, keepdims=True)
+    lse = u[:, 0] + np.log(np.sum(np.exp(lpr - u), axis=1))
+    gam = np.exp(lpr - lse[:, None])
+    S2 = np.einsum("nm,ni,nj->mij", gam, X, X)
+    return gam.sum(0), gam.T @ X, S2, float(lse.sum())
+
+
 # ------------------------------------------------------------------- synthetic generators (SURVEY 8d)
 def synth_model(seed, Dj, M, lam_lo=1e-5, lam_hi=1.0):
     """Synthetic joint GMM: Dirichlet(2) weights, N(0,1) means, covariances Q diag(lam) Q' with lam

@@ -541,3 +541,65 @@ void vco_estep_diag(const double *X, int64_t N, int Dj, int M, const double *w, 
   *loglik = ll;
   free(lpr); free(cst);
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * Full-covariance E-step: what sklearn.mixture.GMM(covariance_type="full").fit computes per EM
+ * iteration (call site bin/train_gmm.jl:84-103; third-party arithmetic restated from its definition).
+ * X (Dj,N); w (M); mu (Dj,M); sigma (Dj,Dj,M) column-major.  S0 (M), S1 (Dj,M), S2 (Dj,Dj,M), loglik.
+ * Returns nonzero if a covariance is not positive definite.
+ * ---------------------------------------------------------------------------------------------- */
+int vco_estep_full(const double *X, int64_t N, int Dj, int M, const double *w, const double *mu, const double *sigma,
+                   double *S0, double *S1, double *S2, double *loglik) {
+  size_t dd = (size_t)Dj * Dj;
+  double *L = (double *)malloc(sizeof(double) * dd * M);
+  double *cst = (double *)malloc(sizeof(double) * M);
+  double *lpr = (double *)malloc(sizeof(double) * M);
+  double *z = (double *)malloc(sizeof(double) * Dj);
+  double *sym = (double *)malloc(sizeof(double) * dd);
+  int bad = 0;
+  for (int m = 0; m < M && !bad; ++m) {
+    const double *S = sigma + dd * m;
+    for (int c = 0; c < Dj; ++c)
+      for (int r = 0; r < Dj; ++r) sym[r + (size_t)Dj * c] = (r <= c) ? S[r + (size_t)Dj * c] : S[c + (size_t)Dj * r];
+    if (cholesky_lower(sym, Dj, L + dd * m)) { bad = 1; break; }
+    double ld = 0.0;
+    for (int d = 0; d < Dj; ++d) ld += log(L[d + (size_t)Dj * d + dd * m]);
+    cst[m] = (w[m] > 0.0 ? log(w[m]) : -INFINITY) - 0.5 * (Dj * LOG2PI + 2.0 * ld);
+  }
+  if (!bad) {
+    memset(S0, 0, sizeof(double) * M);
+    memset(S1, 0, sizeof(double) * Dj * M);
+    memset(S2, 0, sizeof(double) * dd * M);
+    double ll = 0.0;
+    for (int64_t n = 0; n < N; ++n) {
+      const double *x = X + (size_t)Dj * n;
+      for (int m = 0; m < M; ++m) {
+        const double *Lm = L + dd * m, *mm = mu + (size_t)Dj * m;
+        double q = 0.0;
+        for (int i = 0; i < Dj; ++i) {
+          double s = x[i] - mm[i];
+          for (int k = 0; k < i; ++k) s -= Lm[i + (size_t)Dj * k] * z[k];
+          z[i] = s / Lm[i + (size_t)Dj * i];
+          q += z[i] * z[i];
+        }
+        lpr[m] = cst[m] - 0.5 * q;
+      }
+      double lse = logsumexp(lpr, M);
+      ll += lse;
+      for (int m = 0; m < M; ++m) {
+        double gam = exp(lpr[m] - lse);
+        if (gam == 0.0) continue;
+        S0[m] += gam;
+        double *s2 = S2 + dd * m;
+        for (int j = 0; j < Dj; ++j) {
+          double gx = gam * x[j];
+          S1[j + (size_t)Dj * m] += gx;
+          for (int i = 0; i < Dj; ++i) s2[i + (size_t)Dj * j] += gx * x[i];
+        }
+      }
+    }
+    *loglik = ll;
+  }
+  free(L); free(cst); free(lpr); free(z); free(sym);
+  return bad;
+}

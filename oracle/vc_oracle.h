@@ -75,6 +75,12 @@ int vco_vc_traj(const vco_traj *t, const double *fm, int64_t T, int64_t L, doubl
 void vco_estep_diag(const double *X, int64_t N, int Dj, int M, const double *w, const double *mu, const double *var,
                     double *S0, double *S1, double *S2, double *loglik);
 
+/* Full-covariance E-step (what bin/train_gmm.jl:84-103 runs through sklearn.mixture.GMM(covariance_type="full")).
+ * X (Dj,N); w (M); mu (Dj,M); sigma (Dj,Dj,M).  S0 (M), S1 (Dj,M), S2 (Dj,Dj,M) = sum gamma x x', loglik.
+ * Returns nonzero if a covariance is not positive definite.  PARITY UNPINNED by the reference's tests. */
+int vco_estep_full(const double *X, int64_t N, int Dj, int M, const double *w, const double *mu, const double *sigma,
+                   double *S0, double *S1, double *S2, double *loglik);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,110 @@
+"""GPU parity: full-covariance E-step (bin/train_gmm.jl:84-103, covariance_type="full") vs the golden vectors
+and the C oracle.  Tolerance 1e-9 relative to the largest statistic (sums of ~N terms in other orders)."""
+import numpy as np
+import pytest
+
+from conftest import load_golden, relerr
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-9
+
+
+@pytest.fixture(scope="module")
+def vc():
+    import voiceconversion_jl_amd as m
+    assert m.device_count() >= 1
+    return m
+
+
+def _check(got, ref, N):
+    S0, S1, S2, ll = got
+    r0, r1, r2, rl = ref
+    assert relerr(S0, r0) < TOL and relerr(S1, r1.T) < TOL
+    assert relerr(S2, np.transpose(r2, (2, 1, 0))) < TOL
+    assert abs(ll - rl) < TOL * abs(rl)
+    assert abs(S0.sum() - N) < 1e-6 * max(N, 1)
+    assert np.array_equal(S2, np.transpose(S2, (1, 0, 2)))      # exactly symmetric
+
+
+def test_golden(vc):
+    z = load_golden("estep_full_N1000_D80_M8.npz")
+    got = vc.estep_full(z["X"].T, z["w"], z["mu"].T, np.transpose(z["sigma"], (2, 1, 0)))
+    _check(got, (z["S0"], z["S1"], z["S2"], float(z["loglik"])), 1000)
+
+
+# Dj in {32,48,64,80} take the MFMA statistics kernel, the others the generic one; M not a multiple of 8,
+# a single frame, and a frame count that is not a multiple of the 64-frame block are the ragged cases.
+@pytest.mark.parametrize("N,Dj,M", [(3000, 80, 32), (777, 80, 13), (1, 80, 3), (1500, 48, 8), (900, 64, 5),
+                                    (2000, 32, 16), (1000, 6, 2), (500, 50, 4), (40000, 10, 4)])
+def test_vs_oracle(vc, N, Dj, M):
+    from oracle import c_oracle as co, np_oracle as npo
+    w, mu, sig = npo.synth_model(5000 + N + Dj, Dj, M, lam_lo=1e-3)
+    X = npo.sample_frames(N, w, mu, sig, N, 0, Dj)
+    ref = co.estep_full(X, w, mu, sig)
+    got = vc.estep_full(X.T, w, mu.T, np.transpose(sig, (2, 1, 0)))
+    _check(got, ref, N)
+
+
+def test_zero_weight_and_not_pd(vc):
+    from oracle import c_oracle as co, np_oracle as npo
+    w, mu, sig = npo.synth_model(9, 80, 6, lam_lo=1e-3)
+    X = npo.sample_frames(9, w, mu, sig, 400, 0, 80)
+    w[2] = 0.0
+    w /= w.sum()
+    ref = co.estep_full(X, w, mu, sig)
+    got = vc.estep_full(X.T, w, mu.T, np.transpose(sig, (2, 1, 0)))
+    _check(got, ref, 400)
+    assert got[0][2] == 0.0 and not got[2][:, :, 2].any()
+    bad = sig.copy()
+    bad[1] = -bad[1]
+    with pytest.raises(vc.PosDefException):
+        vc.estep_full(X.T, w, mu.T, np.transpose(bad, (2, 1, 0)))
+
+
+def test_device_resident_deterministic_and_additive(vc):
+    """Run-to-run bit-identical and additive over frame shards (what the all-reduce relies on); the diagonal
+    special case reproduces the diagonal E-step."""
+    import torch
+    from oracle import np_oracle as npo
+    Dj, M, N = 80, 16, 20000
+    w, mu, sig = npo.synth_model(78, Dj, M, lam_lo=1e-3)
+    X = npo.sample_frames(78, w, mu, sig, N, 0, Dj)
+    Xd = torch.from_numpy(X).cuda()                  # (N,Dj) row-major == (Dj,N) Julia image
+    sg = np.transpose(sig, (2, 1, 0))
+    a = vc.estep_full_dev(Xd.t(), w, mu.T, sg)
+    b = vc.estep_full_dev(Xd.t(), w, mu.T, sg)
+    assert torch.equal(a, b)
+    h = N // 2 + 37
+    s = vc.estep_full_dev(Xd[:h].t(), w, mu.T, sg) + vc.estep_full_dev(Xd[h:].t(), w, mu.T, sg)
+    assert float((s - a).abs().max() / a.abs().max()) < 1e-12
+    var = np.exp(np.random.default_rng(1).uniform(np.log(1e-2), 0.0, (M, Dj)))
+    dsig = np.zeros((M, Dj, Dj))
+    dsig[:, np.arange(Dj), np.arange(Dj)] = var
+    f0, f1, f2, fl = vc.estep_full(Xd.t(), w, mu.T, np.transpose(dsig, (2, 1, 0)))
+    d0, d1, d2, dl = vc.estep_diag(Xd.t(), w, mu.T, var.T)
+    assert relerr(f0, d0) < TOL and relerr(f1, d1) < TOL and abs(fl - dl) < TOL * abs(dl)
+    assert relerr(f2[np.arange(Dj), np.arange(Dj), :], d2) < TOL
+
+
+def test_em_iterations_match_oracle_em(vc):
+    """fit_full: EM on the device follows the same trajectory as EM driven by the oracle's E-step, and never
+    decreases the mean log-likelihood."""
+    import torch
+    from oracle import np_oracle as npo
+    Dj, M, N = 32, 4, 6000
+    w, mu, sig = npo.synth_model(5, Dj, M, lam_lo=1e-2)
+    X = npo.sample_frames(5, w, mu, sig, N, 0, Dj)
+    rg = np.random.default_rng(0)
+    mu0 = X[rg.choice(N, M, replace=False)].T
+    sig0 = np.repeat(np.cov(X.T)[:, :, None], M, axis=2)
+    w0 = np.full(M, 1.0 / M)
+    Xd = torch.from_numpy(X).cuda().t()
+    w1, mu1, sig1, hist = vc.fit_full(Xd, w0, mu0, sig0, n_iter=8, tol=0.0)
+    assert len(hist) == 8 and all(b >= a - 1e-9 for a, b in zip(hist, hist[1:])) and hist[-1] > hist[0]
+    wr, mur, sigr, ref = w0, mu0, sig0, []
+    for _ in range(8):
+        S0, S1, S2, ll = npo.estep_full(X, wr, mur.T, np.transpose(sigr, (2, 1, 0)))
+        ref.append(ll / N)
+        wr, mur, sigr = vc.mstep_full(S0, S1.T, np.transpose(S2, (2, 1, 0)))
+    assert np.allclose(hist, ref, rtol=1e-8, atol=0)
+    assert relerr(mu1, mur) < 1e-7 and relerr(sig1, sigr) < 1e-7

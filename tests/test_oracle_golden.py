@@ -112,3 +112,19 @@ def test_estep_golden():
     assert relerr(S0, z["S0"]) < 1e-10 and relerr(S1, z["S1"]) < 1e-10 and relerr(S2, z["S2"]) < 1e-10
     assert abs(ll - float(z["loglik"])) < 1e-10 * abs(float(z["loglik"]))
     assert abs(S0.sum() - 2000) < 1e-8
+
+
+def test_estep_full_golden():
+    z = load_golden("estep_full_N1000_D80_M8.npz")
+    S0, S1, S2, ll = co.estep_full(z["X"], z["w"], z["mu"], z["sigma"])
+    assert relerr(S0, z["S0"]) < 1e-10 and relerr(S1, z["S1"]) < 1e-10 and relerr(S2, z["S2"]) < 1e-10
+    assert abs(ll - float(z["loglik"])) < 1e-10 * abs(float(z["loglik"]))
+    assert abs(S0.sum() - 1000) < 1e-8
+    # the full-covariance E-step restricted to diagonal covariances is the diagonal E-step
+    zd = load_golden("estep_diag_N2000_D80_M16.npz")
+    sig = np.zeros((16, 80, 80))
+    sig[:, np.arange(80), np.arange(80)] = zd["var"]
+    f0, f1, f2, fl = co.estep_full(zd["X"], zd["w"], zd["mu"], sig)
+    assert relerr(f0, zd["S0"]) < 1e-10 and relerr(f1, zd["S1"]) < 1e-10
+    assert relerr(f2[:, np.arange(80), np.arange(80)], zd["S2"]) < 1e-10
+    assert abs(fl - float(zd["loglik"])) < 1e-10 * abs(float(zd["loglik"]))

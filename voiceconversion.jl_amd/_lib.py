@@ -73,6 +73,9 @@ SIGNATURES = {
     "vcmi_estep_diag": (_int, [_dp, _i64, _int, _int, _dp, _dp, _dp, _dp, _dp, _dp, _dp]),
     "vcmi_estep_stats_len": (_i64, [_int, _int]),
     "vcmi_estep_diag_dev": (_int, [_vp, _i64, _int, _int, _dp, _dp, _dp, _vp, _vp]),
+    "vcmi_estep_full_stats_len": (_i64, [_int, _int]),
+    "vcmi_estep_full": (_int, [_dp, _i64, _int, _int, _dp, _dp, _dp, _dp, _dp, _dp, _dp]),
+    "vcmi_estep_full_dev": (_int, [_vp, _i64, _int, _int, _dp, _dp, _dp, _vp, _vp]),
     "vcmi_traj_create": (_int, [_vp, _i64, C.POINTER(_vp)]),
     "vcmi_traj_destroy": (_int, [_vp]),
     "vcmi_traj_length": (_i64, [_vp]),

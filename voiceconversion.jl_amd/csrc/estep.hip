@@ -19,7 +19,9 @@
 //  * generic kernels (any Dj, M): gamma to an HBM workspace in chunks, then per-(m,d) sequential accumulation
 //    over fixed frame segments, then a fixed-order reduction.
 #include "vcmi_common.hpp"
+#include "gmmmap_handle.hpp"
 
+#include <algorithm>
 #include <cmath>
 
 namespace vcmi {
@@ -362,6 +364,221 @@ static int estep_device(const double *dX, int64_t N, int Dj, int M, const double
   return VCMI_OK;
 }
 
+
+// ================================================================================================
+// Full-covariance E-step -- what `gmm[:fit](dataset.X')` does per EM iteration in the reference as shipped
+// (bin/train_gmm.jl:84-89 builds sklearn.mixture.GMM(covariance_type="full"); :103 runs EM).  SURVEY 8(f) rank 1.
+//   l_nm = log w_m + log N(x_n; mu_m, Sigma_m)   (Cholesky whitening, the fvconvert log-density kernel, MODE 1)
+//   gamma = softmax_m(l),  S0_m = sum gamma,  S1_m = sum gamma x,  S2_m = sum gamma x x',  loglik = sum_n lse_n
+// Output buffer: [S0 (M) | S1 (Dj,M) | S2 (Dj,Dj,M) | loglik] (one all-reduce).  S2_m is a weighted Gram matrix:
+// wave w of an 8-wave workgroup owns mixture 8*mg + w and accumulates the 15 lower 16x16 tiles of its 80x80 S2 with
+// v_mfma_f64_16x16x4_f64 (A operand = gamma_f * x_f[i], B operand = x_f[j], k = 4 frames per step); the x tile
+// loaded for the A operand is the same register as the B operand of the matching column tile, so a k-step costs
+// Dj/16 LDS reads + Dj/16 multiplies for Dj/16*(Dj/16+1)/2 MFMAs.  S0/S1 ride along as per-lane sums of the A operands.
+// Per-(mixture group, frame segment) partials are reduced in fixed order -> bit-identical run to run.
+// ================================================================================================
+
+// log-weighted densities (n,M) -> gamma in place, lse per frame (thread per frame)
+__global__ void __launch_bounds__(256)
+estep_full_softmax_kernel(double *__restrict__ LP, int M, int64_t n, double *__restrict__ lse) {
+  const int64_t fr = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (fr >= n) return;
+  double *l = LP + fr * M;
+  double u = l[0];
+  for (int m = 1; m < M; ++m) u = fmax(u, l[m]);
+  double s = 0.0;
+  for (int m = 0; m < M; ++m) s += exp(l[m] - u);
+  const double ls = u + log(s);
+  for (int m = 0; m < M; ++m) l[m] = exp(l[m] - ls);
+  lse[fr] = ls;
+}
+
+// deterministic sum of n doubles into out[0] (+=): one workgroup, strided partials then a sequential tail
+__global__ void __launch_bounds__(256)
+estep_sum_kernel(const double *__restrict__ v, int64_t n, double *__restrict__ out) {
+  __shared__ double part[256];
+  double s = 0.0;
+  for (int64_t i = threadIdx.x; i < n; i += 256) s += v[i];
+  part[threadIdx.x] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = out[0];
+    for (int i = 0; i < 256; ++i) t += part[i];
+    out[0] = t;
+  }
+}
+
+static constexpr int kFullFB = 64;   // frames per staged block
+static constexpr int kFullSeg = 16;  // frame segments (grid.y)
+
+template <int DJ>
+__global__ void __launch_bounds__(512)
+estep_full_stats_kernel(const double *__restrict__ X, int64_t n0, int64_t n, int M, const double *__restrict__ G,
+                        double *__restrict__ part, int64_t plen) {
+  constexpr int NTL = DJ / 16, RSX = DJ + 1, FB = kFullFB;
+  static_assert(DJ % 16 == 0, "full-covariance MFMA statistics need Dj to be a multiple of 16");
+  __shared__ double xs[FB * RSX];
+  __shared__ double gs[FB * 8];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lcol = lane & 15, lgrp = lane >> 4;
+  const int m = blockIdx.x * 8 + wave;                 // this wave's mixture (may be >= M: then gamma is staged as 0)
+  const int64_t seglen = (n + gridDim.y - 1) / gridDim.y;
+  const int64_t f_begin = blockIdx.y * seglen, f_end = (f_begin + seglen < n) ? f_begin + seglen : n;
+
+  d4 acc[NTL][NTL];                                    // lower tiles only (j <= a)
+#pragma unroll
+  for (int a = 0; a < NTL; ++a)
+#pragma unroll
+    for (int j = 0; j <= a; ++j) acc[a][j] = d4{0, 0, 0, 0};
+  double s1[NTL], s0 = 0.0;
+#pragma unroll
+  for (int a = 0; a < NTL; ++a) s1[a] = 0.0;
+
+  for (int64_t fb = f_begin; fb < f_end; fb += FB) {
+    for (int e = tid; e < FB * DJ; e += 512) {
+      const int f = e / DJ, d = e % DJ;
+      xs[f * RSX + d] = (fb + f < f_end) ? X[(n0 + fb + f) * DJ + d] : 0.0;
+    }
+    {
+      const int f = tid >> 3, q = tid & 7;             // 64 frames x 8 mixtures
+      const int mm = blockIdx.x * 8 + q;
+      gs[f * 8 + q] = (fb + f < f_end && mm < M) ? G[(fb + f) * M + mm] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll 2
+    for (int ks = 0; ks < FB / 4; ++ks) {
+      const int f = 4 * ks + lgrp;
+      const double gm = gs[f * 8 + wave];
+      const double *xr = xs + f * RSX + lcol;
+      double xv[NTL], ax[NTL];
+#pragma unroll
+      for (int a = 0; a < NTL; ++a) {
+        xv[a] = xr[16 * a];
+        ax[a] = gm * xv[a];
+        s1[a] += ax[a];
+      }
+      s0 += gm;
+#pragma unroll
+      for (int a = 0; a < NTL; ++a)
+#pragma unroll
+        for (int j = 0; j <= a; ++j) acc[a][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(ax[a], xv[j], acc[a][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  if (m >= M) return;
+  // partial statistics of this (mixture, segment) in the final layout [S0 | S1 | S2 | loglik]
+  double *P = part + (size_t)blockIdx.y * plen;
+  s0 += __shfl_xor(s0, 16);
+  s0 += __shfl_xor(s0, 32);
+  if (lane == 0) P[m] = s0;
+#pragma unroll
+  for (int a = 0; a < NTL; ++a) {
+    double v = s1[a];
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    if (lgrp == 0) P[M + (size_t)m * DJ + 16 * a + lcol] = v;
+  }
+  double *S2 = P + M + (size_t)M * DJ + (size_t)m * DJ * DJ;      // (Dj,Dj) column-major
+#pragma unroll
+  for (int a = 0; a < NTL; ++a)
+#pragma unroll
+    for (int j = 0; j <= a; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = 16 * a + lgrp + 4 * r, jc = 16 * j + lcol;  // D[i][jc]
+        if (a != j || i >= jc) {                                   // diagonal tiles: lower part only, then mirrored
+          S2[i + (size_t)DJ * jc] = acc[a][j][r];
+          S2[jc + (size_t)DJ * i] = acc[a][j][r];
+        }
+      }
+}
+
+// generic statistics (any Dj): thread per lower-triangle element of one mixture's S2 (+ S1, S0), sequential over the
+// frames of one segment
+__global__ void __launch_bounds__(256)
+estep_full_stats_generic_kernel(const double *__restrict__ X, int64_t n0, int64_t n, int Dj, int M,
+                                const double *__restrict__ G, double *__restrict__ part, int64_t plen) {
+  const int m = blockIdx.x;
+  const int64_t seglen = (n + gridDim.y - 1) / gridDim.y;
+  const int64_t f_begin = blockIdx.y * seglen, f_end = (f_begin + seglen < n) ? f_begin + seglen : n;
+  double *P = part + (size_t)blockIdx.y * plen;
+  double *S2 = P + M + (size_t)M * Dj + (size_t)m * Dj * Dj;
+  const int ntri = Dj * (Dj + 1) / 2;
+  for (int e = threadIdx.x; e < ntri + Dj + 1; e += 256) {
+    double s = 0.0;
+    if (e < ntri) {
+      int i = (int)((sqrt(8.0 * e + 1.0) - 1.0) / 2.0);
+      while (i * (i + 1) / 2 > e) --i;
+      while ((i + 1) * (i + 2) / 2 <= e) ++i;
+      const int j = e - i * (i + 1) / 2;
+      for (int64_t f = f_begin; f < f_end; ++f) s = fma(G[f * M + m] * X[(n0 + f) * Dj + i], X[(n0 + f) * Dj + j], s);
+      S2[i + (size_t)Dj * j] = s;
+      S2[j + (size_t)Dj * i] = s;
+    } else if (e < ntri + Dj) {
+      const int d = e - ntri;
+      for (int64_t f = f_begin; f < f_end; ++f) s = fma(G[f * M + m], X[(n0 + f) * Dj + d], s);
+      P[M + (size_t)m * Dj + d] = s;
+    } else {
+      for (int64_t f = f_begin; f < f_end; ++f) s += G[f * M + m];
+      P[m] = s;
+    }
+  }
+}
+
+struct EstepFullScratch {
+  DevBuf<double> LP, lse, part, X, stats;
+};
+static EstepFullScratch &full_scratch() {
+  static thread_local EstepFullScratch s;
+  return s;
+}
+
+static int estep_full_device(const double *dX, int64_t N, int Dj, int M, const double *w, const double *mu,
+                             const double *sigma, double *dstats, hipStream_t st) {
+  if (N < 0 || Dj < 1 || M < 1) return fail(VCMI_ERR_DIM, "E-step: N=%lld Dj=%d M=%d invalid", (long long)N, Dj, M);
+  if (!w || !mu || !sigma || !dstats || (N > 0 && !dX)) return fail(VCMI_ERR_ARG, "E-step: NULL argument");
+  const int64_t plen = (int64_t)M * (1 + Dj + (int64_t)Dj * Dj) + 1;
+  VCMI_HIP(hipMemsetAsync(dstats, 0, plen * sizeof(double), st));
+  if (N == 0) return VCMI_OK;
+  vcmi_gmmmap *px = nullptr;
+  VCMI_TRY(gmm_px_create(w, mu, sigma, Dj, M, &px));   // Cholesky whitening blocks of every mixture (PosDef check)
+  struct Guard {
+    vcmi_gmmmap *p;
+    ~Guard() { delete p; }
+  } guard{px};
+  EstepFullScratch &sc = full_scratch();
+  const int64_t chunk = std::min<int64_t>(N, (int64_t)1 << 20);
+  VCMI_TRY(sc.LP.reserve((size_t)chunk * M));
+  VCMI_TRY(sc.lse.reserve((size_t)chunk));
+  VCMI_TRY(sc.part.reserve((size_t)kFullSeg * plen));
+  const bool mfma = (Dj == 32 || Dj == 48 || Dj == 64 || Dj == 80) && !g_estep_force_generic;
+  for (int64_t n0 = 0; n0 < N; n0 += chunk) {
+    const int64_t n = std::min<int64_t>(chunk, N - n0);
+    VCMI_TRY(gmmmap_logdens_device(px, dX + n0 * Dj, Dj, n, sc.LP.p, st));
+    hipLaunchKernelGGL(estep_full_softmax_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, sc.LP.p, M, n, sc.lse.p);
+    hipLaunchKernelGGL(estep_sum_kernel, dim3(1), dim3(256), 0, st, sc.lse.p, n, dstats + (plen - 1));
+    VCMI_HIP(hipMemsetAsync(sc.part.p, 0, (size_t)kFullSeg * plen * sizeof(double), st));
+    const dim3 grid((M + 7) / 8, kFullSeg);
+    if (mfma) {
+      switch (Dj) {
+        case 32: hipLaunchKernelGGL(estep_full_stats_kernel<32>, grid, dim3(512), 0, st, dX, n0, n, M, sc.LP.p, sc.part.p, plen); break;
+        case 48: hipLaunchKernelGGL(estep_full_stats_kernel<48>, grid, dim3(512), 0, st, dX, n0, n, M, sc.LP.p, sc.part.p, plen); break;
+        case 64: hipLaunchKernelGGL(estep_full_stats_kernel<64>, grid, dim3(512), 0, st, dX, n0, n, M, sc.LP.p, sc.part.p, plen); break;
+        default: hipLaunchKernelGGL(estep_full_stats_kernel<80>, grid, dim3(512), 0, st, dX, n0, n, M, sc.LP.p, sc.part.p, plen); break;
+      }
+    } else {
+      hipLaunchKernelGGL(estep_full_stats_generic_kernel, dim3(M, kFullSeg), dim3(256), 0, st, dX, n0, n, Dj, M, sc.LP.p,
+                         sc.part.p, plen);
+    }
+    // the loglik slot of the partial rows is zero, so the generic reduction leaves dstats[plen-1] (set above) intact
+    hipLaunchKernelGGL(estep_reduce_kernel, dim3((unsigned)((plen + 255) / 256)), dim3(256), 0, st, sc.part.p, kFullSeg, plen,
+                       dstats);
+    VCMI_HIP(hipGetLastError());
+  }
+  VCMI_HIP(hipStreamSynchronize(st));   // the px handle (device blocks) is released on return
+  return VCMI_OK;
+}
+
 }  // namespace vcmi
 
 using namespace vcmi;
@@ -396,5 +613,32 @@ extern "C" int vcmi_estep_diag(const double *X, int64_t N, int Dj, int M, const 
 // test hook (not part of include/vcmi.h): 1 forces the generic kernels so that both paths are parity-tested
 extern "C" int vcmi_estep_debug_force_generic(int on) {
   g_estep_force_generic = on;
+  return VCMI_OK;
+}
+
+extern "C" int64_t vcmi_estep_full_stats_len(int Dj, int M) { return (int64_t)M * (1 + Dj + (int64_t)Dj * Dj) + 1; }
+
+extern "C" int vcmi_estep_full_dev(const double *dX, int64_t N, int Dj, int M, const double *w, const double *mu,
+                                   const double *sigma, double *dstats, void *stream) {
+  return estep_full_device(dX, N, Dj, M, w, mu, sigma, dstats, as_stream(stream));
+}
+
+extern "C" int vcmi_estep_full(const double *X, int64_t N, int Dj, int M, const double *w, const double *mu,
+                               const double *sigma, double *S0, double *S1, double *S2, double *loglik) {
+  if (!S0 || !S1 || !S2 || !loglik) return fail(VCMI_ERR_ARG, "vcmi_estep_full: NULL output");
+  if (N < 0 || Dj < 1 || M < 1) return fail(VCMI_ERR_DIM, "E-step: N=%lld Dj=%d M=%d invalid", (long long)N, Dj, M);
+  VCMI_TRY(check_device());
+  EstepFullScratch &sc = full_scratch();
+  const int64_t plen = vcmi_estep_full_stats_len(Dj, M);
+  VCMI_TRY(sc.X.reserve((size_t)std::max<int64_t>(N, 1) * Dj));
+  VCMI_TRY(sc.stats.reserve((size_t)plen));
+  if (N > 0) VCMI_HIP(hipMemcpy(sc.X.p, X, (size_t)N * Dj * 8, hipMemcpyHostToDevice));
+  VCMI_TRY(estep_full_device(sc.X.p, N, Dj, M, w, mu, sigma, sc.stats.p, nullptr));
+  std::vector<double> h((size_t)plen);
+  VCMI_HIP(hipMemcpy(h.data(), sc.stats.p, (size_t)plen * 8, hipMemcpyDeviceToHost));
+  memcpy(S0, h.data(), sizeof(double) * M);
+  memcpy(S1, h.data() + M, sizeof(double) * M * Dj);
+  memcpy(S2, h.data() + M + (size_t)M * Dj, sizeof(double) * M * Dj * Dj);
+  *loglik = h[(size_t)plen - 1];
   return VCMI_OK;
 }

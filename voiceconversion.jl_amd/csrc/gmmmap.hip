@@ -474,8 +474,11 @@ int gmmmap_predict_device(vcmi_gmmmap *g, const double *dX, int64_t ldx, int64_t
 // ------------------------------------------------------------------------------------------------
 // model preparation (host) and upload
 // ------------------------------------------------------------------------------------------------
-static int prepare(vcmi_gmmmap *g, const double *w, const double *mu, const double *sigma, int Dj, int M, int swap) {
-  const int D = Dj >> 1;   // src/gmmmap.jl:70
+// px_only: (mu, sigma) describe a plain GMM p(x) of dimension Dj (no target half): only the whitening side is prepared
+// (used by the full-covariance E-step, estep.hip); the regression blocks stay zero and the convert layouts are skipped.
+static int prepare(vcmi_gmmmap *g, const double *w, const double *mu, const double *sigma, int Dj, int M, int swap,
+                   bool px_only = false) {
+  const int D = px_only ? Dj : Dj >> 1;   // src/gmmmap.jl:70
   const int DP = (D + 3) / 4 * 4;
   g->D = D;
   g->M = M;
@@ -489,28 +492,31 @@ static int prepare(vcmi_gmmmap *g, const double *w, const double *mu, const doub
   g->h_muy.assign((size_t)D * M, 0.0);
   std::vector<double> hU(pp * M, 0.0), hA(pp * M, 0.0), hcz((size_t)DP * M, 0.0), hb((size_t)DP * M, 0.0), hlc(M);
   std::vector<double> Sxx(dd), Syx(dd), inv(dd), L(dd), Ui(dd);
-  const int xo = swap ? D : 0, yo = swap ? 0 : D;   // src/gmmmap.jl:74-78
+  const int xo = (swap && !px_only) ? D : 0, yo = px_only ? 0 : (swap ? 0 : D);   // src/gmmmap.jl:74-78
   const double LOG2PI = 1.8378770664093454835606594728112;
   for (int m = 0; m < M; ++m) {
     const double *S = sigma + (size_t)Dj * Dj * m;   // column-major (Dj,Dj)
     double *mux = &g->h_mux[(size_t)D * m], *muy = &g->h_muy[(size_t)D * m];
     for (int d = 0; d < D; ++d) {
       mux[d] = mu[xo + d + (size_t)Dj * m];
-      muy[d] = mu[yo + d + (size_t)Dj * m];
+      muy[d] = px_only ? 0.0 : mu[yo + d + (size_t)Dj * m];
     }
     // row-major copies of the four blocks, src/gmmmap.jl:41-52
     for (int r = 0; r < D; ++r)
       for (int c = 0; c < D; ++c) {
         Sxx[(size_t)r * D + c] = S[(xo + r) + (size_t)Dj * (xo + c)];
+        if (px_only) continue;
         Syx[(size_t)r * D + c] = S[(yo + r) + (size_t)Dj * (xo + c)];
         g->h_Sxy[dd * m + (size_t)r * D + c] = S[(xo + r) + (size_t)Dj * (yo + c)];
         g->h_Syy[dd * m + (size_t)r * D + c] = S[(yo + r) + (size_t)Dj * (yo + c)];
       }
     // A_m = Syx inv(Sxx) on the raw block, src/gmmmap.jl:35
-    if (!la::inverse(Sxx.data(), D, inv.data()))
-      return fail(VCMI_ERR_NOT_PD, "Sigma^xx of mixture %d is singular", m + 1);
     double *Am = &g->h_A[dd * m];
-    la::matmul(Syx.data(), inv.data(), D, Am);
+    if (!px_only) {
+      if (!la::inverse(Sxx.data(), D, inv.data()))
+        return fail(VCMI_ERR_NOT_PD, "Sigma^xx of mixture %d is singular", m + 1);
+      la::matmul(Syx.data(), inv.data(), D, Am);
+    }
     for (int r = 0; r < D; ++r)
       for (int c = 0; c < D; ++c) {
         g->h_A_julia[dd * m + r + (size_t)D * c] = Am[(size_t)r * D + c];
@@ -547,7 +553,7 @@ static int prepare(vcmi_gmmmap *g, const double *w, const double *mu, const doub
   VCMI_HIP(hipMemcpy(g->lc.p, hlc.data(), hlc.size() * 8, hipMemcpyHostToDevice));
 
   // packed operand blocks for the MFMA kernel (issue order: phase U k-major over U tiles, then phase A)
-  for (int uonly = 0; uonly < 2 && gmmmap_has_mfma(DP); ++uonly) {
+  for (int uonly = px_only ? 1 : 0; uonly < 2 && gmmmap_has_mfma(DP); ++uonly) {
     TilingRT tl(DP, uonly != 0);
     std::vector<double> pk((size_t)tl.BLK * M, 0.0);
     auto wrow = [&](int m, int p, int k) -> double {   // row p of [U_m ; A_m], column k
@@ -580,7 +586,23 @@ static int prepare(vcmi_gmmmap *g, const double *w, const double *mu, const doub
     VCMI_TRY(dst.alloc(pk.size()));
     VCMI_HIP(hipMemcpy(dst.p, pk.data(), pk.size() * 8, hipMemcpyHostToDevice));
   }
-  VCMI_TRY(gmmmap_pack_g4(g, hU, hA, hcz, hb, hlc));
+  if (!px_only) VCMI_TRY(gmmmap_pack_g4(g, hU, hA, hcz, hb, hlc));
+  return VCMI_OK;
+}
+
+// p(x)-only handle over a plain GMM of dimension D (weights (M), mu (D,M), sigma (D,D,M)); used by estep.hip
+int gmm_px_create(const double *w, const double *mu, const double *sigma, int D, int M, vcmi_gmmmap **out) {
+  *out = nullptr;
+  VCMI_TRY(check_device());
+  vcmi_gmmmap *g = new (std::nothrow) vcmi_gmmmap();
+  if (!g) return fail(VCMI_ERR_OOM, "out of host memory");
+  (void)hipGetDevice(&g->device);
+  int rc = prepare(g, w, mu, sigma, D, M, 0, /*px_only=*/true);
+  if (rc != VCMI_OK) {
+    delete g;
+    return rc;
+  }
+  *out = g;
   return VCMI_OK;
 }
 

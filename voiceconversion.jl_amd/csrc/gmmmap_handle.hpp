@@ -31,6 +31,7 @@ int gmmmap_pack_g4(vcmi_gmmmap *g, const std::vector<double> &hU, const std::vec
                    const std::vector<double> &hb, const std::vector<double> &hlc);
 int gmmmap_convert_g4_device(vcmi_gmmmap *g, const double *dX, int64_t ldx, int64_t T, double *dY, int64_t ldy, hipStream_t st);
 bool gmmmap_has_mfma(int DP);
+int gmm_px_create(const double *w, const double *mu, const double *sigma, int D, int M, vcmi_gmmmap **out);
 int gmmmap_convert_device(vcmi_gmmmap *g, const double *dX, int64_t ldx, int64_t T, double *dY, int64_t ldy, hipStream_t st);
 int gmmmap_logdens_device(vcmi_gmmmap *g, const double *dX, int64_t ldx, int64_t T, double *dLP, hipStream_t st);
 int gmmmap_posterior_device(vcmi_gmmmap *g, const double *dX, int64_t ldx, int64_t T, double *dP, hipStream_t st);
