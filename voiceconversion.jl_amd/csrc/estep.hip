@@ -378,19 +378,31 @@ static int estep_device(const double *dX, int64_t N, int Dj, int M, const double
 // Per-(mixture group, frame segment) partials are reduced in fixed order -> bit-identical run to run.
 // ================================================================================================
 
-// log-weighted densities (n,M) -> gamma in place, lse per frame (thread per frame)
+// log-weighted densities (n,M) -> gamma in place; wave per frame (lanes across mixtures: coalesced rows), fixed grid.
+// The per-frame log-sum-exp values are summed per wave in frame order, then per workgroup: lsepart[blockIdx.x].
+static constexpr int kSoftmaxGrid = 2048;
 __global__ void __launch_bounds__(256)
-estep_full_softmax_kernel(double *__restrict__ LP, int M, int64_t n, double *__restrict__ lse) {
-  const int64_t fr = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (fr >= n) return;
-  double *l = LP + fr * M;
-  double u = l[0];
-  for (int m = 1; m < M; ++m) u = fmax(u, l[m]);
-  double s = 0.0;
-  for (int m = 0; m < M; ++m) s += exp(l[m] - u);
-  const double ls = u + log(s);
-  for (int m = 0; m < M; ++m) l[m] = exp(l[m] - ls);
-  lse[fr] = ls;
+estep_full_softmax_kernel(double *__restrict__ LP, int M, int64_t n, double *__restrict__ lsepart) {
+  __shared__ double wsum[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double acc = 0.0;
+  for (int64_t fr = (int64_t)blockIdx.x * 4 + wave; fr < n; fr += (int64_t)gridDim.x * 4) {
+    double *l = LP + fr * M;
+    double u = -INFINITY;
+    for (int m = lane; m < M; m += 64) u = fmax(u, l[m]);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) u = fmax(u, __shfl_xor(u, o));
+    double sm = 0.0;
+    for (int m = lane; m < M; m += 64) sm += exp(l[m] - u);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) sm += __shfl_xor(sm, o);
+    const double ls = u + log(sm);
+    for (int m = lane; m < M; m += 64) l[m] = exp(l[m] - ls);
+    acc += ls;
+  }
+  if (lane == 0) wsum[wave] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) lsepart[blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
 }
 
 // deterministic sum of n doubles into out[0] (+=): one workgroup, strided partials then a sequential tail
@@ -408,17 +420,19 @@ estep_sum_kernel(const double *__restrict__ v, int64_t n, double *__restrict__ o
   }
 }
 
-static constexpr int kFullFB = 64;   // frames per staged block
-static constexpr int kFullSeg = 16;  // frame segments (grid.y)
+static constexpr int kFullFB = 32;   // frames per staged block (double-buffered in LDS)
 
 template <int DJ>
-__global__ void __launch_bounds__(512)
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 estep_full_stats_kernel(const double *__restrict__ X, int64_t n0, int64_t n, int M, const double *__restrict__ G,
                         double *__restrict__ part, int64_t plen) {
-  constexpr int NTL = DJ / 16, RSX = DJ + 1, FB = kFullFB;
+  // row stride == 16 (mod 32) doubles: the four 16-lane groups of an operand read (4 consecutive frames) then fall in
+  // disjoint halves of the 64 LDS banks per half-wave
+  constexpr int NTL = DJ / 16, RSX = (DJ % 32 == 16) ? DJ : DJ + 16, FB = kFullFB;
+  constexpr int NPF = (FB * DJ + 511) / 512;           // staged doubles per thread per block
   static_assert(DJ % 16 == 0, "full-covariance MFMA statistics need Dj to be a multiple of 16");
-  __shared__ double xs[FB * RSX];
-  __shared__ double gs[FB * 8];
+  __shared__ double xs[2][FB * RSX];
+  __shared__ double gs[2][FB * 8];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lcol = lane & 15, lgrp = lane >> 4;
   const int m = blockIdx.x * 8 + wave;                 // this wave's mixture (may be >= M: then gamma is staged as 0)
@@ -434,22 +448,43 @@ estep_full_stats_kernel(const double *__restrict__ X, int64_t n0, int64_t n, int
 #pragma unroll
   for (int a = 0; a < NTL; ++a) s1[a] = 0.0;
 
-  for (int64_t fb = f_begin; fb < f_end; fb += FB) {
-    for (int e = tid; e < FB * DJ; e += 512) {
-      const int f = e / DJ, d = e % DJ;
-      xs[f * RSX + d] = (fb + f < f_end) ? X[(n0 + fb + f) * DJ + d] : 0.0;
+  double pf[NPF], pg = 0.0;
+  const int gf = tid >> 3, gq = tid & 7;               // gamma staging: 32 frames x 8 mixtures = threads 0..255
+  const int gm_idx = blockIdx.x * 8 + gq;
+  auto fetch = [&](int64_t fb) {                       // global -> registers (the block's frames are contiguous in X)
+    const int64_t lim = (f_end - fb) * DJ;
+    const double *src = X + (n0 + fb) * DJ;
+#pragma unroll
+    for (int i = 0; i < NPF; ++i) {
+      const int e = tid + 512 * i;
+      pf[i] = (e < FB * DJ && e < lim) ? src[e] : 0.0;
     }
-    {
-      const int f = tid >> 3, q = tid & 7;             // 64 frames x 8 mixtures
-      const int mm = blockIdx.x * 8 + q;
-      gs[f * 8 + q] = (fb + f < f_end && mm < M) ? G[(fb + f) * M + mm] : 0.0;
+    pg = (tid < FB * 8 && fb + gf < f_end && gm_idx < M) ? G[(fb + gf) * M + gm_idx] : 0.0;
+  };
+  auto stash = [&](int buf) {                          // registers -> LDS
+#pragma unroll
+    for (int i = 0; i < NPF; ++i) {
+      const int e = tid + 512 * i;
+      if (e < FB * DJ) xs[buf][(e / DJ) * RSX + (e % DJ)] = pf[i];
     }
-    __syncthreads();
+    if (tid < FB * 8) gs[buf][gf * 8 + gq] = pg;
+  };
+
+  if (f_begin < f_end) {
+    fetch(f_begin);
+    stash(0);
+  }
+  __syncthreads();
+  int buf = 0;
+  for (int64_t fb = f_begin; fb < f_end; fb += FB, buf ^= 1) {
+    const bool more = fb + FB < f_end;
+    if (more) fetch(fb + FB);
+    const double *xb = xs[buf], *gb = gs[buf];
 #pragma unroll 2
     for (int ks = 0; ks < FB / 4; ++ks) {
       const int f = 4 * ks + lgrp;
-      const double gm = gs[f * 8 + wave];
-      const double *xr = xs + f * RSX + lcol;
+      const double gm = gb[f * 8 + wave];
+      const double *xr = xb + f * RSX + lcol;
       double xv[NTL], ax[NTL];
 #pragma unroll
       for (int a = 0; a < NTL; ++a) {
@@ -463,6 +498,7 @@ estep_full_stats_kernel(const double *__restrict__ X, int64_t n0, int64_t n, int
 #pragma unroll
         for (int j = 0; j <= a; ++j) acc[a][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(ax[a], xv[j], acc[a][j], 0, 0, 0);
     }
+    if (more) stash(buf ^ 1);
     __syncthreads();
   }
   if (m >= M) return;
@@ -527,6 +563,8 @@ estep_full_stats_generic_kernel(const double *__restrict__ X, int64_t n0, int64_
 
 struct EstepFullScratch {
   DevBuf<double> LP, lse, part, X, stats;
+  vcmi_gmmmap *px = nullptr;
+  ~EstepFullScratch() { delete px; }
 };
 static EstepFullScratch &full_scratch() {
   static thread_local EstepFullScratch s;
@@ -540,25 +578,26 @@ static int estep_full_device(const double *dX, int64_t N, int Dj, int M, const d
   const int64_t plen = (int64_t)M * (1 + Dj + (int64_t)Dj * Dj) + 1;
   VCMI_HIP(hipMemsetAsync(dstats, 0, plen * sizeof(double), st));
   if (N == 0) return VCMI_OK;
-  vcmi_gmmmap *px = nullptr;
-  VCMI_TRY(gmm_px_create(w, mu, sigma, Dj, M, &px));   // Cholesky whitening blocks of every mixture (PosDef check)
-  struct Guard {
-    vcmi_gmmmap *p;
-    ~Guard() { delete p; }
-  } guard{px};
   EstepFullScratch &sc = full_scratch();
+  // Cholesky whitening blocks of every mixture (PosDef check); the handle and its device buffers persist per host
+  // thread across EM iterations and are re-prepared in place (this function drains the stream before returning)
+  VCMI_TRY(gmm_px_create(w, mu, sigma, Dj, M, &sc.px));
+  vcmi_gmmmap *px = sc.px;
   const int64_t chunk = std::min<int64_t>(N, (int64_t)1 << 20);
   VCMI_TRY(sc.LP.reserve((size_t)chunk * M));
-  VCMI_TRY(sc.lse.reserve((size_t)chunk));
-  VCMI_TRY(sc.part.reserve((size_t)kFullSeg * plen));
+  VCMI_TRY(sc.lse.reserve((size_t)kSoftmaxGrid));
+  // frame segments (grid.y): one 8-wave workgroup per CU in a single round, whatever the mixture count
+  const int mgroups = (M + 7) / 8;
+  const int nseg = std::max(1, (256 + mgroups - 1) / mgroups);
+  VCMI_TRY(sc.part.reserve((size_t)nseg * plen));
   const bool mfma = (Dj == 32 || Dj == 48 || Dj == 64 || Dj == 80) && !g_estep_force_generic;
   for (int64_t n0 = 0; n0 < N; n0 += chunk) {
     const int64_t n = std::min<int64_t>(chunk, N - n0);
     VCMI_TRY(gmmmap_logdens_device(px, dX + n0 * Dj, Dj, n, sc.LP.p, st));
-    hipLaunchKernelGGL(estep_full_softmax_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, sc.LP.p, M, n, sc.lse.p);
-    hipLaunchKernelGGL(estep_sum_kernel, dim3(1), dim3(256), 0, st, sc.lse.p, n, dstats + (plen - 1));
-    VCMI_HIP(hipMemsetAsync(sc.part.p, 0, (size_t)kFullSeg * plen * sizeof(double), st));
-    const dim3 grid((M + 7) / 8, kFullSeg);
+    hipLaunchKernelGGL(estep_full_softmax_kernel, dim3(kSoftmaxGrid), dim3(256), 0, st, sc.LP.p, M, n, sc.lse.p);
+    hipLaunchKernelGGL(estep_sum_kernel, dim3(1), dim3(256), 0, st, sc.lse.p, (int64_t)kSoftmaxGrid, dstats + (plen - 1));
+    VCMI_HIP(hipMemsetAsync(sc.part.p, 0, (size_t)nseg * plen * sizeof(double), st));
+    const dim3 grid(mgroups, nseg);
     if (mfma) {
       switch (Dj) {
         case 32: hipLaunchKernelGGL(estep_full_stats_kernel<32>, grid, dim3(512), 0, st, dX, n0, n, M, sc.LP.p, sc.part.p, plen); break;
@@ -567,15 +606,15 @@ static int estep_full_device(const double *dX, int64_t N, int Dj, int M, const d
         default: hipLaunchKernelGGL(estep_full_stats_kernel<80>, grid, dim3(512), 0, st, dX, n0, n, M, sc.LP.p, sc.part.p, plen); break;
       }
     } else {
-      hipLaunchKernelGGL(estep_full_stats_generic_kernel, dim3(M, kFullSeg), dim3(256), 0, st, dX, n0, n, Dj, M, sc.LP.p,
+      hipLaunchKernelGGL(estep_full_stats_generic_kernel, dim3(M, nseg), dim3(256), 0, st, dX, n0, n, Dj, M, sc.LP.p,
                          sc.part.p, plen);
     }
     // the loglik slot of the partial rows is zero, so the generic reduction leaves dstats[plen-1] (set above) intact
-    hipLaunchKernelGGL(estep_reduce_kernel, dim3((unsigned)((plen + 255) / 256)), dim3(256), 0, st, sc.part.p, kFullSeg, plen,
+    hipLaunchKernelGGL(estep_reduce_kernel, dim3((unsigned)((plen + 255) / 256)), dim3(256), 0, st, sc.part.p, nseg, plen,
                        dstats);
     VCMI_HIP(hipGetLastError());
   }
-  VCMI_HIP(hipStreamSynchronize(st));   // the px handle (device blocks) is released on return
+  VCMI_HIP(hipStreamSynchronize(st));   // the px handle's device blocks are rewritten by the next call
   return VCMI_OK;
 }
 

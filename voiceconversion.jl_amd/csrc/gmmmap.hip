@@ -484,13 +484,14 @@ static int prepare(vcmi_gmmmap *g, const double *w, const double *mu, const doub
   g->M = M;
   g->DP = DP;
   const size_t dd = (size_t)D * D, pp = (size_t)DP * DP;
-  g->h_A_julia.assign(dd * M, 0.0);
-  g->h_Sxy.assign(dd * M, 0.0);
-  g->h_Syy.assign(dd * M, 0.0);
-  g->h_A.assign(dd * M, 0.0);
+  const size_t reg = px_only ? 0 : 1;   // the regression side (A, b, Sxy, Syy) does not exist for a p(x)-only handle
+  g->h_A_julia.assign(reg * dd * M, 0.0);
+  g->h_Sxy.assign(reg * dd * M, 0.0);
+  g->h_Syy.assign(reg * dd * M, 0.0);
+  g->h_A.assign(reg * dd * M, 0.0);
   g->h_mux.assign((size_t)D * M, 0.0);
   g->h_muy.assign((size_t)D * M, 0.0);
-  std::vector<double> hU(pp * M, 0.0), hA(pp * M, 0.0), hcz((size_t)DP * M, 0.0), hb((size_t)DP * M, 0.0), hlc(M);
+  std::vector<double> hU(pp * M, 0.0), hA(reg * pp * M, 0.0), hcz((size_t)DP * M, 0.0), hb(reg * DP * M, 0.0), hlc(M);
   std::vector<double> Sxx(dd), Syx(dd), inv(dd), L(dd), Ui(dd);
   const int xo = (swap && !px_only) ? D : 0, yo = px_only ? 0 : (swap ? 0 : D);   // src/gmmmap.jl:74-78
   const double LOG2PI = 1.8378770664093454835606594728112;
@@ -511,17 +512,17 @@ static int prepare(vcmi_gmmmap *g, const double *w, const double *mu, const doub
         g->h_Syy[dd * m + (size_t)r * D + c] = S[(yo + r) + (size_t)Dj * (yo + c)];
       }
     // A_m = Syx inv(Sxx) on the raw block, src/gmmmap.jl:35
-    double *Am = &g->h_A[dd * m];
+    double *Am = px_only ? nullptr : &g->h_A[dd * m];
     if (!px_only) {
       if (!la::inverse(Sxx.data(), D, inv.data()))
         return fail(VCMI_ERR_NOT_PD, "Sigma^xx of mixture %d is singular", m + 1);
       la::matmul(Syx.data(), inv.data(), D, Am);
+      for (int r = 0; r < D; ++r)
+        for (int c = 0; c < D; ++c) {
+          g->h_A_julia[dd * m + r + (size_t)D * c] = Am[(size_t)r * D + c];
+          hA[pp * m + (size_t)r * DP + c] = Am[(size_t)r * D + c];
+        }
     }
-    for (int r = 0; r < D; ++r)
-      for (int c = 0; c < D; ++c) {
-        g->h_A_julia[dd * m + r + (size_t)D * c] = Am[(size_t)r * D + c];
-        hA[pp * m + (size_t)r * DP + c] = Am[(size_t)r * D + c];
-      }
     // p(x): Hermitian(Sxx) (upper triangle mirrored, src/gmm.jl:16) -> Cholesky -> U = inv(L)
     if (!la::cholesky_from_upper(Sxx.data(), D, L.data()))
       return fail(VCMI_ERR_NOT_PD, "Sigma^xx of mixture %d is not positive definite", m + 1);
@@ -535,22 +536,28 @@ static int prepare(vcmi_gmmmap *g, const double *w, const double *mu, const doub
       for (int c = 0; c < D; ++c) {
         hU[pp * m + (size_t)r * DP + c] = Ui[(size_t)r * D + c];
         cz += Ui[(size_t)r * D + c] * mux[c];
-        ba += Am[(size_t)r * D + c] * mux[c];
+        if (!px_only) ba += Am[(size_t)r * D + c] * mux[c];
       }
       hcz[(size_t)DP * m + r] = cz;
-      hb[(size_t)DP * m + r] = muy[r] - ba;
+      if (!px_only) hb[(size_t)DP * m + r] = muy[r] - ba;
     }
   }
-  VCMI_TRY(g->U.alloc(hU.size()));
-  VCMI_TRY(g->A.alloc(hA.size()));
-  VCMI_TRY(g->cz.alloc(hcz.size()));
-  VCMI_TRY(g->b.alloc(hb.size()));
-  VCMI_TRY(g->lc.alloc(hlc.size()));
-  VCMI_HIP(hipMemcpy(g->U.p, hU.data(), hU.size() * 8, hipMemcpyHostToDevice));
-  VCMI_HIP(hipMemcpy(g->A.p, hA.data(), hA.size() * 8, hipMemcpyHostToDevice));
-  VCMI_HIP(hipMemcpy(g->cz.p, hcz.data(), hcz.size() * 8, hipMemcpyHostToDevice));
-  VCMI_HIP(hipMemcpy(g->b.p, hb.data(), hb.size() * 8, hipMemcpyHostToDevice));
-  VCMI_HIP(hipMemcpy(g->lc.p, hlc.data(), hlc.size() * 8, hipMemcpyHostToDevice));
+  // row-major blocks for the generic kernels; a p(x)-only handle that takes the MFMA path needs only its packed blocks
+  // (device buffers are grow-only so that a handle re-prepared every EM iteration does not re-allocate)
+  if (!(px_only && gmmmap_has_mfma(DP))) {
+    VCMI_TRY(g->U.reserve(hU.size()));
+    VCMI_TRY(g->cz.reserve(hcz.size()));
+    VCMI_TRY(g->lc.reserve(hlc.size()));
+    VCMI_HIP(hipMemcpy(g->U.p, hU.data(), hU.size() * 8, hipMemcpyHostToDevice));
+    VCMI_HIP(hipMemcpy(g->cz.p, hcz.data(), hcz.size() * 8, hipMemcpyHostToDevice));
+    VCMI_HIP(hipMemcpy(g->lc.p, hlc.data(), hlc.size() * 8, hipMemcpyHostToDevice));
+  }
+  if (!px_only) {
+    VCMI_TRY(g->A.reserve(hA.size()));
+    VCMI_TRY(g->b.reserve(hb.size()));
+    VCMI_HIP(hipMemcpy(g->A.p, hA.data(), hA.size() * 8, hipMemcpyHostToDevice));
+    VCMI_HIP(hipMemcpy(g->b.p, hb.data(), hb.size() * 8, hipMemcpyHostToDevice));
+  }
 
   // packed operand blocks for the MFMA kernel (issue order: phase U k-major over U tiles, then phase A)
   for (int uonly = px_only ? 1 : 0; uonly < 2 && gmmmap_has_mfma(DP); ++uonly) {
@@ -583,26 +590,34 @@ static int prepare(vcmi_gmmmap *g, const double *w, const double *mu, const doub
       blk[tl.LC_OFF] = hlc[m];
     }
     DevBuf<double> &dst = uonly ? g->packedU : g->packed;
-    VCMI_TRY(dst.alloc(pk.size()));
+    VCMI_TRY(dst.reserve(pk.size()));
     VCMI_HIP(hipMemcpy(dst.p, pk.data(), pk.size() * 8, hipMemcpyHostToDevice));
   }
   if (!px_only) VCMI_TRY(gmmmap_pack_g4(g, hU, hA, hcz, hb, hlc));
   return VCMI_OK;
 }
 
-// p(x)-only handle over a plain GMM of dimension D (weights (M), mu (D,M), sigma (D,D,M)); used by estep.hip
-int gmm_px_create(const double *w, const double *mu, const double *sigma, int D, int M, vcmi_gmmmap **out) {
-  *out = nullptr;
+// p(x)-only handle over a plain GMM of dimension D (weights (M), mu (D,M), sigma (D,D,M)); used by estep.hip.
+// *inout == nullptr creates a handle; otherwise the existing handle (same device) is re-prepared in place, reusing its
+// device buffers -- the caller must have drained every stream that still reads them.
+int gmm_px_create(const double *w, const double *mu, const double *sigma, int D, int M, vcmi_gmmmap **inout) {
   VCMI_TRY(check_device());
-  vcmi_gmmmap *g = new (std::nothrow) vcmi_gmmmap();
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (*inout && (*inout)->device != dev) {
+    delete *inout;
+    *inout = nullptr;
+  }
+  vcmi_gmmmap *g = *inout ? *inout : new (std::nothrow) vcmi_gmmmap();
   if (!g) return fail(VCMI_ERR_OOM, "out of host memory");
-  (void)hipGetDevice(&g->device);
+  g->device = dev;
   int rc = prepare(g, w, mu, sigma, D, M, 0, /*px_only=*/true);
   if (rc != VCMI_OK) {
     delete g;
+    *inout = nullptr;
     return rc;
   }
-  *out = g;
+  *inout = g;
   return VCMI_OK;
 }
 

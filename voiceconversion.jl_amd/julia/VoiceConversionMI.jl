@@ -16,7 +16,7 @@ module VoiceConversionMI
 
 export GMMMap, TrajectoryGMMMap, fvconvert, vc, dim, ncomponents,
        DTW, fit!, update!, set_template!, backward, align, push_delta,
-       predict_proba, predict, estep_diag
+       predict_proba, predict, estep_diag, estep_full
 
 const libvcmi = get(ENV, "LIBVCMI", "libvcmi")
 
@@ -237,6 +237,19 @@ function estep_diag(X::Matrix{Float64}, w::Vector{Float64}, μ::Matrix{Float64},
                 (Ptr{Float64}, Int64, Cint, Cint, Ptr{Float64}, Ptr{Float64}, Ptr{Float64},
                  Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ref{Float64}),
                 X, size(X, 2), Dj, M, w, μ, σ², S0, S1, S2, ll))
+    S0, S1, S2, ll[]
+end
+
+# full-covariance statistics: Σ is (Dj,Dj,M) as in the model file; S2 is (Dj,Dj,M) = Σₙ γₙₘ xₙxₙᵀ.  This is the
+# E-step of the sklearn.mixture.GMM(covariance_type="full") that bin/train_gmm.jl:84-89 constructs.
+function estep_full(X::Matrix{Float64}, w::Vector{Float64}, μ::Matrix{Float64}, Σ::Array{Float64,3})
+    Dj, M = size(μ)
+    size(Σ) == (Dj, Dj, M) || throw(DimensionMismatch("Σ must be (Dj,Dj,M)"))
+    S0 = Vector{Float64}(undef, M); S1 = similar(μ); S2 = similar(Σ); ll = Ref{Float64}(0.0)
+    check(ccall((:vcmi_estep_full, libvcmi), Cint,
+                (Ptr{Float64}, Int64, Cint, Cint, Ptr{Float64}, Ptr{Float64}, Ptr{Float64},
+                 Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ref{Float64}),
+                X, size(X, 2), Dj, M, w, μ, Σ, S0, S1, S2, ll))
     S0, S1, S2, ll[]
 end
 
