@@ -88,6 +88,29 @@ def test_batch_ragged_and_align(vc):
         assert src.shape == newtgt.shape
 
 
+@pytest.mark.parametrize("D", [40, 13])
+def test_device_resident_batch(vc, D):
+    """vcmi_dtw_fit_batch_dev: features already in HBM, ragged pairs spanning several 256-frame row blocks and
+    128-frame column blocks of the observation kernel; bit-exact paths."""
+    import torch
+    from oracle import c_oracle as co
+    from voiceconversion_jl_amd.dtw import fit_batch_dev
+    rng = np.random.default_rng(D)
+    shapes = [(500, 500), (513, 129), (64, 550), (129, 128), (550, 450), (1, 7), (300, 1)]
+    pairs = [_warped_pair(rng, S, T, D) for S, T in shapes]
+    chunks, toff, soff, off = [], [], [], 0
+    for t, s in pairs:
+        toff.append(off); chunks.append(t.ravel()); off += t.size
+        soff.append(off); chunks.append(s.ravel()); off += s.size
+    feats = torch.from_numpy(np.concatenate(chunks)).cuda()
+    d = vc.DTW(fstep=0, bstep=2)
+    paths, poff = fit_batch_dev(d, feats, toff, [s for s, _ in shapes], soff, [t for _, t in shapes], D)
+    got = paths.cpu().numpy()
+    for i, (t, s) in enumerate(pairs):
+        ref = co.dtw_fit(t, s, 0, 2, tables=False)
+        assert np.array_equal(got[poff[i]:poff[i] + len(ref)], ref), f"pair {i} {shapes[i]}"
+
+
 def test_empty_sequence_and_errors(vc):
     d = vc.DTW()
     p = vc.fit_(d, np.ones((3, 4)), np.zeros((3, 0)))

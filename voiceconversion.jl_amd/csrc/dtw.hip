@@ -33,6 +33,7 @@ struct DtwPair {
   unsigned char *codes; // (S,T) bytes in HBM, used only when the step codes do not fit in LDS
   int64_t obs_off;      // (S,T) observation costs at obs_ws + obs_off (fast path workspace)
   int64_t spad_off;     // offset of the zero-padded sequence copy (fast path, D != DMAX)
+  int64_t tpad_off;     // offset of the zero-padded template copy (same workspace)
   int32_t S, T;
 };
 
@@ -129,47 +130,110 @@ __device__ void dtw_finish(const DtwPair &P, const double *__restrict__ seq, int
 static constexpr int kObsRows = 256;    // template frames per obs workgroup (4 waves)
 static constexpr int kObsCols = 128;    // sequence frames per obs workgroup
 
-// zero-pads the sequence of every pair to DMAX doubles per frame (only launched when D != DMAX), so that the
-// observation loop below is branch-free: (0 - 0)^2 = +0.0 added to a non-negative sum leaves it bit-identical.
+// zero-pads the sequence and the template of every pair to DMAX doubles per frame (only launched when D != DMAX), so
+// that the observation loop is branch-free: (0 - 0)^2 = +0.0 added to a non-negative sum leaves it bit-identical.
 __global__ void __launch_bounds__(256)
 dtw_pad_kernel(const double *__restrict__ feats, const DtwPair *__restrict__ pairs, int D, int DMAX, double *__restrict__ spad) {
   const DtwPair P = pairs[blockIdx.x];
-  const int64_t n = (int64_t)P.T * DMAX;
-  for (int64_t e = (int64_t)blockIdx.y * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.y * 256) {
-    const int64_t t = e / DMAX;
-    const int d = (int)(e % DMAX);
-    spad[P.spad_off + e] = (d < D) ? feats[P.seq_off + t * D + d] : 0.0;
+  const int64_t ns = (int64_t)P.T * DMAX, nt = (int64_t)P.S * DMAX;
+  for (int64_t e = (int64_t)blockIdx.y * 256 + threadIdx.x; e < ns + nt; e += (int64_t)gridDim.y * 256) {
+    const bool isseq = e < ns;
+    const int64_t k = isseq ? e : e - ns;
+    const int64_t f = k / DMAX;
+    const int d = (int)(k % DMAX);
+    const double v = (d < D) ? feats[(isseq ? P.seq_off : P.tmpl_off) + f * D + d] : 0.0;
+    spad[(isseq ? P.spad_off : P.tpad_off) + k] = v;
   }
 }
 
-// sbase + P.<off>: sequence with exactly DMAX doubles per frame (the caller's buffer when D == DMAX, else the padded copy)
-template <int DMAX>
+// Observation kernels.  `base` + P.<off>: feature matrices with exactly DMAX doubles per frame (the caller's buffer
+// when D == DMAX, else the zero-padded copies made by dtw_pad_kernel).
+//
+// Compiler-scheduled variant (DMAX > 40): RPL template frames per lane (a wave owns 64*RPL consecutive frames), so
+// that every scalar-loaded sequence value feeds RPL subtractions.
+template <int DMAX, int RPL>
 __global__ void __launch_bounds__(kObsRows)
-dtw_obs_kernel(const double *__restrict__ feats, const double *__restrict__ sbase, int padded,
-               const DtwPair *__restrict__ pairs, int D, double *__restrict__ obs_ws) {
+dtw_obs_kernel(const double *__restrict__ base, int padded, const DtwPair *__restrict__ pairs, double *__restrict__ obs_ws) {
   const DtwPair P = pairs[blockIdx.x];
   const int S = P.S, T = P.T;
-  const int r = blockIdx.y * kObsRows + threadIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int rbase = (blockIdx.y * (kObsRows / 64) + wave) * (64 * RPL);
   const int t0 = blockIdx.z * kObsCols;
-  if (blockIdx.y * kObsRows >= S || t0 >= T) return;      // workgroup-uniform
-  const bool active = r < S;
-  const double *__restrict__ seq = sbase + (padded ? P.spad_off : P.seq_off);
-  double tm[DMAX];
+  if (rbase >= S || t0 >= T) return;                          // wave-uniform (no barriers in this kernel)
+  const double *__restrict__ seq = base + (padded ? P.spad_off : P.seq_off);
+  const double *__restrict__ tmpl = base + (padded ? P.tpad_off : P.tmpl_off);
+  double tm[RPL][DMAX];
+  bool active[RPL];
 #pragma unroll
-  for (int d = 0; d < DMAX; ++d) tm[d] = (active && d < D) ? feats[P.tmpl_off + (int64_t)D * r + d] : 0.0;
-  const int t1 = (t0 + kObsCols < T) ? t0 + kObsCols : T;
-  double *__restrict__ O = obs_ws + P.obs_off;   // kernel-argument base: global (not flat) stores
-  for (int t = t0; t < t1; ++t) {
-    const double *__restrict__ v = seq + (size_t)DMAX * t;   // wave-uniform -> scalar loads
-    double o = 0.0;                                       // observation(d, v, i), src/dtw.jl:33-35
+  for (int q = 0; q < RPL; ++q) {
+    const int r = rbase + 64 * q + lane;
+    active[q] = r < S;
+    const double *row = tmpl + (int64_t)DMAX * (active[q] ? r : S - 1);
 #pragma unroll
-    for (int d = 0; d < DMAX; ++d) {
-      const double df = v[d] - tm[d];
-      const double sq = df * df;
-      o = o + sq;
-    }
-    if (active) O[(size_t)S * t + r] = o;
+    for (int d = 0; d < DMAX; ++d) tm[q][d] = row[d];
   }
+  const int t1 = (t0 + kObsCols < T) ? t0 + kObsCols : T;
+  double *__restrict__ O = obs_ws + P.obs_off + rbase + lane;   // kernel-argument base: global (not flat) stores
+  for (int t = t0; t < t1; ++t) {
+    const double *__restrict__ v = seq + (size_t)DMAX * t;     // wave-uniform -> scalar loads
+    double o[RPL];                                              // observation(d, v, i), src/dtw.jl:33-35
+#pragma unroll
+    for (int q = 0; q < RPL; ++q) o[q] = 0.0;
+#pragma unroll
+    for (int d = 0; d < DMAX; ++d)
+#pragma unroll
+      for (int q = 0; q < RPL; ++q) {
+        const double df = v[d] - tm[q][d];
+        const double sq = df * df;
+        o[q] = o[q] + sq;
+      }
+#pragma unroll
+    for (int q = 0; q < RPL; ++q)
+      if (active[q]) O[(size_t)S * t + 64 * q] = o[q];
+  }
+}
+
+// Hand-scheduled column loop (tools/gen_dtw_obs_asm.py -> dtw_obs_asm.inc), DMAX <= 40: lane = template frame (its
+// DMAX values in v[0:2*DMAX-1]), the sequence column arrives through scalar loads in half-column chunks with two SGPR
+// buffers -- wait(0) -> issue the next chunk's loads -> FP64 work of the current chunk -- see the generator for why the
+// compiler cannot produce this schedule.  91 VGPRs -> 5 waves per SIMD.
+#include "dtw_obs_asm.inc"
+template <int DMAX>
+__global__ void __launch_bounds__(kObsRows)
+dtw_obs_asm_kernel(const double *__restrict__ base, int padded, const DtwPair *__restrict__ pairs,
+                   double *__restrict__ obs_ws) {
+  const DtwPair P = pairs[blockIdx.x];
+  const int S = P.S, T = P.T;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int rbase = (blockIdx.y * (kObsRows / 64) + wave) * 64;
+  const int t0 = blockIdx.z * kObsCols;
+  if (rbase >= S || t0 >= T) return;                        // wave-uniform (no barriers in this kernel)
+  const int t1 = (t0 + kObsCols < T) ? t0 + kObsCols : T;
+  const int r0 = rbase + lane;
+  // rows past the template are clamped for the loads and masked for the stores
+  const double *row0 = base + (padded ? P.tpad_off : P.tmpl_off) + (int64_t)DMAX * (r0 < S ? r0 : S - 1);
+  const double *seq = base + (padded ? P.spad_off : P.seq_off) + (int64_t)DMAX * t0;   // wave-uniform
+  double *optr = obs_ws + P.obs_off + (int64_t)S * t0 + r0;
+  const uint64_t m0 = __ballot(r0 < S);
+  const uint64_t stride = (uint64_t)S * 8;
+  uint32_t ncols = (uint32_t)(t1 - t0), off = 0;
+  // Warm this XCD's L2 with the workgroup's block of sequence columns (one vector load per 64-byte line, all in flight
+  // at once): a scalar load has one chunk of lead time, which covers an L2 hit but not an HBM / Infinity-Cache miss.
+  double pf = 0.0;
+  const int nlines = (int)ncols * DMAX / 8;
+  for (int l = threadIdx.x; l < nlines; l += kObsRows) pf += seq[8 * l];
+#define VCMI_OBS_ASM(BODY)                                                                                          \
+  asm volatile(BODY                                                                                                 \
+               : [seq] "+s"(seq), [n] "+s"(ncols), [optr] "+v"(optr), [off] "+s"(off)                               \
+               : [row0] "v"(row0), [stride] "s"(stride), [m0] "s"(m0)                                               \
+               : "memory", "vcc", "scc", VCMI_OBS_ASM_CLOBBERS)
+  if constexpr (DMAX == 8) VCMI_OBS_ASM(VCMI_DTW_OBS_ASM_D8);
+  if constexpr (DMAX == 16) VCMI_OBS_ASM(VCMI_DTW_OBS_ASM_D16);
+  if constexpr (DMAX == 24) VCMI_OBS_ASM(VCMI_DTW_OBS_ASM_D24);
+  if constexpr (DMAX == 32) VCMI_OBS_ASM(VCMI_DTW_OBS_ASM_D32);
+  if constexpr (DMAX == 40) VCMI_OBS_ASM(VCMI_DTW_OBS_ASM_D40);
+#undef VCMI_OBS_ASM
+  if (pf == 0x1.123456789abcdp+1000) obs_ws[0] = pf;   // keeps the warm-up loads alive; never true for finite features
 }
 
 template <int STEPS, int CODES>
@@ -362,17 +426,24 @@ static int dtw_dmax(int D) {
 
 static int launch_obs(const double *feats, const double *spad, const DtwPair *dpairs, int n, int D, int Smax, int Tmax,
                       double *obs_ws, hipStream_t st) {
-  const dim3 grid(n, (Smax + kObsRows - 1) / kObsRows, (Tmax + kObsCols - 1) / kObsCols);
   const int dmax = dtw_dmax(D);
   const int padded = (D != dmax);
   const double *sbase = padded ? spad : feats;
   if (padded) hipLaunchKernelGGL(dtw_pad_kernel, dim3(n, 8), dim3(256), 0, st, feats, dpairs, D, dmax, const_cast<double *>(spad));
-  switch (dmax) {
+  const unsigned colblocks = (Tmax + kObsCols - 1) / kObsCols;
+  if (dmax <= 40) {   // hand-scheduled column loop, one template frame per lane (5 waves per SIMD)
+    const dim3 grid(n, (Smax + kObsRows - 1) / kObsRows, colblocks);
 #define VCMI_OBS_CASE(DM) \
-  case DM: hipLaunchKernelGGL(dtw_obs_kernel<DM>, grid, dim3(kObsRows), 0, st, feats, sbase, padded, dpairs, D, obs_ws); break;
-    VCMI_OBS_CASE(8) VCMI_OBS_CASE(16) VCMI_OBS_CASE(24) VCMI_OBS_CASE(32) VCMI_OBS_CASE(40) VCMI_OBS_CASE(48)
-    VCMI_OBS_CASE(64) VCMI_OBS_CASE(96)
+  case DM: hipLaunchKernelGGL((dtw_obs_asm_kernel<DM>), grid, dim3(kObsRows), 0, st, sbase, padded, dpairs, obs_ws); break;
+    switch (dmax) { VCMI_OBS_CASE(8) VCMI_OBS_CASE(16) VCMI_OBS_CASE(24) VCMI_OBS_CASE(32) VCMI_OBS_CASE(40) }
 #undef VCMI_OBS_CASE
+  } else {            // compiler-scheduled loop (two frames per lane at DMAX = 48 spills SGPRs: one frame per lane)
+    const dim3 grid(n, (Smax + kObsRows - 1) / kObsRows, colblocks);
+    switch (dmax) {
+      case 48: hipLaunchKernelGGL((dtw_obs_kernel<48, 1>), grid, dim3(kObsRows), 0, st, sbase, padded, dpairs, obs_ws); break;
+      case 64: hipLaunchKernelGGL((dtw_obs_kernel<64, 1>), grid, dim3(kObsRows), 0, st, sbase, padded, dpairs, obs_ws); break;
+      default: hipLaunchKernelGGL((dtw_obs_kernel<96, 1>), grid, dim3(kObsRows), 0, st, sbase, padded, dpairs, obs_ws); break;
+    }
   }
   VCMI_HIP(hipGetLastError());
   return VCMI_OK;
@@ -435,7 +506,7 @@ static int dtw_run(const double *feats, std::vector<DtwPair> &pairs, int D, int 
       const int dmax = dtw_dmax(D);
       if (D != dmax) {
         size_t padn = 0;
-        for (int k = lo; k < hi; ++k) padn += (size_t)pairs[k].T * dmax;
+        for (int k = lo; k < hi; ++k) padn += (size_t)(pairs[k].T + pairs[k].S) * dmax;
         VCMI_TRY(spad_ws.reserve(padn));
       }
       size_t off = 0, poff = 0;
@@ -445,6 +516,8 @@ static int dtw_run(const double *feats, std::vector<DtwPair> &pairs, int D, int 
         off += (size_t)pairs[k].S * pairs[k].T;
         pairs[k].spad_off = (int64_t)poff;
         poff += (size_t)pairs[k].T * dmax;
+        pairs[k].tpad_off = (int64_t)poff;
+        poff += (size_t)pairs[k].S * dmax;
         smax = std::max(smax, pairs[k].S);
         tmax = std::max(tmax, pairs[k].T);
       }
@@ -524,6 +597,7 @@ static int dtw_host_batch(int64_t n, const double *const *tmpl, const int64_t *S
     q.codes = nullptr;
     q.obs_off = 0;
     q.spad_off = 0;
+    q.tpad_off = 0;
     q.S = (int32_t)S[p];
     q.T = (int32_t)T[p];
   }
@@ -584,8 +658,13 @@ extern "C" int vcmi_dtw_fit_batch_dev(int64_t n, const double *feats, const int6
   std::vector<DtwPair> pairs(n);
   for (int64_t p = 0; p < n; ++p) {
     if (S[p] < 1 || T[p] < 0 || S[p] > INT32_MAX || T[p] > INT32_MAX) return fail(VCMI_ERR_DIM, "DTW: bad sequence length");
-    pairs[p] = DtwPair{tmpl_off[p], seq_off[p], paths + path_off[p], nullptr, nullptr, nullptr, nullptr, 0, 0,
-                       (int32_t)S[p], (int32_t)T[p]};
+    DtwPair q{};
+    q.tmpl_off = tmpl_off[p];
+    q.seq_off = seq_off[p];
+    q.path = paths + path_off[p];
+    q.S = (int32_t)S[p];
+    q.T = (int32_t)T[p];
+    pairs[p] = q;
   }
   DtwScratch &sc = scratch();
   return dtw_run(feats, pairs, D, fstep, bstep, sc.codes, sc.obs, sc.spad, sc.dpairs, as_stream(stream));

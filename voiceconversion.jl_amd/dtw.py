@@ -88,6 +88,30 @@ def fit_batch(d, templates, sequences):
     return paths
 
 
+def fit_batch_dev(d, feats, tmpl_off, S, seq_off, T, D, paths=None):
+    """Device-resident batch: `feats` is a 1-D float64 torch tensor on the HIP device holding every (D,S) template and
+    (D,T) sequence in the Julia memory image at element offsets tmpl_off / seq_off.  Returns (paths, path_off): one
+    int64 device tensor with the 1-based paths back to back, and the host offsets of each pair's path in it."""
+    import torch
+
+    from ._arrays import current_stream_ptr
+
+    arr = lambda a: np.ascontiguousarray(a, dtype=np.int64)  # noqa: E731
+    tmpl_off, S, seq_off, T = arr(tmpl_off), arr(S), arr(seq_off), arr(T)
+    n = len(S)
+    if not (len(tmpl_off) == len(seq_off) == len(T) == n):
+        raise ValueError("offset and length arrays must have one entry per pair")
+    if feats.dtype != torch.float64 or not feats.is_cuda or not feats.is_contiguous():
+        raise TypeError("feats must be a contiguous float64 tensor on the HIP device")
+    path_off = np.concatenate([[0], np.cumsum(T)[:-1]]).astype(np.int64) if n else np.zeros(0, dtype=np.int64)
+    if paths is None:
+        paths = torch.empty(int(T.sum()), dtype=torch.int64, device=feats.device)
+    _lib.check(_lib.lib.vcmi_dtw_fit_batch_dev(n, feats.data_ptr(), _lib.iptr(tmpl_off), _lib.iptr(S), _lib.iptr(seq_off),
+                                               _lib.iptr(T), int(D), d.fstep, d.bstep, paths.data_ptr(), _lib.iptr(path_off),
+                                               current_stream_ptr()))
+    return paths, path_off
+
+
 def update_(d, v):
     """update!(d, v): one on-line column, src/dtw.jl:61-90.  Host-side by design (the reference
     grows both tables by hcat per call; a single S-cell column is not a GPU target).  Same arithmetic order as
