@@ -244,6 +244,9 @@ dtw_rec_kernel(const double *__restrict__ feats, const DtwPair *__restrict__ pai
   constexpr int BITS = (CODES == 0) ? 2 : 8;
   constexpr int CPW = 32 / BITS;
   constexpr int PF = 8;                                   // columns of O per register set
+  // This kernel is a chain of ~T short dependent steps; observation kernels of the next chunk run beside it on the same
+  // CUs (dtw_run) and must not delay its instruction issue.
+  __builtin_amdgcn_s_setprio(3);
   const DtwPair P = pairs[blockIdx.x];
   const int S = P.S, T = P.T;
   const int r = threadIdx.x;
@@ -420,6 +423,40 @@ static int launch_rec(const double *feats, const DtwPair *dpairs, int n, int D, 
   return VCMI_OK;
 }
 
+// Side stream on which the observation kernels run: the recurrence of chunk c (latency-bound: one barrier per column,
+// few FP64 instructions) overlaps the observation costs of chunk c+1 (FP64-ALU-bound) on the same CUs.
+struct DtwOverlap {
+  static constexpr int kMaxChunks = 8;
+  hipStream_t side = nullptr;
+  hipEvent_t fork = nullptr, done[kMaxChunks] = {};
+  int device = -1;
+  int init() {
+    int dev = 0;
+    VCMI_HIP(hipGetDevice(&dev));
+    if (side && dev == device) return VCMI_OK;
+    release();
+    VCMI_HIP(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+    VCMI_HIP(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
+    for (auto &e : done) VCMI_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    device = dev;
+    return VCMI_OK;
+  }
+  void release() {
+    if (side) (void)hipStreamDestroy(side);
+    if (fork) (void)hipEventDestroy(fork);
+    for (auto &e : done)
+      if (e) (void)hipEventDestroy(e);
+    side = nullptr;
+    fork = nullptr;
+    for (auto &e : done) e = nullptr;
+  }
+  ~DtwOverlap() { release(); }
+};
+static DtwOverlap &dtw_overlap() {
+  static thread_local DtwOverlap o;
+  return o;
+}
+
 static int dtw_dmax(int D) {
   return D <= 8 ? 8 : D <= 16 ? 16 : D <= 24 ? 24 : D <= 32 ? 32 : D <= 40 ? 40 : D <= 48 ? 48 : D <= 64 ? 64 : 96;
 }
@@ -523,8 +560,27 @@ static int dtw_run(const double *feats, std::vector<DtwPair> &pairs, int D, int 
       }
       VCMI_HIP(hipMemcpy(dpairs.p + lo, pairs.data() + lo, sizeof(DtwPair) * (hi - lo), hipMemcpyHostToDevice));
       if (tmax > 0) {
-        VCMI_TRY(launch_obs(feats, spad_ws.p, dpairs.p + lo, hi - lo, D, smax, tmax, obs_ws.p, st));
-        VCMI_TRY(launch_rec(feats, dpairs.p + lo, hi - lo, D, fstep, bstep, Smax, Tmax, steps, codes, shmem, threads, obs_ws.p, st));
+        // chunks of the slice: observation costs on the side stream, recurrences on the caller's stream behind them
+        const int m = hi - lo;
+        // (a recurrence launch occupies one CU per pair for ~T barriers whatever its size: chunks of about one pair
+        // per CU keep every recurrence round full)
+        const int nchunks = (m < 192) ? 1 : std::min(DtwOverlap::kMaxChunks, (m + 255) / 256);
+        if (nchunks == 1) {
+          VCMI_TRY(launch_obs(feats, spad_ws.p, dpairs.p + lo, m, D, smax, tmax, obs_ws.p, st));
+          VCMI_TRY(launch_rec(feats, dpairs.p + lo, m, D, fstep, bstep, Smax, Tmax, steps, codes, shmem, threads, obs_ws.p, st));
+        } else {
+          DtwOverlap &ov = dtw_overlap();
+          VCMI_TRY(ov.init());
+          VCMI_HIP(hipEventRecord(ov.fork, st));                 // the side stream starts behind the caller's earlier work
+          VCMI_HIP(hipStreamWaitEvent(ov.side, ov.fork, 0));     // (which includes the previous call's recurrences)
+          for (int c = 0; c < nchunks; ++c) {
+            const int c0 = lo + (int)((int64_t)m * c / nchunks), c1 = lo + (int)((int64_t)m * (c + 1) / nchunks);
+            VCMI_TRY(launch_obs(feats, spad_ws.p, dpairs.p + c0, c1 - c0, D, smax, tmax, obs_ws.p, ov.side));
+            VCMI_HIP(hipEventRecord(ov.done[c], ov.side));
+            VCMI_HIP(hipStreamWaitEvent(st, ov.done[c], 0));
+            VCMI_TRY(launch_rec(feats, dpairs.p + c0, c1 - c0, D, fstep, bstep, Smax, Tmax, steps, codes, shmem, threads, obs_ws.p, st));
+          }
+        }
       }
       if (hi < n) VCMI_HIP(hipStreamSynchronize(st));   // the next slice reuses the workspace
       lo = hi;
