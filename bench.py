@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload convert|estep|estep_full|dtw|traj]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload convert|estep|estep_full|em_full|dtw|traj]
 
 Default workload = BASELINE.json configs[1]: GMMMap fvconvert, D=40, M=64, T=10^6 synthetic frames per GPU
 (weak scaling: every rank converts its own shard of T frames; frames are independent, so there is no
@@ -285,6 +285,45 @@ def bench_estep_full(args, world, rank):
     return out
 
 
+def bench_em_full(args, world, rank):
+    """One whole EM iteration of the full-covariance GMM as bin/train_gmm.jl:84-103 trains it (Dj=80, M=64, 5e5 frames
+    per GPU): E-step statistics -> ONE all-reduce -> M-step + Cholesky whitening of every mixture, parameters resident
+    in HBM throughout (vcmi_gmm_em_*)."""
+    import torch
+
+    import voiceconversion_jl_amd as vc
+    from oracle import np_oracle as npo
+
+    Dj, M, N = 80, 64, args.frames if args.frames != 1_000_000 else 500_000
+    w, mu, sig = npo.synth_model(1005, Dj, M, lam_lo=1e-3)
+    X = npo.sample_frames(1005 + rank, w, mu, sig, N, 0, Dj)
+    Xd = torch.from_numpy(X).cuda()
+    muT, sgT = np.asfortranarray(mu.T), np.asfortranarray(np.transpose(sig, (2, 1, 0)))
+    em = vc.EMState(w, muT, sgT, min_covar=1e-7)
+    stats = torch.empty(vc.full_stats_len(Dj, M), dtype=torch.float64, device="cuda")
+    hist = []
+
+    def step():
+        em.estep(Xd.t(), out=stats)
+        vc.dist.allreduce_sum_(stats)
+        hist.append(em.mstep(stats))
+
+    wall, kernel_ms = timed_steps(step, args.steps, args.warmup, world)
+    flop = 2 * M * Dj * (Dj + 1) + 2 * M * Dj
+    achieved = flop * N / (kernel_ms * 1e-3) / 1e12
+    out = {"metric": "full-covariance GMM EM iteration frames/sec (Dj=80, M=64)", "value": world * N * args.steps / wall,
+           "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "f64", "data": "synthetic",
+           "config": {"workload": "EM iteration, full covariance (SURVEY 8f rank 1; bin/train_gmm.jl:84-103)", "Dj": Dj, "M": M,
+                      "frames_per_gpu": N, "collective": "all-reduce(sum) of %d doubles per iteration" % vc.full_stats_len(Dj, M)},
+           "roofline": {"bound": "mfma", "kernel": "whole iteration: log-densities + second moments + M-step + whitening",
+                        "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": achieved / FP64_PEAK_TFLOPS, "traffic": None, "flop_per_frame": flop, "kernel_ms": kernel_ms},
+           "loglik_monotone": bool(all(b >= a - 1e-6 * abs(a) for a, b in zip(hist, hist[1:])))}
+    return out
+
+
 # ------------------------------------------------------------------------------------------------ DTW
 def _dtw_pairs(seed, n, D):
     rng = np.random.default_rng(seed)
@@ -419,7 +458,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="convert", choices=["convert", "estep", "estep_full", "dtw", "traj"])
+    ap.add_argument("--workload", default="convert", choices=["convert", "estep", "estep_full", "em_full", "dtw", "traj"])
     ap.add_argument("--frames", type=int, default=1_000_000, help="frames per GPU (BASELINE: 10^6)")
     ap.add_argument("--pairs", type=int, default=1000, help="DTW pairs per GPU")
     ap.add_argument("--utts", type=int, default=256, help="trajectory utterances per GPU")
@@ -429,7 +468,7 @@ def main():
     world, rank, _ = dist_setup(args.gpus)
     if world != args.gpus and rank == 0:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
-    out = {"convert": bench_convert, "estep": bench_estep, "estep_full": bench_estep_full, "dtw": bench_dtw, "traj": bench_traj}[args.workload](args, world, rank)
+    out = {"convert": bench_convert, "estep": bench_estep, "estep_full": bench_estep_full, "em_full": bench_em_full, "dtw": bench_dtw, "traj": bench_traj}[args.workload](args, world, rank)
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

@@ -125,6 +125,24 @@ int vcmi_estep_full(const double *X, int64_t N, int Dj, int M, const double *w, 
 int vcmi_estep_full_dev(const double *dX, int64_t N, int Dj, int M, const double *w, const double *mu,
                         const double *sigma, double *dstats, void *stream);
 
+/* EM state resident on the device -- the loop inside `gmm[:fit](dataset.X')`, bin/train_gmm.jl:84-103
+ * (sklearn.mixture.GMM(covariance_type="full", min_covar)).  Parameters and whitening blocks stay in HBM between
+ * iterations; one iteration is
+ *   vcmi_gmm_em_estep_dev (local statistics of this GPU's frames, asynchronous on `stream`)
+ *   -> the caller sums the statistics buffers of all ranks (one RCCL all-reduce; nothing to do on one GPU)
+ *   -> vcmi_gmm_em_mstep (w = S0/sum S0, mu = S1/S0, Sigma = S2/S0 - mu mu' + min_covar I, then the Cholesky
+ *      whitening of every mixture on the device; returns the log-likelihood the statistics carry).
+ * dstats: caller-owned DEVICE buffer of vcmi_estep_full_stats_len(Dj,M) doubles, layout as vcmi_estep_full_dev.
+ * vcmi_gmm_em_mstep synchronises the stream and reports VCMI_ERR_NOT_PD if a covariance (initial or updated) is not
+ * positive definite. */
+typedef struct vcmi_gmm_em vcmi_gmm_em;
+int vcmi_gmm_em_create(int Dj, int M, const double *w, const double *mu, const double *sigma, double min_covar,
+                       vcmi_gmm_em **out);
+int vcmi_gmm_em_destroy(vcmi_gmm_em *h);
+int vcmi_gmm_em_estep_dev(vcmi_gmm_em *h, const double *dX, int64_t N, double *dstats, void *stream);
+int vcmi_gmm_em_mstep(vcmi_gmm_em *h, const double *dstats, void *stream, double *loglik);
+int vcmi_gmm_em_get(vcmi_gmm_em *h, double *w, double *mu, double *sigma);
+
 /* ---------------------------------------------------------------------------------------------
  * TrajectoryGMMMap -- src/trajectory_gmmmap.jl:3-110, vc src/common.jl:31-63, push_delta src/datasets.jl:6-13
  * ------------------------------------------------------------------------------------------- */

@@ -108,3 +108,62 @@ def test_em_iterations_match_oracle_em(vc):
         wr, mur, sigr = vc.mstep_full(S0, S1.T, np.transpose(S2, (2, 1, 0)))
     assert np.allclose(hist, ref, rtol=1e-8, atol=0)
     assert relerr(mu1, mur) < 1e-7 and relerr(sig1, sigr) < 1e-7
+
+
+def test_device_resident_em_matches_host_em(vc):
+    """EMState (parameters, M-step and Cholesky whitening on the device) follows the same trajectory as the EM loop
+    whose M-step runs on the host (fit_full) and as the oracle-driven EM."""
+    import torch
+    from oracle import np_oracle as npo
+    Dj, M, N = 32, 4, 6000
+    w, mu, sig = npo.synth_model(5, Dj, M, lam_lo=1e-2)
+    X = npo.sample_frames(5, w, mu, sig, N, 0, Dj)
+    rg = np.random.default_rng(0)
+    mu0 = X[rg.choice(N, M, replace=False)].T
+    sig0 = np.repeat(np.cov(X.T)[:, :, None], M, axis=2)
+    w0 = np.full(M, 1.0 / M)
+    Xd = torch.from_numpy(X).cuda().t()
+    em = vc.EMState(w0, mu0, sig0, min_covar=1e-7)
+    hist = []
+    for _ in range(8):
+        st = em.estep(Xd)
+        hist.append(em.mstep(st) / N)
+    w1, mu1, sig1 = em.get()
+    wh, muh, sigh, hh = vc.fit_full(Xd, w0, mu0, sig0, n_iter=8, tol=0.0)
+    assert np.allclose(hist, hh, rtol=1e-10, atol=0)
+    assert relerr(w1, wh) < 1e-9 and relerr(mu1, muh) < 1e-9 and relerr(sig1, sigh) < 1e-9
+    assert np.array_equal(sig1, np.transpose(sig1, (1, 0, 2)))
+    # generic (non-MFMA) dimension takes the same path through px_prep_kernel's row-major outputs
+    Dg = 10
+    wg, mug, sgg = npo.synth_model(6, Dg, 3, lam_lo=1e-2)
+    Xg = npo.sample_frames(6, wg, mug, sgg, 2000, 0, Dg)
+    e2 = vc.EMState(wg, mug.T, np.transpose(sgg, (2, 1, 0)))
+    got = vc.unpack_full_stats(e2.estep(torch.from_numpy(Xg).cuda().t()).cpu().numpy(), Dg, 3)
+    ref = npo.estep_full(Xg, wg, mug, sgg)
+    assert relerr(got[0], ref[0]) < TOL and relerr(got[1], ref[1].T) < TOL and abs(got[3] - ref[3]) < TOL * abs(ref[3])
+
+
+def test_train_gmm_refine_and_init(vc):
+    """train_gmm (bin/train_gmm.jl:84-103): refine keeps improving a pretrained model; a k-means-initialised fit is
+    monotone, beats a single Gaussian and is reproducible for a fixed seed; a non-PD start raises PosDefException."""
+    import torch
+    from oracle import np_oracle as npo
+    Dj, M, N = 16, 4, 12000
+    w, mu, sig = npo.synth_model(11, Dj, M, lam_lo=1e-1)
+    mu = mu * 4.0                                            # well separated mixtures
+    X = npo.sample_frames(11, w, mu, sig, N, 0, Dj)
+    Xd = torch.from_numpy(X).cuda().t()
+    true_ll = npo.estep_full(X, w, mu, sig)[3] / N
+    r = vc.train_gmm(Xd, n_components=M, n_iter=5, refine=(w, mu.T, np.transpose(sig, (2, 1, 0))))
+    assert all(b >= a - 1e-9 for a, b in zip(r["loglik"], r["loglik"][1:])) and r["loglik"][0] > true_ll - 1e-9
+    a = vc.train_gmm(Xd, n_components=M, n_iter=60, n_init=2, seed=3)
+    b = vc.train_gmm(Xd, n_components=M, n_iter=60, n_init=2, seed=3)
+    assert np.array_equal(a["means"], b["means"]) and a["loglik"] == b["loglik"]
+    assert all(y >= x - 1e-9 for x, y in zip(a["loglik"], a["loglik"][1:]))
+    one = npo.estep_full(X, np.ones(1), X.mean(0)[None, :], np.cov(X.T)[None, :, :])[3] / N
+    assert a["loglik"][-1] > one + 1.0 and a["loglik"][-1] > true_ll - 0.2
+    assert abs(a["weights"].sum() - 1.0) < 1e-9 and a["covars"].shape == (Dj, Dj, M)
+    bad = np.transpose(sig, (2, 1, 0)).copy()
+    bad[:, :, 1] = -bad[:, :, 1]
+    with pytest.raises(vc.PosDefException):
+        vc.train_gmm(Xd, n_components=M, n_iter=2, refine=(w, mu.T, bad))

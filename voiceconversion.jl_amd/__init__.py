@@ -15,3 +15,4 @@ from .estep import (estep_diag, estep_diag_allreduce, estep_diag_dev, mstep_diag
                     unpack_full_stats)
 from .trajectory_gmmmap import TrajectoryGMMMap, constructW, push_delta  # noqa: F401,E402
 from . import dist  # noqa: F401,E402
+from .train import EMState, train_gmm  # noqa: F401,E402

@@ -76,6 +76,11 @@ SIGNATURES = {
     "vcmi_estep_full_stats_len": (_i64, [_int, _int]),
     "vcmi_estep_full": (_int, [_dp, _i64, _int, _int, _dp, _dp, _dp, _dp, _dp, _dp, _dp]),
     "vcmi_estep_full_dev": (_int, [_vp, _i64, _int, _int, _dp, _dp, _dp, _vp, _vp]),
+    "vcmi_gmm_em_create": (_int, [_int, _int, _dp, _dp, _dp, C.c_double, C.POINTER(_vp)]),
+    "vcmi_gmm_em_destroy": (_int, [_vp]),
+    "vcmi_gmm_em_estep_dev": (_int, [_vp, _vp, _i64, _vp, _vp]),
+    "vcmi_gmm_em_mstep": (_int, [_vp, _vp, _vp, _dp]),
+    "vcmi_gmm_em_get": (_int, [_vp, _dp, _dp, _dp]),
     "vcmi_traj_create": (_int, [_vp, _i64, C.POINTER(_vp)]),
     "vcmi_traj_destroy": (_int, [_vp]),
     "vcmi_traj_length": (_i64, [_vp]),

@@ -562,7 +562,8 @@ estep_full_stats_generic_kernel(const double *__restrict__ X, int64_t n0, int64_
 }
 
 struct EstepFullScratch {
-  DevBuf<double> LP, lse, part, X, stats;
+  DevBuf<double> LP, lse, part, X, stats, params;
+  DevBuf<int> flag;
   vcmi_gmmmap *px = nullptr;
   ~EstepFullScratch() { delete px; }
 };
@@ -571,18 +572,12 @@ static EstepFullScratch &full_scratch() {
   return s;
 }
 
-static int estep_full_device(const double *dX, int64_t N, int Dj, int M, const double *w, const double *mu,
-                             const double *sigma, double *dstats, hipStream_t st) {
-  if (N < 0 || Dj < 1 || M < 1) return fail(VCMI_ERR_DIM, "E-step: N=%lld Dj=%d M=%d invalid", (long long)N, Dj, M);
-  if (!w || !mu || !sigma || !dstats || (N > 0 && !dX)) return fail(VCMI_ERR_ARG, "E-step: NULL argument");
+// statistics of N device-resident frames under the prepared p(x) handle -> dstats (zeroed here); asynchronous on st
+static int estep_full_core(vcmi_gmmmap *px, const double *dX, int64_t N, int Dj, int M, double *dstats, hipStream_t st) {
   const int64_t plen = (int64_t)M * (1 + Dj + (int64_t)Dj * Dj) + 1;
   VCMI_HIP(hipMemsetAsync(dstats, 0, plen * sizeof(double), st));
   if (N == 0) return VCMI_OK;
   EstepFullScratch &sc = full_scratch();
-  // Cholesky whitening blocks of every mixture (PosDef check); the handle and its device buffers persist per host
-  // thread across EM iterations and are re-prepared in place (this function drains the stream before returning)
-  VCMI_TRY(gmm_px_create(w, mu, sigma, Dj, M, &sc.px));
-  vcmi_gmmmap *px = sc.px;
   const int64_t chunk = std::min<int64_t>(N, (int64_t)1 << 20);
   VCMI_TRY(sc.LP.reserve((size_t)chunk * M));
   VCMI_TRY(sc.lse.reserve((size_t)kSoftmaxGrid));
@@ -614,10 +609,104 @@ static int estep_full_device(const double *dX, int64_t N, int Dj, int M, const d
                        dstats);
     VCMI_HIP(hipGetLastError());
   }
-  VCMI_HIP(hipStreamSynchronize(st));   // the px handle's device blocks are rewritten by the next call
   return VCMI_OK;
 }
 
+static int read_pd_flag(const int *d_flag, hipStream_t st) {
+  int h = 0;
+  VCMI_HIP(hipMemcpyAsync(&h, d_flag, sizeof(int), hipMemcpyDeviceToHost, st));
+  VCMI_HIP(hipStreamSynchronize(st));
+  if (h) return fail(VCMI_ERR_NOT_PD, "covariance of mixture %d is not positive definite", h);
+  return VCMI_OK;
+}
+
+// one E-step from HOST parameters: upload (Dj*Dj*M doubles), Cholesky whitening of every mixture on the device
+// (px_prep_kernel; host fallback for very large Dj), statistics, then the stream is drained (the p(x) handle and the
+// parameter staging buffers persist per host thread and are rewritten by the next call).
+static int estep_full_device(const double *dX, int64_t N, int Dj, int M, const double *w, const double *mu,
+                             const double *sigma, double *dstats, hipStream_t st) {
+  if (N < 0 || Dj < 1 || M < 1) return fail(VCMI_ERR_DIM, "E-step: N=%lld Dj=%d M=%d invalid", (long long)N, Dj, M);
+  if (!w || !mu || !sigma || !dstats || (N > 0 && !dX)) return fail(VCMI_ERR_ARG, "E-step: NULL argument");
+  EstepFullScratch &sc = full_scratch();
+  if (N == 0) return estep_full_core(nullptr, dX, 0, Dj, M, dstats, st);
+  if (gmm_px_device_prepare_supported(Dj)) {
+    const size_t dd = (size_t)Dj * Dj;
+    VCMI_TRY(sc.params.reserve((size_t)M * (1 + Dj + dd)));
+    VCMI_TRY(sc.flag.reserve(1));
+    double *dw = sc.params.p, *dmu = dw + M, *dsig = dmu + (size_t)M * Dj;
+    VCMI_HIP(hipMemcpyAsync(dw, w, sizeof(double) * M, hipMemcpyHostToDevice, st));
+    VCMI_HIP(hipMemcpyAsync(dmu, mu, sizeof(double) * M * Dj, hipMemcpyHostToDevice, st));
+    VCMI_HIP(hipMemcpyAsync(dsig, sigma, sizeof(double) * M * dd, hipMemcpyHostToDevice, st));
+    VCMI_HIP(hipMemsetAsync(sc.flag.p, 0, sizeof(int), st));
+    VCMI_TRY(gmm_px_prepare_device(&sc.px, dw, dmu, dsig, Dj, M, sc.flag.p, st));
+    VCMI_TRY(estep_full_core(sc.px, dX, N, Dj, M, dstats, st));
+    return read_pd_flag(sc.flag.p, st);
+  }
+  VCMI_TRY(gmm_px_create(w, mu, sigma, Dj, M, &sc.px));
+  VCMI_TRY(estep_full_core(sc.px, dX, N, Dj, M, dstats, st));
+  VCMI_HIP(hipStreamSynchronize(st));
+  return VCMI_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// EM state resident on the device (bin/train_gmm.jl:84-103: sklearn.mixture.GMM(covariance_type="full",
+// min_covar).fit): parameters, statistics and whitening blocks stay in HBM; one iteration is
+//   estep (local statistics) -> [caller all-reduces the statistics buffer over RCCL] -> mstep (+ whitening prep).
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+em_mstep_full_kernel(const double *__restrict__ stats, int Dj, int M, double min_covar, double *__restrict__ w,
+                     double *__restrict__ mu, double *__restrict__ sigma) {
+  __shared__ double red[256];
+  __shared__ double mus[256];
+  const int tid = threadIdx.x, m = blockIdx.x;
+  const double eps = 2.220446049250313e-16;
+  double t = 0.0;
+  for (int k = tid; k < M; k += 256) t += stats[k];
+  red[tid] = t;
+  __syncthreads();
+  for (int o = 128; o >= 1; o >>= 1) {
+    if (tid < o) red[tid] += red[tid + o];
+    __syncthreads();
+  }
+  const double tot = red[0], s0 = stats[m];
+  const double inv = 1.0 / (s0 + 10 * eps);
+  const double *S1 = stats + M + (size_t)m * Dj;
+  const double *S2 = stats + M + (size_t)M * Dj + (size_t)m * Dj * Dj;
+  for (int d = tid; d < Dj; d += 256) {
+    const double v = S1[d] * inv;
+    mus[d] = v;
+    mu[(size_t)m * Dj + d] = v;
+  }
+  if (tid == 0) w[m] = s0 / (tot + 10 * eps) + eps;
+  __syncthreads();
+  for (int e = tid; e < Dj * Dj; e += 256) {
+    const int c = e / Dj, r = e - c * Dj;
+    sigma[(size_t)m * Dj * Dj + e] = S2[e] * inv - mus[r] * mus[c] + (r == c ? min_covar : 0.0);
+  }
+}
+
+}  // namespace vcmi
+
+struct vcmi_gmm_em {
+  int Dj = 0, M = 0, device = 0;
+  double min_covar = 0.0;
+  bool prepared = false;
+  vcmi::DevBuf<double> params;   // [w (M) | mu (Dj,M) | sigma (Dj,Dj,M)]
+  vcmi::DevBuf<int> flag;
+  vcmi_gmmmap *px = nullptr;
+  ~vcmi_gmm_em() { delete px; }
+  double *w() { return params.p; }
+  double *mu() { return params.p + M; }
+  double *sigma() { return params.p + M + (size_t)M * Dj; }
+  int64_t plen() const { return (int64_t)M * (1 + Dj + (int64_t)Dj * Dj) + 1; }
+};
+
+namespace vcmi {
+static int em_prepare(vcmi_gmm_em *h, hipStream_t st) {
+  VCMI_TRY(gmm_px_prepare_device(&h->px, h->w(), h->mu(), h->sigma(), h->Dj, h->M, h->flag.p, st));
+  h->prepared = true;
+  return VCMI_OK;
+}
 }  // namespace vcmi
 
 using namespace vcmi;
@@ -679,5 +768,76 @@ extern "C" int vcmi_estep_full(const double *X, int64_t N, int Dj, int M, const 
   memcpy(S1, h.data() + M, sizeof(double) * M * Dj);
   memcpy(S2, h.data() + M + (size_t)M * Dj, sizeof(double) * M * Dj * Dj);
   *loglik = h[(size_t)plen - 1];
+  return VCMI_OK;
+}
+
+// ---- device-resident EM state --------------------------------------------------------------------
+extern "C" int vcmi_gmm_em_create(int Dj, int M, const double *w, const double *mu, const double *sigma, double min_covar,
+                                  vcmi_gmm_em **out) {
+  if (!w || !mu || !sigma || !out) return fail(VCMI_ERR_ARG, "vcmi_gmm_em_create: NULL argument");
+  *out = nullptr;
+  if (Dj < 1 || M < 1) return fail(VCMI_ERR_DIM, "vcmi_gmm_em_create: Dj=%d M=%d invalid", Dj, M);
+  if (!(min_covar >= 0.0)) return fail(VCMI_ERR_ARG, "vcmi_gmm_em_create: min_covar must be >= 0");
+  VCMI_TRY(check_device());
+  if (!gmm_px_device_prepare_supported(Dj)) return fail(VCMI_ERR_ARG, "vcmi_gmm_em_create: joint dimension %d too large", Dj);
+  vcmi_gmm_em *h = new (std::nothrow) vcmi_gmm_em();
+  if (!h) return fail(VCMI_ERR_OOM, "out of host memory");
+  h->Dj = Dj;
+  h->M = M;
+  h->min_covar = min_covar;
+  (void)hipGetDevice(&h->device);
+  const size_t dd = (size_t)Dj * Dj;
+  int rc = h->params.alloc((size_t)M * (1 + Dj + dd));
+  if (rc == VCMI_OK) rc = h->flag.alloc(1);
+  if (rc != VCMI_OK) {
+    delete h;
+    return rc;
+  }
+  hipError_t e = hipMemcpy(h->w(), w, sizeof(double) * M, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(h->mu(), mu, sizeof(double) * M * Dj, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(h->sigma(), sigma, sizeof(double) * M * dd, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemset(h->flag.p, 0, sizeof(int));
+  if (e != hipSuccess) {
+    delete h;
+    return fail(VCMI_ERR_HIP, "vcmi_gmm_em_create: %s", hipGetErrorString(e));
+  }
+  *out = h;
+  return VCMI_OK;
+}
+
+extern "C" int vcmi_gmm_em_destroy(vcmi_gmm_em *h) {
+  delete h;
+  return VCMI_OK;
+}
+
+extern "C" int vcmi_gmm_em_estep_dev(vcmi_gmm_em *h, const double *dX, int64_t N, double *dstats, void *stream) {
+  if (!h || !dstats) return fail(VCMI_ERR_ARG, "vcmi_gmm_em_estep_dev: NULL argument");
+  if (N < 0 || (N > 0 && !dX)) return fail(VCMI_ERR_ARG, "vcmi_gmm_em_estep_dev: bad frame block");
+  hipStream_t st = as_stream(stream);
+  if (!h->prepared) VCMI_TRY(em_prepare(h, st));
+  return estep_full_core(h->px, dX, N, h->Dj, h->M, dstats, st);
+}
+
+extern "C" int vcmi_gmm_em_mstep(vcmi_gmm_em *h, const double *dstats, void *stream, double *loglik) {
+  if (!h || !dstats) return fail(VCMI_ERR_ARG, "vcmi_gmm_em_mstep: NULL argument");
+  hipStream_t st = as_stream(stream);
+  hipLaunchKernelGGL(em_mstep_full_kernel, dim3(h->M), dim3(256), 0, st, dstats, h->Dj, h->M, h->min_covar, h->w(), h->mu(),
+                     h->sigma());
+  VCMI_HIP(hipGetLastError());
+  VCMI_TRY(em_prepare(h, st));
+  double ll = 0.0;
+  VCMI_HIP(hipMemcpyAsync(&ll, dstats + (h->plen() - 1), sizeof(double), hipMemcpyDeviceToHost, st));
+  VCMI_TRY(read_pd_flag(h->flag.p, st));   // synchronises: covers the initial and the new parameters
+  if (loglik) *loglik = ll;
+  return VCMI_OK;
+}
+
+extern "C" int vcmi_gmm_em_get(vcmi_gmm_em *h, double *w, double *mu, double *sigma) {
+  if (!h || !w || !mu || !sigma) return fail(VCMI_ERR_ARG, "vcmi_gmm_em_get: NULL argument");
+  VCMI_HIP(hipDeviceSynchronize());
+  const size_t dd = (size_t)h->Dj * h->Dj;
+  VCMI_HIP(hipMemcpy(w, h->w(), sizeof(double) * h->M, hipMemcpyDeviceToHost));
+  VCMI_HIP(hipMemcpy(mu, h->mu(), sizeof(double) * h->M * h->Dj, hipMemcpyDeviceToHost));
+  VCMI_HIP(hipMemcpy(sigma, h->sigma(), sizeof(double) * h->M * dd, hipMemcpyDeviceToHost));
   return VCMI_OK;
 }

@@ -621,6 +621,146 @@ int gmm_px_create(const double *w, const double *mu, const double *sigma, int D,
   return VCMI_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// p(x) preparation on the device (used by the EM loop: the parameters never leave HBM between iterations).
+// One workgroup per mixture: Hermitian(Sigma) (upper triangle mirrored, src/gmm.jl:16) -> right-looking Cholesky in
+// LDS -> U = L^-1 by forward substitution (thread = column) -> cz = U mu, lc = log w - (D log 2pi + logdet)/2 ->
+// row-major U/cz/lc for the generic kernels and the U-only MFMA operand blocks in issue order.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+px_prep_kernel(const double *__restrict__ w, const double *__restrict__ mu, const double *__restrict__ sigma, int D, int DP,
+               const int *__restrict__ table, int nsteps, int cinit_off, int ncinit, int lc_off, int blk_len,
+               double *__restrict__ U, double *__restrict__ cz, double *__restrict__ lc, double *__restrict__ packedU,
+               int *__restrict__ flag) {
+  extern __shared__ double smem_px[];
+  const int LD = D + 1, tid = threadIdx.x, m = blockIdx.x;
+  double *S = smem_px;                    // [D][LD] covariance, then its lower Cholesky factor
+  double *V = S + (size_t)D * LD;         // [D][LD] U = L^-1 (lower)
+  __shared__ double czs[256];
+  __shared__ double lcs;
+  __shared__ int bad;
+  const double *Sg = sigma + (size_t)m * D * D;
+  for (int e = tid; e < D * D; e += 256) {
+    const int r = e / D, c = e - r * D;
+    S[r * LD + c] = (r <= c) ? Sg[r + (size_t)D * c] : Sg[c + (size_t)D * r];
+    V[r * LD + c] = 0.0;
+  }
+  if (tid == 0) bad = 0;
+  __syncthreads();
+  for (int j = 0; j < D; ++j) {
+    const double d = S[j * LD + j];
+    if (!(d > 0.0) && tid == 0) bad = 1;
+    const double sd = sqrt(d);
+    for (int i = j + tid; i < D; i += 256) S[i * LD + j] = (i == j) ? sd : S[i * LD + j] / sd;
+    __syncthreads();
+    const int n = D - 1 - j;
+    for (int e = tid; e < n * n; e += 256) {
+      const int ii = e / n, kk = e - ii * n;
+      const int i = j + 1 + ii, k = j + 1 + kk;
+      if (i >= k) S[i * LD + k] = fma(-S[i * LD + j], S[k * LD + j], S[i * LD + k]);
+    }
+    __syncthreads();
+  }
+  if (tid < D) {                          // column tid of U
+    const int c = tid;
+    V[c * LD + c] = 1.0 / S[c * LD + c];
+    for (int i = c + 1; i < D; ++i) {
+      double s = 0.0;
+      for (int k = c; k < i; ++k) s = fma(S[i * LD + k], V[k * LD + c], s);
+      V[i * LD + c] = -s / S[i * LD + i];
+    }
+  }
+  __syncthreads();
+  if (tid < D) {
+    double s = 0.0;
+    for (int c = 0; c <= tid; ++c) s = fma(V[tid * LD + c], mu[c + (size_t)D * m], s);
+    czs[tid] = s;
+  } else if (tid == 255) {
+    double ld = 0.0;
+    for (int d = 0; d < D; ++d) ld += log(S[d * LD + d]);
+    const double LOG2PI = 1.8378770664093454835606594728112;
+    lcs = (w[m] > 0.0) ? log(w[m]) - 0.5 * (D * LOG2PI + 2.0 * ld) : -INFINITY;   // zero weight: posterior 0
+  }
+  __syncthreads();
+  for (int e = tid; e < DP * DP; e += 256) {
+    const int r = e / DP, c = e - r * DP;
+    U[(size_t)m * DP * DP + e] = (r < D && c <= r) ? V[r * LD + c] : 0.0;
+  }
+  for (int e = tid; e < DP; e += 256) cz[(size_t)m * DP + e] = (e < D) ? czs[e] : 0.0;
+  if (tid == 0) {
+    lc[m] = lcs;
+    if (bad) atomicMax(flag, m + 1);
+  }
+  if (packedU) {
+    double *blk = packedU + (size_t)m * blk_len;
+    for (int e = tid; e < blk_len; e += 256) {
+      double v = 0.0;
+      const int s = e >> 6, l = e & 63;
+      if (s < nsteps) {
+        const int t = table[s] >> 16, ks = table[s] & 0xffff;
+        const int p = 16 * t + (l & 15), k = 4 * ks + (l >> 4);
+        if (p < D && k <= p) v = V[p * LD + k];
+      } else if (e >= cinit_off && e < cinit_off + ncinit) {
+        const int p = e - cinit_off;
+        if (p < D) v = -czs[p];
+      } else if (e == lc_off) {
+        v = lcs;
+      }
+      blk[e] = v;
+    }
+  }
+}
+
+bool gmm_px_device_prepare_supported(int D) {
+  return D >= 1 && D <= 256 && (size_t)2 * D * (D + 1) * sizeof(double) + 4096 <= (size_t)160 * 1024;
+}
+
+int gmm_px_prepare_device(vcmi_gmmmap **inout, const double *d_w, const double *d_mu, const double *d_sigma, int D, int M,
+                          int *d_flag, hipStream_t st) {
+  VCMI_TRY(check_device());
+  if (!gmm_px_device_prepare_supported(D)) return fail(VCMI_ERR_ARG, "on-device p(x) preparation: dimension %d too large", D);
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (*inout && (*inout)->device != dev) {
+    delete *inout;
+    *inout = nullptr;
+  }
+  vcmi_gmmmap *g = *inout ? *inout : new (std::nothrow) vcmi_gmmmap();
+  if (!g) return fail(VCMI_ERR_OOM, "out of host memory");
+  *inout = g;
+  g->device = dev;
+  const int DP = (D + 3) / 4 * 4;
+  g->D = D;
+  g->DP = DP;
+  g->M = M;
+  VCMI_TRY(g->U.reserve((size_t)M * DP * DP));
+  VCMI_TRY(g->cz.reserve((size_t)M * DP));
+  VCMI_TRY(g->lc.reserve((size_t)M));
+  const bool mfma = gmmmap_has_mfma(DP);
+  TilingRT tl(DP, true);
+  if (mfma) {
+    VCMI_TRY(g->packedU.reserve((size_t)tl.BLK * M));
+    if (g->px_table_dp != DP) {           // issue order: k-major over the U tiles (the host packer's phase 0)
+      std::vector<int> tab;
+      for (int ks = 0; ks < tl.KS; ++ks)
+        for (int t = 0; t < std::min(tl.NU, tl.NT); ++t)
+          if (ks < tl.steps(t)) tab.push_back((t << 16) | ks);
+      if ((int)tab.size() != tl.NSTEPS) return fail(VCMI_ERR_ARG, "internal: tiling table mismatch");
+      VCMI_TRY(g->px_table.reserve(tab.size()));
+      VCMI_HIP(hipMemcpy(g->px_table.p, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice));
+      g->px_table_dp = DP;
+    }
+  }
+  const size_t shmem = (size_t)2 * D * (D + 1) * sizeof(double);
+  VCMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(px_prep_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)shmem));
+  hipLaunchKernelGGL(px_prep_kernel, dim3(M), dim3(256), shmem, st, d_w, d_mu, d_sigma, D, DP, mfma ? g->px_table.p : nullptr,
+                     mfma ? tl.NSTEPS : 0, tl.CINIT_OFF, tl.NT * 16, tl.LC_OFF, tl.BLK, g->U.p, g->cz.p, g->lc.p,
+                     mfma ? g->packedU.p : nullptr, d_flag);
+  VCMI_HIP(hipGetLastError());
+  return VCMI_OK;
+}
+
 }  // namespace vcmi
 
 // ------------------------------------------------------------------------------------------------

@@ -20,6 +20,10 @@ struct vcmi_gmmmap {
   vcmi::DevBuf<double> packedU;   // U_m tiles only (log-density / posterior / argmax)
   vcmi::DevBuf<double> packed4;   // 4-mixture row grouping (gmmmap_g4.hip, kernel choice 3)
 
+  // issue-order table of the U-only tiling (slot -> tile << 16 | k-step) for the on-device packer (gmm_px_prepare_device)
+  vcmi::DevBuf<int> px_table;
+  int px_table_dp = 0;
+
   // grow-only device scratch for the host-pointer entry points
   vcmi::DevBuf<double> scratch_x, scratch_y, scratch_lp;
   vcmi::DevBuf<int64_t> scratch_idx;
@@ -32,6 +36,12 @@ int gmmmap_pack_g4(vcmi_gmmmap *g, const std::vector<double> &hU, const std::vec
 int gmmmap_convert_g4_device(vcmi_gmmmap *g, const double *dX, int64_t ldx, int64_t T, double *dY, int64_t ldy, hipStream_t st);
 bool gmmmap_has_mfma(int DP);
 int gmm_px_create(const double *w, const double *mu, const double *sigma, int D, int M, vcmi_gmmmap **out);
+// Same handle prepared ON THE DEVICE from device-resident parameters (w (M), mu (D,M), sigma (D,D,M)): one workgroup
+// per mixture does the Cholesky, the triangular inverse and the MFMA operand packing.  Asynchronous on `st`;
+// *d_flag (device int, zeroed by the caller) receives m+1 for a mixture whose covariance is not positive definite.
+bool gmm_px_device_prepare_supported(int D);
+int gmm_px_prepare_device(vcmi_gmmmap **inout, const double *d_w, const double *d_mu, const double *d_sigma, int D, int M,
+                          int *d_flag, hipStream_t st);
 int gmmmap_convert_device(vcmi_gmmmap *g, const double *dX, int64_t ldx, int64_t T, double *dY, int64_t ldy, hipStream_t st);
 int gmmmap_logdens_device(vcmi_gmmmap *g, const double *dX, int64_t ldx, int64_t T, double *dLP, hipStream_t st);
 int gmmmap_posterior_device(vcmi_gmmmap *g, const double *dX, int64_t ldx, int64_t T, double *dP, hipStream_t st);

@@ -16,7 +16,7 @@ module VoiceConversionMI
 
 export GMMMap, TrajectoryGMMMap, fvconvert, vc, dim, ncomponents,
        DTW, fit!, update!, set_template!, backward, align, push_delta,
-       predict_proba, predict, estep_diag, estep_full
+       predict_proba, predict, estep_diag, estep_full, GMMEM, estep!, mstep!, params
 
 const libvcmi = get(ENV, "LIBVCMI", "libvcmi")
 
@@ -251,6 +251,44 @@ function estep_full(X::Matrix{Float64}, w::Vector{Float64}, μ::Matrix{Float64},
                  Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ref{Float64}),
                 X, size(X, 2), Dj, M, w, μ, Σ, S0, S1, S2, ll))
     S0, S1, S2, ll[]
+end
+
+# ------------------------------------------------------------------------------------- device-resident EM
+# The loop behind `gmm[:fit](dataset.X')` (bin/train_gmm.jl:84-103) with parameters, statistics and whitening blocks
+# kept in HBM.  `dX` / `dstats` are device pointers (e.g. from AMDGPU.jl); on several GPUs the caller all-reduces
+# `dstats` between estep! and mstep!.
+mutable struct GMMEM
+    handle::Ptr{Cvoid}
+    Dj::Int
+    M::Int
+    function GMMEM(w::Vector{Float64}, μ::Matrix{Float64}, Σ::Array{Float64,3}; min_covar::Float64=1.0e-7)
+        Dj, M = size(μ)
+        size(Σ) == (Dj, Dj, M) || throw(DimensionMismatch("Σ must be (Dj,Dj,M)"))
+        h = Ref{Ptr{Cvoid}}(C_NULL)
+        check(ccall((:vcmi_gmm_em_create, libvcmi), Cint,
+                    (Cint, Cint, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Cdouble, Ref{Ptr{Cvoid}}),
+                    Dj, M, w, μ, Σ, min_covar, h))
+        em = new(h[], Dj, M)
+        finalizer(e -> ccall((:vcmi_gmm_em_destroy, libvcmi), Cint, (Ptr{Cvoid},), e.handle), em)
+        em
+    end
+end
+
+estep!(em::GMMEM, dX::Ptr{Float64}, N::Integer, dstats::Ptr{Float64}; stream::Ptr{Cvoid}=C_NULL) =
+    check(ccall((:vcmi_gmm_em_estep_dev, libvcmi), Cint, (Ptr{Cvoid}, Ptr{Float64}, Int64, Ptr{Float64}, Ptr{Cvoid}),
+                em.handle, dX, N, dstats, stream))
+
+function mstep!(em::GMMEM, dstats::Ptr{Float64}; stream::Ptr{Cvoid}=C_NULL)
+    ll = Ref{Float64}(0.0)
+    check(ccall((:vcmi_gmm_em_mstep, libvcmi), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Cvoid}, Ref{Float64}),
+                em.handle, dstats, stream, ll))
+    ll[]
+end
+
+function params(em::GMMEM)
+    w = Vector{Float64}(undef, em.M); μ = Matrix{Float64}(undef, em.Dj, em.M); Σ = Array{Float64,3}(undef, em.Dj, em.Dj, em.M)
+    check(ccall((:vcmi_gmm_em_get, libvcmi), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}), em.handle, w, μ, Σ))
+    w, μ, Σ
 end
 
 end # module
