@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload convert|estep|estep_full|em_full|dtw|traj]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload convert|estep|estep_full|em_full|dtw|traj|trajgv]
 
 Default workload = BASELINE.json configs[1]: GMMMap fvconvert, D=40, M=64, T=10^6 synthetic frames per GPU
 (weak scaling: every rank converts its own shard of T frames; frames are independent, so there is no
@@ -396,9 +396,10 @@ def bench_dtw(args, world, rank):
 
 
 # ----------------------------------------------------------------------------------------- trajectory
-def bench_traj(args, world, rank):
+def bench_traj(args, world, rank, gv=False):
     """BASELINE configs[4]: TrajectoryGMMMap, static D=40 (X dim 80), M=64, T=2000 per utterance, `--utts`
-    utterances per GPU (weak scaling, utterance-parallel, no collective); device-resident."""
+    utterances per GPU (weak scaling, utterance-parallel, no collective); device-resident.
+    gv=True: TrajectoryGVGMMMap: the same solve followed by 100 epochs of GV gradient ascent."""
     import torch
 
     import voiceconversion_jl_amd as vc
@@ -422,20 +423,38 @@ def bench_traj(args, world, rank):
     yoff = np.arange(n, dtype=np.int64) * T * D
     Ts = np.full(n, T, dtype=np.int64)
 
+    epochs, alpha = 100, 1.0e-5
+    if gv:
+        from oracle import c_oracle as co0
+
+        y0 = co0.TrajectoryGMMMap(co0.GMMMap(w, mu, sig)).fvconvert(base[0][:200])[0]
+        muv = y0.var(axis=0, ddof=1) * 1.3
+        Ar = np.random.default_rng(7).standard_normal((D, D))
+        Sv = Ar @ Ar.T / D * np.mean(muv) ** 2 * 0.1 + np.diag(muv ** 2 * 0.05)
+        tgv = vc.TrajectoryGVGMMMap(tj, muv, Sv)
+
     def step():
-        _lib.check(_lib.lib.vcmi_traj_convert_batch_dev(tj._h, n, Xd.data_ptr(), _lib.iptr(xoff), _lib.iptr(Ts), Yd.data_ptr(),
-                                                        _lib.iptr(yoff), torch.cuda.current_stream().cuda_stream))
+        if gv:
+            _lib.check(_lib.lib.vcmi_trajgv_convert_batch_dev(tgv._h, n, Xd.data_ptr(), _lib.iptr(xoff), _lib.iptr(Ts), epochs,
+                                                              alpha, Yd.data_ptr(), _lib.iptr(yoff),
+                                                              torch.cuda.current_stream().cuda_stream))
+        else:
+            _lib.check(_lib.lib.vcmi_traj_convert_batch_dev(tj._h, n, Xd.data_ptr(), _lib.iptr(xoff), _lib.iptr(Ts), Yd.data_ptr(),
+                                                            _lib.iptr(yoff), torch.cuda.current_stream().cuda_stream))
 
     wall, kernel_ms = timed_steps(step, args.steps, args.warmup, world)
-    flops_per_utt = 2.0e9
+    flops_per_utt = 2.0e9 + (epochs * T * 2.0 * (2 * D) ** 2 if gv else 0.0)
     achieved = flops_per_utt * n / (kernel_ms * 1e-3) / 1e12
-    out = {"metric": "trajectory-converted frames/sec (static D=40, M=64, T=2000)", "value": world * n * T * args.steps / wall,
+    out = {"metric": ("trajectory+GV-converted" if gv else "trajectory-converted") + " frames/sec (static D=40, M=64, T=2000)",
+           "value": world * n * T * args.steps / wall,
            "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "f64", "data": "synthetic",
-           "config": {"workload": "TrajectoryGMMMap fvconvert (BASELINE configs[4])", "static_D": D, "M": M, "T": T,
+           "config": {"workload": ("TrajectoryGVGMMMap fvconvert, 100 epochs (SURVEY 8f rank 2)" if gv else
+                                   "TrajectoryGMMMap fvconvert (BASELINE configs[4])"), "static_D": D, "M": M, "T": T,
                       "utterances_per_gpu": n},
-           "roofline": {"bound": "mfma", "kernel": "predict + traj_g_kernel + traj_solve_kernel", "achieved": achieved,
+           "roofline": {"bound": "mfma", "kernel": "predict + traj_g_kernel + traj_solve_kernel" + (" + traj_gv_kernel" if gv else ""),
+                        "achieved": achieved,
                         "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS, "traffic": None,
                         "flop_per_utterance": flops_per_utt, "kernel_ms": kernel_ms,
                         "note": "whole pipeline (3 kernels); the banded solve is a 2000-step sequential block recurrence"}}
@@ -444,7 +463,7 @@ def bench_traj(args, world, rank):
 
         ref = co.TrajectoryGMMMap(co.GMMMap(w, mu, sig))
         t0 = time.perf_counter()
-        Yref, _, _ = ref.fvconvert(base[0])
+        Yref = ref.fvconvert_gv(base[0], muv, Sv, epochs, alpha) if gv else ref.fvconvert(base[0])[0]
         dt = time.perf_counter() - t0
         err = float(np.max(np.abs(Yd[:T].cpu().numpy() - Yref)) / np.max(np.abs(Yref)))
         out["cpu_baseline"] = {"value": T / dt, "unit": "frames/s", "cores": 1, "kind": "port",
@@ -458,7 +477,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="convert", choices=["convert", "estep", "estep_full", "em_full", "dtw", "traj"])
+    ap.add_argument("--workload", default="convert", choices=["convert", "estep", "estep_full", "em_full", "dtw", "traj", "trajgv"])
     ap.add_argument("--frames", type=int, default=1_000_000, help="frames per GPU (BASELINE: 10^6)")
     ap.add_argument("--pairs", type=int, default=1000, help="DTW pairs per GPU")
     ap.add_argument("--utts", type=int, default=256, help="trajectory utterances per GPU")
@@ -468,7 +487,8 @@ def main():
     world, rank, _ = dist_setup(args.gpus)
     if world != args.gpus and rank == 0:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
-    out = {"convert": bench_convert, "estep": bench_estep, "estep_full": bench_estep_full, "em_full": bench_em_full, "dtw": bench_dtw, "traj": bench_traj}[args.workload](args, world, rank)
+    out = {"convert": bench_convert, "estep": bench_estep, "estep_full": bench_estep_full, "em_full": bench_em_full, "dtw": bench_dtw, "traj": bench_traj,
+           "trajgv": lambda a, w, r: bench_traj(a, w, r, gv=True)}[args.workload](args, world, rank)
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

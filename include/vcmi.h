@@ -164,6 +164,27 @@ int vcmi_vc_traj(vcmi_traj *t, const double *fm, int64_t T, double *out);
 /* push_delta(src (D,T)) -> out (2D,T); src/datasets.jl:6-13 (host-side helper, O(DT)) */
 int vcmi_push_delta(const double *src, int D, int64_t T, double *out);
 
+/* ---------------------------------------------------------------------------------------------
+ * TrajectoryGVGMMMap -- src/trajectory_gmmmap.jl:114-189
+ * ------------------------------------------------------------------------------------------- */
+typedef struct vcmi_trajgv vcmi_trajgv;
+/* TrajectoryGVGMMMap(tgmm, mu^v (D), Sigma^vv (D,D)) :118-129; keeps (does not own) the trajectory handle.
+ * VCMI_ERR_ARG if a GV mean is negative (the @assert of :124), VCMI_ERR_NOT_PD if Sigma^vv is singular. */
+int vcmi_trajgv_create(vcmi_traj *t, const double *muv, const double *sigmavv, vcmi_trajgv **out);
+int vcmi_trajgv_destroy(vcmi_trajgv *h);
+/* fvconvert(tgv, X; epochs=100, alpha=1.0e-5) :139-168: trajectory solve, eq.(58) rescaling, then `epochs` steps of
+ * y += alpha (omega (W'D^-1E - W'D^-1W y) + gvgrad(y)), all on the device.  X (2D,T) -> Y (D,T). */
+int vcmi_trajgv_convert(vcmi_trajgv *h, const double *X, int64_t T, int epochs, double alpha, double *Y);
+int vcmi_trajgv_convert_batch(vcmi_trajgv *h, int64_t n, const double *const *X, const int64_t *T, int epochs, double alpha,
+                              double *const *Y);
+int vcmi_trajgv_convert_batch_dev(vcmi_trajgv *h, int64_t n, const double *dX, const int64_t *x_off, const int64_t *T,
+                                  int epochs, double alpha, double *dY, const int64_t *y_off, void *stream);
+
+/* fvpostf(vs::VarianceScaling, src) -- src/gv.jl:10-21.  src, out (D,T), sigma2 (D); out may alias src. */
+int vcmi_variance_scaling(const double *src, int D, int64_t T, const double *sigma2, double *out);
+/* diffgmm(params) -- src/diffgmm.jl:9-25 on joint parameters mu (2D,M), sigma (2D,2D,M); host arithmetic. */
+int vcmi_diffgmm(const double *mu, const double *sigma, int Dj, int M, double *mu_out, double *sigma_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -51,6 +51,9 @@ def lib():
         L.vco_traj_fvconvert.argtypes = [C.c_void_p, _dp, C.c_int64, _dp, _ip, _dp]
         L.vco_vc_traj.argtypes = [C.c_void_p, _dp, C.c_int64, C.c_int64, _dp]
         L.vco_estep_diag.argtypes = [_dp, C.c_int64, C.c_int, C.c_int, _dp, _dp, _dp, _dp, _dp, _dp, _dp]
+        L.vco_variance_scaling.argtypes = [_dp, C.c_int, C.c_int64, _dp, _dp]
+        L.vco_trajgv_fvconvert.argtypes = [C.c_void_p, _dp, C.c_int64, _dp, _dp, C.c_int, C.c_double, _dp]
+        L.vco_diffgmm.argtypes = [_dp, _dp, C.c_int, C.c_int, _dp, _dp]
         L.vco_estep_full.argtypes = [_dp, C.c_int64, C.c_int, C.c_int, _dp, _dp, _dp, _dp, _dp, _dp, _dp]
         _lib = L
     return _lib
@@ -177,6 +180,15 @@ class TrajectoryGMMMap:
             raise np.linalg.LinAlgError("normal matrix not positive definite")
         return Y, mhat, Ey
 
+    def fvconvert_gv(self, X, muv, Sigvv, epochs=100, alpha=1.0e-5):
+        X, muv, Sigvv = _f64(X), _f64(muv), _f64(Sigvv)
+        T, D2 = X.shape
+        Y = np.empty((T, D2 >> 1))
+        rc = lib().vco_trajgv_fvconvert(self._h, _d(X), T, _d(muv), _d(Sigvv), int(epochs), float(alpha), _d(Y))
+        if rc:
+            raise np.linalg.LinAlgError("trajectory GV conversion failed")
+        return Y
+
     def vc(self, fm, L):
         fm = _f64(fm)
         T = fm.shape[0]
@@ -213,3 +225,20 @@ def estep_full(X, w, mu, sigma):
     if rc:
         raise np.linalg.LinAlgError("covariance not positive definite")
     return S0, S1, S2, ll.value
+
+
+def variance_scaling(src, sigma2):
+    src, sigma2 = _f64(src), _f64(sigma2)
+    T, D = src.shape
+    out = np.empty_like(src)
+    lib().vco_variance_scaling(_d(src), D, T, _d(sigma2), _d(out))
+    return out
+
+
+def diffgmm(mu, sigma):
+    """mu (M,2D), sigma (M,2D,2D) [m][col][row] -> transformed joint parameters in the same layout."""
+    mu, sigma = _f64(mu), _f64(sigma)
+    M, Dj = mu.shape
+    mo, so = np.empty_like(mu), np.empty_like(sigma)
+    lib().vco_diffgmm(_d(mu), _d(sigma), Dj, M, _d(mo), _d(so))
+    return mo, so

@@ -168,6 +168,20 @@ def main():
         pass
     np.savez(os.path.join(OUT, "estep_full_N1000_D80_M8.npz"), X=Xf, w=wf, mu=muf, sigma=sigf, S0=S0, S1=S1, S2=S2,
              loglik=np.array(ll))
+    # ---- (7) TrajectoryGVGMMMap on the same fixture utterance (src/trajectory_gmmmap.jl:114-189), VarianceScaling,
+    #      diffgmm parameters of the fixture model (first two mixtures)
+    rg = np.random.default_rng(7007)
+    muv = Y.var(axis=0, ddof=1) * 1.3
+    Ar = rg.standard_normal((D // 2, D // 2))
+    Sv = Ar @ Ar.T / (D // 2) * np.mean(muv) ** 2 * 0.1 + np.diag(muv ** 2 * 0.05)
+    ygv = npo.trajgv_fvconvert(tn, Xd, muv, Sv, epochs=100, alpha=1.0e-5)
+    assert _relmax(ygv, tc.fvconvert_gv(Xd, muv, Sv, 100, 1.0e-5)) < 1e-6
+    vs = npo.variance_scaling(Y, muv)
+    assert _relmax(vs, co.variance_scaling(Y, muv)) < 1e-13
+    dm, ds = npo.diffgmm(mu[:2], sig[:2])
+    dmc, dsc = co.diffgmm(mu[:2], sig[:2])
+    assert _relmax(dm, dmc) < 1e-15 and _relmax(ds, dsc) < 1e-14
+    np.savez(os.path.join(OUT, "gv_fixture_model.npz"), muv=muv, sigmavv=Sv, Y_gv=ygv, Y_scaled=vs, diff_mu=dm, diff_sigma=ds)
     print("golden fixtures written to", OUT)
     for f in sorted(os.listdir(OUT)):
         print(f"  {f}: {os.path.getsize(os.path.join(OUT, f)) / 1e6:.2f} MB")

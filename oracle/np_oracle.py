@@ -207,6 +207,52 @@ class TrajectoryGMMMap:
         return y.reshape(T, D), mhat, Ey
 
 
+def variance_scaling(src, sigma2):
+    """fvpostf(vs::VarianceScaling, src), src/gv.jl:10-15 (also eq. (58) initialisation, src/trajectory_gmmmap.jl:152).
+    src (T,D): per-dimension  sqrt(sigma2 / var) * (x - mean) + mean  with Julia's corrected variance (1/(T-1))."""
+    mu = src.mean(axis=0)
+    return np.sqrt(sigma2 / src.var(axis=0, ddof=1)) * (src - mu) + mu
+
+
+def gvgrad(pv, muv, y):
+    """gvgrad(tgv, y), src/trajectory_gmmmap.jl:171-189.  y (T,D)."""
+    T = y.shape[0]
+    gv = y.var(axis=0, ddof=1)
+    return -2.0 / T * (pv.T @ (gv - muv)) * (y - y.mean(axis=0))
+
+
+def trajgv_fvconvert(tj, X, muv, Sigvv, epochs=100, alpha=1.0e-5):
+    """fvconvert(tgv::TrajectoryGVGMMMap, X), src/trajectory_gmmmap.jl:139-168, literally: explicit sparse W and
+    block-diagonal D^-1.  X (T,2D) -> (T,D)."""
+    y0, mhat, Ey = tj.fvconvert(X)
+    T, D = y0.shape
+    pv = np.linalg.inv(Sigvv)                                             # :127
+    y = variance_scaling(y0, muv)                                         # :152
+    omega = 1.0 / (2 * T)
+    W = constructW(D, T)
+    Dinv = sp.block_diag([sp.csc_matrix(tj.Dy[m - 1]) for m in mhat], format="csc")
+    WtD = (W.T @ Dinv).tocsc()
+    WtDW = (WtD @ W).tocsc()
+    rhs = WtD @ Ey.ravel()
+    for _ in range(epochs):
+        dy = omega * (-(WtDW @ y.ravel()) + rhs) + gvgrad(pv, muv, y).ravel()   # :163
+        y = y + alpha * dy.reshape(T, D)                                  # :166, eq. (52)
+    return y
+
+
+def diffgmm(mu, sigma):
+    """diffgmm(params), src/diffgmm.jl:9-25, on joint parameters: mu (M,2D), sigma (M,2D,2D) -> the joint parameters
+    whose split gives (mu^x, mu^y - mu^x, Sxx, Sxy - Sxx, (Sxy - Sxx)', Sxx + Syy - Sxy - Syx)."""
+    D = mu.shape[1] >> 1
+    mu2, s2 = mu.copy(), sigma.copy()
+    mu2[:, D:] = mu[:, D:] - mu[:, :D]
+    Sxx, Sxy, Syx, Syy = sigma[:, :D, :D], sigma[:, :D, D:], sigma[:, D:, :D], sigma[:, D:, D:]
+    s2[:, :D, D:] = Sxy - Sxx
+    s2[:, D:, :D] = np.transpose(Sxy - Sxx, (0, 2, 1))
+    s2[:, D:, D:] = Sxx + Syy - Sxy - Syx
+    return mu2, s2
+
+
 def vc_traj(tj, fm, L):
     """vc(c::TrajectoryConverter, fm), src/common.jl:31-63; fm (T, 2D+1) -> (T, D+1); chunks of L frames."""
     T = fm.shape[0]

@@ -501,6 +501,112 @@ int vco_vc_traj(const vco_traj *tj, const double *fm, int64_t T, int64_t L, doub
   return rc;
 }
 
+/* fvpostf!(vs::VarianceScaling, src), src/gv.jl:10-15: per dimension sqrt(sigma2 / var) * (x - mean) + mean with the
+ * corrected variance (Julia's var: 1/(T-1)).  src, out (D,T); in-place allowed. */
+void vco_variance_scaling(const double *src, int D, int64_t T, const double *sigma2, double *out) {
+  for (int d = 0; d < D; ++d) {
+    double mu = 0.0, var = 0.0;
+    for (int64_t t = 0; t < T; ++t) mu += src[d + (size_t)D * t];
+    mu /= (double)T;
+    for (int64_t t = 0; t < T; ++t) { double e = src[d + (size_t)D * t] - mu; var += e * e; }
+    var /= (double)(T - 1);
+    double sc = sqrt(sigma2[d] / var);
+    for (int64_t t = 0; t < T; ++t) out[d + (size_t)D * t] = sc * (src[d + (size_t)D * t] - mu) + mu;
+  }
+}
+
+/* fvconvert(tgv::TrajectoryGVGMMMap, X; epochs, alpha), src/trajectory_gmmmap.jl:139-168 (+ gvgrad :171-189).
+ * muv (D), Sigvv (D,D).  W'D^-1 W y and W'D^-1 E are applied through the stencil, never materialised. */
+int vco_trajgv_fvconvert(const vco_traj *tj, const double *X, int64_t T, const double *muv, const double *Sigvv,
+                         int epochs, double alpha, double *Y) {
+  int D2 = tj->D2, D = D2 >> 1;
+  size_t nn = (size_t)D2 * D2;
+  int64_t *mhat = (int64_t *)malloc(sizeof(int64_t) * T);
+  double *Ey = (double *)malloc(sizeof(double) * D2 * T);
+  double *y = (double *)malloc(sizeof(double) * D * T);
+  int rc = vco_traj_fvconvert(tj, X, T, y, mhat, Ey);          /* y0, :146 */
+  if (rc) { free(mhat); free(Ey); free(y); return rc; }
+  double *pv = (double *)malloc(sizeof(double) * D * D);
+  if (lu_inverse(Sigvv, D, pv)) { free(mhat); free(Ey); free(y); free(pv); return 2; }   /* :127 */
+  vco_variance_scaling(y, D, T, muv, y);                       /* eq. (58), :152 */
+  double omega = 1.0 / (2.0 * (double)T);
+  double *v = (double *)malloc(sizeof(double) * D2 * T);       /* D^-1 (W y) per frame */
+  double *g = (double *)malloc(sizeof(double) * D2 * T);       /* D^-1 E per frame */
+  double *u = (double *)malloc(sizeof(double) * D2);
+  double *mu_y = (double *)malloc(sizeof(double) * D), *gv = (double *)malloc(sizeof(double) * D);
+  double *coef = (double *)malloc(sizeof(double) * D), *dy = (double *)malloc(sizeof(double) * D * T);
+  for (int64_t t = 0; t < T; ++t) {
+    const double *Q = tj->Dy + nn * (mhat[t] - 1);
+    for (int i = 0; i < D2; ++i) {
+      double s = 0.0;
+      for (int k = 0; k < D2; ++k) s += Q[i + D2 * k] * Ey[k + (size_t)D2 * t];
+      g[i + (size_t)D2 * t] = s;
+    }
+  }
+  for (int ep = 0; ep < epochs; ++ep) {
+    for (int64_t t = 0; t < T; ++t) {                          /* v_t = Q_t (W y)_t */
+      for (int d = 0; d < D; ++d) {
+        u[d] = y[d + (size_t)D * t];
+        double dl = 0.0;
+        if (t >= 1) dl -= 0.5 * y[d + (size_t)D * (t - 1)];
+        if (t + 1 < T) dl += 0.5 * y[d + (size_t)D * (t + 1)];
+        u[D + d] = dl;
+      }
+      const double *Q = tj->Dy + nn * (mhat[t] - 1);
+      for (int i = 0; i < D2; ++i) {
+        double s = 0.0;
+        for (int k = 0; k < D2; ++k) s += Q[i + D2 * k] * u[k];
+        v[i + (size_t)D2 * t] = s;
+      }
+    }
+    for (int d = 0; d < D; ++d) {                              /* gvgrad, :171-189 */
+      double m = 0.0, var = 0.0;
+      for (int64_t t = 0; t < T; ++t) m += y[d + (size_t)D * t];
+      m /= (double)T;
+      for (int64_t t = 0; t < T; ++t) { double e = y[d + (size_t)D * t] - m; var += e * e; }
+      mu_y[d] = m; gv[d] = var / (double)(T - 1);
+    }
+    for (int d = 0; d < D; ++d) {
+      double s = 0.0;
+      for (int j = 0; j < D; ++j) s += pv[j + D * d] * (gv[j] - muv[j]);   /* (pv' (gv - muv))_d */
+      coef[d] = -2.0 / (double)T * s;
+    }
+    for (int64_t t = 0; t < T; ++t)
+      for (int d = 0; d < D; ++d) {                            /* W' applied to v and g; :163 */
+        double py = v[d + (size_t)D2 * t], r = g[d + (size_t)D2 * t];
+        if (t >= 1) { py += 0.5 * v[D + d + (size_t)D2 * (t - 1)]; r += 0.5 * g[D + d + (size_t)D2 * (t - 1)]; }
+        if (t + 1 < T) { py -= 0.5 * v[D + d + (size_t)D2 * (t + 1)]; r -= 0.5 * g[D + d + (size_t)D2 * (t + 1)]; }
+        dy[d + (size_t)D * t] = omega * (-py + r) + coef[d] * (y[d + (size_t)D * t] - mu_y[d]);
+      }
+    for (size_t e = 0; e < (size_t)D * T; ++e) y[e] += alpha * dy[e];   /* eq. (52), :166 */
+  }
+  memcpy(Y, y, sizeof(double) * D * T);
+  free(mhat); free(Ey); free(y); free(pv); free(v); free(g); free(u); free(mu_y); free(gv); free(coef); free(dy);
+  return 0;
+}
+
+/* diffgmm(params), src/diffgmm.jl:9-25, on the joint parameters mu (2D,M), sigma (2D,2D,M). */
+void vco_diffgmm(const double *mu, const double *sigma, int Dj, int M, double *mu_out, double *sigma_out) {
+  int D = Dj >> 1;
+  for (int m = 0; m < M; ++m) {
+    const double *S = sigma + (size_t)Dj * Dj * m;
+    double *O = sigma_out + (size_t)Dj * Dj * m;
+    for (int d = 0; d < D; ++d) {
+      mu_out[d + (size_t)Dj * m] = mu[d + (size_t)Dj * m];
+      mu_out[D + d + (size_t)Dj * m] = mu[D + d + (size_t)Dj * m] - mu[d + (size_t)Dj * m];
+    }
+    for (int c = 0; c < D; ++c)
+      for (int r = 0; r < D; ++r) {
+        double xx = S[r + (size_t)Dj * c], xy = S[r + (size_t)Dj * (D + c)], yx = S[(D + r) + (size_t)Dj * c],
+               yy = S[(D + r) + (size_t)Dj * (D + c)];
+        O[r + (size_t)Dj * c] = xx;
+        O[r + (size_t)Dj * (D + c)] = xy - xx;                 /* Sxy' = Sxy - Sxx */
+        O[(D + c) + (size_t)Dj * r] = xy - xx;                 /* Syx' = (Sxy - Sxx)' */
+        O[(D + r) + (size_t)Dj * (D + c)] = xx + yy - xy - yx;
+      }
+  }
+}
+
 /* ------------------------------------------------------------------------------------------------
  * Diagonal E-step
  * ---------------------------------------------------------------------------------------------- */

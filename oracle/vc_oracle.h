@@ -70,6 +70,15 @@ int vco_traj_fvconvert(const vco_traj *t, const double *X, int64_t T, double *Y,
 /* vc(c::TrajectoryConverter, fm) -- src/common.jl:31-63.  fm (2D+1,T) -> out (D+1,T), chunks of L frames */
 int vco_vc_traj(const vco_traj *t, const double *fm, int64_t T, int64_t L, double *out);
 
+/* fvpostf(vs::VarianceScaling, src) -- src/gv.jl:10-15; src, out (D,T) */
+void vco_variance_scaling(const double *src, int D, int64_t T, const double *sigma2, double *out);
+/* fvconvert(tgv::TrajectoryGVGMMMap, X; epochs, alpha) -- src/trajectory_gmmmap.jl:139-189.  muv (D), Sigvv (D,D).
+ * Returns nonzero if the trajectory solve fails or Sigvv is singular.  PARITY UNPINNED by the reference's tests. */
+int vco_trajgv_fvconvert(const vco_traj *t, const double *X, int64_t T, const double *muv, const double *Sigvv,
+                         int epochs, double alpha, double *Y);
+/* diffgmm(params) -- src/diffgmm.jl:9-25, on joint parameters mu (2D,M), sigma (2D,2D,M) */
+void vco_diffgmm(const double *mu, const double *sigma, int Dj, int M, double *mu_out, double *sigma_out);
+
 /* Diagonal-covariance E-step (call site bin/train_gmm.jl:103 -> sklearn.mixture).
  * X (Dj,N); w (M); mu, var (Dj,M).  Outputs S0 (M), S1,S2 (Dj,M), loglik = sum_n lse_n. */
 void vco_estep_diag(const double *X, int64_t N, int Dj, int M, const double *w, const double *mu, const double *var,

@@ -128,3 +128,15 @@ def test_estep_full_golden():
     assert relerr(f0, zd["S0"]) < 1e-10 and relerr(f1, zd["S1"]) < 1e-10
     assert relerr(f2[:, np.arange(80), np.arange(80)], zd["S2"]) < 1e-10
     assert abs(fl - float(zd["loglik"])) < 1e-10 * abs(float(zd["loglik"]))
+
+
+def test_gv_golden(fixture_model):
+    """TrajectoryGVGMMMap / VarianceScaling / diffgmm: C oracle vs the fixtures the literal numpy restatement
+    (explicit sparse W, block-diagonal D^-1) produced"""
+    z, zt = load_golden("gv_fixture_model.npz"), load_golden("trajectory_fixture_model.npz")
+    w, mu, sig = fixture_model
+    t = co.TrajectoryGMMMap(co.GMMMap(w, mu, sig))
+    assert relerr(t.fvconvert_gv(zt["X"], z["muv"], z["sigmavv"], 100, 1.0e-5), z["Y_gv"]) < 1e-6
+    assert relerr(co.variance_scaling(zt["Y"], z["muv"]), z["Y_scaled"]) < 1e-13
+    dm, ds = co.diffgmm(mu[:2], sig[:2])
+    assert relerr(dm, z["diff_mu"]) < 1e-15 and relerr(ds, z["diff_sigma"]) < 1e-14

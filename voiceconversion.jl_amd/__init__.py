@@ -13,6 +13,7 @@ from .align import align, align_batch  # noqa: F401,E402
 from .estep import (estep_diag, estep_diag_allreduce, estep_diag_dev, mstep_diag, stats_len, unpack_stats,  # noqa: F401,E402
                     estep_full, estep_full_allreduce, estep_full_dev, fit_full, full_stats_len, mstep_full,
                     unpack_full_stats)
-from .trajectory_gmmmap import TrajectoryGMMMap, constructW, push_delta  # noqa: F401,E402
+from .trajectory_gmmmap import TrajectoryGVGMMMap, TrajectoryGMMMap, constructW, push_delta  # noqa: F401,E402
 from . import dist  # noqa: F401,E402
 from .train import EMState, train_gmm  # noqa: F401,E402
+from .gv import VarianceScaling, diffgmm, fvpostf, fvpostf_  # noqa: F401,E402

@@ -89,6 +89,13 @@ SIGNATURES = {
     "vcmi_traj_convert_batch_dev": (_int, [_vp, _i64, _vp, _ip, _ip, _vp, _ip, _vp]),
     "vcmi_vc_traj": (_int, [_vp, _dp, _i64, _dp]),
     "vcmi_push_delta": (_int, [_dp, _int, _i64, _dp]),
+    "vcmi_trajgv_create": (_int, [_vp, _dp, _dp, C.POINTER(_vp)]),
+    "vcmi_trajgv_destroy": (_int, [_vp]),
+    "vcmi_trajgv_convert": (_int, [_vp, _dp, _i64, _int, C.c_double, _dp]),
+    "vcmi_trajgv_convert_batch": (_int, [_vp, _i64, _dpp, _ip, _int, C.c_double, _dpp]),
+    "vcmi_trajgv_convert_batch_dev": (_int, [_vp, _i64, _vp, _ip, _ip, _int, C.c_double, _vp, _ip, _vp]),
+    "vcmi_variance_scaling": (_int, [_dp, _int, _i64, _dp, _dp]),
+    "vcmi_diffgmm": (_int, [_dp, _dp, _int, _int, _dp, _dp]),
 }
 
 for _name, (_res, _args) in SIGNATURES.items():

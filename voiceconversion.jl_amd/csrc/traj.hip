@@ -29,13 +29,27 @@ struct vcmi_traj {
   int M = 0;
   int64_t length = 0;  // length(t), src/trajectory_gmmmap.jl:34
   vcmi::DevBuf<double> AT, QT, bvec, Q;   // [M][k][r] transposed A and Q (coalesced gemv), b [M][2D], Q row-major [M][2D][2D]
+  vcmi::DevBuf<double> Qfrag;             // Q in v_mfma_f64_16x16x4 A-operand order [M][row tile][k-step][lane] (GV ascent)
+  int NT = 0, KS = 0;                     // row tiles / k-steps of Qfrag
   vcmi::DevBuf<double> gbuf, ws, xbuf, ybuf;
   vcmi::DevBuf<int64_t> mhat;
   vcmi::DevBuf<int> status;
   vcmi::DevBuf<unsigned char> uttbuf;
 };
 
+// TrajectoryGVGMMMap(tgmm, mu^v, Sigma^vv), src/trajectory_gmmmap.jl:114-130
+struct vcmi_trajgv {
+  vcmi_traj *t = nullptr;
+  vcmi::DevBuf<double> muv, pv;   // (D), (D,D) = inv(Sigma^vv) in the Julia memory image
+};
+
 namespace vcmi {
+
+struct TrajGV {          // per-call parameters of the GV ascent
+  const double *muv, *pv;
+  int epochs;
+  double alpha;
+};
 
 struct TrajUtt {
   const double *X;   // (2D,T) dense
@@ -412,6 +426,200 @@ traj_solve_kernel(const TrajUtt *__restrict__ utts, int n, int D, const double *
 }
 
 // ------------------------------------------------------------------------------------------------
+// Global-variance ascent, fvconvert(tgv::TrajectoryGVGMMMap, X), src/trajectory_gmmmap.jl:139-189.
+// One workgroup per utterance runs all epochs:  y <- y + alpha * ( omega (r - P y) + gvgrad(y) ),  omega = 1/(2T),
+// with P y = W' D^-1 W y applied as  u_t = [y_t ; (y_{t+1} - y_{t-1})/2]  ->  v_t = Q_mhat_t u_t  ->
+// (P y)_t = vs_t + vd_{t-1}/2 - vd_{t+1}/2  (the stencil of W; W is never built) and r = W' D^-1 E from the g_t the
+// solve already has.  v = Q u runs on v_mfma_f64_16x16x4 over tiles of 16 consecutive frames: wave i owns row tile i
+// of Q; the tile's frames usually share one or two mixtures, so the product is accumulated over the DISTINCT
+// mixtures of the tile with the B operand masked to that mixture's frames (exact: the other frames add 0).
+// ------------------------------------------------------------------------------------------------
+__device__ void gv_moments(const double *__restrict__ y, int D, int T, int nthr, double *red, double *mean, double *var) {
+  const int tid = threadIdx.x;
+  const int NG = nthr / D;                 // frame groups per dimension
+  const int d = tid % D, g = tid / D;
+  double s = 0.0;
+  if (g < NG)
+    for (int t = g; t < T; t += NG) s += y[(size_t)t * D + d];
+  if (g < NG) red[g * D + d] = s;
+  __syncthreads();
+  if (tid < D) {
+    double m = 0.0;
+    for (int k = 0; k < NG; ++k) m += red[k * D + tid];
+    mean[tid] = m / (double)T;
+  }
+  __syncthreads();
+  s = 0.0;
+  if (g < NG) {
+    const double m = mean[d];
+    for (int t = g; t < T; t += NG) {
+      const double e = y[(size_t)t * D + d] - m;
+      s = fma(e, e, s);
+    }
+    red[g * D + d] = s;
+  }
+  __syncthreads();
+  if (tid < D) {
+    double v = 0.0;
+    for (int k = 0; k < NG; ++k) v += red[k * D + tid];
+    var[tid] = v / (double)(T - 1);        // Julia's var: corrected
+  }
+  __syncthreads();
+}
+
+typedef double gv_d4 __attribute__((ext_vector_type(4)));
+static constexpr int kGvNB = 8;   // 16-frame tiles per round of the GV product
+static constexpr int kGvMaxKS = 24;   // k-steps of the widest supported feature vector (2D <= 96)
+
+__global__ void __launch_bounds__(384)
+traj_gv_kernel(const TrajUtt *__restrict__ utts, int n, int D, int M, int KS, const double *__restrict__ Qfrag,
+               const int64_t *__restrict__ mhat_all, const double *__restrict__ g_all, double *__restrict__ ws_all,
+               int64_t ws_stride, TrajGV gv) {
+  extern __shared__ double gsm[];
+  const int D2 = 2 * D, nthr = blockDim.x, NT = nthr >> 6;
+  double *Ut = gsm;                        // [kGvNB][4*KS][16]  u of the tiles' frames, k-major
+  double *red = Ut + (size_t)kGvNB * 4 * KS * 16;  // [nthr]
+  double *mean = red + nthr;               // [D]
+  double *var = mean + D;                  // [D]
+  double *coef = var + D;                  // [D]
+  int *cnt = reinterpret_cast<int *>(coef + D);   // [M] frames per mixture, then the fill cursor
+  int *start = cnt + M;                           // [M] first slot of the mixture's (16-padded) segment
+  __shared__ int tidx[16 * kGvNB];
+  __shared__ int ntiles_s;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lcol = lane & 15, lgrp = lane >> 4;
+
+  for (int u = blockIdx.x; u < n; u += gridDim.x) {
+    const TrajUtt U = utts[u];
+    const int T = U.T;
+    if (T < 2) continue;                   // var() of one frame is undefined; the host rejects such calls
+    const int64_t *mh = mhat_all + U.frame0;
+    const double *g = g_all + U.frame0 * D2;
+    double *y = U.Y;
+    double *V = ws_all + (size_t)blockIdx.x * ws_stride;   // [T][2D]
+    double *R = V + (size_t)T * D2;                        // [T][D]   r = W' D^-1 E
+    int *perm = reinterpret_cast<int *>(R + (size_t)T * D); // frames grouped by mixture, segments padded to 16 with -1
+    const double omega = 1.0 / (2.0 * (double)T);
+
+    // frames grouped by mixture (the selection mhat is fixed over the epochs): every 16-frame tile of the product
+    // below then has ONE mixture.  The order inside a group comes from atomics and is irrelevant: each frame's
+    // product is computed independently.
+    for (int m = tid; m < M; m += nthr) cnt[m] = 0;
+    __syncthreads();
+    for (int t = tid; t < T; t += nthr) atomicAdd(&cnt[(int)mh[t] - 1], 1);
+    __syncthreads();
+    if (tid == 0) {
+      int pos = 0;
+      for (int m = 0; m < M; ++m) {
+        start[m] = pos;
+        pos += (cnt[m] + 15) / 16 * 16;
+        cnt[m] = 0;
+      }
+      ntiles_s = pos / 16;
+    }
+    __syncthreads();
+    const int ntiles = ntiles_s;
+    for (int e = tid; e < ntiles * 16; e += nthr) perm[e] = -1;
+    __syncthreads();
+    for (int t = tid; t < T; t += nthr) {
+      const int m = (int)mh[t] - 1;
+      perm[start[m] + atomicAdd(&cnt[m], 1)] = t;
+    }
+
+    // eq. (58): y <- sqrt(mu^v / var(y)) (y - mean) + mean, src/trajectory_gmmmap.jl:152; and r
+    gv_moments(y, D, T, nthr, red, mean, var);
+    for (int e = tid; e < D * T; e += nthr) {
+      const int t = e / D, d = e - t * D;
+      y[e] = sqrt(gv.muv[d] / var[d]) * (y[e] - mean[d]) + mean[d];
+      double r = g[(size_t)t * D2 + d];
+      if (t >= 1) r += 0.5 * g[(size_t)(t - 1) * D2 + D + d];
+      if (t + 1 < T) r -= 0.5 * g[(size_t)(t + 1) * D2 + D + d];
+      R[e] = r;
+    }
+    __syncthreads();
+
+    double afr[kGvMaxKS];
+    int mcur = -1;
+    for (int ep = 0; ep < gv.epochs; ++ep) {
+      // gvgrad coefficients, src/trajectory_gmmmap.jl:171-189: -2/T (pv' (var(y) - mu^v)), times (y - mean) below
+      gv_moments(y, D, T, nthr, red, mean, var);
+      if (tid < D) {
+        double s = 0.0;
+        for (int j = 0; j < D; ++j) s = fma(gv.pv[j + (size_t)D * tid], var[j] - gv.muv[j], s);
+        coef[tid] = -2.0 / (double)T * s;
+      }
+      // v_t = Q_mhat_t u_t for every frame: kGvNB single-mixture tiles of 16 frames per round, so that the gathers of
+      // y, the loads of the Q fragments and the barriers are paid once per 16*kGvNB frames
+      for (int tile0 = 0; tile0 < ntiles; tile0 += kGvNB) {
+        const int nb = (ntiles - tile0 < kGvNB) ? ntiles - tile0 : kGvNB;
+        if (tid < 16 * nb) tidx[tid] = perm[tile0 * 16 + tid];
+        __syncthreads();
+        for (int e = tid; e < nb * 4 * KS * 16; e += nthr) {
+          const int b = e / (4 * KS * 16), q = e - b * (4 * KS * 16);
+          const int k = q >> 4, t = tidx[b * 16 + (q & 15)];
+          double v = 0.0;
+          if (t >= 0 && k < D2) {
+            if (k < D) {
+              v = y[(size_t)t * D + k];
+            } else {
+              if (t + 1 < T) v += 0.5 * y[(size_t)(t + 1) * D + (k - D)];
+              if (t >= 1) v -= 0.5 * y[(size_t)(t - 1) * D + (k - D)];
+            }
+          }
+          Ut[e] = v;
+        }
+        __syncthreads();
+        for (int b = 0; b < nb; ++b) {
+          const int m = (int)mh[tidx[b * 16]] - 1;         // the tile's mixture (slot 0 of a tile is never padding)
+          if (m != mcur) {                                 // Q fragments of this wave's row tile: all k-steps in flight at
+            mcur = m;                                      // once, kept in registers while consecutive tiles share m
+            const double *A = Qfrag + (((size_t)m * NT + wave) * KS) * 64 + lane;
+#pragma unroll
+            for (int ks = 0; ks < kGvMaxKS; ++ks) afr[ks] = (ks < KS) ? A[(size_t)ks * 64] : 0.0;
+          }
+          const double *Ub = Ut + (size_t)b * 4 * KS * 16;
+          gv_d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+          for (int ks = 0; ks < kGvMaxKS; ++ks)
+            if (ks < KS) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(afr[ks], Ub[(4 * ks + lgrp) * 16 + lcol], acc, 0, 0, 0);
+          const int t = tidx[b * 16 + lcol];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = 16 * wave + lgrp + 4 * r;
+            if (row < D2 && t >= 0) V[(size_t)t * D2 + row] = acc[r];
+          }
+        }
+        __syncthreads();
+      }
+      // y <- y + alpha * ( omega (r - P y) + coef (y - mean) ), eq. (52), src/trajectory_gmmmap.jl:163-166
+      for (int e = tid; e < D * T; e += nthr) {
+        const int t = e / D, d = e - t * D;
+        double py = V[(size_t)t * D2 + d];
+        if (t >= 1) py += 0.5 * V[(size_t)(t - 1) * D2 + D + d];
+        if (t + 1 < T) py -= 0.5 * V[(size_t)(t + 1) * D2 + D + d];
+        const double yy = y[e];
+        const double dy = omega * (R[e] - py) + coef[d] * (yy - mean[d]);
+        y[e] = fma(gv.alpha, dy, yy);
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// fvpostf!(vs::VarianceScaling, src), src/gv.jl:10-15: one workgroup per matrix (D,T)
+__global__ void __launch_bounds__(256)
+variance_scaling_kernel(const double *__restrict__ src, int D, int T, const double *__restrict__ sigma2,
+                        double *__restrict__ out) {
+  extern __shared__ double vsm[];
+  double *red = vsm, *mean = red + 256, *var = mean + D;
+  gv_moments(src, D, T, 256, red, mean, var);
+  for (int e = threadIdx.x; e < D * T; e += 256) {
+    const int d = e % D;
+    out[e] = sqrt(sigma2[d] / var[d]) * (src[e] - mean[d]) + mean[d];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
 static size_t solve_lds_bytes(int D) {
@@ -421,7 +629,7 @@ static size_t solve_lds_bytes(int D) {
 }
 
 static int traj_run(vcmi_traj *t, std::vector<TrajUtt> &utts, int64_t nframes, bool contiguous, const double *dX0,
-                    hipStream_t st) {
+                    hipStream_t st, const TrajGV *gv = nullptr) {
   const int n = (int)utts.size();
   if (n == 0 || nframes == 0) return VCMI_OK;
   const int D = t->D, D2 = t->D2;
@@ -448,7 +656,8 @@ static int traj_run(vcmi_traj *t, std::vector<TrajUtt> &utts, int64_t nframes, b
   (void)hipGetDevice(&dev);
   (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
   const int grid = std::min(n, cus);
-  const int64_t ws_stride = (int64_t)Tmax * (3 * D + 1) * D;
+  int64_t ws_stride = (int64_t)Tmax * (3 * D + 1) * D;
+  if (gv) ws_stride = std::max<int64_t>(ws_stride, (int64_t)Tmax * 3 * D + (17 * (int64_t)Tmax + 1) / 2 + 16);   // V, r, perm
   VCMI_TRY(t->ws.reserve((size_t)grid * ws_stride));
   VCMI_TRY(t->status.reserve(1));
   VCMI_TRY(t->uttbuf.reserve(sizeof(TrajUtt) * n));
@@ -483,6 +692,16 @@ static int traj_run(vcmi_traj *t, std::vector<TrajUtt> &utts, int64_t nframes, b
                        ws_stride, t->status.p);
   }
   VCMI_HIP(hipGetLastError());
+  if (gv && gv->epochs >= 0) {
+    // (3) global-variance ascent on the solved trajectories, in place; workspace: V (2D,T) + r (D,T) <= the panel area
+    const int nthr = 64 * t->NT;
+    const size_t shmem = ((size_t)kGvNB * 4 * t->KS * 16 + nthr + 3 * (size_t)D) * sizeof(double) + 2 * (size_t)t->M * sizeof(int);
+    VCMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(traj_gv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)shmem));
+    hipLaunchKernelGGL(traj_gv_kernel, dim3(grid), dim3(nthr), shmem, st, du, n, D, t->M, t->KS, t->Qfrag.p, t->mhat.p, t->gbuf.p,
+                       t->ws.p, ws_stride, *gv);
+    VCMI_HIP(hipGetLastError());
+  }
   return VCMI_OK;
 }
 
@@ -495,7 +714,8 @@ static int traj_check_status(vcmi_traj *t, hipStream_t st) {
 }
 
 // host-pointer batch: pack, run, unpack
-static int traj_host_batch(vcmi_traj *t, int64_t n, const double *const *X, const int64_t *T, double *const *Y) {
+static int traj_host_batch(vcmi_traj *t, int64_t n, const double *const *X, const int64_t *T, double *const *Y,
+                           const TrajGV *gv = nullptr) {
   if (!t) return fail(VCMI_ERR_ARG, "trajectory: NULL handle");
   if (n < 0) return fail(VCMI_ERR_ARG, "trajectory: negative batch size");
   if (n == 0) return VCMI_OK;
@@ -519,7 +739,7 @@ static int traj_host_batch(vcmi_traj *t, int64_t n, const double *const *X, cons
     f0 += T[u];
   }
   VCMI_HIP(hipMemcpy(t->xbuf.p, hx.data(), hx.size() * 8, hipMemcpyHostToDevice));
-  VCMI_TRY(traj_run(t, utts, nframes, true, t->xbuf.p, nullptr));
+  VCMI_TRY(traj_run(t, utts, nframes, true, t->xbuf.p, nullptr, gv));
   VCMI_TRY(traj_check_status(t, nullptr));
   std::vector<double> hy((size_t)nframes * D);
   VCMI_HIP(hipMemcpy(hy.data(), t->ybuf.p, hy.size() * 8, hipMemcpyDeviceToHost));
@@ -570,9 +790,20 @@ extern "C" int vcmi_traj_create(vcmi_gmmmap *g, int64_t T, vcmi_traj **out) {
       bv[(size_t)D2 * m + r] = g->h_muy[(size_t)D2 * m + r] - ba;
     }
   }
+  // Q in MFMA A-operand order for the GV ascent: lane l of fragment (row tile i, k-step ks) holds Q[16i + (l&15)][4ks + (l>>4)]
+  t->NT = (D2 + 15) / 16;
+  t->KS = (D2 + 3) / 4;
+  std::vector<double> Qf((size_t)M * t->NT * t->KS * 64, 0.0);
+  for (int m = 0; m < M; ++m)
+    for (int i = 0; i < t->NT; ++i)
+      for (int ks = 0; ks < t->KS; ++ks)
+        for (int l = 0; l < 64; ++l) {
+          const int r = 16 * i + (l & 15), k = 4 * ks + (l >> 4);
+          if (r < D2 && k < D2) Qf[(((size_t)m * t->NT + i) * t->KS + ks) * 64 + l] = Q[nn * m + (size_t)r * D2 + k];
+        }
   int rc = VCMI_OK;
   if ((rc = t->Q.alloc(Q.size())) || (rc = t->QT.alloc(QT.size())) || (rc = t->AT.alloc(AT.size())) ||
-      (rc = t->bvec.alloc(bv.size()))) {
+      (rc = t->bvec.alloc(bv.size())) || (rc = t->Qfrag.alloc(Qf.size()))) {
     delete t;
     return rc;
   }
@@ -580,6 +811,7 @@ extern "C" int vcmi_traj_create(vcmi_gmmmap *g, int64_t T, vcmi_traj **out) {
   if (e == hipSuccess) e = hipMemcpy(t->QT.p, QT.data(), QT.size() * 8, hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(t->AT.p, AT.data(), AT.size() * 8, hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(t->bvec.p, bv.data(), bv.size() * 8, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(t->Qfrag.p, Qf.data(), Qf.size() * 8, hipMemcpyHostToDevice);
   if (e != hipSuccess) {
     delete t;
     return fail(VCMI_ERR_HIP, "TrajectoryGMMMap: upload failed: %s", hipGetErrorString(e));
@@ -658,5 +890,136 @@ extern "C" int vcmi_push_delta(const double *src, int D, int64_t T, double *out)
   for (int64_t t = 1; t + 1 < T; ++t)   // t = 2:T-1, src/datasets.jl:9-11
     for (int d = 0; d < D; ++d)
       out[D + d + (size_t)2 * D * t] = -0.5 * src[d + (size_t)D * (t - 1)] + 0.5 * src[d + (size_t)D * (t + 1)];
+  return VCMI_OK;
+}
+
+// ---- TrajectoryGVGMMMap, src/trajectory_gmmmap.jl:114-189 ----------------------------------------
+extern "C" int vcmi_trajgv_create(vcmi_traj *t, const double *muv, const double *sigmavv, vcmi_trajgv **out) {
+  if (!t || !muv || !sigmavv || !out) return fail(VCMI_ERR_ARG, "vcmi_trajgv_create: NULL argument");
+  *out = nullptr;
+  const int D = t->D;
+  if (64 * t->NT > 384) return fail(VCMI_ERR_ARG, "TrajectoryGVGMMMap: feature dimension %d too large", t->D2);
+  for (int d = 0; d < D; ++d)
+    if (muv[d] < 0.0) return fail(VCMI_ERR_ARG, "TrajectoryGVGMMMap: the GV mean must be non-negative");   // the @assert of :124
+  std::vector<double> S((size_t)D * D), P((size_t)D * D);
+  for (int r = 0; r < D; ++r)
+    for (int c = 0; c < D; ++c) S[(size_t)r * D + c] = sigmavv[r + (size_t)D * c];
+  if (!la::inverse(S.data(), D, P.data())) return fail(VCMI_ERR_NOT_PD, "TrajectoryGVGMMMap: the GV covariance is singular");
+  std::vector<double> Pj((size_t)D * D);                       // back to the Julia memory image
+  for (int r = 0; r < D; ++r)
+    for (int c = 0; c < D; ++c) Pj[r + (size_t)D * c] = P[(size_t)r * D + c];
+  vcmi_trajgv *h = new (std::nothrow) vcmi_trajgv();
+  if (!h) return fail(VCMI_ERR_OOM, "out of host memory");
+  h->t = t;
+  int rc = VCMI_OK;
+  if ((rc = h->muv.alloc(D)) || (rc = h->pv.alloc((size_t)D * D))) {
+    delete h;
+    return rc;
+  }
+  hipError_t e = hipMemcpy(h->muv.p, muv, sizeof(double) * D, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(h->pv.p, Pj.data(), sizeof(double) * D * D, hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    delete h;
+    return fail(VCMI_ERR_HIP, "TrajectoryGVGMMMap: upload failed: %s", hipGetErrorString(e));
+  }
+  *out = h;
+  return VCMI_OK;
+}
+
+extern "C" int vcmi_trajgv_destroy(vcmi_trajgv *h) {
+  delete h;
+  return VCMI_OK;
+}
+
+static int trajgv_args(const vcmi_trajgv *h, int64_t n, const int64_t *T, int epochs, TrajGV *gv) {
+  if (!h) return fail(VCMI_ERR_ARG, "TrajectoryGVGMMMap: NULL handle");
+  if (epochs < 0) return fail(VCMI_ERR_ARG, "TrajectoryGVGMMMap: negative epoch count");
+  for (int64_t u = 0; T && u < n; ++u)
+    if (T[u] == 1) return fail(VCMI_ERR_DIM, "TrajectoryGVGMMMap: the variance of a one-frame trajectory is undefined");
+  gv->muv = h->muv.p;
+  gv->pv = h->pv.p;
+  gv->epochs = epochs;
+  return VCMI_OK;
+}
+
+extern "C" int vcmi_trajgv_convert_batch(vcmi_trajgv *h, int64_t n, const double *const *X, const int64_t *T, int epochs,
+                                         double alpha, double *const *Y) {
+  TrajGV gv{};
+  gv.alpha = alpha;
+  VCMI_TRY(trajgv_args(h, n, T, epochs, &gv));
+  return traj_host_batch(h->t, n, X, T, Y, &gv);
+}
+
+extern "C" int vcmi_trajgv_convert(vcmi_trajgv *h, const double *X, int64_t T, int epochs, double alpha, double *Y) {
+  const double *xs[1] = {X};
+  double *ys[1] = {Y};
+  return vcmi_trajgv_convert_batch(h, 1, xs, &T, epochs, alpha, ys);
+}
+
+extern "C" int vcmi_trajgv_convert_batch_dev(vcmi_trajgv *h, int64_t n, const double *dX, const int64_t *x_off, const int64_t *T,
+                                             int epochs, double alpha, double *dY, const int64_t *y_off, void *stream) {
+  TrajGV gv{};
+  gv.alpha = alpha;
+  VCMI_TRY(trajgv_args(h, n, T, epochs, &gv));
+  vcmi_traj *t = h->t;
+  if (n < 0) return fail(VCMI_ERR_ARG, "vcmi_trajgv_convert_batch_dev: negative batch size");
+  if (n == 0) return VCMI_OK;
+  if (!dX || !x_off || !T || !dY || !y_off) return fail(VCMI_ERR_ARG, "vcmi_trajgv_convert_batch_dev: NULL argument");
+  std::vector<TrajUtt> utts(n);
+  int64_t f0 = 0;
+  bool contiguous = true;
+  for (int64_t u = 0; u < n; ++u) {
+    if (T[u] < 0 || T[u] > INT32_MAX) return fail(VCMI_ERR_DIM, "trajectory: bad utterance length");
+    if (x_off[u] != x_off[0] + f0 * t->D2) contiguous = false;
+    utts[u] = TrajUtt{dX + x_off[u], dY + y_off[u], f0, (int32_t)T[u]};
+    f0 += T[u];
+  }
+  VCMI_TRY(traj_run(t, utts, f0, contiguous, dX + x_off[0], as_stream(stream), &gv));
+  return traj_check_status(t, as_stream(stream));
+}
+
+// fvpostf(vs::VarianceScaling, src) -- src/gv.jl:10-21.  src, out (D,T) host matrices (may alias), sigma2 (D).
+extern "C" int vcmi_variance_scaling(const double *src, int D, int64_t T, const double *sigma2, double *out) {
+  if (!src || !sigma2 || !out) return fail(VCMI_ERR_ARG, "vcmi_variance_scaling: NULL argument");
+  if (D < 1 || D > 256 || T < 2 || T > INT32_MAX / D)
+    return fail(VCMI_ERR_DIM, "vcmi_variance_scaling: D=%d T=%lld unsupported (needs 1 <= D <= 256, T >= 2)", D, (long long)T);
+  VCMI_TRY(check_device());
+  DevBuf<double> dsrc, dout, dsig;
+  VCMI_TRY(dsrc.alloc((size_t)D * T));
+  VCMI_TRY(dout.alloc((size_t)D * T));
+  VCMI_TRY(dsig.alloc(D));
+  VCMI_HIP(hipMemcpy(dsrc.p, src, sizeof(double) * D * T, hipMemcpyHostToDevice));
+  VCMI_HIP(hipMemcpy(dsig.p, sigma2, sizeof(double) * D, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(variance_scaling_kernel, dim3(1), dim3(256), (256 + 2 * (size_t)D) * sizeof(double), nullptr, dsrc.p, D,
+                     (int)T, dsig.p, dout.p);
+  VCMI_HIP(hipGetLastError());
+  VCMI_HIP(hipMemcpy(out, dout.p, sizeof(double) * D * T, hipMemcpyDeviceToHost));
+  return VCMI_OK;
+}
+
+// diffgmm(params) -- src/diffgmm.jl:9-25, on the joint parameters mu (2D,M), sigma (2D,2D,M) (host arithmetic: a
+// one-time parameter transform).  Feed the result to vcmi_gmmmap_create for the differential converter.
+extern "C" int vcmi_diffgmm(const double *mu, const double *sigma, int Dj, int M, double *mu_out, double *sigma_out) {
+  if (!mu || !sigma || !mu_out || !sigma_out) return fail(VCMI_ERR_ARG, "vcmi_diffgmm: NULL argument");
+  if (Dj < 2 || (Dj & 1) || M < 1) return fail(VCMI_ERR_DIM, "vcmi_diffgmm: joint dimension %d / mixtures %d invalid", Dj, M);
+  const int D = Dj / 2;
+  for (int m = 0; m < M; ++m) {
+    const double *S = sigma + (size_t)Dj * Dj * m;
+    double *O = sigma_out + (size_t)Dj * Dj * m;
+    for (int d = 0; d < D; ++d) {
+      const double mx = mu[d + (size_t)Dj * m], my = mu[D + d + (size_t)Dj * m];
+      mu_out[d + (size_t)Dj * m] = mx;
+      mu_out[D + d + (size_t)Dj * m] = my - mx;                                  // eq. (6)
+    }
+    for (int c = 0; c < D; ++c)
+      for (int r = 0; r < D; ++r) {
+        const double xx = S[r + (size_t)Dj * c], xy = S[r + (size_t)Dj * (D + c)], yx = S[(D + r) + (size_t)Dj * c],
+                     yy = S[(D + r) + (size_t)Dj * (D + c)];
+        O[r + (size_t)Dj * c] = xx;
+        O[r + (size_t)Dj * (D + c)] = xy - xx;                                    // eq. (7)
+        O[(D + c) + (size_t)Dj * r] = xy - xx;                                    // its transpose
+        O[(D + r) + (size_t)Dj * (D + c)] = xx + yy - xy - yx;                    // eq. (8)
+      }
+  }
   return VCMI_OK;
 }

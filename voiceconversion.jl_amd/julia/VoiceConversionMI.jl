@@ -16,7 +16,8 @@ module VoiceConversionMI
 
 export GMMMap, TrajectoryGMMMap, fvconvert, vc, dim, ncomponents,
        DTW, fit!, update!, set_template!, backward, align, push_delta,
-       predict_proba, predict, estep_diag, estep_full, GMMEM, estep!, mstep!, params
+       predict_proba, predict, estep_diag, estep_full, GMMEM, estep!, mstep!, params,
+       TrajectoryGVGMMMap, VarianceScaling, fvpostf, fvpostf!, diffgmm
 
 const libvcmi = get(ENV, "LIBVCMI", "libvcmi")
 
@@ -251,6 +252,51 @@ function estep_full(X::Matrix{Float64}, w::Vector{Float64}, μ::Matrix{Float64},
                  Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ref{Float64}),
                 X, size(X, 2), Dj, M, w, μ, Σ, S0, S1, S2, ll))
     S0, S1, S2, ll[]
+end
+
+# --------------------------------------------------------------------------- GV trajectory converter, post filter
+# TrajectoryGVGMMMap(tgmm, μᵛ, Σᵛᵛ) and fvconvert(tgv, X; epochs, α) -- src/trajectory_gmmmap.jl:114-189
+mutable struct TrajectoryGVGMMMap <: TrajectoryConverter
+    handle::Ptr{Cvoid}
+    tgmm::TrajectoryGMMMap
+    function TrajectoryGVGMMMap(tgmm::TrajectoryGMMMap, μᵛ::Vector{Float64}, Σᵛᵛ::Matrix{Float64})
+        @assert sum(μᵛ .< 0) == 0
+        h = Ref{Ptr{Cvoid}}(C_NULL)
+        check(ccall((:vcmi_trajgv_create, libvcmi), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ref{Ptr{Cvoid}}),
+                    tgmm.handle, μᵛ, Σᵛᵛ, h))
+        tgv = new(h[], tgmm)
+        finalizer(x -> ccall((:vcmi_trajgv_destroy, libvcmi), Cint, (Ptr{Cvoid},), x.handle), tgv)
+        tgv
+    end
+end
+Base.length(t::TrajectoryGVGMMMap) = length(t.tgmm)
+dim(t::TrajectoryGVGMMMap) = dim(t.tgmm)
+ncomponents(t::TrajectoryGVGMMMap) = ncomponents(t.tgmm)
+
+function fvconvert(tgv::TrajectoryGVGMMMap, X::Matrix{Float64}; epochs::Int=100, α::Float64=1.0e-5, verbose::Bool=false)
+    size(X, 1) == dim(tgv) || throw(DimensionMismatch("Inconsistent dimentions."))
+    Y = Matrix{Float64}(undef, dim(tgv) >> 1, size(X, 2))
+    check(ccall((:vcmi_trajgv_convert, libvcmi), Cint, (Ptr{Cvoid}, Ptr{Float64}, Int64, Cint, Cdouble, Ptr{Float64}),
+                tgv.handle, X, size(X, 2), epochs, α, Y))
+    Y
+end
+
+# fvpostf(vs::VarianceScaling, src) -- src/gv.jl:10-21 ; diffgmm on joint parameters -- src/diffgmm.jl:9-25
+struct VarianceScaling
+    σ²::Vector{Float64}
+end
+function fvpostf(vs::VarianceScaling, src::Matrix{Float64})
+    out = similar(src)
+    check(ccall((:vcmi_variance_scaling, libvcmi), Cint, (Ptr{Float64}, Cint, Int64, Ptr{Float64}, Ptr{Float64}),
+                src, size(src, 1), size(src, 2), vs.σ², out))
+    out
+end
+fvpostf!(vs::VarianceScaling, src::Matrix{Float64}) = (src[:, :] = fvpostf(vs, src); src)
+function diffgmm(μ::Matrix{Float64}, Σ::Array{Float64,3})
+    μd = similar(μ); Σd = similar(Σ)
+    check(ccall((:vcmi_diffgmm, libvcmi), Cint, (Ptr{Float64}, Ptr{Float64}, Cint, Cint, Ptr{Float64}, Ptr{Float64}),
+                μ, Σ, size(μ, 1), size(μ, 2), μd, Σd))
+    μd, Σd
 end
 
 # ------------------------------------------------------------------------------------- device-resident EM

@@ -104,3 +104,71 @@ class TrajectoryGMMMap(TrajectoryConverter):
         out = np.empty((D2 // 2 + 1, T), order="F")
         _lib.check(_lib.lib.vcmi_vc_traj(self._h, _lib.dptr(fm), T, _lib.dptr(out)))
         return out
+
+
+class TrajectoryGVGMMMap(TrajectoryConverter):
+    """TrajectoryGVGMMMap(tgmm, mu^v, Sigma^vv) -- src/trajectory_gmmmap.jl:114-137: trajectory conversion followed
+    by gradient ascent on the likelihood that includes the global variance (Toda et al. 2007, eqs. (52), (58))."""
+
+    def __init__(self, tgmm, muv, sigmavv):
+        muv = np.ascontiguousarray(np.asarray(muv, dtype=np.float64).reshape(-1))
+        sigmavv = jl_matrix(sigmavv, "sigmavv")
+        D = tgmm._dim() // 2
+        if muv.shape != (D,) or sigmavv.shape != (D, D):
+            raise _lib.DimensionMismatch("the GV statistics must have the static feature dimension")
+        if np.any(muv < 0):                 # @assert sum(mu^v .< 0) == 0, src/trajectory_gmmmap.jl:124
+            raise AssertionError("the GV mean must be non-negative")
+        self.tgmm = tgmm
+        h = C.c_void_p()
+        _lib.check(_lib.lib.vcmi_trajgv_create(tgmm._h, _lib.dptr(muv), _lib.dptr(sigmavv), C.byref(h)))
+        self._h = h
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            _lib.lib.vcmi_trajgv_destroy(h)
+            self._h = None
+
+    def __len__(self):                      # src/trajectory_gmmmap.jl:132
+        return len(self.tgmm)
+
+    def _dim(self):                         # :133
+        return self.tgmm._dim()
+
+    def _ncomponents(self):                 # :134
+        return self.tgmm._ncomponents()
+
+    def _fvconvert(self, X, epochs=100, alpha=1.0e-5, verbose=False):
+        """fvconvert(tgv, X (2D,T); epochs=100, alpha=1.0e-5) -> (D,T); src/trajectory_gmmmap.jl:139-168"""
+        return self.fvconvert_batch([X], epochs=epochs, alpha=alpha)[0]
+
+    def fvconvert_batch(self, Xs, epochs=100, alpha=1.0e-5):
+        n = len(Xs)
+        if n == 0:
+            return []
+        Xs = [jl_matrix(x, "X") for x in Xs]
+        D2 = self._dim()
+        for x in Xs:
+            if x.shape[0] != D2:
+                raise _lib.DimensionMismatch("Inconsistent dimentions.")
+        T = np.array([x.shape[1] for x in Xs], dtype=np.int64)
+        Ys = [np.empty((D2 // 2, int(t)), order="F") for t in T]
+        dpp = C.POINTER(C.c_double) * n
+        _lib.check(_lib.lib.vcmi_trajgv_convert_batch(self._h, n, dpp(*[_lib.dptr(x) for x in Xs]), _lib.iptr(T), int(epochs),
+                                                      float(alpha), dpp(*[_lib.dptr(y) for y in Ys])))
+        return Ys
+
+    def _vc(self, fm):
+        """vc(c::TrajectoryConverter, fm): chunks of length(c) frames, each converted with the default epochs / alpha;
+        src/common.jl:31-63"""
+        fm = jl_matrix(fm, "fm")
+        D2 = self._dim()
+        if fm.shape[0] != D2 + 1:
+            raise _lib.DimensionMismatch("Inconsistent dimentions.")
+        T, L = fm.shape[1], len(self)
+        out = np.empty((D2 // 2 + 1, T), order="F")
+        chunks = [np.asfortranarray(fm[1:, b:min(b + L, T)]) for b in range(0, T, L)]
+        for k, y in enumerate(self.fvconvert_batch(chunks)):
+            out[1:, k * L:k * L + y.shape[1]] = y
+        out[0, :] = fm[0, :]
+        return out
