@@ -435,9 +435,13 @@ estep_full_stats_kernel(const double *__restrict__ X, int64_t n0, int64_t n, int
   __shared__ double gs[2][FB * 8];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lcol = lane & 15, lgrp = lane >> 4;
-  const int m = blockIdx.x * 8 + wave;                 // this wave's mixture (may be >= M: then gamma is staged as 0)
-  const int64_t seglen = (n + gridDim.y - 1) / gridDim.y;
-  const int64_t f_begin = blockIdx.y * seglen, f_end = (f_begin + seglen < n) ? f_begin + seglen : n;
+  // grid = (frame segments, mixture groups): consecutive workgroups go to consecutive XCDs, so with the segment as the
+  // FAST index the mixture groups that read one segment of X share an XCD (when the segment count is a multiple of 8)
+  // and X reaches that L2 once instead of once per mixture group
+  const int mg = blockIdx.y, seg = blockIdx.x, nsegs = gridDim.x;
+  const int m = mg * 8 + wave;                         // this wave's mixture (may be >= M: then gamma is staged as 0)
+  const int64_t seglen = (n + nsegs - 1) / nsegs;
+  const int64_t f_begin = seg * seglen, f_end = (f_begin + seglen < n) ? f_begin + seglen : n;
 
   d4 acc[NTL][NTL];                                    // lower tiles only (j <= a)
 #pragma unroll
@@ -450,7 +454,7 @@ estep_full_stats_kernel(const double *__restrict__ X, int64_t n0, int64_t n, int
 
   double pf[NPF], pg = 0.0;
   const int gf = tid >> 3, gq = tid & 7;               // gamma staging: 32 frames x 8 mixtures = threads 0..255
-  const int gm_idx = blockIdx.x * 8 + gq;
+  const int gm_idx = mg * 8 + gq;
   auto fetch = [&](int64_t fb) {                       // global -> registers (the block's frames are contiguous in X)
     const int64_t lim = (f_end - fb) * DJ;
     const double *src = X + (n0 + fb) * DJ;
@@ -503,7 +507,7 @@ estep_full_stats_kernel(const double *__restrict__ X, int64_t n0, int64_t n, int
   }
   if (m >= M) return;
   // partial statistics of this (mixture, segment) in the final layout [S0 | S1 | S2 | loglik]
-  double *P = part + (size_t)blockIdx.y * plen;
+  double *P = part + (size_t)seg * plen;
   s0 += __shfl_xor(s0, 16);
   s0 += __shfl_xor(s0, 32);
   if (lane == 0) P[m] = s0;
@@ -592,7 +596,7 @@ static int estep_full_core(vcmi_gmmmap *px, const double *dX, int64_t N, int Dj,
     hipLaunchKernelGGL(estep_full_softmax_kernel, dim3(kSoftmaxGrid), dim3(256), 0, st, sc.LP.p, M, n, sc.lse.p);
     hipLaunchKernelGGL(estep_sum_kernel, dim3(1), dim3(256), 0, st, sc.lse.p, (int64_t)kSoftmaxGrid, dstats + (plen - 1));
     VCMI_HIP(hipMemsetAsync(sc.part.p, 0, (size_t)nseg * plen * sizeof(double), st));
-    const dim3 grid(mgroups, nseg);
+    const dim3 grid(nseg, mgroups);
     if (mfma) {
       switch (Dj) {
         case 32: hipLaunchKernelGGL(estep_full_stats_kernel<32>, grid, dim3(512), 0, st, dX, n0, n, M, sc.LP.p, sc.part.p, plen); break;

@@ -90,6 +90,11 @@ gmmmap_mfma_kernel(const double *__restrict__ packed, int M, int D, const double
   constexpr int NV = BLK / 2 / NTHREADS;   // double2 copies per thread per block (BLK is a multiple of 1024)
   static_assert(BLK % (2 * NTHREADS) == 0, "block size must be a whole number of double2 per thread");
   extern __shared__ double smem[];                          // NBUF * BLK doubles
+  // MODE 1: write-combining stage for the (T,M) log-density output.  A lane owns a frame and produces one value per
+  // mixture iteration; written directly these are 8-byte stores 8*M bytes apart (PMC: WRITE_SIZE 4x the bytes of the
+  // matrix).  Values of 8 consecutive mixtures are parked here and then leave as 64-byte rows.
+  constexpr int LROW = 10;                                  // 8 values + pad: 16-byte aligned, conflict-free for 16 lanes
+  __shared__ __attribute__((aligned(16))) double lstage[(MODE == 1) ? WAVES * FT * 16 * LROW : 2];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -191,10 +196,7 @@ gmmmap_mfma_kernel(const double *__restrict__ packed, int M, int D, const double
         // log-weighted density of mixture m for the wave's frames; one lane group writes
         if (lgrp == 0) {
 #pragma unroll
-          for (int f = 0; f < FT; ++f) {
-            const int64_t fr = frame0 + 16 * f + lcol;
-            if (fr < T) Y[fr * ldy + m] = lc - 0.5 * q[f];
-          }
+          for (int f = 0; f < FT; ++f) lstage[((wave * FT + f) * 16 + lcol) * LROW + (m & 7)] = lc - 0.5 * q[f];
         }
       } else {
         // ---------------- phase A: regression tiles, E = A x + b ----------------
@@ -251,10 +253,33 @@ gmmmap_mfma_kernel(const double *__restrict__ packed, int M, int D, const double
 
     else if (MODE == 1 && lgrp == 0) {
 #pragma unroll
-      for (int f = 0; f < FT; ++f) {
-        const int64_t fr = frame0 + 16 * f + lcol;
-        if (fr < T) Y[fr * ldy + m] = -INFINITY;
+      for (int f = 0; f < FT; ++f) lstage[((wave * FT + f) * 16 + lcol) * LROW + (m & 7)] = -INFINITY;
+    }
+    if (MODE == 1 && ((m & 7) == 7 || m == M - 1)) {
+      // flush mixtures m0..m of the wave's FT*16 frames: lane = (frame, half row) -> 32 contiguous bytes each
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the wave's own ds_writes above have landed
+      const int m0 = m & ~7, nv = m - m0 + 1;
+#pragma unroll
+      for (int i = 0; i < (FT * 16 * 2 + 63) / 64; ++i) {
+        const int slot = lane + 64 * i, fl = slot >> 1, h = slot & 1;
+        if (fl < FT * 16) {
+          const int64_t fr = frame0 + fl;
+          const double *row = &lstage[(wave * FT * 16 + fl) * LROW + 4 * h];
+          double *dst = Y + fr * ldy + m0 + 4 * h;
+          if (fr < T) {
+            if (nv == 8 && ((ldy | m0) & 1) == 0) {
+              const double2 a = *reinterpret_cast<const double2 *>(row), b2 = *reinterpret_cast<const double2 *>(row + 2);
+              *reinterpret_cast<double2 *>(dst) = a;
+              *reinterpret_cast<double2 *>(dst + 2) = b2;
+            } else {
+#pragma unroll
+              for (int j = 0; j < 4; ++j)
+                if (4 * h + j < nv) dst[j] = row[j];
+            }
+          }
+        }
       }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // reads done before the next group's ds_writes reuse the rows
     }
 
     if (NBUF == 1) __syncthreads();   // single buffer: everyone is done reading before it is overwritten
