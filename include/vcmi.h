@@ -185,6 +185,26 @@ int vcmi_variance_scaling(const double *src, int D, int64_t T, const double *sig
 /* diffgmm(params) -- src/diffgmm.jl:9-25 on joint parameters mu (2D,M), sigma (2D,2D,M); host arithmetic. */
 int vcmi_diffgmm(const double *mu, const double *sigma, int Dj, int M, double *mu_out, double *sigma_out);
 
+/* ---------------------------------------------------------------------------------------------
+ * align_mcep and the joint training matrix -- src/align.jl:38-55, src/datasets.jl:52-98
+ * ------------------------------------------------------------------------------------------- */
+/* mc2e(mc, alpha, len) of MelGeneralizedCepstrums (third party; call site src/align.jl:48) for every column of
+ * mc (D,T): energy of c2ir(freqt(mc, len-1, -alpha), len).  e (T). */
+int vcmi_mc2e(const double *mc, int D, int64_t T, double alpha, int fftlen, double *e);
+/* align_mcep(src, tgt, alpha, fftlen; threshold=-14.0, remove_silence=true): align, then keep the columns whose
+ * log(mc2e(src)) exceeds the threshold.  src (D,S), tgt (D,T); src_out, newtgt_out (D, up to S); *ncols kept. */
+int vcmi_align_mcep(const double *src, int64_t S, const double *tgt, int64_t T, int D, double alpha, int fftlen,
+                    double threshold, int remove_silence, double *src_out, double *newtgt_out, int64_t *ncols);
+/* align_mcep of every pair followed by ParallelDataset(joint=true; diff, ignore0th, add_delta).X, left ON THE DEVICE
+ * for the E-step: per pair drop row 1 (ignore0th), push_delta on the kept frames (add_delta), tgt - src (diff), vcat;
+ * pairs concatenated in order.  do_align = 0 takes pairs that are already aligned (S == T).  dXY: device buffer of
+ * Dj * capacity_frames doubles with capacity_frames >= sum(S), Dj = 2 (D - ignore0th)(1 + add_delta); *nframes
+ * receives the number of columns written; counts (optional, host, n entries) the frames kept per pair. */
+int vcmi_parallel_dataset_dev(int64_t n, const double *const *src, const int64_t *S, const double *const *tgt,
+                              const int64_t *T, int D, int do_align, double alpha, int fftlen, double threshold,
+                              int remove_silence, int ignore0th, int add_delta, int diff, double *dXY,
+                              int64_t capacity_frames, int64_t *nframes, int64_t *counts);
+
 #ifdef __cplusplus
 }
 #endif

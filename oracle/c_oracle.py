@@ -54,6 +54,10 @@ def lib():
         L.vco_variance_scaling.argtypes = [_dp, C.c_int, C.c_int64, _dp, _dp]
         L.vco_trajgv_fvconvert.argtypes = [C.c_void_p, _dp, C.c_int64, _dp, _dp, C.c_int, C.c_double, _dp]
         L.vco_diffgmm.argtypes = [_dp, _dp, C.c_int, C.c_int, _dp, _dp]
+        L.vco_mc2e.argtypes = [_dp, C.c_int, C.c_int64, C.c_double, C.c_int, _dp]
+        L.vco_align_mcep.restype = C.c_int64
+        L.vco_align_mcep.argtypes = [_dp, C.c_int64, _dp, C.c_int64, C.c_int, C.c_double, C.c_int, C.c_double, C.c_int, _dp, _dp]
+        L.vco_joint_features.argtypes = [_dp, _dp, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, _dp]
         L.vco_estep_full.argtypes = [_dp, C.c_int64, C.c_int, C.c_int, _dp, _dp, _dp, _dp, _dp, _dp, _dp]
         _lib = L
     return _lib
@@ -242,3 +246,29 @@ def diffgmm(mu, sigma):
     mo, so = np.empty_like(mu), np.empty_like(sigma)
     lib().vco_diffgmm(_d(mu), _d(sigma), Dj, M, _d(mo), _d(so))
     return mo, so
+
+
+def mc2e(mc, alpha, fftlen):
+    mc = _f64(mc)
+    T, D = mc.shape
+    e = np.empty(T)
+    lib().vco_mc2e(_d(mc), D, T, float(alpha), int(fftlen), _d(e))
+    return e
+
+
+def align_mcep(src, tgt, alpha, fftlen, threshold=-14.0, remove_silence=True):
+    src, tgt = _f64(src), _f64(tgt)
+    S, D = src.shape
+    so, to = np.empty_like(src), np.empty_like(src)
+    k = lib().vco_align_mcep(_d(src), S, _d(tgt), tgt.shape[0], D, float(alpha), int(fftlen), float(threshold),
+                             int(bool(remove_silence)), _d(so), _d(to))
+    return so[:k].copy(), to[:k].copy()
+
+
+def joint_features(src, tgt, ignore0th=True, add_delta=False, diff=False):
+    src, tgt = _f64(src), _f64(tgt)
+    n, D = src.shape
+    Dj = 2 * (D - int(ignore0th)) * (2 if add_delta else 1)
+    out = np.empty((n, Dj))
+    lib().vco_joint_features(_d(src), _d(tgt), D, n, int(ignore0th), int(add_delta), int(diff), _d(out))
+    return out

@@ -182,6 +182,22 @@ def main():
     dmc, dsc = co.diffgmm(mu[:2], sig[:2])
     assert _relmax(dm, dmc) < 1e-15 and _relmax(ds, dsc) < 1e-14
     np.savez(os.path.join(OUT, "gv_fixture_model.npz"), muv=muv, sigmavv=Sv, Y_gv=ygv, Y_scaled=vs, diff_mu=dm, diff_sigma=ds)
+    # ---- (8) align_mcep / mc2e / joint features (src/align.jl:38-55, src/datasets.jl:52-98); mc2e is third-party
+    #      arithmetic restated from the SPTK recursions -- anchored by the closed form for a c0-only cepstrum
+    rg = np.random.default_rng(8008)
+    srcm = rg.standard_normal((60, 25)) * np.exp(-0.3 * np.arange(25)) * 0.3
+    srcm[:, 0] = rg.uniform(-9.0, 1.0, 60)
+    tgtm = srcm[np.sort(rg.integers(0, 60, 70))] + 0.01 * rg.standard_normal((70, 25))
+    en = npo.mc2e(srcm, 0.41, 256)
+    assert np.max(np.abs(en - co.mc2e(srcm, 0.41, 256)) / en) < 1e-12
+    c0 = np.zeros((1, 5)); c0[0, 0] = 0.7
+    assert abs(npo.mc2e(c0, 0.35, 64)[0] - np.exp(1.4)) < 1e-12
+    sa, ta = npo.align_mcep(srcm, tgtm, 0.41, 256)
+    sac, tac = co.align_mcep(srcm, tgtm, 0.41, 256)
+    assert np.array_equal(sa, sac) and np.array_equal(ta, tac)
+    jf = npo.parallel_dataset([(sa, ta)], diff=True, ignore0th=True, add_delta=True)
+    assert np.array_equal(jf, co.joint_features(sa, ta, True, True, True))
+    np.savez(os.path.join(OUT, "align_mcep_case.npz"), src=srcm, tgt=tgtm, energy=en, src_kept=sa, tgt_kept=ta, joint=jf)
     print("golden fixtures written to", OUT)
     for f in sorted(os.listdir(OUT)):
         print(f"  {f}: {os.path.getsize(os.path.join(OUT, f)) / 1e6:.2f} MB")

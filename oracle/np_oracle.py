@@ -163,6 +163,64 @@ def align(src, tgt):
     return newtgt, path
 
 
+# ----------------------------------------------------------- align_mcep / ParallelDataset
+def freqt(c, order, alpha):
+    """Frequency transformation of a cepstrum (SPTK `freqt`; MelGeneralizedCepstrums.freqt, third party -- restated
+    from the published recursion, Tokuda et al.): c (m1+1,) -> (order+1,)."""
+    m1 = len(c) - 1
+    b = 1.0 - alpha * alpha
+    g = np.zeros(order + 1)
+    for i in range(m1, -1, -1):
+        d = g.copy()
+        g[0] = c[i] + alpha * d[0]
+        if order >= 1:
+            g[1] = b * d[0] + alpha * d[1]
+        for j in range(2, order + 1):
+            g[j] = d[j - 1] + alpha * (d[j] - g[j - 1])
+    return g
+
+
+def c2ir(c, length):
+    """Cepstrum -> minimum-phase impulse response (SPTK `c2ir`): h[0] = exp(c[0]), h[n] = sum_k (k/n) c[k] h[n-k]."""
+    h = np.zeros(length)
+    h[0] = np.exp(c[0])
+    for n in range(1, length):
+        up = min(n, len(c) - 1)
+        k = np.arange(1, up + 1)
+        h[n] = np.dot(k * c[1:up + 1], h[n - k]) / n
+    return h
+
+
+def mc2e(mc, alpha, fftlen):
+    """mc2e(mc, alpha, len), call site src/align.jl:48 (MelGeneralizedCepstrums, third party): energy of the impulse
+    response of the spectrum a mel-cepstrum describes.  mc (T,D) -> (T,)."""
+    return np.array([np.sum(c2ir(freqt(row, fftlen - 1, -alpha), fftlen) ** 2) for row in mc])
+
+
+def align_mcep(src, tgt, alpha, fftlen, threshold=-14.0, remove_silence=True):
+    """align_mcep, src/align.jl:38-55.  src (S,D), tgt (T,D) -> (src', newtgt') with silent source frames dropped."""
+    newtgt, _ = align(src, tgt)
+    if remove_silence:
+        keep = np.log(mc2e(src, alpha, fftlen)) > threshold
+        return src[keep], newtgt[keep]
+    return src, newtgt
+
+
+def parallel_dataset(pairs, diff=False, ignore0th=True, add_delta=False):
+    """ParallelDataset(path; joint=true, ...).X, src/datasets.jl:52-98: per utterance drop row 1, push_delta, tgt - src,
+    vcat, then hcat over utterances.  pairs: [(src (n,D), tgt (n,D))] -> (N, Dj)."""
+    out = []
+    for sx, tx in pairs:
+        if ignore0th:
+            sx, tx = sx[:, 1:], tx[:, 1:]
+        if add_delta:
+            sx, tx = push_delta(sx), push_delta(tx)
+        if diff:
+            tx = tx - sx
+        out.append(np.concatenate([sx, tx], axis=1))
+    return np.concatenate(out, axis=0)
+
+
 # ---------------------------------------------------------------------------------------- trajectory
 def constructW(D, T):
     """src/trajectory_gmmmap.jl:39-61, as a scipy CSC matrix (2DT x DT)."""

@@ -607,6 +607,86 @@ void vco_diffgmm(const double *mu, const double *sigma, int Dj, int M, double *m
   }
 }
 
+/* mc2e(mc, alpha, len) -- call site src/align.jl:48; MelGeneralizedCepstrums (third party, not under /root/reference):
+ * e = sum_n h[n]^2, h = c2ir(freqt(mc, len-1, -alpha), len); freqt / c2ir restated from the published SPTK recursions.
+ * mc (D,T) -> e (T). */
+void vco_mc2e(const double *mc, int D, int64_t T, double alpha, int fftlen, double *e) {
+  int m2 = fftlen - 1;
+  double a = -alpha, b = 1.0 - a * a;
+  double *g = (double *)malloc(sizeof(double) * (m2 + 1)), *d = (double *)malloc(sizeof(double) * (m2 + 1));
+  double *h = (double *)malloc(sizeof(double) * fftlen);
+  for (int64_t t = 0; t < T; ++t) {
+    const double *c = mc + (size_t)D * t;
+    memset(g, 0, sizeof(double) * (m2 + 1));
+    for (int i = D - 1; i >= 0; --i) {                        /* freqt */
+      memcpy(d, g, sizeof(double) * (m2 + 1));
+      g[0] = c[i] + a * d[0];
+      if (m2 >= 1) g[1] = b * d[0] + a * d[1];
+      for (int j = 2; j <= m2; ++j) g[j] = d[j - 1] + a * (d[j] - g[j - 1]);
+    }
+    h[0] = exp(g[0]);                                         /* c2ir */
+    for (int n = 1; n < fftlen; ++n) {
+      double s = 0.0;
+      int up = n < m2 ? n : m2;
+      for (int k = 1; k <= up; ++k) s += k * g[k] * h[n - k];
+      h[n] = s / n;
+    }
+    double en = 0.0;
+    for (int n = 0; n < fftlen; ++n) en += h[n] * h[n];
+    e[t] = en;
+  }
+  free(g); free(d); free(h);
+}
+
+/* align_mcep(src, tgt, alpha, fftlen; threshold, remove_silence) -- src/align.jl:38-55.  src (D,S), tgt (D,T);
+ * outputs (D, <=S) compacted; returns the number of kept columns. */
+int64_t vco_align_mcep(const double *src, int64_t S, const double *tgt, int64_t T, int D, double alpha, int fftlen,
+                       double threshold, int remove_silence, double *src_out, double *newtgt_out) {
+  double *nt = (double *)malloc(sizeof(double) * D * S);
+  vco_align(src, S, tgt, T, D, nt, NULL);
+  int64_t k = 0;
+  if (remove_silence) {
+    double *e = (double *)malloc(sizeof(double) * S);
+    vco_mc2e(src, D, S, alpha, fftlen, e);
+    for (int64_t i = 0; i < S; ++i)
+      if (log(e[i]) > threshold) {
+        memcpy(src_out + (size_t)D * k, src + (size_t)D * i, sizeof(double) * D);
+        memcpy(newtgt_out + (size_t)D * k, nt + (size_t)D * i, sizeof(double) * D);
+        ++k;
+      }
+    free(e);
+  } else {
+    memcpy(src_out, src, sizeof(double) * D * S);
+    memcpy(newtgt_out, nt, sizeof(double) * D * S);
+    k = S;
+  }
+  free(nt);
+  return k;
+}
+
+/* One utterance of ParallelDataset(...; joint=true), src/datasets.jl:60-84: drop row 1 (ignore0th), push_delta,
+ * tgt - src (diff), vcat.  src, tgt (D,n) -> out (Dj,n), Dj = 2 (D - ignore0th) (1 + add_delta). */
+void vco_joint_features(const double *src, const double *tgt, int D, int64_t n, int ignore0th, int add_delta, int diff,
+                        double *out) {
+  int r0 = ignore0th ? 1 : 0, Ds = D - r0, Dh = Ds * (add_delta ? 2 : 1), Dj = 2 * Dh;
+  for (int half = 0; half < 2; ++half) {
+    const double *x = half ? tgt : src;
+    for (int64_t t = 0; t < n; ++t)
+      for (int d = 0; d < Ds; ++d) {
+        double v = x[(r0 + d) + (size_t)D * t];
+        out[half * Dh + d + (size_t)Dj * t] = v;
+        if (add_delta) {                                      /* push_delta, src/datasets.jl:6-13 */
+          double dl = v;
+          if (t >= 1 && t + 1 < n) dl = -0.5 * x[(r0 + d) + (size_t)D * (t - 1)] + 0.5 * x[(r0 + d) + (size_t)D * (t + 1)];
+          out[half * Dh + Ds + d + (size_t)Dj * t] = dl;
+        }
+      }
+  }
+  if (diff)
+    for (int64_t t = 0; t < n; ++t)
+      for (int d = 0; d < Dh; ++d) out[Dh + d + (size_t)Dj * t] -= out[d + (size_t)Dj * t];
+}
+
 /* ------------------------------------------------------------------------------------------------
  * Diagonal E-step
  * ---------------------------------------------------------------------------------------------- */

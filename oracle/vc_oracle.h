@@ -79,6 +79,15 @@ int vco_trajgv_fvconvert(const vco_traj *t, const double *X, int64_t T, const do
 /* diffgmm(params) -- src/diffgmm.jl:9-25, on joint parameters mu (2D,M), sigma (2D,2D,M) */
 void vco_diffgmm(const double *mu, const double *sigma, int Dj, int M, double *mu_out, double *sigma_out);
 
+/* mc2e(mc, alpha, len) (MelGeneralizedCepstrums, third party; call site src/align.jl:48).  mc (D,T) -> e (T) */
+void vco_mc2e(const double *mc, int D, int64_t T, double alpha, int fftlen, double *e);
+/* align_mcep -- src/align.jl:38-55; returns the number of kept columns; outputs hold up to S columns */
+int64_t vco_align_mcep(const double *src, int64_t S, const double *tgt, int64_t T, int D, double alpha, int fftlen,
+                       double threshold, int remove_silence, double *src_out, double *newtgt_out);
+/* one utterance of ParallelDataset(joint=true) -- src/datasets.jl:60-84 */
+void vco_joint_features(const double *src, const double *tgt, int D, int64_t n, int ignore0th, int add_delta, int diff,
+                        double *out);
+
 /* Diagonal-covariance E-step (call site bin/train_gmm.jl:103 -> sklearn.mixture).
  * X (Dj,N); w (M); mu, var (Dj,M).  Outputs S0 (M), S1,S2 (Dj,M), loglik = sum_n lse_n. */
 void vco_estep_diag(const double *X, int64_t N, int Dj, int M, const double *w, const double *mu, const double *var,

@@ -140,3 +140,12 @@ def test_gv_golden(fixture_model):
     assert relerr(co.variance_scaling(zt["Y"], z["muv"]), z["Y_scaled"]) < 1e-13
     dm, ds = co.diffgmm(mu[:2], sig[:2])
     assert relerr(dm, z["diff_mu"]) < 1e-15 and relerr(ds, z["diff_sigma"]) < 1e-14
+
+
+def test_align_mcep_golden():
+    z = load_golden("align_mcep_case.npz")
+    e = co.mc2e(z["src"], 0.41, 256)
+    assert np.max(np.abs(e - z["energy"]) / z["energy"]) < 1e-12
+    s, t = co.align_mcep(z["src"], z["tgt"], 0.41, 256)
+    assert np.array_equal(s, z["src_kept"]) and np.array_equal(t, z["tgt_kept"]) and 0 < len(s) < 60
+    assert np.array_equal(co.joint_features(s, t, True, True, True), z["joint"])

@@ -96,6 +96,10 @@ SIGNATURES = {
     "vcmi_trajgv_convert_batch_dev": (_int, [_vp, _i64, _vp, _ip, _ip, _int, C.c_double, _vp, _ip, _vp]),
     "vcmi_variance_scaling": (_int, [_dp, _int, _i64, _dp, _dp]),
     "vcmi_diffgmm": (_int, [_dp, _dp, _int, _int, _dp, _dp]),
+    "vcmi_mc2e": (_int, [_dp, _int, _i64, C.c_double, _int, _dp]),
+    "vcmi_align_mcep": (_int, [_dp, _i64, _dp, _i64, _int, C.c_double, _int, C.c_double, _int, _dp, _dp, _ip]),
+    "vcmi_parallel_dataset_dev": (_int, [_i64, _dpp, _ip, _dpp, _ip, _int, _int, C.c_double, _int, C.c_double, _int, _int, _int,
+                                         _int, _vp, _i64, _ip, _ip]),
 }
 
 for _name, (_res, _args) in SIGNATURES.items():

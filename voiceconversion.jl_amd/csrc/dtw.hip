@@ -687,6 +687,29 @@ static int dtw_host_batch(int64_t n, const double *const *tmpl, const int64_t *S
   return VCMI_OK;
 }
 
+// align(src_p, tgt_p) for a batch, results LEFT ON THE DEVICE (dataset.hip builds the training matrix from them):
+// *d_feats + src_off[p] is src_p (D,S_p), *d_newtgt + nt_off[p] the aligned target (D,S_p).  The buffers belong to the
+// calling thread's DTW scratch and stay valid until its next DTW / align call.
+int dtw_align_on_device(int64_t n, const double *const *src, const int64_t *S, const double *const *tgt, const int64_t *T,
+                        int D, const double **d_feats, const double **d_newtgt, std::vector<int64_t> &src_off,
+                        std::vector<int64_t> &nt_off) {
+  std::vector<double *> nulls((size_t)std::max<int64_t>(n, 1), nullptr);
+  VCMI_TRY(dtw_host_batch(n, src, S, tgt, T, D, /*fstep=*/0, /*bstep=*/2, nullptr, nullptr, nullptr, nulls.data()));
+  DtwScratch &sc = scratch();
+  *d_feats = sc.feats.p;
+  *d_newtgt = sc.newtgt.p;
+  src_off.resize((size_t)n);
+  nt_off.resize((size_t)n);
+  int64_t fo = 0, to = 0;
+  for (int64_t p = 0; p < n; ++p) {
+    src_off[p] = fo;
+    nt_off[p] = to;
+    fo += (int64_t)D * (S[p] + T[p]);
+    to += (int64_t)D * S[p];
+  }
+  return VCMI_OK;
+}
+
 }  // namespace vcmi
 
 using namespace vcmi;

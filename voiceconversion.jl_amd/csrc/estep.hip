@@ -707,7 +707,18 @@ struct vcmi_gmm_em {
 
 namespace vcmi {
 static int em_prepare(vcmi_gmm_em *h, hipStream_t st) {
-  VCMI_TRY(gmm_px_prepare_device(&h->px, h->w(), h->mu(), h->sigma(), h->Dj, h->M, h->flag.p, st));
+  if (gmm_px_device_prepare_supported(h->Dj)) {
+    VCMI_TRY(gmm_px_prepare_device(&h->px, h->w(), h->mu(), h->sigma(), h->Dj, h->M, h->flag.p, st));
+  } else {
+    // joint dimensions whose covariance does not fit the LDS of px_prep_kernel (Dj > 98): Cholesky on the host
+    const size_t dd = (size_t)h->Dj * h->Dj;
+    std::vector<double> hw(h->M), hmu((size_t)h->M * h->Dj), hs((size_t)h->M * dd);
+    VCMI_HIP(hipStreamSynchronize(st));
+    VCMI_HIP(hipMemcpy(hw.data(), h->w(), hw.size() * 8, hipMemcpyDeviceToHost));
+    VCMI_HIP(hipMemcpy(hmu.data(), h->mu(), hmu.size() * 8, hipMemcpyDeviceToHost));
+    VCMI_HIP(hipMemcpy(hs.data(), h->sigma(), hs.size() * 8, hipMemcpyDeviceToHost));
+    VCMI_TRY(gmm_px_create(hw.data(), hmu.data(), hs.data(), h->Dj, h->M, &h->px));
+  }
   h->prepared = true;
   return VCMI_OK;
 }
@@ -783,7 +794,6 @@ extern "C" int vcmi_gmm_em_create(int Dj, int M, const double *w, const double *
   if (Dj < 1 || M < 1) return fail(VCMI_ERR_DIM, "vcmi_gmm_em_create: Dj=%d M=%d invalid", Dj, M);
   if (!(min_covar >= 0.0)) return fail(VCMI_ERR_ARG, "vcmi_gmm_em_create: min_covar must be >= 0");
   VCMI_TRY(check_device());
-  if (!gmm_px_device_prepare_supported(Dj)) return fail(VCMI_ERR_ARG, "vcmi_gmm_em_create: joint dimension %d too large", Dj);
   vcmi_gmm_em *h = new (std::nothrow) vcmi_gmm_em();
   if (!h) return fail(VCMI_ERR_OOM, "out of host memory");
   h->Dj = Dj;

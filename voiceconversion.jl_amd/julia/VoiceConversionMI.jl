@@ -17,7 +17,7 @@ module VoiceConversionMI
 export GMMMap, TrajectoryGMMMap, fvconvert, vc, dim, ncomponents,
        DTW, fit!, update!, set_template!, backward, align, push_delta,
        predict_proba, predict, estep_diag, estep_full, GMMEM, estep!, mstep!, params,
-       TrajectoryGVGMMMap, VarianceScaling, fvpostf, fvpostf!, diffgmm
+       TrajectoryGVGMMMap, VarianceScaling, fvpostf, fvpostf!, diffgmm, align_mcep
 
 const libvcmi = get(ENV, "LIBVCMI", "libvcmi")
 
@@ -297,6 +297,19 @@ function diffgmm(μ::Matrix{Float64}, Σ::Array{Float64,3})
     check(ccall((:vcmi_diffgmm, libvcmi), Cint, (Ptr{Float64}, Ptr{Float64}, Cint, Cint, Ptr{Float64}, Ptr{Float64}),
                 μ, Σ, size(μ, 1), size(μ, 2), μd, Σd))
     μd, Σd
+end
+
+# align_mcep(src, tgt, α, fftlen; threshold, remove_silence) -- src/align.jl:38-55 (mc2e included)
+function align_mcep(src::Matrix{Float64}, tgt::Matrix{Float64}, α::AbstractFloat, fftlen::Integer;
+                    threshold::Float64=-14.0, remove_silence::Bool=true)
+    size(src, 1) == size(tgt, 1) ||
+        throw(DimensionMismatch("order of feature vector between source and target must be equal"))
+    D, S = size(src)
+    so = similar(src); to = similar(src); k = Ref{Int64}(0)
+    check(ccall((:vcmi_align_mcep, libvcmi), Cint,
+                (Ptr{Float64}, Int64, Ptr{Float64}, Int64, Cint, Cdouble, Cint, Cdouble, Cint, Ptr{Float64}, Ptr{Float64}, Ref{Int64}),
+                src, S, tgt, size(tgt, 2), D, α, fftlen, threshold, remove_silence, so, to, k))
+    so[:, 1:k[]], to[:, 1:k[]]
 end
 
 # ------------------------------------------------------------------------------------- device-resident EM
