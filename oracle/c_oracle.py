@@ -37,6 +37,7 @@ def lib():
         L.vco_gmmmap_get_A.argtypes = [C.c_void_p, _dp]
         L.vco_fvconvert.argtypes = [C.c_void_p, _dp, _dp, _dp]
         L.vco_fvconvert_batch.argtypes = [C.c_void_p, _dp, C.c_int64, _dp]
+        L.vco_fvconvert_batch_mt.argtypes = [C.c_void_p, _dp, C.c_int64, _dp]
         L.vco_predict_proba.argtypes = [C.c_void_p, _dp, C.c_int64, _dp]
         L.vco_predict.argtypes = [C.c_void_p, _dp, C.c_int64, _ip]
         L.vco_vc_frames.argtypes = [C.c_void_p, _dp, C.c_int64, _dp]
@@ -100,6 +101,13 @@ class GMMMap:
         Y = np.empty_like(X)
         lib().vco_fvconvert_batch(self._h, _d(X), X.shape[0], _d(Y))
         return Y
+
+    def fvconvert_mt(self, X):
+        """all host cores (OpenMP); returns (Y, threads)"""
+        X = _f64(X)
+        Y = np.empty_like(X)
+        n = lib().vco_fvconvert_batch_mt(self._h, _d(X), X.shape[0], _d(Y))
+        return Y, int(n)
 
     def predict_proba(self, X):
         X = _f64(X)

@@ -79,26 +79,25 @@ class GMMMap:
         return np.stack([self.fvconvert1(x) for x in X])
 
 
-def fvconvert_batched_gemm(g, X, chunk=65536):
-    """Same math as GMMMap.fvconvert but restructured as batched GEMMs over frame chunks (numpy -> multithreaded
-    BLAS): the 'strong CPU baseline' of SURVEY 8d(ii).  z = (X - mux_m) inv(L_m)', l_m = c_m - |z|^2/2,
-    softmax over m, y = sum_m p_m (muy_m + (X - mux_m) A_m')."""
-    Uinv = [sla.solve_triangular(L, np.eye(g.D), lower=True) for L in g.chol]
-    cst = np.array([np.log(g.w[m]) - (g.D * LOG2PI + g.logdet[m]) / 2.0 if g.w[m] > 0 else -np.inf for m in range(g.M)])
+def fvconvert_batched_gemm(g, X, chunk=8192):
+    """Same math as GMMMap.fvconvert restructured as ONE dense GEMM per frame chunk (numpy -> multithreaded BLAS): the
+    'strong CPU baseline' of SURVEY 8d(ii).  All mixtures' whitening and regression rows are stacked into
+    W = [U_1; A_1; U_2; A_2; ...] (2DM x D): G = X W' gives z_m = U_m x - U_m mux_m and A_m x for every m at once;
+    l_m = c_m - |z_m|^2/2, softmax over m, y = sum_m p_m (A_m x + b_m)."""
+    D, M = g.D, g.M
+    U = [sla.solve_triangular(L, np.eye(D), lower=True) for L in g.chol]
+    W = np.concatenate([np.concatenate([U[m], g.A[m]], axis=0) for m in range(M)], axis=0)          # (2DM, D)
+    off = np.concatenate([np.concatenate([-U[m] @ g.mux[m], g.muy[m] - g.A[m] @ g.mux[m]]) for m in range(M)])
+    cst = np.array([np.log(g.w[m]) - (D * LOG2PI + g.logdet[m]) / 2.0 if g.w[m] > 0 else -np.inf for m in range(M)])
+    Wt = np.ascontiguousarray(W.T)
     Y = np.empty_like(X)
     for lo in range(0, X.shape[0], chunk):
-        Xc = X[lo:lo + chunk]
-        lpr = np.empty((Xc.shape[0], g.M))
-        for m in range(g.M):
-            Z = (Xc - g.mux[m]) @ Uinv[m].T
-            lpr[:, m] = cst[m] - 0.5 * np.einsum("ij,ij->i", Z, Z)
+        G = (X[lo:lo + chunk] @ Wt + off).reshape(-1, M, 2 * D)
+        lpr = cst - 0.5 * np.einsum("tmd,tmd->tm", G[:, :, :D], G[:, :, :D])
         lpr -= lpr.max(axis=1, keepdims=True)
         P = np.exp(lpr)
         P /= P.sum(axis=1, keepdims=True)
-        acc = np.zeros_like(Xc)
-        for m in range(g.M):
-            acc += P[:, m:m + 1] * (g.muy[m] + (Xc - g.mux[m]) @ g.A[m].T)
-        Y[lo:lo + chunk] = acc
+        Y[lo:lo + chunk] = np.einsum("tm,tmd->td", P, G[:, :, D:])
     return Y
 
 

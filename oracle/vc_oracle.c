@@ -13,6 +13,9 @@
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 #define LOG2PI 1.8378770664093454835606594728112
 
@@ -225,6 +228,24 @@ void vco_fvconvert(const vco_gmmmap *g, const double *x, double *y, double *post
 
 void vco_fvconvert_batch(const vco_gmmmap *g, const double *X, int64_t T, double *Y) {
   for (int64_t t = 0; t < T; ++t) vco_fvconvert(g, X + (size_t)g->D * t, Y + (size_t)g->D * t, NULL);
+}
+
+/* The strong CPU baseline of SURVEY 8d(ii): the same per-frame arithmetic on every host core (OpenMP, frames are
+ * independent); returns the number of threads used.  Built with -fopenmp (oracle/Makefile); without it: 1 thread. */
+int vco_fvconvert_batch_mt(const vco_gmmmap *g, const double *X, int64_t T, double *Y) {
+  int nthreads = 1;
+#ifdef _OPENMP
+#pragma omp parallel
+  {
+#pragma omp single
+    nthreads = omp_get_num_threads();
+#pragma omp for schedule(static)
+    for (int64_t t = 0; t < T; ++t) vco_fvconvert(g, X + (size_t)g->D * t, Y + (size_t)g->D * t, NULL);
+  }
+#else
+  vco_fvconvert_batch(g, X, T, Y);
+#endif
+  return nthreads;
 }
 
 void vco_predict_proba(const vco_gmmmap *g, const double *X, int64_t T, double *P) {

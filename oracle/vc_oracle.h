@@ -40,6 +40,8 @@ void vco_gmmmap_get_A(const vco_gmmmap *g, double *A);
 void vco_fvconvert(const vco_gmmmap *g, const double *x, double *y, double *post);
 /* batch: X (D,T) -> Y (D,T); the loop of src/common.jl:17-19 without the power row */
 void vco_fvconvert_batch(const vco_gmmmap *g, const double *X, int64_t T, double *Y);
+/* same, frames spread over all host cores with OpenMP (strong CPU baseline); returns the thread count */
+int vco_fvconvert_batch_mt(const vco_gmmmap *g, const double *X, int64_t T, double *Y);
 /* predict_proba(gmm, X) -- src/gmm.jl:24-41 ; P is (M,T) */
 void vco_predict_proba(const vco_gmmmap *g, const double *X, int64_t T, double *P);
 /* predict(gmm, X) -- src/gmm.jl:44-58 ; 1-based argmax, first maximum wins */
