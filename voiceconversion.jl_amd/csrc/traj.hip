@@ -21,6 +21,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 struct vcmi_traj {
   vcmi_gmmmap *g = nullptr;
@@ -212,8 +213,8 @@ traj_solve_reg_kernel(const TrajUtt *__restrict__ utts, int n, const double *__r
   extern __shared__ double sm[];
   double *Wd = sm;                       // [W3][LD]  staging window (assembly, shift)
   double *rr = Wd + (size_t)W3 * LD;     // [W3] right-hand side
-  double *colb = rr + W3;                // [2][NK*16+1] masked pivot column (+ the pivot itself), double-buffered
-  double *yring = colb + 2 * (NK * 16 + 1);   // [2][D]
+  double *colb = rr + W3;                // [2][NK*16+2] masked pivot column + the pivot + the rhs entry of its row, double-buffered
+  double *yring = colb + 2 * (NK * 16 + 2);   // [2][D]
   double *wv = yring + 2 * D;            // [D]
   __shared__ int bad;
   const int tid = threadIdx.x;
@@ -230,7 +231,7 @@ traj_solve_reg_kernel(const TrajUtt *__restrict__ utts, int n, const double *__r
     if (tid == 0) bad = 0;
     for (int e = tid; e < W3 * LD; e += 256) Wd[e] = 0.0;
     for (int e = tid; e < W3; e += 256) rr[e] = 0.0;
-    for (int e = tid; e < 2 * (NK * 16 + 1); e += 256) colb[e] = 0.0;
+    for (int e = tid; e < 2 * (NK * 16 + 2); e += 256) colb[e] = 0.0;
     __syncthreads();
     for (int a = 0; a < 3 && a < T; ++a) traj_add_block_row(Wd, rr, LD, D, a, a, T, mh, g, Qall);
     __syncthreads();
@@ -246,45 +247,58 @@ traj_solve_reg_kernel(const TrajUtt *__restrict__ utts, int n, const double *__r
           v[ka][kb] = (i < W3 && j < W3) ? Wd[(size_t)i * LD + j] : 0.0;
         }
       double *pan = ws + (size_t)t * PAN;
-      constexpr int NKC = (D + 15) / 16;             // tiles that can hold a pivot column of this block step
-      for (int c = 0; c < D; ++c) {
-        const int kc = c >> 4, oc = c & 15;
-        double *cb = colb + (c & 1) * (NK * 16 + 1);
-        if (tj == oc) {                               // owners of column c publish it, already masked: rows i <= c
+      double rreg = (tid < W3) ? rr[tid] : 0.0;
+      // the D pivot columns of this block step, in phases of one column tile each: inside a phase the tile index of
+      // the pivot column is a compile-time constant (no per-column select chain over the window registers)
+      auto column_phase = [&](auto kc_tag, int c_lo, int c_hi) {
+        constexpr int KC = decltype(kc_tag)::value;
+        for (int c = c_lo; c < c_hi; ++c) {
+          const int oc = c & 15;
+          double *cb = colb + (c & 1) * (NK * 16 + 2);
+          if (tj == oc) {                               // owners of column c publish it, already masked: rows i <= c
 #pragma unroll                                        // (finished rows / columns of the window) are written as 0 so that
-          for (int ka = 0; ka < NK; ++ka) {           // the readers need no compare/select at all; the pivot goes to cb[NK*16-1]
-            double x = v[ka][0];
-#pragma unroll
-            for (int q = 1; q < NKC; ++q)
-              if (q <= ka) x = (kc == q) ? v[ka][q] : x;
-            const int i = ti + 16 * ka;
-            cb[i] = (i > c) ? x : 0.0;
-            if (i == c) cb[NK * 16] = x;
+            for (int ka = 0; ka < NK; ++ka) {           // the readers need no compare/select at all; the pivot goes to cb[NK*16-1]
+              const double x = v[ka][KC <= ka ? KC : 0];      // column tile KC exists in tile rows ka >= KC only; rows
+                                                               // above the diagonal tile are finished (masked to 0 below)
+              const int i = ti + 16 * ka;
+              cb[i] = (i > c) ? x : 0.0;
+              if (i == c) cb[NK * 16] = x;
+            }
           }
-        }
-        __syncthreads();
-        const double piv = cb[NK * 16];
-        if (!(piv > 0.0) && tid == 0) bad = 1;
-        const double dinv = traj_rsqrt(piv);
-        double lr_[NK], lc_[NK];
+          if (tid == c) cb[NK * 16 + 1] = rreg;          // rhs entry of the pivot row rides along
+          __syncthreads();
+          // every LDS read of this column is issued here, before the rsqrt chain: one round trip per column
+          const double piv = cb[NK * 16], rc = cb[NK * 16 + 1];
+          const double xt = (tid < W3) ? cb[tid] : 0.0;
+          if (!(piv > 0.0) && tid == 0) bad = 1;
+          const double dinv = traj_rsqrt(piv);
+          // rank-1 update v -= (x_i / piv) x_j.  Tile rows / columns below KC are finished (their published entries are
+          // 0), so they are skipped at compile time; only the row factor is scaled (one multiply per tile row)
+          const double winv = dinv * dinv;
+          double lr_[NK], lc_[NK];
 #pragma unroll
-        for (int k = 0; k < NK; ++k) {
-          lr_[k] = cb[ti + 16 * k] * dinv;
-          lc_[k] = cb[tj + 16 * k] * dinv;
-        }
+          for (int k = KC; k < NK; ++k) {
+            lr_[k] = cb[ti + 16 * k] * winv;
+            lc_[k] = cb[tj + 16 * k];
+          }
 #pragma unroll
-        for (int ka = 0; ka < NK; ++ka)
+          for (int ka = KC; ka < NK; ++ka)
 #pragma unroll
-          for (int kb = 0; kb <= ka; ++kb) v[ka][kb] = fma(-lr_[ka], lc_[kb], v[ka][kb]);
-        // finished column of L -> panel (rows c..3D-1; rows above the diagonal of this block column are never read)
-        const double zc = rr[c] * dinv;
-        if (tid < W3) {
-          const double l = (tid == c) ? piv * dinv : cb[tid] * dinv;
-          if (tid >= c) pan[(size_t)tid * D + c] = l;
-          if (tid > c) rr[tid] = fma(-zc, l, rr[tid]);
+            for (int kb = KC; kb <= ka; ++kb) v[ka][kb] = fma(-lr_[ka], lc_[kb], v[ka][kb]);
+          // finished column of L -> panel (rows c..3D-1; rows above the diagonal of this block column are never read)
+          const double zc = rc * dinv;
+          if (tid < W3) {
+            const double l = (tid == c) ? piv * dinv : xt * dinv;
+            if (tid >= c) pan[(size_t)tid * D + c] = l;
+            if (tid > c) rreg = fma(-zc, l, rreg);         // this thread's rhs entry lives in a register for the block step
+          }
+          if (tid == 255) pan[(size_t)W3 * D + c] = zc;
         }
-        if (tid == 255) pan[(size_t)W3 * D + c] = zc;
-      }
+      };
+      column_phase(std::integral_constant<int, 0>{}, 0, D < 16 ? D : 16);
+      if constexpr (D > 16) column_phase(std::integral_constant<int, 1>{}, 16, D < 32 ? D : 32);
+      if constexpr (D > 32) column_phase(std::integral_constant<int, 2>{}, 32, D < 48 ? D : 48);
+      if (tid < W3) rr[tid] = rreg;
       __syncthreads();
       // registers -> window shifted up-left by D; rows 2D..3D-1 are re-assembled (or zeroed at the tail)
 #pragma unroll
@@ -625,7 +639,7 @@ variance_scaling_kernel(const double *__restrict__ src, int D, int T, const doub
 static size_t solve_lds_bytes(int D) {
   const size_t W3 = 3 * (size_t)D;
   const size_t NK = (W3 + 15) / 16;
-  return (W3 * (W3 + 1) + 2 * W3 + 2 * (NK * 16 + 1) + 2 * D + D) * sizeof(double);   // covers both solve kernels
+  return (W3 * (W3 + 1) + 2 * W3 + 2 * (NK * 16 + 2) + 2 * D + D) * sizeof(double);   // covers both solve kernels
 }
 
 static int traj_run(vcmi_traj *t, std::vector<TrajUtt> &utts, int64_t nframes, bool contiguous, const double *dX0,
