@@ -254,8 +254,40 @@ estep_mfma_kernel(const double *__restrict__ X, int64_t N, int M, const double *
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
+// Pinned, double-buffered staging for the (tiny) model parameters of the MFMA path: the copy to the device is a real
+// asynchronous copy, the host buffers outlive the call, and nothing in the call waits for the GPU -- consecutive
+// E-steps queue back to back (the first version packed on the host and drained the stream before every launch:
+// 0.4 ms of a 2.3 ms step).
+struct EstepStaging {
+  double *host[2] = {nullptr, nullptr};
+  hipEvent_t copied[2] = {nullptr, nullptr};
+  size_t cap = 0;
+  int next = 0;
+  int reserve(size_t n) {
+    if (n <= cap) return VCMI_OK;
+    release();
+    for (int i = 0; i < 2; ++i) {
+      VCMI_HIP(hipHostMalloc(reinterpret_cast<void **>(&host[i]), n * sizeof(double), hipHostMallocDefault));
+      VCMI_HIP(hipEventCreateWithFlags(&copied[i], hipEventDisableTiming));
+    }
+    cap = n;
+    return VCMI_OK;
+  }
+  void release() {
+    for (int i = 0; i < 2; ++i) {
+      if (host[i]) (void)hipHostFree(host[i]);
+      if (copied[i]) (void)hipEventDestroy(copied[i]);
+      host[i] = nullptr;
+      copied[i] = nullptr;
+    }
+    cap = 0;
+  }
+  ~EstepStaging() { release(); }
+};
+
 struct EstepScratch {
-  DevBuf<double> mu, iv, cst, G, LSE, part, Wpack, cinit, X, stats;
+  DevBuf<double> mu, iv, cst, G, LSE, part, Wpack, cinit, X, stats, raw;
+  EstepStaging stage;
 };
 static EstepScratch &scratch() {
   static thread_local EstepScratch s;
@@ -264,60 +296,80 @@ static EstepScratch &scratch() {
 
 static int g_estep_force_generic = 0;
 
+// raw = [w (M) | mu (DJ,M) | var (DJ,M)] on the device -> the MFMA kernel's operands:
+//   Wpack[mt][ks][lane]: A-operand fragments of W[m][k], k < DJ -> -1/(2 var) (multiplies x^2), k >= DJ -> mu/var
+//   cinit[m] = log w - (DJ log 2pi + sum log var)/2 - sum mu^2/(2 var)   (-inf for m >= M and for zero weights)
+template <int DJ>
+__global__ void __launch_bounds__(256)
+estep_prep_kernel(const double *__restrict__ raw, int M, double *__restrict__ Wpack, double *__restrict__ cinit) {
+  using C = EstepCfg<DJ>;
+  const double *w = raw, *mu = raw + M, *var = mu + (size_t)DJ * M;
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e < 8 * C::KS * 64) {
+    const int l = e & 63, ks = (e >> 6) % C::KS, mt = (e >> 6) / C::KS;
+    const int m = 16 * mt + (l & 15), k = 4 * ks + (l >> 4);
+    double v = 0.0;
+    if (m < M) {
+      const int d = k < DJ ? k : k - DJ;
+      const double ivv = 1.0 / var[d + (size_t)DJ * m];
+      v = k < DJ ? -0.5 * ivv : mu[d + (size_t)DJ * m] * ivv;
+    }
+    Wpack[e] = v;
+  }
+  if (e < C::MMAX) {
+    double c = -INFINITY;
+    if (e < M) {
+      double sl = 0.0, t = 0.0;
+      for (int d = 0; d < DJ; ++d) {
+        const double vv = var[d + (size_t)DJ * e], mm = mu[d + (size_t)DJ * e];
+        sl += log(vv);
+        t += mm * mm * (1.0 / vv);
+      }
+      c = (w[e] > 0.0 ? log(w[e]) : -INFINITY) - 0.5 * (DJ * kLog2Pi + sl) - 0.5 * t;
+    }
+    cinit[e] = c;
+  }
+}
+
 static int estep_device(const double *dX, int64_t N, int Dj, int M, const double *w, const double *mu, const double *var,
                         double *dstats, hipStream_t st) {
   if (N < 0 || Dj < 1 || M < 1) return fail(VCMI_ERR_DIM, "E-step: N=%lld Dj=%d M=%d invalid", (long long)N, Dj, M);
   if (!w || !mu || !var || !dstats || (N > 0 && !dX)) return fail(VCMI_ERR_ARG, "E-step: NULL argument");
   EstepScratch &sc = scratch();
   const int64_t plen = (int64_t)M * (1 + 2 * Dj) + 1;
-  std::vector<double> hiv((size_t)M * Dj), hc(M);
-  for (int m = 0; m < M; ++m) {
-    double sl = 0.0;
-    for (int d = 0; d < Dj; ++d) {
-      const double v = var[d + (size_t)Dj * m];
-      if (!(v > 0.0)) return fail(VCMI_ERR_NOT_PD, "E-step: variance (%d,%d) is not positive", d + 1, m + 1);
-      sl += std::log(v);
-      hiv[(size_t)m * Dj + d] = 1.0 / v;
-    }
-    hc[m] = (w[m] > 0.0 ? std::log(w[m]) : -INFINITY) - 0.5 * (Dj * kLog2Pi + sl);
-  }
+  for (int m = 0; m < M; ++m)
+    for (int d = 0; d < Dj; ++d)
+      if (!(var[d + (size_t)Dj * m] > 0.0))
+        return fail(VCMI_ERR_NOT_PD, "E-step: variance (%d,%d) is not positive", d + 1, m + 1);
   VCMI_HIP(hipMemsetAsync(dstats, 0, plen * sizeof(double), st));
   if (N == 0) return VCMI_OK;
 
   const bool mfma = (Dj == 80 && M <= EstepCfg<80>::MMAX && !g_estep_force_generic);
   if (mfma) {
     using C = EstepCfg<80>;
-    // A-operand fragments of W[m][k]: k < Dj -> -iv/2 (multiplies x^2), k >= Dj -> mu*iv (multiplies x)
-    std::vector<double> hW((size_t)8 * C::KS * 64, 0.0), hci(C::MMAX, -INFINITY);
-    for (int mt = 0; mt < 8; ++mt)
-      for (int ks = 0; ks < C::KS; ++ks)
-        for (int l = 0; l < 64; ++l) {
-          const int m = 16 * mt + (l & 15), k = 4 * ks + (l >> 4);
-          double v = 0.0;
-          if (m < M) {
-            const int d = k < Dj ? k : k - Dj;
-            const double ivv = hiv[(size_t)m * Dj + d];
-            v = k < Dj ? -0.5 * ivv : mu[d + (size_t)Dj * m] * ivv;
-          }
-          hW[((size_t)mt * C::KS + ks) * 64 + l] = v;
-        }
-    // c_m absorbs the constant term -sum_d mu^2 iv / 2 of the expanded square
-    for (int m = 0; m < M; ++m) {
-      double t = 0.0;
-      for (int d = 0; d < Dj; ++d) t += mu[d + (size_t)Dj * m] * mu[d + (size_t)Dj * m] * hiv[(size_t)m * Dj + d];
-      hci[m] = hc[m] - 0.5 * t;
-    }
     int dev = 0, cus = 256;
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     const int64_t nblocks = (N + C::FB - 1) / C::FB;
     const int grid = (int)std::min<int64_t>(nblocks, cus);
-    VCMI_TRY(sc.Wpack.reserve(hW.size()));
-    VCMI_TRY(sc.cinit.reserve(hci.size()));
+    const size_t nraw = (size_t)M * (1 + 2 * Dj);
+    VCMI_TRY(sc.raw.reserve(2 * nraw));                  // one device copy per staging buffer
+    VCMI_TRY(sc.Wpack.reserve((size_t)8 * C::KS * 64));
+    VCMI_TRY(sc.cinit.reserve((size_t)C::MMAX));
     VCMI_TRY(sc.part.reserve((size_t)grid * plen));
-    VCMI_HIP(hipMemcpyAsync(sc.Wpack.p, hW.data(), hW.size() * 8, hipMemcpyHostToDevice, st));
-    VCMI_HIP(hipMemcpyAsync(sc.cinit.p, hci.data(), hci.size() * 8, hipMemcpyHostToDevice, st));
-    VCMI_HIP(hipStreamSynchronize(st));   // host vectors die at return
+    VCMI_TRY(sc.stage.reserve(nraw));
+    const int b = sc.stage.next;
+    sc.stage.next ^= 1;
+    VCMI_HIP(hipEventSynchronize(sc.stage.copied[b]));   // the copy that last used this buffer (two calls ago) is done
+    double *h = sc.stage.host[b], *draw = sc.raw.p + (size_t)b * nraw;
+    memcpy(h, w, sizeof(double) * M);
+    memcpy(h + M, mu, sizeof(double) * M * Dj);
+    memcpy(h + M + (size_t)M * Dj, var, sizeof(double) * M * Dj);
+    VCMI_HIP(hipMemcpyAsync(draw, h, nraw * sizeof(double), hipMemcpyHostToDevice, st));
+    VCMI_HIP(hipEventRecord(sc.stage.copied[b], st));
+    hipLaunchKernelGGL(estep_prep_kernel<80>, dim3((8 * C::KS * 64 + 255) / 256), dim3(256), 0, st, draw, M, sc.Wpack.p,
+                       sc.cinit.p);
+    VCMI_HIP(hipGetLastError());
     auto kern = estep_mfma_kernel<80>;
     VCMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)C::LDS_BYTES));
@@ -329,6 +381,16 @@ static int estep_device(const double *dX, int64_t N, int Dj, int M, const double
     return VCMI_OK;
   }
 
+  std::vector<double> hiv((size_t)M * Dj), hc(M);
+  for (int m = 0; m < M; ++m) {
+    double sl = 0.0;
+    for (int d = 0; d < Dj; ++d) {
+      const double v = var[d + (size_t)Dj * m];
+      sl += std::log(v);
+      hiv[(size_t)m * Dj + d] = 1.0 / v;
+    }
+    hc[m] = (w[m] > 0.0 ? std::log(w[m]) : -INFINITY) - 0.5 * (Dj * kLog2Pi + sl);
+  }
   // generic path
   std::vector<double> hmu((size_t)M * Dj);
   for (int m = 0; m < M; ++m)
