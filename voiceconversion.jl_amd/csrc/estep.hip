@@ -111,10 +111,13 @@ struct EstepCfg {
   static constexpr int KS = 2 * DJ / 4;          // k-steps of the log-density contraction
   static constexpr int NDT = 2 * DJ / 16;        // 16-wide column tiles of the statistics [x | x^2]
   static constexpr int FB = 64;                  // frames per block
-  static constexpr int RSX = DJ + 1;             // LDS row stride of x (doubles), odd -> conflict-free column reads
+  static constexpr int RSX = DJ + 2;             // LDS row stride of x (doubles): a multiple of 16 bytes (LDS-DMA rows),
+                                                 // 164 dwords = 36 mod 64 -> step A's 16-row column reads hit distinct banks
   static constexpr int MMAX = 128;               // 8 waves x 16 mixtures
   static constexpr int RSG = MMAX + 16;          // LDS row stride of gamma; == 16 mod 32 -> f-groups land 32 banks apart
-  static constexpr size_t LDS_BYTES = ((size_t)FB * RSX + (size_t)FB * RSG + 8 * 64) * sizeof(double);
+  // two x buffers (block k+1 streams in by LDS-DMA while block k is processed) + l/gamma; the log-likelihood scratch of
+  // the epilogue aliases the l/gamma area
+  static constexpr size_t LDS_BYTES = ((size_t)2 * FB * RSX + (size_t)FB * RSG) * sizeof(double);
 };
 
 // Wpack: [mt (8)][ks (KS)][lane (64)] A-operand fragments of W = [-iv/2 | mu*iv] (rows = mixtures), zero rows for m >= M
@@ -126,9 +129,9 @@ estep_mfma_kernel(const double *__restrict__ X, int64_t N, int M, const double *
   using C = EstepCfg<DJ>;
   constexpr int KS = C::KS, NDT = C::NDT, FB = C::FB, RSX = C::RSX, RSG = C::RSG;
   extern __shared__ double smem[];
-  double *xs = smem;                       // [FB][RSX]
-  double *lg = smem + FB * RSX;            // [FB][RSG]   l, then gamma
-  double *red = lg + FB * RSG;             // [8][64] scratch for the log-likelihood reduction
+  double *xbuf = smem;                     // [2][FB][RSX]
+  double *lg = smem + 2 * FB * RSX;        // [FB][RSG]   l, then gamma
+  double *red = lg;                        // [8][64] scratch for the log-likelihood reduction (epilogue only)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lcol = lane & 15, lgrp = lane >> 4;
@@ -149,14 +152,35 @@ estep_mfma_kernel(const double *__restrict__ X, int64_t N, int M, const double *
   double llacc = 0.0;
 
   const int64_t nblocks = (N + FB - 1) / FB;
-  for (int64_t blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
-    const int64_t f0 = blk * FB;
-    // ---- stage x: FB frames x DJ doubles, coalesced, zero beyond N ----
-    for (int e = tid; e < FB * DJ; e += 512) {
-      const int f = e / DJ, d = e % DJ;
-      xs[f * RSX + d] = (f0 + f < N) ? X[(f0 + f) * DJ + d] : 0.0;
+  // ---- x staging by LDS-DMA (global_load_lds_dwordx4: 16 bytes per lane straight into LDS, no VGPRs -- the kernel has
+  //      none to spare): a wave-instruction fills 1 KB of the padded [FB][RSX] image; lanes that fall into a row's
+  //      16-byte pad, and frames beyond N, fetch a valid address (frame N-1 / the block start) and are never used ----
+  constexpr int ROWB = RSX * 8, NCHUNK = (FB * ROWB + 1023) / 1024;
+  static_assert(FB * ROWB % 1024 == 0, "the padded block image is a whole number of 1 KB wave-instructions");
+  auto stage = [&](int64_t f0, double *dst) {
+    const char *base = reinterpret_cast<const char *>(X + f0 * DJ);          // workgroup-uniform 64-bit base,
+    const int last = (int)((N - 1 - f0 < FB - 1) ? N - 1 - f0 : FB - 1);     // 32-bit per-lane offsets
+#pragma unroll
+    for (int i = 0; i < (NCHUNK + 7) / 8; ++i) {
+      const int q = wave + 8 * i;
+      if (q < NCHUNK) {                                          // wave-uniform
+        const int o = 1024 * q + 16 * lane, row = o / ROWB, col = o - row * ROWB;
+        const int rowc = row < last ? row : last;
+        const unsigned off = (col < DJ * 8) ? (unsigned)(rowc * (DJ * 8) + col) : 0u;
+        const char *src = base + off;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                         (__attribute__((address_space(3))) void *)(reinterpret_cast<char *>(dst) + 1024 * q),
+                                         16, 0, 0);
+      }
     }
-    __syncthreads();
+  };
+  if (blockIdx.x < nblocks) stage((int64_t)blockIdx.x * FB, xbuf);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  int cur = 0;
+  for (int64_t blk = blockIdx.x; blk < nblocks; blk += gridDim.x, cur ^= 1) {
+    const int64_t f0 = blk * FB;
+    const double *xs = xbuf + cur * FB * RSX;
     // ---- step A: l[m][f] = c_m + sum_k W[m][k] Xe[k][f],  Xe = [x^2 ; x] ----
 #pragma unroll
     for (int ft = 0; ft < FB / 16; ++ft) {
@@ -179,6 +203,9 @@ estep_mfma_kernel(const double *__restrict__ X, int64_t N, int M, const double *
     // ---- softmax over the 128 mixture slots of each frame.  16 lanes per frame, lane lcol owns slots lcol + 16 i:
     //      per instruction a 32-lane group touches 2 frame rows x 16 consecutive doubles, which with RSG == 16 mod 32
     //      is conflict-free (same pattern as step B's gamma reads) ----
+    // the next block streams in from here on (issued in the phase with the lowest register pressure; it has the
+    // softmax and step B to land)
+    if (blk + gridDim.x < nblocks) stage((blk + gridDim.x) * FB, xbuf + (cur ^ 1) * FB * RSX);
 #pragma unroll
     for (int ps = 0; ps < FB / 32; ++ps) {
       const int f = 32 * ps + 4 * wave + lgrp;
@@ -221,6 +248,7 @@ estep_mfma_kernel(const double *__restrict__ X, int64_t N, int M, const double *
       }
       s0l += gm;
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next block's LDS-DMA has landed
     __syncthreads();
   }
 
