@@ -107,6 +107,10 @@ def test_variance_scaling_and_diffgmm(vc, fixture_model):
     got = vc.fvpostf(vc.VarianceScaling(s2), src.T)
     assert relerr(got, co.variance_scaling(src, s2).T) < 1e-12
     assert np.allclose(got.var(axis=1, ddof=1), s2, rtol=1e-12) and np.allclose(got.mean(axis=1), src.mean(axis=0), atol=1e-12)
+    big = rng.standard_normal((300000, 40)) * rng.uniform(0.1, 3.0, 40) + 5.0     # many workgroup chunks
+    s40 = rng.uniform(0.5, 2.0, 40)
+    gb = vc.fvpostf(vc.VarianceScaling(s40), big.T)
+    assert relerr(gb, npo.variance_scaling(big, s40).T) < 1e-12
     buf = np.asfortranarray(src.T.copy())
     assert vc.fvpostf_(vc.VarianceScaling(s2), buf) is buf and np.array_equal(buf, got)
     # diffgmm: parameters, then the converter built from them against the oracle built from the oracle's transform

@@ -620,15 +620,48 @@ traj_gv_kernel(const TrajUtt *__restrict__ utts, int n, int D, int M, int KS, co
   }
 }
 
-// fvpostf!(vs::VarianceScaling, src), src/gv.jl:10-15: one workgroup per matrix (D,T)
+// fvpostf!(vs::VarianceScaling, src), src/gv.jl:10-15, for a matrix of any length: three streaming passes (sums,
+// centred squares, scale) over frame chunks, every reduction in a fixed order (deterministic).
+//   vs_partial_kernel: part[chunk][d] = sum over the chunk's frames of x (MODE 0) or (x - mean[d])^2 (MODE 1)
+//   vs_final_kernel:   stat[d] = sum_chunk part[chunk][d] / denom
+static constexpr int kVsChunk = 2048;   // frames per workgroup
+template <int MODE>
 __global__ void __launch_bounds__(256)
-variance_scaling_kernel(const double *__restrict__ src, int D, int T, const double *__restrict__ sigma2,
-                        double *__restrict__ out) {
-  extern __shared__ double vsm[];
-  double *red = vsm, *mean = red + 256, *var = mean + D;
-  gv_moments(src, D, T, 256, red, mean, var);
-  for (int e = threadIdx.x; e < D * T; e += 256) {
-    const int d = e % D;
+vs_partial_kernel(const double *__restrict__ src, int D, int64_t T, const double *__restrict__ mean, double *__restrict__ part) {
+  extern __shared__ double vred[];       // [NG][D]
+  const int tid = threadIdx.x, NG = 256 / D, d = tid % D, g = tid / D;
+  const int64_t f0 = (int64_t)blockIdx.x * kVsChunk, f1 = (f0 + kVsChunk < T) ? f0 + kVsChunk : T;
+  double s = 0.0;
+  if (g < NG) {
+    const double m = MODE ? mean[d] : 0.0;
+    for (int64_t t = f0 + g; t < f1; t += NG) {
+      const double e = src[(size_t)t * D + d] - m;
+      s = MODE ? fma(e, e, s) : s + e;
+    }
+    vred[g * D + d] = s;
+  }
+  __syncthreads();
+  if (tid < D) {
+    double a = 0.0;
+    for (int k = 0; k < NG; ++k) a += vred[k * D + tid];
+    part[(size_t)blockIdx.x * D + tid] = a;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+vs_final_kernel(const double *__restrict__ part, int nchunks, int D, double denom, double *__restrict__ stat) {
+  const int d = threadIdx.x;
+  if (d >= D) return;
+  double a = 0.0;
+  for (int c = 0; c < nchunks; ++c) a += part[(size_t)c * D + d];
+  stat[d] = a / denom;
+}
+
+__global__ void __launch_bounds__(256)
+vs_scale_kernel(const double *__restrict__ src, int D, int64_t n, const double *__restrict__ sigma2,
+                const double *__restrict__ mean, const double *__restrict__ var, double *__restrict__ out) {
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
+    const int d = (int)(e % D);
     out[e] = sqrt(sigma2[d] / var[d]) * (src[e] - mean[d]) + mean[d];
   }
 }
@@ -995,17 +1028,25 @@ extern "C" int vcmi_trajgv_convert_batch_dev(vcmi_trajgv *h, int64_t n, const do
 // fvpostf(vs::VarianceScaling, src) -- src/gv.jl:10-21.  src, out (D,T) host matrices (may alias), sigma2 (D).
 extern "C" int vcmi_variance_scaling(const double *src, int D, int64_t T, const double *sigma2, double *out) {
   if (!src || !sigma2 || !out) return fail(VCMI_ERR_ARG, "vcmi_variance_scaling: NULL argument");
-  if (D < 1 || D > 256 || T < 2 || T > INT32_MAX / D)
+  if (D < 1 || D > 256 || T < 2)
     return fail(VCMI_ERR_DIM, "vcmi_variance_scaling: D=%d T=%lld unsupported (needs 1 <= D <= 256, T >= 2)", D, (long long)T);
   VCMI_TRY(check_device());
-  DevBuf<double> dsrc, dout, dsig;
+  DevBuf<double> dsrc, dout, dsig, dpart, dstat;
+  const int nchunks = (int)((T + kVsChunk - 1) / kVsChunk);
   VCMI_TRY(dsrc.alloc((size_t)D * T));
   VCMI_TRY(dout.alloc((size_t)D * T));
   VCMI_TRY(dsig.alloc(D));
+  VCMI_TRY(dpart.alloc((size_t)nchunks * D));
+  VCMI_TRY(dstat.alloc((size_t)2 * D));
   VCMI_HIP(hipMemcpy(dsrc.p, src, sizeof(double) * D * T, hipMemcpyHostToDevice));
   VCMI_HIP(hipMemcpy(dsig.p, sigma2, sizeof(double) * D, hipMemcpyHostToDevice));
-  hipLaunchKernelGGL(variance_scaling_kernel, dim3(1), dim3(256), (256 + 2 * (size_t)D) * sizeof(double), nullptr, dsrc.p, D,
-                     (int)T, dsig.p, dout.p);
+  const size_t shm = (size_t)(256 / D) * D * sizeof(double);
+  double *mean = dstat.p, *var = dstat.p + D;
+  hipLaunchKernelGGL(vs_partial_kernel<0>, dim3(nchunks), dim3(256), shm, nullptr, dsrc.p, D, T, mean, dpart.p);
+  hipLaunchKernelGGL(vs_final_kernel, dim3(1), dim3(256), 0, nullptr, dpart.p, nchunks, D, (double)T, mean);
+  hipLaunchKernelGGL(vs_partial_kernel<1>, dim3(nchunks), dim3(256), shm, nullptr, dsrc.p, D, T, mean, dpart.p);
+  hipLaunchKernelGGL(vs_final_kernel, dim3(1), dim3(256), 0, nullptr, dpart.p, nchunks, D, (double)(T - 1), var);   // Julia's var
+  hipLaunchKernelGGL(vs_scale_kernel, dim3(2048), dim3(256), 0, nullptr, dsrc.p, D, (int64_t)D * T, dsig.p, mean, var, dout.p);
   VCMI_HIP(hipGetLastError());
   VCMI_HIP(hipMemcpy(out, dout.p, sizeof(double) * D * T, hipMemcpyDeviceToHost));
   return VCMI_OK;
