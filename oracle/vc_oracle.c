@@ -199,13 +199,11 @@ static void posterior(const vco_gmmmap *g, const double *x, double *p, double *z
   for (int m = 0; m < g->M; ++m) p[m] = exp(p[m] - lse);   /* src/gmm.jl:29 */
 }
 
-void vco_fvconvert(const vco_gmmmap *g, const double *x, double *y, double *post) {
+/* one frame with caller-provided scratch: E (D*M), p (M), z (D), dx (D) */
+static void fvconvert_core(const vco_gmmmap *g, const double *x, double *y, double *post, double *E, double *p, double *z,
+                           double *dx) {
   int D = g->D, M = g->M;
   size_t dd = (size_t)D * D;
-  double *E = (double *)malloc(sizeof(double) * D * M);
-  double *p = (double *)malloc(sizeof(double) * M);
-  double *z = (double *)malloc(sizeof(double) * D);
-  double *dx = (double *)malloc(sizeof(double) * D);
   /* Eq.(11): E[:,m] = muy[:,m] + A[:,:,m] * (x - mux[:,m])  -- src/gmmmap.jl:109-111 */
   for (int m = 0; m < M; ++m) {
     const double *A = g->A + dd * m;
@@ -223,6 +221,16 @@ void vco_fvconvert(const vco_gmmmap *g, const double *x, double *y, double *post
     y[i] = s;
   }
   if (post) memcpy(post, p, sizeof(double) * M);
+}
+
+/* the reference allocates its temporaries per frame (src/gmmmap.jl:105-117); so does this entry */
+void vco_fvconvert(const vco_gmmmap *g, const double *x, double *y, double *post) {
+  int D = g->D, M = g->M;
+  double *E = (double *)malloc(sizeof(double) * D * M);
+  double *p = (double *)malloc(sizeof(double) * M);
+  double *z = (double *)malloc(sizeof(double) * D);
+  double *dx = (double *)malloc(sizeof(double) * D);
+  fvconvert_core(g, x, y, post, E, p, z, dx);
   free(E); free(p); free(z); free(dx);
 }
 
@@ -237,10 +245,14 @@ int vco_fvconvert_batch_mt(const vco_gmmmap *g, const double *X, int64_t T, doub
 #ifdef _OPENMP
 #pragma omp parallel
   {
+    int D = g->D, M = g->M;                        /* per-thread scratch, allocated once */
+    double *E = (double *)malloc(sizeof(double) * D * M), *p = (double *)malloc(sizeof(double) * M);
+    double *z = (double *)malloc(sizeof(double) * D), *dx = (double *)malloc(sizeof(double) * D);
 #pragma omp single
     nthreads = omp_get_num_threads();
 #pragma omp for schedule(static)
-    for (int64_t t = 0; t < T; ++t) vco_fvconvert(g, X + (size_t)g->D * t, Y + (size_t)g->D * t, NULL);
+    for (int64_t t = 0; t < T; ++t) fvconvert_core(g, X + (size_t)D * t, Y + (size_t)D * t, NULL, E, p, z, dx);
+    free(E); free(p); free(z); free(dx);
   }
 #else
   vco_fvconvert_batch(g, X, T, Y);
