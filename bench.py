@@ -45,6 +45,19 @@ def estep_flops_per_frame(Dj, M):
     return 8 * Dj * M + 25 * M
 
 
+def pmc_traffic(fname, kernel_prefix):
+    """HBM bytes per bench step of a kernel from a committed PMC pass (profiles/r01c_pmc/*.json, tools/pmc_traffic.sh);
+    the counters cannot be collected inside the timed run.  Raw FETCH_SIZE + WRITE_SIZE: see profiles/r01c_pmc/README.txt."""
+    try:
+        tr = json.load(open(os.path.join(ROOT, "profiles", "r01c_pmc", fname)))
+        for k, v in tr.items():
+            if kernel_prefix in k:
+                return v.get("hbm_bytes_per_step_raw", v["hbm_bytes_per_launch_raw"])
+    except (OSError, KeyError, ValueError):
+        pass
+    return None
+
+
 def dist_setup(n_gpus):
     import torch
     import torch.distributed as dist
@@ -230,7 +243,8 @@ def bench_estep(args, world, rank):
            "config": {"workload": "diag E-step (BASELINE configs[2])", "Dj": Dj, "M": M, "frames_per_gpu": N,
                       "collective": "all-reduce(sum) of %d doubles per step" % vc.stats_len(Dj, M)},
            "roofline": {"bound": "mfma", "kernel": "estep_mfma_kernel<80> (+ all-reduce)", "achieved": achieved,
-                        "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS, "traffic": None,
+                        "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS,
+                        "traffic": pmc_traffic("estep_traffic.json", "estep_mfma_kernel") if N == 1_250_000 else None,
                         "flop_per_frame": estep_flops_per_frame(Dj, M), "kernel_ms": kernel_ms}}
     if rank == 0:
         from oracle import c_oracle as co
@@ -327,7 +341,12 @@ def bench_em_full(args, world, rank):
                       "frames_per_gpu": N, "collective": "all-reduce(sum) of %d doubles per iteration" % vc.full_stats_len(Dj, M)},
            "roofline": {"bound": "mfma", "kernel": "whole iteration: log-densities + second moments + M-step + whitening",
                         "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": achieved / FP64_PEAK_TFLOPS, "traffic": None, "flop_per_frame": flop, "kernel_ms": kernel_ms},
+                        "frac": achieved / FP64_PEAK_TFLOPS,
+                        "traffic": ((pmc_traffic("em_full_traffic.json", "gmmmap_mfma_kernel") or 0) +
+                                    (pmc_traffic("em_full_traffic.json", "estep_full_stats_kernel") or 0) +
+                                    (pmc_traffic("em_full_traffic.json", "estep_full_softmax_kernel") or 0)) or None
+                        if N == 500_000 else None,
+                        "flop_per_frame": flop, "kernel_ms": kernel_ms},
            "loglik_monotone": bool(all(b >= a - 1e-6 * abs(a) for a, b in zip(hist, hist[1:])))}
     return out
 
@@ -383,7 +402,9 @@ def bench_dtw(args, world, rank):
                       "fstep": 0, "bstep": 2},
            "roofline": {"bound": "mfma", "kernel": "dtw_obs_asm_kernel<40> (+ dtw_rec_kernel<2,0> overlapped)",
                         "achieved": achieved, "peak": FP64_PEAK_TFLOPS / 2, "unit": "TFLOP/s",
-                        "frac": achieved / (FP64_PEAK_TFLOPS / 2), "traffic": None,
+                        "frac": achieved / (FP64_PEAK_TFLOPS / 2),
+                        "traffic": ((pmc_traffic("dtw_traffic.json", "dtw_obs_asm_kernel") or 0) +
+                                    (pmc_traffic("dtw_traffic.json", "dtw_rec_kernel") or 0)) or None if n == 1000 else None,
                         "note": "the bit-exact contract forbids fused multiply-add, so the roof is the FP64 vector pipe at ONE "
                                 "flop per lane-instruction = half the FMA/MFMA figure; `achieved` prices the whole step "
                                 "(observation + recurrence kernels) at 3*D+10 flop per cell",

@@ -12,6 +12,7 @@ done
 python3 - "$R/gpurun_out/pmc_traffic/$w" <<'PY'
 import csv, sys, glob, collections, json
 root = sys.argv[1]
+NSTEPS = 3
 res = collections.defaultdict(dict)
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     f = glob.glob(f"{root}/{c}/*/*counter_collection.csv")[0]
@@ -22,8 +23,11 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
             acc[k] += float(r["Counter_Value"]); n[k] += 1
     for k in acc:
         res[k][c + "_KB_per_launch"] = acc[k] / n[k]
+        res[k][c + "_KB_per_step"] = acc[k] / NSTEPS        # the bench ran NSTEPS steps (2 timed + 1 warm-up)
+        res[k]["launches_per_step"] = n[k] / NSTEPS
 for k, d in res.items():
     d["hbm_bytes_per_launch_raw"] = (d.get("FETCH_SIZE_KB_per_launch", 0) + d.get("WRITE_SIZE_KB_per_launch", 0)) * 1024
+    d["hbm_bytes_per_step_raw"] = (d.get("FETCH_SIZE_KB_per_step", 0) + d.get("WRITE_SIZE_KB_per_step", 0)) * 1024
 print(json.dumps(res, indent=1))
 json.dump(res, open(f"{root}/traffic.json", "w"), indent=1)
 PY
