@@ -30,7 +30,8 @@ struct vcmi_traj {
   int M = 0;
   int64_t length = 0;  // length(t), src/trajectory_gmmmap.jl:34
   vcmi::DevBuf<double> AT, QT, bvec, Q;   // [M][k][r] transposed A and Q (coalesced gemv), b [M][2D], Q row-major [M][2D][2D]
-  vcmi::DevBuf<double> Qfrag;             // Q in v_mfma_f64_16x16x4 A-operand order [M][row tile][k-step][lane] (GV ascent)
+  vcmi::DevBuf<double> Qfrag, Afrag;      // Q and A in v_mfma_f64_16x16x4 A-operand order [M][row tile][k-step][lane]
+  vcmi::DevBuf<int> gperm;                // frames of every utterance grouped by mixture (traj_g_mfma_kernel)
   int NT = 0, KS = 0;                     // row tiles / k-steps of Qfrag
   vcmi::DevBuf<double> gbuf, ws, xbuf, ybuf;
   vcmi::DevBuf<int64_t> mhat;
@@ -439,6 +440,111 @@ traj_solve_kernel(const TrajUtt *__restrict__ utts, int n, int D, const double *
   }
 }
 
+#include "traj_solve_blk.hpp"
+
+// ------------------------------------------------------------------------------------------------
+// g_t = Q_mhat (A_mhat x_t + b_mhat) on v_mfma_f64_16x16x4 (replaces one workgroup per frame streaming both 2D x 2D
+// matrices from L2: 52 GB of L2 traffic per 512k frames).  One workgroup per utterance: frames grouped by mixture
+// (counting sort, segments padded to 16), so a tile of 16 frames has ONE mixture; wave i owns row tile i of both
+// products.  The two products chain without a layout change: register r of wave i's E accumulator (row 16i+4r+lane/16,
+// frame lane%16) IS the B operand of k-step 4i+r of the second product for the same lane -- it only has to be shared
+// with the other waves, through LDS.
+// ------------------------------------------------------------------------------------------------
+static constexpr int kGMaxKS = 24;   // k-steps of the widest supported feature vector (2D <= 96)
+typedef double g_d4 __attribute__((ext_vector_type(4)));
+
+__global__ void __launch_bounds__(384)
+traj_g_mfma_kernel(const TrajUtt *__restrict__ utts, int n, int D2, int M, int KS, const double *__restrict__ Afrag,
+                   const double *__restrict__ Qfrag, const double *__restrict__ bvec, const int64_t *__restrict__ mhat_all,
+                   int *__restrict__ perm_all, double *__restrict__ G_all) {
+  extern __shared__ double gsm2[];
+  const int nthr = blockDim.x, NT = nthr >> 6;
+  double *Xt = gsm2;                              // [4*KS][16] x of the tile's frames, k-major
+  double *Ef = Xt + (size_t)4 * KS * 16;          // [4*NT][64] E accumulators in B-operand order (k-step major)
+  int *cnt = reinterpret_cast<int *>(Ef + (size_t)4 * NT * 64);   // [M]
+  int *start = cnt + M;                           // [M]
+  __shared__ int tidx[16];
+  __shared__ int ntiles_s;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lcol = lane & 15, lgrp = lane >> 4;
+  for (int u = blockIdx.x; u < n; u += gridDim.x) {
+    const TrajUtt U = utts[u];
+    const int T = U.T;
+    if (T == 0) continue;
+    const int64_t *mh = mhat_all + U.frame0;
+    double *G = G_all + U.frame0 * D2;
+    int *perm = perm_all + U.frame0 + (int64_t)16 * M * u;
+    // frames grouped by mixture; the order inside a group (atomics) is irrelevant, each frame is computed on its own
+    for (int m = tid; m < M; m += nthr) cnt[m] = 0;
+    __syncthreads();
+    for (int t = tid; t < T; t += nthr) atomicAdd(&cnt[(int)mh[t] - 1], 1);
+    __syncthreads();
+    if (tid == 0) {
+      int pos = 0;
+      for (int m = 0; m < M; ++m) {
+        start[m] = pos;
+        pos += (cnt[m] + 15) / 16 * 16;
+        cnt[m] = 0;
+      }
+      ntiles_s = pos / 16;
+    }
+    __syncthreads();
+    const int ntiles = ntiles_s;
+    for (int e = tid; e < ntiles * 16; e += nthr) perm[e] = -1;
+    __syncthreads();
+    for (int t = tid; t < T; t += nthr) {
+      const int m = (int)mh[t] - 1;
+      perm[start[m] + atomicAdd(&cnt[m], 1)] = t;
+    }
+    __syncthreads();
+    double afr[kGMaxKS], qfr[kGMaxKS];
+    int mcur = -1;
+    for (int tile = 0; tile < ntiles; ++tile) {
+      if (tid < 16) tidx[tid] = perm[tile * 16 + tid];
+      __syncthreads();
+      for (int e = tid; e < 4 * KS * 16; e += nthr) {
+        const int k = e >> 4, t = tidx[e & 15];
+        Xt[e] = (t >= 0 && k < D2) ? U.X[(size_t)t * D2 + k] : 0.0;
+      }
+      const int m = (int)mh[tidx[0]] - 1;               // slot 0 of a tile is never padding
+      if (m != mcur) {
+        mcur = m;
+        const double *A = Afrag + (((size_t)m * NT + wave) * KS) * 64 + lane;
+        const double *Q = Qfrag + (((size_t)m * NT + wave) * KS) * 64 + lane;
+#pragma unroll
+        for (int ks = 0; ks < kGMaxKS; ++ks) {
+          afr[ks] = (ks < KS) ? A[(size_t)ks * 64] : 0.0;
+          qfr[ks] = (ks < KS) ? Q[(size_t)ks * 64] : 0.0;
+        }
+      }
+      g_d4 acc;                                         // E = A x + b, src/trajectory_gmmmap.jl:88
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * wave + lgrp + 4 * r;
+        acc[r] = (row < D2) ? bvec[(size_t)m * D2 + row] : 0.0;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int ks = 0; ks < kGMaxKS; ++ks)
+        if (ks < KS) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(afr[ks], Xt[(4 * ks + lgrp) * 16 + lcol], acc, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Ef[(size_t)(4 * wave + r) * 64 + lane] = acc[r];
+      __syncthreads();
+      g_d4 gac = {0.0, 0.0, 0.0, 0.0};                  // g = Q E
+#pragma unroll
+      for (int ks = 0; ks < kGMaxKS; ++ks)
+        if (ks < KS) gac = __builtin_amdgcn_mfma_f64_16x16x4f64(qfr[ks], Ef[(size_t)ks * 64 + lane], gac, 0, 0, 0);
+      const int t = tidx[lcol];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * wave + lgrp + 4 * r;
+        if (row < D2 && t >= 0) G[(size_t)t * D2 + row] = gac[r];
+      }
+      __syncthreads();
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Global-variance ascent, fvconvert(tgv::TrajectoryGVGMMMap, X), src/trajectory_gmmmap.jl:139-189.
 // One workgroup per utterance runs all epochs:  y <- y + alpha * ( omega (r - P y) + gvgrad(y) ),  omega = 1/(2T),
@@ -715,7 +821,26 @@ static int traj_run(vcmi_traj *t, std::vector<TrajUtt> &utts, int64_t nframes, b
   const size_t shmem = solve_lds_bytes(D);
   const TrajUtt *du = reinterpret_cast<const TrajUtt *>(t->uttbuf.p);
   bool launched = false;
-  if (!getenv("VCMI_TRAJ_GENERIC")) {
+  const char *solver = getenv("VCMI_TRAJ_SOLVER");     // "reg": the scalar-column register-window kernel (A/B runs)
+  if (!getenv("VCMI_TRAJ_GENERIC") && !(solver && !strcmp(solver, "reg"))) {
+    switch (D) {
+#define VCMI_TRAJ_BLK_CASE(DV)                                                                                      \
+  case DV: {                                                                                                        \
+    auto kern = traj_solve_blk_kernel<DV>;                                                                          \
+    const size_t shb = BlkCfg<DV>::lds_doubles * sizeof(double);                                                    \
+    VCMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,  \
+                                 (int)shb));                                                                        \
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), shb, st, du, n, t->Q.p, t->mhat.p, t->gbuf.p, t->ws.p, ws_stride, \
+                       t->status.p);                                                                                \
+    launched = true;                                                                                                \
+  } break;
+      VCMI_TRAJ_BLK_CASE(12) VCMI_TRAJ_BLK_CASE(16) VCMI_TRAJ_BLK_CASE(20) VCMI_TRAJ_BLK_CASE(24) VCMI_TRAJ_BLK_CASE(25)
+      VCMI_TRAJ_BLK_CASE(30) VCMI_TRAJ_BLK_CASE(32) VCMI_TRAJ_BLK_CASE(40)
+#undef VCMI_TRAJ_BLK_CASE
+      default: break;
+    }
+  }
+  if (!launched && !getenv("VCMI_TRAJ_GENERIC")) {
     switch (D) {
 #define VCMI_TRAJ_CASE(DV)                                                                                          \
   case DV: {                                                                                                        \
@@ -753,6 +878,16 @@ static int traj_run(vcmi_traj *t, std::vector<TrajUtt> &utts, int64_t nframes, b
 }
 
 static int traj_check_status(vcmi_traj *t, hipStream_t st) {
+#ifdef TRAJ_BLK_PROF
+  {
+    long long h[8], z[8] = {0};
+    (void)hipStreamSynchronize(st);
+    (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(blk_prof), sizeof(h));
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(blk_prof), z, sizeof(z));
+    fprintf(stderr, "blk_prof cycles: pivot %lld trsm %lld update %lld panel %lld assemble %lld backsub %lld\n", h[0], h[1], h[2],
+            h[3], h[4], h[5]);
+  }
+#endif
   int h = 0;
   VCMI_HIP(hipMemcpyAsync(&h, t->status.p, sizeof(int), hipMemcpyDeviceToHost, st));
   VCMI_HIP(hipStreamSynchronize(st));
@@ -840,17 +975,20 @@ extern "C" int vcmi_traj_create(vcmi_gmmmap *g, int64_t T, vcmi_traj **out) {
   // Q in MFMA A-operand order for the GV ascent: lane l of fragment (row tile i, k-step ks) holds Q[16i + (l&15)][4ks + (l>>4)]
   t->NT = (D2 + 15) / 16;
   t->KS = (D2 + 3) / 4;
-  std::vector<double> Qf((size_t)M * t->NT * t->KS * 64, 0.0);
+  std::vector<double> Qf((size_t)M * t->NT * t->KS * 64, 0.0), Af(Qf.size(), 0.0);
   for (int m = 0; m < M; ++m)
     for (int i = 0; i < t->NT; ++i)
       for (int ks = 0; ks < t->KS; ++ks)
         for (int l = 0; l < 64; ++l) {
           const int r = 16 * i + (l & 15), k = 4 * ks + (l >> 4);
-          if (r < D2 && k < D2) Qf[(((size_t)m * t->NT + i) * t->KS + ks) * 64 + l] = Q[nn * m + (size_t)r * D2 + k];
+          if (r < D2 && k < D2) {
+            Qf[(((size_t)m * t->NT + i) * t->KS + ks) * 64 + l] = Q[nn * m + (size_t)r * D2 + k];
+            Af[(((size_t)m * t->NT + i) * t->KS + ks) * 64 + l] = g->h_A[nn * m + (size_t)r * D2 + k];
+          }
         }
   int rc = VCMI_OK;
   if ((rc = t->Q.alloc(Q.size())) || (rc = t->QT.alloc(QT.size())) || (rc = t->AT.alloc(AT.size())) ||
-      (rc = t->bvec.alloc(bv.size())) || (rc = t->Qfrag.alloc(Qf.size()))) {
+      (rc = t->bvec.alloc(bv.size())) || (rc = t->Qfrag.alloc(Qf.size())) || (rc = t->Afrag.alloc(Af.size()))) {
     delete t;
     return rc;
   }
@@ -859,6 +997,7 @@ extern "C" int vcmi_traj_create(vcmi_gmmmap *g, int64_t T, vcmi_traj **out) {
   if (e == hipSuccess) e = hipMemcpy(t->AT.p, AT.data(), AT.size() * 8, hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(t->bvec.p, bv.data(), bv.size() * 8, hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(t->Qfrag.p, Qf.data(), Qf.size() * 8, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(t->Afrag.p, Af.data(), Af.size() * 8, hipMemcpyHostToDevice);
   if (e != hipSuccess) {
     delete t;
     return fail(VCMI_ERR_HIP, "TrajectoryGMMMap: upload failed: %s", hipGetErrorString(e));
