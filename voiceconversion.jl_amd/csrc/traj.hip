@@ -884,8 +884,8 @@ static int traj_check_status(vcmi_traj *t, hipStream_t st) {
     (void)hipStreamSynchronize(st);
     (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(blk_prof), sizeof(h));
     (void)hipMemcpyToSymbol(HIP_SYMBOL(blk_prof), z, sizeof(z));
-    fprintf(stderr, "blk_prof cycles: pivot %lld trsm %lld update %lld panel %lld assemble %lld backsub %lld\n", h[0], h[1], h[2],
-            h[3], h[4], h[5]);
+    fprintf(stderr, "blk_prof cycles: phase1 %lld trsm %lld update %lld backsub %lld | pivot done at %lld, deferred: L20 at %lld, S21/S22 at %lld, panel+assembly at %lld\n",
+            h[0], h[1], h[2], h[5], h[3], h[4], h[6], h[7]);
   }
 #endif
   int h = 0;

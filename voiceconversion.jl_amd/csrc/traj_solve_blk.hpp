@@ -27,9 +27,10 @@ struct BlkCfg {
   static constexpr int LS = DP + 2;                     // row stride in doubles: LS/2 odd -> MFMA operand reads conflict-free
   static constexpr int BUF = DP * LS;                   // doubles per block buffer
   static constexpr int NB8 = (D + 7) / 8;               // 8 x 8 lane-grid tiles per dimension (pivot phase)
-  static constexpr int CB = 2 * 8 * NB8 + 2;            // published pivot column: S part, U part, pivot
+  static constexpr int CB = 128;                        // published pivot column: S part [64], U part [64], permuted
+  static constexpr int JOINCOL = D < 6 ? D - 1 : 5;     // pivot column after which the pivot wave joins the mid-phase barrier
   static constexpr size_t PAN = (size_t)(3 * D + 1) * D;   // panel doubles per block step: U (D,D), L10 (D+1,D) incl. z0, L20 (D,D)
-  static constexpr size_t lds_doubles = (size_t)6 * BUF + CB + 2 * D + 2 * 256;
+  static constexpr size_t lds_doubles = (size_t)6 * BUF + CB + 2 * D + 2 * 256 + 2;
 };
 
 typedef double blk_d4 __attribute__((ext_vector_type(4)));
@@ -43,9 +44,15 @@ __device__ long long blk_prof[8];   // cycles of workgroup 0 per phase: pivot, t
     if (blockIdx.x == 0 && threadIdx.x == 0) blk_prof[k] += n_ - pt_;   \
     pt_ = n_;                                                           \
   } while (0)
+// time since the last BLK_PROF mark, seen by thread `thr` (does not move the mark)
+#define BLK_PROF_AT(k, thr)                                                                                         \
+  do {                                                                                                              \
+    if (blockIdx.x == 0 && threadIdx.x == (thr)) blk_prof[k] += (long long)__builtin_readcyclecounter() - pt_;      \
+  } while (0)
 #else
 #define BLK_PROF_T0()
 #define BLK_PROF(k)
+#define BLK_PROF_AT(k, thr)
 #endif
 
 // blocks (a,a-2), (a,a-1), (a,a) of P and r_a (row D of the diagonal block) into three block buffers; every entry of the
@@ -87,10 +94,14 @@ __device__ void blk_assemble(double *Bm2, double *Bm1, double *Bd, int a, int T,
 // Pivot phase, one wave.  B00 rows/cols < D hold S00 (lower triangle valid); on return they hold U = chol(S00)^-1
 // (lower triangular, zeros above).  Lane (ti,tj) of the 8 x 8 grid owns elements i = ti + 8 ka, j = tj + 8 kb.
 // s: S00 tiles kb <= ka; u: tiles of U' (= the identity rows of the augmented matrix), kb >= ka.
+// Per column the owners publish it to LDS in a permuted order (row i at (i%8)*8 + i/8), so the five values a lane
+// needs are contiguous (16-byte LDS accesses); the pivot itself travels by v_readlane, so its rsqrt chain runs while the
+// column is on its way through LDS.  The wave joins one workgroup barrier on the way (after column JOINCOL): the other
+// three waves use it to order their deferred work of the previous block step.
 template <int D>
 __device__ void blk_pivot(double *B00, double *cb, int lane, int *bad) {
   using C = BlkCfg<D>;
-  constexpr int NB = C::NB8, LS = C::LS, DP = C::DP, UO = 8 * NB, PIV = 16 * NB;
+  constexpr int NB = C::NB8, LS = C::LS, DP = C::DP, UO = 64, NQ = (NB + 1) / 2;
   const int ti = lane >> 3, tj = lane & 7;
   double s[NB][NB], u[NB][NB];
 #pragma unroll
@@ -101,36 +112,56 @@ __device__ void blk_pivot(double *B00, double *cb, int lane, int *bad) {
       s[ka][kb] = (kb <= ka && i < D && j < D) ? B00[i * LS + j] : 0.0;
       u[ka][kb] = (ka == kb && ti == tj && i < D) ? 1.0 : 0.0;
     }
+  typedef double pv_d2 __attribute__((ext_vector_type(2)));
+  pv_d2 *cbs_w = reinterpret_cast<pv_d2 *>(cb + ti * 8), *cbu_w = reinterpret_cast<pv_d2 *>(cb + UO + ti * 8);
+  const pv_d2 *cbs_c = reinterpret_cast<const pv_d2 *>(cb + tj * 8);
+  const double *cbu_row = cb + UO + (lane & 7) * 8 + (lane >> 3);
   auto phase = [&](auto kc_tag, int c_lo, int c_hi) {
     constexpr int KC = decltype(kc_tag)::value;
+    constexpr int Q0 = KC / 2;
+#pragma nounroll     // 40 unrolled columns are 27 KB of straight-line code per block step: instruction-cache misses
     for (int c = c_lo; c < c_hi; ++c) {
       const int oc = c & 7;
+      const double pvl = s[KC][KC];
+      const double piv = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(pvl), 9 * oc),
+                                          __builtin_amdgcn_readlane(__double2loint(pvl), 9 * oc));
       if (tj == oc) {       // owners publish column c: S rows i > c (finished rows as 0), U' rows i <= c
 #pragma unroll
-        for (int ka = KC; ka < NB; ++ka) {
-          const int i = ti + 8 * ka;
-          cb[i] = (i > c) ? s[ka][KC] : 0.0;
+        for (int q = Q0; q < NQ; ++q) {
+          const int k0 = 2 * q, k1 = 2 * q + 1;
+          pv_d2 v;
+          v.x = (k0 >= KC && ti + 8 * k0 > c) ? s[k0][KC] : 0.0;
+          v.y = (k1 < NB && ti + 8 * k1 > c) ? s[k1 < NB ? k1 : 0][KC] : 0.0;
+          cbs_w[q] = v;
         }
-        if (ti == oc) cb[PIV] = s[KC][KC];
 #pragma unroll
-        for (int ka = 0; ka <= KC; ++ka) {
-          const int i = ti + 8 * ka;
-          cb[UO + i] = (i <= c) ? u[ka][KC] : 0.0;
+        for (int q = 0; q <= Q0; ++q) {
+          const int k0 = 2 * q, k1 = 2 * q + 1;
+          pv_d2 v;
+          v.x = (ti + 8 * k0 <= c) ? u[k0][KC] : 0.0;
+          v.y = (k1 <= KC && ti + 8 * k1 <= c) ? u[k1 <= KC ? k1 : 0][KC] : 0.0;
+          cbu_w[q] = v;
         }
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      const double piv = cb[PIV];
-      double lr_[NB], lc_[NB], ur_[NB];
+      double lr_[2 * NQ], lc_[2 * NQ], ur_[2 * NQ];
 #pragma unroll
-      for (int k = KC; k < NB; ++k) {
-        lr_[k] = cb[ti + 8 * k];
-        lc_[k] = cb[tj + 8 * k];
+      for (int q = Q0; q < NQ; ++q) {
+        const pv_d2 a = cbs_w[q], b = cbs_c[q];
+        lr_[2 * q] = a.x;
+        lr_[2 * q + 1] = a.y;
+        lc_[2 * q] = b.x;
+        lc_[2 * q + 1] = b.y;
       }
 #pragma unroll
-      for (int k = 0; k <= KC; ++k) ur_[k] = cb[UO + ti + 8 * k];
-      const double urow = (lane <= c) ? cb[UO + lane] : 0.0;
+      for (int q = 0; q <= Q0; ++q) {
+        const pv_d2 a = cbu_w[q];
+        ur_[2 * q] = a.x;
+        ur_[2 * q + 1] = a.y;
+      }
+      const double urow = (lane <= c) ? *cbu_row : 0.0;
       if (!(piv > 0.0) && lane == 0) *bad = 1;
       const double dinv = traj_rsqrt(piv), winv = dinv * dinv;
       // a_ij -= (a_ic / p) a_jc over the live tiles; finished rows / columns were published as zeros
@@ -148,14 +179,17 @@ __device__ void blk_pivot(double *B00, double *cb, int lane, int *bad) {
       }
       if (lane < DP) B00[c * LS + lane] = urow * dinv;     // row c of U = column c of U', final
       __builtin_amdgcn_wave_barrier();
+      if (c == C::JOINCOL) __syncthreads();    // the other waves' L20 products are complete (see the kernel)
     }
   };
+  auto joins = [&](int) {};
   phase(std::integral_constant<int, 0>{}, 0, D < 8 ? D : 8);
-  if constexpr (NB > 1) phase(std::integral_constant<int, 1>{}, 8, D < 16 ? D : 16);
-  if constexpr (NB > 2) phase(std::integral_constant<int, 2>{}, 16, D < 24 ? D : 24);
-  if constexpr (NB > 3) phase(std::integral_constant<int, 3>{}, 24, D < 32 ? D : 32);
-  if constexpr (NB > 4) phase(std::integral_constant<int, 4>{}, 32, D < 40 ? D : 40);
-  if constexpr (NB > 5) phase(std::integral_constant<int, 5>{}, 40, D < 48 ? D : 48);
+  joins(0);
+  if constexpr (NB > 1) { phase(std::integral_constant<int, 1>{}, 8, D < 16 ? D : 16); joins(1); }
+  if constexpr (NB > 2) { phase(std::integral_constant<int, 2>{}, 16, D < 24 ? D : 24); joins(2); }
+  if constexpr (NB > 3) { phase(std::integral_constant<int, 3>{}, 24, D < 32 ? D : 32); joins(3); }
+  if constexpr (NB > 4) { phase(std::integral_constant<int, 4>{}, 32, D < 40 ? D : 40); joins(4); }
+  if constexpr (NB > 5) { phase(std::integral_constant<int, 5>{}, 40, D < 48 ? D : 48); joins(5); }
 }
 
 // row tile `it` of  S <- S U'  in place (one wave): the row tile's A fragments are read first, every output tile
@@ -182,22 +216,26 @@ __device__ __forceinline__ void blk_trsm_rowtile(double *S, const double *U, int
   }
 }
 
-// tile (it, jt) of  Cm -= X Y'  (k over the D columns).  Columns >= D are stored as zeros.
+// tile (it, jt) of  Cm -= X Y'  (k over the D columns; even and odd k-steps in two accumulators: two independent
+// MFMA chains).  Columns >= D are stored as zeros.
 template <int D>
 __device__ __forceinline__ void blk_update_tile(double *Cm, const double *X, const double *Y, int it, int jt, int lane) {
   using C = BlkCfg<D>;
   constexpr int LS = C::LS, KS = C::KS;
   const int lrow = lane & 15, lq = lane >> 4;
   double *cp = Cm + (16 * it + lq) * LS + 16 * jt + lrow;
-  blk_d4 acc;
+  blk_d4 acc, acc2 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
   for (int r = 0; r < 4; ++r) acc[r] = cp[4 * r * LS];
   const double *xa = X + (16 * it + lrow) * LS + lq, *yb = Y + (16 * jt + lrow) * LS + lq;
 #pragma unroll
-  for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-xa[4 * ks], yb[4 * ks], acc, 0, 0, 0);
+  for (int ks = 0; ks < KS; ++ks) {
+    if (ks & 1) acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(-xa[4 * ks], yb[4 * ks], acc2, 0, 0, 0);
+    else acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-xa[4 * ks], yb[4 * ks], acc, 0, 0, 0);
+  }
   const bool keep = 16 * jt + lrow < D;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) cp[4 * r * LS] = keep ? acc[r] : 0.0;
+  for (int r = 0; r < 4; ++r) cp[4 * r * LS] = keep ? acc[r] + acc2[r] : 0.0;
 }
 
 // Back substitution from the panels in the HBM workspace: y_t = U' (z0 - L10' y_{t+1} - L20' y_{t+2}).
@@ -224,7 +262,7 @@ __device__ void blk_backsub(const double *__restrict__ ws, int T, double *buf, d
     double *pn = buf + (size_t)((t + 1) & 1) * PAN;       // receives panel t-1
     double pre[NPRE];
     if (t > 0) {
-      const double *pan = ws + (size_t)(t - 1) * PAN;
+      const double *pan = ws + (size_t)(t > 0 ? t - 1 : 0) * PAN;
 #pragma unroll
       for (int k = 0; k < NPRE; ++k) {
         const size_t e = tid + (size_t)k * 256;
@@ -268,6 +306,12 @@ __device__ void blk_backsub(const double *__restrict__ ws, int T, double *buf, d
   }
 }
 
+// Workgroup schedule of block step t (4 waves, one per SIMD; the scalar-column pivot is the critical path, so
+// everything that does not feed the next pivot is deferred by one step and runs beside it):
+//   phase 1   wave 0: pivot(t)                        waves 1-3: L20(t-1) | S21, S22 updates (t-1) | panel t-1 -> HBM,
+//                                                                block row t+2 assembled into the three freed buffers
+//   phase 2   all:    L10(t) = S10 U', then S11 -= L10 L10'   (-> S00 of step t+1)
+// Buffers: b00, b10, b11 (window of step t) and p0, p1, p2 = U, L10, S20 -> L20 of step t-1, then block row t+2.
 template <int D>
 __global__ void __launch_bounds__(256)
 traj_solve_blk_kernel(const TrajUtt *__restrict__ utts, int n, const double *__restrict__ Qall,
@@ -276,12 +320,15 @@ traj_solve_blk_kernel(const TrajUtt *__restrict__ utts, int n, const double *__r
   using C = BlkCfg<D>;
   constexpr int D2 = 2 * D, DP = C::DP, LS = C::LS, NT = C::NT, BUF = C::BUF;
   constexpr size_t PAN = C::PAN;
-  constexpr int NLOW = NT * (NT + 1) / 2, NJOB = 2 * NLOW + NT * NT;
-  extern __shared__ double sm[];
+  constexpr int NLOW = NT * (NT + 1) / 2, NDEF = NT * NT + NLOW;
+  constexpr int NDT = 192, NIT = (DP * DP + NDT - 1) / NDT;
+  constexpr int RT = D / 16;             // row tile that holds the rhs row D
+  extern __shared__ __attribute__((aligned(16))) double blk_sm[];
+  double *const sm = blk_sm;   // 16-byte LDS accesses in the pivot phase
   double *cb = sm + (size_t)6 * BUF;
   double *yring = cb + C::CB;
   double *part = yring + 2 * D;          // [2 * 256]
-  __shared__ int bad;
+  int &bad = *reinterpret_cast<int *>(part + 2 * 256);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
   for (int u = blockIdx.x; u < n; u += gridDim.x) {
@@ -291,63 +338,153 @@ traj_solve_blk_kernel(const TrajUtt *__restrict__ utts, int n, const double *__r
     const int64_t *mh = mhat_all + U.frame0;
     const double *g = g_all + U.frame0 * D2;
     double *ws = ws_all + (size_t)blockIdx.x * ws_stride;
-    double *b00 = sm, *b10 = sm + BUF, *b20 = sm + 2 * BUF, *b11 = sm + 3 * BUF, *b21 = sm + 4 * BUF, *b22 = sm + 5 * BUF;
+    double *b00 = sm, *b10 = sm + BUF, *b11 = sm + 2 * BUF, *p0 = sm + 3 * BUF, *p1 = sm + 4 * BUF, *p2 = sm + 5 * BUF;
     if (tid == 0) bad = 0;
     for (int e = tid; e < C::CB; e += 256) cb[e] = 0.0;
     blk_assemble<D>(nullptr, nullptr, b00, 0, T, mh, g, Qall, tid, 256);
     blk_assemble<D>(nullptr, b10, b11, 1, T, mh, g, Qall, tid, 256);
-    blk_assemble<D>(b20, b21, b22, 2, T, mh, g, Qall, tid, 256);
     __syncthreads();
-
     BLK_PROF_T0();
-    for (int t = 0; t < T; ++t) {
+
+    for (int t = 0; t <= T; ++t) {
+      // ---------------- phase 1 ----------------
       if (wave == 0) {
-        if (lane < DP) {               // r0 under S10 and S20: row D of L10 / L20 becomes z0 = U r0
-          const double v = (lane < D) ? b00[D * LS + lane] : 0.0;
-          b10[D * LS + lane] = v;
-          b20[D * LS + lane] = v;
+        if (t < T) {
+          blk_pivot<D>(b00, cb, lane, &bad);
+          BLK_PROF_AT(3, 0);
+        } else {
+          __syncthreads();
         }
-        blk_pivot<D>(b00, cb, lane, &bad);
+        __syncthreads();                  // end of phase 1
+      } else {
+        const int dt = tid - 64, dw = wave - 1;
+#ifdef TRAJ_BLK_EXP1
+        const bool defer = false;
+#else
+        const bool defer = t >= 1;
+#endif
+        if (defer && dw < NT) {          // L20(t-1) = S20 U' in place; row D of S20 := r0(t-1) -> row D of L20 = z0
+          if (dw == RT) {
+            if (lane < DP) p2[D * LS + lane] = (lane < D) ? p0[D * LS + lane] : 0.0;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          }
+          blk_trsm_rowtile<D>(p2, p0, dw, lane);
+        }
+        BLK_PROF_AT(4, 64);
+        __syncthreads();
+        if (defer) {                     // S21 -= L20 L10' (all tiles), S22 -= L20 L20' (lower tiles)
+          for (int job = dw; job < NDEF; job += 3) {
+            int q = job, it, jt;
+            if (q < NT * NT) {
+              it = q / NT;
+              jt = q - it * NT;
+              blk_update_tile<D>(b10, p2, p1, it, jt, lane);
+            } else {
+              q -= NT * NT;
+              it = 0;
+              while (q > it) { q -= it + 1; ++it; }
+              jt = q;
+              blk_update_tile<D>(b11, p2, p2, it, jt, lane);
+            }
+          }
+        }
+        // Block row a = t+2 of the stencil.  Every load is unconditional on a clamped address (a select on a loaded
+        // value would make the wave wait for each load in turn); masks are applied when the operands are combined.
+        const int a = t + 2;
+        const bool live = a < T, hasp = a + 1 < T;
+        double q0[NIT], q1[NIT], q2[NIT], q3[NIT], q4[NIT];
+        {
+          const int ac = live ? a : T - 1, am = ac >= 1 ? ac - 1 : 0, ap = hasp ? a + 1 : ac;
+          const double *Qa = Qall + (size_t)(mh[ac] - 1) * D2 * D2;
+          const double *Qm = Qall + (size_t)(mh[am] - 1) * D2 * D2;
+          const double *Qp = Qall + (size_t)(mh[ap] - 1) * D2 * D2;
+          const double *ga = g + (size_t)ac * D2, *gm = g + (size_t)am * D2 + D, *gp = g + (size_t)ap * D2 + D;
+#pragma unroll
+          for (int k = 0; k < NIT; ++k) {
+            const int e = dt + NDT * k, i = e / DP, j = e - i * DP;
+            const int ic = i < D ? i : D - 1, jc = j < D ? j : D - 1;
+            const bool isr = i >= D;
+            const double *a0 = isr ? ga + jc : Qa + (size_t)ic * D2 + jc;
+            const double *a1 = isr ? gm + jc : Qa + (size_t)ic * D2 + (D + jc);
+            const double *a2 = isr ? gp + jc : Qm + (size_t)(D + ic) * D2 + jc;
+            q0[k] = *a0;
+            q1[k] = *a1;
+            q2[k] = *a2;
+            q3[k] = Qm[(size_t)(D + ic) * D2 + (D + jc)];
+            q4[k] = Qp[(size_t)(D + ic) * D2 + (D + jc)];
+          }
+        }
+        BLK_PROF_AT(6, 64);
+        if (defer) {   // panel t-1 -> HBM (reads only: no barrier against the products above)
+          double *pan = ws + (size_t)(t - 1) * PAN;
+#pragma unroll
+          for (int k = 0; k < NIT; ++k) {
+            const int e = dt + NDT * k, i = e / DP, j = e - i * DP;
+            if (e < DP * DP && j < D) {
+              const int o = i * LS + j;
+              if (i < D) {
+                pan[i * D + j] = p0[o];
+                pan[(2 * D + 1) * D + i * D + j] = p2[o];
+              }
+              if (i <= D) pan[D * D + i * D + j] = p1[o];
+            }
+          }
+        }
+        double vd[NIT], v1[NIT], v2[NIT];
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+          const int e = dt + NDT * k, i = e / DP, j = e - i * DP;
+          const bool in = live && j < D;
+          const double w4 = hasp ? 0.25 : 0.0, w2 = hasp ? 0.5 : 0.0;
+          const double blockv = (q0[k] + 0.25 * q3[k]) + w4 * q4[k];      // Qss(a) + Qdd(a-1)/4 + Qdd(a+1)/4
+          const double rhsv = (q0[k] + 0.5 * q1[k]) - w2 * q2[k];          // gs(a) + gd(a-1)/2 - gd(a+1)/2
+          vd[k] = (in && i <= D) ? (i == D ? rhsv : blockv) : 0.0;
+          v1[k] = (in && i < D) ? 0.5 * q2[k] - 0.5 * q1[k] : 0.0;         // Qds(a-1)/2 - Qsd(a)/2
+          v2[k] = (in && i < D) ? -0.25 * q3[k] : 0.0;                     // -Qdd(a-1)/4
+        }
+        BLK_PROF_AT(7, 64);
+        __syncthreads();                  // end of phase 1: every read of p0, p1, p2 is done
+        if (t < T) {
+#pragma unroll
+          for (int k = 0; k < NIT; ++k) {
+            const int e = dt + NDT * k, i = e / DP, j = e - i * DP;
+            if (e < DP * DP) {
+              const int o = i * LS + j;
+              p0[o] = vd[k];
+              p1[o] = v1[k];
+              p2[o] = v2[k];
+            }
+          }
+        }
+      }
+      BLK_PROF(0);
+      if (t == T) break;
+      // ---------------- phase 2 ----------------
+      if (wave < NT) {                    // L10 = S10 U' in place; row D of S10 := r0 -> row D of L10 = z0
+        if (wave == RT) {
+          if (lane < DP) b10[D * LS + lane] = (lane < D) ? b00[D * LS + lane] : 0.0;
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        blk_trsm_rowtile<D>(b10, b00, wave, lane);
       }
       __syncthreads();
-      BLK_PROF(0);
-      for (int job = wave; job < 2 * NT; job += 4) blk_trsm_rowtile<D>(job < NT ? b10 : b20, b00, job < NT ? job : job - NT, lane);
-      __syncthreads();
       BLK_PROF(1);
-      for (int job = wave; job < NJOB; job += 4) {
-        // S11 -= L10 L10' (lower tiles), S21 -= L20 L10' (all tiles), S22 -= L20 L20' (lower tiles)
-        double *Cm;
-        const double *X, *Y;
-        int q = job, it, jt;
-        if (q < NLOW) { Cm = b11; X = b10; Y = b10; }
-        else if (q < NLOW + NT * NT) { q -= NLOW; Cm = b21; X = b20; Y = b10; }
-        else { q -= NLOW + NT * NT; Cm = b22; X = b20; Y = b20; }
-        if (Cm == b21) { it = q / NT; jt = q - it * NT; }
-        else { it = 0; while (q > it) { q -= it + 1; ++it; } jt = q; }
-        blk_update_tile<D>(Cm, X, Y, it, jt, lane);
+      for (int job = wave; job < NLOW; job += 4) {      // S11 -= L10 L10' (lower tiles) -> S00 of the next step
+        int q = job, it = 0;
+        while (q > it) { q -= it + 1; ++it; }
+        blk_update_tile<D>(b11, b10, b10, it, q, lane);
       }
       __syncthreads();
       BLK_PROF(2);
-      double *pan = ws + (size_t)t * PAN;
-      for (int e = tid; e < D * D; e += 256) {
-        const int i = e / D, j = e - i * D;
-        pan[e] = b00[i * LS + j];
-        pan[(size_t)(2 * D + 1) * D + e] = b20[i * LS + j];
+      {   // the window moves by one block
+        double *f0 = p0, *f1 = p1;
+        p0 = b00; p1 = b10;               // U(t), L10(t); p2 already holds S20(t)
+        b00 = b11; b10 = f1; b11 = f0;    // S11 -> S00, block (t+2,t+1) -> S10, block (t+2,t+2) -> S11
       }
-      for (int e = tid; e < (D + 1) * D; e += 256) {
-        const int i = e / D, j = e - i * D;
-        pan[(size_t)D * D + e] = b10[i * LS + j];
-      }
-      __syncthreads();
-      BLK_PROF(3);
-      {   // the window moves by one block: pointer rotation, the three freed buffers receive block row t+3
-        double *f0 = b00, *f1 = b10, *f2 = b20;
-        b00 = b11; b10 = b21; b11 = b22;
-        b20 = f0; b21 = f1; b22 = f2;
-      }
-      blk_assemble<D>(b20, b21, b22, t + 3, T, mh, g, Qall, tid, 256);
-      __syncthreads();
-      BLK_PROF(4);
     }
     blk_backsub<D>(ws, T, sm, yring, part, U.Y);
     BLK_PROF(5);
