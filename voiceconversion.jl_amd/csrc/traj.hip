@@ -789,16 +789,19 @@ static int traj_run(vcmi_traj *t, std::vector<TrajUtt> &utts, int64_t nframes, b
   VCMI_TRY(t->mhat.reserve((size_t)nframes));
   VCMI_TRY(t->gbuf.reserve((size_t)nframes * D2));
   // (1) mhat = predict(g.px, X), src/trajectory_gmmmap.jl:82
+  const bool g_mfma = t->NT <= 6 && !getenv("VCMI_TRAJ_G_SCALAR");   // g_t on MFMA tiles (one workgroup per utterance)
   if (contiguous) {
     VCMI_TRY(gmmmap_predict_device(t->g, dX0, D2, nframes, t->mhat.p, st));
-    hipLaunchKernelGGL(traj_g_kernel, dim3((unsigned)nframes), dim3(128), 2 * D2 * sizeof(double), st, dX0, nframes, D2,
-                       t->mhat.p, t->AT.p, t->QT.p, t->bvec.p, t->gbuf.p);
+    if (!g_mfma)
+      hipLaunchKernelGGL(traj_g_kernel, dim3((unsigned)nframes), dim3(128), 2 * D2 * sizeof(double), st, dX0, nframes, D2,
+                         t->mhat.p, t->AT.p, t->QT.p, t->bvec.p, t->gbuf.p);
   } else {
     for (auto &u : utts) {
       if (u.T == 0) continue;
       VCMI_TRY(gmmmap_predict_device(t->g, u.X, D2, u.T, t->mhat.p + u.frame0, st));
-      hipLaunchKernelGGL(traj_g_kernel, dim3((unsigned)u.T), dim3(128), 2 * D2 * sizeof(double), st, u.X, (int64_t)u.T, D2,
-                         t->mhat.p + u.frame0, t->AT.p, t->QT.p, t->bvec.p, t->gbuf.p + (size_t)u.frame0 * D2);
+      if (!g_mfma)
+        hipLaunchKernelGGL(traj_g_kernel, dim3((unsigned)u.T), dim3(128), 2 * D2 * sizeof(double), st, u.X, (int64_t)u.T, D2,
+                           t->mhat.p + u.frame0, t->AT.p, t->QT.p, t->bvec.p, t->gbuf.p + (size_t)u.frame0 * D2);
     }
   }
   VCMI_HIP(hipGetLastError());
@@ -820,6 +823,16 @@ static int traj_run(vcmi_traj *t, std::vector<TrajUtt> &utts, int64_t nframes, b
   VCMI_HIP(hipMemcpy(t->uttbuf.p, utts.data(), sizeof(TrajUtt) * n, hipMemcpyHostToDevice));
   const size_t shmem = solve_lds_bytes(D);
   const TrajUtt *du = reinterpret_cast<const TrajUtt *>(t->uttbuf.p);
+  if (g_mfma) {
+    VCMI_TRY(t->gperm.reserve((size_t)nframes + (size_t)16 * t->M * n));
+    const int nthr = 64 * t->NT;
+    const size_t shg = ((size_t)4 * t->KS * 16 + (size_t)4 * t->NT * 64) * sizeof(double) + 2 * (size_t)t->M * sizeof(int);
+    VCMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(traj_g_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)shg));
+    hipLaunchKernelGGL(traj_g_mfma_kernel, dim3(std::min(n, 4 * cus)), dim3(nthr), shg, st, du, n, D2, t->M, t->KS, t->Afrag.p,
+                       t->Qfrag.p, t->bvec.p, t->mhat.p, t->gperm.p, t->gbuf.p);
+    VCMI_HIP(hipGetLastError());
+  }
   bool launched = false;
   const char *solver = getenv("VCMI_TRAJ_SOLVER");     // "reg": the scalar-column register-window kernel (A/B runs)
   if (!getenv("VCMI_TRAJ_GENERIC") && !(solver && !strcmp(solver, "reg"))) {

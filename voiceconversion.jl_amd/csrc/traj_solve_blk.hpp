@@ -30,7 +30,8 @@ struct BlkCfg {
   static constexpr int CB = 128;                        // published pivot column: S part [64], U part [64], permuted
   static constexpr int JOINCOL = D < 6 ? D - 1 : 5;     // pivot column after which the pivot wave joins the mid-phase barrier
   static constexpr size_t PAN = (size_t)(3 * D + 1) * D;   // panel doubles per block step: U (D,D), L10 (D+1,D) incl. z0, L20 (D,D)
-  static constexpr size_t lds_doubles = (size_t)6 * BUF + CB + 2 * D + 2 * 256 + 2;
+  static constexpr size_t WORK = (size_t)6 * BUF;       // the six window buffers (the back substitution stages two panels there)
+  static constexpr size_t lds_doubles = WORK + CB + 2 * D + 640 + 2;
 };
 
 typedef double blk_d4 __attribute__((ext_vector_type(4)));
@@ -116,15 +117,21 @@ __device__ void blk_pivot(double *B00, double *cb, int lane, int *bad) {
   pv_d2 *cbs_w = reinterpret_cast<pv_d2 *>(cb + ti * 8), *cbu_w = reinterpret_cast<pv_d2 *>(cb + UO + ti * 8);
   const pv_d2 *cbs_c = reinterpret_cast<const pv_d2 *>(cb + tj * 8);
   const double *cbu_row = cb + UO + (lane & 7) * 8 + (lane >> 3);
+  // One column phase = the columns of one 8-column tile (KC compile-time).  The loop is software-pipelined by one
+  // column: after the rank-1 update of tile column KC alone (it holds column c+1), column c+1 is published and its
+  // reads are issued, and only then the rest of the update of step c runs -- the LDS round trip and the rsqrt chain
+  // of the next column hide behind it.  Two register sets (A, B) alternate, so nothing is copied.
+  struct ColRegs {
+    double lr[2 * NQ], lc[2 * NQ], ur[2 * NQ], urow, piv;
+  };
   auto phase = [&](auto kc_tag, int c_lo, int c_hi) {
     constexpr int KC = decltype(kc_tag)::value;
     constexpr int Q0 = KC / 2;
-#pragma nounroll     // 40 unrolled columns are 27 KB of straight-line code per block step: instruction-cache misses
-    for (int c = c_lo; c < c_hi; ++c) {
+    auto publish_and_read = [&](int c, ColRegs &R) {
       const int oc = c & 7;
       const double pvl = s[KC][KC];
-      const double piv = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(pvl), 9 * oc),
-                                          __builtin_amdgcn_readlane(__double2loint(pvl), 9 * oc));
+      R.piv = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(pvl), 9 * oc),
+                               __builtin_amdgcn_readlane(__double2loint(pvl), 9 * oc));
       if (tj == oc) {       // owners publish column c: S rows i > c (finished rows as 0), U' rows i <= c
 #pragma unroll
         for (int q = Q0; q < NQ; ++q) {
@@ -146,40 +153,57 @@ __device__ void blk_pivot(double *B00, double *cb, int lane, int *bad) {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      double lr_[2 * NQ], lc_[2 * NQ], ur_[2 * NQ];
 #pragma unroll
       for (int q = Q0; q < NQ; ++q) {
         const pv_d2 a = cbs_w[q], b = cbs_c[q];
-        lr_[2 * q] = a.x;
-        lr_[2 * q + 1] = a.y;
-        lc_[2 * q] = b.x;
-        lc_[2 * q + 1] = b.y;
+        R.lr[2 * q] = a.x;
+        R.lr[2 * q + 1] = a.y;
+        R.lc[2 * q] = b.x;
+        R.lc[2 * q + 1] = b.y;
       }
 #pragma unroll
       for (int q = 0; q <= Q0; ++q) {
         const pv_d2 a = cbu_w[q];
-        ur_[2 * q] = a.x;
-        ur_[2 * q + 1] = a.y;
+        R.ur[2 * q] = a.x;
+        R.ur[2 * q + 1] = a.y;
       }
-      const double urow = (lane <= c) ? *cbu_row : 0.0;
-      if (!(piv > 0.0) && lane == 0) *bad = 1;
-      const double dinv = traj_rsqrt(piv), winv = dinv * dinv;
+      R.urow = (lane <= c) ? *cbu_row : 0.0;
+    };
+    auto step = [&](int c, ColRegs &R, ColRegs &N) {
+      if (!(R.piv > 0.0) && lane == 0) *bad = 1;
+      const double dinv = traj_rsqrt(R.piv), winv = dinv * dinv;
       // a_ij -= (a_ic / p) a_jc over the live tiles; finished rows / columns were published as zeros
+      double fs[NB], fu[NB];
 #pragma unroll
       for (int ka = KC; ka < NB; ++ka) {
-        const double f = lr_[ka] * winv;
-#pragma unroll
-        for (int kb = KC; kb <= ka; ++kb) s[ka][kb] = fma(-f, lc_[kb], s[ka][kb]);
+        fs[ka] = R.lr[ka] * winv;
+        s[ka][KC] = fma(-fs[ka], R.lc[KC], s[ka][KC]);
       }
 #pragma unroll
       for (int ka = 0; ka <= KC; ++ka) {
-        const double f = ur_[ka] * winv;
-#pragma unroll
-        for (int kb = KC; kb < NB; ++kb) u[ka][kb] = fma(-f, lc_[kb], u[ka][kb]);
+        fu[ka] = R.ur[ka] * winv;
+        u[ka][KC] = fma(-fu[ka], R.lc[KC], u[ka][KC]);
       }
-      if (lane < DP) B00[c * LS + lane] = urow * dinv;     // row c of U = column c of U', final
-      __builtin_amdgcn_wave_barrier();
+      if (c + 1 < c_hi) publish_and_read(c + 1, N);
+      __builtin_amdgcn_sched_barrier(0);       // keep the rest of this update between the reads and their first use
+#pragma unroll
+      for (int ka = KC + 1; ka < NB; ++ka)
+#pragma unroll
+        for (int kb = KC + 1; kb <= ka; ++kb) s[ka][kb] = fma(-fs[ka], R.lc[kb], s[ka][kb]);
+#pragma unroll
+      for (int ka = 0; ka <= KC; ++ka)
+#pragma unroll
+        for (int kb = KC + 1; kb < NB; ++kb) u[ka][kb] = fma(-fu[ka], R.lc[kb], u[ka][kb]);
+      if (lane < DP) B00[c * LS + lane] = R.urow * dinv;     // row c of U = column c of U', final
+      __builtin_amdgcn_sched_barrier(0);
       if (c == C::JOINCOL) __syncthreads();    // the other waves' L20 products are complete (see the kernel)
+    };
+    ColRegs A, B;
+    publish_and_read(c_lo, A);
+#pragma nounroll
+    for (int c = c_lo; c < c_hi; c += 2) {
+      step(c, A, B);
+      if (c + 1 < c_hi) step(c + 1, B, A);
     }
   };
   auto joins = [&](int) {};
@@ -325,10 +349,10 @@ traj_solve_blk_kernel(const TrajUtt *__restrict__ utts, int n, const double *__r
   constexpr int RT = D / 16;             // row tile that holds the rhs row D
   extern __shared__ __attribute__((aligned(16))) double blk_sm[];
   double *const sm = blk_sm;   // 16-byte LDS accesses in the pivot phase
-  double *cb = sm + (size_t)6 * BUF;
+  double *cb = sm + C::WORK;
   double *yring = cb + C::CB;
-  double *part = yring + 2 * D;          // [2 * 256]
-  int &bad = *reinterpret_cast<int *>(part + 2 * 256);
+  double *part = yring + 2 * D;          // [640]
+  int &bad = *reinterpret_cast<int *>(part + 640);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
   for (int u = blockIdx.x; u < n; u += gridDim.x) {
@@ -358,6 +382,12 @@ traj_solve_blk_kernel(const TrajUtt *__restrict__ utts, int n, const double *__r
         __syncthreads();                  // end of phase 1
       } else {
         const int dt = tid - 64, dw = wave - 1;
+        // mixtures of block rows t+1, t+2, t+3 (clamped), loaded before the products so that the stencil loads below
+        // do not wait for them
+        const int a = t + 2;
+        const bool live = a < T, hasp = a + 1 < T;
+        const int ac = live ? a : T - 1, am = ac >= 1 ? ac - 1 : 0, ap = hasp ? a + 1 : ac;
+        const int64_t mxa = mh[ac], mxm = mh[am], mxp = mh[ap];
 #ifdef TRAJ_BLK_EXP1
         const bool defer = false;
 #else
@@ -392,14 +422,11 @@ traj_solve_blk_kernel(const TrajUtt *__restrict__ utts, int n, const double *__r
         }
         // Block row a = t+2 of the stencil.  Every load is unconditional on a clamped address (a select on a loaded
         // value would make the wave wait for each load in turn); masks are applied when the operands are combined.
-        const int a = t + 2;
-        const bool live = a < T, hasp = a + 1 < T;
         double q0[NIT], q1[NIT], q2[NIT], q3[NIT], q4[NIT];
         {
-          const int ac = live ? a : T - 1, am = ac >= 1 ? ac - 1 : 0, ap = hasp ? a + 1 : ac;
-          const double *Qa = Qall + (size_t)(mh[ac] - 1) * D2 * D2;
-          const double *Qm = Qall + (size_t)(mh[am] - 1) * D2 * D2;
-          const double *Qp = Qall + (size_t)(mh[ap] - 1) * D2 * D2;
+          const double *Qa = Qall + (size_t)(mxa - 1) * D2 * D2;
+          const double *Qm = Qall + (size_t)(mxm - 1) * D2 * D2;
+          const double *Qp = Qall + (size_t)(mxp - 1) * D2 * D2;
           const double *ga = g + (size_t)ac * D2, *gm = g + (size_t)am * D2 + D, *gp = g + (size_t)ap * D2 + D;
 #pragma unroll
           for (int k = 0; k < NIT; ++k) {
