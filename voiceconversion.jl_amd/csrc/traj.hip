@@ -893,12 +893,14 @@ static int traj_run(vcmi_traj *t, std::vector<TrajUtt> &utts, int64_t nframes, b
 static int traj_check_status(vcmi_traj *t, hipStream_t st) {
 #ifdef TRAJ_BLK_PROF
   {
-    long long h[8], z[8] = {0};
+    long long h[16], z[16] = {0};
     (void)hipStreamSynchronize(st);
     (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(blk_prof), sizeof(h));
     (void)hipMemcpyToSymbol(HIP_SYMBOL(blk_prof), z, sizeof(z));
-    fprintf(stderr, "blk_prof cycles: phase1 %lld trsm %lld update %lld backsub %lld | pivot done at %lld, deferred: L20 at %lld, S21/S22 at %lld, panel+assembly at %lld\n",
+    fprintf(stderr, "blk_prof cycles: phase1 %lld trsm %lld update %lld backsub %lld | pivot S done at %lld, pivot U at %lld, deferred: S21/S22 at %lld, panel+assembly at %lld\n",
             h[0], h[1], h[2], h[5], h[3], h[4], h[6], h[7]);
+    fprintf(stderr, "   deferred wave 2: L20 done %lld, past barrier %lld, S21/S22 done %lld, loads issued %lld, panel stored %lld, combined %lld\n", h[8], h[9],
+            h[6], h[10], h[11], h[7]);
   }
 #endif
   int h = 0;

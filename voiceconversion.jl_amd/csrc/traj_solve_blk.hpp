@@ -27,17 +27,18 @@ struct BlkCfg {
   static constexpr int LS = DP + 2;                     // row stride in doubles: LS/2 odd -> MFMA operand reads conflict-free
   static constexpr int BUF = DP * LS;                   // doubles per block buffer
   static constexpr int NB8 = (D + 7) / 8;               // 8 x 8 lane-grid tiles per dimension (pivot phase)
-  static constexpr int CB = 128;                        // published pivot column: S part [64], U part [64], permuted
-  static constexpr int JOINCOL = D < 6 ? D - 1 : 5;     // pivot column after which the pivot wave joins the mid-phase barrier
+  static constexpr int CB = 64;                         // wave U's published column of U', permuted
+  static constexpr int RING = D * 64;                   // wave S's published columns: one 64-double slot each (entries 6, 7 of a lane group: pivot, tag)
+  static constexpr int JOINCOL = D < 9 ? D - 1 : 7;   // pivot column after which the pivot waves join the mid-phase barrier
   static constexpr size_t PAN = (size_t)(3 * D + 1) * D;   // panel doubles per block step: U (D,D), L10 (D+1,D) incl. z0, L20 (D,D)
   static constexpr size_t WORK = (size_t)6 * BUF;       // the six window buffers (the back substitution stages two panels there)
-  static constexpr size_t lds_doubles = WORK + CB + 2 * D + 640 + 2;
+  static constexpr size_t lds_doubles = WORK + CB + RING + 2 * D + 640 + 2;
 };
 
 typedef double blk_d4 __attribute__((ext_vector_type(4)));
 
 #ifdef TRAJ_BLK_PROF
-__device__ long long blk_prof[8];   // cycles of workgroup 0 per phase: pivot, trsm, update, panel, assemble, backsub
+__device__ long long blk_prof[16];   // cycles of workgroup 0 per phase: pivot, trsm, update, panel, assemble, backsub
 #define BLK_PROF_T0() long long pt_ = (long long)__builtin_readcyclecounter()
 #define BLK_PROF(k)                                                     \
   do {                                                                  \
@@ -92,55 +93,128 @@ __device__ void blk_assemble(double *Bm2, double *Bm1, double *Bd, int a, int T,
   }
 }
 
-// Pivot phase, one wave.  B00 rows/cols < D hold S00 (lower triangle valid); on return they hold U = chol(S00)^-1
-// (lower triangular, zeros above).  Lane (ti,tj) of the 8 x 8 grid owns elements i = ti + 8 ka, j = tj + 8 kb.
-// s: S00 tiles kb <= ka; u: tiles of U' (= the identity rows of the augmented matrix), kb >= ka.
-// Per column the owners publish it to LDS in a permuted order (row i at (i%8)*8 + i/8), so the five values a lane
-// needs are contiguous (16-byte LDS accesses); the pivot itself travels by v_readlane, so its rsqrt chain runs while the
-// column is on its way through LDS.  The wave joins one workgroup barrier on the way (after column JOINCOL): the other
-// three waves use it to order their deferred work of the previous block step.
+// Pivot phase, TWO waves.  B00 rows/cols < D hold S00 (lower triangle valid); on return they hold U = chol(S00)^-1
+// (lower triangular, zeros above).  Both waves use an 8 x 8 lane grid: lane (ti,tj) owns elements i = ti + 8 ka,
+// j = tj + 8 kb of its matrix.
+//   wave S (blk_pivot_s): right-looking Cholesky of S00, tiles kb <= ka.  Per column the owners publish it -- rows
+//     i > c, finished rows as zeros -- into slot c of a ring in LDS, in a permuted order (row i at (i%8)*8 + i/8) so
+//     that the values a lane needs are contiguous (16-byte LDS accesses); the pivot itself travels by v_readlane, so
+//     its rsqrt chain runs while the column is on its way through LDS.  Then one lane bumps a counter in LDS.
+//   wave U (blk_pivot_u): the identity rows of the augmented matrix [S00; I], tiles kb >= ka: the same column
+//     operations turn them into U' = L00^-T.  It follows wave S through the ring (LDS operations of a wave execute in
+//     order, so a column is visible before the counter that announces it) and leaves row c of U in B00 after column c.
+// A lone wave issues one FP64 instruction per 5.6 cycles (10 if dependent) and sees ~84 cycles per LDS round trip
+// (tools/microbench_wave.hip): a column costs ~670 cycles in one wave; split like this each wave carries half.
+// Both waves join one workgroup barrier on the way (after column JOINCOL): the two other waves use it to order
+// their deferred work of the previous block step.
+typedef double pv_d2 __attribute__((ext_vector_type(2)));
+
 template <int D>
-__device__ void blk_pivot(double *B00, double *cb, int lane, int *bad) {
+__device__ void blk_pivot_s(const double *B00, double *ring, int fbase, int lane, int *bad) {
   using C = BlkCfg<D>;
-  constexpr int NB = C::NB8, LS = C::LS, DP = C::DP, UO = 64, NQ = (NB + 1) / 2;
+  constexpr int NB = C::NB8, LS = C::LS, NQ = (NB + 1) / 2;
   const int ti = lane >> 3, tj = lane & 7;
-  double s[NB][NB], u[NB][NB];
+  double s[NB][NB];
 #pragma unroll
   for (int ka = 0; ka < NB; ++ka)
 #pragma unroll
     for (int kb = 0; kb < NB; ++kb) {
       const int i = ti + 8 * ka, j = tj + 8 * kb;
       s[ka][kb] = (kb <= ka && i < D && j < D) ? B00[i * LS + j] : 0.0;
-      u[ka][kb] = (ka == kb && ti == tj && i < D) ? 1.0 : 0.0;
     }
-  typedef double pv_d2 __attribute__((ext_vector_type(2)));
-  pv_d2 *cbs_w = reinterpret_cast<pv_d2 *>(cb + ti * 8), *cbu_w = reinterpret_cast<pv_d2 *>(cb + UO + ti * 8);
-  const pv_d2 *cbs_c = reinterpret_cast<const pv_d2 *>(cb + tj * 8);
-  const double *cbu_row = cb + UO + (lane & 7) * 8 + (lane >> 3);
-  // One column phase = the columns of one 8-column tile (KC compile-time).  The loop is software-pipelined by one
-  // column: after the rank-1 update of tile column KC alone (it holds column c+1), column c+1 is published and its
-  // reads are issued, and only then the rest of the update of step c runs -- the LDS round trip and the rsqrt chain
-  // of the next column hide behind it.  Two register sets (A, B) alternate, so nothing is copied.
-  struct ColRegs {
-    double lr[2 * NQ], lc[2 * NQ], ur[2 * NQ], urow, piv;
-  };
+  bool notpd = false;
   auto phase = [&](auto kc_tag, int c_lo, int c_hi) {
     constexpr int KC = decltype(kc_tag)::value;
     constexpr int Q0 = KC / 2;
-    auto publish_and_read = [&](int c, ColRegs &R) {
+#pragma nounroll
+    for (int c = c_lo; c < c_hi; ++c) {
       const int oc = c & 7;
       const double pvl = s[KC][KC];
-      R.piv = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(pvl), 9 * oc),
-                               __builtin_amdgcn_readlane(__double2loint(pvl), 9 * oc));
-      if (tj == oc) {       // owners publish column c: S rows i > c (finished rows as 0), U' rows i <= c
+#if defined(PIV_EXP) && PIV_EXP == 3
+      const double piv = 50.0 + c + 0.0 * pvl;
+#else
+      const double piv = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(pvl), 9 * oc),
+                                          __builtin_amdgcn_readlane(__double2loint(pvl), 9 * oc));
+#endif
+      pv_d2 *slot_w = reinterpret_cast<pv_d2 *>(ring + c * 64 + ti * 8);
+#if defined(PIV_EXP) && PIV_EXP == 2
+      const pv_d2 *slot_c = reinterpret_cast<const pv_d2 *>(ring + (c > 0 ? c - 1 : 0) * 64 + tj * 8);
+      const pv_d2 *slot_r = reinterpret_cast<const pv_d2 *>(ring + (c > 0 ? c - 1 : 0) * 64 + ti * 8);
+#else
+      const pv_d2 *slot_c = reinterpret_cast<const pv_d2 *>(ring + c * 64 + tj * 8);
+      const pv_d2 *slot_r = slot_w;
+#endif
+      if (tj == oc) {       // owners publish column c: rows i > c, finished rows as 0
 #pragma unroll
         for (int q = Q0; q < NQ; ++q) {
           const int k0 = 2 * q, k1 = 2 * q + 1;
           pv_d2 v;
           v.x = (k0 >= KC && ti + 8 * k0 > c) ? s[k0][KC] : 0.0;
           v.y = (k1 < NB && ti + 8 * k1 > c) ? s[k1 < NB ? k1 : 0][KC] : 0.0;
-          cbs_w[q] = v;
+          slot_w[q] = v;
         }
+        // the pivot and the column's sequence tag, in a later instruction than the column itself (the LDS executes a
+        // wave's operations in order): wave U polls the tag of lane group ti = 0
+        slot_w[3] = pv_d2{piv, (double)(fbase + c + 1)};
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      double lr_[2 * NQ], lc_[2 * NQ];
+#pragma unroll
+      for (int q = Q0; q < NQ; ++q) {
+        const pv_d2 x = slot_r[q], y = slot_c[q];
+        lr_[2 * q] = x.x;
+        lr_[2 * q + 1] = x.y;
+        lc_[2 * q] = y.x;
+        lc_[2 * q + 1] = y.y;
+      }
+      notpd |= !(piv > 0.0);
+#if defined(PIV_EXP) && PIV_EXP == 1
+      const double dinv = piv * 1e-3, winv = dinv * dinv;
+#else
+      const double dinv = traj_rsqrt(piv), winv = dinv * dinv;
+#endif
+      // a_ij -= (a_ic / p) a_jc over the live tiles; finished rows / columns were published as zeros
+#pragma unroll
+      for (int ka = KC; ka < NB; ++ka) {
+        const double f = lr_[ka] * winv;
+#pragma unroll
+        for (int kb = KC; kb <= ka; ++kb) s[ka][kb] = fma(-f, lc_[kb], s[ka][kb]);
+      }
+      __builtin_amdgcn_wave_barrier();
+      if (c == C::JOINCOL) __syncthreads();    // the other waves' L20 products are complete (see the kernel)
+    }
+  };
+  phase(std::integral_constant<int, 0>{}, 0, D < 8 ? D : 8);
+  if constexpr (NB > 1) phase(std::integral_constant<int, 1>{}, 8, D < 16 ? D : 16);
+  if constexpr (NB > 2) phase(std::integral_constant<int, 2>{}, 16, D < 24 ? D : 24);
+  if constexpr (NB > 3) phase(std::integral_constant<int, 3>{}, 24, D < 32 ? D : 32);
+  if constexpr (NB > 4) phase(std::integral_constant<int, 4>{}, 32, D < 40 ? D : 40);
+  if constexpr (NB > 5) phase(std::integral_constant<int, 5>{}, 40, D < 48 ? D : 48);
+  if (notpd && lane == 0) *bad = 1;
+}
+
+template <int D>
+__device__ void blk_pivot_u(double *B00, double *ring, int fbase, double *cbu,
+                            int lane) {
+  using C = BlkCfg<D>;
+  constexpr int NB = C::NB8, LS = C::LS, DP = C::DP, NQ = (NB + 1) / 2;
+  const int ti = lane >> 3, tj = lane & 7;
+  double u[NB][NB];
+#pragma unroll
+  for (int ka = 0; ka < NB; ++ka)
+#pragma unroll
+    for (int kb = 0; kb < NB; ++kb) u[ka][kb] = (ka == kb && ti == tj && ti + 8 * ka < D) ? 1.0 : 0.0;
+  pv_d2 *cbu_w = reinterpret_cast<pv_d2 *>(cbu + ti * 8);
+  const double *cbu_row = cbu + (lane & 7) * 8 + (lane >> 3);
+  auto phase = [&](auto kc_tag, int c_lo, int c_hi) {
+    constexpr int KC = decltype(kc_tag)::value;
+    constexpr int Q0 = KC / 2;
+#pragma nounroll
+    for (int c = c_lo; c < c_hi; ++c) {
+      const int oc = c & 7;
+      if (tj == oc) {       // owners publish column c of U': rows i <= c (needs nothing from wave S)
 #pragma unroll
         for (int q = 0; q <= Q0; ++q) {
           const int k0 = 2 * q, k1 = 2 * q + 1;
@@ -150,70 +224,46 @@ __device__ void blk_pivot(double *B00, double *cb, int lane, int *bad) {
           cbu_w[q] = v;
         }
       }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      {                                          // column c of S00 published?  (its tag is unique per block step and column)
+        unsigned long long *tagp = reinterpret_cast<unsigned long long *>(ring + c * 64 + 7);
+        const unsigned long long want = (unsigned long long)__double_as_longlong((double)(fbase + c + 1));
+        while (__hip_atomic_load(tagp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != want) __builtin_amdgcn_s_sleep(1);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      const pv_d2 *slot_c = reinterpret_cast<const pv_d2 *>(ring + c * 64 + tj * 8);
+      const double piv = ring[c * 64 + 6];
+      double lc_[2 * NQ], ur_[2 * NQ];
 #pragma unroll
       for (int q = Q0; q < NQ; ++q) {
-        const pv_d2 a = cbs_w[q], b = cbs_c[q];
-        R.lr[2 * q] = a.x;
-        R.lr[2 * q + 1] = a.y;
-        R.lc[2 * q] = b.x;
-        R.lc[2 * q + 1] = b.y;
+        const pv_d2 y = slot_c[q];
+        lc_[2 * q] = y.x;
+        lc_[2 * q + 1] = y.y;
       }
 #pragma unroll
       for (int q = 0; q <= Q0; ++q) {
-        const pv_d2 a = cbu_w[q];
-        R.ur[2 * q] = a.x;
-        R.ur[2 * q + 1] = a.y;
+        const pv_d2 x = cbu_w[q];
+        ur_[2 * q] = x.x;
+        ur_[2 * q + 1] = x.y;
       }
-      R.urow = (lane <= c) ? *cbu_row : 0.0;
-    };
-    auto step = [&](int c, ColRegs &R, ColRegs &N) {
-      if (!(R.piv > 0.0) && lane == 0) *bad = 1;
-      const double dinv = traj_rsqrt(R.piv), winv = dinv * dinv;
-      // a_ij -= (a_ic / p) a_jc over the live tiles; finished rows / columns were published as zeros
-      double fs[NB], fu[NB];
-#pragma unroll
-      for (int ka = KC; ka < NB; ++ka) {
-        fs[ka] = R.lr[ka] * winv;
-        s[ka][KC] = fma(-fs[ka], R.lc[KC], s[ka][KC]);
-      }
+      const double urow = (lane <= c) ? *cbu_row : 0.0;
+      const double dinv = traj_rsqrt(piv), winv = dinv * dinv;
 #pragma unroll
       for (int ka = 0; ka <= KC; ++ka) {
-        fu[ka] = R.ur[ka] * winv;
-        u[ka][KC] = fma(-fu[ka], R.lc[KC], u[ka][KC]);
+        const double f = ur_[ka] * winv;
+#pragma unroll
+        for (int kb = KC; kb < NB; ++kb) u[ka][kb] = fma(-f, lc_[kb], u[ka][kb]);
       }
-      if (c + 1 < c_hi) publish_and_read(c + 1, N);
-      __builtin_amdgcn_sched_barrier(0);       // keep the rest of this update between the reads and their first use
-#pragma unroll
-      for (int ka = KC + 1; ka < NB; ++ka)
-#pragma unroll
-        for (int kb = KC + 1; kb <= ka; ++kb) s[ka][kb] = fma(-fs[ka], R.lc[kb], s[ka][kb]);
-#pragma unroll
-      for (int ka = 0; ka <= KC; ++ka)
-#pragma unroll
-        for (int kb = KC + 1; kb < NB; ++kb) u[ka][kb] = fma(-fu[ka], R.lc[kb], u[ka][kb]);
-      if (lane < DP) B00[c * LS + lane] = R.urow * dinv;     // row c of U = column c of U', final
-      __builtin_amdgcn_sched_barrier(0);
-      if (c == C::JOINCOL) __syncthreads();    // the other waves' L20 products are complete (see the kernel)
-    };
-    ColRegs A, B;
-    publish_and_read(c_lo, A);
-#pragma nounroll
-    for (int c = c_lo; c < c_hi; c += 2) {
-      step(c, A, B);
-      if (c + 1 < c_hi) step(c + 1, B, A);
+      if (lane < DP) B00[c * LS + lane] = urow * dinv;     // row c of U = column c of U', final
+      __builtin_amdgcn_wave_barrier();
+      if (c == C::JOINCOL) __syncthreads();
     }
   };
-  auto joins = [&](int) {};
   phase(std::integral_constant<int, 0>{}, 0, D < 8 ? D : 8);
-  joins(0);
-  if constexpr (NB > 1) { phase(std::integral_constant<int, 1>{}, 8, D < 16 ? D : 16); joins(1); }
-  if constexpr (NB > 2) { phase(std::integral_constant<int, 2>{}, 16, D < 24 ? D : 24); joins(2); }
-  if constexpr (NB > 3) { phase(std::integral_constant<int, 3>{}, 24, D < 32 ? D : 32); joins(3); }
-  if constexpr (NB > 4) { phase(std::integral_constant<int, 4>{}, 32, D < 40 ? D : 40); joins(4); }
-  if constexpr (NB > 5) { phase(std::integral_constant<int, 5>{}, 40, D < 48 ? D : 48); joins(5); }
+  if constexpr (NB > 1) phase(std::integral_constant<int, 1>{}, 8, D < 16 ? D : 16);
+  if constexpr (NB > 2) phase(std::integral_constant<int, 2>{}, 16, D < 24 ? D : 24);
+  if constexpr (NB > 3) phase(std::integral_constant<int, 3>{}, 24, D < 32 ? D : 32);
+  if constexpr (NB > 4) phase(std::integral_constant<int, 4>{}, 32, D < 40 ? D : 40);
+  if constexpr (NB > 5) phase(std::integral_constant<int, 5>{}, 40, D < 48 ? D : 48);
 }
 
 // row tile `it` of  S <- S U'  in place (one wave): the row tile's A fragments are read first, every output tile
@@ -332,9 +382,10 @@ __device__ void blk_backsub(const double *__restrict__ ws, int T, double *buf, d
 
 // Workgroup schedule of block step t (4 waves, one per SIMD; the scalar-column pivot is the critical path, so
 // everything that does not feed the next pivot is deferred by one step and runs beside it):
-//   phase 1   wave 0: pivot(t)                        waves 1-3: L20(t-1) | S21, S22 updates (t-1) | panel t-1 -> HBM,
-//                                                                block row t+2 assembled into the three freed buffers
-//   phase 2   all:    L10(t) = S10 U', then S11 -= L10 L10'   (-> S00 of step t+1)
+//   phase 1   waves 0, 1: pivot(t) (Cholesky of S00 / its inverse U)
+//             waves 2, 3: L20(t-1) | S21, S22 updates (t-1) | panel t-1 -> HBM, block row t+2 of the stencil
+//                         fetched and, after the barrier, written into the three freed buffers
+//   phase 2   all:        L10(t) = S10 U', then S11 -= L10 L10'   (-> S00 of step t+1)
 // Buffers: b00, b10, b11 (window of step t) and p0, p1, p2 = U, L10, S20 -> L20 of step t-1, then block row t+2.
 template <int D>
 __global__ void __launch_bounds__(256)
@@ -345,15 +396,33 @@ traj_solve_blk_kernel(const TrajUtt *__restrict__ utts, int n, const double *__r
   constexpr int D2 = 2 * D, DP = C::DP, LS = C::LS, NT = C::NT, BUF = C::BUF;
   constexpr size_t PAN = C::PAN;
   constexpr int NLOW = NT * (NT + 1) / 2, NDEF = NT * NT + NLOW;
-  constexpr int NDT = 192, NIT = (DP * DP + NDT - 1) / NDT;
+  constexpr int NDW = 2, NDT = 64 * NDW;   // deferred team
+  constexpr int VW = (D % 2 == 0) ? 2 : 1;                 // elements per access: 16-byte LDS / global accesses when D is even
+  constexpr int NIT = (D * D / VW + NDT - 1) / NDT;        // element groups per thread
   constexpr int RT = D / 16;             // row tile that holds the rhs row D
   extern __shared__ __attribute__((aligned(16))) double blk_sm[];
-  double *const sm = blk_sm;   // 16-byte LDS accesses in the pivot phase
-  double *cb = sm + C::WORK;
-  double *yring = cb + C::CB;
+  double *const sm = blk_sm;             // 16-byte LDS accesses in the pivot phase
+  double *cbu = sm + C::WORK;
+  double *ring = cbu + C::CB;
+  double *yring = ring + C::RING;
   double *part = yring + 2 * D;          // [640]
-  int &bad = *reinterpret_cast<int *>(part + 640);
+  int *flags = reinterpret_cast<int *>(part + 640);   // [0] not-PD flag
+  int &bad = flags[0];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+  // per-thread element tables of the deferred team (the same D x D elements every block step): LDS offset, offset in
+  // a mixture's Q matrix, offset in a panel block -- a lone wave pays ~6 cycles per VALU instruction, so index
+  // arithmetic is kept out of the step loop
+  const int dt = tid - 64 * (4 - NDW);
+  int eo[NIT], eq[NIT], ep[NIT];
+#pragma unroll
+  for (int k = 0; k < NIT; ++k) {
+    const int e = VW * (dt + NDT * k), ec = (e >= 0 && e < D * D) ? e : 0, i = ec / D, j = ec - i * D;
+    eo[k] = (e >= 0 && e < D * D) ? i * LS + j : -1;
+    eq[k] = i * D2 + j;
+    ep[k] = ec;
+  }
+  typedef double ev_t __attribute__((ext_vector_type(VW)));
 
   for (int u = blockIdx.x; u < n; u += gridDim.x) {
     const TrajUtt U = utts[u];
@@ -363,8 +432,13 @@ traj_solve_blk_kernel(const TrajUtt *__restrict__ utts, int n, const double *__r
     const double *g = g_all + U.frame0 * D2;
     double *ws = ws_all + (size_t)blockIdx.x * ws_stride;
     double *b00 = sm, *b10 = sm + BUF, *b11 = sm + 2 * BUF, *p0 = sm + 3 * BUF, *p1 = sm + 4 * BUF, *p2 = sm + 5 * BUF;
-    if (tid == 0) bad = 0;
-    for (int e = tid; e < C::CB; e += 256) cb[e] = 0.0;
+    if (tid == 0) {
+      flags[0] = 0;
+      flags[1] = 0;
+    }
+    for (int e = tid; e < C::CB + C::RING; e += 256) cbu[e] = 0.0;   // cbu and the ring (stale tags of the previous utterance)
+    // p0, p1, p2 receive only D x D elements (+ the rhs row) per step: their padding stays zero from here on
+    for (int e = tid; e < 3 * BUF; e += 256) p0[e] = 0.0;
     blk_assemble<D>(nullptr, nullptr, b00, 0, T, mh, g, Qall, tid, 256);
     blk_assemble<D>(nullptr, b10, b11, 1, T, mh, g, Qall, tid, 256);
     __syncthreads();
@@ -372,40 +446,43 @@ traj_solve_blk_kernel(const TrajUtt *__restrict__ utts, int n, const double *__r
 
     for (int t = 0; t <= T; ++t) {
       // ---------------- phase 1 ----------------
-      if (wave == 0) {
+      ev_t vd[NIT], v1[NIT], v2[NIT];     // block row t+2 of the stencil, written to p0, p1, p2 during phase 2 (deferred team)
+      double rv = 0.0;
+      if (wave < 4 - NDW) {
         if (t < T) {
-          blk_pivot<D>(b00, cb, lane, &bad);
+          if (wave == 0) blk_pivot_s<D>(b00, ring, t * D, lane, &bad);
+          else blk_pivot_u<D>(b00, ring, t * D, cbu, lane);
           BLK_PROF_AT(3, 0);
+          BLK_PROF_AT(4, 64);
         } else {
           __syncthreads();
         }
         __syncthreads();                  // end of phase 1
       } else {
-        const int dt = tid - 64, dw = wave - 1;
+        const int dw = wave - (4 - NDW);
         // mixtures of block rows t+1, t+2, t+3 (clamped), loaded before the products so that the stencil loads below
         // do not wait for them
         const int a = t + 2;
         const bool live = a < T, hasp = a + 1 < T;
         const int ac = live ? a : T - 1, am = ac >= 1 ? ac - 1 : 0, ap = hasp ? a + 1 : ac;
         const int64_t mxa = mh[ac], mxm = mh[am], mxp = mh[ap];
-#ifdef TRAJ_BLK_EXP1
-        const bool defer = false;
-#else
         const bool defer = t >= 1;
-#endif
-        if (defer && dw < NT) {          // L20(t-1) = S20 U' in place; row D of S20 := r0(t-1) -> row D of L20 = z0
-          if (dw == RT) {
-            if (lane < DP) p2[D * LS + lane] = (lane < D) ? p0[D * LS + lane] : 0.0;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (defer) {                      // L20(t-1) = S20 U' in place; row D of S20 := r0(t-1) -> row D of L20 = z0
+          for (int it = dw; it < NT; it += NDW) {
+            if (it == RT) {
+              if (lane < DP) p2[D * LS + lane] = (lane < D) ? p0[D * LS + lane] : 0.0;
+              __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+              __builtin_amdgcn_wave_barrier();
+              __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
+            blk_trsm_rowtile<D>(p2, p0, it, lane);
           }
-          blk_trsm_rowtile<D>(p2, p0, dw, lane);
         }
-        BLK_PROF_AT(4, 64);
+        BLK_PROF_AT(8, 128);
         __syncthreads();
-        if (defer) {                     // S21 -= L20 L10' (all tiles), S22 -= L20 L20' (lower tiles)
-          for (int job = dw; job < NDEF; job += 3) {
+        BLK_PROF_AT(9, 128);
+        if (defer) {                      // S21 -= L20 L10' (all tiles), S22 -= L20 L20' (lower tiles)
+          for (int job = dw; job < NDEF; job += NDW) {
             int q = job, it, jt;
             if (q < NT * NT) {
               it = q / NT;
@@ -420,75 +497,63 @@ traj_solve_blk_kernel(const TrajUtt *__restrict__ utts, int n, const double *__r
             }
           }
         }
+        BLK_PROF_AT(6, 128);
         // Block row a = t+2 of the stencil.  Every load is unconditional on a clamped address (a select on a loaded
         // value would make the wave wait for each load in turn); masks are applied when the operands are combined.
-        double q0[NIT], q1[NIT], q2[NIT], q3[NIT], q4[NIT];
-        {
-          const double *Qa = Qall + (size_t)(mxa - 1) * D2 * D2;
-          const double *Qm = Qall + (size_t)(mxm - 1) * D2 * D2;
-          const double *Qp = Qall + (size_t)(mxp - 1) * D2 * D2;
-          const double *ga = g + (size_t)ac * D2, *gm = g + (size_t)am * D2 + D, *gp = g + (size_t)ap * D2 + D;
+        ev_t q0[NIT], q1[NIT], q2[NIT], q3[NIT], q4[NIT];
+        const double *Qss = Qall + (size_t)(mxa - 1) * D2 * D2, *Qsd = Qss + D;
+        const double *Qds = Qall + (size_t)(mxm - 1) * D2 * D2 + (size_t)D * D2, *Qdd = Qds + D;
+        const double *Qpp = Qall + (size_t)(mxp - 1) * D2 * D2 + (size_t)D * D2 + D;
 #pragma unroll
-          for (int k = 0; k < NIT; ++k) {
-            const int e = dt + NDT * k, i = e / DP, j = e - i * DP;
-            const int ic = i < D ? i : D - 1, jc = j < D ? j : D - 1;
-            const bool isr = i >= D;
-            const double *a0 = isr ? ga + jc : Qa + (size_t)ic * D2 + jc;
-            const double *a1 = isr ? gm + jc : Qa + (size_t)ic * D2 + (D + jc);
-            const double *a2 = isr ? gp + jc : Qm + (size_t)(D + ic) * D2 + jc;
-            q0[k] = *a0;
-            q1[k] = *a1;
-            q2[k] = *a2;
-            q3[k] = Qm[(size_t)(D + ic) * D2 + (D + jc)];
-            q4[k] = Qp[(size_t)(D + ic) * D2 + (D + jc)];
-          }
+        for (int k = 0; k < NIT; ++k) {
+          q0[k] = *reinterpret_cast<const ev_t *>(Qss + eq[k]);
+          q1[k] = *reinterpret_cast<const ev_t *>(Qsd + eq[k]);
+          q2[k] = *reinterpret_cast<const ev_t *>(Qds + eq[k]);
+          q3[k] = *reinterpret_cast<const ev_t *>(Qdd + eq[k]);
+          q4[k] = *reinterpret_cast<const ev_t *>(Qpp + eq[k]);
         }
-        BLK_PROF_AT(6, 64);
+        // the right-hand side row (lanes 0..D-1 of the team): r_a = gs(a) + gd(a-1)/2 - gd(a+1)/2
+        const int jr = dt < D ? dt : D - 1;
+        const double g0 = g[(size_t)ac * D2 + jr], g1 = g[(size_t)am * D2 + D + jr], g2 = g[(size_t)ap * D2 + D + jr];
+        BLK_PROF_AT(10, 128);
         if (defer) {   // panel t-1 -> HBM (reads only: no barrier against the products above)
           double *pan = ws + (size_t)(t - 1) * PAN;
 #pragma unroll
-          for (int k = 0; k < NIT; ++k) {
-            const int e = dt + NDT * k, i = e / DP, j = e - i * DP;
-            if (e < DP * DP && j < D) {
-              const int o = i * LS + j;
-              if (i < D) {
-                pan[i * D + j] = p0[o];
-                pan[(2 * D + 1) * D + i * D + j] = p2[o];
-              }
-              if (i <= D) pan[D * D + i * D + j] = p1[o];
+          for (int k = 0; k < NIT; ++k)
+            if (eo[k] >= 0) {
+              *reinterpret_cast<ev_t *>(pan + ep[k]) = *reinterpret_cast<const ev_t *>(p0 + eo[k]);
+              *reinterpret_cast<ev_t *>(pan + D * D + ep[k]) = *reinterpret_cast<const ev_t *>(p1 + eo[k]);
+              *reinterpret_cast<ev_t *>(pan + (2 * D + 1) * D + ep[k]) = *reinterpret_cast<const ev_t *>(p2 + eo[k]);
             }
-          }
+          if (dt < D) pan[2 * D * D + dt] = p1[D * LS + dt];      // z0 = row D of L10
         }
-        double vd[NIT], v1[NIT], v2[NIT];
+        BLK_PROF_AT(11, 128);
+        const double w4 = hasp ? 0.25 : 0.0, w2 = hasp ? 0.5 : 0.0, lv = live ? 1.0 : 0.0;
 #pragma unroll
         for (int k = 0; k < NIT; ++k) {
-          const int e = dt + NDT * k, i = e / DP, j = e - i * DP;
-          const bool in = live && j < D;
-          const double w4 = hasp ? 0.25 : 0.0, w2 = hasp ? 0.5 : 0.0;
-          const double blockv = (q0[k] + 0.25 * q3[k]) + w4 * q4[k];      // Qss(a) + Qdd(a-1)/4 + Qdd(a+1)/4
-          const double rhsv = (q0[k] + 0.5 * q1[k]) - w2 * q2[k];          // gs(a) + gd(a-1)/2 - gd(a+1)/2
-          vd[k] = (in && i <= D) ? (i == D ? rhsv : blockv) : 0.0;
-          v1[k] = (in && i < D) ? 0.5 * q2[k] - 0.5 * q1[k] : 0.0;         // Qds(a-1)/2 - Qsd(a)/2
-          v2[k] = (in && i < D) ? -0.25 * q3[k] : 0.0;                     // -Qdd(a-1)/4
+          vd[k] = lv * ((q0[k] + 0.25 * q3[k]) + w4 * q4[k]);     // Qss(a) + Qdd(a-1)/4 + Qdd(a+1)/4
+          v1[k] = lv * (0.5 * q2[k] - 0.5 * q1[k]);               // Qds(a-1)/2 - Qsd(a)/2
+          v2[k] = lv * (-0.25 * q3[k]);                           // -Qdd(a-1)/4
         }
-        BLK_PROF_AT(7, 64);
+        rv = lv * ((g0 + 0.5 * g1) - w2 * g2);
+        BLK_PROF_AT(7, 128);
         __syncthreads();                  // end of phase 1: every read of p0, p1, p2 is done
-        if (t < T) {
-#pragma unroll
-          for (int k = 0; k < NIT; ++k) {
-            const int e = dt + NDT * k, i = e / DP, j = e - i * DP;
-            if (e < DP * DP) {
-              const int o = i * LS + j;
-              p0[o] = vd[k];
-              p1[o] = v1[k];
-              p2[o] = v2[k];
-            }
-          }
-        }
       }
       BLK_PROF(0);
       if (t == T) break;
       // ---------------- phase 2 ----------------
+      // The freed buffers p0, p1, p2 receive block row t+2 during this phase: wave 3 while the others form L10, wave 2
+      // after its share of the S11 update (nothing reads them before phase 1 of the next step).
+      auto write_row = [&](int k_lo, int k_hi) {
+#pragma unroll
+        for (int k = 0; k < NIT; ++k)
+          if (k >= k_lo && k < k_hi && eo[k] >= 0) {
+            *reinterpret_cast<ev_t *>(p0 + eo[k]) = vd[k];
+            *reinterpret_cast<ev_t *>(p1 + eo[k]) = v1[k];
+            *reinterpret_cast<ev_t *>(p2 + eo[k]) = v2[k];
+          }
+        if (k_lo == 0 && dt >= 0 && dt < D) p0[D * LS + dt] = rv;
+      };
       if (wave < NT) {                    // L10 = S10 U' in place; row D of S10 := r0 -> row D of L10 = z0
         if (wave == RT) {
           if (lane < DP) b10[D * LS + lane] = (lane < D) ? b00[D * LS + lane] : 0.0;
@@ -498,6 +563,7 @@ traj_solve_blk_kernel(const TrajUtt *__restrict__ utts, int n, const double *__r
         }
         blk_trsm_rowtile<D>(b10, b00, wave, lane);
       }
+      if (wave == 3 || (wave == 2 && NT <= 2)) write_row(0, NIT);
       __syncthreads();
       BLK_PROF(1);
       for (int job = wave; job < NLOW; job += 4) {      // S11 -= L10 L10' (lower tiles) -> S00 of the next step
@@ -505,6 +571,7 @@ traj_solve_blk_kernel(const TrajUtt *__restrict__ utts, int n, const double *__r
         while (q > it) { q -= it + 1; ++it; }
         blk_update_tile<D>(b11, b10, b10, it, q, lane);
       }
+      if (wave == 2 && NT > 2) write_row(0, NIT);
       __syncthreads();
       BLK_PROF(2);
       {   // the window moves by one block
