@@ -43,10 +43,12 @@ def test_golden_fixture_model(vc, fixture_model):
         vc.fvconvert(t, np.zeros((38, 10)))                          # src/trajectory_gmmmap.jl:68
 
 
-@pytest.mark.parametrize("D,M,Ts", [(40, 8, [300]), (12, 4, [1, 2, 3, 4, 5, 50]), (20, 6, [64, 7, 129])])
+@pytest.mark.parametrize("D,M,Ts", [(40, 8, [300]), (12, 4, [1, 2, 3, 4, 5, 50]), (20, 6, [64, 7, 129]),
+                                    (16, 4, [40, 3]), (25, 4, [33, 2]), (32, 3, [21])])
 def test_vs_oracle_batch(vc, D, M, Ts):
     """Config-5 shape (static D=40, X dim 80) at a length the oracle finishes in seconds, plus the short-utterance
-    edge cases T = 1..5 where the stencil loses neighbours."""
+    edge cases T = 1..5 where the stencil loses neighbours; D = 16 / 32 (the rhs row opens a tile of its own) and the
+    odd D = 25 (8-byte stencil / panel accesses) cover the other instantiations of the blocked solver."""
     from oracle import c_oracle as co, np_oracle as npo
     w, mu, sig = npo.synth_model(500 + D, 4 * D, M, lam_lo=1e-3)
     ref = co.TrajectoryGMMMap(co.GMMMap(w, mu, sig))
@@ -85,3 +87,26 @@ def test_constructW_structure(vc):
         if t < T - 1:
             assert np.array_equal(Wd[s + D:s + 2 * D, (t + 1) * D:(t + 2) * D], 0.5 * I)
     assert W.nnz == D * T + 2 * D * (T - 1)
+
+
+def test_blocked_and_scalar_column_solvers_agree(vc, monkeypatch):
+    """The MFMA-blocked banded Cholesky (default) against the scalar-column register-window kernel
+    (VCMI_TRAJ_SOLVER=reg) and the MFMA g_t kernel against the one-workgroup-per-frame kernel (VCMI_TRAJ_G_SCALAR):
+    two independent device implementations of src/trajectory_gmmmap.jl:85-105 on the same utterances."""
+    from oracle import np_oracle as npo
+    D, M = 40, 8
+    w, mu, sig = npo.synth_model(777, 4 * D, M, lam_lo=1e-3)
+    g = vc.GMMMap(*julia_model(w, mu, sig))
+    t = vc.TrajectoryGMMMap(g, 400)
+    rng = np.random.default_rng(5)
+    Xs = []
+    for T in (400, 57, 1):
+        static = npo.sample_frames(int(rng.integers(1 << 30)), w, mu, sig, T, 0, D)
+        static = np.cumsum(static, axis=0) / np.sqrt(np.arange(1, T + 1))[:, None]
+        Xs.append(npo.push_delta(static).T)
+    Yb = t.fvconvert_batch(Xs)
+    monkeypatch.setenv("VCMI_TRAJ_SOLVER", "reg")
+    monkeypatch.setenv("VCMI_TRAJ_G_SCALAR", "1")
+    Yr = t.fvconvert_batch(Xs)
+    for a, b in zip(Yb, Yr):
+        assert relerr(a, b) < 1e-9

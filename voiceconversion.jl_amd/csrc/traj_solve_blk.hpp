@@ -6,17 +6,20 @@
 // window   S00            r0        (block rows t, t+1, t+2; S20 and S22 are still the raw assembled blocks)
 //          S10 S11        r1
 //          S20 S21 S22    r2
-//   1. pivot (ONE wave, no barriers): right-looking Cholesky of S00 on an 8 x 8 lane grid with the identity riding
-//      along, so the same column operations leave U = L00^-1 (explicit, lower triangular) -- the only part of the
-//      algorithm that is sequential in the scalar columns;
+//   1. pivot (two waves, no workgroup barrier inside): right-looking Cholesky of S00 on an 8 x 8 lane grid (wave S) and
+//      the identity rows of [S00; I] under the same column operations (wave U), which leave U = L00^-1 explicit and
+//      lower triangular -- the only part of the algorithm that is sequential in the scalar columns;
 //   2. L10 = S10 U', L20 = S20 U'                                  (MFMA, in place; U' is triangular: k-steps skipped)
 //   3. S11 -= L10 L10', S21 -= L20 L10', S22 -= L20 L20'          (MFMA, lower tiles only for the symmetric ones)
 //   4. the panel [U; L10; z0; L20] goes to the HBM workspace, the window shifts by pointer rotation and block row
 //      t+3 is assembled from the stencil.
+// Only L10 and the S11 update feed the next pivot; everything else of step t runs one step late on the other two waves,
+// beside pivot(t+1) (schedule: see the kernel).
 // The right-hand side needs no code of its own: r_b lives in row D (a padding row of the 16-row tiles) of S_bb, a copy
 // of r0 is put in row D of S10 and S20, and then row D of L10 / L20 is z0 = U r0 and the updates of step 3 apply
 // r1 -= L10 z0, r2 -= L20 z0 to row D of S11 / S22.
 // Back substitution: y_t = U' (z0 - L10' y_{t+1} - L20' y_{t+2}) -- two matrix-vector products, no sequential chain.
+// Cycle counters per phase: build with -DTRAJ_BLK_PROF (make EXTRA=-DTRAJ_BLK_PROF), printed to stderr per call.
 #pragma once
 
 template <int D>
@@ -31,14 +34,14 @@ struct BlkCfg {
   static constexpr int RING = D * 64;                   // wave S's published columns: one 64-double slot each (entries 6, 7 of a lane group: pivot, tag)
   static constexpr int JOINCOL = D < 9 ? D - 1 : 7;   // pivot column after which the pivot waves join the mid-phase barrier
   static constexpr size_t PAN = (size_t)(3 * D + 1) * D;   // panel doubles per block step: U (D,D), L10 (D+1,D) incl. z0, L20 (D,D)
-  static constexpr size_t WORK = (size_t)6 * BUF;       // the six window buffers (the back substitution stages two panels there)
-  static constexpr size_t lds_doubles = WORK + CB + RING + 2 * D + 640 + 2;
+  static constexpr size_t WORK = 6 * (size_t)BUF > 3 * PAN ? 6 * (size_t)BUF : 3 * PAN;   // six window buffers / three staged panels
+  static constexpr size_t lds_doubles = WORK + CB + RING + 2 * D + 768 + 2;
 };
 
 typedef double blk_d4 __attribute__((ext_vector_type(4)));
 
 #ifdef TRAJ_BLK_PROF
-__device__ long long blk_prof[16];   // cycles of workgroup 0 per phase: pivot, trsm, update, panel, assemble, backsub
+__device__ long long blk_prof[16];   // cycles of workgroup 0 per phase (printed by traj_check_status)
 #define BLK_PROF_T0() long long pt_ = (long long)__builtin_readcyclecounter()
 #define BLK_PROF(k)                                                     \
   do {                                                                  \
@@ -130,20 +133,10 @@ __device__ void blk_pivot_s(const double *B00, double *ring, int fbase, int lane
     for (int c = c_lo; c < c_hi; ++c) {
       const int oc = c & 7;
       const double pvl = s[KC][KC];
-#if defined(PIV_EXP) && PIV_EXP == 3
-      const double piv = 50.0 + c + 0.0 * pvl;
-#else
       const double piv = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(pvl), 9 * oc),
                                           __builtin_amdgcn_readlane(__double2loint(pvl), 9 * oc));
-#endif
       pv_d2 *slot_w = reinterpret_cast<pv_d2 *>(ring + c * 64 + ti * 8);
-#if defined(PIV_EXP) && PIV_EXP == 2
-      const pv_d2 *slot_c = reinterpret_cast<const pv_d2 *>(ring + (c > 0 ? c - 1 : 0) * 64 + tj * 8);
-      const pv_d2 *slot_r = reinterpret_cast<const pv_d2 *>(ring + (c > 0 ? c - 1 : 0) * 64 + ti * 8);
-#else
       const pv_d2 *slot_c = reinterpret_cast<const pv_d2 *>(ring + c * 64 + tj * 8);
-      const pv_d2 *slot_r = slot_w;
-#endif
       if (tj == oc) {       // owners publish column c: rows i > c, finished rows as 0
 #pragma unroll
         for (int q = Q0; q < NQ; ++q) {
@@ -163,18 +156,14 @@ __device__ void blk_pivot_s(const double *B00, double *ring, int fbase, int lane
       double lr_[2 * NQ], lc_[2 * NQ];
 #pragma unroll
       for (int q = Q0; q < NQ; ++q) {
-        const pv_d2 x = slot_r[q], y = slot_c[q];
+        const pv_d2 x = slot_w[q], y = slot_c[q];
         lr_[2 * q] = x.x;
         lr_[2 * q + 1] = x.y;
         lc_[2 * q] = y.x;
         lc_[2 * q + 1] = y.y;
       }
       notpd |= !(piv > 0.0);
-#if defined(PIV_EXP) && PIV_EXP == 1
-      const double dinv = piv * 1e-3, winv = dinv * dinv;
-#else
       const double dinv = traj_rsqrt(piv), winv = dinv * dinv;
-#endif
       // a_ij -= (a_ic / p) a_jc over the live tiles; finished rows / columns were published as zeros
 #pragma unroll
       for (int ka = KC; ka < NB; ++ka) {
@@ -313,70 +302,97 @@ __device__ __forceinline__ void blk_update_tile(double *Cm, const double *X, con
 }
 
 // Back substitution from the panels in the HBM workspace: y_t = U' (z0 - L10' y_{t+1} - L20' y_{t+2}).
-// Panels are double-buffered in LDS (through registers, one panel ahead); both products are split over the four
-// waves (lane = column, wave = quarter of the rows) and summed in fixed order.
+// The loop is bound by the HBM read of the panels (38.7 KB per step at D = 40), so they are requested two steps ahead:
+// global -> registers at the start of a step (two register sets alternate), registers -> one of three LDS slots at the
+// end of the next one.  The results are collected in LDS and written out every 8 steps, followed by an explicit wait:
+// a global store pending beside the panel loads would make every wait of the loop a wait for all of them (loads and
+// stores share the vmcnt counter and may complete out of order).
+// Both products are split over the four waves (lane = column, wave = quarter of the rows) and summed in fixed order.
 template <int D>
 __device__ void blk_backsub(const double *__restrict__ ws, int T, double *buf, double *yring, double *part,
                             double *__restrict__ Y) {
   using C = BlkCfg<D>;
-  constexpr size_t PAN = C::PAN;
-  constexpr int NPRE = (int)((PAN + 255) / 256);
+  constexpr int PAN = (int)C::PAN;
+  constexpr int NPRE = (PAN + 255) / 256;
   constexpr int OU = 0, OL1 = D * D, OZ = 2 * D * D, OL2 = (2 * D + 1) * D;
+  constexpr int YB = 8;                    // steps per result flush
   const int tid = threadIdx.x, j = tid & 63, p = tid >> 6;
+  double *ybuf = part + 320;               // [YB][D]
+  auto fetch = [&](int t, double (&regs)[NPRE]) {
+    const double *pan = ws + (size_t)t * PAN;
+#pragma unroll
+    for (int k = 0; k < NPRE; ++k) {
+      const int e = tid + k * 256;
+      regs[k] = pan[e < PAN ? e : 0];
+    }
+  };
+  auto stage = [&](int t, const double (&regs)[NPRE]) {
+    double *dst = buf + (size_t)(t % 3) * PAN;
+#pragma unroll
+    for (int k = 0; k < NPRE; ++k) {
+      const int e = tid + k * 256;
+      if (e < PAN) dst[e] = regs[k];
+    }
+  };
+  double ra[NPRE], rb[NPRE];
   for (int i = tid; i < 2 * D; i += 256) yring[i] = 0.0;
-  {
-    const double *pan = ws + (size_t)(T - 1) * PAN;
-    for (size_t e = tid; e < PAN; e += 256) buf[((T - 1) & 1) * PAN + e] = pan[e];
-  }
+  fetch(T - 1, ra);
+  stage(T - 1, ra);
+  if (T >= 2) fetch(T - 2, ra);
   __syncthreads();
   constexpr int R1 = (2 * D + 3) / 4;      // rows of [L10; L20] per wave
   constexpr int R2 = (D + 3) / 4;          // rows of U per wave
-  for (int t = T - 1; t >= 0; --t) {
-    const double *pb = buf + (size_t)(t & 1) * PAN;
-    double *pn = buf + (size_t)((t + 1) & 1) * PAN;       // receives panel t-1
-    double pre[NPRE];
-    if (t > 0) {
-      const double *pan = ws + (size_t)(t > 0 ? t - 1 : 0) * PAN;
-#pragma unroll
-      for (int k = 0; k < NPRE; ++k) {
-        const size_t e = tid + (size_t)k * 256;
-        pre[k] = (e < PAN) ? pan[e] : 0.0;
-      }
-    }
+  auto step = [&](int t, double (&cur)[NPRE], double (&nxt)[NPRE]) {
+    // `cur` holds panel t-1 (requested one step ago), `nxt` receives panel t-2
+    if (t >= 2) fetch(t - 2, nxt);
+    const double *pb = buf + (size_t)(t % 3) * PAN;
     double *y1 = yring + ((t + 1) & 1) * D, *y2 = yring + (t & 1) * D;   // y_{t+1}, y_{t+2}
-    if (j < D) {
-      double sacc = (p == 0) ? pb[OZ + j] : 0.0;
-      const int r_lo = p * R1, r_hi = (r_lo + R1 < 2 * D) ? r_lo + R1 : 2 * D;
-      for (int r = r_lo; r < r_hi; ++r) {
-        const double l = (r < D) ? pb[OL1 + r * D + j] : pb[OL2 + (r - D) * D + j];
-        const double yv = (r < D) ? y1[r] : y2[r - D];
-        sacc = fma(-l, yv, sacc);
+    const int jc = j < D ? j : D - 1;
+    {   // partial sums of z0 - [L10; L20]' [y_{t+1}; y_{t+2}]: compile-time trip count, all LDS reads issued up front
+      double s0 = (p == 0) ? pb[OZ + jc] : 0.0, s1 = 0.0;
+      const int r_lo = p * R1;
+#pragma unroll
+      for (int q = 0; q < R1; ++q) {
+        const int r = r_lo + q, rc = r < 2 * D ? r : 0;                  // wave-uniform
+        const double *row = rc < D ? pb + OL1 + rc * D : pb + OL2 + (rc - D) * D;
+        const double l = row[jc], yv = rc < D ? y1[rc] : y2[rc - D];
+        if (q & 1) s1 = fma(r < 2 * D ? -l : 0.0, yv, s1);
+        else s0 = fma(r < 2 * D ? -l : 0.0, yv, s0);
       }
-      part[p * 64 + j] = sacc;
+      part[p * 64 + j] = s0 + s1;
     }
     __syncthreads();
     if (tid < D) part[256 + tid] = ((part[tid] + part[64 + tid]) + part[128 + tid]) + part[192 + tid];   // w
     __syncthreads();
-    if (j < D) {
-      double sacc = 0.0;
-      const int r_lo = p * R2, r_hi = (r_lo + R2 < D) ? r_lo + R2 : D;
-      for (int r = (r_lo > j ? r_lo : j); r < r_hi; ++r) sacc = fma(pb[OU + r * D + j], part[256 + r], sacc);
-      part[p * 64 + j] = sacc;
+    {   // partial sums of U' w (U is stored with its zeros above the diagonal)
+      double s0 = 0.0, s1 = 0.0;
+      const int r_lo = p * R2;
+#pragma unroll
+      for (int q = 0; q < R2; ++q) {
+        const int r = r_lo + q, rc = r < D ? r : 0;
+        const double ue = pb[OU + rc * D + jc], wv = part[256 + rc];
+        if (q & 1) s1 = fma(r < D ? ue : 0.0, wv, s1);
+        else s0 = fma(r < D ? ue : 0.0, wv, s0);
+      }
+      part[p * 64 + j] = s0 + s1;
     }
     __syncthreads();
     if (tid < D) {
       const double yv = ((part[tid] + part[64 + tid]) + part[128 + tid]) + part[192 + tid];
       y2[tid] = yv;                       // becomes y_t; the slot of y_{t+2} is free now
-      Y[(size_t)t * D + tid] = yv;        // reshape(y, D, T), src/trajectory_gmmmap.jl:109
+      ybuf[(t & (YB - 1)) * D + tid] = yv;
     }
-    if (t > 0) {
-#pragma unroll
-      for (int k = 0; k < NPRE; ++k) {
-        const size_t e = tid + (size_t)k * 256;
-        if (e < PAN) pn[e] = pre[k];
-      }
-    }
+    if (t >= 1) stage(t - 1, cur);
     __syncthreads();
+    if ((t & (YB - 1)) == 0) {            // rows t .. t+YB-1 of reshape(y, D, T), src/trajectory_gmmmap.jl:109
+      const int nrow = (T - t < YB) ? T - t : YB;
+      for (int e = tid; e < nrow * D; e += 256) Y[(size_t)t * D + e] = ybuf[e];
+      __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): no store is pending when the loop goes on
+    }
+  };
+  for (int t = T - 1; t >= 0; t -= 2) {
+    step(t, ra, rb);
+    if (t >= 1) step(t - 1, rb, ra);
   }
 }
 
@@ -405,8 +421,8 @@ traj_solve_blk_kernel(const TrajUtt *__restrict__ utts, int n, const double *__r
   double *cbu = sm + C::WORK;
   double *ring = cbu + C::CB;
   double *yring = ring + C::RING;
-  double *part = yring + 2 * D;          // [640]
-  int *flags = reinterpret_cast<int *>(part + 640);   // [0] not-PD flag
+  double *part = yring + 2 * D;          // [768]
+  int *flags = reinterpret_cast<int *>(part + 768);   // [0] not-PD flag
   int &bad = flags[0];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
