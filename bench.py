@@ -482,11 +482,12 @@ def bench_traj(args, world, rank, gv=False):
            "config": {"workload": ("TrajectoryGVGMMMap fvconvert, 100 epochs (SURVEY 8f rank 2)" if gv else
                                    "TrajectoryGMMMap fvconvert (BASELINE configs[4])"), "static_D": D, "M": M, "T": T,
                       "utterances_per_gpu": n},
-           "roofline": {"bound": "mfma", "kernel": "predict + traj_g_kernel + traj_solve_kernel" + (" + traj_gv_kernel" if gv else ""),
+           "roofline": {"bound": "mfma", "kernel": "predict + traj_g_mfma_kernel + traj_solve_blk_kernel<40>" + (" + traj_gv_kernel" if gv else ""),
                         "achieved": achieved,
                         "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS, "traffic": None,
                         "flop_per_utterance": flops_per_utt, "kernel_ms": kernel_ms,
-                        "note": "whole pipeline (3 kernels); the banded solve is a 2000-step sequential block recurrence"}}
+                        "note": "whole pipeline (3 kernels); the banded solve is a 2000-step sequential block recurrence "
+                                "whose pivot block is factorised column by column (latency-bound, see DESIGN 3.4)"}}
     if rank == 0:
         from oracle import c_oracle as co
 
