@@ -559,8 +559,19 @@ __device__ void gv_moments(const double *__restrict__ y, int D, int T, int nthr,
   const int NG = nthr / D;                 // frame groups per dimension
   const int d = tid % D, g = tid / D;
   double s = 0.0;
-  if (g < NG)
-    for (int t = g; t < T; t += NG) s += y[(size_t)t * D + d];
+  if (g < NG) {
+    // 8 loads in flight per thread (a plain loop keeps one: with one workgroup per CU the passes of this kernel are
+    // bound by memory-level parallelism, not by HBM bandwidth); the additions stay in frame order
+    int t = g;
+    for (; t + 7 * NG < T; t += 8 * NG) {
+      double v[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] = y[(size_t)(t + q * NG) * D + d];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) s += v[q];
+    }
+    for (; t < T; t += NG) s += y[(size_t)t * D + d];
+  }
   if (g < NG) red[g * D + d] = s;
   __syncthreads();
   if (tid < D) {
@@ -572,7 +583,18 @@ __device__ void gv_moments(const double *__restrict__ y, int D, int T, int nthr,
   s = 0.0;
   if (g < NG) {
     const double m = mean[d];
-    for (int t = g; t < T; t += NG) {
+    int t = g;
+    for (; t + 7 * NG < T; t += 8 * NG) {
+      double v[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] = y[(size_t)(t + q * NG) * D + d];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const double e = v[q] - m;
+        s = fma(e, e, s);
+      }
+    }
+    for (; t < T; t += NG) {
       const double e = y[(size_t)t * D + d] - m;
       s = fma(e, e, s);
     }
@@ -598,8 +620,8 @@ traj_gv_kernel(const TrajUtt *__restrict__ utts, int n, int D, int M, int KS, co
   extern __shared__ double gsm[];
   const int D2 = 2 * D, nthr = blockDim.x, NT = nthr >> 6;
   double *Ut = gsm;                        // [kGvNB][4*KS][16]  u of the tiles' frames, k-major
-  double *red = Ut + (size_t)kGvNB * 4 * KS * 16;  // [nthr]
-  double *mean = red + nthr;               // [D]
+  double *red = Ut + (size_t)kGvNB * 4 * KS * 16;  // [2][nthr]
+  double *mean = red + 2 * nthr;           // [D]
   double *var = mean + D;                  // [D]
   double *coef = var + D;                  // [D]
   int *cnt = reinterpret_cast<int *>(coef + D);   // [M] frames per mixture, then the fill cursor
@@ -646,23 +668,56 @@ traj_gv_kernel(const TrajUtt *__restrict__ utts, int n, int D, int M, int KS, co
       perm[start[m] + atomicAdd(&cnt[m], 1)] = t;
     }
 
-    // eq. (58): y <- sqrt(mu^v / var(y)) (y - mean) + mean, src/trajectory_gmmmap.jl:152; and r
+    // eq. (58): y <- sqrt(mu^v / var(y)) (y - mean) + mean, src/trajectory_gmmmap.jl:152; and r.
+    // Every pass that writes y also accumulates the moments of what it writes (thread = (dimension d, frame group g),
+    // the mapping of gv_moments): sum (y - c) and sum (y - c)^2 with the shift c = mean before the pass, so that
+    // mean = c + S1/T, var = (S2 - S1^2/T)/(T-1) lose nothing to cancellation and the next epoch needs no pass of
+    // its own over y for them.
     gv_moments(y, D, T, nthr, red, mean, var);
-    for (int e = tid; e < D * T; e += nthr) {
-      const int t = e / D, d = e - t * D;
-      y[e] = sqrt(gv.muv[d] / var[d]) * (y[e] - mean[d]) + mean[d];
-      double r = g[(size_t)t * D2 + d];
-      if (t >= 1) r += 0.5 * g[(size_t)(t - 1) * D2 + D + d];
-      if (t + 1 < T) r -= 0.5 * g[(size_t)(t + 1) * D2 + D + d];
-      R[e] = r;
+    const int NGm = nthr / D, dm = tid % D, gm = tid / D;
+    auto finish_moments = [&](double s1, double s2) {
+      if (gm < NGm) {
+        red[gm * D + dm] = s1;
+        red[nthr + gm * D + dm] = s2;
+      }
+      __syncthreads();
+      if (tid < D) {
+        double a1 = 0.0, a2 = 0.0;
+        for (int k = 0; k < NGm; ++k) {
+          a1 += red[k * D + tid];
+          a2 += red[nthr + k * D + tid];
+        }
+        mean[tid] += a1 / (double)T;
+        var[tid] = (a2 - a1 * a1 / (double)T) / (double)(T - 1);       // Julia's var: corrected
+      }
+      __syncthreads();
+    };
+    {
+      double s1 = 0.0, s2 = 0.0;
+      if (gm < NGm) {
+        const double mu = mean[dm], sc = sqrt(gv.muv[dm] / var[dm]);
+#pragma unroll 8
+        for (int t = gm; t < T; t += NGm) {
+          const size_t e = (size_t)t * D + dm;
+          const int tm = t >= 1 ? t - 1 : t, tp = t + 1 < T ? t + 1 : t;
+          const double yo = y[e], g0 = g[(size_t)t * D2 + dm], g1 = g[(size_t)tm * D2 + D + dm], g2 = g[(size_t)tp * D2 + D + dm];
+          const double yn = sc * (yo - mu) + mu;
+          y[e] = yn;
+          R[e] = (g0 + (t >= 1 ? 0.5 : 0.0) * g1) - (t + 1 < T ? 0.5 : 0.0) * g2;
+          const double dv = yn - mu;
+          s1 += dv;
+          s2 = fma(dv, dv, s2);
+        }
+      }
+      __syncthreads();
+      finish_moments(s1, s2);
     }
-    __syncthreads();
 
     double afr[kGvMaxKS];
     int mcur = -1;
     for (int ep = 0; ep < gv.epochs; ++ep) {
-      // gvgrad coefficients, src/trajectory_gmmmap.jl:171-189: -2/T (pv' (var(y) - mu^v)), times (y - mean) below
-      gv_moments(y, D, T, nthr, red, mean, var);
+      // gvgrad coefficients, src/trajectory_gmmmap.jl:171-189: -2/T (pv' (var(y) - mu^v)), times (y - mean) below;
+      // mean and var of the current y come from the pass that wrote it
       if (tid < D) {
         double s = 0.0;
         for (int j = 0; j < D; ++j) s = fma(gv.pv[j + (size_t)D * tid], var[j] - gv.muv[j], s);
@@ -674,19 +729,18 @@ traj_gv_kernel(const TrajUtt *__restrict__ utts, int n, int D, int M, int KS, co
         const int nb = (ntiles - tile0 < kGvNB) ? ntiles - tile0 : kGvNB;
         if (tid < 16 * nb) tidx[tid] = perm[tile0 * 16 + tid];
         __syncthreads();
+        // u_t = [y_t ; (y_{t+1} - y_{t-1})/2]: two unconditional loads per element on clamped addresses with 0 / 1 / +-1/2
+        // weights (a branch or a select on the loaded value would serialise the loads), eight elements in flight
+#pragma unroll 8
         for (int e = tid; e < nb * 4 * KS * 16; e += nthr) {
           const int b = e / (4 * KS * 16), q = e - b * (4 * KS * 16);
           const int k = q >> 4, t = tidx[b * 16 + (q & 15)];
-          double v = 0.0;
-          if (t >= 0 && k < D2) {
-            if (k < D) {
-              v = y[(size_t)t * D + k];
-            } else {
-              if (t + 1 < T) v += 0.5 * y[(size_t)(t + 1) * D + (k - D)];
-              if (t >= 1) v -= 0.5 * y[(size_t)(t - 1) * D + (k - D)];
-            }
-          }
-          Ut[e] = v;
+          const bool ok = t >= 0 && k < D2, st = k < D;
+          const int tc = t >= 0 ? t : 0, kd = st ? (k < D ? k : 0) : (k < D2 ? k - D : 0);
+          const int tp = tc + 1 < T ? tc + 1 : tc, tm = tc >= 1 ? tc - 1 : tc;
+          const double a = y[(size_t)(st ? tc : tp) * D + kd], c = y[(size_t)(st ? tc : tm) * D + kd];
+          const double wa = !ok ? 0.0 : (st ? 1.0 : (tc + 1 < T ? 0.5 : 0.0)), wc = (!ok || st) ? 0.0 : (tc >= 1 ? -0.5 : 0.0);
+          Ut[e] = wa * a + wc * c;
         }
         __syncthreads();
         for (int b = 0; b < nb; ++b) {
@@ -712,16 +766,26 @@ traj_gv_kernel(const TrajUtt *__restrict__ utts, int n, int D, int M, int KS, co
         __syncthreads();
       }
       // y <- y + alpha * ( omega (r - P y) + coef (y - mean) ), eq. (52), src/trajectory_gmmmap.jl:163-166
-      for (int e = tid; e < D * T; e += nthr) {
-        const int t = e / D, d = e - t * D;
-        double py = V[(size_t)t * D2 + d];
-        if (t >= 1) py += 0.5 * V[(size_t)(t - 1) * D2 + D + d];
-        if (t + 1 < T) py -= 0.5 * V[(size_t)(t + 1) * D2 + D + d];
-        const double yy = y[e];
-        const double dy = omega * (R[e] - py) + coef[d] * (yy - mean[d]);
-        y[e] = fma(gv.alpha, dy, yy);
+      double s1 = 0.0, s2 = 0.0;
+      if (gm < NGm) {
+        const double mu = mean[dm], cf = coef[dm];
+#pragma unroll 8
+        for (int t = gm; t < T; t += NGm) {
+          const size_t e = (size_t)t * D + dm;
+          const int tm = t >= 1 ? t - 1 : t, tp = t + 1 < T ? t + 1 : t;
+          const double vs = V[(size_t)t * D2 + dm], vm = V[(size_t)tm * D2 + D + dm], vp = V[(size_t)tp * D2 + D + dm];
+          const double yy = y[e], rr = R[e];
+          const double py = (vs + (t >= 1 ? 0.5 : 0.0) * vm) - (t + 1 < T ? 0.5 : 0.0) * vp;
+          const double dy = omega * (rr - py) + cf * (yy - mu);
+          const double yn = fma(gv.alpha, dy, yy);
+          y[e] = yn;
+          const double dv = yn - mu;
+          s1 += dv;
+          s2 = fma(dv, dv, s2);
+        }
       }
       __syncthreads();
+      finish_moments(s1, s2);
     }
   }
 }
@@ -880,7 +944,7 @@ static int traj_run(vcmi_traj *t, std::vector<TrajUtt> &utts, int64_t nframes, b
   if (gv && gv->epochs >= 0) {
     // (3) global-variance ascent on the solved trajectories, in place; workspace: V (2D,T) + r (D,T) <= the panel area
     const int nthr = 64 * t->NT;
-    const size_t shmem = ((size_t)kGvNB * 4 * t->KS * 16 + nthr + 3 * (size_t)D) * sizeof(double) + 2 * (size_t)t->M * sizeof(int);
+    const size_t shmem = ((size_t)kGvNB * 4 * t->KS * 16 + 2 * nthr + 3 * (size_t)D) * sizeof(double) + 2 * (size_t)t->M * sizeof(int);
     VCMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(traj_gv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)shmem));
     hipLaunchKernelGGL(traj_gv_kernel, dim3(grid), dim3(nthr), shmem, st, du, n, D, t->M, t->KS, t->Qfrag.p, t->mhat.p, t->gbuf.p,
