@@ -110,3 +110,22 @@ def test_blocked_and_scalar_column_solvers_agree(vc, monkeypatch):
     Yr = t.fvconvert_batch(Xs)
     for a, b in zip(Yb, Yr):
         assert relerr(a, b) < 1e-9
+
+
+@pytest.mark.parametrize("solver", ["blk", "reg"])
+def test_not_positive_definite_normal_matrix(vc, monkeypatch, solver):
+    """A joint covariance whose x block is PD but whose conditional covariance Syy - A Sxy is negative definite passes
+    the GMMMap constructor (only p(x) is factorised, src/gmm.jl:17) and makes W'D^-1W indefinite: the reference's
+    Cholesky-based solve would throw; both device solvers report it through the status flag -> PosDefException."""
+    D, M, T = 12, 2, 9
+    Dj = 4 * D
+    rng = np.random.default_rng(3)
+    w = np.array([0.5, 0.5])
+    mu = rng.standard_normal((M, Dj))
+    I = np.eye(2 * D)
+    sig = np.stack([np.block([[I, 2.0 * I], [2.0 * I, I]])] * M)
+    g = vc.GMMMap(*julia_model(w, mu, sig))
+    t = vc.TrajectoryGMMMap(g, T)
+    monkeypatch.setenv("VCMI_TRAJ_SOLVER", solver)
+    with pytest.raises(vc.PosDefException):
+        vc.fvconvert(t, rng.standard_normal((2 * D, T)))
