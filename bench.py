@@ -45,11 +45,11 @@ def estep_flops_per_frame(Dj, M):
     return 8 * Dj * M + 25 * M
 
 
-def pmc_traffic(fname, kernel_prefix):
+def pmc_traffic(fname, kernel_prefix, subdir="r01c_pmc"):
     """HBM bytes per bench step of a kernel from a committed PMC pass (profiles/r01c_pmc/*.json, tools/pmc_traffic.sh);
     the counters cannot be collected inside the timed run.  Raw FETCH_SIZE + WRITE_SIZE: see profiles/r01c_pmc/README.txt."""
     try:
-        tr = json.load(open(os.path.join(ROOT, "profiles", "r01c_pmc", fname)))
+        tr = json.load(open(os.path.join(ROOT, "profiles", subdir, fname)))
         for k, v in tr.items():
             if kernel_prefix in k:
                 return v.get("hbm_bytes_per_step_raw", v["hbm_bytes_per_launch_raw"])
@@ -484,7 +484,11 @@ def bench_traj(args, world, rank, gv=False):
                       "utterances_per_gpu": n},
            "roofline": {"bound": "mfma", "kernel": "predict + traj_g_mfma_kernel + traj_solve_blk_kernel<40>" + (" + traj_gv_kernel" if gv else ""),
                         "achieved": achieved,
-                        "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS, "traffic": None,
+                        "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS,
+                        "traffic": (sum(pmc_traffic(("trajgv" if gv else "traj") + "_traffic.json", k, "r01e_pmc") or 0
+                                        for k in ("gmmmap_mfma_kernel", "posterior_finish_kernel", "traj_g_mfma_kernel",
+                                                  "traj_solve_blk_kernel", "traj_gv_kernel")) or None) if n == 256 else None,
+                        "traffic_unit": "bytes per step, all kernels (rocprofv3 FETCH_SIZE+WRITE_SIZE, profiles/r01e_pmc/)",
                         "flop_per_utterance": flops_per_utt, "kernel_ms": kernel_ms,
                         "note": "whole pipeline (3 kernels); the banded solve is a 2000-step sequential block recurrence "
                                 "whose pivot block is factorised column by column (latency-bound, see DESIGN 3.4)"}}
