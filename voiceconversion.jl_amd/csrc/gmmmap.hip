@@ -79,12 +79,14 @@ __device__ __forceinline__ double vc_exp(double x) { return exp(x); }
 // MFMA tile kernel.  One wave owns FT tiles of 16 frames; a workgroup of WAVES waves shares the
 // per-mixture operand block, double-buffered in LDS.
 // MODE 0: convert (writes Y).  MODE 1: log-weighted densities l_m (writes LP (M,T)), no A tiles used.
+// MODE 2: predict -- the 1-based index of the first maximum of l_m over m (src/gmm.jl:44-47) written as int64 to Y[frame];
+// the (M,T) matrix never exists.
 // ------------------------------------------------------------------------------------------------
 template <int DP, int FT, int WAVES, int MODE, int NBUF>
 __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(DP <= 40 ? (FT == 2 ? 3 : 4) : 2)))
 gmmmap_mfma_kernel(const double *__restrict__ packed, int M, int D, const double *__restrict__ X, int64_t ldx,
                    int64_t T, double *__restrict__ Y, int64_t ldy) {
-  using TL = Tiling<DP, MODE == 1>;
+  using TL = Tiling<DP, MODE >= 1>;
   constexpr int KS = TL::KS, NT = TL::NT, NU = TL::NU, BLK = TL::BLK;
   constexpr int NTHREADS = WAVES * 64;
   constexpr int NV = BLK / 2 / NTHREADS;   // double2 copies per thread per block (BLK is a multiple of 1024)
@@ -117,8 +119,10 @@ gmmmap_mfma_kernel(const double *__restrict__ packed, int M, int D, const double
 
   double yacc[FT][KS];
   double runmax[FT], den[FT];
+  int bestm[FT];                  // MODE 2: runmax = the largest l_m so far, bestm = its (first) mixture
 #pragma unroll
   for (int f = 0; f < FT; ++f) {
+    bestm[f] = 0;
     runmax[f] = -INFINITY;
     den[f] = 0.0;
 #pragma unroll
@@ -197,6 +201,15 @@ gmmmap_mfma_kernel(const double *__restrict__ packed, int M, int D, const double
         if (lgrp == 0) {
 #pragma unroll
           for (int f = 0; f < FT; ++f) lstage[((wave * FT + f) * 16 + lcol) * LROW + (m & 7)] = lc - 0.5 * q[f];
+        }
+      } else if (MODE == 2) {
+#pragma unroll
+        for (int f = 0; f < FT; ++f) {
+          const double l = lc - 0.5 * q[f];
+          if (l > runmax[f]) {          // strict: the first maximum wins, as in posterior_finish_kernel<1>
+            runmax[f] = l;
+            bestm[f] = m;
+          }
         }
       } else {
         // ---------------- phase A: regression tiles, E = A x + b ----------------
@@ -288,6 +301,15 @@ gmmmap_mfma_kernel(const double *__restrict__ packed, int M, int D, const double
     __syncthreads();
   }
 
+  if (MODE == 2) {
+    if (lgrp == 0) {
+#pragma unroll
+      for (int f = 0; f < FT; ++f) {
+        const int64_t fr = frame0 + 16 * f + lcol;
+        if (fr < T) reinterpret_cast<int64_t *>(Y)[fr] = bestm[f] + 1;
+      }
+    }
+  }
   if (MODE == 0) {
 #pragma unroll
     for (int f = 0; f < FT; ++f) {
@@ -391,9 +413,9 @@ posterior_finish_kernel(double *__restrict__ LP, int M, int64_t T, int64_t *__re
 template <int DP, int MODE, int FTV, int WV>
 static int launch_mfma(const vcmi_gmmmap *g, const double *dX, int64_t ldx, int64_t T, double *dY, int64_t ldy,
                        hipStream_t st) {
-  constexpr int FT = (MODE == 1) ? 2 : FTV;
+  constexpr int FT = (MODE >= 1) ? 2 : FTV;
   constexpr int WAVES = WV;
-  using TL = Tiling<DP, MODE == 1>;
+  using TL = Tiling<DP, MODE >= 1>;
   // double-buffer the per-mixture block when two copies fit in half of the CU's 160 KiB LDS
   constexpr int NBUF = (2 * (size_t)TL::BLK * sizeof(double) <= 80 * 1024) ? 2 : 1;
   const size_t shmem = NBUF * (size_t)TL::BLK * sizeof(double);
@@ -406,7 +428,7 @@ static int launch_mfma(const vcmi_gmmmap *g, const double *dX, int64_t ldx, int6
   }
   const int64_t per_wg = (int64_t)16 * FT * WAVES;
   const int64_t blocks = (T + per_wg - 1) / per_wg;
-  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(WAVES * 64), shmem, st, MODE == 1 ? g->packedU.p : g->packed.p, g->M,
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(WAVES * 64), shmem, st, MODE >= 1 ? g->packedU.p : g->packed.p, g->M,
                      g->D, dX, ldx, T, dY, ldy);
   VCMI_HIP(hipGetLastError());
   return VCMI_OK;
@@ -488,6 +510,8 @@ int gmmmap_posterior_device(vcmi_gmmmap *g, const double *dX, int64_t ldx, int64
 
 int gmmmap_predict_device(vcmi_gmmmap *g, const double *dX, int64_t ldx, int64_t T, int64_t *didx, hipStream_t st) {
   if (T == 0) return VCMI_OK;
+  if (use_mfma(g) && !getenv("VCMI_PREDICT_TWO_PASS"))      // argmax inside the MFMA kernel: no (M,T) matrix, one launch
+    return dispatch_mfma<2>(g, dX, ldx, T, reinterpret_cast<double *>(didx), 0, st);
   VCMI_TRY(g->scratch_lp.reserve((size_t)T * g->M));
   VCMI_TRY(gmmmap_logdens_device(g, dX, ldx, T, g->scratch_lp.p, st));
   hipLaunchKernelGGL(posterior_finish_kernel<1>, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, st, g->scratch_lp.p,
