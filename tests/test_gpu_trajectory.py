@@ -129,3 +129,25 @@ def test_not_positive_definite_normal_matrix(vc, monkeypatch, solver):
     monkeypatch.setenv("VCMI_TRAJ_SOLVER", solver)
     with pytest.raises(vc.PosDefException):
         vc.fvconvert(t, rng.standard_normal((2 * D, T)))
+
+
+def test_more_utterances_than_compute_units(vc):
+    """A batch larger than the device's CU count: workgroups loop over utterances, so every per-utterance piece of
+    workgroup state (window buffers, published-column ring, sequence tags, flags) is re-initialised.  Each result must
+    equal, bit for bit, the single-utterance call."""
+    from oracle import c_oracle as co, np_oracle as npo
+    D, M = 12, 4
+    w, mu, sig = npo.synth_model(4242, 4 * D, M, lam_lo=1e-3)
+    g = vc.GMMMap(*julia_model(w, mu, sig))
+    t = vc.TrajectoryGMMMap(g, 16)
+    rng = np.random.default_rng(11)
+    Ts = rng.integers(1, 17, size=700)
+    Xs = []
+    for T in Ts:
+        static = npo.sample_frames(int(rng.integers(1 << 30)), w, mu, sig, int(T), 0, D)
+        Xs.append(npo.push_delta(static).T)
+    Ys = t.fvconvert_batch(Xs)
+    ref = co.TrajectoryGMMMap(co.GMMMap(w, mu, sig))
+    for i in list(range(0, 700, 37)) + [699]:
+        assert np.array_equal(vc.fvconvert(t, Xs[i]), Ys[i])
+        assert relerr(Ys[i], ref.fvconvert(Xs[i].T)[0].T) < TOL

@@ -58,6 +58,7 @@ struct TrajUtt {
   double *Y;         // (D,T) dense
   int64_t frame0;    // offset of this utterance in the packed per-frame scratch (mhat, g)
   int32_t T;
+  int32_t idx;       // position in the caller's batch (the list is sorted by length before the launch)
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -473,7 +474,8 @@ traj_g_mfma_kernel(const TrajUtt *__restrict__ utts, int n, int D2, int M, int K
     if (T == 0) continue;
     const int64_t *mh = mhat_all + U.frame0;
     double *G = G_all + U.frame0 * D2;
-    int *perm = perm_all + U.frame0 + (int64_t)16 * M * u;
+    // regions indexed by the utterance's position in the batch (frame0 grows with it): disjoint whatever the launch order
+    int *perm = perm_all + U.frame0 + (int64_t)16 * M * U.idx;
     // frames grouped by mixture; the order inside a group (atomics) is irrelevant, each frame is computed on its own
     for (int m = tid; m < M; m += nthr) cnt[m] = 0;
     __syncthreads();
@@ -996,7 +998,7 @@ static int traj_host_batch(vcmi_traj *t, int64_t n, const double *const *X, cons
   int64_t f0 = 0;
   for (int64_t u = 0; u < n; ++u) {
     if (T[u] > 0) memcpy(&hx[(size_t)f0 * D2], X[u], sizeof(double) * D2 * T[u]);
-    utts[u] = TrajUtt{t->xbuf.p + (size_t)f0 * D2, t->ybuf.p + (size_t)f0 * D, f0, (int32_t)T[u]};
+    utts[u] = TrajUtt{t->xbuf.p + (size_t)f0 * D2, t->ybuf.p + (size_t)f0 * D, f0, (int32_t)T[u], (int32_t)u};
     f0 += T[u];
   }
   VCMI_HIP(hipMemcpy(t->xbuf.p, hx.data(), hx.size() * 8, hipMemcpyHostToDevice));
@@ -1113,7 +1115,7 @@ extern "C" int vcmi_traj_convert_batch_dev(vcmi_traj *t, int64_t n, const double
   for (int64_t u = 0; u < n; ++u) {
     if (T[u] < 0 || T[u] > INT32_MAX) return fail(VCMI_ERR_DIM, "trajectory: bad utterance length");
     if (x_off[u] != x_off[0] + f0 * t->D2) contiguous = false;
-    utts[u] = TrajUtt{dX + x_off[u], dY + y_off[u], f0, (int32_t)T[u]};
+    utts[u] = TrajUtt{dX + x_off[u], dY + y_off[u], f0, (int32_t)T[u], (int32_t)u};
     f0 += T[u];
   }
   VCMI_TRY(traj_run(t, utts, f0, contiguous, dX + x_off[0], as_stream(stream)));
@@ -1236,7 +1238,7 @@ extern "C" int vcmi_trajgv_convert_batch_dev(vcmi_trajgv *h, int64_t n, const do
   for (int64_t u = 0; u < n; ++u) {
     if (T[u] < 0 || T[u] > INT32_MAX) return fail(VCMI_ERR_DIM, "trajectory: bad utterance length");
     if (x_off[u] != x_off[0] + f0 * t->D2) contiguous = false;
-    utts[u] = TrajUtt{dX + x_off[u], dY + y_off[u], f0, (int32_t)T[u]};
+    utts[u] = TrajUtt{dX + x_off[u], dY + y_off[u], f0, (int32_t)T[u], (int32_t)u};
     f0 += T[u];
   }
   VCMI_TRY(traj_run(t, utts, f0, contiguous, dX + x_off[0], as_stream(stream), &gv));
