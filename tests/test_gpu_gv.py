@@ -125,3 +125,23 @@ def test_variance_scaling_and_diffgmm(vc, fixture_model):
     # the differential converter predicts y - x: same posterior, E[y|x] - x
     full = vc.fvconvert(vc.GMMMap(*julia_model(w, mu, sig)), X.T)
     assert relerr(y, full - X.T) < 1e-6
+
+
+def test_gv_more_utterances_than_compute_units(vc):
+    """Ragged batch larger than the CU count: every workgroup runs several utterances one after the other; each result
+    equals the single-utterance call bit for bit (the frame order inside a mixture group comes from atomics, but each
+    frame's product is computed independently)."""
+    from oracle import c_oracle as co, np_oracle as npo
+    D, M = 12, 4
+    w, mu, sig = npo.synth_model(911, 4 * D, M, lam_lo=1e-3)
+    ref = co.TrajectoryGMMMap(co.GMMMap(w, mu, sig))
+    t = vc.TrajectoryGMMMap(vc.GMMMap(*julia_model(w, mu, sig)), 40)
+    rng = np.random.default_rng(8)
+    Ts = [int(v) for v in rng.integers(2, 41, size=600)]
+    Xs = _utterances(npo, rng, w, mu, sig, D, Ts)
+    muv, Sv = _gv_stats(rng, ref.fvconvert(Xs[int(np.argmax(Ts))])[0])
+    tgv = vc.TrajectoryGVGMMMap(t, muv, Sv)
+    got = tgv.fvconvert_batch([x.T for x in Xs], epochs=7, alpha=1.0e-5)
+    for i in list(range(0, 600, 41)) + [599]:
+        assert np.array_equal(vc.fvconvert(tgv, Xs[i].T, epochs=7, alpha=1.0e-5), got[i])
+        assert relerr(got[i], ref.fvconvert_gv(Xs[i], muv, Sv, 7, 1.0e-5).T) < TOL
