@@ -11,14 +11,15 @@
 //      lower triangular -- the only part of the algorithm that is sequential in the scalar columns;
 //   2. L10 = S10 U', L20 = S20 U'                                  (MFMA, in place; U' is triangular: k-steps skipped)
 //   3. S11 -= L10 L10', S21 -= L20 L10', S22 -= L20 L20'          (MFMA, lower tiles only for the symmetric ones)
-//   4. the panel [U; L10; z0; L20] goes to the HBM workspace, the window shifts by pointer rotation and block row
-//      t+3 is assembled from the stencil.
+//   4. the panel [M1 = L10 U (last row: h = U' z0); M2 = L20 U] goes to the HBM workspace, the window shifts by pointer
+//      rotation and block row t+3 is assembled from the stencil.
 // Only L10 and the S11 update feed the next pivot; everything else of step t runs one step late on the other two waves,
 // beside pivot(t+1) (schedule: see the kernel).
 // The right-hand side needs no code of its own: r_b lives in row D (a padding row of the 16-row tiles) of S_bb, a copy
 // of r0 is put in row D of S10 and S20, and then row D of L10 / L20 is z0 = U r0 and the updates of step 3 apply
 // r1 -= L10 z0, r2 -= L20 z0 to row D of S11 / S22.
-// Back substitution: y_t = U' (z0 - L10' y_{t+1} - L20' y_{t+2}) -- two matrix-vector products, no sequential chain.
+// Back substitution: y_t = U' (z0 - L10' y_{t+1} - L20' y_{t+2}) = h - M1' y_{t+1} - M2' y_{t+2} -- one matrix-vector
+// product per step, no sequential chain.
 // Cycle counters per phase: build with -DTRAJ_BLK_PROF (make EXTRA=-DTRAJ_BLK_PROF), printed to stderr per call.
 #pragma once
 
@@ -33,7 +34,7 @@ struct BlkCfg {
   static constexpr int CB = 64;                         // wave U's published column of U', permuted
   static constexpr int RING = D * 64;                   // wave S's published columns: one 64-double slot each (entries 6, 7 of a lane group: pivot, tag)
   static constexpr int JOINCOL = D < 9 ? D - 1 : 7;   // pivot column after which the pivot waves join the mid-phase barrier
-  static constexpr size_t PAN = (size_t)(3 * D + 1) * D;   // panel doubles per block step: U (D,D), L10 (D+1,D) incl. z0, L20 (D,D)
+  static constexpr size_t PAN = (size_t)(2 * D + 1) * D;   // panel doubles per block step: M1 = L10 U (D+1,D) incl. h = U' z0, M2 = L20 U (D,D)
   static constexpr size_t WORK = 6 * (size_t)BUF > 3 * PAN ? 6 * (size_t)BUF : 3 * PAN;   // six window buffers / three staged panels
   static constexpr size_t lds_doubles = WORK + CB + RING + 2 * D + 768 + 2;
 };
@@ -301,20 +302,53 @@ __device__ __forceinline__ void blk_update_tile(double *Cm, const double *X, con
   for (int r = 0; r < 4; ++r) cp[4 * r * LS] = keep ? acc[r] + acc2[r] : 0.0;
 }
 
-// Back substitution from the panels in the HBM workspace: y_t = U' (z0 - L10' y_{t+1} - L20' y_{t+2}).
-// The loop is bound by the HBM read of the panels (38.7 KB per step at D = 40), so they are requested two steps ahead:
-// global -> registers at the start of a step (two register sets alternate), registers -> one of three LDS slots at the
-// end of the next one.  The results are collected in LDS and written out every 8 steps, followed by an explicit wait:
-// a global store pending beside the panel loads would make every wait of the loop a wait for all of them (loads and
-// stores share the vmcnt counter and may complete out of order).
-// Both products are split over the four waves (lane = column, wave = quarter of the rows) and summed in fixed order.
+// row tile `it` of  L U  (U lower triangular: column tile jt needs only k >= 16 jt) straight from the accumulators to
+// the HBM panel `out` (row-major, D columns): rows < nrows, columns < D.  The A fragments of the row tile are read
+// once; the column tiles are independent MFMA chains.
+template <int D>
+__device__ __forceinline__ void blk_lu_rowtile_to_panel(const double *L, const double *U, int it, int nrows,
+                                                        double *__restrict__ out, int lane) {
+  using C = BlkCfg<D>;
+  constexpr int LS = C::LS, KS = C::KS, NT = C::NT;
+  const int lrow = lane & 15, lq = lane >> 4;
+  double a[KS];
+  const double *xa = L + (16 * it + lrow) * LS + lq;
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) a[ks] = xa[4 * ks];
+  blk_d4 acc[NT];
+#pragma unroll
+  for (int jt = 0; jt < NT; ++jt) acc[jt] = blk_d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+    for (int jt = 0; jt < NT; ++jt)
+      if (ks >= 4 * jt) acc[jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], U[(4 * ks + lq) * LS + 16 * jt + lrow], acc[jt], 0, 0, 0);
+#pragma unroll
+  for (int jt = 0; jt < NT; ++jt) {
+    const int col = 16 * jt + lrow;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = 16 * it + 4 * r + lq;
+      if (col < D && row < nrows) out[row * D + col] = acc[jt][r];
+    }
+  }
+}
+
+// Back substitution from the panels in the HBM workspace:
+//   y_t = U' (z0 - L10' y_{t+1} - L20' y_{t+2}) = h - M1' y_{t+1} - M2' y_{t+2},   M1 = L10 U, M2 = L20 U, h = U' z0
+// (formed by the deferred team of the factorisation): one product per step, split over the four waves (lane = column,
+// wave = quarter of the rows) and summed in fixed order.  The loop is bound by the HBM read of the panels (25.9 KB per
+// step at D = 40), so they are requested two steps ahead: global -> registers at the start of a step (two register sets
+// alternate), registers -> one of three LDS slots at the end of the next one.  The results are collected in LDS and
+// written out every 8 steps, followed by an explicit wait: a global store pending beside the panel loads would make
+// every wait of the loop a wait for all of them (loads and stores share the vmcnt counter).
 template <int D>
 __device__ void blk_backsub(const double *__restrict__ ws, int T, double *buf, double *yring, double *part,
                             double *__restrict__ Y) {
   using C = BlkCfg<D>;
   constexpr int PAN = (int)C::PAN;
   constexpr int NPRE = (PAN + 255) / 256;
-  constexpr int OU = 0, OL1 = D * D, OZ = 2 * D * D, OL2 = (2 * D + 1) * D;
+  constexpr int OH = D * D, OM2 = (D + 1) * D;
   constexpr int YB = 8;                    // steps per result flush
   const int tid = threadIdx.x, j = tid & 63, p = tid >> 6;
   double *ybuf = part + 320;               // [YB][D]
@@ -340,39 +374,23 @@ __device__ void blk_backsub(const double *__restrict__ ws, int T, double *buf, d
   stage(T - 1, ra);
   if (T >= 2) fetch(T - 2, ra);
   __syncthreads();
-  constexpr int R1 = (2 * D + 3) / 4;      // rows of [L10; L20] per wave
-  constexpr int R2 = (D + 3) / 4;          // rows of U per wave
+  constexpr int R1 = (2 * D + 3) / 4;      // rows of [M1; M2] per wave
   auto step = [&](int t, double (&cur)[NPRE], double (&nxt)[NPRE]) {
     // `cur` holds panel t-1 (requested one step ago), `nxt` receives panel t-2
     if (t >= 2) fetch(t - 2, nxt);
     const double *pb = buf + (size_t)(t % 3) * PAN;
     double *y1 = yring + ((t + 1) & 1) * D, *y2 = yring + (t & 1) * D;   // y_{t+1}, y_{t+2}
     const int jc = j < D ? j : D - 1;
-    {   // partial sums of z0 - [L10; L20]' [y_{t+1}; y_{t+2}]: compile-time trip count, all LDS reads issued up front
-      double s0 = (p == 0) ? pb[OZ + jc] : 0.0, s1 = 0.0;
+    {   // partial sums of h - [M1; M2]' [y_{t+1}; y_{t+2}]: compile-time trip count, all LDS reads issued up front
+      double s0 = (p == 0) ? pb[OH + jc] : 0.0, s1 = 0.0;
       const int r_lo = p * R1;
 #pragma unroll
       for (int q = 0; q < R1; ++q) {
         const int r = r_lo + q, rc = r < 2 * D ? r : 0;                  // wave-uniform
-        const double *row = rc < D ? pb + OL1 + rc * D : pb + OL2 + (rc - D) * D;
+        const double *row = rc < D ? pb + rc * D : pb + OM2 + (rc - D) * D;
         const double l = row[jc], yv = rc < D ? y1[rc] : y2[rc - D];
         if (q & 1) s1 = fma(r < 2 * D ? -l : 0.0, yv, s1);
         else s0 = fma(r < 2 * D ? -l : 0.0, yv, s0);
-      }
-      part[p * 64 + j] = s0 + s1;
-    }
-    __syncthreads();
-    if (tid < D) part[256 + tid] = ((part[tid] + part[64 + tid]) + part[128 + tid]) + part[192 + tid];   // w
-    __syncthreads();
-    {   // partial sums of U' w (U is stored with its zeros above the diagonal)
-      double s0 = 0.0, s1 = 0.0;
-      const int r_lo = p * R2;
-#pragma unroll
-      for (int q = 0; q < R2; ++q) {
-        const int r = r_lo + q, rc = r < D ? r : 0;
-        const double ue = pb[OU + rc * D + jc], wv = part[256 + rc];
-        if (q & 1) s1 = fma(r < D ? ue : 0.0, wv, s1);
-        else s0 = fma(r < D ? ue : 0.0, wv, s0);
       }
       part[p * 64 + j] = s0 + s1;
     }
@@ -399,7 +417,7 @@ __device__ void blk_backsub(const double *__restrict__ ws, int T, double *buf, d
 // Workgroup schedule of block step t (4 waves, one per SIMD; the scalar-column pivot is the critical path, so
 // everything that does not feed the next pivot is deferred by one step and runs beside it):
 //   phase 1   waves 0, 1: pivot(t) (Cholesky of S00 / its inverse U)
-//             waves 2, 3: L20(t-1) | S21, S22 updates (t-1) | panel t-1 -> HBM, block row t+2 of the stencil
+//             waves 2, 3: L20(t-1) | S21, S22 updates (t-1) | panel t-1 = [L10 U; L20 U] -> HBM, block row t+2 of the stencil
 //                         fetched and, after the barrier, written into the three freed buffers
 //   phase 2   all:        L10(t) = S10 U', then S11 -= L10 L10'   (-> S00 of step t+1)
 // Buffers: b00, b10, b11 (window of step t) and p0, p1, p2 = U, L10, S20 -> L20 of step t-1, then block row t+2.
@@ -430,13 +448,12 @@ traj_solve_blk_kernel(const TrajUtt *__restrict__ utts, int n, const double *__r
   // a mixture's Q matrix, offset in a panel block -- a lone wave pays ~6 cycles per VALU instruction, so index
   // arithmetic is kept out of the step loop
   const int dt = tid - 64 * (4 - NDW);
-  int eo[NIT], eq[NIT], ep[NIT];
+  int eo[NIT], eq[NIT];
 #pragma unroll
   for (int k = 0; k < NIT; ++k) {
     const int e = VW * (dt + NDT * k), ec = (e >= 0 && e < D * D) ? e : 0, i = ec / D, j = ec - i * D;
     eo[k] = (e >= 0 && e < D * D) ? i * LS + j : -1;
     eq[k] = i * D2 + j;
-    ep[k] = ec;
   }
   typedef double ev_t __attribute__((ext_vector_type(VW)));
 
@@ -532,16 +549,13 @@ traj_solve_blk_kernel(const TrajUtt *__restrict__ utts, int n, const double *__r
         const int jr = dt < D ? dt : D - 1;
         const double g0 = g[(size_t)ac * D2 + jr], g1 = g[(size_t)am * D2 + D + jr], g2 = g[(size_t)ap * D2 + D + jr];
         BLK_PROF_AT(10, 128);
-        if (defer) {   // panel t-1 -> HBM (reads only: no barrier against the products above)
+        if (defer) {   // panel t-1 -> HBM: M1 = L10 U (row D: h = U' z0) and M2 = L20 U, formed here so that the back
+                       // substitution is one product per step on a 2/3-size panel (reads only: no barrier needed)
           double *pan = ws + (size_t)(t - 1) * PAN;
-#pragma unroll
-          for (int k = 0; k < NIT; ++k)
-            if (eo[k] >= 0) {
-              *reinterpret_cast<ev_t *>(pan + ep[k]) = *reinterpret_cast<const ev_t *>(p0 + eo[k]);
-              *reinterpret_cast<ev_t *>(pan + D * D + ep[k]) = *reinterpret_cast<const ev_t *>(p1 + eo[k]);
-              *reinterpret_cast<ev_t *>(pan + (2 * D + 1) * D + ep[k]) = *reinterpret_cast<const ev_t *>(p2 + eo[k]);
-            }
-          if (dt < D) pan[2 * D * D + dt] = p1[D * LS + dt];      // z0 = row D of L10
+          for (int job = dw; job < 2 * NT; job += NDW) {
+            if (job < NT) blk_lu_rowtile_to_panel<D>(p1, p0, job, D + 1, pan, lane);
+            else blk_lu_rowtile_to_panel<D>(p2, p0, job - NT, D, pan + (D + 1) * D, lane);
+          }
         }
         BLK_PROF_AT(11, 128);
         const double w4 = hasp ? 0.25 : 0.0, w2 = hasp ? 0.5 : 0.0, lv = live ? 1.0 : 0.0;
