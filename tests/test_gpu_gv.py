@@ -145,3 +145,23 @@ def test_gv_more_utterances_than_compute_units(vc):
     for i in list(range(0, 600, 41)) + [599]:
         assert np.array_equal(vc.fvconvert(tgv, Xs[i].T, epochs=7, alpha=1.0e-5), got[i])
         assert relerr(got[i], ref.fvconvert_gv(Xs[i], muv, Sv, 7, 1.0e-5).T) < TOL
+
+
+def test_one_team_and_two_team_kernels_agree(vc, monkeypatch):
+    """traj_gv2_kernel (gather waves beside the MFMA waves; the default when the frame permutation fits in LDS) against
+    traj_gv_kernel (VCMI_GV_ONE_TEAM=1, the path of very long utterances): same ascent, different thread counts in the
+    moment reductions -> agreement to rounding."""
+    from oracle import c_oracle as co, np_oracle as npo
+    D, M = 20, 6
+    w, mu, sig = npo.synth_model(620, 4 * D, M, lam_lo=1e-3)
+    ref = co.TrajectoryGMMMap(co.GMMMap(w, mu, sig))
+    t = vc.TrajectoryGMMMap(vc.GMMMap(*julia_model(w, mu, sig)), 200)
+    rng = np.random.default_rng(21)
+    Xs = _utterances(npo, rng, w, mu, sig, D, [200, 33, 2])
+    muv, Sv = _gv_stats(rng, ref.fvconvert(Xs[0])[0])
+    tgv = vc.TrajectoryGVGMMMap(t, muv, Sv)
+    two = tgv.fvconvert_batch([x.T for x in Xs], epochs=25, alpha=1.0e-5)
+    monkeypatch.setenv("VCMI_GV_ONE_TEAM", "1")
+    one = tgv.fvconvert_batch([x.T for x in Xs], epochs=25, alpha=1.0e-5)
+    for a, b in zip(two, one):
+        assert relerr(a, b) < 1e-10

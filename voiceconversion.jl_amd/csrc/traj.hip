@@ -792,6 +792,229 @@ traj_gv_kernel(const TrajUtt *__restrict__ utts, int n, int D, int M, int KS, co
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// traj_gv2_kernel: the same ascent with the product phase run by TWO teams of waves.  With one workgroup per CU the
+// product rounds of traj_gv_kernel are a chain  gather (memory latency) -> barrier -> MFMA + store -> barrier;  here
+// waves NT..2NT-1 gather the rows of y for round r+1 into the other of two LDS images of u while waves 0..NT-1 run the
+// MFMAs of round r -- one barrier per round, and the streaming passes (scaling, update, moments) run on twice the
+// threads.  The frame permutation and the tile mixtures live in LDS (no dependent global load in the rounds), which
+// bounds the utterance length; longer utterances take traj_gv_kernel.
+// ------------------------------------------------------------------------------------------------
+static constexpr int kGv2NB = 4;     // 16-frame tiles per round
+static constexpr int kGv2Threads = 768;   // 12 waves: NT = ceil(2D/16) MFMA waves, the rest gather (three waves per SIMD: 168 VGPRs)
+
+__global__ void __launch_bounds__(kGv2Threads)
+traj_gv2_kernel(const TrajUtt *__restrict__ utts, int n, int D, int M, int KS, int pcap, const double *__restrict__ Qfrag,
+                const int64_t *__restrict__ mhat_all, const double *__restrict__ g_all, double *__restrict__ ws_all,
+                int64_t ws_stride, TrajGV gv) {
+  extern __shared__ double gsm[];
+  const int D2 = 2 * D, nthr = blockDim.x, NT = (D2 + 15) / 16, nmf = 64 * NT, ngth = nthr - nmf;
+  const int UTS = 4 * KS * 17, UTR = kGv2NB * UTS;
+  double *Ut = gsm;                        // [2][kGv2NB][4*KS][17]  u of the tiles' frames, k-major, row stride 17
+  double *red = Ut + 2 * (size_t)UTR;      // [2][nthr]
+  double *mean = red + 2 * nthr;           // [D]
+  double *var = mean + D;                  // [D]
+  double *coef = var + D;                  // [D]
+  int *cnt = reinterpret_cast<int *>(coef + D);   // [M] frames per mixture, then the fill cursor
+  int *start = cnt + M;                           // [M] first slot of the mixture's (16-padded) segment
+  int *perm = start + M;                          // [pcap] frames grouped by mixture, segments padded to 16 with -1
+  int *tilem = perm + pcap;                       // [pcap / 16 + 1] mixture of every tile
+  __shared__ int ntiles_s;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lcol = lane & 15, lgrp = lane >> 4;
+  const bool gatherer = wave >= NT;
+  const int gtid = tid - nmf;
+
+  for (int u = blockIdx.x; u < n; u += gridDim.x) {
+    const TrajUtt U = utts[u];
+    const int T = U.T;
+    if (T < 2) continue;                   // var() of one frame is undefined; the host rejects such calls
+    const int64_t *mh = mhat_all + U.frame0;
+    const double *g = g_all + U.frame0 * D2;
+    double *y = U.Y;
+    double *V = ws_all + (size_t)blockIdx.x * ws_stride;   // [T][2D]
+    double *R = V + (size_t)T * D2;                        // [T][D]   r = W' D^-1 E
+    const double omega = 1.0 / (2.0 * (double)T);
+
+    // frames grouped by mixture (see traj_gv_kernel)
+    for (int m = tid; m < M; m += nthr) cnt[m] = 0;
+    __syncthreads();
+    for (int t = tid; t < T; t += nthr) atomicAdd(&cnt[(int)mh[t] - 1], 1);
+    __syncthreads();
+    if (tid == 0) {
+      int pos = 0;
+      for (int m = 0; m < M; ++m) {
+        start[m] = pos;
+        pos += (cnt[m] + 15) / 16 * 16;
+        cnt[m] = 0;
+      }
+      ntiles_s = pos / 16;
+    }
+    __syncthreads();
+    const int ntiles = ntiles_s;
+    for (int e = tid; e < ntiles * 16; e += nthr) perm[e] = -1;
+    __syncthreads();
+    for (int t = tid; t < T; t += nthr) {
+      const int m = (int)mh[t] - 1;
+      perm[start[m] + atomicAdd(&cnt[m], 1)] = t;
+    }
+    __syncthreads();
+    for (int i = tid; i < ntiles; i += nthr) tilem[i] = (int)mh[perm[i * 16]] - 1;
+    for (int e = tid; e < 2 * UTR; e += nthr) Ut[e] = 0.0;      // rows k >= 2D of the k-padding stay zero
+    // elements of u a gather thread fetches in a round: e = gtid + i * ngth -> (frame slot e / 2D, k = e % 2D), k fastest
+    // across threads; one division here, increments in the rounds
+    const int gsl0 = gatherer ? gtid / D2 : 0, gk0 = gatherer ? gtid % D2 : 0, dsl = ngth / D2, dk = ngth % D2;
+
+    // eq. (58) and r; every pass that writes y accumulates the moments of what it writes (see traj_gv_kernel)
+    gv_moments(y, D, T, nthr, red, mean, var);
+    const int NGm = nthr / D, dm = tid % D, gm = tid / D;
+    auto finish_moments = [&](double s1, double s2) {
+      if (gm < NGm) {
+        red[gm * D + dm] = s1;
+        red[nthr + gm * D + dm] = s2;
+      }
+      __syncthreads();
+      if (tid < D) {
+        double a1 = 0.0, a2 = 0.0;
+        for (int k = 0; k < NGm; ++k) {
+          a1 += red[k * D + tid];
+          a2 += red[nthr + k * D + tid];
+        }
+        mean[tid] += a1 / (double)T;
+        var[tid] = (a2 - a1 * a1 / (double)T) / (double)(T - 1);       // Julia's var: corrected
+      }
+      __syncthreads();
+    };
+    {
+      double s1 = 0.0, s2 = 0.0;
+      if (gm < NGm) {
+        const double mu = mean[dm], sc = sqrt(gv.muv[dm] / var[dm]);
+#pragma unroll 4
+        for (int t = gm; t < T; t += NGm) {
+          const size_t e = (size_t)t * D + dm;
+          const int tm = t >= 1 ? t - 1 : t, tp = t + 1 < T ? t + 1 : t;
+          const double yo = y[e], g0 = g[(size_t)t * D2 + dm], g1 = g[(size_t)tm * D2 + D + dm], g2 = g[(size_t)tp * D2 + D + dm];
+          const double yn = sc * (yo - mu) + mu;
+          y[e] = yn;
+          R[e] = (g0 + (t >= 1 ? 0.5 : 0.0) * g1) - (t + 1 < T ? 0.5 : 0.0) * g2;
+          const double dv = yn - mu;
+          s1 += dv;
+          s2 = fma(dv, dv, s2);
+        }
+      }
+      __syncthreads();
+      finish_moments(s1, s2);
+    }
+
+    // gather of one round into an LDS image of u: two unconditional loads per element on clamped addresses, eight
+    // elements in flight, 0 / 1 / +-1/2 weights applied on the way into LDS
+    auto gather = [&](int r, double *Ub0) {
+      const int tile0 = r * kGv2NB, total = 16 * kGv2NB * D2;
+      int sl = gsl0, k = gk0;
+      for (int e = gtid; e < total; e += 8 * ngth) {
+        double ya[8], yc[8];
+        int tt[8], oo[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const bool in = e + i * ngth < total;
+          const int idx = tile0 * 16 + sl;
+          const int t = (in && idx < ntiles * 16) ? perm[idx] : -1;
+          tt[i] = (t < 0 ? -1 : t) | (k < D ? 0 : 1 << 30);         // frame and static / delta half
+          oo[i] = in ? ((sl >> 4) * 4 * KS + k) * 17 + (sl & 15) : -1;
+          const bool st = k < D;
+          const int tc = t >= 0 ? t : 0, kd = st ? k : k - D;
+          const int tp = tc + 1 < T ? tc + 1 : tc, tm = tc >= 1 ? tc - 1 : tc;
+          ya[i] = y[(size_t)(st ? tc : tp) * D + kd];
+          yc[i] = y[(size_t)(st ? tc : tm) * D + kd];
+          sl += dsl;
+          k += dk;
+          if (k >= D2) {
+            k -= D2;
+            ++sl;
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          if (oo[i] >= 0) {
+            const bool ok = tt[i] >= 0, st = (tt[i] & (1 << 30)) == 0;
+            const int t = tt[i] & ~(1 << 30);
+            const double wa = !ok ? 0.0 : (st ? 1.0 : (t + 1 < T ? 0.5 : 0.0)), wc = (!ok || st) ? 0.0 : (t >= 1 ? -0.5 : 0.0);
+            Ub0[oo[i]] = wa * ya[i] + wc * yc[i];
+          }
+      }
+    };
+
+    double afr[kGvMaxKS];
+    int mcur = -1;
+    const int nrounds = (ntiles + kGv2NB - 1) / kGv2NB;
+    BLK_PROF_T0();
+    for (int ep = 0; ep < gv.epochs; ++ep) {
+      // gvgrad coefficients, src/trajectory_gmmmap.jl:171-189: -2/T (pv' (var(y) - mu^v)), times (y - mean) below
+      if (tid < D) {
+        double s = 0.0;
+        for (int j = 0; j < D; ++j) s = fma(gv.pv[j + (size_t)D * tid], var[j] - gv.muv[j], s);
+        coef[tid] = -2.0 / (double)T * s;
+      }
+      // v_t = Q_mhat_t u_t for every frame
+      if (gatherer) gather(0, Ut);
+      __syncthreads();
+      for (int r = 0; r < nrounds; ++r) {
+        if (gatherer) {
+          if (r + 1 < nrounds) gather(r + 1, Ut + (size_t)((r + 1) & 1) * UTR);
+        } else {
+          const double *Ub0 = Ut + (size_t)(r & 1) * UTR;
+          const int tile0 = r * kGv2NB, nb = (ntiles - tile0 < kGv2NB) ? ntiles - tile0 : kGv2NB;
+          for (int b = 0; b < nb; ++b) {
+            const int m = tilem[tile0 + b];
+            if (m != mcur) {                               // Q fragments of this wave's row tile, kept while tiles share m
+              mcur = m;
+              const double *A = Qfrag + (((size_t)m * NT + wave) * KS) * 64 + lane;
+#pragma unroll
+              for (int ks = 0; ks < kGvMaxKS; ++ks) afr[ks] = (ks < KS) ? A[(size_t)ks * 64] : 0.0;
+            }
+            const double *Ub = Ub0 + (size_t)b * UTS;
+            gv_d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int ks = 0; ks < kGvMaxKS; ++ks)
+              if (ks < KS) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(afr[ks], Ub[(4 * ks + lgrp) * 17 + lcol], acc, 0, 0, 0);
+            const int t = perm[(tile0 + b) * 16 + lcol];
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+              const int row = 16 * wave + lgrp + 4 * r4;
+              if (row < D2 && t >= 0) V[(size_t)t * D2 + row] = acc[r4];
+            }
+          }
+        }
+        __syncthreads();
+      }
+      BLK_PROF(13);
+      // y <- y + alpha * ( omega (r - P y) + coef (y - mean) ), eq. (52), src/trajectory_gmmmap.jl:163-166
+      double s1 = 0.0, s2 = 0.0;
+      if (gm < NGm) {
+        const double mu = mean[dm], cf = coef[dm];
+#pragma unroll 4
+        for (int t = gm; t < T; t += NGm) {
+          const size_t e = (size_t)t * D + dm;
+          const int tm = t >= 1 ? t - 1 : t, tp = t + 1 < T ? t + 1 : t;
+          const double vs = V[(size_t)t * D2 + dm], vm = V[(size_t)tm * D2 + D + dm], vp = V[(size_t)tp * D2 + D + dm];
+          const double yy = y[e], rr = R[e];
+          const double py = (vs + (t >= 1 ? 0.5 : 0.0) * vm) - (t + 1 < T ? 0.5 : 0.0) * vp;
+          const double dy = omega * (rr - py) + cf * (yy - mu);
+          const double yn = fma(gv.alpha, dy, yy);
+          y[e] = yn;
+          const double dv = yn - mu;
+          s1 += dv;
+          s2 = fma(dv, dv, s2);
+        }
+      }
+      __syncthreads();
+      BLK_PROF(14);
+      finish_moments(s1, s2);
+      BLK_PROF(15);
+    }
+  }
+}
+
 // fvpostf!(vs::VarianceScaling, src), src/gv.jl:10-15, for a matrix of any length: three streaming passes (sums,
 // centred squares, scale) over frame chunks, every reduction in a fixed order (deterministic).
 //   vs_partial_kernel: part[chunk][d] = sum over the chunk's frames of x (MODE 0) or (x - mean[d])^2 (MODE 1)
@@ -945,12 +1168,24 @@ static int traj_run(vcmi_traj *t, std::vector<TrajUtt> &utts, int64_t nframes, b
   VCMI_HIP(hipGetLastError());
   if (gv && gv->epochs >= 0) {
     // (3) global-variance ascent on the solved trajectories, in place; workspace: V (2D,T) + r (D,T) <= the panel area
-    const int nthr = 64 * t->NT;
-    const size_t shmem = ((size_t)kGvNB * 4 * t->KS * 16 + 2 * nthr + 3 * (size_t)D) * sizeof(double) + 2 * (size_t)t->M * sizeof(int);
-    VCMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(traj_gv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 (int)shmem));
-    hipLaunchKernelGGL(traj_gv_kernel, dim3(grid), dim3(nthr), shmem, st, du, n, D, t->M, t->KS, t->Qfrag.p, t->mhat.p, t->gbuf.p,
-                       t->ws.p, ws_stride, *gv);
+    // two-team kernel when the frame permutation of the longest utterance fits in LDS beside the two images of u
+    const int pcap = ((Tmax + 15) / 16 + t->M) * 16;
+    const int nthr2 = kGv2Threads;
+    const size_t shmem2 = ((size_t)2 * kGv2NB * 4 * t->KS * 17 + 2 * nthr2 + 3 * (size_t)D) * sizeof(double) +
+                          (2 * (size_t)t->M + (size_t)pcap + (size_t)pcap / 16 + 2) * sizeof(int);
+    if (shmem2 <= 160 * 1024 - 256 && t->NT <= 6 && !getenv("VCMI_GV_ONE_TEAM")) {
+      VCMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(traj_gv2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)shmem2));
+      hipLaunchKernelGGL(traj_gv2_kernel, dim3(grid), dim3(nthr2), shmem2, st, du, n, D, t->M, t->KS, pcap, t->Qfrag.p, t->mhat.p,
+                         t->gbuf.p, t->ws.p, ws_stride, *gv);
+    } else {
+      const int nthr = 64 * t->NT;
+      const size_t shmem = ((size_t)kGvNB * 4 * t->KS * 16 + 2 * nthr + 3 * (size_t)D) * sizeof(double) + 2 * (size_t)t->M * sizeof(int);
+      VCMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(traj_gv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)shmem));
+      hipLaunchKernelGGL(traj_gv_kernel, dim3(grid), dim3(nthr), shmem, st, du, n, D, t->M, t->KS, t->Qfrag.p, t->mhat.p, t->gbuf.p,
+                         t->ws.p, ws_stride, *gv);
+    }
     VCMI_HIP(hipGetLastError());
   }
   return VCMI_OK;
@@ -965,6 +1200,7 @@ static int traj_check_status(vcmi_traj *t, hipStream_t st) {
     (void)hipMemcpyToSymbol(HIP_SYMBOL(blk_prof), z, sizeof(z));
     fprintf(stderr, "blk_prof cycles: phase1 %lld trsm %lld update %lld backsub %lld | pivot S done at %lld, pivot U at %lld, deferred: S21/S22 at %lld, panel+assembly at %lld\n",
             h[0], h[1], h[2], h[5], h[3], h[4], h[6], h[7]);
+    fprintf(stderr, "   gv kernel: product phase %lld, update %lld, moments %lld\n", h[13], h[14], h[15]);
     fprintf(stderr, "   deferred wave 2: L20 done %lld, past barrier %lld, S21/S22 done %lld, loads issued %lld, panel stored %lld, combined %lld\n", h[8], h[9],
             h[6], h[10], h[11], h[7]);
   }
