@@ -482,12 +482,12 @@ def bench_traj(args, world, rank, gv=False):
            "config": {"workload": ("TrajectoryGVGMMMap fvconvert, 100 epochs (SURVEY 8f rank 2)" if gv else
                                    "TrajectoryGMMMap fvconvert (BASELINE configs[4])"), "static_D": D, "M": M, "T": T,
                       "utterances_per_gpu": n},
-           "roofline": {"bound": "mfma", "kernel": "predict + traj_g_mfma_kernel + traj_solve_blk_kernel<40>" + (" + traj_gv_kernel" if gv else ""),
+           "roofline": {"bound": "mfma", "kernel": "predict + traj_g_mfma_kernel + traj_solve_blk_kernel<40>" + (" + traj_gv2_kernel" if gv else ""),
                         "achieved": achieved,
                         "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS,
                         "traffic": (sum(pmc_traffic(("trajgv" if gv else "traj") + "_traffic.json", k, "r01e_pmc") or 0
                                         for k in ("gmmmap_mfma_kernel", "posterior_finish_kernel", "traj_g_mfma_kernel",
-                                                  "traj_solve_blk_kernel", "traj_gv_kernel")) or None) if n == 256 else None,
+                                                  "traj_solve_blk_kernel", "traj_gv_kernel", "traj_gv2_kernel")) or None) if n == 256 else None,
                         "traffic_unit": "bytes per step, all kernels (rocprofv3 FETCH_SIZE+WRITE_SIZE, profiles/r01e_pmc/)",
                         "flop_per_utterance": flops_per_utt, "kernel_ms": kernel_ms,
                         "note": "whole pipeline (3 kernels); the banded solve is a 2000-step sequential block recurrence "
