@@ -61,6 +61,10 @@ struct TrajUtt {
   int32_t idx;       // position in the caller's batch (the list is sorted by length before the launch)
 };
 
+// A pointer read from a descriptor in memory has no known address space: every access through it is a FLAT
+// instruction (both wait counters, no saddr form).  The utterance matrices are global memory: say so.
+typedef double __attribute__((address_space(1))) gdouble;
+
 // ------------------------------------------------------------------------------------------------
 // g_t = Q_mhat (A_mhat x_t + b_mhat): one workgroup per frame, thread r owns output row r
 // ------------------------------------------------------------------------------------------------
@@ -556,7 +560,8 @@ traj_g_mfma_kernel(const TrajUtt *__restrict__ utts, int n, int D2, int M, int K
 // of Q; the tile's frames usually share one or two mixtures, so the product is accumulated over the DISTINCT
 // mixtures of the tile with the B operand masked to that mixture's frames (exact: the other frames add 0).
 // ------------------------------------------------------------------------------------------------
-__device__ void gv_moments(const double *__restrict__ y, int D, int T, int nthr, double *red, double *mean, double *var) {
+template <typename YP>
+__device__ void gv_moments(YP y, int D, int T, int nthr, double *red, double *mean, double *var) {
   const int tid = threadIdx.x;
   const int NG = nthr / D;                 // frame groups per dimension
   const int d = tid % D, g = tid / D;
@@ -639,7 +644,7 @@ traj_gv_kernel(const TrajUtt *__restrict__ utts, int n, int D, int M, int KS, co
     if (T < 2) continue;                   // var() of one frame is undefined; the host rejects such calls
     const int64_t *mh = mhat_all + U.frame0;
     const double *g = g_all + U.frame0 * D2;
-    double *y = U.Y;
+    gdouble *y = (gdouble *)U.Y;
     double *V = ws_all + (size_t)blockIdx.x * ws_stride;   // [T][2D]
     double *R = V + (size_t)T * D2;                        // [T][D]   r = W' D^-1 E
     int *perm = reinterpret_cast<int *>(R + (size_t)T * D); // frames grouped by mixture, segments padded to 16 with -1
@@ -831,7 +836,7 @@ traj_gv2_kernel(const TrajUtt *__restrict__ utts, int n, int D, int M, int KS, i
     if (T < 2) continue;                   // var() of one frame is undefined; the host rejects such calls
     const int64_t *mh = mhat_all + U.frame0;
     const double *g = g_all + U.frame0 * D2;
-    double *y = U.Y;
+    gdouble *y = (gdouble *)U.Y;
     double *V = ws_all + (size_t)blockIdx.x * ws_stride;   // [T][2D]
     double *R = V + (size_t)T * D2;                        // [T][D]   r = W' D^-1 E
     const double omega = 1.0 / (2.0 * (double)T);
