@@ -1,6 +1,7 @@
 """CPU: the C oracle (oracle/vc_oracle.c) against the committed golden vectors and the reference's own KATs;
 numpy restatement spot checks.  No GPU, no /root/reference."""
 import numpy as np
+import pytest
 import scipy.sparse as sp
 
 from conftest import load_golden, relerr
@@ -149,3 +150,17 @@ def test_align_mcep_golden():
     s, t = co.align_mcep(z["src"], z["tgt"], 0.41, 256)
     assert np.array_equal(s, z["src_kept"]) and np.array_equal(t, z["tgt_kept"]) and 0 < len(s) < 60
     assert np.array_equal(co.joint_features(s, t, True, True, True), z["joint"])
+
+
+@pytest.mark.parametrize("D,M,T", [(12, 4, 17), (16, 4, 9), (25, 4, 12), (32, 3, 8), (12, 4, 1), (12, 4, 2)])
+def test_trajectory_two_restatements_agree(D, M, T):
+    """The two independent restatements of src/trajectory_gmmmap.jl:65-110 -- C (stencil + banded Cholesky) and numpy
+    (explicit sparse W as the reference builds it, block-diagonal D^-1, sparse direct solve) -- on the dimensions the
+    GPU tests run the blocked solver at (one-tile, rhs-row-in-its-own-tile, odd, three-tile), incl. T = 1, 2 where the
+    stencil loses its neighbours.  Neither side is the product; this pins the checker."""
+    w, mu, sig = npo.synth_model(900 + D, 4 * D, M, lam_lo=1e-3)
+    static = npo.sample_frames(7 + T, w, mu, sig, T, 0, D)
+    X = npo.push_delta(static)
+    yc, mc, ec = co.TrajectoryGMMMap(co.GMMMap(w, mu, sig)).fvconvert(X)
+    yn, mn, en = npo.TrajectoryGMMMap(npo.GMMMap(w, mu, sig)).fvconvert(X)
+    assert np.array_equal(mc, mn) and relerr(ec, en) < 1e-10 and relerr(yc, yn) < 1e-7
