@@ -33,7 +33,7 @@ struct BlkCfg {
   static constexpr int NB8 = (D + 7) / 8;               // 8 x 8 lane-grid tiles per dimension (pivot phase)
   static constexpr int CB = 64;                         // wave U's published column of U', permuted
   static constexpr int RING = D * 64;                   // wave S's published columns: one 64-double slot each (entries 6, 7 of a lane group: pivot, tag)
-  static constexpr int JOINCOL = D < 9 ? D - 1 : 7;   // pivot column after which the pivot waves join the mid-phase barrier
+  static constexpr int JOINCOL = D < 11 ? D - 1 : 9;   // pivot column after which the pivot waves join the mid-phase barrier
   static constexpr size_t PAN = (size_t)(2 * D + 1) * D;   // panel doubles per block step: M1 = L10 U (D+1,D) incl. h = U' z0, M2 = L20 U (D,D)
   static constexpr size_t WORK = 6 * (size_t)BUF > 3 * PAN ? 6 * (size_t)BUF : 3 * PAN;   // six window buffers / three staged panels
   static constexpr size_t lds_doubles = WORK + CB + RING + 2 * D + 768 + 2;
