@@ -151,3 +151,25 @@ def test_more_utterances_than_compute_units(vc):
     for i in list(range(0, 700, 37)) + [699]:
         assert np.array_equal(vc.fvconvert(t, Xs[i]), Ys[i])
         assert relerr(Ys[i], ref.fvconvert(Xs[i].T)[0].T) < TOL
+
+
+def test_repeated_runs_are_bit_identical(vc):
+    """The blocked solver's two pivot waves hand columns over through LDS without a barrier (sequence tags), the GV
+    ascent has a gather team beside its MFMA team: any ordering slip would show as run-to-run differences.  A ragged
+    batch converted six times must give the same bits every time."""
+    from oracle import np_oracle as npo
+    D, M = 40, 8
+    w, mu, sig = npo.synth_model(31, 4 * D, M, lam_lo=1e-3)
+    t = vc.TrajectoryGMMMap(vc.GMMMap(*julia_model(w, mu, sig)), 200)
+    rng = np.random.default_rng(1)
+    Xs = []
+    for T in rng.integers(2, 200, size=120):
+        st = npo.sample_frames(int(rng.integers(1 << 30)), w, mu, sig, int(T), 0, D)
+        Xs.append(npo.push_delta(st).T)
+    ref = t.fvconvert_batch(Xs)
+    muv = np.var(ref[0], axis=1, ddof=1) * 1.3 + 1e-3
+    tgv = vc.TrajectoryGVGMMMap(t, muv, np.diag(muv ** 2 * 0.05))
+    refg = tgv.fvconvert_batch(Xs, epochs=4, alpha=1e-5)
+    for _ in range(5):
+        assert all(np.array_equal(a, b) for a, b in zip(t.fvconvert_batch(Xs), ref))
+        assert all(np.array_equal(a, b) for a, b in zip(tgv.fvconvert_batch(Xs, epochs=4, alpha=1e-5), refg))
