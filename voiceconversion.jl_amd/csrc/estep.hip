@@ -160,11 +160,16 @@ estep_mfma_kernel(const double *__restrict__ X, int64_t N, int M, const double *
   auto stage = [&](int64_t f0, double *dst) {
     const char *base = reinterpret_cast<const char *>(X + f0 * DJ);          // workgroup-uniform 64-bit base,
     const int last = (int)((N - 1 - f0 < FB - 1) ? N - 1 - f0 : FB - 1);     // 32-bit per-lane offsets
+    // The per-lane (row, column) of every chunk is loop-invariant; hoisted out of the block loop it costs 9 VGPRs this
+    // kernel does not have -- they were spilled and came back from scratch behind four exposed s_waitcnt vmcnt per
+    // block.  The opaque copy of the lane id makes them a handful of integer instructions per block instead.
+    int lane_v = lane;
+    asm volatile("" : "+v"(lane_v));
 #pragma unroll
     for (int i = 0; i < (NCHUNK + 7) / 8; ++i) {
       const int q = wave + 8 * i;
       if (q < NCHUNK) {                                          // wave-uniform
-        const int o = 1024 * q + 16 * lane, row = o / ROWB, col = o - row * ROWB;
+        const int o = 1024 * q + 16 * lane_v, row = o / ROWB, col = o - row * ROWB;
         const int rowc = row < last ? row : last;
         const unsigned off = (col < DJ * 8) ? (unsigned)(rowc * (DJ * 8) + col) : 0u;
         const char *src = base + off;
