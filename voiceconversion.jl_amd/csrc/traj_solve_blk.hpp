@@ -467,12 +467,15 @@ traj_solve_blk_kernel(const TrajUtt *__restrict__ utts, int n, const double *__r
   constexpr int RT = D / 16;             // row tile that holds the rhs row D
   extern __shared__ __attribute__((aligned(16))) double blk_sm[];
   double *const sm = blk_sm;             // 16-byte LDS accesses in the pivot phase
-  double *cbu = sm + C::WORK;
+  // the pivot pair's exchange areas first: their DS offsets then fit the instructions' 16-bit immediates (behind the
+  // 115 KB of window buffers every access needed its own v_add, ~8 per pivot column)
+  double *cbu = sm;
   double *ring = cbu + C::CB;
   double *yring = ring + C::RING;
   double *part = yring + 2 * D;          // [768]
   int *flags = reinterpret_cast<int *>(part + 768);   // [0] not-PD flag
   int &bad = flags[0];
+  double *const wk = part + 770;         // six window buffers / three staged panels
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
   // per-thread element tables of the deferred team (the same D x D elements every block step): LDS offset, offset in
@@ -495,7 +498,7 @@ traj_solve_blk_kernel(const TrajUtt *__restrict__ utts, int n, const double *__r
     const int64_t *mh = mhat_all + U.frame0;
     const double *g = g_all + U.frame0 * D2;
     double *ws = ws_all + (size_t)blockIdx.x * ws_stride;
-    double *b00 = sm, *b10 = sm + BUF, *b11 = sm + 2 * BUF, *p0 = sm + 3 * BUF, *p1 = sm + 4 * BUF, *p2 = sm + 5 * BUF;
+    double *b00 = wk, *b10 = wk + BUF, *b11 = wk + 2 * BUF, *p0 = wk + 3 * BUF, *p1 = wk + 4 * BUF, *p2 = wk + 5 * BUF;
     if (tid == 0) {
       flags[0] = 0;
       flags[1] = 0;
@@ -631,7 +634,7 @@ traj_solve_blk_kernel(const TrajUtt *__restrict__ utts, int n, const double *__r
         b00 = b11; b10 = f1; b11 = f0;    // S11 -> S00, block (t+2,t+1) -> S10, block (t+2,t+2) -> S11
       }
     }
-    blk_backsub<D>(ws, T, sm, yring, part, U.Y);
+    blk_backsub<D>(ws, T, wk, yring, part, U.Y);
     BLK_PROF(5);
     if (tid == 0 && bad) status[0] = 1;
     __syncthreads();
