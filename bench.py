@@ -58,6 +58,33 @@ def pmc_traffic(fname, kernel_prefix, subdir="r01c_pmc"):
     return None
 
 
+def free_port():
+    import socket
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def self_launch(argv, n_gpus):
+    """`python bench.py --gpus N` with N > 1 and no torchrun environment: start the N ranks ourselves, as the driver
+    would (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same arguments>`), as a CHILD
+    process, and exit with its code.  This runs before anything in this process has touched torch.cuda or HIP (a process
+    that has initialised the GPU must never be replaced or forked into ranks); the launcher itself never imports
+    torch."""
+    import subprocess
+
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    return subprocess.call(cmd, env=env)
+
+
+BACKEND = {"name": None}
+
+
 def dist_setup(n_gpus):
     import torch
     import torch.distributed as dist
@@ -65,28 +92,57 @@ def dist_setup(n_gpus):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != n_gpus:
+        # never report a line whose n_gpus is not the number of ranks that actually ran
+        print(f"bench.py: --gpus {n_gpus} but WORLD_SIZE={world}: refusing to run", file=sys.stderr)
+        sys.exit(2)
     # VCMI_BENCH_DEVICE / VCMI_BENCH_BACKEND exist only to smoke-test the multi-rank code path on a 1-GPU box
-    # (all ranks on one device, gloo); the real launch is one rank per GPU over RCCL ("nccl").
-    dev = int(os.environ.get("VCMI_BENCH_DEVICE", local))
+    # (all ranks on one device, gloo) or on a CPU box (`--workload selftest`); the real launch is one rank per GPU
+    # over RCCL ("nccl").  VCMI_BENCH_FORCE_PG=1 creates the process group even for one rank, so that the RCCL
+    # communicator and its all-reduce are exercised on a 1-GPU box.
     backend = os.environ.get("VCMI_BENCH_BACKEND", "nccl")
-    torch.cuda.set_device(dev)
-    if world > 1:
+    have_gpu = torch.cuda.is_available()
+    dev = int(os.environ.get("VCMI_BENCH_DEVICE", local))
+    if have_gpu:
+        if backend == "nccl" and dev >= torch.cuda.device_count():
+            print(f"bench.py: rank {rank} wants device {dev} but only {torch.cuda.device_count()} visible", file=sys.stderr)
+            sys.exit(2)
+        torch.cuda.set_device(dev)
+        from voiceconversion_jl_amd import _lib
+
+        _lib.set_device(dev)
+    if world > 1 or os.environ.get("VCMI_BENCH_FORCE_PG") == "1":
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(29400 + os.getpid() % 500))
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
         else:
             dist.init_process_group(backend)
+        if dist.get_world_size() != n_gpus:
+            print(f"bench.py: process group has {dist.get_world_size()} ranks, expected {n_gpus}", file=sys.stderr)
+            sys.exit(2)
+        BACKEND["name"] = backend
     return world, rank, local
+
+
+def _dev():
+    import torch
+
+    return "cuda" if torch.cuda.is_available() else "cpu"
 
 
 def barrier_sync(world):
     import torch
     import torch.distributed as dist
 
-    torch.cuda.synchronize()
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
 
 
 def max_over_ranks(x, world):
@@ -95,9 +151,25 @@ def max_over_ranks(x, world):
 
     if world == 1:
         return x
-    t = torch.tensor([x], dtype=torch.float64, device="cuda")
+    t = torch.tensor([x], dtype=torch.float64, device=_dev())
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def gather_over_ranks(x, world):
+    """Every rank's value of x (rank order), on every rank."""
+    import torch
+    import torch.distributed as dist
+
+    if world == 1:
+        return [x]
+    t = torch.zeros(world, dtype=torch.float64, device=_dev())
+    t[dist.get_rank()] = x
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return [float(v) for v in t.tolist()]
+
+
+PER_RANK = {}
 
 
 def timed_steps(step_fn, steps, warmup, world):
@@ -116,6 +188,8 @@ def timed_steps(step_fn, steps, warmup, world):
     barrier_sync(world)
     t1 = time.perf_counter()
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
+    PER_RANK["wall_s"] = gather_over_ranks(t1 - t0, world)
+    PER_RANK["kernel_ms"] = gather_over_ranks(kernel_ms, world)
     return max_over_ranks(t1 - t0, world), kernel_ms
 
 
@@ -222,10 +296,14 @@ def bench_estep(args, world, rank):
 
     Dj, M, N = 80, 128, args.frames if args.frames != 1_000_000 else 1_250_000
     w, mu, _ = npo.synth_model(1003, Dj, M)
-    rg = np.random.default_rng(1003 + rank)
-    var = np.exp(rg.uniform(np.log(1e-3), 0.0, (M, Dj)))
-    comp = rg.choice(M, size=N, p=w)
-    X = mu[comp] + rg.standard_normal((N, Dj)) * np.sqrt(var[comp])
+    var = np.exp(np.random.default_rng(1003).uniform(np.log(1e-3), 0.0, (M, Dj)))   # the model: same on every rank
+
+    def shard_frames(r):                             # rank r's frames, drawn from the model
+        rg = np.random.default_rng(2003 + r)
+        comp = rg.choice(M, size=N, p=w)
+        return mu[comp] + rg.standard_normal((N, Dj)) * np.sqrt(var[comp])
+
+    X = shard_frames(rank)
     Xd = torch.from_numpy(X).cuda()
     out_t = torch.empty(vc.stats_len(Dj, M), dtype=torch.float64, device="cuda")
     muT, varT = np.asfortranarray(mu.T), np.asfortranarray(var.T)
@@ -257,6 +335,14 @@ def bench_estep(args, world, rank):
         out["cpu_baseline"] = {"value": n / dt, "unit": "frames/s", "cores": 1, "kind": "port",
                                "sample": f"first {n} frames, C oracle, {dt:.1f} s on 1 of {os.cpu_count()} host cores"}
         out["parity_max_rel_err_vs_oracle"] = float(np.max(np.abs(S1 - r1.T)) / np.max(np.abs(r1)))
+        if args.verify_allreduce:
+            # the statistics every rank now holds (after the all-reduce) against ONE process over all ranks' frames
+            single = torch.empty_like(out_t)
+            allX = np.concatenate([X] + [shard_frames(r) for r in range(1, world)])
+            vc.estep_diag_dev(torch.from_numpy(allX).cuda().t(), w, muT, varT, out=single)
+            a, b = out_t.cpu().numpy(), single.cpu().numpy()
+            out["allreduce_check"] = {"max_rel_err_vs_single_process": float(np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-300))),
+                                      "frames_total": world * N}
     return out
 
 
@@ -506,28 +592,70 @@ def bench_traj(args, world, rank, gv=False):
     return out
 
 
+def bench_selftest(args, world, rank):
+    """Launch plumbing only (runs without a GPU): rendezvous, barrier-bracketed timed region with a no-op step, the
+    max-over-ranks reduction and one all-reduce(sum) of a rank-dependent statistics-sized vector, checked exactly.  Lets
+    a CPU box verify that `bench.py --gpus N` starts N ranks and reports n_gpus = N (tests/test_bench_launch.py)."""
+    import torch
+    import torch.distributed as dist
+
+    if os.environ.get("VCMI_SELFTEST_DIE_RANK") == str(rank):     # fault injection for tests/test_bench_launch.py
+        sys.exit(3)
+    n = 20_609                                       # the diag E-step payload at Dj=80, M=128
+    v = torch.arange(n, dtype=torch.float64, device=_dev()) * (rank + 1)
+    barrier_sync(world)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        pass
+    barrier_sync(world)
+    wall = max_over_ranks(time.perf_counter() - t0, world)
+    if world > 1:
+        dist.all_reduce(v)
+    expect = torch.arange(n, dtype=torch.float64, device=_dev()) * (world * (world + 1) // 2)
+    ok = bool(torch.equal(v, expect))
+    PER_RANK["wall_s"] = gather_over_ranks(wall, world)
+    return {"metric": "launch self-test (no kernels)", "value": 0.0, "unit": "n/a", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": wall / max(args.steps, 1) * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic", "config": {"workload": "selftest"},
+            "allreduce_exact": ok}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="convert", choices=["convert", "estep", "estep_full", "em_full", "dtw", "traj", "trajgv"])
+    ap.add_argument("--workload", default="convert",
+                    choices=["convert", "estep", "estep_full", "em_full", "dtw", "traj", "trajgv", "selftest"])
     ap.add_argument("--frames", type=int, default=1_000_000, help="frames per GPU (BASELINE: 10^6)")
     ap.add_argument("--pairs", type=int, default=1000, help="DTW pairs per GPU")
     ap.add_argument("--utts", type=int, default=256, help="trajectory utterances per GPU")
+    ap.add_argument("--chunk", type=int, default=0, help="traj: convert in vc() chunks of this many frames "
+                    "(bin/vc.jl:18 default --T=100); 0 = whole 2000-frame utterances (BASELINE configs[4])")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU time budget of the cpu_baseline sample")
+    ap.add_argument("--verify-allreduce", action="store_true",
+                    help="estep: rank 0 recomputes the statistics of every rank's frames in one process and compares")
     args = ap.parse_args()
 
-    world, rank, _ = dist_setup(args.gpus)
-    if world != args.gpus and rank == 0:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
-    out = {"convert": bench_convert, "estep": bench_estep, "estep_full": bench_estep_full, "em_full": bench_em_full, "dtw": bench_dtw, "traj": bench_traj,
-           "trajgv": lambda a, w, r: bench_traj(a, w, r, gv=True)}[args.workload](args, world, rank)
-    if rank == 0:
-        print(json.dumps(out))
-    if world > 1:
-        import torch.distributed as dist
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no torchrun environment: start the ranks ourselves (child process), before any torch.cuda / HIP call
+        sys.exit(self_launch(sys.argv[1:], args.gpus))
 
+    world, rank, _ = dist_setup(args.gpus)
+    out = {"convert": bench_convert, "estep": bench_estep, "estep_full": bench_estep_full, "em_full": bench_em_full,
+           "dtw": bench_dtw, "traj": bench_traj, "trajgv": lambda a, w, r: bench_traj(a, w, r, gv=True),
+           "selftest": bench_selftest}[args.workload](args, world, rank)
+    out["n_gpus"] = world
+    out["per_rank"] = dict(PER_RANK)
+    out["collective_backend"] = BACKEND["name"]
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    import torch.distributed as dist
+
+    if dist.is_initialized():
+        dist.barrier()
         dist.destroy_process_group()
 
 

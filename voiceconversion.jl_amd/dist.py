@@ -53,10 +53,11 @@ def shard_by_cost(costs, world):
 
 
 def allreduce_sum_(t, group=None):
-    """In-place sum over ranks; a no-op without an initialised multi-rank group."""
+    """In-place sum over ranks; a no-op without an initialised process group.  A one-rank group still goes through the
+    backend (RCCL on a GPU): that is how the collective path is exercised on a 1-GPU box."""
     import torch.distributed as dist
 
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if dist.is_available() and dist.is_initialized():
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     return t
 
