@@ -268,8 +268,19 @@ def bench_convert(args, world, rank):
         for _ in range(3):
             vc.fvconvert(g, Xh)
         dth = (time.perf_counter() - t0) / 3
+        Yh = np.empty_like(Xh, order="F")
+        vc.fvconvert(g, Xh, out=Yh)
+        t0 = time.perf_counter()
+        for _ in range(3):
+            vc.fvconvert(g, Xh, out=Yh)
+        dtr = (time.perf_counter() - t0) / 3
         out["host_inclusive"] = {"value": T / dth, "unit": "frames/s", "ms_per_call": dth * 1e3,
-                                 "note": "vcmi_gmmmap_convert on pageable host arrays: H2D + kernel + D2H per call"}
+                                 "reused_output": {"value": T / dtr, "ms_per_call": dtr * 1e3},
+                                 "note": "vcmi_gmmmap_convert on pageable host arrays (what a Julia ccall passes): chunked "
+                                         "pinned staging, H2D / kernel / D2H of consecutive chunks overlapped; `value` "
+                                         "allocates a fresh output per call like `similar(X)` (first-touch page faults "
+                                         "included), `reused_output` writes into an existing array",
+                                 "parity_vs_device_path": bool(np.array_equal(Yh.T, Yd.cpu().numpy()))}
         # the honest strong CPU baseline -- the same arithmetic on every host core (OpenMP over frames)
         try:
             ns = int(min(T, max(n, 8 * n)))

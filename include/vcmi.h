@@ -44,6 +44,19 @@ const char *vcmi_version(void);
 int vcmi_device_count(int *count);
 /* Select the HIP device used by this thread's subsequent calls (one process per GPU: LOCAL_RANK). */
 int vcmi_set_device(int device);
+/* ONE host process driving several GPUs -- what a Julia host is (the reference is a single process, src/common.jl:7-63,
+ * bin/train_gmm.jl:103).  vcmi_set_devices(devs, n) makes a device group: one persistent worker thread per listed
+ * device.  From then on the HOST-POINTER entry points shard their work over the group and join before returning:
+ *   vcmi_gmmmap_convert / vcmi_vc_frames / _posterior / _predict   contiguous frame blocks, no collective;
+ *   vcmi_dtw_fit_batch / vcmi_align_batch                          pairs split by cost S*T, no collective;
+ *   vcmi_traj_convert_batch / vcmi_vc_traj / vcmi_trajgv_convert_batch   utterances (chunks) split by length, no collective;
+ *   vcmi_estep_diag / vcmi_estep_full                              frame blocks, then ONE ncclAllReduce(sum) of the packed
+ *                                                                  statistics over RCCL (librccl is loaded on first use).
+ * Converters are re-created on the other devices on first use.  The `_dev` entry points are unaffected (they run on the
+ * device that owns their pointers).  n = 0 removes the group.  The list may name a device twice (both workers share it;
+ * useful to test the sharding on a 1-GPU box) except for the E-step, whose RCCL communicator needs distinct devices. */
+int vcmi_set_devices(const int *devices, int n);
+int vcmi_get_devices(int *devices, int capacity, int *n);
 
 /* ---------------------------------------------------------------------------------------------
  * GMMMap -- src/gmmmap.jl:57-118, posterior helpers src/gmm.jl:24-58
@@ -75,8 +88,7 @@ int vcmi_gmmmap_posterior_dev(vcmi_gmmmap *g, const double *dX, int64_t ldx, int
 int vcmi_gmmmap_predict(vcmi_gmmmap *g, const double *X, int64_t ldx, int64_t T, int64_t *idx);
 int vcmi_gmmmap_predict_dev(vcmi_gmmmap *g, const double *dX, int64_t ldx, int64_t T, int64_t *didx, void *stream);
 /* Kernel selection for convert: 0 = auto (MFMA tile kernel when dim(g) has an instantiation, else the
- * generic VALU kernel), 1 = force the generic VALU kernel, 2 = force MFMA (VCMI_ERR_ARG if unavailable),
- * 3 = MFMA kernel with 4-mixture row grouping (experimental alternative tiling; D = 24 or 40 only). */
+ * generic VALU kernel), 1 = force the generic VALU kernel, 2 = force MFMA (VCMI_ERR_ARG if unavailable). */
 int vcmi_gmmmap_set_kernel(vcmi_gmmmap *g, int which);
 
 /* ---------------------------------------------------------------------------------------------
@@ -93,6 +105,10 @@ int vcmi_dtw_fit_batch(int64_t n, const double *const *tmpl, const int64_t *S, c
 /* Device-resident batch: `feats` is one device buffer holding every (D,len) matrix; pair p has its template at
  * feats + tmpl_off[p] (S[p] frames) and its sequence at feats + seq_off[p] (T[p] frames); its path goes to
  * paths + path_off[p].  Offsets (in elements) and lengths are HOST arrays of n entries. */
+/* Stream semantics: the call only enqueues work on `stream`.  The pair descriptors and the per-thread workspaces are
+ * shared between calls: every call first makes `stream` wait for the previous call's last kernel (whatever stream that
+ * ran on), and the descriptors are copied asynchronously on `stream` from pinned slots -- consecutive calls on any
+ * streams, including non-blocking ones, are ordered correctly without a host synchronisation. */
 int vcmi_dtw_fit_batch_dev(int64_t n, const double *feats, const int64_t *tmpl_off, const int64_t *S,
                            const int64_t *seq_off, const int64_t *T, int D, int fstep, int bstep, int64_t *paths,
                            const int64_t *path_off, void *stream);
@@ -151,6 +167,9 @@ typedef struct vcmi_traj vcmi_traj;
  * (:24-28).  T only sets length(t) (:34); W is a stencil and is never materialised.  g must outlive t. */
 int vcmi_traj_create(vcmi_gmmmap *g, int64_t T, vcmi_traj **out);
 int vcmi_traj_destroy(vcmi_traj *t);
+/* length(t).  As in the reference, fvconvert rebuilds W when the sequence length differs (src/trajectory_gmmmap.jl:70-72),
+ * so after vcmi_traj_convert(t, X, T, Y) the length is T, and after vcmi_vc_traj it is the length of the last chunk --
+ * which is the chunk length the NEXT vc call uses (src/common.jl:41).  The batch entry points leave it unchanged. */
 int64_t vcmi_traj_length(const vcmi_traj *t);
 /* fvconvert(t, X (2D,T)) -> Y (D,T); src/trajectory_gmmmap.jl:65-110 */
 int vcmi_traj_convert(vcmi_traj *t, const double *X, int64_t T, double *Y);

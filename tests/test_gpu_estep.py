@@ -20,8 +20,7 @@ def vc():
 
 def _force_generic(vc, on):
     from voiceconversion_jl_amd import _lib
-    _lib.lib.vcmi_estep_debug_force_generic.argtypes = [ctypes.c_int]
-    _lib.lib.vcmi_estep_debug_force_generic(int(on))
+    _lib.debug_force(_lib.DBG_ESTEP_GENERIC if on else 0)
 
 
 @pytest.mark.parametrize("generic", [False, True])

@@ -147,9 +147,9 @@ def test_gv_more_utterances_than_compute_units(vc):
         assert relerr(got[i], ref.fvconvert_gv(Xs[i], muv, Sv, 7, 1.0e-5).T) < TOL
 
 
-def test_one_team_and_two_team_kernels_agree(vc, monkeypatch):
+def test_one_team_and_two_team_kernels_agree(vc):
     """traj_gv2_kernel (gather waves beside the MFMA waves; the default when the frame permutation fits in LDS) against
-    traj_gv_kernel (VCMI_GV_ONE_TEAM=1, the path of very long utterances): same ascent, different thread counts in the
+    traj_gv_kernel (forced through the debug hook; the path of very long utterances): same ascent, different thread counts in the
     moment reductions -> agreement to rounding."""
     from oracle import c_oracle as co, np_oracle as npo
     D, M = 20, 6
@@ -161,7 +161,11 @@ def test_one_team_and_two_team_kernels_agree(vc, monkeypatch):
     muv, Sv = _gv_stats(rng, ref.fvconvert(Xs[0])[0])
     tgv = vc.TrajectoryGVGMMMap(t, muv, Sv)
     two = tgv.fvconvert_batch([x.T for x in Xs], epochs=25, alpha=1.0e-5)
-    monkeypatch.setenv("VCMI_GV_ONE_TEAM", "1")
-    one = tgv.fvconvert_batch([x.T for x in Xs], epochs=25, alpha=1.0e-5)
+    from voiceconversion_jl_amd import _lib
+    _lib.debug_force(_lib.DBG_GV_ONE_TEAM)
+    try:
+        one = tgv.fvconvert_batch([x.T for x in Xs], epochs=25, alpha=1.0e-5)
+    finally:
+        _lib.debug_force(0)
     for a, b in zip(two, one):
         assert relerr(a, b) < 1e-10

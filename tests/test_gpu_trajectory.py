@@ -89,10 +89,11 @@ def test_constructW_structure(vc):
     assert W.nnz == D * T + 2 * D * (T - 1)
 
 
-def test_blocked_and_scalar_column_solvers_agree(vc, monkeypatch):
-    """The MFMA-blocked banded Cholesky (default) against the scalar-column register-window kernel
-    (VCMI_TRAJ_SOLVER=reg) and the MFMA g_t kernel against the one-workgroup-per-frame kernel (VCMI_TRAJ_G_SCALAR):
-    two independent device implementations of src/trajectory_gmmmap.jl:85-105 on the same utterances."""
+def test_blocked_and_generic_solvers_agree(vc):
+    """The MFMA-blocked banded Cholesky (default) against the runtime-D LDS-window kernel (the path of static dimensions
+    without a blocked instantiation) and the MFMA g_t kernel against the one-workgroup-per-frame kernel: two independent
+    device implementations of src/trajectory_gmmmap.jl:85-105 on the same utterances."""
+    from voiceconversion_jl_amd import _lib
     from oracle import np_oracle as npo
     D, M = 40, 8
     w, mu, sig = npo.synth_model(777, 4 * D, M, lam_lo=1e-3)
@@ -105,15 +106,17 @@ def test_blocked_and_scalar_column_solvers_agree(vc, monkeypatch):
         static = np.cumsum(static, axis=0) / np.sqrt(np.arange(1, T + 1))[:, None]
         Xs.append(npo.push_delta(static).T)
     Yb = t.fvconvert_batch(Xs)
-    monkeypatch.setenv("VCMI_TRAJ_SOLVER", "reg")
-    monkeypatch.setenv("VCMI_TRAJ_G_SCALAR", "1")
-    Yr = t.fvconvert_batch(Xs)
+    _lib.debug_force(_lib.DBG_TRAJ_GENERIC | _lib.DBG_TRAJ_G_SCALAR)
+    try:
+        Yr = t.fvconvert_batch(Xs)
+    finally:
+        _lib.debug_force(0)
     for a, b in zip(Yb, Yr):
         assert relerr(a, b) < 1e-9
 
 
-@pytest.mark.parametrize("solver", ["blk", "reg"])
-def test_not_positive_definite_normal_matrix(vc, monkeypatch, solver):
+@pytest.mark.parametrize("solver", ["blk", "generic"])
+def test_not_positive_definite_normal_matrix(vc, solver):
     """A joint covariance whose x block is PD but whose conditional covariance Syy - A Sxy is negative definite passes
     the GMMMap constructor (only p(x) is factorised, src/gmm.jl:17) and makes W'D^-1W indefinite: the reference's
     Cholesky-based solve would throw; both device solvers report it through the status flag -> PosDefException."""
@@ -126,9 +129,13 @@ def test_not_positive_definite_normal_matrix(vc, monkeypatch, solver):
     sig = np.stack([np.block([[I, 2.0 * I], [2.0 * I, I]])] * M)
     g = vc.GMMMap(*julia_model(w, mu, sig))
     t = vc.TrajectoryGMMMap(g, T)
-    monkeypatch.setenv("VCMI_TRAJ_SOLVER", solver)
-    with pytest.raises(vc.PosDefException):
-        vc.fvconvert(t, rng.standard_normal((2 * D, T)))
+    from voiceconversion_jl_amd import _lib
+    _lib.debug_force(_lib.DBG_TRAJ_GENERIC if solver == "generic" else 0)
+    try:
+        with pytest.raises(vc.PosDefException):
+            vc.fvconvert(t, rng.standard_normal((2 * D, T)))
+    finally:
+        _lib.debug_force(0)
 
 
 def test_more_utterances_than_compute_units(vc):

@@ -52,6 +52,8 @@ SIGNATURES = {
     "vcmi_version": (C.c_char_p, []),
     "vcmi_device_count": (_int, [C.POINTER(_int)]),
     "vcmi_set_device": (_int, [_int]),
+    "vcmi_set_devices": (_int, [C.POINTER(_int), _int]),
+    "vcmi_get_devices": (_int, [C.POINTER(_int), _int, C.POINTER(_int)]),
     "vcmi_gmmmap_create": (_int, [_dp, _dp, _dp, _int, _int, _int, C.POINTER(_vp)]),
     "vcmi_gmmmap_destroy": (_int, [_vp]),
     "vcmi_gmmmap_dim": (_int, [_vp]),
@@ -140,3 +142,28 @@ def device_count():
 
 def set_device(i):
     check(lib.vcmi_set_device(int(i)))
+
+
+def set_devices(devices):
+    """One host process, several GPUs: the host-pointer entry points shard over `devices` (see include/vcmi.h).
+    An empty list restores the single-device behaviour."""
+    devices = [int(d) for d in devices]
+    arr = (_int * max(len(devices), 1))(*devices)
+    check(lib.vcmi_set_devices(arr, len(devices)))
+
+
+def get_devices():
+    n = _int(0)
+    arr = (_int * 64)()
+    check(lib.vcmi_get_devices(arr, 64, C.byref(n)))
+    return [arr[i] for i in range(n.value)]
+
+
+# Test hook (NOT part of include/vcmi.h): force the fallback kernels a shape would not select by itself.
+DBG_TRAJ_GENERIC, DBG_TRAJ_G_SCALAR, DBG_GV_ONE_TEAM, DBG_PREDICT_TWO_PASS, DBG_ESTEP_GENERIC = 1, 2, 4, 8, 16
+
+
+def debug_force(flags):
+    lib.vcmi_debug_force.argtypes = [C.c_uint]
+    lib.vcmi_debug_force.restype = _int
+    lib.vcmi_debug_force(int(flags))

@@ -1,6 +1,8 @@
 // core.cpp -- error plumbing, device selection, version string of libvcmi.
 #include "vcmi_common.hpp"
 
+#include <atomic>
+
 namespace vcmi {
 
 char *error_buffer() {
@@ -26,7 +28,16 @@ int check_device() {
   return VCMI_OK;
 }
 
+static std::atomic<unsigned> g_debug_flags{0};
+bool debug_flag(unsigned which) { return (g_debug_flags.load(std::memory_order_relaxed) & which) != 0; }
+
 }  // namespace vcmi
+
+// test hook, deliberately absent from include/vcmi.h
+extern "C" int vcmi_debug_force(unsigned flags) {
+  vcmi::g_debug_flags.store(flags);
+  return VCMI_OK;
+}
 
 extern "C" const char *vcmi_last_error(void) { return vcmi::error_buffer(); }
 extern "C" const char *vcmi_version(void) { return "vcmi 0.1 (gfx950, FP64)"; }

@@ -17,6 +17,8 @@
 // per LDS word when bstep+fstep <= 3, so the backward pass never touches HBM; the full Float64 / Int64 tables
 // of the reference (d.costtable, d.backpointer) are streamed to HBM only when the caller asks for them.
 #include "vcmi_common.hpp"
+#include "devgroup.hpp"
+#include "hostpipe.hpp"
 
 #include <algorithm>
 #include <numeric>
@@ -486,13 +488,76 @@ static int launch_obs(const double *feats, const double *spad, const DtwPair *dp
   return VCMI_OK;
 }
 
+// per-thread scratch shared by the DTW entry points
+struct DtwScratch {
+  DevBuf<unsigned char> codes;
+  DevBuf<DtwPair> dpairs;
+  DevBuf<double> feats, cost, newtgt, obs, spad;
+  DevBuf<int64_t> paths, bp;
+  // Stream ordering of the shared workspaces (descriptors, observation costs, step codes): a call on ANY stream first
+  // waits for the previous call's last kernel (`last_use`), and the descriptors travel to the device by an asynchronous
+  // copy on the caller's stream from a small ring of pinned slots (a slot is reused only after its copy completed).
+  static constexpr int kSlots = 4;
+  hipEvent_t last_use = nullptr, slot_done[kSlots] = {};
+  DtwPair *slot[kSlots] = {};
+  size_t slot_cap[kSlots] = {};
+  int next_slot = 0, device = -1;
+  int init() {
+    int dev = 0;
+    VCMI_HIP(hipGetDevice(&dev));
+    if (last_use && dev == device) return VCMI_OK;
+    release_sync();
+    VCMI_HIP(hipEventCreateWithFlags(&last_use, hipEventDisableTiming));
+    for (auto &e : slot_done) VCMI_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    device = dev;
+    return VCMI_OK;
+  }
+  // pinned copy of `n` descriptors, valid until the returned slot's event (recorded by the caller) completes
+  int stage(const DtwPair *src, size_t n, DtwPair **out, hipEvent_t *ev) {
+    const int s = next_slot;
+    next_slot = (next_slot + 1) % kSlots;
+    VCMI_HIP(hipEventSynchronize(slot_done[s]));
+    if (n > slot_cap[s]) {
+      if (slot[s]) (void)hipHostFree(slot[s]);
+      slot[s] = nullptr;
+      slot_cap[s] = 0;
+      const size_t cap = std::max<size_t>(n, 1024);
+      VCMI_HIP(hipHostMalloc(reinterpret_cast<void **>(&slot[s]), cap * sizeof(DtwPair), hipHostMallocDefault));
+      slot_cap[s] = cap;
+    }
+    memcpy(slot[s], src, n * sizeof(DtwPair));
+    *out = slot[s];
+    *ev = slot_done[s];
+    return VCMI_OK;
+  }
+  void release_sync() {
+    if (last_use) (void)hipEventDestroy(last_use);
+    last_use = nullptr;
+    for (int i = 0; i < kSlots; ++i) {
+      if (slot_done[i]) (void)hipEventDestroy(slot_done[i]);
+      if (slot[i]) (void)hipHostFree(slot[i]);
+      slot_done[i] = nullptr;
+      slot[i] = nullptr;
+      slot_cap[i] = 0;
+    }
+  }
+  ~DtwScratch() { release_sync(); }
+};
+static DtwScratch &scratch() {
+  static thread_local DtwScratch s;
+  return s;
+}
+
 // Launch one workgroup per pair.  `pairs` holds DEVICE pointers (codes filled in here when needed).
 // codes_ws: grow-only device scratch for HBM step codes.
-static int dtw_run(const double *feats, std::vector<DtwPair> &pairs, int D, int fstep, int bstep, DevBuf<unsigned char> &codes_ws,
-                   DevBuf<double> &obs_ws, DevBuf<double> &spad_ws,
-                   DevBuf<DtwPair> &dpairs, hipStream_t st) {
+static int dtw_run(const double *feats, std::vector<DtwPair> &pairs, int D, int fstep, int bstep, DtwScratch &sc, hipStream_t st) {
+  DevBuf<unsigned char> &codes_ws = sc.codes;
+  DevBuf<double> &obs_ws = sc.obs, &spad_ws = sc.spad;
+  DevBuf<DtwPair> &dpairs = sc.dpairs;
   const int n = (int)pairs.size();
   if (n == 0) return VCMI_OK;
+  VCMI_TRY(sc.init());
+  VCMI_HIP(hipStreamWaitEvent(st, sc.last_use, 0));   // the workspaces may still be read by the previous call's kernels
   if (D < 1) return fail(VCMI_ERR_DIM, "DTW: feature dimension %d invalid", D);
   if (fstep < 0 || bstep < 0 || fstep + bstep > 255) return fail(VCMI_ERR_ARG, "DTW: fstep/bstep out of range");
   int Smax = 0, Tmax = 0;
@@ -558,7 +623,13 @@ static int dtw_run(const double *feats, std::vector<DtwPair> &pairs, int D, int 
         smax = std::max(smax, pairs[k].S);
         tmax = std::max(tmax, pairs[k].T);
       }
-      VCMI_HIP(hipMemcpy(dpairs.p + lo, pairs.data() + lo, sizeof(DtwPair) * (hi - lo), hipMemcpyHostToDevice));
+      {
+        DtwPair *pinned = nullptr;
+        hipEvent_t copied = nullptr;
+        VCMI_TRY(sc.stage(pairs.data() + lo, (size_t)(hi - lo), &pinned, &copied));
+        VCMI_HIP(hipMemcpyAsync(dpairs.p + lo, pinned, sizeof(DtwPair) * (hi - lo), hipMemcpyHostToDevice, st));
+        VCMI_HIP(hipEventRecord(copied, st));
+      }
       if (tmax > 0) {
         // chunks of the slice: observation costs on the side stream, recurrences on the caller's stream behind them
         const int m = hi - lo;
@@ -585,47 +656,37 @@ static int dtw_run(const double *feats, std::vector<DtwPair> &pairs, int D, int 
       if (hi < n) VCMI_HIP(hipStreamSynchronize(st));   // the next slice reuses the workspace
       lo = hi;
     }
+    VCMI_HIP(hipEventRecord(sc.last_use, st));
     return VCMI_OK;
   }
-  VCMI_HIP(hipMemcpy(dpairs.p, pairs.data(), sizeof(DtwPair) * n, hipMemcpyHostToDevice));   // tiny, synchronous: `pairs` may die after return
+  {
+    DtwPair *pinned = nullptr;
+    hipEvent_t copied = nullptr;
+    VCMI_TRY(sc.stage(pairs.data(), (size_t)n, &pinned, &copied));
+    VCMI_HIP(hipMemcpyAsync(dpairs.p, pinned, sizeof(DtwPair) * n, hipMemcpyHostToDevice, st));
+    VCMI_HIP(hipEventRecord(copied, st));
+  }
   VCMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(dtw_generic_kernel),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)base_generic));
   hipLaunchKernelGGL(dtw_generic_kernel, dim3(n), dim3(1024), base_generic, st, feats, dpairs.p, D, fstep, bstep, Smax, Tmax);
   VCMI_HIP(hipGetLastError());
+  VCMI_HIP(hipEventRecord(sc.last_use, st));
   return VCMI_OK;
 }
 
-// per-thread scratch shared by the DTW entry points
-struct DtwScratch {
-  DevBuf<unsigned char> codes;
-  DevBuf<DtwPair> dpairs;
-  DevBuf<double> feats, cost, newtgt, obs, spad;
-  DevBuf<int64_t> paths, bp;
-};
-static DtwScratch &scratch() {
-  static thread_local DtwScratch s;
-  return s;
-}
-
-// Host-pointer batch: packs all feature matrices into one upload, runs, downloads paths / tables / newtgt.
-static int dtw_host_batch(int64_t n, const double *const *tmpl, const int64_t *S, const double *const *seq,
-                          const int64_t *T, int D, int fstep, int bstep, int64_t *const *path, double *cost,
-                          int64_t *bp, double *const *newtgt) {
-  if (n < 0) return fail(VCMI_ERR_ARG, "DTW: negative batch size");
-  if (n == 0) return VCMI_OK;
-  if (!tmpl || !S || !seq || !T) return fail(VCMI_ERR_ARG, "DTW: NULL argument");
-  if (D < 1) return fail(VCMI_ERR_DIM, "DTW: feature dimension %d invalid", D);
+// Host-pointer batch on the current device: the feature matrices are gathered straight into the pinned staging slots
+// (no intermediate host copy), run, and paths / tables / newtgt come back through the same ring.
+static int dtw_host_batch_local(int64_t n, const double *const *tmpl, const int64_t *S, const double *const *seq,
+                                const int64_t *T, int D, int fstep, int bstep, int64_t *const *path, double *cost,
+                                int64_t *bp, double *const *newtgt) {
   VCMI_TRY(check_device());
   DtwScratch &sc = scratch();
   size_t nfeat = 0, npath = 0, ntgt = 0;
   for (int64_t p = 0; p < n; ++p) {
-    if (S[p] < 1 || T[p] < 0 || S[p] > INT32_MAX || T[p] > INT32_MAX) return fail(VCMI_ERR_DIM, "DTW: bad sequence length");
-    if (!tmpl[p] || (T[p] > 0 && !seq[p])) return fail(VCMI_ERR_ARG, "DTW: NULL feature matrix");
     nfeat += (size_t)D * (S[p] + T[p]);
     npath += (size_t)T[p];
     ntgt += (size_t)D * S[p];
   }
-  std::vector<double> hfeat(nfeat);
   VCMI_TRY(sc.feats.reserve(nfeat));
   VCMI_TRY(sc.paths.reserve(std::max<size_t>(npath, 1)));
   if (newtgt) VCMI_TRY(sc.newtgt.reserve(ntgt));
@@ -635,13 +696,15 @@ static int dtw_host_batch(int64_t n, const double *const *tmpl, const int64_t *S
     VCMI_TRY(sc.bp.reserve((size_t)S[0] * (T[0] + 1)));
   }
   std::vector<DtwPair> pairs(n);
+  std::vector<HostPiece> up;
+  up.reserve((size_t)2 * n);
   size_t fo = 0, po = 0, to = 0;
   for (int64_t p = 0; p < n; ++p) {
     DtwPair &q = pairs[p];
-    memcpy(&hfeat[fo], tmpl[p], sizeof(double) * D * S[p]);
+    up.push_back(HostPiece{const_cast<double *>(tmpl[p]), sizeof(double) * D * S[p]});
     q.tmpl_off = (int64_t)fo;
     fo += (size_t)D * S[p];
-    if (T[p] > 0) memcpy(&hfeat[fo], seq[p], sizeof(double) * D * T[p]);
+    if (T[p] > 0) up.push_back(HostPiece{const_cast<double *>(seq[p]), sizeof(double) * D * T[p]});
     q.seq_off = (int64_t)fo;
     fo += (size_t)D * T[p];
     q.path = sc.paths.p + po;
@@ -657,7 +720,7 @@ static int dtw_host_batch(int64_t n, const double *const *tmpl, const int64_t *S
     q.S = (int32_t)S[p];
     q.T = (int32_t)T[p];
   }
-  VCMI_HIP(hipMemcpy(sc.feats.p, hfeat.data(), nfeat * 8, hipMemcpyHostToDevice));
+  VCMI_TRY(staged_upload_gather(sc.feats.p, up, nullptr));
   if (tables && T[0] == 0) {   // lazy_init! only: column 1 = 1:S
     for (int64_t i = 0; i < S[0]; ++i) {
       if (cost) cost[i] = (double)(i + 1);
@@ -665,26 +728,94 @@ static int dtw_host_batch(int64_t n, const double *const *tmpl, const int64_t *S
     }
   }
   std::vector<DtwPair> order = pairs;   // dtw_run sorts its argument; keep `pairs` in caller order for the copy-back
-  VCMI_TRY(dtw_run(sc.feats.p, order, D, fstep, bstep, sc.codes, sc.obs, sc.spad, sc.dpairs, nullptr));
-  VCMI_HIP(hipDeviceSynchronize());
-  std::vector<int64_t> hpath(std::max<size_t>(npath, 1));
-  VCMI_HIP(hipMemcpy(hpath.data(), sc.paths.p, npath * 8, hipMemcpyDeviceToHost));
-  po = 0;
-  to = 0;
-  for (int64_t p = 0; p < n; ++p) {
-    if (path && path[p] && T[p] > 0) memcpy(path[p], &hpath[po], sizeof(int64_t) * T[p]);
-    po += (size_t)T[p];
-    if (newtgt && newtgt[p]) {
-      if (T[p] > 0) VCMI_HIP(hipMemcpy(newtgt[p], sc.newtgt.p + to, sizeof(double) * D * S[p], hipMemcpyDeviceToHost));
-      else memset(newtgt[p], 0, sizeof(double) * D * S[p]);
+  VCMI_TRY(dtw_run(sc.feats.p, order, D, fstep, bstep, sc, nullptr));
+  if (path && npath > 0) {
+    std::vector<HostPiece> down;
+    std::vector<int64_t> dummy;
+    bool all = true;
+    for (int64_t p = 0; p < n; ++p) all = all && (path[p] != nullptr || T[p] == 0);
+    if (all) {
+      for (int64_t p = 0; p < n; ++p)
+        if (T[p] > 0) down.push_back(HostPiece{path[p], sizeof(int64_t) * T[p]});
+      VCMI_TRY(staged_download_scatter(down, sc.paths.p, nullptr));
+    } else {   // some pairs want no path: take everything, hand out what was asked for
+      dummy.resize(npath);
+      VCMI_TRY(staged_download(dummy.data(), sc.paths.p, npath * 8, nullptr));
+      po = 0;
+      for (int64_t p = 0; p < n; ++p) {
+        if (path[p] && T[p] > 0) memcpy(path[p], &dummy[po], sizeof(int64_t) * T[p]);
+        po += (size_t)T[p];
+      }
     }
-    to += (size_t)D * S[p];
+  }
+  if (newtgt) {
+    // aligned targets: contiguous on the device in pair order; pairs without a sequence are all-zero (src/align.jl:19)
+    std::vector<HostPiece> down;
+    bool contiguous = true;
+    for (int64_t p = 0; p < n; ++p) contiguous = contiguous && newtgt[p] && T[p] > 0;
+    if (contiguous) {
+      for (int64_t p = 0; p < n; ++p) down.push_back(HostPiece{newtgt[p], sizeof(double) * D * S[p]});
+      VCMI_TRY(staged_download_scatter(down, sc.newtgt.p, nullptr));
+    } else {
+      VCMI_HIP(hipStreamSynchronize(nullptr));
+      to = 0;
+      for (int64_t p = 0; p < n; ++p) {
+        if (newtgt[p]) {
+          if (T[p] > 0) VCMI_HIP(hipMemcpy(newtgt[p], sc.newtgt.p + to, sizeof(double) * D * S[p], hipMemcpyDeviceToHost));
+          else memset(newtgt[p], 0, sizeof(double) * D * S[p]);
+        }
+        to += (size_t)D * S[p];
+      }
+    }
   }
   if (tables && T[0] > 0) {
-    if (cost) VCMI_HIP(hipMemcpy(cost, sc.cost.p, sizeof(double) * S[0] * (T[0] + 1), hipMemcpyDeviceToHost));
-    if (bp) VCMI_HIP(hipMemcpy(bp, sc.bp.p, sizeof(int64_t) * S[0] * (T[0] + 1), hipMemcpyDeviceToHost));
+    if (cost) VCMI_TRY(staged_download(cost, sc.cost.p, sizeof(double) * S[0] * (T[0] + 1), nullptr));
+    if (bp) VCMI_TRY(staged_download(bp, sc.bp.p, sizeof(int64_t) * S[0] * (T[0] + 1), nullptr));
   }
+  VCMI_HIP(hipStreamSynchronize(nullptr));
   return VCMI_OK;
+}
+
+// pairs below which a batch stays on one device even when a device group is set
+static constexpr int64_t kGroupMinPairs = 8;
+
+// Pairs are independent: with a device group they are split by cost S*T (longest-processing-time) and every
+// member aligns its share on its own device; no collective.
+static int dtw_host_batch(int64_t n, const double *const *tmpl, const int64_t *S, const double *const *seq,
+                          const int64_t *T, int D, int fstep, int bstep, int64_t *const *path, double *cost,
+                          int64_t *bp, double *const *newtgt, bool allow_group = true) {
+  if (n < 0) return fail(VCMI_ERR_ARG, "DTW: negative batch size");
+  if (n == 0) return VCMI_OK;
+  if (!tmpl || !S || !seq || !T) return fail(VCMI_ERR_ARG, "DTW: NULL argument");
+  if (D < 1) return fail(VCMI_ERR_DIM, "DTW: feature dimension %d invalid", D);
+  for (int64_t p = 0; p < n; ++p) {
+    if (S[p] < 1 || T[p] < 0 || S[p] > INT32_MAX || T[p] > INT32_MAX) return fail(VCMI_ERR_DIM, "DTW: bad sequence length");
+    if (!tmpl[p] || (T[p] > 0 && !seq[p])) return fail(VCMI_ERR_ARG, "DTW: NULL feature matrix");
+  }
+  const int m = group_size();
+  if (!allow_group || m == 0 || n < kGroupMinPairs || cost || bp)
+    return dtw_host_batch_local(n, tmpl, S, seq, T, D, fstep, bstep, path, cost, bp, newtgt);
+  std::vector<int64_t> costs((size_t)n);
+  for (int64_t p = 0; p < n; ++p) costs[(size_t)p] = S[p] * std::max<int64_t>(T[p], 1);
+  const std::vector<int> part = shard_by_cost(costs, m);
+  return group_run([&](int i) -> int {
+    std::vector<const double *> t2, s2;
+    std::vector<int64_t> S2, T2;
+    std::vector<int64_t *> p2;
+    std::vector<double *> n2;
+    for (int64_t p = 0; p < n; ++p) {
+      if (part[(size_t)p] != i) continue;
+      t2.push_back(tmpl[p]);
+      s2.push_back(seq[p]);
+      S2.push_back(S[p]);
+      T2.push_back(T[p]);
+      if (path) p2.push_back(path[p]);
+      if (newtgt) n2.push_back(newtgt[p]);
+    }
+    if (t2.empty()) return VCMI_OK;
+    return dtw_host_batch_local((int64_t)t2.size(), t2.data(), S2.data(), s2.data(), T2.data(), D, fstep, bstep,
+                                path ? p2.data() : nullptr, nullptr, nullptr, newtgt ? n2.data() : nullptr);
+  });
 }
 
 // align(src_p, tgt_p) for a batch, results LEFT ON THE DEVICE (dataset.hip builds the training matrix from them):
@@ -694,7 +825,8 @@ int dtw_align_on_device(int64_t n, const double *const *src, const int64_t *S, c
                         int D, const double **d_feats, const double **d_newtgt, std::vector<int64_t> &src_off,
                         std::vector<int64_t> &nt_off) {
   std::vector<double *> nulls((size_t)std::max<int64_t>(n, 1), nullptr);
-  VCMI_TRY(dtw_host_batch(n, src, S, tgt, T, D, /*fstep=*/0, /*bstep=*/2, nullptr, nullptr, nullptr, nulls.data()));
+  // results stay in THIS thread's scratch on the current device: never spread over a device group
+  VCMI_TRY(dtw_host_batch(n, src, S, tgt, T, D, /*fstep=*/0, /*bstep=*/2, nullptr, nullptr, nullptr, nulls.data(), false));
   DtwScratch &sc = scratch();
   *d_feats = sc.feats.p;
   *d_newtgt = sc.newtgt.p;
@@ -746,7 +878,7 @@ extern "C" int vcmi_dtw_fit_batch_dev(int64_t n, const double *feats, const int6
     pairs[p] = q;
   }
   DtwScratch &sc = scratch();
-  return dtw_run(feats, pairs, D, fstep, bstep, sc.codes, sc.obs, sc.spad, sc.dpairs, as_stream(stream));
+  return dtw_run(feats, pairs, D, fstep, bstep, sc, as_stream(stream));
 }
 
 extern "C" int vcmi_align(const double *src, int64_t S, const double *tgt, int64_t T, int D, double *newtgt,

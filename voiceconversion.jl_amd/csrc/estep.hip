@@ -20,6 +20,8 @@
 //    over fixed frame segments, then a fixed-order reduction.
 #include "vcmi_common.hpp"
 #include "gmmmap_handle.hpp"
+#include "devgroup.hpp"
+#include "hostpipe.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -327,7 +329,6 @@ static EstepScratch &scratch() {
   return s;
 }
 
-static int g_estep_force_generic = 0;
 
 // raw = [w (M) | mu (DJ,M) | var (DJ,M)] on the device -> the MFMA kernel's operands:
 //   Wpack[mt][ks][lane]: A-operand fragments of W[m][k], k < DJ -> -1/(2 var) (multiplies x^2), k >= DJ -> mu/var
@@ -377,7 +378,7 @@ static int estep_device(const double *dX, int64_t N, int Dj, int M, const double
   VCMI_HIP(hipMemsetAsync(dstats, 0, plen * sizeof(double), st));
   if (N == 0) return VCMI_OK;
 
-  const bool mfma = (Dj == 80 && M <= EstepCfg<80>::MMAX && !g_estep_force_generic);
+  const bool mfma = (Dj == 80 && M <= EstepCfg<80>::MMAX && !debug_flag(kDbgEstepGeneric));
   if (mfma) {
     using C = EstepCfg<80>;
     int dev = 0, cus = 256;
@@ -684,7 +685,7 @@ static int estep_full_core(vcmi_gmmmap *px, const double *dX, int64_t N, int Dj,
   const int mgroups = (M + 7) / 8;
   const int nseg = std::max(1, (256 + mgroups - 1) / mgroups);
   VCMI_TRY(sc.part.reserve((size_t)nseg * plen));
-  const bool mfma = (Dj == 32 || Dj == 48 || Dj == 64 || Dj == 80) && !g_estep_force_generic;
+  const bool mfma = (Dj == 32 || Dj == 48 || Dj == 64 || Dj == 80) && !debug_flag(kDbgEstepGeneric);
   for (int64_t n0 = 0; n0 < N; n0 += chunk) {
     const int64_t n = std::min<int64_t>(chunk, N - n0);
     VCMI_TRY(gmmmap_logdens_device(px, dX + n0 * Dj, Dj, n, sc.LP.p, st));
@@ -828,29 +829,59 @@ extern "C" int vcmi_estep_diag_dev(const double *dX, int64_t N, int Dj, int M, c
   return estep_device(dX, N, Dj, M, w, mu, var, dstats, as_stream(stream));
 }
 
+// Host-pointer E-step shared by the diagonal and the full-covariance entry points: X goes up through the pinned staging
+// ring; with a device group (vcmi_set_devices) member i takes the contiguous frame block [lo, hi), computes its local
+// statistics, and ONE ncclAllReduce(sum) of the packed buffer over RCCL leaves the global statistics on every member
+//  -- member 0 returns them.  Two group phases, so that a member that failed never leaves the others
+// waiting inside the collective.
+template <class Scratch, class DevFn>
+static int estep_host(Scratch &(*get_scratch)(), const double *X, int64_t N, int Dj, int64_t plen, const DevFn &dev_fn,
+                      std::vector<double> &h) {
+  h.assign((size_t)plen, 0.0);
+  auto local = [&](int64_t lo, int64_t hi) -> int {
+    Scratch &sc = get_scratch();
+    const int64_t n = hi - lo;
+    VCMI_TRY(sc.X.reserve((size_t)std::max<int64_t>(n, 1) * Dj));
+    VCMI_TRY(sc.stats.reserve((size_t)plen));
+    if (n > 0) VCMI_TRY(staged_upload(sc.X.p, X + (size_t)lo * Dj, (size_t)n * Dj * 8, nullptr));
+    VCMI_TRY(dev_fn(sc.X.p, n, sc.stats.p));
+    VCMI_HIP(hipStreamSynchronize(nullptr));
+    return VCMI_OK;
+  };
+  const int m = group_size();
+  if (m == 0) {
+    VCMI_TRY(check_device());
+    VCMI_TRY(local(0, N));
+    VCMI_HIP(hipMemcpy(h.data(), get_scratch().stats.p, (size_t)plen * 8, hipMemcpyDeviceToHost));
+    return VCMI_OK;
+  }
+  VCMI_TRY(group_run([&](int i) -> int {
+    int64_t lo, hi;
+    shard_range(N, i, m, &lo, &hi);
+    return local(lo, hi);
+  }));
+  return group_run([&](int i) -> int {
+    Scratch &sc = get_scratch();
+    VCMI_TRY(group_allreduce_sum(i, sc.stats.p, (size_t)plen, nullptr));
+    if (i == 0) VCMI_HIP(hipMemcpy(h.data(), sc.stats.p, (size_t)plen * 8, hipMemcpyDeviceToHost));
+    return VCMI_OK;
+  });
+}
+
 extern "C" int vcmi_estep_diag(const double *X, int64_t N, int Dj, int M, const double *w, const double *mu,
                                const double *var, double *S0, double *S1, double *S2, double *loglik) {
   if (!S0 || !S1 || !S2 || !loglik) return fail(VCMI_ERR_ARG, "vcmi_estep_diag: NULL output");
   if (N < 0 || Dj < 1 || M < 1) return fail(VCMI_ERR_DIM, "E-step: N=%lld Dj=%d M=%d invalid", (long long)N, Dj, M);
-  VCMI_TRY(check_device());
-  EstepScratch &sc = scratch();
+  if (N > 0 && !X) return fail(VCMI_ERR_ARG, "vcmi_estep_diag: NULL frames");
   const int64_t plen = vcmi_estep_stats_len(Dj, M);
-  VCMI_TRY(sc.X.reserve((size_t)std::max<int64_t>(N, 1) * Dj));
-  VCMI_TRY(sc.stats.reserve((size_t)plen));
-  if (N > 0) VCMI_HIP(hipMemcpy(sc.X.p, X, (size_t)N * Dj * 8, hipMemcpyHostToDevice));
-  VCMI_TRY(estep_device(sc.X.p, N, Dj, M, w, mu, var, sc.stats.p, nullptr));
-  std::vector<double> h((size_t)plen);
-  VCMI_HIP(hipMemcpy(h.data(), sc.stats.p, (size_t)plen * 8, hipMemcpyDeviceToHost));
+  std::vector<double> h;
+  VCMI_TRY(estep_host<EstepScratch>(scratch, X, N, Dj, plen, [&](const double *dX, int64_t n, double *dstats) -> int {
+    return estep_device(dX, n, Dj, M, w, mu, var, dstats, nullptr);
+  }, h));
   memcpy(S0, h.data(), sizeof(double) * M);
   memcpy(S1, h.data() + M, sizeof(double) * M * Dj);
   memcpy(S2, h.data() + M + (size_t)M * Dj, sizeof(double) * M * Dj);
   *loglik = h[(size_t)plen - 1];
-  return VCMI_OK;
-}
-
-// test hook (not part of include/vcmi.h): 1 forces the generic kernels so that both paths are parity-tested
-extern "C" int vcmi_estep_debug_force_generic(int on) {
-  g_estep_force_generic = on;
   return VCMI_OK;
 }
 
@@ -865,15 +896,12 @@ extern "C" int vcmi_estep_full(const double *X, int64_t N, int Dj, int M, const 
                                const double *sigma, double *S0, double *S1, double *S2, double *loglik) {
   if (!S0 || !S1 || !S2 || !loglik) return fail(VCMI_ERR_ARG, "vcmi_estep_full: NULL output");
   if (N < 0 || Dj < 1 || M < 1) return fail(VCMI_ERR_DIM, "E-step: N=%lld Dj=%d M=%d invalid", (long long)N, Dj, M);
-  VCMI_TRY(check_device());
-  EstepFullScratch &sc = full_scratch();
+  if (N > 0 && !X) return fail(VCMI_ERR_ARG, "vcmi_estep_full: NULL frames");
   const int64_t plen = vcmi_estep_full_stats_len(Dj, M);
-  VCMI_TRY(sc.X.reserve((size_t)std::max<int64_t>(N, 1) * Dj));
-  VCMI_TRY(sc.stats.reserve((size_t)plen));
-  if (N > 0) VCMI_HIP(hipMemcpy(sc.X.p, X, (size_t)N * Dj * 8, hipMemcpyHostToDevice));
-  VCMI_TRY(estep_full_device(sc.X.p, N, Dj, M, w, mu, sigma, sc.stats.p, nullptr));
-  std::vector<double> h((size_t)plen);
-  VCMI_HIP(hipMemcpy(h.data(), sc.stats.p, (size_t)plen * 8, hipMemcpyDeviceToHost));
+  std::vector<double> h;
+  VCMI_TRY(estep_host<EstepFullScratch>(full_scratch, X, N, Dj, plen, [&](const double *dX, int64_t n, double *dstats) -> int {
+    return estep_full_device(dX, n, Dj, M, w, mu, sigma, dstats, nullptr);
+  }, h));
   memcpy(S0, h.data(), sizeof(double) * M);
   memcpy(S1, h.data() + M, sizeof(double) * M * Dj);
   memcpy(S2, h.data() + M + (size_t)M * Dj, sizeof(double) * M * Dj * Dj);
@@ -887,6 +915,8 @@ extern "C" int vcmi_gmm_em_create(int Dj, int M, const double *w, const double *
   if (!w || !mu || !sigma || !out) return fail(VCMI_ERR_ARG, "vcmi_gmm_em_create: NULL argument");
   *out = nullptr;
   if (Dj < 1 || M < 1) return fail(VCMI_ERR_DIM, "vcmi_gmm_em_create: Dj=%d M=%d invalid", Dj, M);
+  if (Dj > 256)   // em_mstep_full_kernel stages the mean vector in a 256-entry LDS array
+    return fail(VCMI_ERR_DIM, "vcmi_gmm_em_create: joint dimension %d exceeds the device EM limit (256)", Dj);
   if (!(min_covar >= 0.0)) return fail(VCMI_ERR_ARG, "vcmi_gmm_em_create: min_covar must be >= 0");
   VCMI_TRY(check_device());
   vcmi_gmm_em *h = new (std::nothrow) vcmi_gmm_em();

@@ -23,7 +23,10 @@
 #include "vcmi_common.hpp"
 #include "host_linalg.hpp"
 #include "gmmmap_handle.hpp"
+#include "devgroup.hpp"
+#include "hostpipe.hpp"
 
+#include <atomic>
 #include <cmath>
 #include <cstdlib>
 #include <limits>
@@ -420,11 +423,14 @@ static int launch_mfma(const vcmi_gmmmap *g, const double *dX, int64_t ldx, int6
   constexpr int NBUF = (2 * (size_t)TL::BLK * sizeof(double) <= 80 * 1024) ? 2 : 1;
   const size_t shmem = NBUF * (size_t)TL::BLK * sizeof(double);
   auto kern = gmmmap_mfma_kernel<DP, FT, WAVES, MODE, NBUF>;
-  static bool attr_done = false;
-  if (!attr_done) {
+  // the attribute is per DEVICE: one flag per device, so a host that drives several GPUs sets it on each of them
+  static std::atomic<bool> attr_done[64];
+  int dev = 0;
+  VCMI_HIP(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 64 || !attr_done[dev].load(std::memory_order_acquire)) {
     VCMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)shmem));
-    attr_done = true;
+    if (dev >= 0 && dev < 64) attr_done[dev].store(true, std::memory_order_release);
   }
   const int64_t per_wg = (int64_t)16 * FT * WAVES;
   const int64_t blocks = (T + per_wg - 1) / per_wg;
@@ -437,12 +443,6 @@ static int launch_mfma(const vcmi_gmmmap *g, const double *dX, int64_t ldx, int6
 template <int MODE>
 static int dispatch_mfma(const vcmi_gmmmap *g, const double *dX, int64_t ldx, int64_t T, double *dY, int64_t ldy,
                          hipStream_t st) {
-  if (g->DP == 40 && MODE == 0) {   // tuning variants (VCMI_VARIANT), experiments only
-    static const int variant = getenv("VCMI_VARIANT") ? atoi(getenv("VCMI_VARIANT")) : 0;
-    if (variant == 1) return launch_mfma<40, 0, 1, 4>(g, dX, ldx, T, dY, ldy, st);
-    if (variant == 2) return launch_mfma<40, 0, 1, 8>(g, dX, ldx, T, dY, ldy, st);
-    if (variant == 3) return launch_mfma<40, 0, 2, 8>(g, dX, ldx, T, dY, ldy, st);
-  }
   switch (g->DP) {
 #define VCMI_CASE(DPV) \
   case DPV: return launch_mfma<DPV, MODE, ((DPV) <= 48 ? 2 : 1), 4>(g, dX, ldx, T, dY, ldy, st);
@@ -487,7 +487,6 @@ int gmmmap_convert_device(vcmi_gmmmap *g, const double *dX, int64_t ldx, int64_t
   if (T == 0) return VCMI_OK;
   if (g->kernel_choice == 2 && !gmmmap_has_mfma(g->DP))
     return fail(VCMI_ERR_ARG, "MFMA kernel forced but dimension %d has no instantiation", g->D);
-  if (g->kernel_choice == 3) return gmmmap_convert_g4_device(g, dX, ldx, T, dY, ldy, st);
   if (use_mfma(g)) return dispatch_mfma<0>(g, dX, ldx, T, dY, ldy, st);
   return launch_generic<0>(g, dX, ldx, T, dY, ldy, st);
 }
@@ -510,7 +509,7 @@ int gmmmap_posterior_device(vcmi_gmmmap *g, const double *dX, int64_t ldx, int64
 
 int gmmmap_predict_device(vcmi_gmmmap *g, const double *dX, int64_t ldx, int64_t T, int64_t *didx, hipStream_t st) {
   if (T == 0) return VCMI_OK;
-  if (use_mfma(g) && !getenv("VCMI_PREDICT_TWO_PASS"))      // argmax inside the MFMA kernel: no (M,T) matrix, one launch
+  if (use_mfma(g) && !debug_flag(kDbgPredictTwoPass))      // argmax inside the MFMA kernel: no (M,T) matrix, one launch
     return dispatch_mfma<2>(g, dX, ldx, T, reinterpret_cast<double *>(didx), 0, st);
   VCMI_TRY(g->scratch_lp.reserve((size_t)T * g->M));
   VCMI_TRY(gmmmap_logdens_device(g, dX, ldx, T, g->scratch_lp.p, st));
@@ -642,7 +641,6 @@ static int prepare(vcmi_gmmmap *g, const double *w, const double *mu, const doub
     VCMI_TRY(dst.reserve(pk.size()));
     VCMI_HIP(hipMemcpy(dst.p, pk.data(), pk.size() * 8, hipMemcpyHostToDevice));
   }
-  if (!px_only) VCMI_TRY(gmmmap_pack_g4(g, hU, hA, hcz, hb, hlc));
   return VCMI_OK;
 }
 
@@ -813,6 +811,69 @@ int gmm_px_prepare_device(vcmi_gmmmap **inout, const double *d_w, const double *
 }  // namespace vcmi
 
 // ------------------------------------------------------------------------------------------------
+// device-group replicas (devgroup.hpp)
+// ------------------------------------------------------------------------------------------------
+namespace vcmi {
+
+void gmmmap_sync_replicas(vcmi_gmmmap *g) {
+  const uint64_t ep = group_epoch();
+  if (g->replicas_epoch == ep && (int)g->replicas.size() == group_size()) return;
+  for (vcmi_gmmmap *r : g->replicas) delete r;
+  g->replicas.assign((size_t)group_size(), nullptr);
+  g->replicas_epoch = ep;
+}
+
+int gmmmap_member(vcmi_gmmmap *g, int member, vcmi_gmmmap **out) {
+  // g itself serves the first member that sits on g's device; every other member gets its own converter
+  bool first_on_home = group_device(member) == g->device;
+  for (int k = 0; k < member && first_on_home; ++k)
+    if (group_device(k) == g->device) first_on_home = false;
+  if (first_on_home) {
+    *out = g;
+    return VCMI_OK;
+  }
+  vcmi_gmmmap *&r = g->replicas[(size_t)member];
+  if (!r) {
+    if (g->in_w.empty()) return fail(VCMI_ERR_ARG, "this converter cannot be replicated on another device");
+    vcmi_gmmmap *n = new (std::nothrow) vcmi_gmmmap();
+    if (!n) return fail(VCMI_ERR_OOM, "out of host memory");
+    (void)hipGetDevice(&n->device);
+    const int rc = prepare(n, g->in_w.data(), g->in_mu.data(), g->in_sigma.data(), g->in_Dj, g->M, g->in_swap);
+    if (rc != VCMI_OK) {
+      delete n;
+      return rc;
+    }
+    r = n;
+  }
+  r->kernel_choice = g->kernel_choice;
+  *out = r;
+  return VCMI_OK;
+}
+
+// frames below which a call is not worth spreading over the group
+static constexpr int64_t kGroupMinFrames = 4096;
+// chunks of the host pipeline hold at least this many frames: one full round of workgroups on 256 CUs
+static constexpr int64_t kMinChunkFrames = 98304;
+
+// Frames are independent: member i of the group converts the contiguous block [lo, hi).
+template <class PerShard>
+static int over_frames(vcmi_gmmmap *g, int64_t T, const PerShard &fn) {
+  const int m = group_size();
+  if (m == 0 || T < kGroupMinFrames) return fn(g, (int64_t)0, T);
+  gmmmap_sync_replicas(g);
+  return group_run([&](int i) -> int {
+    int64_t lo, hi;
+    shard_range(T, i, m, &lo, &hi);
+    if (hi == lo) return VCMI_OK;
+    vcmi_gmmmap *r = nullptr;
+    VCMI_TRY(gmmmap_member(g, i, &r));
+    return fn(r, lo, hi);
+  });
+}
+
+}  // namespace vcmi
+
+// ------------------------------------------------------------------------------------------------
 // C-ABI
 // ------------------------------------------------------------------------------------------------
 using namespace vcmi;
@@ -831,6 +892,11 @@ extern "C" int vcmi_gmmmap_create(const double *weights, const double *mu, const
     delete g;
     return rc;
   }
+  g->in_w.assign(weights, weights + M);
+  g->in_mu.assign(mu, mu + (size_t)Dj * M);
+  g->in_sigma.assign(sigma, sigma + (size_t)Dj * Dj * M);
+  g->in_Dj = Dj;
+  g->in_swap = swap;
   *out = g;
   return VCMI_OK;
 }
@@ -847,8 +913,7 @@ extern "C" int vcmi_gmmmap_get_A(const vcmi_gmmmap *g, double *A) {
   return VCMI_OK;
 }
 extern "C" int vcmi_gmmmap_set_kernel(vcmi_gmmmap *g, int which) {
-  if (!g || which < 0 || which > 3) return fail(VCMI_ERR_ARG, "vcmi_gmmmap_set_kernel: bad argument");
-  if (which == 3 && !gmmmap_has_g4(g->DP)) return fail(VCMI_ERR_ARG, "no grouped-tiling instantiation for dimension %d", g->D);
+  if (!g || which < 0 || which > 2) return fail(VCMI_ERR_ARG, "vcmi_gmmmap_set_kernel: bad argument");
   if (which == 2 && !gmmmap_has_mfma(g->DP)) return fail(VCMI_ERR_ARG, "no MFMA instantiation for dimension %d", g->D);
   g->kernel_choice = which;
   return VCMI_OK;
@@ -869,18 +934,19 @@ extern "C" int vcmi_gmmmap_convert_dev(vcmi_gmmmap *g, const double *dX, int64_t
   return gmmmap_convert_device(g, dX, ldx, T, dY, ldy, as_stream(stream));
 }
 
+// Host pointers: chunks of frames travel pageable -> pinned -> HBM -> kernel -> pinned -> pageable with the three
+// stages of consecutive chunks overlapping (hostpipe.hpp); with a device group the frame range is split first.
 extern "C" int vcmi_gmmmap_convert(vcmi_gmmmap *g, const double *X, int64_t ldx, int64_t T, double *Y, int64_t ldy) {
   VCMI_TRY(check_xy(g, X, ldx, T, Y, ldy, "vcmi_gmmmap_convert"));
   if (ldy < g->D) return fail(VCMI_ERR_DIM, "vcmi_gmmmap_convert: ldy %lld < dim %d", (long long)ldy, g->D);
   if (T == 0) return VCMI_OK;
-  const size_t nx = (size_t)(T - 1) * ldx + g->D, ny = (size_t)T * g->D;
-  VCMI_TRY(g->scratch_x.reserve(nx));
-  VCMI_TRY(g->scratch_y.reserve(ny));
-  VCMI_HIP(hipMemcpy(g->scratch_x.p, X, nx * 8, hipMemcpyHostToDevice));
-  VCMI_TRY(gmmmap_convert_device(g, g->scratch_x.p, ldx, T, g->scratch_y.p, g->D, nullptr));
-  VCMI_HIP(hipMemcpy2D(Y, (size_t)ldy * 8, g->scratch_y.p, (size_t)g->D * 8, (size_t)g->D * 8, (size_t)T,
-                       hipMemcpyDeviceToHost));
-  return VCMI_OK;
+  const size_t row = (size_t)g->D * 8;
+  return over_frames(g, T, [&](vcmi_gmmmap *r, int64_t lo, int64_t hi) -> int {
+    return staged_pipeline(X + lo * ldx, row, (size_t)ldx * 8, Y + lo * ldy, row, (size_t)ldy * 8, hi - lo, kMinChunkFrames,
+                           [&](const void *dIn, void *dOut, int64_t, int64_t n, hipStream_t st) -> int {
+                             return gmmmap_convert_device(r, (const double *)dIn, r->D, n, (double *)dOut, r->D, st);
+                           });
+  });
 }
 
 extern "C" int vcmi_vc_frames(vcmi_gmmmap *g, const double *fm, int64_t T, double *out) {
@@ -888,14 +954,15 @@ extern "C" int vcmi_vc_frames(vcmi_gmmmap *g, const double *fm, int64_t T, doubl
   if (T < 0 || (T > 0 && (!fm || !out))) return fail(VCMI_ERR_ARG, "vcmi_vc_frames: bad argument");
   if (T == 0) return VCMI_OK;
   const int64_t ld = g->D + 1;   // row 1 is the power coefficient, src/common.jl:11
-  const size_t n = (size_t)T * ld;
-  VCMI_TRY(g->scratch_x.reserve(n));
-  VCMI_TRY(g->scratch_y.reserve(n));
-  VCMI_HIP(hipMemcpy(g->scratch_x.p, fm, n * 8, hipMemcpyHostToDevice));
-  VCMI_HIP(hipMemcpyAsync(g->scratch_y.p, g->scratch_x.p, n * 8, hipMemcpyDeviceToDevice, nullptr));   // keeps row 1, src/common.jl:23
-  VCMI_TRY(gmmmap_convert_device(g, g->scratch_x.p + 1, ld, T, g->scratch_y.p + 1, ld, nullptr));
-  VCMI_HIP(hipMemcpy(out, g->scratch_y.p, n * 8, hipMemcpyDeviceToHost));
-  return VCMI_OK;
+  const size_t row = (size_t)ld * 8;
+  return over_frames(g, T, [&](vcmi_gmmmap *r, int64_t lo, int64_t hi) -> int {
+    return staged_pipeline(fm + lo * ld, row, row, out + lo * ld, row, row, hi - lo, kMinChunkFrames,
+                           [&](const void *dIn, void *dOut, int64_t, int64_t n, hipStream_t st) -> int {
+                             // the copy keeps row 1 (src/common.jl:23); the kernel then overwrites rows 2..D+1
+                             VCMI_HIP(hipMemcpyAsync(dOut, dIn, (size_t)n * row, hipMemcpyDeviceToDevice, st));
+                             return gmmmap_convert_device(r, (const double *)dIn + 1, ld, n, (double *)dOut + 1, ld, st);
+                           });
+  });
 }
 
 extern "C" int vcmi_gmmmap_posterior_dev(vcmi_gmmmap *g, const double *dX, int64_t ldx, int64_t T, double *dP, void *stream) {
@@ -906,13 +973,13 @@ extern "C" int vcmi_gmmmap_posterior_dev(vcmi_gmmmap *g, const double *dX, int64
 extern "C" int vcmi_gmmmap_posterior(vcmi_gmmmap *g, const double *X, int64_t ldx, int64_t T, double *P) {
   VCMI_TRY(check_xy(g, X, ldx, T, P, 1, "vcmi_gmmmap_posterior"));
   if (T == 0) return VCMI_OK;
-  const size_t nx = (size_t)(T - 1) * ldx + g->D, np = (size_t)T * g->M;
-  VCMI_TRY(g->scratch_x.reserve(nx));
-  VCMI_TRY(g->scratch_y.reserve(np));
-  VCMI_HIP(hipMemcpy(g->scratch_x.p, X, nx * 8, hipMemcpyHostToDevice));
-  VCMI_TRY(gmmmap_posterior_device(g, g->scratch_x.p, ldx, T, g->scratch_y.p, nullptr));
-  VCMI_HIP(hipMemcpy(P, g->scratch_y.p, np * 8, hipMemcpyDeviceToHost));
-  return VCMI_OK;
+  const int M = g->M;
+  return over_frames(g, T, [&](vcmi_gmmmap *r, int64_t lo, int64_t hi) -> int {
+    return staged_pipeline(X + lo * ldx, (size_t)r->D * 8, (size_t)ldx * 8, P + lo * M, (size_t)M * 8, (size_t)M * 8, hi - lo,
+                           kMinChunkFrames, [&](const void *dIn, void *dOut, int64_t, int64_t n, hipStream_t st) -> int {
+                             return gmmmap_posterior_device(r, (const double *)dIn, r->D, n, (double *)dOut, st);
+                           });
+  });
 }
 
 extern "C" int vcmi_gmmmap_predict_dev(vcmi_gmmmap *g, const double *dX, int64_t ldx, int64_t T, int64_t *didx, void *stream) {
@@ -923,11 +990,10 @@ extern "C" int vcmi_gmmmap_predict_dev(vcmi_gmmmap *g, const double *dX, int64_t
 extern "C" int vcmi_gmmmap_predict(vcmi_gmmmap *g, const double *X, int64_t ldx, int64_t T, int64_t *idx) {
   VCMI_TRY(check_xy(g, X, ldx, T, idx, 1, "vcmi_gmmmap_predict"));
   if (T == 0) return VCMI_OK;
-  const size_t nx = (size_t)(T - 1) * ldx + g->D;
-  VCMI_TRY(g->scratch_x.reserve(nx));
-  VCMI_TRY(g->scratch_idx.reserve((size_t)T));
-  VCMI_HIP(hipMemcpy(g->scratch_x.p, X, nx * 8, hipMemcpyHostToDevice));
-  VCMI_TRY(gmmmap_predict_device(g, g->scratch_x.p, ldx, T, g->scratch_idx.p, nullptr));
-  VCMI_HIP(hipMemcpy(idx, g->scratch_idx.p, (size_t)T * 8, hipMemcpyDeviceToHost));
-  return VCMI_OK;
+  return over_frames(g, T, [&](vcmi_gmmmap *r, int64_t lo, int64_t hi) -> int {
+    return staged_pipeline(X + lo * ldx, (size_t)r->D * 8, (size_t)ldx * 8, idx + lo, 8, 8, hi - lo, kMinChunkFrames,
+                           [&](const void *dIn, void *dOut, int64_t, int64_t n, hipStream_t st) -> int {
+                             return gmmmap_predict_device(r, (const double *)dIn, r->D, n, (int64_t *)dOut, st);
+                           });
+  });
 }

@@ -7,7 +7,7 @@ struct vcmi_gmmmap {
   int DP = 0;   // D rounded up to a multiple of 4 (MFMA k-step)
   int M = 0;    // ncomponents(g)
   int device = 0;
-  int kernel_choice = 0;   // 0 auto, 1 generic VALU, 2 MFMA, 3 MFMA with 4-mixture row grouping
+  int kernel_choice = 0;   // 0 auto, 1 generic VALU, 2 MFMA
 
   // host copies kept for accessors and for TrajectoryGMMMap's constructor (row-major (D,D) per mixture)
   std::vector<double> h_A_julia;   // Julia memory image (D,D,M) of ΣʸˣΣˣˣ⁻¹
@@ -18,22 +18,26 @@ struct vcmi_gmmmap {
   // device parameters, MFMA fragment order: [M][Tiling::BLK]
   vcmi::DevBuf<double> packed;    // [U_m ; A_m] tiles (convert)
   vcmi::DevBuf<double> packedU;   // U_m tiles only (log-density / posterior / argmax)
-  vcmi::DevBuf<double> packed4;   // 4-mixture row grouping (gmmmap_g4.hip, kernel choice 3)
 
   // issue-order table of the U-only tiling (slot -> tile << 16 | k-step) for the on-device packer (gmm_px_prepare_device)
   vcmi::DevBuf<int> px_table;
   int px_table_dp = 0;
 
-  // grow-only device scratch for the host-pointer entry points
-  vcmi::DevBuf<double> scratch_x, scratch_y, scratch_lp;
-  vcmi::DevBuf<int64_t> scratch_idx;
+  // grow-only device scratch (two-pass predict of the generic path)
+  vcmi::DevBuf<double> scratch_lp;
+
+  // constructor arguments, kept so that the converter can be re-created on the other devices of a device group
+  // (vcmi_set_devices): replicas[i] lives on member i's device and is made lazily by that member's worker thread
+  std::vector<double> in_w, in_mu, in_sigma;
+  int in_Dj = 0, in_swap = 0;
+  std::vector<vcmi_gmmmap *> replicas;
+  uint64_t replicas_epoch = 0;
+  ~vcmi_gmmmap() {
+    for (vcmi_gmmmap *r : replicas) delete r;
+  }
 };
 
 namespace vcmi {
-bool gmmmap_has_g4(int DP);
-int gmmmap_pack_g4(vcmi_gmmmap *g, const std::vector<double> &hU, const std::vector<double> &hA, const std::vector<double> &hcz,
-                   const std::vector<double> &hb, const std::vector<double> &hlc);
-int gmmmap_convert_g4_device(vcmi_gmmmap *g, const double *dX, int64_t ldx, int64_t T, double *dY, int64_t ldy, hipStream_t st);
 bool gmmmap_has_mfma(int DP);
 int gmm_px_create(const double *w, const double *mu, const double *sigma, int D, int M, vcmi_gmmmap **out);
 // Same handle prepared ON THE DEVICE from device-resident parameters (w (M), mu (D,M), sigma (D,D,M)): one workgroup
@@ -46,4 +50,8 @@ int gmmmap_convert_device(vcmi_gmmmap *g, const double *dX, int64_t ldx, int64_t
 int gmmmap_logdens_device(vcmi_gmmmap *g, const double *dX, int64_t ldx, int64_t T, double *dLP, hipStream_t st);
 int gmmmap_posterior_device(vcmi_gmmmap *g, const double *dX, int64_t ldx, int64_t T, double *dP, hipStream_t st);
 int gmmmap_predict_device(vcmi_gmmmap *g, const double *dX, int64_t ldx, int64_t T, int64_t *didx, hipStream_t st);
+// Device group support (devgroup.hpp): gmmmap_sync_replicas is called by the host thread before group_run; inside the
+// run member i obtains its converter (g itself on g's device, else a replica created on first use).
+void gmmmap_sync_replicas(vcmi_gmmmap *g);
+int gmmmap_member(vcmi_gmmmap *g, int member, vcmi_gmmmap **out);
 }  // namespace vcmi

@@ -1,0 +1,427 @@
+// hostpipe.cpp -- pinned staging rings, worker-thread copies and the chunked upload / kernel / download pipeline
+// behind the host-pointer entry points (see hostpipe.hpp).
+#include "hostpipe.hpp"
+
+#include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <cstdlib>
+#include <deque>
+#include <mutex>
+#include <thread>
+
+#include <sys/mman.h>
+#include <unistd.h>
+
+namespace vcmi {
+
+// ------------------------------------------------------------------------------------------------
+// worker threads
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+struct Latch {
+  std::atomic<int> remaining{0};
+  std::mutex m;
+  std::condition_variable c;
+  void done() {
+    if (remaining.fetch_sub(1) == 1) {
+      std::lock_guard<std::mutex> lk(m);
+      c.notify_all();
+    }
+  }
+};
+
+struct Task {
+  const std::function<void(int64_t, int64_t)> *fn;
+  int64_t lo, hi;
+  Latch *latch;
+};
+
+class Pool {
+ public:
+  static Pool &get() {
+    static Pool *p = new Pool();   // never destroyed: the workers may outlive static destruction
+    return *p;
+  }
+  int workers() const { return nworkers_; }
+  void push(const Task *tasks, int n) {
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      for (int i = 0; i < n; ++i) q_.push_back(tasks[i]);
+    }
+    cv_.notify_all();
+  }
+  bool try_run_one() {
+    Task t;
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      if (q_.empty()) return false;
+      t = q_.front();
+      q_.pop_front();
+    }
+    (*t.fn)(t.lo, t.hi);
+    t.latch->done();
+    return true;
+  }
+
+ private:
+  Pool() {
+    unsigned hw = std::thread::hardware_concurrency();
+    int n = (int)std::min(16u, std::max(2u, hw / 4));
+    if (const char *e = getenv("VCMI_HOST_THREADS")) n = std::max(0, std::min(64, atoi(e)));
+    nworkers_ = n;
+    for (int i = 0; i < n; ++i) std::thread([this] { loop(); }).detach();
+  }
+  void loop() {
+    for (;;) {
+      Task t;
+      {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_.wait(lk, [this] { return !q_.empty(); });
+        t = q_.front();
+        q_.pop_front();
+      }
+      (*t.fn)(t.lo, t.hi);
+      t.latch->done();
+    }
+  }
+  std::mutex mu_;
+  std::condition_variable cv_;
+  std::deque<Task> q_;
+  int nworkers_ = 0;
+};
+
+}  // namespace
+
+void host_parallel_for(int64_t n, int64_t grain, const std::function<void(int64_t, int64_t)> &fn) {
+  if (n <= 0) return;
+  Pool &pool = Pool::get();
+  grain = std::max<int64_t>(grain, 1);
+  int64_t parts = std::min<int64_t>((n + grain - 1) / grain, pool.workers() + 1);
+  if (parts <= 1) {
+    fn(0, n);
+    return;
+  }
+  std::vector<Task> tasks;
+  Latch latch;
+  const int64_t per = (n + parts - 1) / parts;
+  for (int64_t p = 1; p < parts; ++p) {
+    const int64_t lo = p * per, hi = std::min(n, lo + per);
+    if (lo < hi) tasks.push_back(Task{&fn, lo, hi, &latch});
+  }
+  latch.remaining = (int)tasks.size();
+  if (!tasks.empty()) pool.push(tasks.data(), (int)tasks.size());
+  fn(0, std::min(n, per));
+  // help until our own parts are done (also covers a process that forked away from its worker threads)
+  while (latch.remaining.load() > 0) {
+    if (pool.try_run_one()) continue;
+    std::unique_lock<std::mutex> lk(latch.m);
+    latch.c.wait_for(lk, std::chrono::microseconds(200), [&] { return latch.remaining.load() == 0; });
+  }
+}
+
+void host_copy(void *dst, const void *src, size_t bytes) {
+  if (bytes < ((size_t)1 << 20)) {
+    if (bytes) memcpy(dst, src, bytes);
+    return;
+  }
+  const size_t blk = (size_t)256 << 10;   // whole 256 KB blocks per part
+  const int64_t nblk = (int64_t)((bytes + blk - 1) / blk);
+  host_parallel_for(nblk, 2, [=](int64_t lo, int64_t hi) {
+    const size_t a = (size_t)lo * blk, b = std::min(bytes, (size_t)hi * blk);
+    memcpy((char *)dst + a, (const char *)src + a, b - a);
+  });
+}
+
+void host_copy_rows(void *dst, size_t dst_stride, const void *src, size_t src_stride, size_t row_bytes, int64_t rows) {
+  if (rows <= 0 || row_bytes == 0) return;
+  if (dst_stride == row_bytes && src_stride == row_bytes) {
+    host_copy(dst, src, row_bytes * (size_t)rows);
+    return;
+  }
+  const int64_t grain = std::max<int64_t>(1, (int64_t)(((size_t)512 << 10) / row_bytes));
+  host_parallel_for(rows, grain, [=](int64_t lo, int64_t hi) {
+    for (int64_t r = lo; r < hi; ++r)
+      memcpy((char *)dst + (size_t)r * dst_stride, (const char *)src + (size_t)r * src_stride, row_bytes);
+  });
+}
+
+// ------------------------------------------------------------------------------------------------
+// per-device staging ring
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+constexpr int K = 3;                                   // slots in flight
+constexpr size_t kXferChunk = (size_t)16 << 20;        // plain uploads / downloads
+constexpr size_t kPipeChunk = (size_t)32 << 20;        // pipeline chunks (bytes of the wider side)
+
+struct Ring {
+  std::mutex mu;
+  int device = -1;
+  bool ready = false;
+  hipStream_t up = nullptr, run = nullptr, down = nullptr;
+  hipEvent_t ev_up[K] = {}, ev_run[K] = {}, ev_down[K] = {}, ev_tmp = nullptr;
+  char *pin_in[K] = {}, *pin_out[K] = {}, *dev_in[K] = {}, *dev_out[K] = {};
+  size_t pin_in_cap = 0, pin_out_cap = 0, dev_in_cap = 0, dev_out_cap = 0;
+
+  int init() {
+    if (ready) return VCMI_OK;
+    VCMI_HIP(hipStreamCreateWithFlags(&up, hipStreamNonBlocking));
+    VCMI_HIP(hipStreamCreateWithFlags(&run, hipStreamNonBlocking));
+    VCMI_HIP(hipStreamCreateWithFlags(&down, hipStreamNonBlocking));
+    for (int i = 0; i < K; ++i) {
+      VCMI_HIP(hipEventCreateWithFlags(&ev_up[i], hipEventDisableTiming));
+      VCMI_HIP(hipEventCreateWithFlags(&ev_run[i], hipEventDisableTiming));
+      VCMI_HIP(hipEventCreateWithFlags(&ev_down[i], hipEventDisableTiming));
+    }
+    VCMI_HIP(hipEventCreateWithFlags(&ev_tmp, hipEventDisableTiming));
+    ready = true;
+    return VCMI_OK;
+  }
+  // every user of a set of slots first drains what an earlier call may have left in flight on them
+  int quiesce() {
+    VCMI_HIP(hipStreamSynchronize(up));
+    VCMI_HIP(hipStreamSynchronize(run));
+    VCMI_HIP(hipStreamSynchronize(down));
+    return VCMI_OK;
+  }
+  int reserve(char *(&slots)[K], size_t &cap, size_t bytes, bool pinned) {
+    if (bytes <= cap) return VCMI_OK;
+    VCMI_TRY(quiesce());
+    bytes = (bytes + 4095) & ~(size_t)4095;
+    for (int i = 0; i < K; ++i) {
+      if (slots[i]) (void)(pinned ? hipHostFree(slots[i]) : hipFree(slots[i]));
+      slots[i] = nullptr;
+    }
+    cap = 0;
+    for (int i = 0; i < K; ++i) {
+      hipError_t e = pinned ? hipHostMalloc(reinterpret_cast<void **>(&slots[i]), bytes, hipHostMallocPortable)
+                            : hipMalloc(reinterpret_cast<void **>(&slots[i]), bytes);
+      if (e != hipSuccess) {
+        slots[i] = nullptr;
+        return fail(VCMI_ERR_OOM, "%s of %zu staging bytes failed: %s", pinned ? "hipHostMalloc" : "hipMalloc", bytes,
+                    hipGetErrorString(e));
+      }
+    }
+    cap = bytes;
+    return VCMI_OK;
+  }
+};
+
+constexpr int kMaxDevices = 64;
+std::mutex g_rings_mu;
+Ring *g_rings[kMaxDevices] = {};
+
+int current_ring(Ring **out) {
+  int dev = 0;
+  VCMI_HIP(hipGetDevice(&dev));
+  if (dev < 0 || dev >= kMaxDevices) return fail(VCMI_ERR_ARG, "device index %d out of range", dev);
+  std::lock_guard<std::mutex> lk(g_rings_mu);
+  if (!g_rings[dev]) {
+    g_rings[dev] = new (std::nothrow) Ring();
+    if (!g_rings[dev]) return fail(VCMI_ERR_OOM, "out of host memory");
+    g_rings[dev]->device = dev;
+  }
+  *out = g_rings[dev];
+  return VCMI_OK;
+}
+
+struct Seg {   // one memcpy of a gather / scatter window
+  size_t slot_off;
+  char *host;
+  size_t bytes;
+};
+
+// segments of the window [w0, w1) of the concatenated pieces, split so that no segment exceeds 1 MB
+void window_segments(const std::vector<HostPiece> &pieces, const std::vector<size_t> &prefix, size_t w0, size_t w1,
+                     std::vector<Seg> &segs) {
+  segs.clear();
+  size_t p = (size_t)(std::upper_bound(prefix.begin(), prefix.end(), w0) - prefix.begin()) - 1;
+  const size_t kMax = (size_t)1 << 20;
+  for (; p < pieces.size() && prefix[p] < w1; ++p) {
+    const size_t a = std::max(w0, prefix[p]), b = std::min(w1, prefix[p] + pieces[p].bytes);
+    for (size_t o = a; o < b; o += kMax)
+      segs.push_back(Seg{o - w0, (char *)pieces[p].host + (o - prefix[p]), std::min(kMax, b - o)});
+  }
+}
+
+int do_upload(Ring *r, char *dDst, const std::vector<HostPiece> *pieces, const char *hSrc, size_t bytes, hipStream_t consumer) {
+  if (bytes == 0) return VCMI_OK;
+  const size_t chunk = std::min(bytes, kXferChunk);
+  VCMI_TRY(r->reserve(r->pin_in, r->pin_in_cap, chunk, true));
+  // dDst may still be read by work the consumer enqueued earlier
+  VCMI_HIP(hipEventRecord(r->ev_tmp, consumer));
+  VCMI_HIP(hipStreamWaitEvent(r->up, r->ev_tmp, 0));
+  std::vector<size_t> prefix;
+  std::vector<Seg> segs;
+  if (pieces) {
+    prefix.resize(pieces->size() + 1, 0);
+    for (size_t i = 0; i < pieces->size(); ++i) prefix[i + 1] = prefix[i] + (*pieces)[i].bytes;
+  }
+  int s = 0, last = 0;
+  for (size_t off = 0; off < bytes; off += chunk, s = (s + 1) % K) {
+    const size_t n = std::min(chunk, bytes - off);
+    VCMI_HIP(hipEventSynchronize(r->ev_up[s]));   // the slot's previous upload (this call's or an earlier one's)
+    char *slot = r->pin_in[s];
+    if (pieces) {
+      window_segments(*pieces, prefix, off, off + n, segs);
+      const Seg *sg = segs.data();
+      host_parallel_for((int64_t)segs.size(), 1, [=](int64_t lo, int64_t hi) {
+        for (int64_t i = lo; i < hi; ++i) memcpy(slot + sg[i].slot_off, sg[i].host, sg[i].bytes);
+      });
+    } else {
+      host_copy(slot, hSrc + off, n);
+    }
+    VCMI_HIP(hipMemcpyAsync(dDst + off, slot, n, hipMemcpyHostToDevice, r->up));
+    VCMI_HIP(hipEventRecord(r->ev_up[s], r->up));
+    last = s;
+  }
+  VCMI_HIP(hipStreamWaitEvent(consumer, r->ev_up[last], 0));
+  return VCMI_OK;
+}
+
+int do_download(Ring *r, const std::vector<HostPiece> *pieces, char *hDst, const char *dSrc, size_t bytes, hipStream_t producer) {
+  if (bytes == 0) return VCMI_OK;
+  const size_t chunk = std::min(bytes, kXferChunk);
+  VCMI_TRY(r->reserve(r->pin_out, r->pin_out_cap, chunk, true));
+  VCMI_HIP(hipEventRecord(r->ev_tmp, producer));
+  VCMI_HIP(hipStreamWaitEvent(r->down, r->ev_tmp, 0));
+  // (pin_out slots are always free here: download and pipeline calls return only after the host drained them)
+  std::vector<size_t> prefix;
+  std::vector<Seg> segs;
+  if (pieces) {
+    prefix.resize(pieces->size() + 1, 0);
+    for (size_t i = 0; i < pieces->size(); ++i) prefix[i + 1] = prefix[i] + (*pieces)[i].bytes;
+  }
+  const int64_t nch = (int64_t)((bytes + chunk - 1) / chunk);
+  for (int64_t c = 0; c <= nch; ++c) {
+    if (c < nch) {
+      const int s = (int)(c % K);
+      const size_t off = (size_t)c * chunk, n = std::min(chunk, bytes - off);
+      VCMI_HIP(hipMemcpyAsync(r->pin_out[s], dSrc + off, n, hipMemcpyDeviceToHost, r->down));
+      VCMI_HIP(hipEventRecord(r->ev_down[s], r->down));
+    }
+    const int64_t j = c - 1;
+    if (j >= 0) {
+      const int s = (int)(j % K);
+      const size_t off = (size_t)j * chunk, n = std::min(chunk, bytes - off);
+      VCMI_HIP(hipEventSynchronize(r->ev_down[s]));
+      const char *slot = r->pin_out[s];
+      if (pieces) {
+        window_segments(*pieces, prefix, off, off + n, segs);
+        const Seg *sg = segs.data();
+        host_parallel_for((int64_t)segs.size(), 1, [=](int64_t lo, int64_t hi) {
+          for (int64_t i = lo; i < hi; ++i) memcpy(sg[i].host, slot + sg[i].slot_off, sg[i].bytes);
+        });
+      } else {
+        host_copy(hDst + off, slot, n);
+      }
+    }
+  }
+  return VCMI_OK;
+}
+
+size_t total_bytes(const std::vector<HostPiece> &pieces) {
+  size_t n = 0;
+  for (auto &p : pieces) n += p.bytes;
+  return n;
+}
+
+}  // namespace
+
+int staged_upload(void *dDst, const void *hSrc, size_t bytes, hipStream_t consumer) {
+  Ring *r = nullptr;
+  VCMI_TRY(current_ring(&r));
+  std::lock_guard<std::mutex> lk(r->mu);
+  VCMI_TRY(r->init());
+  return do_upload(r, (char *)dDst, nullptr, (const char *)hSrc, bytes, consumer);
+}
+
+int staged_upload_gather(void *dDst, const std::vector<HostPiece> &pieces, hipStream_t consumer) {
+  Ring *r = nullptr;
+  VCMI_TRY(current_ring(&r));
+  std::lock_guard<std::mutex> lk(r->mu);
+  VCMI_TRY(r->init());
+  return do_upload(r, (char *)dDst, &pieces, nullptr, total_bytes(pieces), consumer);
+}
+
+int staged_download(void *hDst, const void *dSrc, size_t bytes, hipStream_t producer) {
+  Ring *r = nullptr;
+  VCMI_TRY(current_ring(&r));
+  std::lock_guard<std::mutex> lk(r->mu);
+  VCMI_TRY(r->init());
+  return do_download(r, nullptr, (char *)hDst, (const char *)dSrc, bytes, producer);
+}
+
+int staged_download_scatter(const std::vector<HostPiece> &pieces, const void *dSrc, hipStream_t producer) {
+  Ring *r = nullptr;
+  VCMI_TRY(current_ring(&r));
+  std::lock_guard<std::mutex> lk(r->mu);
+  VCMI_TRY(r->init());
+  return do_download(r, &pieces, nullptr, (const char *)dSrc, total_bytes(pieces), producer);
+}
+
+int staged_pipeline(const void *hIn, size_t in_unit, size_t in_stride, void *hOut, size_t out_unit, size_t out_stride,
+                    int64_t units, int64_t min_chunk_units, const ChunkLaunch &launch) {
+  if (units <= 0) return VCMI_OK;
+  Ring *r = nullptr;
+  VCMI_TRY(current_ring(&r));
+  std::lock_guard<std::mutex> lk(r->mu);
+  VCMI_TRY(r->init());
+  const size_t wide = std::max(in_unit, out_unit);
+  int64_t chunk = std::max<int64_t>(min_chunk_units, (int64_t)(kPipeChunk / std::max<size_t>(wide, 1)));
+  const int64_t nch = (units + chunk - 1) / chunk;
+  chunk = ((units + nch - 1) / nch + 255) / 256 * 256;
+  chunk = std::min(chunk, (units + 255) / 256 * 256);
+  VCMI_TRY(r->reserve(r->pin_in, r->pin_in_cap, (size_t)chunk * in_unit, true));
+  VCMI_TRY(r->reserve(r->pin_out, r->pin_out_cap, (size_t)chunk * out_unit, true));
+  VCMI_TRY(r->reserve(r->dev_in, r->dev_in_cap, (size_t)chunk * in_unit, false));
+  VCMI_TRY(r->reserve(r->dev_out, r->dev_out_cap, (size_t)chunk * out_unit, false));
+  VCMI_TRY(r->quiesce());
+  // A large output array is usually fresh (`similar(X)`, numpy.empty): its first touch is ~80k page faults per 320 MB.
+  // Ask for huge pages on the 2 MB-aligned interior before the workers touch it (a hint; ignored where unsupported).
+  {
+    const size_t span = (size_t)(units - 1) * out_stride + out_unit, huge = (size_t)2 << 20;
+    if (span >= 16 * huge) {
+      const uintptr_t a = ((uintptr_t)hOut + huge - 1) & ~(uintptr_t)(huge - 1), b = ((uintptr_t)hOut + span) & ~(uintptr_t)(huge - 1);
+      if (b > a) (void)madvise(reinterpret_cast<void *>(a), b - a, MADV_HUGEPAGE);
+    }
+  }
+  constexpr int LAG = K - 1;
+  int rc = VCMI_OK;
+  auto body = [&]() -> int {
+    for (int64_t c = 0; c < nch + LAG; ++c) {
+      if (c < nch) {
+        const int s = (int)(c % K);
+        const int64_t first = c * chunk, n = std::min(chunk, units - first);
+        if (c >= K) VCMI_HIP(hipEventSynchronize(r->ev_up[s]));                 // pinned slot: upload of chunk c-K done
+        host_copy_rows(r->pin_in[s], in_unit, (const char *)hIn + (size_t)first * in_stride, in_stride, in_unit, n);
+        if (c >= K) VCMI_HIP(hipStreamWaitEvent(r->up, r->ev_run[s], 0));        // device slot: kernels of chunk c-K done
+        VCMI_HIP(hipMemcpyAsync(r->dev_in[s], r->pin_in[s], (size_t)n * in_unit, hipMemcpyHostToDevice, r->up));
+        VCMI_HIP(hipEventRecord(r->ev_up[s], r->up));
+        VCMI_HIP(hipStreamWaitEvent(r->run, r->ev_up[s], 0));
+        if (c >= K) VCMI_HIP(hipStreamWaitEvent(r->run, r->ev_down[s], 0));      // output slot: download of chunk c-K done
+        VCMI_TRY(launch(r->dev_in[s], r->dev_out[s], first, n, r->run));
+        VCMI_HIP(hipEventRecord(r->ev_run[s], r->run));
+        VCMI_HIP(hipStreamWaitEvent(r->down, r->ev_run[s], 0));
+        // pin_out[s] was drained by the host LAG < K iterations ago
+        VCMI_HIP(hipMemcpyAsync(r->pin_out[s], r->dev_out[s], (size_t)n * out_unit, hipMemcpyDeviceToHost, r->down));
+        VCMI_HIP(hipEventRecord(r->ev_down[s], r->down));
+      }
+      const int64_t j = c - LAG;
+      if (j >= 0 && j < nch) {
+        const int s = (int)(j % K);
+        const int64_t first = j * chunk, n = std::min(chunk, units - first);
+        VCMI_HIP(hipEventSynchronize(r->ev_down[s]));
+        host_copy_rows((char *)hOut + (size_t)first * out_stride, out_stride, r->pin_out[s], out_unit, out_unit, n);
+      }
+    }
+    return VCMI_OK;
+  };
+  rc = body();
+  if (rc != VCMI_OK) (void)r->quiesce();   // leave nothing in flight on the slots
+  return rc;
+}
+
+}  // namespace vcmi

@@ -18,6 +18,8 @@
 #include "vcmi_common.hpp"
 #include "host_linalg.hpp"
 #include "gmmmap_handle.hpp"
+#include "devgroup.hpp"
+#include "hostpipe.hpp"
 
 #include <algorithm>
 #include <cstdlib>
@@ -37,12 +39,24 @@ struct vcmi_traj {
   vcmi::DevBuf<int64_t> mhat;
   vcmi::DevBuf<int> status;
   vcmi::DevBuf<unsigned char> uttbuf;
+  // converters on the other devices of a device group (vcmi_set_devices), made lazily by the members' worker threads
+  std::vector<vcmi_traj *> replicas;
+  uint64_t replicas_epoch = 0;
+  ~vcmi_traj() {
+    for (vcmi_traj *r : replicas) delete r;
+  }
 };
 
 // TrajectoryGVGMMMap(tgmm, mu^v, Sigma^vv), src/trajectory_gmmmap.jl:114-130
 struct vcmi_trajgv {
   vcmi_traj *t = nullptr;
   vcmi::DevBuf<double> muv, pv;   // (D), (D,D) = inv(Sigma^vv) in the Julia memory image
+  std::vector<double> h_muv, h_pv;             // host copies for the device-group replicas
+  std::vector<vcmi_trajgv *> replicas;
+  uint64_t replicas_epoch = 0;
+  ~vcmi_trajgv() {
+    for (vcmi_trajgv *r : replicas) delete r;
+  }
 };
 
 namespace vcmi {
@@ -198,134 +212,6 @@ __device__ void traj_add_block_row(double *Wd, double *rr, int LD, int D, int a,
     if (a >= 1) v += 0.5 * g[(size_t)(a - 1) * D2 + D + k];
     if (a + 1 < T) v -= 0.5 * g[(size_t)(a + 1) * D2 + D + k];
     rr[la * D + k] = v;
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
-// Register-resident solve kernel (static D).  The 3D x 3D window lives in REGISTERS, block-cyclically over a
-// 16 x 16 thread grid (thread (ti,tj) owns elements i = ti + 16 ka, j = tj + 16 kb, kb <= ka; register indices are
-// compile-time, the pivot column's tile is picked with a short select chain).  Per column: the owners of column c
-// publish it to LDS (double-buffered -> ONE barrier per column), every thread scales the entries it needs itself,
-// and the rank-1 update is pure register FMAs over all tiles (finished rows/columns are masked by zero
-// multipliers, no branches).  Between block steps the window is shifted by D
-// through LDS, where block row t+3 is assembled.
-// ------------------------------------------------------------------------------------------------
-template <int D>
-__global__ void __launch_bounds__(256)
-traj_solve_reg_kernel(const TrajUtt *__restrict__ utts, int n, const double *__restrict__ Qall,
-                      const int64_t *__restrict__ mhat_all, const double *__restrict__ g_all, double *__restrict__ ws_all,
-                      int64_t ws_stride, int *__restrict__ status) {
-  constexpr int D2 = 2 * D, W3 = 3 * D, LD = W3 + 1, NK = (W3 + 15) / 16;
-  extern __shared__ double sm[];
-  double *Wd = sm;                       // [W3][LD]  staging window (assembly, shift)
-  double *rr = Wd + (size_t)W3 * LD;     // [W3] right-hand side
-  double *colb = rr + W3;                // [2][NK*16+2] masked pivot column + the pivot + the rhs entry of its row, double-buffered
-  double *yring = colb + 2 * (NK * 16 + 2);   // [2][D]
-  double *wv = yring + 2 * D;            // [D]
-  __shared__ int bad;
-  const int tid = threadIdx.x;
-  const int ti = tid >> 4, tj = tid & 15;
-  constexpr size_t PAN = (size_t)(W3 + 1) * D;
-
-  for (int u = blockIdx.x; u < n; u += gridDim.x) {
-    const TrajUtt U = utts[u];
-    const int T = U.T;
-    if (T == 0) continue;
-    const int64_t *mh = mhat_all + U.frame0;
-    const double *g = g_all + U.frame0 * D2;
-    double *ws = ws_all + (size_t)blockIdx.x * ws_stride;
-    if (tid == 0) bad = 0;
-    for (int e = tid; e < W3 * LD; e += 256) Wd[e] = 0.0;
-    for (int e = tid; e < W3; e += 256) rr[e] = 0.0;
-    for (int e = tid; e < 2 * (NK * 16 + 2); e += 256) colb[e] = 0.0;
-    __syncthreads();
-    for (int a = 0; a < 3 && a < T; ++a) traj_add_block_row(Wd, rr, LD, D, a, a, T, mh, g, Qall);
-    __syncthreads();
-
-    for (int t = 0; t < T; ++t) {
-      // window -> registers
-      double v[NK][NK];
-#pragma unroll
-      for (int ka = 0; ka < NK; ++ka)
-#pragma unroll
-        for (int kb = 0; kb <= ka; ++kb) {
-          const int i = ti + 16 * ka, j = tj + 16 * kb;
-          v[ka][kb] = (i < W3 && j < W3) ? Wd[(size_t)i * LD + j] : 0.0;
-        }
-      double *pan = ws + (size_t)t * PAN;
-      double rreg = (tid < W3) ? rr[tid] : 0.0;
-      // the D pivot columns of this block step, in phases of one column tile each: inside a phase the tile index of
-      // the pivot column is a compile-time constant (no per-column select chain over the window registers)
-      auto column_phase = [&](auto kc_tag, int c_lo, int c_hi) {
-        constexpr int KC = decltype(kc_tag)::value;
-        for (int c = c_lo; c < c_hi; ++c) {
-          const int oc = c & 15;
-          double *cb = colb + (c & 1) * (NK * 16 + 2);
-          if (tj == oc) {                               // owners of column c publish it, already masked: rows i <= c
-#pragma unroll                                        // (finished rows / columns of the window) are written as 0 so that
-            for (int ka = 0; ka < NK; ++ka) {           // the readers need no compare/select at all; the pivot goes to cb[NK*16-1]
-              const double x = v[ka][KC <= ka ? KC : 0];      // column tile KC exists in tile rows ka >= KC only; rows
-                                                               // above the diagonal tile are finished (masked to 0 below)
-              const int i = ti + 16 * ka;
-              cb[i] = (i > c) ? x : 0.0;
-              if (i == c) cb[NK * 16] = x;
-            }
-          }
-          if (tid == c) cb[NK * 16 + 1] = rreg;          // rhs entry of the pivot row rides along
-          __syncthreads();
-          // every LDS read of this column is issued here, before the rsqrt chain: one round trip per column
-          const double piv = cb[NK * 16], rc = cb[NK * 16 + 1];
-          const double xt = (tid < W3) ? cb[tid] : 0.0;
-          if (!(piv > 0.0) && tid == 0) bad = 1;
-          const double dinv = traj_rsqrt(piv);
-          // rank-1 update v -= (x_i / piv) x_j.  Tile rows / columns below KC are finished (their published entries are
-          // 0), so they are skipped at compile time; only the row factor is scaled (one multiply per tile row)
-          const double winv = dinv * dinv;
-          double lr_[NK], lc_[NK];
-#pragma unroll
-          for (int k = KC; k < NK; ++k) {
-            lr_[k] = cb[ti + 16 * k] * winv;
-            lc_[k] = cb[tj + 16 * k];
-          }
-#pragma unroll
-          for (int ka = KC; ka < NK; ++ka)
-#pragma unroll
-            for (int kb = KC; kb <= ka; ++kb) v[ka][kb] = fma(-lr_[ka], lc_[kb], v[ka][kb]);
-          // finished column of L -> panel (rows c..3D-1; rows above the diagonal of this block column are never read)
-          const double zc = rc * dinv;
-          if (tid < W3) {
-            const double l = (tid == c) ? piv * dinv : xt * dinv;
-            if (tid >= c) pan[(size_t)tid * D + c] = l;
-            if (tid > c) rreg = fma(-zc, l, rreg);         // this thread's rhs entry lives in a register for the block step
-          }
-          if (tid == 255) pan[(size_t)W3 * D + c] = zc;
-        }
-      };
-      column_phase(std::integral_constant<int, 0>{}, 0, D < 16 ? D : 16);
-      if constexpr (D > 16) column_phase(std::integral_constant<int, 1>{}, 16, D < 32 ? D : 32);
-      if constexpr (D > 32) column_phase(std::integral_constant<int, 2>{}, 32, D < 48 ? D : 48);
-      if (tid < W3) rr[tid] = rreg;
-      __syncthreads();
-      // registers -> window shifted up-left by D; rows 2D..3D-1 are re-assembled (or zeroed at the tail)
-#pragma unroll
-      for (int ka = 0; ka < NK; ++ka)
-#pragma unroll
-        for (int kb = 0; kb <= ka; ++kb) {
-          const int i = ti + 16 * ka, j = tj + 16 * kb;
-          if (i >= D && j >= D && i < W3 && j < W3) Wd[(size_t)(i - D) * LD + (j - D)] = v[ka][kb];
-        }
-      double rsh = (tid < D2) ? rr[tid + D] : 0.0;
-      __syncthreads();
-      if (tid < D2) rr[tid] = rsh;
-      for (int e = tid; e < D * LD; e += 256) Wd[(size_t)D2 * LD + e] = 0.0;
-      if (tid < D) rr[D2 + tid] = 0.0;
-      __syncthreads();
-      if (t + 3 < T) traj_add_block_row(Wd, rr, LD, D, t + 3, 2, T, mh, g, Qall);
-      __syncthreads();
-    }
-    traj_backsub<((W3 + 1) * D + 255) / 256>(ws, PAN, D, T, Wd, yring, wv, colb, U.Y);
-    if (tid == 0 && bad) status[0] = 1;
-    __syncthreads();
   }
 }
 
@@ -1083,7 +969,7 @@ static int traj_run(vcmi_traj *t, std::vector<TrajUtt> &utts, int64_t nframes, b
   VCMI_TRY(t->mhat.reserve((size_t)nframes));
   VCMI_TRY(t->gbuf.reserve((size_t)nframes * D2));
   // (1) mhat = predict(g.px, X), src/trajectory_gmmmap.jl:82
-  const bool g_mfma = t->NT <= 6 && !getenv("VCMI_TRAJ_G_SCALAR");   // g_t on MFMA tiles (one workgroup per utterance)
+  const bool g_mfma = t->NT <= 6 && !debug_flag(kDbgTrajGScalar);   // g_t on MFMA tiles (one workgroup per utterance)
   if (contiguous) {
     VCMI_TRY(gmmmap_predict_device(t->g, dX0, D2, nframes, t->mhat.p, st));
     if (!g_mfma)
@@ -1128,8 +1014,7 @@ static int traj_run(vcmi_traj *t, std::vector<TrajUtt> &utts, int64_t nframes, b
     VCMI_HIP(hipGetLastError());
   }
   bool launched = false;
-  const char *solver = getenv("VCMI_TRAJ_SOLVER");     // "reg": the scalar-column register-window kernel (A/B runs)
-  if (!getenv("VCMI_TRAJ_GENERIC") && !(solver && !strcmp(solver, "reg"))) {
+  if (!debug_flag(kDbgTrajGeneric)) {
     switch (D) {
 #define VCMI_TRAJ_BLK_CASE(DV)                                                                                      \
   case DV: {                                                                                                        \
@@ -1147,23 +1032,6 @@ static int traj_run(vcmi_traj *t, std::vector<TrajUtt> &utts, int64_t nframes, b
       default: break;
     }
   }
-  if (!launched && !getenv("VCMI_TRAJ_GENERIC")) {
-    switch (D) {
-#define VCMI_TRAJ_CASE(DV)                                                                                          \
-  case DV: {                                                                                                        \
-    auto kern = traj_solve_reg_kernel<DV>;                                                                          \
-    VCMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,  \
-                                 (int)shmem));                                                                      \
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), shmem, st, du, n, t->Q.p, t->mhat.p, t->gbuf.p, t->ws.p, ws_stride, \
-                       t->status.p);                                                                                \
-    launched = true;                                                                                                \
-  } break;
-      VCMI_TRAJ_CASE(12) VCMI_TRAJ_CASE(16) VCMI_TRAJ_CASE(20) VCMI_TRAJ_CASE(24) VCMI_TRAJ_CASE(25) VCMI_TRAJ_CASE(30)
-      VCMI_TRAJ_CASE(32) VCMI_TRAJ_CASE(40)
-#undef VCMI_TRAJ_CASE
-      default: break;
-    }
-  }
   if (!launched) {
     VCMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(traj_solve_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)shmem));
@@ -1178,7 +1046,7 @@ static int traj_run(vcmi_traj *t, std::vector<TrajUtt> &utts, int64_t nframes, b
     const int nthr2 = kGv2Threads;
     const size_t shmem2 = ((size_t)2 * kGv2NB * 4 * t->KS * 17 + 2 * nthr2 + 3 * (size_t)D) * sizeof(double) +
                           (2 * (size_t)t->M + (size_t)pcap + (size_t)pcap / 16 + 2) * sizeof(int);
-    if (shmem2 <= 160 * 1024 - 256 && t->NT <= 6 && !getenv("VCMI_GV_ONE_TEAM")) {
+    if (shmem2 <= 160 * 1024 - 256 && t->NT <= 6 && !debug_flag(kDbgGvOneTeam)) {
       VCMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(traj_gv2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)shmem2));
       hipLaunchKernelGGL(traj_gv2_kernel, dim3(grid), dim3(nthr2), shmem2, st, du, n, D, t->M, t->KS, pcap, t->Qfrag.p, t->mhat.p,
@@ -1217,42 +1085,115 @@ static int traj_check_status(vcmi_traj *t, hipStream_t st) {
   return VCMI_OK;
 }
 
-// host-pointer batch: pack, run, unpack
-static int traj_host_batch(vcmi_traj *t, int64_t n, const double *const *X, const int64_t *T, double *const *Y,
-                           const TrajGV *gv = nullptr) {
-  if (!t) return fail(VCMI_ERR_ARG, "trajectory: NULL handle");
-  if (n < 0) return fail(VCMI_ERR_ARG, "trajectory: negative batch size");
-  if (n == 0) return VCMI_OK;
-  if (!X || !T || !Y) return fail(VCMI_ERR_ARG, "trajectory: NULL argument");
+// host-pointer batch on the current device: the utterances are gathered straight into the pinned staging slots, run,
+// and scattered back the same way
+static int traj_host_batch_local(vcmi_traj *t, int64_t n, const double *const *X, const int64_t *T, double *const *Y,
+                                 const TrajGV *gv) {
   int64_t nframes = 0;
-  for (int64_t u = 0; u < n; ++u) {
-    if (T[u] < 0 || T[u] > INT32_MAX) return fail(VCMI_ERR_DIM, "trajectory: bad utterance length");
-    if (T[u] > 0 && (!X[u] || !Y[u])) return fail(VCMI_ERR_ARG, "trajectory: NULL matrix");
-    nframes += T[u];
-  }
+  for (int64_t u = 0; u < n; ++u) nframes += T[u];
   if (nframes == 0) return VCMI_OK;
   const int D = t->D, D2 = t->D2;
   VCMI_TRY(t->xbuf.reserve((size_t)nframes * D2));
   VCMI_TRY(t->ybuf.reserve((size_t)nframes * D));
-  std::vector<double> hx((size_t)nframes * D2);
   std::vector<TrajUtt> utts(n);
+  std::vector<HostPiece> up, down;
   int64_t f0 = 0;
   for (int64_t u = 0; u < n; ++u) {
-    if (T[u] > 0) memcpy(&hx[(size_t)f0 * D2], X[u], sizeof(double) * D2 * T[u]);
+    if (T[u] > 0) {
+      up.push_back(HostPiece{const_cast<double *>(X[u]), sizeof(double) * D2 * T[u]});
+      down.push_back(HostPiece{Y[u], sizeof(double) * D * T[u]});
+    }
     utts[u] = TrajUtt{t->xbuf.p + (size_t)f0 * D2, t->ybuf.p + (size_t)f0 * D, f0, (int32_t)T[u], (int32_t)u};
     f0 += T[u];
   }
-  VCMI_HIP(hipMemcpy(t->xbuf.p, hx.data(), hx.size() * 8, hipMemcpyHostToDevice));
+  VCMI_TRY(staged_upload_gather(t->xbuf.p, up, nullptr));
   VCMI_TRY(traj_run(t, utts, nframes, true, t->xbuf.p, nullptr, gv));
   VCMI_TRY(traj_check_status(t, nullptr));
-  std::vector<double> hy((size_t)nframes * D);
-  VCMI_HIP(hipMemcpy(hy.data(), t->ybuf.p, hy.size() * 8, hipMemcpyDeviceToHost));
-  f0 = 0;
-  for (int64_t u = 0; u < n; ++u) {
-    if (T[u] > 0) memcpy(Y[u], &hy[(size_t)f0 * D], sizeof(double) * D * T[u]);
-    f0 += T[u];
+  return staged_download_scatter(down, t->ybuf.p, nullptr);
+}
+
+static void traj_sync_replicas(vcmi_traj *t) {
+  gmmmap_sync_replicas(t->g);
+  const uint64_t ep = group_epoch();
+  if (t->replicas_epoch == ep && (int)t->replicas.size() == group_size()) return;
+  for (vcmi_traj *r : t->replicas) delete r;
+  t->replicas.assign((size_t)group_size(), nullptr);
+  t->replicas_epoch = ep;
+}
+
+// member i's trajectory converter: t itself when member i got t's own GMMMap, else a replica over the member's GMMMap
+static int traj_member(vcmi_traj *t, int member, vcmi_traj **out) {
+  vcmi_gmmmap *g = nullptr;
+  VCMI_TRY(gmmmap_member(t->g, member, &g));
+  if (g == t->g) {
+    *out = t;
+    return VCMI_OK;
   }
+  vcmi_traj *&r = t->replicas[(size_t)member];
+  if (!r) VCMI_TRY(vcmi_traj_create(g, t->length, &r));
+  *out = r;
   return VCMI_OK;
+}
+
+// utterances below which a batch stays on one device even when a device group is set
+static constexpr int64_t kGroupMinUtts = 8;
+
+// Utterances (and the chunks of vc) are independent: with a device group they are split by length
+// (longest-processing-time) and every member converts its share on its own device; no collective.
+static int traj_host_batch(vcmi_traj *t, int64_t n, const double *const *X, const int64_t *T, double *const *Y,
+                           const TrajGV *gv = nullptr, vcmi_trajgv *gvh = nullptr) {
+  if (!t) return fail(VCMI_ERR_ARG, "trajectory: NULL handle");
+  if (n < 0) return fail(VCMI_ERR_ARG, "trajectory: negative batch size");
+  if (n == 0) return VCMI_OK;
+  if (!X || !T || !Y) return fail(VCMI_ERR_ARG, "trajectory: NULL argument");
+  for (int64_t u = 0; u < n; ++u) {
+    if (T[u] < 0 || T[u] > INT32_MAX) return fail(VCMI_ERR_DIM, "trajectory: bad utterance length");
+    if (T[u] > 0 && (!X[u] || !Y[u])) return fail(VCMI_ERR_ARG, "trajectory: NULL matrix");
+  }
+  const int m = group_size();
+  if (m == 0 || n < kGroupMinUtts) return traj_host_batch_local(t, n, X, T, Y, gv);
+  traj_sync_replicas(t);
+  if (gvh && (gvh->replicas_epoch != group_epoch() || (int)gvh->replicas.size() != m)) {
+    for (vcmi_trajgv *r : gvh->replicas) delete r;
+    gvh->replicas.assign((size_t)m, nullptr);
+    gvh->replicas_epoch = group_epoch();
+  }
+  std::vector<int64_t> costs((size_t)n);
+  for (int64_t u = 0; u < n; ++u) costs[(size_t)u] = T[u];
+  const std::vector<int> part = shard_by_cost(costs, m);
+  return group_run([&](int i) -> int {
+    std::vector<const double *> x2;
+    std::vector<double *> y2;
+    std::vector<int64_t> T2;
+    for (int64_t u = 0; u < n; ++u) {
+      if (part[(size_t)u] != i) continue;
+      x2.push_back(X[u]);
+      y2.push_back(Y[u]);
+      T2.push_back(T[u]);
+    }
+    if (x2.empty()) return VCMI_OK;
+    vcmi_traj *r = nullptr;
+    VCMI_TRY(traj_member(t, i, &r));
+    TrajGV gv2;
+    if (gv) {
+      gv2 = *gv;
+      if (r != t) {   // the GV statistics on this member's device
+        vcmi_trajgv *&gr = gvh->replicas[(size_t)i];
+        if (!gr) {
+          gr = new (std::nothrow) vcmi_trajgv();
+          if (!gr) return fail(VCMI_ERR_OOM, "out of host memory");
+          gr->t = r;
+          VCMI_TRY(gr->muv.alloc(gvh->h_muv.size()));
+          VCMI_TRY(gr->pv.alloc(gvh->h_pv.size()));
+          VCMI_HIP(hipMemcpy(gr->muv.p, gvh->h_muv.data(), gvh->h_muv.size() * 8, hipMemcpyHostToDevice));
+          VCMI_HIP(hipMemcpy(gr->pv.p, gvh->h_pv.data(), gvh->h_pv.size() * 8, hipMemcpyHostToDevice));
+        }
+        gv2.muv = gr->muv.p;
+        gv2.pv = gr->pv.p;
+      }
+    }
+    return traj_host_batch_local(r, (int64_t)x2.size(), x2.data(), T2.data(), y2.data(), gv ? &gv2 : nullptr);
+  });
 }
 
 }  // namespace vcmi
@@ -1337,7 +1278,11 @@ extern "C" int64_t vcmi_traj_length(const vcmi_traj *t) { return t ? t->length :
 extern "C" int vcmi_traj_convert(vcmi_traj *t, const double *X, int64_t T, double *Y) {
   const double *xs[1] = {X};
   double *ys[1] = {Y};
-  return traj_host_batch(t, 1, xs, &T, ys);
+  VCMI_TRY(traj_host_batch(t, 1, xs, &T, ys));
+  // The reference rebuilds W when the sequence length differs from length(tgmm) (src/trajectory_gmmmap.jl:70-72), so
+  // afterwards length(tgmm) == T -- and with it the chunk length of the next vc call (src/common.jl:41).  Reproduced.
+  t->length = T;
+  return VCMI_OK;
 }
 
 extern "C" int vcmi_traj_convert_batch(vcmi_traj *t, int64_t n, const double *const *X, const int64_t *T, double *const *Y) {
@@ -1359,6 +1304,7 @@ extern "C" int vcmi_traj_convert_batch_dev(vcmi_traj *t, int64_t n, const double
     utts[u] = TrajUtt{dX + x_off[u], dY + y_off[u], f0, (int32_t)T[u], (int32_t)u};
     f0 += T[u];
   }
+  if (f0 == 0) return VCMI_OK;   // only empty utterances: nothing was launched, there is no status to read
   VCMI_TRY(traj_run(t, utts, f0, contiguous, dX + x_off[0], as_stream(stream)));
   return traj_check_status(t, as_stream(stream));
 }
@@ -1385,6 +1331,7 @@ extern "C" int vcmi_vc_traj(vcmi_traj *t, const double *fm, int64_t T, double *o
     out[(size_t)f * (D + 1)] = fm[(size_t)f * (D2 + 1)];   // power row kept, src/common.jl:60
     memcpy(out + (size_t)f * (D + 1) + 1, &y[(size_t)f * D], sizeof(double) * D);
   }
+  t->length = Ts[nch - 1];   // the last fvconvert of the loop left W at the last chunk's length (see vcmi_traj_convert)
   return VCMI_OK;
 }
 
@@ -1430,6 +1377,8 @@ extern "C" int vcmi_trajgv_create(vcmi_traj *t, const double *muv, const double 
     delete h;
     return fail(VCMI_ERR_HIP, "TrajectoryGVGMMMap: upload failed: %s", hipGetErrorString(e));
   }
+  h->h_muv.assign(muv, muv + D);
+  h->h_pv = Pj;
   *out = h;
   return VCMI_OK;
 }
@@ -1455,13 +1404,15 @@ extern "C" int vcmi_trajgv_convert_batch(vcmi_trajgv *h, int64_t n, const double
   TrajGV gv{};
   gv.alpha = alpha;
   VCMI_TRY(trajgv_args(h, n, T, epochs, &gv));
-  return traj_host_batch(h->t, n, X, T, Y, &gv);
+  return traj_host_batch(h->t, n, X, T, Y, &gv, h);
 }
 
 extern "C" int vcmi_trajgv_convert(vcmi_trajgv *h, const double *X, int64_t T, int epochs, double alpha, double *Y) {
   const double *xs[1] = {X};
   double *ys[1] = {Y};
-  return vcmi_trajgv_convert_batch(h, 1, xs, &T, epochs, alpha, ys);
+  VCMI_TRY(vcmi_trajgv_convert_batch(h, 1, xs, &T, epochs, alpha, ys));
+  h->t->length = T;   // fvconvert(tgv.tgmm, X) rebuilt W for this T, src/trajectory_gmmmap.jl:70-72,146
+  return VCMI_OK;
 }
 
 extern "C" int vcmi_trajgv_convert_batch_dev(vcmi_trajgv *h, int64_t n, const double *dX, const int64_t *x_off, const int64_t *T,
@@ -1482,6 +1433,7 @@ extern "C" int vcmi_trajgv_convert_batch_dev(vcmi_trajgv *h, int64_t n, const do
     utts[u] = TrajUtt{dX + x_off[u], dY + y_off[u], f0, (int32_t)T[u], (int32_t)u};
     f0 += T[u];
   }
+  if (f0 == 0) return VCMI_OK;
   VCMI_TRY(traj_run(t, utts, f0, contiguous, dX + x_off[0], as_stream(stream), &gv));
   return traj_check_status(t, as_stream(stream));
 }

@@ -60,6 +60,17 @@ struct DevBuf {
 
 int check_device();  // VCMI_ERR_NO_DEVICE when no HIP device is visible
 
+// Test hook (vcmi_debug_force, not part of include/vcmi.h): forces the fallback kernels that a given shape would not
+// select by itself, so that the parity tests cover them.  Nothing on the call path reads the environment.
+enum : unsigned {
+  kDbgTrajGeneric = 1u,      // runtime-D LDS-window trajectory solver instead of the MFMA-blocked one
+  kDbgTrajGScalar = 2u,      // one-workgroup-per-frame g_t kernel instead of the MFMA one
+  kDbgGvOneTeam = 4u,        // one-team GV kernel (the path of very long utterances)
+  kDbgPredictTwoPass = 8u,   // (M,T) log-density matrix + argmax kernel instead of the in-kernel argmax
+  kDbgEstepGeneric = 16u     // generic diagonal E-step kernels instead of the MFMA one
+};
+bool debug_flag(unsigned which);
+
 inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 
 }  // namespace vcmi

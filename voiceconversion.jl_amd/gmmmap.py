@@ -82,7 +82,12 @@ class GMMMap(FrameByFrameConverter):
         D, T = X.shape
         if D != self._D:
             raise _lib.DimensionMismatch("Inconsistent dimentions.")
-        Y = np.empty((D, T), order="F")
+        if out is None:
+            Y = np.empty((D, T), order="F")
+        else:
+            Y = out
+            if Y.shape != (D, T) or Y.dtype != np.float64 or not Y.flags.f_contiguous:
+                raise _lib.DimensionMismatch("out must be a Fortran-ordered float64 (D,T) array")
         _lib.check(_lib.lib.vcmi_gmmmap_convert(self._h, _lib.dptr(X), D, T, _lib.dptr(Y), D))
         return Y
 

@@ -1,23 +1,30 @@
 # VoiceConversionMI.jl -- drop-in Julia host side for the MI355X hot path of VoiceConversion.jl.
 #
-# Thin, logic-free `ccall` wrapper over libvcmi.so (include/vcmi.h).  It keeps the reference's exported names
-# and signatures (reference src/VoiceConversion.jl:12-38, src/dtw.jl:7) for the hot path:
-#   GMMMap, fvconvert, vc, dim, ncomponents, TrajectoryGMMMap, DTW, fit!, update!, set_template!, backward,
-#   align, push_delta
+# Thin `ccall` wrapper over libvcmi.so (include/vcmi.h).  It keeps the reference's exported names, signatures and
+# the struct fields its own code reads (reference src/VoiceConversion.jl:12-38, src/dtw.jl:7):
+#   GMMMapParam, GMMMap (fields params, px), fvconvert, vc, dim, ncomponents, predict_proba(g.px, X),
+#   predict(g.px, X), TrajectoryGMMMap, TrajectoryGVGMMMap, DTW, fit!, update!, set_template!, backward, align,
+#   align_mcep, push_delta, VarianceScaling, fvpostf, fvpostf!, diffgmm(params)
 # and adds the batch methods the reference lacks (fvconvert(g, X::Matrix), fit!(d, templates, sequences),
-# align(srcs, tgts), estep_diag).
+# estep_diag, estep_full, GMMEM) plus set_devices (single host process driving several GPUs).
 #
-# NOTE: no Julia binary exists in the build image or on the GPU box, so this file has never been executed; it
-# is kept mechanical on purpose -- every method is one ccall plus the status check.  The identical ABI is
-# exercised from Python ctypes (voiceconversion.jl_amd/_lib.py) by the parity tests.
-# Written for Julia >= 1.0; for the reference's Julia 0.5 replace `mutable struct` by `type`,
-# `finalizer(f, obj)` by `finalizer(obj, f)` and `Cvoid` by `Void`.
+# NOTE: no Julia binary exists in the build image or on the GPU box, so this file has never been executed.  What can
+# be checked without Julia is checked by tests/test_julia_binding_lint.py: every `ccall` (symbol, return type, arity
+# and each argument type) against include/vcmi.h, and every `obj.field` access against the struct declarations.
+# The identical ABI is exercised from Python ctypes (voiceconversion.jl_amd/_lib.py) by the parity tests.
+# Written for Julia >= 1.0; for the reference's Julia 0.5 replace `mutable struct` by `type`, `struct` by
+# `immutable`, `finalizer(f, obj)` by `finalizer(obj, f)`, `Cvoid` by `Void`, `undef` constructors by `Array(T, dims)`.
 module VoiceConversionMI
 
-export GMMMap, TrajectoryGMMMap, fvconvert, vc, dim, ncomponents,
-       DTW, fit!, update!, set_template!, backward, align, push_delta,
-       predict_proba, predict, estep_diag, estep_full, GMMEM, estep!, mstep!, params,
-       TrajectoryGVGMMMap, VarianceScaling, fvpostf, fvpostf!, diffgmm, align_mcep
+import LinearAlgebra
+
+export FrameByFrameConverter, TrajectoryConverter, GMMMapParam, GMMMap, TrajectoryGMMMap, TrajectoryGVGMMMap,
+       fvconvert, vc, ncomponents, dim,
+       VarianceScaling, fvpostf!, fvpostf,
+       align, align_mcep, push_delta,
+       DTW, fit!, update!, set_template!, backward,
+       predict_proba, predict_proba!, predict, predict!, diffgmm,
+       estep_diag, estep_full, GMMEM, estep!, mstep!, params, set_devices, device_count
 
 const libvcmi = get(ENV, "LIBVCMI", "libvcmi")
 
@@ -29,24 +36,115 @@ function check(status::Cint)
     status == 2 && throw(LinearAlgebra.PosDefException(0))             # MvNormal in src/gmm.jl:17
     error("libvcmi status $status: $msg")
 end
-import LinearAlgebra
+
+function device_count()
+    n = Ref{Cint}(0)
+    check(ccall((:vcmi_device_count, libvcmi), Cint, (Ref{Cint},), n))
+    Int(n[])
+end
+
+# One host process, several GPUs: after set_devices(0:7) the host-pointer entry points (fvconvert / vc on matrices,
+# fit! / align on vectors of pairs, trajectory batches, estep_*) shard their frames / pairs / utterances over these
+# devices; only the E-step exchanges data (one RCCL all-reduce of the statistics).  set_devices(Int[]) restores the
+# single-device behaviour.
+function set_devices(devices)
+    d = Cint[Cint(x) for x in devices]
+    check(ccall((:vcmi_set_devices, libvcmi), Cint, (Ptr{Cint}, Cint), d, length(d)))
+end
 
 abstract type AbstractConverter end                                    # src/common.jl:2-4
 abstract type FrameByFrameConverter <: AbstractConverter end
 abstract type TrajectoryConverter <: AbstractConverter end
 
-# ---------------------------------------------------------------------------------------------- GMMMap
-mutable struct GMMMap <: FrameByFrameConverter                        # src/gmmmap.jl:57
-    h::Ptr{Cvoid}
-    function GMMMap(weights::Vector{Float64}, μ::Matrix{Float64}, Σ::Array{Float64,3}; swap::Bool=false)
-        h = Ref{Ptr{Cvoid}}(C_NULL)
-        check(ccall((:vcmi_gmmmap_create, libvcmi), Cint,
-                    (Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Cint, Cint, Cint, Ref{Ptr{Cvoid}}),
-                    weights, μ, Σ, size(μ, 1), length(weights), swap ? 1 : 0, h))
-        g = new(h[])
-        finalizer(x -> ccall((:vcmi_gmmmap_destroy, libvcmi), Cint, (Ptr{Cvoid},), x.h), g)
-        g
+# ------------------------------------------------------------------------------------------ GMMMapParam
+struct GMMMapParam                                                     # src/gmmmap.jl:10-39
+    weights::Vector{Float64}
+    μˣ::Matrix{Float64}
+    μʸ::Matrix{Float64}
+    Σˣˣ::Array{Float64,3}
+    Σˣʸ::Array{Float64,3}
+    Σʸˣ::Array{Float64,3}
+    Σʸʸ::Array{Float64,3}
+    ΣʸˣΣˣˣ⁻¹::Array{Float64,3}
+end
+
+function GMMMapParam(weights::Vector{Float64}, μˣ::Matrix{Float64}, μʸ::Matrix{Float64}, Σˣˣ::Array{Float64,3},
+                     Σˣʸ::Array{Float64,3}, Σʸˣ::Array{Float64,3}, Σʸʸ::Array{Float64,3})
+    M = length(weights)
+    D = size(μˣ, 1)
+    A = Array{Float64,3}(undef, D, D, M)
+    for m = 1:M                                                        # src/gmmmap.jl:33-36 (one-time set-up)
+        A[:, :, m] = Σʸˣ[:, :, m] * inv(Σˣˣ[:, :, m])
     end
+    GMMMapParam(weights, μˣ, μʸ, Σˣˣ, Σˣʸ, Σʸˣ, Σʸʸ, A)
+end
+
+function split_joint_gmm(μ::Matrix{Float64}, Σ::Array{Float64,3})     # src/gmmmap.jl:41-52
+    D = size(μ, 1) >> 1
+    μ[1:D, :], μ[D+1:end, :], Σ[1:D, 1:D, :], Σ[1:D, D+1:end, :], Σ[D+1:end, 1:D, :], Σ[D+1:end, D+1:end, :]
+end
+
+# joint (μ, Σ) image of a parameter set: what vcmi_gmmmap_create takes
+function joint_gmm(p::GMMMapParam)
+    μ = vcat(p.μˣ, p.μʸ)
+    D, M = size(p.μˣ)
+    Σ = Array{Float64,3}(undef, 2D, 2D, M)
+    Σ[1:D, 1:D, :] = p.Σˣˣ
+    Σ[1:D, D+1:end, :] = p.Σˣʸ
+    Σ[D+1:end, 1:D, :] = p.Σʸˣ
+    Σ[D+1:end, D+1:end, :] = p.Σʸʸ
+    μ, Σ
+end
+
+# ------------------------------------------------------------------------------------------ GMM (g.px)
+# In the reference g.px is a Distributions.MixtureModel (src/gmm.jl:5-20); here it is a view onto the converter's
+# device-resident whitening blocks.  `owner` keeps the handle alive.
+mutable struct GMM
+    h::Ptr{Cvoid}
+    D::Int
+    M::Int
+    owner::Any
+end
+
+# ---------------------------------------------------------------------------------------------- GMMMap
+mutable struct GMMMap <: FrameByFrameConverter                        # src/gmmmap.jl:57-60
+    params::GMMMapParam
+    px::GMM
+    h::Ptr{Cvoid}
+end
+
+function gmmmap_handle(weights::Vector{Float64}, μ::Matrix{Float64}, Σ::Array{Float64,3}, swap::Bool)
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:vcmi_gmmmap_create, libvcmi), Cint,
+                (Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Cint, Cint, Cint, Ref{Ptr{Cvoid}}),
+                weights, μ, Σ, size(μ, 1), length(weights), swap ? 1 : 0, h))
+    h[]
+end
+
+function GMMMap(weights::Vector{Float64}, μ::Matrix{Float64}, Σ::Array{Float64,3}; swap::Bool=false)   # src/gmmmap.jl:62-90
+    size(Σ) == (size(μ, 1), size(μ, 1), length(weights)) || throw(DimensionMismatch("weights, μ, Σ are inconsistent"))
+    μˣ, μʸ, Σˣˣ, Σˣʸ, Σʸˣ, Σʸʸ = split_joint_gmm(μ, Σ)
+    if swap                                                            # src/gmmmap.jl:74-78
+        μˣ, μʸ = μʸ, μˣ
+        Σˣˣ, Σʸʸ = Σʸʸ, Σˣˣ
+        Σˣʸ, Σʸˣ = Σʸˣ, Σˣʸ
+    end
+    p = GMMMapParam(weights, μˣ, μʸ, Σˣˣ, Σˣʸ, Σʸˣ, Σʸʸ)
+    h = gmmmap_handle(weights, μ, Σ, swap)
+    g = GMMMap(p, GMM(h, size(μˣ, 1), length(weights), nothing), h)
+    g.px.owner = g
+    finalizer(x -> ccall((:vcmi_gmmmap_destroy, libvcmi), Cint, (Ptr{Cvoid},), x.h), g)
+    g
+end
+
+# converter over an explicit parameter set, e.g. GMMMap(diffgmm(g.params))
+function GMMMap(p::GMMMapParam)
+    μ, Σ = joint_gmm(p)
+    h = gmmmap_handle(p.weights, μ, Σ, false)
+    g = GMMMap(p, GMM(h, size(p.μˣ, 1), length(p.weights), nothing), h)
+    g.px.owner = g
+    finalizer(x -> ccall((:vcmi_gmmmap_destroy, libvcmi), Cint, (Ptr{Cvoid},), x.h), g)
+    g
 end
 
 Base.length(g::GMMMap) = 1                                             # src/gmmmap.jl:93
@@ -56,8 +154,8 @@ Base.size(g::GMMMap) = (dim(g), length(g))
 
 # fvconvert(g, x) -- src/gmmmap.jl:101-118
 function fvconvert(g::GMMMap, x::Vector{Float64})
-    y = Vector{Float64}(undef, dim(g))
     length(x) == dim(g) || throw(DimensionMismatch("Inconsistent dimentions."))
+    y = Vector{Float64}(undef, dim(g))
     check(ccall((:vcmi_gmmmap_convert, libvcmi), Cint,
                 (Ptr{Cvoid}, Ptr{Float64}, Int64, Int64, Ptr{Float64}, Int64), g.h, x, dim(g), 1, y, dim(g)))
     y
@@ -82,18 +180,36 @@ function vc(g::GMMMap, fm::Matrix{Float64})
     out
 end
 
-# predict_proba / predict on g.px -- src/gmm.jl:24-58 (here methods of the mapper itself)
-function predict_proba(g::GMMMap, X::Matrix{Float64})
-    P = Matrix{Float64}(undef, ncomponents(g), size(X, 2))
+# predict_proba / predict -- src/gmm.jl:24-58, called as predict_proba(g.px, x) (src/gmmmap.jl:114) and
+# predict(g.px, X) (src/trajectory_gmmmap.jl:82)
+function predict_proba!(r::Matrix{Float64}, gmm::GMM, X::Matrix{Float64})          # src/gmm.jl:32-37
+    size(X, 1) == gmm.D || throw(DimensionMismatch("Inconsistent dimentions."))
+    size(r) == (gmm.M, size(X, 2)) || throw(DimensionMismatch("posterior matrix must be (M,T)"))
     check(ccall((:vcmi_gmmmap_posterior, libvcmi), Cint, (Ptr{Cvoid}, Ptr{Float64}, Int64, Int64, Ptr{Float64}),
-                g.h, X, size(X, 1), size(X, 2), P))
-    P
+                gmm.h, X, size(X, 1), size(X, 2), r))
+    r
 end
-function predict(g::GMMMap, X::Matrix{Float64})
-    idx = Vector{Int64}(undef, size(X, 2))
+predict_proba(gmm::GMM, X::Matrix{Float64}) = predict_proba!(Matrix{Float64}(undef, gmm.M, size(X, 2)), gmm, X)   # :39-41
+predict_proba(gmm::GMM, x::Vector{Float64}) = vec(predict_proba(gmm, reshape(x, length(x), 1)))                    # :24-30
+
+function predict!(r::Vector{Int}, gmm::GMM, X::Matrix{Float64})                    # src/gmm.jl:49-54
+    size(X, 1) == gmm.D || throw(DimensionMismatch("Inconsistent dimentions."))
+    length(r) == size(X, 2) || throw(DimensionMismatch("label vector must have one entry per frame"))
     check(ccall((:vcmi_gmmmap_predict, libvcmi), Cint, (Ptr{Cvoid}, Ptr{Float64}, Int64, Int64, Ptr{Int64}),
-                g.h, X, size(X, 1), size(X, 2), idx))
-    idx
+                gmm.h, X, size(X, 1), size(X, 2), r))
+    r
+end
+predict(gmm::GMM, X::Matrix{Float64}) = predict!(Vector{Int}(undef, size(X, 2)), gmm, X)                           # :56-58
+predict(gmm::GMM, x::Vector{Float64}) = predict(gmm, reshape(x, length(x), 1))[1]                                  # :44-47
+
+# diffgmm(params) -- src/diffgmm.jl:9-25 (the reference's `(Σˣʸ - Σˣˣ)'` is applied per mixture)
+function diffgmm(p::GMMMapParam)
+    μ, Σ = joint_gmm(p)
+    μd = similar(μ); Σd = similar(Σ)
+    check(ccall((:vcmi_diffgmm, libvcmi), Cint, (Ptr{Float64}, Ptr{Float64}, Cint, Cint, Ptr{Float64}, Ptr{Float64}),
+                μ, Σ, size(μ, 1), size(μ, 2), μd, Σd))
+    μˣ, μʸ, Σˣˣ, Σˣʸ, Σʸˣ, Σʸʸ = split_joint_gmm(μd, Σd)
+    GMMMapParam(p.weights, μˣ, μʸ, Σˣˣ, Σˣʸ, Σʸˣ, Σʸʸ)
 end
 
 # ---------------------------------------------------------------------------------- TrajectoryGMMMap
@@ -108,6 +224,8 @@ mutable struct TrajectoryGMMMap <: TrajectoryConverter                 # src/tra
         t
     end
 end
+# length(t) follows the reference: fvconvert rebuilds W for a new T (src/trajectory_gmmmap.jl:70-72), so the length
+# is that of the last converted (sub-)sequence; the library tracks it.
 Base.length(t::TrajectoryGMMMap) = Int(ccall((:vcmi_traj_length, libvcmi), Int64, (Ptr{Cvoid},), t.h))
 dim(t::TrajectoryGMMMap) = dim(t.gmmmap)
 ncomponents(t::TrajectoryGMMMap) = ncomponents(t.gmmmap)
@@ -122,8 +240,22 @@ function fvconvert(t::TrajectoryGMMMap, X::Matrix{Float64})
     Y
 end
 
-# vc(c::TrajectoryConverter, fm) -- src/common.jl:31-63
+# batch method: independent utterances in one launch
+function fvconvert(t::TrajectoryGMMMap, Xs::Vector{Matrix{Float64}})
+    n = length(Xs)
+    T = Int64[size(x, 2) for x in Xs]
+    Ys = [Matrix{Float64}(undef, dim(t) >> 1, k) for k in T]
+    GC.@preserve Xs Ys begin
+        check(ccall((:vcmi_traj_convert_batch, libvcmi), Cint,
+                    (Ptr{Cvoid}, Int64, Ptr{Ptr{Float64}}, Ptr{Int64}, Ptr{Ptr{Float64}}),
+                    t.h, n, pointer.(Xs), T, pointer.(Ys)))
+    end
+    Ys
+end
+
+# vc(c::TrajectoryConverter, fm) -- src/common.jl:31-63: all chunks of length(c) frames in one launch
 function vc(t::TrajectoryGMMMap, fm::Matrix{Float64})
+    size(fm, 1) == dim(t) + 1 || throw(DimensionMismatch("Inconsistent dimentions."))
     out = Matrix{Float64}(undef, (size(fm, 1) - 1) >> 1 + 1, size(fm, 2))
     check(ccall((:vcmi_vc_traj, libvcmi), Cint, (Ptr{Cvoid}, Ptr{Float64}, Int64, Ptr{Float64}),
                 t.h, fm, size(fm, 2), out))
@@ -228,6 +360,19 @@ function align(src::Matrix{Float64}, tgt::Matrix{Float64})
     src, newtgt
 end
 
+# batch method: n pairs in one launch
+function align(srcs::Vector{Matrix{Float64}}, tgts::Vector{Matrix{Float64}})
+    n = length(srcs)
+    S = Int64[size(s, 2) for s in srcs]; T = Int64[size(t, 2) for t in tgts]
+    newtgts = [similar(s) for s in srcs]
+    GC.@preserve srcs tgts newtgts begin
+        check(ccall((:vcmi_align_batch, libvcmi), Cint,
+                    (Int64, Ptr{Ptr{Float64}}, Ptr{Int64}, Ptr{Ptr{Float64}}, Ptr{Int64}, Cint, Ptr{Ptr{Float64}}),
+                    n, pointer.(srcs), S, pointer.(tgts), T, size(srcs[1], 1), pointer.(newtgts)))
+    end
+    srcs, newtgts
+end
+
 # ---------------------------------------------------------------------------------------------- E-step
 # sufficient statistics of a diagonal GMM on joint features X (Dj,N); replaces the E-step inside
 # `gmm[:fit](dataset.X')` of bin/train_gmm.jl:103
@@ -257,31 +402,57 @@ end
 # --------------------------------------------------------------------------- GV trajectory converter, post filter
 # TrajectoryGVGMMMap(tgmm, μᵛ, Σᵛᵛ) and fvconvert(tgv, X; epochs, α) -- src/trajectory_gmmmap.jl:114-189
 mutable struct TrajectoryGVGMMMap <: TrajectoryConverter
-    handle::Ptr{Cvoid}
     tgmm::TrajectoryGMMMap
+    μᵛ::Vector{Float64}
+    Σᵛᵛ::Matrix{Float64}
+    h::Ptr{Cvoid}
     function TrajectoryGVGMMMap(tgmm::TrajectoryGMMMap, μᵛ::Vector{Float64}, Σᵛᵛ::Matrix{Float64})
-        @assert sum(μᵛ .< 0) == 0
+        @assert sum(μᵛ .< 0) == 0                                       # src/trajectory_gmmmap.jl:124
         h = Ref{Ptr{Cvoid}}(C_NULL)
         check(ccall((:vcmi_trajgv_create, libvcmi), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ref{Ptr{Cvoid}}),
-                    tgmm.handle, μᵛ, Σᵛᵛ, h))
-        tgv = new(h[], tgmm)
-        finalizer(x -> ccall((:vcmi_trajgv_destroy, libvcmi), Cint, (Ptr{Cvoid},), x.handle), tgv)
+                    tgmm.h, μᵛ, Σᵛᵛ, h))
+        tgv = new(tgmm, μᵛ, Σᵛᵛ, h[])
+        finalizer(x -> ccall((:vcmi_trajgv_destroy, libvcmi), Cint, (Ptr{Cvoid},), x.h), tgv)
         tgv
     end
 end
 Base.length(t::TrajectoryGVGMMMap) = length(t.tgmm)
 dim(t::TrajectoryGVGMMMap) = dim(t.tgmm)
 ncomponents(t::TrajectoryGVGMMMap) = ncomponents(t.tgmm)
+Base.size(t::TrajectoryGVGMMMap) = size(t.tgmm)
 
 function fvconvert(tgv::TrajectoryGVGMMMap, X::Matrix{Float64}; epochs::Int=100, α::Float64=1.0e-5, verbose::Bool=false)
     size(X, 1) == dim(tgv) || throw(DimensionMismatch("Inconsistent dimentions."))
     Y = Matrix{Float64}(undef, dim(tgv) >> 1, size(X, 2))
     check(ccall((:vcmi_trajgv_convert, libvcmi), Cint, (Ptr{Cvoid}, Ptr{Float64}, Int64, Cint, Cdouble, Ptr{Float64}),
-                tgv.handle, X, size(X, 2), epochs, α, Y))
+                tgv.h, X, size(X, 2), epochs, α, Y))
     Y
 end
 
-# fvpostf(vs::VarianceScaling, src) -- src/gv.jl:10-21 ; diffgmm on joint parameters -- src/diffgmm.jl:9-25
+# vc(c::TrajectoryConverter, fm) for the GV converter -- src/common.jl:31-63: the chunks (default epochs / α, as the
+# reference's loop calls fvconvert(c, phrase)) go to the device as one batch
+function vc(tgv::TrajectoryGVGMMMap, fm::Matrix{Float64})
+    size(fm, 1) == dim(tgv) + 1 || throw(DimensionMismatch("Inconsistent dimentions."))
+    T = size(fm, 2)
+    limit = length(tgv)
+    spans = [(b, min(b + limit - 1, T)) for b in 1:limit:T]
+    Xs = [fm[2:end, b:e] for (b, e) in spans]
+    Ts = Int64[size(x, 2) for x in Xs]
+    Ys = [Matrix{Float64}(undef, dim(tgv) >> 1, k) for k in Ts]
+    GC.@preserve Xs Ys begin
+        check(ccall((:vcmi_trajgv_convert_batch, libvcmi), Cint,
+                    (Ptr{Cvoid}, Int64, Ptr{Ptr{Float64}}, Ptr{Int64}, Cint, Cdouble, Ptr{Ptr{Float64}}),
+                    tgv.h, length(Xs), pointer.(Xs), Ts, 100, 1.0e-5, pointer.(Ys)))
+    end
+    out = Matrix{Float64}(undef, dim(tgv) >> 1 + 1, T)
+    for (k, (b, e)) in enumerate(spans)
+        out[2:end, b:e] = Ys[k]
+    end
+    out[1, :] = fm[1, :]
+    out
+end
+
+# fvpostf(vs::VarianceScaling, src) -- src/gv.jl:6-21
 struct VarianceScaling
     σ²::Vector{Float64}
 end
@@ -291,12 +462,10 @@ function fvpostf(vs::VarianceScaling, src::Matrix{Float64})
                 src, size(src, 1), size(src, 2), vs.σ², out))
     out
 end
-fvpostf!(vs::VarianceScaling, src::Matrix{Float64}) = (src[:, :] = fvpostf(vs, src); src)
-function diffgmm(μ::Matrix{Float64}, Σ::Array{Float64,3})
-    μd = similar(μ); Σd = similar(Σ)
-    check(ccall((:vcmi_diffgmm, libvcmi), Cint, (Ptr{Float64}, Ptr{Float64}, Cint, Cint, Ptr{Float64}, Ptr{Float64}),
-                μ, Σ, size(μ, 1), size(μ, 2), μd, Σd))
-    μd, Σd
+function fvpostf!(vs::VarianceScaling, src::Matrix{Float64})          # in place: the library allows out == src
+    check(ccall((:vcmi_variance_scaling, libvcmi), Cint, (Ptr{Float64}, Cint, Int64, Ptr{Float64}, Ptr{Float64}),
+                src, size(src, 1), size(src, 2), vs.σ², src))
+    src
 end
 
 # align_mcep(src, tgt, α, fftlen; threshold, remove_silence) -- src/align.jl:38-55 (mc2e included)
@@ -308,7 +477,7 @@ function align_mcep(src::Matrix{Float64}, tgt::Matrix{Float64}, α::AbstractFloa
     so = similar(src); to = similar(src); k = Ref{Int64}(0)
     check(ccall((:vcmi_align_mcep, libvcmi), Cint,
                 (Ptr{Float64}, Int64, Ptr{Float64}, Int64, Cint, Cdouble, Cint, Cdouble, Cint, Ptr{Float64}, Ptr{Float64}, Ref{Int64}),
-                src, S, tgt, size(tgt, 2), D, α, fftlen, threshold, remove_silence, so, to, k))
+                src, S, tgt, size(tgt, 2), D, α, fftlen, threshold, remove_silence ? 1 : 0, so, to, k))
     so[:, 1:k[]], to[:, 1:k[]]
 end
 
@@ -317,7 +486,7 @@ end
 # kept in HBM.  `dX` / `dstats` are device pointers (e.g. from AMDGPU.jl); on several GPUs the caller all-reduces
 # `dstats` between estep! and mstep!.
 mutable struct GMMEM
-    handle::Ptr{Cvoid}
+    h::Ptr{Cvoid}
     Dj::Int
     M::Int
     function GMMEM(w::Vector{Float64}, μ::Matrix{Float64}, Σ::Array{Float64,3}; min_covar::Float64=1.0e-7)
@@ -328,25 +497,25 @@ mutable struct GMMEM
                     (Cint, Cint, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Cdouble, Ref{Ptr{Cvoid}}),
                     Dj, M, w, μ, Σ, min_covar, h))
         em = new(h[], Dj, M)
-        finalizer(e -> ccall((:vcmi_gmm_em_destroy, libvcmi), Cint, (Ptr{Cvoid},), e.handle), em)
+        finalizer(e -> ccall((:vcmi_gmm_em_destroy, libvcmi), Cint, (Ptr{Cvoid},), e.h), em)
         em
     end
 end
 
 estep!(em::GMMEM, dX::Ptr{Float64}, N::Integer, dstats::Ptr{Float64}; stream::Ptr{Cvoid}=C_NULL) =
     check(ccall((:vcmi_gmm_em_estep_dev, libvcmi), Cint, (Ptr{Cvoid}, Ptr{Float64}, Int64, Ptr{Float64}, Ptr{Cvoid}),
-                em.handle, dX, N, dstats, stream))
+                em.h, dX, N, dstats, stream))
 
 function mstep!(em::GMMEM, dstats::Ptr{Float64}; stream::Ptr{Cvoid}=C_NULL)
     ll = Ref{Float64}(0.0)
     check(ccall((:vcmi_gmm_em_mstep, libvcmi), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Cvoid}, Ref{Float64}),
-                em.handle, dstats, stream, ll))
+                em.h, dstats, stream, ll))
     ll[]
 end
 
 function params(em::GMMEM)
     w = Vector{Float64}(undef, em.M); μ = Matrix{Float64}(undef, em.Dj, em.M); Σ = Array{Float64,3}(undef, em.Dj, em.Dj, em.M)
-    check(ccall((:vcmi_gmm_em_get, libvcmi), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}), em.handle, w, μ, Σ))
+    check(ccall((:vcmi_gmm_em_get, libvcmi), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}), em.h, w, μ, Σ))
     w, μ, Σ
 end
 
