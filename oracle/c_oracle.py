@@ -10,7 +10,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "_build", "libvcoracle.so")
+# VCORACLE_LIB: an alternative build of the same sources (the ASan/UBSan library of tests/test_sanitizers.py)
+_SO = os.environ.get("VCORACLE_LIB") or os.path.join(_HERE, "_build", "libvcoracle.so")
 _lib = None
 
 _dp = C.POINTER(C.c_double)
@@ -19,6 +20,8 @@ _ip = C.POINTER(C.c_int64)
 
 def build(force=False):
     src = [os.path.join(_HERE, f) for f in ("vc_oracle.c", "vc_oracle.h", "Makefile")]
+    if os.environ.get("VCORACLE_LIB"):
+        return _SO
     if force or not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in src):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return _SO

@@ -1,0 +1,60 @@
+"""CPU: sanitizer builds.  GPU AddressSanitizer is not available on this pool, so the host side is
+checked here: the C oracle under ASan + UBSan against a golden case, and the host-only translation units of libvcmi
+(error plumbing, worker-thread copies, device groups) under ASan + UBSan and under ThreadSanitizer with a stress driver."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+CSRC = os.path.join(ROOT, "voiceconversion.jl_amd", "csrc")
+OUT = os.path.join(ROOT, "oracle", "_build")
+HOST_SRCS = [os.path.join(CSRC, f) for f in ("core.cpp", "hostpipe.cpp", "devgroup.cpp")]
+COMMON = ["g++", "-std=c++17", "-O1", "-g", "-fno-omit-frame-pointer", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
+          os.path.join(ROOT, "tests", "c", "host_stress.cpp")] + HOST_SRCS
+LINK = ["-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib", "-lamdhip64", "-ldl", "-lpthread"]
+
+
+def _build_and_run(name, flags, env_extra):
+    os.makedirs(OUT, exist_ok=True)
+    exe = os.path.join(OUT, name)
+    subprocess.run(COMMON + flags + ["-o", exe] + LINK, check=True, capture_output=True, text=True)
+    env = dict(os.environ, **env_extra)
+    p = subprocess.run([exe], capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0 and "host_stress: ok" in p.stdout, (p.stdout[-2000:], p.stderr[-4000:])
+    assert "ERROR: AddressSanitizer" not in p.stderr and "WARNING: ThreadSanitizer" not in p.stderr and "runtime error" not in p.stderr, p.stderr[-4000:]
+
+
+def test_host_code_under_asan_ubsan():
+    # leaks: the worker pool and the staging rings are deliberate process-lifetime singletons; the HIP runtime keeps its own
+    _build_and_run("host_stress_asan", ["-fsanitize=address,undefined"], {"ASAN_OPTIONS": "detect_leaks=0", "UBSAN_OPTIONS": "print_stacktrace=1"})
+
+
+def test_host_code_under_tsan():
+    _build_and_run("host_stress_tsan", ["-fsanitize=thread"], {"TSAN_OPTIONS": "halt_on_error=0 report_signal_unsafe=0"})
+
+
+def test_oracle_under_asan_ubsan():
+    subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "asan", "-s"], check=True)
+    lib = os.path.join(OUT, "libvcoracle_asan.so")
+    asan = subprocess.run(["gcc", "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip()
+    code = (
+        "import sys, numpy as np; sys.path.insert(0, %r)\n"
+        "import os; os.environ['VCORACLE_LIB'] = %r\n"
+        "from oracle import c_oracle as co\n"
+        "z = np.load(%r)\n"
+        "g = co.GMMMap(z['weights'], z['means'], z['covars'])\n"
+        "Y = g.fvconvert(z['X'])\n"
+        "assert np.max(np.abs(Y - z['Y'])) < 1e-9 * np.max(np.abs(z['Y']))\n"
+        "d = np.load(%r)\n"
+        "p = co.dtw_fit(d['r0_tmpl'], d['r0_seq'], int(d['r0_steps'][0]), int(d['r0_steps'][1]), tables=False)\n"
+        "assert np.array_equal(p, d['r0_path'])\n"
+        "print('oracle asan ok')\n"
+    ) % (ROOT, lib, os.path.join(ROOT, "tests", "golden", "gmmmap_cfg1_D24_M8_T1000.npz"),
+         os.path.join(ROOT, "tests", "golden", "dtw_cases.npz"))
+    env = dict(os.environ, LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0", UBSAN_OPTIONS="print_stacktrace=1")
+    p = subprocess.run(["python3", "-c", code], capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0 and "oracle asan ok" in p.stdout, (p.stdout[-2000:], p.stderr[-4000:])
+    assert "ERROR: AddressSanitizer" not in p.stderr and "runtime error" not in p.stderr, p.stderr[-4000:]

@@ -7,6 +7,7 @@
 #include <condition_variable>
 #include <cstdlib>
 #include <deque>
+#include <memory>
 #include <mutex>
 #include <thread>
 
@@ -20,22 +21,26 @@ namespace vcmi {
 // ------------------------------------------------------------------------------------------------
 namespace {
 
+// Completion counter of one host_parallel_for call.  Shared ownership (caller + every task): it cannot disappear under
+// a worker that is still inside done(), whatever the caller does; the count is only touched under the mutex.
 struct Latch {
-  std::atomic<int> remaining{0};
+  int remaining = 0;
   std::mutex m;
   std::condition_variable c;
   void done() {
-    if (remaining.fetch_sub(1) == 1) {
-      std::lock_guard<std::mutex> lk(m);
-      c.notify_all();
-    }
+    std::lock_guard<std::mutex> lk(m);
+    if (--remaining == 0) c.notify_all();
+  }
+  bool finished() {
+    std::lock_guard<std::mutex> lk(m);
+    return remaining == 0;
   }
 };
 
 struct Task {
   const std::function<void(int64_t, int64_t)> *fn;
   int64_t lo, hi;
-  Latch *latch;
+  std::shared_ptr<Latch> latch;
 };
 
 class Pool {
@@ -104,21 +109,23 @@ void host_parallel_for(int64_t n, int64_t grain, const std::function<void(int64_
     return;
   }
   std::vector<Task> tasks;
-  Latch latch;
+  std::shared_ptr<Latch> lp = std::make_shared<Latch>();
+  Latch &latch = *lp;
   const int64_t per = (n + parts - 1) / parts;
   for (int64_t p = 1; p < parts; ++p) {
     const int64_t lo = p * per, hi = std::min(n, lo + per);
-    if (lo < hi) tasks.push_back(Task{&fn, lo, hi, &latch});
+    if (lo < hi) tasks.push_back(Task{&fn, lo, hi, lp});
   }
   latch.remaining = (int)tasks.size();
   if (!tasks.empty()) pool.push(tasks.data(), (int)tasks.size());
   fn(0, std::min(n, per));
   // help until our own parts are done (also covers a process that forked away from its worker threads)
-  while (latch.remaining.load() > 0) {
-    if (pool.try_run_one()) continue;
-    std::unique_lock<std::mutex> lk(latch.m);
-    latch.c.wait_for(lk, std::chrono::microseconds(200), [&] { return latch.remaining.load() == 0; });
+  // Help with whatever is queued (ours or another caller's); once the queue is empty every unfinished part of ours is
+  // in the hands of a worker, so an untimed wait is safe.  (Tasks are leaf copies: they never wait for anything.)
+  while (pool.try_run_one()) {
   }
+  std::unique_lock<std::mutex> lk(latch.m);
+  latch.c.wait(lk, [&] { return latch.remaining == 0; });
 }
 
 void host_copy(void *dst, const void *src, size_t bytes) {
@@ -425,3 +432,14 @@ int staged_pipeline(const void *hIn, size_t in_unit, size_t in_stride, void *hOu
 }
 
 }  // namespace vcmi
+
+// test hooks (not part of include/vcmi.h): the worker-thread copies without a device, for the CPU stress / sanitizer tests
+extern "C" int vcmi_debug_host_copy(void *dst, const void *src, size_t bytes) {
+  vcmi::host_copy(dst, src, bytes);
+  return VCMI_OK;
+}
+extern "C" int vcmi_debug_host_copy_rows(void *dst, size_t dst_stride, const void *src, size_t src_stride, size_t row_bytes,
+                                         int64_t rows) {
+  vcmi::host_copy_rows(dst, dst_stride, src, src_stride, row_bytes, rows);
+  return VCMI_OK;
+}
