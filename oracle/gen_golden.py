@@ -5,7 +5,9 @@ fixture and /opt/conda/bin/h5dump).  TEST INFRASTRUCTURE ONLY.
 
 Expected outputs come from the numpy/scipy restatement (oracle/np_oracle.py); before anything is
 written, each is checked against the C oracle (oracle/vc_oracle.c) -- the two independent
-restatements must agree (bit-exact for DTW, <=1e-9 relative for floating-point paths).  The only data
+restatements must agree (bit-exact for DTW, <=1e-9 relative for floating-point paths) -- AND against
+third-party code (oracle/crosscheck.py: sklearn GaussianMixture, scipy multivariate_normal /
+logsumexp / solveh_banded, numpy.linalg.solve, 50-digit mpmath).  The only data
 taken from the reference tree are the trained-model tensors of
 test/models/clb_to_slt_gmm32_order40_diff.jld (the model test/gmmmap.jl:3-8 loads) and the DTW
 known-answer vectors of test/dtw.jl:7-31.
@@ -17,6 +19,7 @@ import tempfile
 import numpy as np
 
 from . import c_oracle as co
+from . import crosscheck as cc
 from . import np_oracle as npo
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -62,6 +65,10 @@ def main():
         assert _relmax(Y, gc.fvconvert(X)) < 1e-9 and np.max(np.abs(P - gc.predict_proba(X))) < 1e-9
         assert np.array_equal(idx, gc.predict(X))
         assert _relmax(gn.A, gc.A) < 1e-9
+        # third-party pins (sklearn, scipy, LAPACK gesv; 50-digit mpmath for the forward direction)
+        print("cross-check", "swap" if swap else "fwd", cc.check_conversion(w, mu, sig, X, Y, P, idx, swap=swap))
+        if not swap:
+            print("cross-check mpmath", cc.check_conversion_mpmath(w, mu, sig, X, Y, P))
         k = "swap" if swap else "fwd"
         out.update({f"X_{k}": X, f"Y_{k}": Y, f"P_{k}": P, f"idx_{k}": idx})
     # vc(): power row passthrough
@@ -76,6 +83,7 @@ def main():
     g1n, g1c = npo.GMMMap(w1, mu1, sig1), co.GMMMap(w1, mu1, sig1)
     Y1 = g1n.fvconvert(X1)
     assert _relmax(Y1, g1c.fvconvert(X1)) < 1e-9
+    cc.check_conversion(w1, mu1, sig1, X1, Y1, g1n.predict_proba(X1), g1n.predict(X1))
     np.savez(os.path.join(OUT, "gmmmap_cfg1_D24_M8_T1000.npz"), weights=w1, means=mu1, covars=sig1, X=X1, Y=Y1,
              idx=g1n.predict(X1))
 
@@ -134,6 +142,7 @@ def main():
     Y, mh, Ey = tn.fvconvert(Xd)
     Yc, mhc, Eyc = tc.fvconvert(Xd)
     assert np.array_equal(mh, mhc) and _relmax(Y, Yc) < 1e-6 and _relmax(Ey, Eyc) < 1e-9, (_relmax(Y, Yc))
+    print("cross-check trajectory", cc.check_trajectory(w, mu, sig, Xd, Y, mh, Ey))   # LAPACK pbsv on the band
     fmt = np.concatenate([np.linspace(0, 1, 100)[:, None], Xd], axis=1)
     vco = npo.vc_traj(tn, fmt, 30)
     assert _relmax(vco, tc.vc(fmt, 30)) < 1e-6
@@ -149,6 +158,7 @@ def main():
     S0, S1, S2, ll = npo.estep_diag(Xe, wd, mud, var)
     c0, c1, c2, cl = co.estep_diag(Xe, wd, mud, var)
     assert _relmax(S0, c0) < 1e-10 and _relmax(S1, c1) < 1e-10 and _relmax(S2, c2) < 1e-10 and abs(ll - cl) < 1e-8 * abs(ll)
+    cc.check_estep_diag(Xe, wd, mud, var, S0, S1, S2, ll)                              # sklearn responsibilities
     np.savez(os.path.join(OUT, "estep_diag_N2000_D80_M16.npz"), X=Xe, w=wd, mu=mud, var=var, S0=S0, S1=S1, S2=S2,
              loglik=np.array(ll))
     # ---- (6) full-covariance E-step (what bin/train_gmm.jl:84-103 runs), N=1000, Dj=80, M=8; the log-density
@@ -158,14 +168,7 @@ def main():
     S0, S1, S2, ll = npo.estep_full(Xf, wf, muf, sigf)
     c0, c1, c2, cl = co.estep_full(Xf, wf, muf, sigf)
     assert _relmax(S0, c0) < 1e-10 and _relmax(S1, c1) < 1e-10 and _relmax(S2, c2) < 1e-10 and abs(ll - cl) < 1e-8 * abs(ll)
-    try:
-        from scipy.special import logsumexp
-        from sklearn.mixture._gaussian_mixture import _compute_precision_cholesky, _estimate_log_gaussian_prob
-        lp = _estimate_log_gaussian_prob(Xf, muf, _compute_precision_cholesky(sigf, "full"), "full") + np.log(wf)
-        assert abs(logsumexp(lp, axis=1).sum() - ll) < 1e-9 * abs(ll)
-        print("full-covariance log-likelihood agrees with scikit-learn's _estimate_log_gaussian_prob")
-    except ImportError:
-        pass
+    cc.check_estep_full(Xf, wf, muf, sigf, S0, S1, S2, ll)                             # sklearn, full covariance
     np.savez(os.path.join(OUT, "estep_full_N1000_D80_M8.npz"), X=Xf, w=wf, mu=muf, sigma=sigf, S0=S0, S1=S1, S2=S2,
              loglik=np.array(ll))
     # ---- (7) TrajectoryGVGMMMap on the same fixture utterance (src/trajectory_gmmmap.jl:114-189), VarianceScaling,

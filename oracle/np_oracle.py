@@ -8,8 +8,13 @@ oracle/gen_golden.py to produce tests/golden/*.npz and by the CPU tests.  The pr
 Arrays follow numpy convention [frame, feature] = the Julia (feature, frame) column-major memory image,
 so `X.ravel()` is byte-for-byte what Julia would hand to ccall.  Indices returned are 1-based (Julia).
 
-Pinning: DTW by test/dtw.jl:7-31, constructW by test/trajectory_gmmmap.jl:1-34 of the reference;
-fvconvert / trajectory / E-step numerics are PARITY UNPINNED by the reference's tests (isfinite only).
+Pinning: DTW by test/dtw.jl:7-31, constructW by test/trajectory_gmmmap.jl:1-34 of the reference.
+fvconvert / predict_proba / trajectory / E-step numerics are PARITY UNPINNED BY THE REFERENCE (its tests
+assert isfinite only, and no Julia exists here to run it); they are pinned instead against third-party
+implementations of the same published formulas -- sklearn GaussianMixture, scipy multivariate_normal /
+logsumexp / solveh_banded, LAPACK gesv, 50-digit mpmath -- in oracle/crosscheck.py, re-run on the
+committed fixtures by tests/test_oracle_thirdparty.py.  GV ascent and mc2e have no third-party
+counterpart in this image: unpinned.
 """
 import numpy as np
 import scipy.linalg as sla

@@ -8,6 +8,12 @@
  * Third-party arithmetic the reference calls (Distributions.jl MvNormal logpdf via PDMats Cholesky,
  * StatsFuns.logsumexp, Base LinAlg inv, SuiteSparse `\`, sklearn.mixture) is restated from its
  * published mathematical definition; those package sources are not available offline.
+ *
+ * Pinning: DTW paths by test/dtw.jl:7-31 and W by test/trajectory_gmmmap.jl:1-34 (exact).  Everything
+ * floating-point (fvconvert, predict_proba, trajectory solve, E-steps) is PARITY UNPINNED BY THE REFERENCE
+ * -- its tests assert isfinite only and no Julia exists here -- and is pinned instead against third-party
+ * code (sklearn, scipy, LAPACK, 50-digit mpmath) through the golden vectors: oracle/crosscheck.py,
+ * tests/test_oracle_thirdparty.py.  GV ascent and mc2e: unpinned.
  */
 #include "vc_oracle.h"
 #include <math.h>
