@@ -497,14 +497,15 @@ def bench_dtw(args, world, rank):
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
            "config": {"workload": "DTW fit!+backward, path-only (BASELINE configs[3])", "D": D, "pairs_per_gpu": n,
                       "fstep": 0, "bstep": 2},
-           "roofline": {"bound": "mfma", "kernel": "dtw_obs_asm_kernel<40> (+ dtw_rec_kernel<2,0> overlapped)",
+           "roofline": {"bound": "valu", "kernel": "dtw_fused_kernel<40,2> (+ dtw_fused_finish_kernel)",
                         "achieved": achieved, "peak": FP64_PEAK_TFLOPS / 2, "unit": "TFLOP/s",
                         "frac": achieved / (FP64_PEAK_TFLOPS / 2),
-                        "traffic": ((pmc_traffic("dtw_traffic.json", "dtw_obs_asm_kernel") or 0) +
-                                    (pmc_traffic("dtw_traffic.json", "dtw_rec_kernel") or 0)) or None if n == 1000 else None,
-                        "note": "the bit-exact contract forbids fused multiply-add, so the roof is the FP64 vector pipe at ONE "
-                                "flop per lane-instruction = half the FMA/MFMA figure; `achieved` prices the whole step "
-                                "(observation + recurrence kernels) at 3*D+10 flop per cell",
+                        "traffic": pmc_traffic("dtw_traffic.json", "dtw_fused", "r02_pmc") if n == 1000 else None,
+                        "algorithmic_bytes": float(np.sum((S + T) * D * 8 + T * 8)),
+                        "note": "bound: the FP64 VECTOR pipe, not MFMA and not HBM -- the bit-exact contract (src/dtw.jl:33-35: "
+                                "sequential in d, separately rounded multiply and add) forbids fused multiply-add and any "
+                                "GEMM form, so the roof is one flop per lane-instruction = half the FMA/MFMA figure; "
+                                "`achieved` prices the whole step (forward + backward kernels) at 3*D+10 flop per cell",
                         "cells_per_s": cells / (kernel_ms * 1e-3), "kernel_ms": kernel_ms}}
     if rank == 0:
         from oracle import c_oracle as co

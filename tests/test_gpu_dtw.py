@@ -132,3 +132,52 @@ def test_online_update_matches_fit(vc):
         vc.update_(d2, s[k])
     assert np.array_equal(d1.costtable, d2.costtable) and np.array_equal(d1.backpointer, d2.backpointer)
     assert np.array_equal(vc.backward(d2), vc.backward(d1))
+
+
+@pytest.mark.parametrize("bs", [1, 2])
+def test_fused_kernel_strips_ties_and_two_kernel_path(vc, bs):
+    """The fused forward kernel (observation + recurrence in one hand-scheduled loop, two rows per lane, waves coupled
+    through sequence-tagged LDS rings, long templates split into row strips that hand their top two rows over through
+    HBM) against the oracle AND against the observation + recurrence kernels it replaced (still the path of tables,
+    D > 40 and wide windows).  Shapes: strip boundaries (512 / 513 / 549 / 1025 / 1537 rows), odd and even S, every
+    wave count, T not a multiple of 16, padded D, coarse features (exact cost ties exercise the strict '<' rule)."""
+    from oracle import c_oracle as co
+    from voiceconversion_jl_amd import _lib
+    rng = np.random.default_rng(1234 + bs)
+    shapes = [(512, 160, 40), (513, 97, 40), (549, 130, 40), (550, 33, 24), (1025, 70, 40), (1537, 40, 8), (127, 500, 40),
+              (128, 17, 40), (129, 16, 40), (255, 15, 13), (2, 300, 40), (3, 1, 40), (383, 64, 32), (64, 65, 1)]
+    pairs = []
+    for k, (S, T, D) in enumerate(shapes):
+        t, s = _warped_pair(rng, S, T, D)
+        if k % 2:
+            t, s = np.round(t * 2) / 2, np.round(s * 2) / 2
+        pairs.append((t, s))
+    d = vc.DTW(fstep=0, bstep=bs)
+    for Dsel in sorted({D for _, _, D in shapes}):
+        sub = [(t, s) for (t, s), (_, _, D) in zip(pairs, shapes) if D == Dsel]
+        fused = vc.fit_batch(d, [t.T for t, _ in sub], [s.T for _, s in sub])
+        _lib.debug_force(_lib.DBG_DTW_TWO_KERNELS)
+        try:
+            two = vc.fit_batch(d, [t.T for t, _ in sub], [s.T for _, s in sub])
+        finally:
+            _lib.debug_force(0)
+        for (t, s), a, b in zip(sub, fused, two):
+            ref = co.dtw_fit(t, s, 0, bs, tables=False)
+            assert np.array_equal(a, ref), (t.shape, s.shape)
+            assert np.array_equal(b, ref), (t.shape, s.shape)
+
+
+def test_fused_kernel_more_workgroups_than_slots(vc):
+    """700 small pairs + 40 two-strip pairs in one launch: several rounds of workgroups per CU, upper strips waiting on
+    flags set by workgroups earlier in the grid; align output included."""
+    from oracle import c_oracle as co
+    rng = np.random.default_rng(77)
+    pairs = [_warped_pair(rng, int(rng.integers(20, 140)), int(rng.integers(20, 90)), 16) for _ in range(700)]
+    pairs += [_warped_pair(rng, int(rng.integers(513, 700)), int(rng.integers(20, 60)), 16) for _ in range(40)]
+    outs = vc.align_batch([t.T for t, _ in pairs], [s.T for _, s in pairs])
+    d = vc.DTW(fstep=0, bstep=2)
+    paths = vc.fit_batch(d, [t.T for t, _ in pairs], [s.T for _, s in pairs])
+    for i in list(range(0, 740, 23)) + list(range(700, 740)):
+        t, s = pairs[i]
+        assert np.array_equal(paths[i], co.dtw_fit(t, s, 0, 2, tables=False)), i
+        assert np.array_equal(outs[i][1], co.align(t, s)[0].T), i

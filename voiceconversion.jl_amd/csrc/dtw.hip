@@ -36,7 +36,19 @@ struct DtwPair {
   int64_t obs_off;      // (S,T) observation costs at obs_ws + obs_off (fast path workspace)
   int64_t spad_off;     // offset of the zero-padded sequence copy (fast path, D != DMAX)
   int64_t tpad_off;     // offset of the zero-padded template copy (same workspace)
+  int64_t fcodes_off;   // fused path: this pair's packed step codes, [ceil(T/16)][Se] dwords at fcodes_ws + fcodes_off
+  int64_t clast_off;    // fused path: last cost column (S doubles) at clast_ws + clast_off
   int32_t S, T;
+};
+
+// One workgroup of the fused kernel: rows [row0, row0 + nrows) of a pair ("row strip").  Row r of column t+1 depends
+// only on rows r, r-1, r-2 of column t (src/dtw.jl:107-121 with fstep = 0), so a strip needs nothing from the rows above
+// it: a template longer than one workgroup's 512 rows is processed bottom strip first, each strip leaving the costs of
+// its top two rows (per column) for the next one.
+struct DtwStrip {
+  int32_t pair, row0, nrows;
+  int32_t flag_in, flag_out;     // indices into the flag array (-1: none): wait for / signal the neighbouring strip
+  int64_t bnd_in, bnd_out;       // offsets (doubles) into bnd_ws of the (T,2) boundary arrays, -1: none
 };
 
 __device__ __forceinline__ double dtw_transition(int j, int i) {   // transition(d, j, i), src/dtw.jl:23-31
@@ -44,7 +56,9 @@ __device__ __forceinline__ double dtw_transition(int j, int i) {   // transition
 }
 
 // shared epilogue: argmin of the last column, backward pass, path output, align post-processing.
-template <bool LDSCODES, int BITS>
+// PACKED: the codes are BITS-bit fields of 32-bit words [t / CPW][row] wherever they live (LDS, or global memory when
+// LDSCODES is false); otherwise global codes are one byte per cell at P.codes.
+template <bool LDSCODES, int BITS, bool PACKED = false>
 __device__ void dtw_finish(const DtwPair &P, const double *__restrict__ seq, int D, int fstep, const double *clast, int32_t *path32, int32_t *owner,
                            int32_t *holes, const uint32_t *codes_lds, int Smax) {
   constexpr int CPW = 32 / BITS;
@@ -76,7 +90,7 @@ __device__ void dtw_finish(const DtwPair &P, const double *__restrict__ seq, int
       path32[T - 1] = row;
       for (int t = T - 1; t >= 1; --t) {              // src/dtw.jl:140-142; `row` stays in a register
         int code;
-        if (LDSCODES) code = (codes_lds[(t / CPW) * Smax + row] >> (BITS * (t % CPW))) & ((1u << BITS) - 1u);
+        if (LDSCODES || PACKED) code = (codes_lds[(size_t)(t / CPW) * Smax + row] >> (BITS * (t % CPW))) & ((1u << BITS) - 1u);
         else code = P.codes[(size_t)S * t + row];
         row -= code - fstep;
         path32[t - 1] = row;
@@ -344,6 +358,182 @@ dtw_rec_kernel(const double *__restrict__ feats, const DtwPair *__restrict__ pai
 }
 
 // ------------------------------------------------------------------------------------------------
+// Fused path (fstep = 0, bstep in {1,2}, D <= 40, path-only): ONE forward kernel computes observation costs and the
+// recurrence together -- O never exists in memory -- and streams the 2-bit step codes to HBM (62.5 KB per 500x500 pair,
+// against 2 MB for O); a short second kernel per pair loads the pair's codes into LDS and runs backward + align.
+//
+// dtw_fused_kernel<DMAX,STEPS>: workgroup = one row strip (<= 512 rows) of a pair = up to 4 waves; a wave owns 128
+// consecutive rows, lane l the rows 2l and 2l+1 (their features stay in 160 VGPRs); the sequence column is the wave-
+// uniform SGPR operand.  The column loop is hand-scheduled (tools/gen_dtw_fused_asm.py -> dtw_fused_asm.inc, where the
+// schedule, the register map and the arithmetic order are documented).  No workgroup barrier inside the loop: the only
+// coupling between waves is "lane 0 needs the previous wave's top two rows of the previous column", handed over through
+// a sequence-tagged ring in LDS.  LDS use is ~9 KB + 16 B per column, so occupancy is set by the registers (2 waves per
+// SIMD = two workgroups per CU).
+// ------------------------------------------------------------------------------------------------
+#include "dtw_fused_asm.inc"
+static constexpr int kFusedRows = 512;        // rows per strip (4 waves x 64 lanes x 2 rows)
+static constexpr int kFusedThreads = 256;
+
+// wave-uniform value held in VGPRs -> SGPRs (inline-asm "s" operands)
+__device__ __forceinline__ uint64_t uniform64(uint64_t v) {
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+  return ((uint64_t)hi << 32) | lo;
+}
+
+__device__ __forceinline__ uint32_t lds_addr(const void *p) {
+  return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char *)p;
+}
+
+template <int DMAX, int STEPS>
+__global__ void __launch_bounds__(kFusedThreads)
+dtw_fused_kernel(const double *__restrict__ base, int padded, const DtwPair *__restrict__ pairs,
+                 const DtwStrip *__restrict__ strips, uint32_t *__restrict__ fcodes_ws, double *__restrict__ bnd_ws,
+                 double *__restrict__ clast_ws, int *__restrict__ flags, int epoch, int npacked) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char fsm[];
+  unsigned char *outbox = fsm;                                                        // [4][VCMI_FUSED_OUTBOX]
+  double *clast = reinterpret_cast<double *>(fsm + 4 * VCMI_FUSED_OUTBOX);            // [kFusedRows]
+  double *bnd = clast + kFusedRows;                                                   // [1 + T][2]
+  // The first `npacked` workgroups are PACKED: each of their waves runs its own one-wave strip (the short bottom strips
+  // of long templates, <= 128 rows), four unrelated strips per workgroup, so that no wave slot idles beside them.
+  const int tid = threadIdx.x, lane = tid & 63;
+  const bool packed = (int)blockIdx.x < npacked;
+  const int slotw = tid >> 6;                                  // wave slot in the workgroup (outbox, clast area)
+  const DtwStrip st = packed ? strips[4 * blockIdx.x + slotw] : strips[3 * npacked + blockIdx.x];
+  const DtwPair P = pairs[st.pair];
+  const int S = P.S, T = P.T;
+  if (!packed && T == 0) return;
+  const int wave = packed ? 0 : slotw;                         // wave index within the strip
+  const int nw = (st.nrows + 127) >> 7;
+  const int lr0 = 128 * wave + 2 * lane;            // first row of the lane, local to the strip
+  const int gr0 = st.row0 + lr0;                    // ... and in the pair
+  // lazy_init!: costtable[:,1] = 1:S (src/dtw.jl:49); the neighbours of column 1 are rows gr0-2, gr0-1
+  double c0 = (double)(gr0 + 1), c1 = (double)(gr0 + 2);
+  double p0 = gr0 >= 2 ? (double)(gr0 - 1) : INFINITY, p1 = gr0 >= 1 ? (double)gr0 : INFINITY;
+  if (tid < 4) *reinterpret_cast<uint32_t *>(outbox + tid * VCMI_FUSED_OUTBOX + VCMI_FUSED_RING * 16) = 0u;   // tags
+  if (lane == 63) {   // what the next wave's lane 0 reads for column 0: the ring's last slot holds the initial costs
+    double *slot = reinterpret_cast<double *>(outbox + slotw * VCMI_FUSED_OUTBOX + (VCMI_FUSED_RING - 1) * 16);
+    slot[0] = c0;
+    slot[1] = c1;
+  }
+  if (!packed && st.flag_in >= 0) {
+    // the strip below must be complete (it precedes this workgroup in the grid, so it is resident or finished)
+    if (tid == 0)
+      while (__hip_atomic_load(&flags[st.flag_in], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != epoch) __builtin_amdgcn_s_sleep(32);
+    __syncthreads();
+    // entry 0: initial costs of the two rows below the strip; entry 1+t: their costs after column t
+    const double *src = bnd_ws + st.bnd_in;
+    if (tid == 0) {
+      bnd[0] = (double)(st.row0 - 1);
+      bnd[1] = (double)st.row0;
+    }
+    for (int i = tid; i < 2 * T; i += (int)blockDim.x) bnd[2 + i] = __builtin_nontemporal_load(src + i);
+  }
+  __syncthreads();
+  if (wave < nw && T > 0) {
+    const double *tmpl = base + (padded ? P.tpad_off : P.tmpl_off);
+    const double *rowA = tmpl + (int64_t)DMAX * (gr0 < S ? gr0 : S - 1);
+    const double *rowB = tmpl + (int64_t)DMAX * (gr0 + 1 < S ? gr0 + 1 : S - 1);
+    const double *seq = base + (padded ? P.spad_off : P.seq_off);
+    const int Se = (S + 1) & ~1;
+    uint32_t *codes = fcodes_ws + P.fcodes_off + gr0;
+    const uint64_t cstride = (uint64_t)Se * 4;
+    int cnt = (st.nrows - 128 * wave + 1) >> 1;
+    cnt = cnt > 64 ? 64 : cnt;
+    uint32_t out = lds_addr(outbox + slotw * VCMI_FUSED_OUTBOX), bndl = lds_addr(bnd);
+    uint32_t mode = (wave > 0 ? 1u : 0u) | ((wave == 0 && !packed && st.flag_in >= 0) ? 2u : 0u) | (wave + 1 < nw ? 4u : 0u);
+    int explane = -1;
+    double *gout = bnd_ws;
+    if (st.bnd_out >= 0 && wave == nw - 1) {          // non-final strips have an even number of rows
+      explane = (st.nrows >> 1) - 1 - 64 * wave;
+      gout = bnd_ws + st.bnd_out;
+    }
+    uint32_t clast_a = lds_addr(clast + 128 * slotw + 2 * lane);
+    uint32_t ncols = (uint32_t)T, off = 0, tcol = 0;
+    // every operand the loop reads is wave-uniform or per-lane as declared; force the uniform ones into SGPRs
+    cnt = __builtin_amdgcn_readfirstlane(cnt);
+    out = __builtin_amdgcn_readfirstlane(out);
+    bndl = __builtin_amdgcn_readfirstlane(bndl);
+    mode = __builtin_amdgcn_readfirstlane(mode);
+    explane = __builtin_amdgcn_readfirstlane(explane);
+    ncols = __builtin_amdgcn_readfirstlane(ncols);
+    seq = reinterpret_cast<const double *>(uniform64(reinterpret_cast<uint64_t>(seq)));
+    const uint64_t cstride_u = uniform64(cstride);
+#define VCMI_FUSED_ASM(BODY)                                                                                          \
+  asm volatile(BODY                                                                                                   \
+               : [seq] "+s"(seq), [off] "+s"(off), [n] "+s"(ncols), [t] "+s"(tcol), [codes] "+v"(codes), [gout] "+v"(gout) \
+               : [cstride] "s"(cstride_u), [cnt] "s"(cnt), [out] "s"(out), [bnd] "s"(bndl), [mode] "s"(mode),          \
+                 [explane] "s"(explane), [rowA] "v"(rowA), [rowB] "v"(rowB), [c0] "v"(c0), [c1] "v"(c1), [p0] "v"(p0), \
+                 [p1] "v"(p1), [clast] "v"(clast_a)                                                                   \
+               : "memory", "vcc", "scc", VCMI_FUSED_ASM_CLOBBERS)
+    if constexpr (STEPS == 1) {
+      if constexpr (DMAX == 8) VCMI_FUSED_ASM(VCMI_DTW_FUSED_ASM_D8_S1);
+      if constexpr (DMAX == 16) VCMI_FUSED_ASM(VCMI_DTW_FUSED_ASM_D16_S1);
+      if constexpr (DMAX == 24) VCMI_FUSED_ASM(VCMI_DTW_FUSED_ASM_D24_S1);
+      if constexpr (DMAX == 32) VCMI_FUSED_ASM(VCMI_DTW_FUSED_ASM_D32_S1);
+      if constexpr (DMAX == 40) VCMI_FUSED_ASM(VCMI_DTW_FUSED_ASM_D40_S1);
+    } else {
+      if constexpr (DMAX == 8) VCMI_FUSED_ASM(VCMI_DTW_FUSED_ASM_D8_S2);
+      if constexpr (DMAX == 16) VCMI_FUSED_ASM(VCMI_DTW_FUSED_ASM_D16_S2);
+      if constexpr (DMAX == 24) VCMI_FUSED_ASM(VCMI_DTW_FUSED_ASM_D24_S2);
+      if constexpr (DMAX == 32) VCMI_FUSED_ASM(VCMI_DTW_FUSED_ASM_D32_S2);
+#if !defined(VCMI_FUSED_VARIANT)
+      if constexpr (DMAX == 40) VCMI_FUSED_ASM(VCMI_DTW_FUSED_ASM_D40_S2);
+#elif VCMI_FUSED_VARIANT == 1   // timing experiments only (wrong results): see tools/gen_dtw_fused_asm.py
+      if constexpr (DMAX == 40) VCMI_FUSED_ASM(VCMI_DTW_FUSED_ASM_D40_S2_V1);
+#elif VCMI_FUSED_VARIANT == 2
+      if constexpr (DMAX == 40) VCMI_FUSED_ASM(VCMI_DTW_FUSED_ASM_D40_S2_V2);
+#else
+      if constexpr (DMAX == 40) VCMI_FUSED_ASM(VCMI_DTW_FUSED_ASM_D40_S2_V3);
+#endif
+    }
+#undef VCMI_FUSED_ASM
+  }
+  __syncthreads();
+  if (packed) {      // every wave finishes its own strip
+    if (T > 0) {
+      for (int i = lane; i < st.nrows; i += 64) clast_ws[P.clast_off + st.row0 + i] = clast[128 * slotw + i];
+      if (st.flag_out >= 0) {
+        __threadfence();
+        if (lane == 0) __hip_atomic_store(&flags[st.flag_out], epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    return;
+  }
+  for (int i = tid; i < st.nrows; i += (int)blockDim.x) clast_ws[P.clast_off + st.row0 + i] = clast[i];
+  if (st.flag_out >= 0) {
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(&flags[st.flag_out], epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+// Backward pass + align epilogue of the fused path: one workgroup per pair.  The pair's packed step codes come back
+// from HBM / the Infinity Cache into LDS with coalesced loads (the backward pass is a chain of T dependent reads: it
+// has to run out of LDS), then dtw_finish does what it does for the other kernels.
+template <bool LDSCODES>
+__global__ void __launch_bounds__(256)
+dtw_fused_finish_kernel(const double *__restrict__ feats, const DtwPair *__restrict__ pairs, int D, int Smax, int Tmax,
+                        const uint32_t *__restrict__ fcodes_ws, const double *__restrict__ clast_ws) {
+  const DtwPair P = pairs[blockIdx.x];
+  const int S = P.S, T = P.T, tid = threadIdx.x;
+  if (T == 0) return;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int Se = (S + 1) & ~1, SmaxE = (Smax + 1) & ~1;
+  double *clast = reinterpret_cast<double *>(smem_raw);               // [SmaxE]
+  int32_t *path32 = reinterpret_cast<int32_t *>(clast + SmaxE);       // [Tmax]
+  int32_t *owner = path32 + Tmax;                                     // [SmaxE]
+  int32_t *holes = owner + SmaxE;                                     // [SmaxE]
+  uint32_t *codes = reinterpret_cast<uint32_t *>(holes + SmaxE);      // [ceil(T/16)][Se] when LDSCODES
+  for (int i = tid; i < S; i += 256) clast[i] = clast_ws[P.clast_off + i];
+  const uint32_t *gc = fcodes_ws + P.fcodes_off;
+  const int nwords = ((T + 15) >> 4) * Se;
+  if (LDSCODES)
+    for (int i = tid; i < nwords; i += 256) codes[i] = gc[i];
+  __syncthreads();
+  dtw_finish<LDSCODES, 2, true>(P, feats + P.seq_off, D, 0, clast, path32, owner, holes, LDSCODES ? codes : gc, Se);
+}
+
+// ------------------------------------------------------------------------------------------------
 // Generic kernel: any D, S up to the LDS capacity of two cost columns; rows strided over threads,
 // template read from HBM/L2, step codes as bytes in HBM.
 // ------------------------------------------------------------------------------------------------
@@ -497,11 +687,17 @@ struct DtwScratch {
   // Stream ordering of the shared workspaces (descriptors, observation costs, step codes): a call on ANY stream first
   // waits for the previous call's last kernel (`last_use`), and the descriptors travel to the device by an asynchronous
   // copy on the caller's stream from a small ring of pinned slots (a slot is reused only after its copy completed).
-  static constexpr int kSlots = 4;
+  static constexpr int kSlots = 6;
   hipEvent_t last_use = nullptr, slot_done[kSlots] = {};
-  DtwPair *slot[kSlots] = {};
+  unsigned char *slot[kSlots] = {};
   size_t slot_cap[kSlots] = {};
   int next_slot = 0, device = -1;
+  // fused path: strip descriptors, packed step codes, strip boundaries, last cost columns, strip-completion flags
+  DevBuf<DtwStrip> dstrips;
+  DevBuf<uint32_t> fcodes;
+  DevBuf<double> bnd, clast;
+  DevBuf<int> flags;
+  int epoch = 0;
   int init() {
     int dev = 0;
     VCMI_HIP(hipGetDevice(&dev));
@@ -513,21 +709,33 @@ struct DtwScratch {
     return VCMI_OK;
   }
   // pinned copy of `n` descriptors, valid until the returned slot's event (recorded by the caller) completes
-  int stage(const DtwPair *src, size_t n, DtwPair **out, hipEvent_t *ev) {
+  template <typename Desc>
+  int stage(const Desc *src, size_t n, Desc **out, hipEvent_t *ev) {
     const int s = next_slot;
     next_slot = (next_slot + 1) % kSlots;
+    const size_t bytes = n * sizeof(Desc);
     VCMI_HIP(hipEventSynchronize(slot_done[s]));
-    if (n > slot_cap[s]) {
+    if (bytes > slot_cap[s]) {
       if (slot[s]) (void)hipHostFree(slot[s]);
       slot[s] = nullptr;
       slot_cap[s] = 0;
-      const size_t cap = std::max<size_t>(n, 1024);
-      VCMI_HIP(hipHostMalloc(reinterpret_cast<void **>(&slot[s]), cap * sizeof(DtwPair), hipHostMallocDefault));
+      const size_t cap = std::max<size_t>(bytes, (size_t)128 << 10);
+      VCMI_HIP(hipHostMalloc(reinterpret_cast<void **>(&slot[s]), cap, hipHostMallocDefault));
       slot_cap[s] = cap;
     }
-    memcpy(slot[s], src, n * sizeof(DtwPair));
-    *out = slot[s];
+    memcpy(slot[s], src, bytes);
+    *out = reinterpret_cast<Desc *>(slot[s]);
     *ev = slot_done[s];
+    return VCMI_OK;
+  }
+  // asynchronous upload of descriptors on `st` through a pinned slot
+  template <typename Desc>
+  int upload(Desc *dst, const Desc *src, size_t n, hipStream_t st) {
+    Desc *pinned = nullptr;
+    hipEvent_t copied = nullptr;
+    VCMI_TRY(stage(src, n, &pinned, &copied));
+    VCMI_HIP(hipMemcpyAsync(dst, pinned, sizeof(Desc) * n, hipMemcpyHostToDevice, st));
+    VCMI_HIP(hipEventRecord(copied, st));
     return VCMI_OK;
   }
   void release_sync() {
@@ -546,6 +754,124 @@ struct DtwScratch {
 static DtwScratch &scratch() {
   static thread_local DtwScratch s;
   return s;
+}
+
+// Fused path of dtw_run (see dtw_fused_kernel): strips, workspaces, the forward launch and the backward / align launch.
+static int dtw_run_fused(const double *feats, std::vector<DtwPair> &pairs, int D, int bstep, DtwScratch &sc, hipStream_t st,
+                         int Smax, int Tmax) {
+  const int n = (int)pairs.size();
+  const int dmax = dtw_dmax(D);
+  // single-strip pairs largest first (shortens the tail); the strips of long templates are ordered by level: all
+  // bottom strips lead the grid -- they are what the upper strips wait for -- and the upper strips follow the
+  // single-strip pairs, by which time their predecessors are done.
+  std::stable_sort(pairs.begin(), pairs.end(), [](const DtwPair &a, const DtwPair &b) {
+    return (int64_t)a.S * a.T > (int64_t)b.S * b.T;
+  });
+  size_t ncodes = 0, nclast = 0, nbnd = 0, padn = 0;
+  int nflags = 0;
+  std::vector<std::vector<DtwStrip>> levels;
+  std::vector<DtwStrip> singles;
+  for (int k = 0; k < n; ++k) {
+    DtwPair &p = pairs[k];
+    const int Se = (p.S + 1) & ~1;
+    p.fcodes_off = (int64_t)ncodes;
+    ncodes += (size_t)((p.T + 15) >> 4) * Se;
+    p.clast_off = (int64_t)nclast;
+    nclast += (size_t)p.S;
+    p.spad_off = (int64_t)padn;
+    padn += (size_t)p.T * dmax;
+    p.tpad_off = (int64_t)padn;
+    padn += (size_t)p.S * dmax;
+    if (p.T == 0) continue;
+    const int nstr = (p.S + kFusedRows - 1) / kFusedRows;
+    if (nstr == 1) {
+      singles.push_back(DtwStrip{k, 0, p.S, -1, -1, -1, -1});
+      continue;
+    }
+    int first = p.S - kFusedRows * (nstr - 1);      // remainder strip at the bottom, an even number of rows
+    first += first & 1;
+    int row = 0;
+    for (int s = 0; s < nstr; ++s) {
+      const int rows = (s == 0) ? first : std::min(kFusedRows, p.S - row);
+      DtwStrip ds{k, row, rows, -1, -1, -1, -1};
+      if (s > 0) {
+        ds.flag_in = nflags - 1;
+        ds.bnd_in = (int64_t)(nbnd - (size_t)2 * p.T);
+      }
+      if (s + 1 < nstr) {
+        ds.flag_out = nflags++;
+        ds.bnd_out = (int64_t)nbnd;
+        nbnd += (size_t)2 * p.T;
+      }
+      if ((int)levels.size() <= s) levels.resize(s + 1);
+      levels[s].push_back(ds);
+      row += rows;
+    }
+  }
+  // grid order: packed groups of one-wave bottom strips (four per workgroup, padded with empty strips), the other
+  // bottom strips, the single-strip pairs, then the upper strips level by level
+  std::vector<DtwStrip> strips, wide;
+  if (!levels.empty())
+    for (const DtwStrip &ds : levels[0]) (ds.nrows <= 128 ? strips : wide).push_back(ds);
+  while (strips.size() % 4) strips.push_back(DtwStrip{strips.empty() ? 0 : strips.back().pair, 0, 0, -1, -1, -1, -1});
+  const int npacked = (int)(strips.size() / 4);
+  strips.insert(strips.end(), wide.begin(), wide.end());
+  strips.insert(strips.end(), singles.begin(), singles.end());
+  for (size_t l = 1; l < levels.size(); ++l) strips.insert(strips.end(), levels[l].begin(), levels[l].end());
+  const unsigned ngroups = (unsigned)(strips.size() - 3 * (size_t)npacked);
+  if (strips.empty()) return VCMI_OK;
+  VCMI_TRY(sc.fcodes.reserve(ncodes));
+  VCMI_TRY(sc.clast.reserve(nclast));
+  VCMI_TRY(sc.bnd.reserve(std::max<size_t>(nbnd, 1)));
+  if ((size_t)nflags > sc.flags.n) {
+    VCMI_TRY(sc.flags.reserve(std::max<size_t>((size_t)nflags, 1024)));
+    VCMI_HIP(hipMemsetAsync(sc.flags.p, 0, sc.flags.n * sizeof(int), st));
+    sc.epoch = 0;
+  }
+  const int epoch = ++sc.epoch;
+  VCMI_TRY(sc.dpairs.reserve((size_t)n));
+  VCMI_TRY(sc.dstrips.reserve(strips.size()));
+  VCMI_TRY(sc.upload(sc.dpairs.p, pairs.data(), (size_t)n, st));
+  VCMI_TRY(sc.upload(sc.dstrips.p, strips.data(), strips.size(), st));
+  const bool padded = (D != dmax);
+  if (padded) {
+    VCMI_TRY(sc.spad.reserve(padn));
+    hipLaunchKernelGGL(dtw_pad_kernel, dim3(n, 8), dim3(256), 0, st, feats, sc.dpairs.p, D, dmax, sc.spad.p);
+  }
+  const double *base = padded ? sc.spad.p : feats;
+  const size_t shf = (size_t)4 * VCMI_FUSED_OUTBOX + (size_t)kFusedRows * 8 + ((size_t)Tmax + 1) * 16;
+  if (shf > kLdsLimit) return fail(VCMI_ERR_ARG, "DTW: sequence of %d frames exceeds the supported length", Tmax);
+#define VCMI_FUSED_LAUNCH(DM, STP)                                                                                    \
+  do {                                                                                                                \
+    auto kern = dtw_fused_kernel<DM, STP>;                                                                            \
+    VCMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,    \
+                                 (int)shf));                                                                          \
+    hipLaunchKernelGGL(kern, dim3(ngroups), dim3(kFusedThreads), shf, st, base, (int)padded, sc.dpairs.p,             \
+                       sc.dstrips.p, sc.fcodes.p, sc.bnd.p, sc.clast.p, sc.flags.p, epoch, npacked);                  \
+  } while (0)
+#define VCMI_FUSED_CASE(DM) \
+  case DM: if (bstep == 1) VCMI_FUSED_LAUNCH(DM, 1); else VCMI_FUSED_LAUNCH(DM, 2); break;
+  switch (dmax) { VCMI_FUSED_CASE(8) VCMI_FUSED_CASE(16) VCMI_FUSED_CASE(24) VCMI_FUSED_CASE(32) VCMI_FUSED_CASE(40) }
+#undef VCMI_FUSED_CASE
+#undef VCMI_FUSED_LAUNCH
+  VCMI_HIP(hipGetLastError());
+  // backward + align
+  const size_t SmaxE = (size_t)((Smax + 1) & ~1);
+  const size_t shb = SmaxE * 8 + (size_t)Tmax * 4 + SmaxE * 8;
+  const size_t shc = (size_t)((Tmax + 15) >> 4) * SmaxE * 4;
+  if (shb > kLdsLimit) return fail(VCMI_ERR_ARG, "DTW: template of %d frames exceeds the supported length", Smax);
+  if (shb + shc <= kLdsLimit) {
+    auto kern = dtw_fused_finish_kernel<true>;
+    VCMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(shb + shc)));
+    hipLaunchKernelGGL(kern, dim3(n), dim3(256), shb + shc, st, feats, sc.dpairs.p, D, Smax, Tmax, sc.fcodes.p, sc.clast.p);
+  } else {
+    auto kern = dtw_fused_finish_kernel<false>;
+    VCMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shb));
+    hipLaunchKernelGGL(kern, dim3(n), dim3(256), shb, st, feats, sc.dpairs.p, D, Smax, Tmax, sc.fcodes.p, sc.clast.p);
+  }
+  VCMI_HIP(hipGetLastError());
+  VCMI_HIP(hipEventRecord(sc.last_use, st));
+  return VCMI_OK;
 }
 
 // Launch one workgroup per pair.  `pairs` holds DEVICE pointers (codes filled in here when needed).
@@ -567,6 +893,12 @@ static int dtw_run(const double *feats, std::vector<DtwPair> &pairs, int D, int 
     Tmax = std::max(Tmax, p.T);
   }
   if (Tmax == 0) return VCMI_OK;
+  {
+    bool tables = false;
+    for (auto &p : pairs) tables = tables || p.cost || p.bp;
+    if (fstep == 0 && (bstep == 1 || bstep == 2) && D <= 40 && !tables && !debug_flag(kDbgDtwTwoKernels))
+      return dtw_run_fused(feats, pairs, D, bstep, sc, st, Smax, Tmax);
+  }
   // largest pairs first: shortens the tail when n is not a multiple of the resident workgroup count
   std::stable_sort(pairs.begin(), pairs.end(), [](const DtwPair &a, const DtwPair &b) {
     return (int64_t)a.S * a.T > (int64_t)b.S * b.T;
@@ -623,13 +955,7 @@ static int dtw_run(const double *feats, std::vector<DtwPair> &pairs, int D, int 
         smax = std::max(smax, pairs[k].S);
         tmax = std::max(tmax, pairs[k].T);
       }
-      {
-        DtwPair *pinned = nullptr;
-        hipEvent_t copied = nullptr;
-        VCMI_TRY(sc.stage(pairs.data() + lo, (size_t)(hi - lo), &pinned, &copied));
-        VCMI_HIP(hipMemcpyAsync(dpairs.p + lo, pinned, sizeof(DtwPair) * (hi - lo), hipMemcpyHostToDevice, st));
-        VCMI_HIP(hipEventRecord(copied, st));
-      }
+      VCMI_TRY(sc.upload(dpairs.p + lo, pairs.data() + lo, (size_t)(hi - lo), st));
       if (tmax > 0) {
         // chunks of the slice: observation costs on the side stream, recurrences on the caller's stream behind them
         const int m = hi - lo;
@@ -659,13 +985,7 @@ static int dtw_run(const double *feats, std::vector<DtwPair> &pairs, int D, int 
     VCMI_HIP(hipEventRecord(sc.last_use, st));
     return VCMI_OK;
   }
-  {
-    DtwPair *pinned = nullptr;
-    hipEvent_t copied = nullptr;
-    VCMI_TRY(sc.stage(pairs.data(), (size_t)n, &pinned, &copied));
-    VCMI_HIP(hipMemcpyAsync(dpairs.p, pinned, sizeof(DtwPair) * n, hipMemcpyHostToDevice, st));
-    VCMI_HIP(hipEventRecord(copied, st));
-  }
+  VCMI_TRY(sc.upload(dpairs.p, pairs.data(), (size_t)n, st));
   VCMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(dtw_generic_kernel),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)base_generic));
   hipLaunchKernelGGL(dtw_generic_kernel, dim3(n), dim3(1024), base_generic, st, feats, dpairs.p, D, fstep, bstep, Smax, Tmax);

@@ -67,7 +67,8 @@ enum : unsigned {
   kDbgTrajGScalar = 2u,      // one-workgroup-per-frame g_t kernel instead of the MFMA one
   kDbgGvOneTeam = 4u,        // one-team GV kernel (the path of very long utterances)
   kDbgPredictTwoPass = 8u,   // (M,T) log-density matrix + argmax kernel instead of the in-kernel argmax
-  kDbgEstepGeneric = 16u     // generic diagonal E-step kernels instead of the MFMA one
+  kDbgEstepGeneric = 16u,    // generic diagonal E-step kernels instead of the MFMA one
+  kDbgDtwTwoKernels = 32u    // observation + recurrence kernels (the path of tables / D > 40 / wide windows) instead of the fused one
 };
 bool debug_flag(unsigned which);
 
