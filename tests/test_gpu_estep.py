@@ -79,3 +79,57 @@ def test_errors(vc):
         vc.estep_diag(np.zeros((4, 10)), np.ones(2) / 2, np.zeros((4, 2)), np.zeros((4, 2)))
     with pytest.raises(vc.DimensionMismatch):
         vc.estep_diag(np.zeros((5, 10)), np.ones(2) / 2, np.zeros((4, 2)), np.ones((4, 2)))
+
+
+def _hard_case(seed, Dj, M, N, spread, lo, hi, overlap):
+    """Tight variances (down to sklearn's min_covar, bin/train_gmm.jl:18), means far from the origin and mixtures that
+    overlap: the regime where an expanded-form log-density  x^2 a + x b + c  cancels catastrophically."""
+    rg = np.random.default_rng(seed)
+    w = rg.dirichlet(2.0 * np.ones(M))
+    base = rg.uniform(-spread, spread, (1, Dj))
+    vd = np.exp(rg.uniform(np.log(lo), np.log(hi), (1, Dj)))               # per-dimension scale shared by the cluster
+    var = vd * np.exp(rg.uniform(np.log(0.5), np.log(2.0), (M, Dj)))
+    # clustered means, apart by a fraction of a standard deviation in EVERY dimension: soft, shared posteriors
+    mu = base + overlap * rg.standard_normal((M, Dj)) * np.sqrt(vd) / np.sqrt(Dj)
+    mu[: M // 4] = rg.uniform(-spread, spread, (M // 4, Dj))                # ... plus some far-away mixtures
+    comp = rg.choice(M, size=N, p=w)
+    X = mu[comp] + rg.standard_normal((N, Dj)) * np.sqrt(var[comp])
+    return w, mu, var, X
+
+
+@pytest.mark.parametrize("generic", [False, True])
+@pytest.mark.parametrize("Dj,M", [(80, 128), (80, 37), (48, 16)])
+def test_tight_variances_far_means_overlapping_mixtures(vc, generic, Dj, M):
+    """sigma^2 log-uniform in [1e-7, 1e-2], |mu| up to 10, overlapping mixtures -- within 1e-9 of the
+    oracle (which evaluates (x - mu)^2 / sigma^2 term by term) for both device paths."""
+    from oracle import c_oracle as co
+    from voiceconversion_jl_amd import _lib
+    w, mu, var, X = _hard_case(515 + Dj + M, Dj, M, 6000, 10.0, 1e-7, 1e-2, 3.0)
+    r0, r1, r2, rl = co.estep_diag(X, w, mu, var)
+    _lib.debug_force(_lib.DBG_ESTEP_GENERIC if generic else 0)
+    try:
+        S0, S1, S2, ll = vc.estep_diag(X.T, w, mu.T, var.T)
+    finally:
+        _lib.debug_force(0)
+    assert relerr(S0, r0) < TOL and relerr(S1, r1.T) < TOL and relerr(S2, r2.T) < TOL, (relerr(S0, r0), relerr(S1, r1.T), relerr(S2, r2.T))
+    assert abs(ll - rl) < TOL * abs(rl)
+    # responsibilities are genuinely shared in this case (otherwise the test would not see log-density errors)
+    import voiceconversion_jl_amd  # noqa: F401
+    from oracle import np_oracle as npo
+    lp = -0.5 * (((X[:200, None, :] - mu[None]) ** 2 / var[None]).sum(-1) + np.log(var).sum(-1)[None]) + np.log(w)[None]
+    g = np.exp(lp - lp.max(1, keepdims=True)); g /= g.sum(1, keepdims=True)
+    assert np.mean(g.max(1)) < 0.97
+
+
+def test_fixture_model_diagonal(vc, fixture_model):
+    """The shipped model's own diagonal (variances down to ~1e-7 on some dimensions) with frames drawn from it."""
+    from oracle import c_oracle as co
+    w, mu, sig = fixture_model
+    var = np.stack([np.diag(s.T).copy() for s in sig])
+    rg = np.random.default_rng(4)
+    comp = rg.choice(len(w), size=5000, p=w)
+    X = mu[comp] + rg.standard_normal((5000, mu.shape[1])) * np.sqrt(var[comp])
+    r0, r1, r2, rl = co.estep_diag(X, w, mu, var)
+    S0, S1, S2, ll = vc.estep_diag(X.T, w, mu.T, var.T)
+    assert relerr(S0, r0) < TOL and relerr(S1, r1.T) < TOL and relerr(S2, r2.T) < TOL
+    assert abs(ll - rl) < TOL * abs(rl)

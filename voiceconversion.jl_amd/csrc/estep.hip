@@ -127,7 +127,8 @@ struct EstepCfg {
 template <int DJ>
 __global__ void __launch_bounds__(512)
 estep_mfma_kernel(const double *__restrict__ X, int64_t N, int M, const double *__restrict__ Wpack,
-                  const double *__restrict__ cinit, double *__restrict__ part, int64_t plen) {
+                  const double *__restrict__ cinit, double *__restrict__ part, int64_t plen,
+                  const double *__restrict__ refmu, const double *__restrict__ refiv, const double *__restrict__ refc) {
   using C = EstepCfg<DJ>;
   constexpr int KS = C::KS, NDT = C::NDT, FB = C::FB, RSX = C::RSX, RSG = C::RSG;
   extern __shared__ double smem[];
@@ -226,6 +227,48 @@ estep_mfma_kernel(const double *__restrict__ X, int64_t N, int M, const double *
       }
 #pragma unroll
       for (int sh = 1; sh < 16; sh <<= 1) u = fmax(u, __shfl_xor(u, sh));
+      // ---- refinement.  The GEMM form  x^2 (-1/2var) + x (mu/var) + c  cancels: with var down to min_covar = 1e-7 and
+      //      |mu| ~ 10 its terms reach 1e9 and l carries an absolute error of ~1e-7.  That is harmless while one mixture
+      //      owns the frame (gamma = 1 whatever l is) and wrong when several compete: the responsibilities inherit the
+      //      error.  So when more than one mixture is within kRefine of the frame's maximum, exactly those are
+      //      re-evaluated term by term, (x - mu)^2 / var summed over d, as the reference formula reads.
+      //      The kernel sits at the register cap: the re-evaluation works on the LDS copy of l with run-time loops
+      //      (nothing of v[] stays live across it) and the softmax then reloads its eight values. ----
+      {
+        constexpr double kRefine = 36.0;   // e^-36 = 2e-16: a mixture further below the maximum cannot change a sum
+        int nc = 0;
+#pragma unroll
+        for (int i = 0; i < C::MMAX / 16; ++i) nc += (v[i] > u - kRefine) ? 1 : 0;
+#pragma unroll
+        for (int sh = 1; sh < 16; sh <<= 1) nc += __shfl_xor(nc, sh);
+        if (nc > 1) {
+          const double thr = u - kRefine;
+          const double *xf = xs + f * RSX;
+#pragma unroll 1
+          for (int i = 0; i < C::MMAX / 16; ++i) {
+            const double li = row[16 * i];
+            if (li > thr) {
+              const int m = lcol + 16 * i;
+              const double *mp = refmu + (size_t)DJ * m, *ip = refiv + (size_t)DJ * m;
+              double q = 0.0;
+#pragma unroll 2
+              for (int d = 0; d < DJ; ++d) {
+                const double df = xf[d] - mp[d];
+                q = fma(df * df, ip[d], q);
+              }
+              row[16 * i] = refc[m] - 0.5 * q;
+            }
+          }
+          u = -INFINITY;
+#pragma unroll
+          for (int i = 0; i < C::MMAX / 16; ++i) {
+            v[i] = row[16 * i];
+            u = fmax(u, v[i]);
+          }
+#pragma unroll
+          for (int sh = 1; sh < 16; sh <<= 1) u = fmax(u, __shfl_xor(u, sh));
+        }
+      }
       double s = 0.0;
 #pragma unroll
       for (int i = 0; i < C::MMAX / 16; ++i) {
@@ -321,7 +364,7 @@ struct EstepStaging {
 };
 
 struct EstepScratch {
-  DevBuf<double> mu, iv, cst, G, LSE, part, Wpack, cinit, X, stats, raw;
+  DevBuf<double> mu, iv, cst, G, LSE, part, Wpack, cinit, X, stats, raw, refiv, refc;
   EstepStaging stage;
 };
 static EstepScratch &scratch() {
@@ -335,10 +378,19 @@ static EstepScratch &scratch() {
 //   cinit[m] = log w - (DJ log 2pi + sum log var)/2 - sum mu^2/(2 var)   (-inf for m >= M and for zero weights)
 template <int DJ>
 __global__ void __launch_bounds__(256)
-estep_prep_kernel(const double *__restrict__ raw, int M, double *__restrict__ Wpack, double *__restrict__ cinit) {
+estep_prep_kernel(const double *__restrict__ raw, int M, double *__restrict__ Wpack, double *__restrict__ cinit,
+                  double *__restrict__ refiv, double *__restrict__ refc) {
   using C = EstepCfg<DJ>;
   const double *w = raw, *mu = raw + M, *var = mu + (size_t)DJ * M;
   const int e = blockIdx.x * 256 + threadIdx.x;
+  // operands of the exact re-evaluation (estep_mfma_kernel, "refinement"): 1/var in the parameters' own (DJ,M) layout and
+  // the constant WITHOUT the -mu^2/(2 var) term
+  if (e < M * DJ) refiv[e] = 1.0 / var[e];
+  if (e < M) {
+    double sl = 0.0;
+    for (int d = 0; d < DJ; ++d) sl += log(var[d + (size_t)DJ * e]);
+    refc[e] = (w[e] > 0.0 ? log(w[e]) : -INFINITY) - 0.5 * (DJ * kLog2Pi + sl);
+  }
   if (e < 8 * C::KS * 64) {
     const int l = e & 63, ks = (e >> 6) % C::KS, mt = (e >> 6) / C::KS;
     const int m = 16 * mt + (l & 15), k = 4 * ks + (l >> 4);
@@ -390,6 +442,8 @@ static int estep_device(const double *dX, int64_t N, int Dj, int M, const double
     VCMI_TRY(sc.raw.reserve(2 * nraw));                  // one device copy per staging buffer
     VCMI_TRY(sc.Wpack.reserve((size_t)8 * C::KS * 64));
     VCMI_TRY(sc.cinit.reserve((size_t)C::MMAX));
+    VCMI_TRY(sc.refiv.reserve((size_t)M * Dj));
+    VCMI_TRY(sc.refc.reserve((size_t)M));
     VCMI_TRY(sc.part.reserve((size_t)grid * plen));
     VCMI_TRY(sc.stage.reserve(nraw));
     const int b = sc.stage.next;
@@ -402,12 +456,14 @@ static int estep_device(const double *dX, int64_t N, int Dj, int M, const double
     VCMI_HIP(hipMemcpyAsync(draw, h, nraw * sizeof(double), hipMemcpyHostToDevice, st));
     VCMI_HIP(hipEventRecord(sc.stage.copied[b], st));
     hipLaunchKernelGGL(estep_prep_kernel<80>, dim3((8 * C::KS * 64 + 255) / 256), dim3(256), 0, st, draw, M, sc.Wpack.p,
-                       sc.cinit.p);
+                       sc.cinit.p, sc.refiv.p, sc.refc.p);
     VCMI_HIP(hipGetLastError());
     auto kern = estep_mfma_kernel<80>;
     VCMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)C::LDS_BYTES));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), C::LDS_BYTES, st, dX, N, M, sc.Wpack.p, sc.cinit.p, sc.part.p, plen);
+    // (the means of the re-evaluation are the uploaded parameters themselves: raw = [w | mu (Dj,M) | var (Dj,M)])
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), C::LDS_BYTES, st, dX, N, M, sc.Wpack.p, sc.cinit.p, sc.part.p, plen,
+                       draw + M, sc.refiv.p, sc.refc.p);
     VCMI_HIP(hipGetLastError());
     hipLaunchKernelGGL(estep_reduce_kernel, dim3((unsigned)((plen + 255) / 256)), dim3(256), 0, st, sc.part.p, grid, plen,
                        dstats);
