@@ -549,6 +549,15 @@ def bench_traj(args, world, rank, gv=False):
     xoff = np.arange(n, dtype=np.int64) * T * 2 * D
     yoff = np.arange(n, dtype=np.int64) * T * D
     Ts = np.full(n, T, dtype=np.int64)
+    L = int(args.chunk)
+    if L > 0 and not gv:
+        # the reference CLI's regime: vc(c::TrajectoryConverter, fm) converts every utterance in independent chunks of
+        # length(c) = --T frames (bin/vc.jl:18 default 100; src/common.jl:42-57) -> n * ceil(T/L) short solves per batch
+        starts = [(u, b) for u in range(n) for b in range(0, T, L)]
+        xoff = np.array([(u * T + b) * 2 * D for u, b in starts], dtype=np.int64)
+        yoff = np.array([(u * T + b) * D for u, b in starts], dtype=np.int64)
+        Ts = np.array([min(L, T - b) for _, b in starts], dtype=np.int64)
+    nsolve = len(Ts)
 
     epochs, alpha = 100, 1.0e-5
     if gv:
@@ -566,7 +575,7 @@ def bench_traj(args, world, rank, gv=False):
                                                               alpha, Yd.data_ptr(), _lib.iptr(yoff),
                                                               torch.cuda.current_stream().cuda_stream))
         else:
-            _lib.check(_lib.lib.vcmi_traj_convert_batch_dev(tj._h, n, Xd.data_ptr(), _lib.iptr(xoff), _lib.iptr(Ts), Yd.data_ptr(),
+            _lib.check(_lib.lib.vcmi_traj_convert_batch_dev(tj._h, nsolve, Xd.data_ptr(), _lib.iptr(xoff), _lib.iptr(Ts), Yd.data_ptr(),
                                                             _lib.iptr(yoff), torch.cuda.current_stream().cuda_stream))
 
     wall, kernel_ms = timed_steps(step, args.steps, args.warmup, world)
@@ -578,8 +587,10 @@ def bench_traj(args, world, rank, gv=False):
            "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "f64", "data": "synthetic",
            "config": {"workload": ("TrajectoryGVGMMMap fvconvert, 100 epochs (SURVEY 8f rank 2)" if gv else
-                                   "TrajectoryGMMMap fvconvert (BASELINE configs[4])"), "static_D": D, "M": M, "T": T,
-                      "utterances_per_gpu": n},
+                                   "TrajectoryGMMMap fvconvert (BASELINE configs[4])" if L <= 0 else
+                                   f"vc(TrajectoryGMMMap) in chunks of {L} frames (bin/vc.jl:18, src/common.jl:42-57)"),
+                      "static_D": D, "M": M, "T": T, "utterances_per_gpu": n, "solves_per_step": nsolve,
+                      "frames_per_solve": int(Ts.max())},
            "roofline": {"bound": "mfma", "kernel": "predict + traj_g_mfma_kernel + traj_solve_blk_kernel<40>" + (" + traj_gv2_kernel" if gv else ""),
                         "achieved": achieved,
                         "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS,
@@ -588,14 +599,20 @@ def bench_traj(args, world, rank, gv=False):
                                                   "traj_solve_blk_kernel", "traj_gv_kernel", "traj_gv2_kernel")) or None) if n == 256 else None,
                         "traffic_unit": "bytes per step, all kernels (rocprofv3 FETCH_SIZE+WRITE_SIZE, profiles/r01e_pmc/)",
                         "flop_per_utterance": flops_per_utt, "kernel_ms": kernel_ms,
-                        "note": "whole pipeline (3 kernels); the banded solve is a 2000-step sequential block recurrence "
-                                "whose pivot block is factorised column by column (latency-bound, see DESIGN 3.4)"}}
+                        "note": "whole pipeline (3 kernels); the banded solve is a sequential block recurrence along each "
+                                "(sub-)sequence whose pivot block is factorised column by column (latency-bound, see DESIGN "
+                                "3.4); chunked conversion has the same number of block steps per CU, in shorter chains"}}
     if rank == 0:
         from oracle import c_oracle as co
 
         ref = co.TrajectoryGMMMap(co.GMMMap(w, mu, sig))
         t0 = time.perf_counter()
-        Yref = ref.fvconvert_gv(base[0], muv, Sv, epochs, alpha) if gv else ref.fvconvert(base[0])[0]
+        if gv:
+            Yref = ref.fvconvert_gv(base[0], muv, Sv, epochs, alpha)
+        elif L > 0:     # chunk by chunk, as the reference's vc loop does
+            Yref = np.concatenate([ref.fvconvert(base[0][b0:b0 + L])[0] for b0 in range(0, T, L)])
+        else:
+            Yref = ref.fvconvert(base[0])[0]
         dt = time.perf_counter() - t0
         err = float(np.max(np.abs(Yd[:T].cpu().numpy() - Yref)) / np.max(np.abs(Yref)))
         out["cpu_baseline"] = {"value": T / dt, "unit": "frames/s", "cores": 1, "kind": "port",
