@@ -45,9 +45,10 @@ def estep_flops_per_frame(Dj, M):
     return 8 * Dj * M + 25 * M
 
 
-def pmc_traffic(fname, kernel_prefix, subdir="r01c_pmc"):
-    """HBM bytes per bench step of a kernel from a committed PMC pass (profiles/r01c_pmc/*.json, tools/pmc_traffic.sh);
-    the counters cannot be collected inside the timed run.  Raw FETCH_SIZE + WRITE_SIZE: see profiles/r01c_pmc/README.txt."""
+def pmc_traffic(fname, kernel_prefix, subdir="r02_pmc"):
+    """HBM bytes per bench step of a kernel from a committed PMC pass (profiles/r02_pmc/*.json, tools/pmc_traffic.sh: FETCH_SIZE
+    and WRITE_SIZE in SEPARATE rocprofv3 passes of this same bench command); the counters cannot be collected inside the
+    timed run.  Raw (KB counters x 1024): see profiles/r02_pmc/README.txt for the guide's gfx950 correction."""
     try:
         tr = json.load(open(os.path.join(ROOT, "profiles", subdir, fname)))
         for k, v in tr.items():
@@ -236,10 +237,9 @@ def bench_convert(args, world, rank):
     }
     # HBM traffic of the kernel from the committed PMC passes (cannot be collected inside the timed run)
     try:
-        tr = json.load(open(os.path.join(ROOT, "profiles", "r01b_pmc", "convert_traffic.json")))
-        if tr["frames"] == T:
-            out["roofline"]["traffic"] = tr["hbm_bytes_per_launch_raw"]
-            out["roofline"]["traffic_unit"] = "bytes per launch (rocprofv3 FETCH_SIZE+WRITE_SIZE, see profiles/r01b_pmc/)"
+        if T == 1_000_000:
+            out["roofline"]["traffic"] = pmc_traffic("convert_traffic.json", "gmmmap_mfma_kernel", "r02_pmc")
+            out["roofline"]["traffic_unit"] = "bytes per launch (rocprofv3 FETCH_SIZE+WRITE_SIZE in separate passes, raw; see profiles/r02_pmc/README.txt)"
     except (OSError, KeyError, ValueError):
         pass
     if rank == 0:
@@ -305,7 +305,7 @@ def bench_estep(args, world, rank):
     import voiceconversion_jl_amd as vc
     from oracle import np_oracle as npo
 
-    Dj, M, N = 80, 128, args.frames if args.frames != 1_000_000 else 1_250_000
+    Dj, M, N = args.dj, 128, args.frames if args.frames != 1_000_000 else 1_250_000
     w, mu, _ = npo.synth_model(1003, Dj, M)
     var = np.exp(np.random.default_rng(1003).uniform(np.log(1e-3), 0.0, (M, Dj)))   # the model: same on every rank
 
@@ -329,11 +329,11 @@ def bench_estep(args, world, rank):
     out = {"metric": "diag-GMM E-step frames/sec (Dj=80, M=128)", "value": fps, "unit": "frames/s", "n_gpus": world,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True,
            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-           "config": {"workload": "diag E-step (BASELINE configs[2])", "Dj": Dj, "M": M, "frames_per_gpu": N,
+           "config": {"workload": "diag E-step (BASELINE configs[2])" if Dj == 80 else f"diag E-step, Dj={Dj} (--add_delta features; generic kernels)", "Dj": Dj, "M": M, "frames_per_gpu": N,
                       "collective": "all-reduce(sum) of %d doubles per step" % vc.stats_len(Dj, M)},
-           "roofline": {"bound": "mfma", "kernel": "estep_mfma_kernel<80> (+ all-reduce)", "achieved": achieved,
+           "roofline": {"bound": "mfma", "kernel": ("estep_mfma_kernel<80>" if Dj == 80 else "estep_gamma_kernel + estep_stats_kernel (generic path)") + " (+ all-reduce)", "achieved": achieved,
                         "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS,
-                        "traffic": pmc_traffic("estep_traffic.json", "estep_mfma_kernel") if N == 1_250_000 else None,
+                        "traffic": pmc_traffic("estep_traffic.json", "estep_mfma_kernel", "r02_pmc") if (N == 1_250_000 and Dj == 80) else None,
                         "flop_per_frame": estep_flops_per_frame(Dj, M), "kernel_ms": kernel_ms}}
     if rank == 0:
         from oracle import c_oracle as co
@@ -439,9 +439,9 @@ def bench_em_full(args, world, rank):
            "roofline": {"bound": "mfma", "kernel": "whole iteration: log-densities + second moments + M-step + whitening",
                         "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                         "frac": achieved / FP64_PEAK_TFLOPS,
-                        "traffic": ((pmc_traffic("em_full_traffic.json", "gmmmap_mfma_kernel") or 0) +
-                                    (pmc_traffic("em_full_traffic.json", "estep_full_stats_kernel") or 0) +
-                                    (pmc_traffic("em_full_traffic.json", "estep_full_softmax_kernel") or 0)) or None
+                        "traffic": ((pmc_traffic("em_full_traffic.json", "gmmmap_mfma_kernel", "r02_pmc") or 0) +
+                                    (pmc_traffic("em_full_traffic.json", "estep_full_stats_kernel", "r02_pmc") or 0) +
+                                    (pmc_traffic("em_full_traffic.json", "estep_full_softmax_kernel", "r02_pmc") or 0)) or None
                         if N == 500_000 else None,
                         "flop_per_frame": flop, "kernel_ms": kernel_ms},
            "loglik_monotone": bool(all(b >= a - 1e-6 * abs(a) for a, b in zip(hist, hist[1:])))}
@@ -594,10 +594,10 @@ def bench_traj(args, world, rank, gv=False):
            "roofline": {"bound": "mfma", "kernel": "predict + traj_g_mfma_kernel + traj_solve_blk_kernel<40>" + (" + traj_gv2_kernel" if gv else ""),
                         "achieved": achieved,
                         "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS,
-                        "traffic": (sum(pmc_traffic(("trajgv" if gv else "traj") + "_traffic.json", k, "r01e_pmc") or 0
+                        "traffic": (sum(pmc_traffic(("trajgv" if gv else "traj") + "_traffic.json", k, "r02_pmc") or 0
                                         for k in ("gmmmap_mfma_kernel", "posterior_finish_kernel", "traj_g_mfma_kernel",
                                                   "traj_solve_blk_kernel", "traj_gv_kernel", "traj_gv2_kernel")) or None) if n == 256 else None,
-                        "traffic_unit": "bytes per step, all kernels (rocprofv3 FETCH_SIZE+WRITE_SIZE, profiles/r01e_pmc/)",
+                        "traffic_unit": "bytes per step, all kernels (rocprofv3 FETCH_SIZE+WRITE_SIZE, profiles/r02_pmc/)",
                         "flop_per_utterance": flops_per_utt, "kernel_ms": kernel_ms,
                         "note": "whole pipeline (3 kernels); the banded solve is a sequential block recurrence along each "
                                 "(sub-)sequence whose pivot block is factorised column by column (latency-bound, see DESIGN "
@@ -661,6 +661,7 @@ def main():
     ap.add_argument("--utts", type=int, default=256, help="trajectory utterances per GPU")
     ap.add_argument("--chunk", type=int, default=0, help="traj: convert in vc() chunks of this many frames "
                     "(bin/vc.jl:18 default --T=100); 0 = whole 2000-frame utterances (BASELINE configs[4])")
+    ap.add_argument("--dj", type=int, default=80, help="estep: joint feature dimension (80 = BASELINE; 160 = --add_delta features, generic kernels)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU time budget of the cpu_baseline sample")
     ap.add_argument("--verify-allreduce", action="store_true",
                     help="estep: rank 0 recomputes the statistics of every rank's frames in one process and compares")
