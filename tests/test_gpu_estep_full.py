@@ -167,3 +167,28 @@ def test_train_gmm_refine_and_init(vc):
     bad[:, :, 1] = -bad[:, :, 1]
     with pytest.raises(vc.PosDefException):
         vc.train_gmm(Xd, n_components=M, n_iter=2, refine=(w, mu.T, bad))
+
+
+def test_empty_mixture_survives_the_mstep(vc):
+    """A mixture that receives no responsibility (S0 = 0) must not poison the model: with the old sklearn.mixture.GMM
+    guards (w = S0/(sum + 10 eps) + eps, mu = S1/(S0 + 10 eps), Sigma = S2/(S0 + 10 eps) - mu mu' + min_covar I) it comes
+    out as weight eps, mean 0, covariance min_covar I -- finite and positive definite -- and the next E-step runs."""
+    import torch
+    from oracle import np_oracle as npo
+    Dj, M, N = 12, 3, 4000
+    w, mu, sig = npo.synth_model(91, Dj, M, lam_lo=1e-1)
+    X = npo.sample_frames(92, w[:2] / w[:2].sum(), mu[:2], sig[:2], N, 0, Dj)      # frames from mixtures 0 and 1 only
+    mu = mu.copy()
+    mu[2] = 1.0e3                                                                  # mixture 2 is nowhere near any frame
+    em = vc.EMState(w, mu.T, np.transpose(sig, (2, 1, 0)), min_covar=1e-7)
+    Xd = torch.from_numpy(X).cuda().t()
+    st = em.estep(Xd)
+    S0 = st.cpu().numpy()[:M]
+    assert S0[2] == 0.0 and abs(S0[:2].sum() - N) < 1e-6
+    ll = em.mstep(st)                                                              # would raise PosDefException on NaN
+    w2, mu2, sg2 = em.get()
+    assert np.isfinite(ll) and np.all(np.isfinite(w2)) and np.all(np.isfinite(mu2)) and np.all(np.isfinite(sg2))
+    assert w2[2] == np.finfo(np.float64).eps and np.all(mu2[:, 2] == 0.0)
+    assert np.allclose(sg2[:, :, 2], 1e-7 * np.eye(Dj), rtol=0, atol=0)
+    ll2 = em.mstep(em.estep(Xd))                                                   # and EM goes on
+    assert np.isfinite(ll2) and ll2 >= ll - 1e-6 * abs(ll)
