@@ -1022,8 +1022,8 @@ static int traj_run(vcmi_traj *t, std::vector<TrajUtt> &utts, int64_t nframes, b
     const size_t shb = BlkCfg<DV>::lds_doubles * sizeof(double);                                                    \
     VCMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,  \
                                  (int)shb));                                                                        \
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), shb, st, du, n, t->Q.p, t->mhat.p, t->gbuf.p, t->ws.p, ws_stride, \
-                       t->status.p);                                                                                \
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlkThreads), shb, st, du, n, t->Q.p, t->mhat.p, t->gbuf.p, t->ws.p,   \
+                       ws_stride, t->status.p);                                                                     \
     launched = true;                                                                                                \
   } break;
       VCMI_TRAJ_BLK_CASE(12) VCMI_TRAJ_BLK_CASE(16) VCMI_TRAJ_BLK_CASE(20) VCMI_TRAJ_BLK_CASE(24) VCMI_TRAJ_BLK_CASE(25)

@@ -256,96 +256,226 @@ __device__ void blk_pivot_u(double *B00, double *ring, int fbase, double *cbu,
   if constexpr (NB > 5) phase(std::integral_constant<int, 5>{}, 40, D < 48 ? D : 48);
 }
 
-// row tile `it` of  S <- S U'  in place (one wave): the row tile's A fragments are read first, every output tile
-// (it, jt) needs only k < 16 (jt + 1) because U is lower triangular.  Columns >= D are stored as zeros.
+// ------------------------------------------------------------------------------------------------
+// Pivot phase, version 2: blocked.  The column-by-column scheme above pays ~600 cycles per pivot column whatever the
+// amount of arithmetic, because every column is published through LDS and read back (write -> read round trip, tag
+// polling) before the next one can start: 40 columns = 24k cycles of a 32k-cycle block step.  Here S00 is processed in
+// 16 x 16 diagonal blocks:
+//   wave 0, scalar chain per diagonal block: ONE LANE OWNS A WHOLE ROW of the block (16 values of the block and 16 of
+//     the identity that becomes its inverse) and a pivot column is applied with v_fmac_f64_dpp row_newbcast -- the
+//     multiply-add reads row c's value straight out of lane c's register, so the chain never touches LDS:
+//     pivot broadcast -> rsqrt -> multiplier -> 16 DPP multiply-adds, ~150-180 cycles per column;
+//   wave 1, MFMA: the panel below a finished diagonal block  L_rk = A_rk U_kk'  and the rank-16 trailing update
+//     A_rc -= L_rk L_ck'  (the next diagonal tile first, so that wave 0 can go on), then U = L00^-1 block by block
+//     (U_rc = -U_rr sum_j L_rj U_jc), 16 x 16 x 16 products.
+// The two waves hand over through counters in LDS.  Row D of the last tile row (the right-hand side living in the
+// tile padding) is never modified: L rows >= D are stored as zeros and U is written for rows < D only.
+// ------------------------------------------------------------------------------------------------
+template <int D>
+struct Pv2 {
+  static constexpr int NTD = (D + 15) / 16;      // diagonal blocks
+  static constexpr int TS = 18;                  // row stride of the scratch tiles (TS/2 odd: conflict-free operand reads)
+  static constexpr int TILE = 16 * TS;
+  // scratch (in the ring area of the column-by-column scheme): L tiles (r,k), r > k, then the W tiles of one block row
+  static constexpr int NL = NTD * (NTD - 1) / 2;
+  static constexpr int SCRATCH = (NL + (NTD > 1 ? NTD - 1 : 1)) * TILE;
+  __device__ static constexpr int lidx(int r, int k) { return r * (r - 1) / 2 + k; }
+};
+
+__device__ __forceinline__ void pv2_signal(int *flag, int v, int lane) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  if (lane == 0) __hip_atomic_store(flag, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void pv2_wait(int *flag, int v) {
+  while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < v) __builtin_amdgcn_s_sleep(1);
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// acc += A B'  /  acc += A B  over one 16 x 16 x 16 product (4 k-steps); tile origins and row strides
+__device__ __forceinline__ blk_d4 pv2_mm_nt(const double *A, int lda, const double *B, int ldb, int lane, blk_d4 acc) {
+  const int lrow = lane & 15, lq = lane >> 4;
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks)
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(A[lrow * lda + 4 * ks + lq], B[lrow * ldb + 4 * ks + lq], acc, 0, 0, 0);
+  return acc;
+}
+__device__ __forceinline__ blk_d4 pv2_mm_nn(const double *A, int lda, const double *B, int ldb, int lane, blk_d4 acc) {
+  const int lrow = lane & 15, lq = lane >> 4;
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks)
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(A[lrow * lda + 4 * ks + lq], B[(4 * ks + lq) * ldb + lrow], acc, 0, 0, 0);
+  return acc;
+}
+// store acc (sign applied) into a tile: rows [0, nrows) get the values, the others zeros (zero_rest) or stay untouched
+__device__ __forceinline__ void pv2_store(double *Tl, int ld, blk_d4 acc, double sign, int nrows, bool zero_rest, int lane) {
+  const int lrow = lane & 15, lq = lane >> 4;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = 4 * r + lq;
+    if (row < nrows) Tl[row * ld + lrow] = sign * acc[r];
+    else if (zero_rest) Tl[row * ld + lrow] = 0.0;
+  }
+}
+
+// wave 0: the scalar chains of the diagonal blocks.  flags[0] counts finished stages of this block step (see pv2_wave1).
+template <int D>
+__device__ void pv2_wave0(double *B00, int *flags, int fbase, int lane, int *bad) {
+  using C = BlkCfg<D>;
+  using P = Pv2<D>;
+  constexpr int LS = C::LS;
+  const int i = lane & 15;
+  bool notpd = false;
+#pragma unroll 1
+  for (int k = 0; k < P::NTD; ++k) {
+    if (k > 0) pv2_wait(flags, fbase + 2 * k);          // tile (k,k) has the updates of the blocks before it
+    const int r0 = 16 * k, nb = (D - r0 < 16) ? D - r0 : 16;
+    double a[16], e[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int rr = i >= j ? i : j, cc = i >= j ? j : i;     // the lower triangle holds the block
+      a[j] = (i < nb && j < nb) ? B00[(r0 + rr) * LS + r0 + cc] : ((i == j) ? 1.0 : 0.0);
+      e[j] = (i == j) ? 1.0 : 0.0;
+    }
+    double sc = 1.0;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      if (c < nb) {                                        // wave-uniform
+        double pv;
+        asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(pv) : "v"(a[c]), "n"(c));
+        notpd |= !(pv > 0.0);
+        // 1/p for the multipliers (on the chain: hardware reciprocal + two Newton steps); 1/sqrt(p) only scales the
+        // finished row at the end (off the chain)
+        double winv = __builtin_amdgcn_rcp(pv);
+        winv = winv * fma(-pv, winv, 2.0);
+        winv = winv * fma(-pv, winv, 2.0);
+        const double dinv = traj_rsqrt(pv);
+        const double m = (i > c) ? -(a[c] * winv) : 0.0;   // row i -= (a_ic / p) row c, for the rows below c
+#pragma unroll
+        for (int j = c + 1; j < 16; ++j)
+          asm volatile("v_fmac_f64_dpp %0, %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "+v"(a[j]) : "v"(m), "n"(c));
+#pragma unroll
+        for (int j = 0; j <= c; ++j)
+          asm volatile("v_fmac_f64_dpp %0, %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "+v"(e[j]) : "v"(m), "n"(c));
+        sc = (i == c) ? dinv : sc;
+      }
+    }
+    // U_kk = D^-1/2 (unit-lower inverse): row i of the identity part scaled by 1/sqrt(p_i); zeros above the diagonal
+    if (lane < 16 && i < nb) {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) B00[(r0 + i) * LS + r0 + j] = (j <= i) ? e[j] * sc : 0.0;
+    }
+    pv2_signal(flags, fbase + 2 * k + 1, lane);
+  }
+  if (notpd && lane == 0) *bad = 1;
+}
+
+// wave 1: panels, trailing updates and the off-diagonal blocks of U on MFMA.  Stage counter flags[0] of block step
+// `fbase / 16`:  fbase + 2k + 1 = diagonal block k inverted (wave 0),  fbase + 2k + 2 = tile (k+1,k+1) updated (wave 1).
+// While wave 1 waits for a diagonal block it runs `job(0) .. job(njobs-1)` (independent pieces of the deferred team's
+// work on the previous block step).  The first `nfirst` jobs run before anything else (the deferred team waits for
+// them); then at most `TRAJ_W1_GAP` jobs per wait, re-checking the counter in between, so that a job never holds up
+// the chain for longer than its own length; what is left runs after the last product of the step.
+#ifndef TRAJ_W1_GAP
+#define TRAJ_W1_GAP 1
+#endif
+template <int D, class Job>
+__device__ void pv2_wave1(double *B00, double *scratch, int *flags, int fbase, int lane, int njobs, int nfirst, const Job &job) {
+  using C = BlkCfg<D>;
+  using P = Pv2<D>;
+  constexpr int LS = C::LS, NTD = P::NTD, TS = P::TS;
+  const blk_d4 zero = {0.0, 0.0, 0.0, 0.0};
+  double *Ls = scratch, *Wt = scratch + P::NL * P::TILE;      // L tiles (r,k), r > k; W tiles of one block row
+  auto tile = [&](int r, int c) { return B00 + 16 * r * LS + 16 * c; };
+  auto rows_of = [&](int r) { return (D - 16 * r < 16) ? D - 16 * r : 16; };
+  int next_job = 0;
+  for (; next_job < nfirst && next_job < njobs; ++next_job) job(next_job);
+  auto wait_working = [&](int v, int budget) {
+    while (__hip_atomic_load(flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < v) {
+      if (next_job < njobs && budget > 0) {
+        job(next_job++);
+        --budget;
+      } else __builtin_amdgcn_s_sleep(1);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  };
+  auto wave_sync = [&]() {      // LDS stores of this wave -> loads by its other lanes
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
+  auto ltile = [&](int r, int k) { return Ls + P::lidx(r, k) * P::TILE; };
+  auto trailing = [&](int r, int c, int k) {      // A_rc -= L_rk L_ck'
+    const int lrow = lane & 15, lq = lane >> 4;
+    double *cp = tile(r, c) + lq * LS + lrow;
+    blk_d4 acc;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[q] = -cp[4 * q * LS];
+    acc = pv2_mm_nt(ltile(r, k), TS, ltile(c, k), TS, lane, acc);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) cp[4 * q * LS] = -acc[q];
+  };
+  for (int k = 0; k < NTD; ++k) {
+    wait_working(fbase + 2 * k + 1, k == 0 ? (nfirst > 0 ? 0 : 1) : TRAJ_W1_GAP);
+    if (k + 1 < NTD) {
+      // what wave 0 waits for: the panel tile below the block, L = A U_kk' (rows >= D stored as zeros), and the update
+      // of the next diagonal tile
+      pv2_store(ltile(k + 1, k), TS, pv2_mm_nt(tile(k + 1, k), LS, tile(k, k), LS, lane, zero), 1.0, rows_of(k + 1), true, lane);
+      wave_sync();
+      trailing(k + 1, k + 1, k);
+      pv2_signal(flags, fbase + 2 * k + 2, lane);
+      // the rest of the panel and of the rank-16 update, beside wave 0's next chain
+      for (int r = k + 2; r < NTD; ++r)
+        pv2_store(ltile(r, k), TS, pv2_mm_nt(tile(r, k), LS, tile(k, k), LS, lane, zero), 1.0, rows_of(r), true, lane);
+      wave_sync();
+      for (int c = k + 1; c < NTD; ++c)
+        for (int r = (c == k + 1) ? c + 1 : c; r < NTD; ++r) trailing(r, c, k);
+    }
+    // U = L00^-1, row k of the off-diagonal blocks: U_kc = -U_kk W_kc with W_kc = sum_{j=c}^{k-1} L_kj U_jc formed while
+    // wave 0 was busy with block k (below): after the last diagonal block only these independent products remain
+    if (k > 0) {
+      blk_d4 acc[NTD > 1 ? NTD - 1 : 1];
+#pragma unroll
+      for (int c = 0; c < NTD - 1; ++c)
+        if (c < k) acc[c] = pv2_mm_nn(tile(k, k), LS, Wt + c * P::TILE, TS, lane, zero);
+#pragma unroll
+      for (int c = 0; c < NTD - 1; ++c)
+        if (c < k) pv2_store(tile(k, c), LS, acc[c], -1.0, rows_of(k), false, lane);
+      wave_sync();
+    }
+    if (k + 1 < NTD) {
+      for (int c = 0; c <= k; ++c) {
+        blk_d4 acc = zero;
+        for (int j = c; j <= k; ++j) acc = pv2_mm_nn(ltile(k + 1, j), TS, tile(j, c), LS, lane, acc);
+        pv2_store(Wt + c * P::TILE, TS, acc, 1.0, 16, false, lane);
+      }
+      wave_sync();
+    }
+  }
+  while (next_job < njobs) job(next_job++);
+}
+
+// The MFMA building blocks below share one shape: every LDS operand of the call is requested first (a few dozen
+// ds_reads in flight), then the products run back to back with the column tiles as independent accumulator chains, then
+// the results are stored.  A tile-by-tile order (load C, 10 products, store C, next tile) exposes an LDS round trip
+// and the 16-pass drain of the accumulators per tile: 50-59 % of the FP64 MFMA rate when measured alone
+// (tools/microbench_blkops.hip), against 80-90 % in this form.
+
+// row tile `it` of  S <- S U'  in place (one wave): output tile (it, jt) needs only k < 16 (jt + 1) because U is lower
+// triangular.  Columns >= D are stored as zeros.
 template <int D>
 __device__ __forceinline__ void blk_trsm_rowtile(double *S, const double *U, int it, int lane) {
   using C = BlkCfg<D>;
   constexpr int LS = C::LS, KS = C::KS, NT = C::NT;
   const int lrow = lane & 15, lq = lane >> 4;
-  double a[KS];
+  double a[KS], b[NT][KS];
   const double *xa = S + (16 * it + lrow) * LS + lq;
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) a[ks] = xa[4 * ks];
 #pragma unroll
-  for (int jt = 0; jt < NT; ++jt) {
-    const double *yb = U + (16 * jt + lrow) * LS + lq;
-    blk_d4 acc = {0.0, 0.0, 0.0, 0.0};
+  for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks)
-      if (ks < 4 * (jt + 1)) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], yb[4 * ks], acc, 0, 0, 0);
-    const int col = 16 * jt + lrow;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) S[(16 * it + 4 * r + lq) * LS + col] = (col < D) ? acc[r] : 0.0;
-  }
-}
-
-// tile (it, jt) of  Cm -= X Y'  (k over the D columns; even and odd k-steps in two accumulators: two independent
-// MFMA chains).  Columns >= D are stored as zeros.
-template <int D>
-__device__ __forceinline__ void blk_update_tile(double *Cm, const double *X, const double *Y, int it, int jt, int lane) {
-  using C = BlkCfg<D>;
-  constexpr int LS = C::LS, KS = C::KS;
-  const int lrow = lane & 15, lq = lane >> 4;
-  double *cp = Cm + (16 * it + lq) * LS + 16 * jt + lrow;
-  blk_d4 acc, acc2 = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-  for (int r = 0; r < 4; ++r) acc[r] = cp[4 * r * LS];
-  const double *xa = X + (16 * it + lrow) * LS + lq, *yb = Y + (16 * jt + lrow) * LS + lq;
-#pragma unroll
-  for (int ks = 0; ks < KS; ++ks) {
-    if (ks & 1) acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(-xa[4 * ks], yb[4 * ks], acc2, 0, 0, 0);
-    else acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-xa[4 * ks], yb[4 * ks], acc, 0, 0, 0);
-  }
-  const bool keep = 16 * jt + lrow < D;
-#pragma unroll
-  for (int r = 0; r < 4; ++r) cp[4 * r * LS] = keep ? acc[r] + acc2[r] : 0.0;
-}
-
-// tiles (it, 0 .. njt-1) of  Cm -= X Y'  with the A fragments of row tile `it` of X read once for the whole row group
-// (a third fewer LDS reads than tile by tile; the column tiles are independent MFMA chains).
-template <int D>
-__device__ __forceinline__ void blk_update_rowgroup(double *Cm, const double *X, const double *Y, int it, int njt, int lane) {
-  using C = BlkCfg<D>;
-  constexpr int LS = C::LS, KS = C::KS, NT = C::NT;
-  const int lrow = lane & 15, lq = lane >> 4;
-  double a[KS];
-  const double *xa = X + (16 * it + lrow) * LS + lq;
-#pragma unroll
-  for (int ks = 0; ks < KS; ++ks) a[ks] = -xa[4 * ks];
-#pragma unroll
-  for (int jt = 0; jt < NT; ++jt) {
-    if (jt < njt) {
-      double *cp = Cm + (16 * it + lq) * LS + 16 * jt + lrow;
-      const double *yb = Y + (16 * jt + lrow) * LS + lq;
-      blk_d4 acc, acc2 = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-      for (int r = 0; r < 4; ++r) acc[r] = cp[4 * r * LS];
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        if (ks & 1) acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], yb[4 * ks], acc2, 0, 0, 0);
-        else acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], yb[4 * ks], acc, 0, 0, 0);
-      }
-      const bool keep = 16 * jt + lrow < D;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) cp[4 * r * LS] = keep ? acc[r] + acc2[r] : 0.0;
-    }
-  }
-}
-
-// row tile `it` of  L U  (U lower triangular: column tile jt needs only k >= 16 jt) straight from the accumulators to
-// the HBM panel `out` (row-major, D columns): rows < nrows, columns < D.  The A fragments of the row tile are read
-// once; the column tiles are independent MFMA chains.
-template <int D>
-__device__ __forceinline__ void blk_lu_rowtile_to_panel(const double *L, const double *U, int it, int nrows,
-                                                        double *__restrict__ out, int lane) {
-  using C = BlkCfg<D>;
-  constexpr int LS = C::LS, KS = C::KS, NT = C::NT;
-  const int lrow = lane & 15, lq = lane >> 4;
-  double a[KS];
-  const double *xa = L + (16 * it + lrow) * LS + lq;
-#pragma unroll
-  for (int ks = 0; ks < KS; ++ks) a[ks] = xa[4 * ks];
+    for (int jt = 0; jt < NT; ++jt)
+      if (ks < 4 * (jt + 1)) b[jt][ks] = U[(16 * jt + lrow) * LS + lq + 4 * ks];
   blk_d4 acc[NT];
 #pragma unroll
   for (int jt = 0; jt < NT; ++jt) acc[jt] = blk_d4{0.0, 0.0, 0.0, 0.0};
@@ -353,7 +483,121 @@ __device__ __forceinline__ void blk_lu_rowtile_to_panel(const double *L, const d
   for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
     for (int jt = 0; jt < NT; ++jt)
-      if (ks >= 4 * jt) acc[jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], U[(4 * ks + lq) * LS + 16 * jt + lrow], acc[jt], 0, 0, 0);
+      if (ks < 4 * (jt + 1)) acc[jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], b[jt][ks], acc[jt], 0, 0, 0);
+#pragma unroll
+  for (int jt = 0; jt < NT; ++jt) {
+    const int col = 16 * jt + lrow;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) S[(16 * it + 4 * r + lq) * LS + col] = (col < D) ? acc[jt][r] : 0.0;
+  }
+}
+
+// tile (it, jt) of  Cm -= X Y'  (k over the D columns; even and odd k-steps in two accumulators).  Columns >= D are
+// stored as zeros.
+template <int D>
+__device__ __forceinline__ void blk_update_tile(double *Cm, const double *X, const double *Y, int it, int jt, int lane) {
+  using C = BlkCfg<D>;
+  constexpr int LS = C::LS, KS = C::KS;
+  const int lrow = lane & 15, lq = lane >> 4;
+  double *cp = Cm + (16 * it + lq) * LS + 16 * jt + lrow;
+  const double *xa = X + (16 * it + lrow) * LS + lq, *yb = Y + (16 * jt + lrow) * LS + lq;
+  double a[KS], b[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    a[ks] = xa[4 * ks];
+    b[ks] = yb[4 * ks];
+  }
+  blk_d4 acc, acc2 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int r = 0; r < 4; ++r) acc[r] = -cp[4 * r * LS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    if (ks & 1) acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], b[ks], acc2, 0, 0, 0);
+    else acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], b[ks], acc, 0, 0, 0);
+  }
+  const bool keep = 16 * jt + lrow < D;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) cp[4 * r * LS] = keep ? -(acc[r] + acc2[r]) : 0.0;
+}
+
+// tiles (it, 0 .. NJ-1) of  Cm -= X Y': the A fragments of row tile `it` of X are read once for the row group and the
+// column tiles are independent MFMA chains (accumulating  X Y' - Cm, negated when stored).
+template <int D, int NJ>
+__device__ __forceinline__ void blk_update_rowgroup_n(double *Cm, const double *X, const double *Y, int it, int lane) {
+  using C = BlkCfg<D>;
+  constexpr int LS = C::LS, KS = C::KS;
+  const int lrow = lane & 15, lq = lane >> 4;
+  double a[KS], b[NJ][KS];
+  blk_d4 acc[NJ];
+  const double *xa = X + (16 * it + lrow) * LS + lq;
+  double *cp = Cm + (16 * it + lq) * LS + lrow;
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) a[ks] = xa[4 * ks];
+#pragma unroll
+  for (int jt = 0; jt < NJ; ++jt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[jt][r] = -cp[4 * r * LS + 16 * jt];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+    for (int jt = 0; jt < NJ; ++jt) b[jt][ks] = Y[(16 * jt + lrow) * LS + lq + 4 * ks];
+  if constexpr (NJ == 1) {      // one tile: two chains (even and odd k-steps)
+    blk_d4 acc2 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      if (ks & 1) acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], b[0][ks], acc2, 0, 0, 0);
+      else acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], b[0][ks], acc[0], 0, 0, 0);
+    }
+    acc[0] += acc2;
+  } else {
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int jt = 0; jt < NJ; ++jt) acc[jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], b[jt][ks], acc[jt], 0, 0, 0);
+  }
+#pragma unroll
+  for (int jt = 0; jt < NJ; ++jt) {
+    const bool keep = 16 * jt + lrow < D;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) cp[4 * r * LS + 16 * jt] = keep ? -acc[jt][r] : 0.0;
+  }
+}
+template <int D>
+__device__ __forceinline__ void blk_update_rowgroup(double *Cm, const double *X, const double *Y, int it, int njt, int lane) {
+  constexpr int NT = BlkCfg<D>::NT;
+  static_assert(NT <= 4, "row groups of up to four column tiles");
+  if (njt == 1) blk_update_rowgroup_n<D, 1>(Cm, X, Y, it, lane);
+  else if (njt == 2) blk_update_rowgroup_n<D, NT >= 2 ? 2 : 1>(Cm, X, Y, it, lane);
+  else if (njt == 3) blk_update_rowgroup_n<D, NT >= 3 ? 3 : 1>(Cm, X, Y, it, lane);
+  else if (njt == 4) blk_update_rowgroup_n<D, NT >= 4 ? 4 : 1>(Cm, X, Y, it, lane);
+}
+
+// row tile `it` of  L U  (U lower triangular: column tile jt needs only k >= 16 jt) straight from the accumulators to
+// the HBM panel `out` (row-major, D columns): rows < nrows, columns < D.
+template <int D>
+__device__ __forceinline__ void blk_lu_rowtile_to_panel(const double *L, const double *U, int it, int nrows,
+                                                        double *__restrict__ out, int lane) {
+  using C = BlkCfg<D>;
+  constexpr int LS = C::LS, KS = C::KS, NT = C::NT;
+  const int lrow = lane & 15, lq = lane >> 4;
+  double a[KS], b[NT][KS];
+  const double *xa = L + (16 * it + lrow) * LS + lq;
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) a[ks] = xa[4 * ks];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+    for (int jt = 0; jt < NT; ++jt)
+      if (ks >= 4 * jt) b[jt][ks] = U[(4 * ks + lq) * LS + 16 * jt + lrow];
+  blk_d4 acc[NT];
+#pragma unroll
+  for (int jt = 0; jt < NT; ++jt) acc[jt] = blk_d4{0.0, 0.0, 0.0, 0.0};
+  // the short chains first in every k-step, so that the last products of the call belong to three different chains
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+    for (int jt = NT - 1; jt >= 0; --jt)
+      if (ks >= 4 * jt) acc[jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], b[jt][ks], acc[jt], 0, 0, 0);
 #pragma unroll
   for (int jt = 0; jt < NT; ++jt) {
     const int col = 16 * jt + lrow;
@@ -423,7 +667,7 @@ __device__ void blk_backsub(const double *__restrict__ ws, int T, double *buf, d
         if (q & 1) s1 = fma(r < 2 * D ? -l : 0.0, yv, s1);
         else s0 = fma(r < 2 * D ? -l : 0.0, yv, s0);
       }
-      part[p * 64 + j] = s0 + s1;
+      if (p < 4) part[p * 64 + j] = s0 + s1;      // the product is split over four waves; further waves only stage panels
     }
     __syncthreads();
     if (tid < D) {
@@ -452,8 +696,23 @@ __device__ void blk_backsub(const double *__restrict__ ws, int T, double *buf, d
 //                         fetched and, after the barrier, written into the three freed buffers
 //   phase 2   all:        L10(t) = S10 U', then S11 -= L10 L10'   (-> S00 of step t+1)
 // Buffers: b00, b10, b11 (window of step t) and p0, p1, p2 = U, L10, S20 -> L20 of step t-1, then block row t+2.
+#ifndef TRAJ_DEFERRED_WAVES
+#ifndef TRAJ_W1_JOBS
+#define TRAJ_W1_JOBS 2            // M1 panel row tiles (of NT) formed by pivot wave 1 in its waiting gaps
+#endif
+#ifndef TRAJ_W1_L20
+#define TRAJ_W1_L20 1             // L20 row tiles formed by pivot wave 1 (when there are three)
+#endif
+#ifndef TRAJ_W1_M2
+#define TRAJ_W1_M2 0              // M2 panel row tiles formed by pivot wave 1
+#endif
+#define TRAJ_DEFERRED_WAVES 2     // waves of the deferred team (beside the two pivot waves); 4 was measured: the kernel
+                                  // then has two waves per SIMD, spills 68 VGPRs and the scalar chain shares its FP64 pipe: 40.6 ms
+#endif
+static constexpr int kBlkThreads = 64 * (2 + TRAJ_DEFERRED_WAVES);
+
 template <int D>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(kBlkThreads)
 traj_solve_blk_kernel(const TrajUtt *__restrict__ utts, int n, const double *__restrict__ Qall,
                       const int64_t *__restrict__ mhat_all, const double *__restrict__ g_all, double *__restrict__ ws_all,
                       int64_t ws_stride, int *__restrict__ status) {
@@ -461,9 +720,13 @@ traj_solve_blk_kernel(const TrajUtt *__restrict__ utts, int n, const double *__r
   constexpr int D2 = 2 * D, DP = C::DP, LS = C::LS, NT = C::NT, BUF = C::BUF;
   constexpr size_t PAN = C::PAN;
   constexpr int NLOW = NT * (NT + 1) / 2;
-  constexpr int NDW = 2, NDT = 64 * NDW;   // deferred team
+  constexpr int NPW = 2, NDW = TRAJ_DEFERRED_WAVES, NDT = 64 * NDW, W1J = TRAJ_W1_JOBS < BlkCfg<D>::NT ? TRAJ_W1_JOBS : BlkCfg<D>::NT;
+  constexpr int W1L = BlkCfg<D>::NT >= 3 ? TRAJ_W1_L20 : 0, W1M2 = TRAJ_W1_M2 < BlkCfg<D>::NT ? TRAJ_W1_M2 : BlkCfg<D>::NT, W1N = W1L + W1J + W1M2;
+  static_assert(W1L == 0 || D / 16 >= W1L, "pivot wave 1 does not form the L20 row tile that holds the rhs row");   // pivot pair, deferred team
+  constexpr int NW = NPW + NDW, NTHR = 64 * NW;
   constexpr int VW = (D % 2 == 0) ? 2 : 1;                 // elements per access: 16-byte LDS / global accesses when D is even
   constexpr int NIT = (D * D / VW + NDT - 1) / NDT;        // element groups per thread
+  static_assert(Pv2<D>::SCRATCH <= BlkCfg<D>::RING, "pivot wave 1's scratch tiles live in the ring area");
   constexpr int RT = D / 16;             // row tile that holds the rhs row D
   extern __shared__ __attribute__((aligned(16))) double blk_sm[];
   double *const sm = blk_sm;             // 16-byte LDS accesses in the pivot phase
@@ -481,7 +744,7 @@ traj_solve_blk_kernel(const TrajUtt *__restrict__ utts, int n, const double *__r
   // per-thread element tables of the deferred team (the same D x D elements every block step): LDS offset, offset in
   // a mixture's Q matrix, offset in a panel block -- a lone wave pays ~6 cycles per VALU instruction, so index
   // arithmetic is kept out of the step loop
-  const int dt = tid - 64 * (4 - NDW);
+  const int dt = tid - 64 * NPW;
   int eo[NIT], eq[NIT];
 #pragma unroll
   for (int k = 0; k < NIT; ++k) {
@@ -503,11 +766,11 @@ traj_solve_blk_kernel(const TrajUtt *__restrict__ utts, int n, const double *__r
       flags[0] = 0;
       flags[1] = 0;
     }
-    for (int e = tid; e < C::CB + C::RING; e += 256) cbu[e] = 0.0;   // cbu and the ring (stale tags of the previous utterance)
+    for (int e = tid; e < C::CB + C::RING; e += NTHR) cbu[e] = 0.0;   // cbu and the ring (stale tags of the previous utterance)
     // p0, p1, p2 receive only D x D elements (+ the rhs row) per step: their padding stays zero from here on
-    for (int e = tid; e < 3 * BUF; e += 256) p0[e] = 0.0;
-    blk_assemble<D>(nullptr, nullptr, b00, 0, T, mh, g, Qall, tid, 256);
-    blk_assemble<D>(nullptr, b10, b11, 1, T, mh, g, Qall, tid, 256);
+    for (int e = tid; e < 3 * BUF; e += NTHR) p0[e] = 0.0;
+    blk_assemble<D>(nullptr, nullptr, b00, 0, T, mh, g, Qall, tid, NTHR);
+    blk_assemble<D>(nullptr, b10, b11, 1, T, mh, g, Qall, tid, NTHR);
     __syncthreads();
     BLK_PROF_T0();
 
@@ -515,18 +778,47 @@ traj_solve_blk_kernel(const TrajUtt *__restrict__ utts, int n, const double *__r
       // ---------------- phase 1 ----------------
       ev_t vd[NIT], v1[NIT], v2[NIT];     // block row t+2 of the stencil, written to p0, p1, p2 during phase 2 (deferred team)
       double rv = 0.0;
-      if (wave < 4 - NDW) {
+#ifndef TRAJ_PIVOT_COLUMNWISE
+      // Pivot wave 1's share of the deferred work on step t-1, run in the gaps in which it waits for wave 0's scalar chains:
+      // W1L row tiles of L20 (so that each of the three waves forms one at D = 40), W1J row tiles of the M1 panel (they
+      // read U(t-1) and L10(t-1) only) and W1M2 row tiles of the M2 panel (after the L20 tiles of all waves are complete).
+      int *mid = reinterpret_cast<int *>(cbu) + 2;
+      auto w1_job = [&](int j) {
+        double *pan1 = ws + (size_t)(t - 1) * PAN;
+        if (j < W1L) {
+          blk_trsm_rowtile<D>(p2, p0, j, lane);
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+          if (lane == 0) __hip_atomic_fetch_add(mid, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        } else if (j < W1L + W1J) {
+          blk_lu_rowtile_to_panel<D>(p1, p0, j - W1L, D + 1, pan1, lane);
+        } else {
+          pv2_wait(mid, (NDW + W1L) * t);
+          blk_lu_rowtile_to_panel<D>(p2, p0, j - W1L - W1J, D, pan1 + (D + 1) * D, lane);
+        }
+      };
+#endif
+      if (wave < NPW) {
         if (t < T) {
+#ifndef TRAJ_PIVOT_COLUMNWISE
+          if (wave == 0) pv2_wave0<D>(b00, reinterpret_cast<int *>(cbu), 16 * t, lane, &bad);
+          else pv2_wave1<D>(b00, ring, reinterpret_cast<int *>(cbu), 16 * t, lane, t >= 1 ? W1N : 0, W1L, w1_job);
+#else
           if (wave == 0) blk_pivot_s<D>(b00, ring, t * D, lane, &bad);
           else blk_pivot_u<D>(b00, ring, t * D, cbu, lane);
+#endif
           BLK_PROF_AT(3, 0);
           BLK_PROF_AT(4, 64);
         } else {
+#ifndef TRAJ_PIVOT_COLUMNWISE
+          if (wave == 1)                  // wave 1's share of the last step's deferred work
+            for (int j = 0; j < W1N; ++j) w1_job(j);
+#else
           __syncthreads();
+#endif
         }
         __syncthreads();                  // end of phase 1
       } else {
-        const int dw = wave - (4 - NDW);
+        const int dw = wave - NPW;
         // mixtures of block rows t+1, t+2, t+3 (clamped), loaded before the products so that the stencil loads below
         // do not wait for them
         const int a = t + 2;
@@ -535,7 +827,7 @@ traj_solve_blk_kernel(const TrajUtt *__restrict__ utts, int n, const double *__r
         const int64_t mxa = mh[ac], mxm = mh[am], mxp = mh[ap];
         const bool defer = t >= 1;
         if (defer) {                      // L20(t-1) = S20 U' in place; row D of S20 := r0(t-1) -> row D of L20 = z0
-          for (int it = dw; it < NT; it += NDW) {
+          for (int it = W1L + dw; it < NT; it += NDW) {
             if (it == RT) {
               if (lane < DP) p2[D * LS + lane] = (lane < D) ? p0[D * LS + lane] : 0.0;
               __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -545,16 +837,26 @@ traj_solve_blk_kernel(const TrajUtt *__restrict__ utts, int n, const double *__r
             blk_trsm_rowtile<D>(p2, p0, it, lane);
           }
         }
-        BLK_PROF_AT(8, 128);
+        BLK_PROF_AT(8, 64 * NPW);
+#ifndef TRAJ_PIVOT_COLUMNWISE
+        // The row groups below read every wave's L20 tiles: the deferred waves meet on an arrival counter in LDS (the pivot
+        // pair does not take part, so neither side waits for the other in the middle of the phase).
+        if (defer) {
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+          if (lane == 0) __hip_atomic_fetch_add(mid, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          pv2_wait(mid, (NDW + W1L) * t);
+        }
+#else
         __syncthreads();
-        BLK_PROF_AT(9, 128);
+#endif
+        BLK_PROF_AT(9, 64 * NPW);
         if (defer) {                      // S21 -= L20 L10' (all tiles), S22 -= L20 L20' (lower tiles), row group by row group
           for (int it = 0; it < NT; ++it) {
             if ((it % NDW) == dw) blk_update_rowgroup<D>(b10, p2, p1, it, NT, lane);
             if (((it + 1) % NDW) == dw) blk_update_rowgroup<D>(b11, p2, p2, it, it + 1, lane);
           }
         }
-        BLK_PROF_AT(6, 128);
+        BLK_PROF_AT(6, 64 * NPW);
         // Block row a = t+2 of the stencil.  Every load is unconditional on a clamped address (a select on a loaded
         // value would make the wave wait for each load in turn); masks are applied when the operands are combined.
         ev_t q0[NIT], q1[NIT], q2[NIT], q3[NIT], q4[NIT];
@@ -572,16 +874,24 @@ traj_solve_blk_kernel(const TrajUtt *__restrict__ utts, int n, const double *__r
         // the right-hand side row (lanes 0..D-1 of the team): r_a = gs(a) + gd(a-1)/2 - gd(a+1)/2
         const int jr = dt < D ? dt : D - 1;
         const double g0 = g[(size_t)ac * D2 + jr], g1 = g[(size_t)am * D2 + D + jr], g2 = g[(size_t)ap * D2 + D + jr];
-        BLK_PROF_AT(10, 128);
+        BLK_PROF_AT(10, 64 * NPW);
         if (defer) {   // panel t-1 -> HBM: M1 = L10 U (row D: h = U' z0) and M2 = L20 U, formed here so that the back
                        // substitution is one product per step on a 2/3-size panel (reads only: no barrier needed)
           double *pan = ws + (size_t)(t - 1) * PAN;
+#ifndef TRAJ_PIVOT_COLUMNWISE
+          int cnt = 0;                    // the row tiles pivot wave 1 does not form (see w1_job)
+          for (int j = W1J; j < NT; ++j, ++cnt)
+            if (cnt % NDW == dw) blk_lu_rowtile_to_panel<D>(p1, p0, j, D + 1, pan, lane);
+          for (int j = W1M2; j < NT; ++j, ++cnt)
+            if (cnt % NDW == dw) blk_lu_rowtile_to_panel<D>(p2, p0, j, D, pan + (D + 1) * D, lane);
+#else
           for (int job = dw; job < 2 * NT; job += NDW) {
             if (job < NT) blk_lu_rowtile_to_panel<D>(p1, p0, job, D + 1, pan, lane);
             else blk_lu_rowtile_to_panel<D>(p2, p0, job - NT, D, pan + (D + 1) * D, lane);
           }
+#endif
         }
-        BLK_PROF_AT(11, 128);
+        BLK_PROF_AT(11, 64 * NPW);
         const double w4 = hasp ? 0.25 : 0.0, w2 = hasp ? 0.5 : 0.0, lv = live ? 1.0 : 0.0;
 #pragma unroll
         for (int k = 0; k < NIT; ++k) {
@@ -590,7 +900,7 @@ traj_solve_blk_kernel(const TrajUtt *__restrict__ utts, int n, const double *__r
           v2[k] = lv * (-0.25 * q3[k]);                           // -Qdd(a-1)/4
         }
         rv = lv * ((g0 + 0.5 * g1) - w2 * g2);
-        BLK_PROF_AT(7, 128);
+        BLK_PROF_AT(7, 64 * NPW);
         __syncthreads();                  // end of phase 1: every read of p0, p1, p2 is done
       }
       BLK_PROF(0);
@@ -617,16 +927,41 @@ traj_solve_blk_kernel(const TrajUtt *__restrict__ utts, int n, const double *__r
         }
         blk_trsm_rowtile<D>(b10, b00, wave, lane);
       }
-      if (wave == 3 || (wave == 2 && NT <= 2)) write_row(0, NIT);
+      // deferred waves that form no L10 row tile write their stencil values now, the others after the S11 update
+      if (wave >= NPW && wave >= NT) write_row(0, NIT);
       __syncthreads();
       BLK_PROF(1);
-      for (int job = wave; job < NLOW; job += 4) {      // S11 -= L10 L10' (lower tiles) -> S00 of the next step
+#ifndef TRAJ_PIVOT_COLUMNWISE
+      // S11 -= L10 L10' (lower tiles) -> S00 of the next step.  Wave 0 forms tile (0,0) and goes straight on to the scalar
+      // chain of the next step's first diagonal block (all it needs); the other waves share the remaining tiles and meet on
+      // an arrival counter: wave 1's trailing updates and the deferred team need them (and the stencil rows) complete,
+      // the chain does not.  This takes the S11 update off the critical path of the factorisation.
+      if (wave == 0) {
+        blk_update_tile<D>(b11, b10, b10, 0, 0, lane);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      } else {
+        for (int job = wave; job < NLOW; job += NW - 1) {
+          int q = job, it = 0;
+          while (q > it) { q -= it + 1; ++it; }
+          blk_update_tile<D>(b11, b10, b10, it, q, lane);
+        }
+        if (wave >= NPW && wave < NT) write_row(0, NIT);
+        int *s11 = reinterpret_cast<int *>(cbu) + 3;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) __hip_atomic_fetch_add(s11, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        pv2_wait(s11, (NW - 1) * (t + 1));
+      }
+#else
+      for (int job = wave; job < NLOW; job += NW) {     // S11 -= L10 L10' (lower tiles) -> S00 of the next step
         int q = job, it = 0;
         while (q > it) { q -= it + 1; ++it; }
         blk_update_tile<D>(b11, b10, b10, it, q, lane);
       }
-      if (wave == 2 && NT > 2) write_row(0, NIT);
+      if (wave >= NPW && wave < NT) write_row(0, NIT);
       __syncthreads();
+#endif
       BLK_PROF(2);
       {   // the window moves by one block
         double *f0 = p0, *f1 = p1;
