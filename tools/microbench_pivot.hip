@@ -1,5 +1,6 @@
-// microbench_pivot.hip -- cycles per column of the blocked trajectory solver's pivot waves (blk_pivot_s / blk_pivot_u of
-// voiceconversion.jl_amd/csrc/traj_solve_blk.hpp) run alone on one CU.
+// microbench_pivot.hip -- counts (s_memtime ticks, ~1.27 per shader cycle) per pivot column of the blocked trajectory
+// solver's scalar chain (pv2_wave0 of voiceconversion.jl_amd/csrc/traj_solve_blk.hpp) run alone: the hand-over
+// counter is preset so that no wait blocks.
 // build: hipcc -O3 -std=c++17 --offload-arch=gfx950 -I voiceconversion.jl_amd/csrc tools/microbench_pivot.hip -o tools/microbench_pivot
 #include <hip/hip_runtime.h>
 #include <cstdint>
@@ -20,43 +21,47 @@ __device__ __forceinline__ long long now() {
   return t;
 }
 template <int D>
-__global__ void __launch_bounds__(256) k(long long *out, int mode) {
+__global__ void __launch_bounds__(64) k(long long *out, double *chk) {
   using C = BlkCfg<D>;
   extern __shared__ __attribute__((aligned(16))) double msm[];
-  double *b00 = msm, *ring = msm + C::BUF, *cbu = ring + C::RING;
-  int *flags = reinterpret_cast<int *>(cbu + 64);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int i = tid; i < C::BUF; i += 256) {
-    const int r = i / C::LS, c = i % C::LS;
-    b00[i] = (r == c) ? 50.0 + r : 1.0 / (1.0 + r + c);    // SPD (diagonally dominant)
-  }
-  if (tid == 0) flags[0] = flags[1] = 0;
-  for (int i = tid; i < C::RING + 64; i += 256) ring[i] = 0.0;
-  __syncthreads();
-  long long t0 = now();
-  for (int rep = 0; rep < 8; ++rep) {
-    if (wave == 0) blk_pivot_s<D>(b00, ring, rep * D, lane, flags);
-    else if (wave == 1 && mode >= 1) blk_pivot_u<D>(b00, ring, rep * D, cbu, lane);
-    else __syncthreads();
+  double *b00 = msm;
+  int *flags = reinterpret_cast<int *>(msm + C::BUF);
+  const int lane = threadIdx.x;
+  __shared__ int bad;
+  long long total = 0;
+  for (int rep = 0; rep < 9; ++rep) {
+    for (int i = lane; i < C::BUF; i += 64) {
+      const int r = i / C::LS, c = i % C::LS;
+      b00[i] = (r == c) ? 50.0 + r : 1.0 / (1.0 + r + c);    // SPD (diagonally dominant); only the diagonal tiles are used
+    }
+    if (lane == 0) flags[0] = 1 << 30;
+    __syncthreads();
+    const long long t0 = now();
+    pv2_wave0<D, false>(b00, flags, 0, lane, &bad);
+    const long long t1 = now();
+    if (rep > 0) total += t1 - t0;
     __syncthreads();
   }
-  long long t1 = now();
-  if (lane == 0) out[wave] = (t1 - t0) / (8 * D);
+  if (lane == 0) out[0] = total / (8 * D);
+  if (lane < 16) chk[lane] = b00[lane * C::LS + (lane >> 1)];     // U_00 entries, for a look at the values
 }
 }  // namespace vcmi
 int main() {
-  long long *d, h[4];
+  long long *d, h[1];
+  double *chk, hc[16];
   (void)hipMalloc(&d, sizeof(h));
+  (void)hipMalloc(&chk, sizeof(hc));
   constexpr int D = 40;
-  const size_t shm = (vcmi::BlkCfg<D>::BUF + vcmi::BlkCfg<D>::RING + 64 + 8) * 8;
+  const size_t shm = (vcmi::BlkCfg<D>::BUF + 8) * 8;
   auto kern = vcmi::k<D>;
   (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-  for (int mode = 0; mode < 2; ++mode) {
-    (void)hipMemset(d, 0, sizeof(h));
-    for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL(kern, dim3(1), dim3(256), shm, 0, d, mode);
-    (void)hipDeviceSynchronize();
-    (void)hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
-    printf("%s: cycles per pivot column: wave S %lld, wave U %lld (idle waves %lld %lld)\n", mode ? "S + U" : "S alone", h[0], h[1], h[2], h[3]);
-  }
+  for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL(kern, dim3(1), dim3(64), shm, 0, d, chk);
+  (void)hipDeviceSynchronize();
+  (void)hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
+  (void)hipMemcpy(hc, chk, sizeof(hc), hipMemcpyDeviceToHost);
+  printf("scalar chain alone: %lld counts per pivot column (D = %d: %d blocks incl. tile load / store)\n", h[0], D, (D + 15) / 16);
+  printf("U_00 sample:");
+  for (int i = 0; i < 16; i += 3) printf(" %.12g", hc[i]);
+  printf("\n");
   return 0;
 }

@@ -30,10 +30,8 @@ struct BlkCfg {
   static constexpr int KS = (D + 3) / 4;                // k-steps of a product over the D columns
   static constexpr int LS = DP + 2;                     // row stride in doubles: LS/2 odd -> MFMA operand reads conflict-free
   static constexpr int BUF = DP * LS;                   // doubles per block buffer
-  static constexpr int NB8 = (D + 7) / 8;               // 8 x 8 lane-grid tiles per dimension (pivot phase)
-  static constexpr int CB = 64;                         // wave U's published column of U', permuted
-  static constexpr int RING = D * 64;                   // wave S's published columns: one 64-double slot each (entries 6, 7 of a lane group: pivot, tag)
-  static constexpr int JOINCOL = D < 11 ? D - 1 : 9;   // pivot column after which the pivot waves join the mid-phase barrier
+  static constexpr int CB = 64;                         // counters of the workgroup (ints): [0] pivot stage, [2] L20 arrivals, [3] S11 arrivals
+  static constexpr int RING = D * 64;                   // pivot wave 1's scratch tiles (Pv2<D>::SCRATCH doubles are used)
   static constexpr size_t PAN = (size_t)(2 * D + 1) * D;   // panel doubles per block step: M1 = L10 U (D+1,D) incl. h = U' z0, M2 = L20 U (D,D)
   static constexpr size_t WORK = 6 * (size_t)BUF > 3 * PAN ? 6 * (size_t)BUF : 3 * PAN;   // six window buffers / three staged panels
   static constexpr size_t lds_doubles = WORK + CB + RING + 2 * D + 768 + 2;
@@ -97,177 +95,21 @@ __device__ void blk_assemble(double *Bm2, double *Bm1, double *Bd, int a, int T,
   }
 }
 
-// Pivot phase, TWO waves.  B00 rows/cols < D hold S00 (lower triangle valid); on return they hold U = chol(S00)^-1
-// (lower triangular, zeros above).  Both waves use an 8 x 8 lane grid: lane (ti,tj) owns elements i = ti + 8 ka,
-// j = tj + 8 kb of its matrix.
-//   wave S (blk_pivot_s): right-looking Cholesky of S00, tiles kb <= ka.  Per column the owners publish it -- rows
-//     i > c, finished rows as zeros -- into slot c of a ring in LDS, in a permuted order (row i at (i%8)*8 + i/8) so
-//     that the values a lane needs are contiguous (16-byte LDS accesses); the pivot itself travels by v_readlane, so
-//     its rsqrt chain runs while the column is on its way through LDS.  Then one lane bumps a counter in LDS.
-//   wave U (blk_pivot_u): the identity rows of the augmented matrix [S00; I], tiles kb >= ka: the same column
-//     operations turn them into U' = L00^-T.  It follows wave S through the ring (LDS operations of a wave execute in
-//     order, so a column is visible before the counter that announces it) and leaves row c of U in B00 after column c.
-// A lone wave issues one FP64 instruction per 5.6 cycles (10 if dependent) and sees ~84 cycles per LDS round trip
-// (tools/microbench_wave.hip): a column costs ~670 cycles in one wave; split like this each wave carries half.
-// Both waves join one workgroup barrier on the way (after column JOINCOL): the two other waves use it to order
-// their deferred work of the previous block step.
 typedef double pv_d2 __attribute__((ext_vector_type(2)));
 
-template <int D>
-__device__ void blk_pivot_s(const double *B00, double *ring, int fbase, int lane, int *bad) {
-  using C = BlkCfg<D>;
-  constexpr int NB = C::NB8, LS = C::LS, NQ = (NB + 1) / 2;
-  const int ti = lane >> 3, tj = lane & 7;
-  double s[NB][NB];
-#pragma unroll
-  for (int ka = 0; ka < NB; ++ka)
-#pragma unroll
-    for (int kb = 0; kb < NB; ++kb) {
-      const int i = ti + 8 * ka, j = tj + 8 * kb;
-      s[ka][kb] = (kb <= ka && i < D && j < D) ? B00[i * LS + j] : 0.0;
-    }
-  bool notpd = false;
-  auto phase = [&](auto kc_tag, int c_lo, int c_hi) {
-    constexpr int KC = decltype(kc_tag)::value;
-    constexpr int Q0 = KC / 2;
-#pragma nounroll
-    for (int c = c_lo; c < c_hi; ++c) {
-      const int oc = c & 7;
-      const double pvl = s[KC][KC];
-      const double piv = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(pvl), 9 * oc),
-                                          __builtin_amdgcn_readlane(__double2loint(pvl), 9 * oc));
-      pv_d2 *slot_w = reinterpret_cast<pv_d2 *>(ring + c * 64 + ti * 8);
-      const pv_d2 *slot_c = reinterpret_cast<const pv_d2 *>(ring + c * 64 + tj * 8);
-      if (tj == oc) {       // owners publish column c: rows i > c, finished rows as 0
-#pragma unroll
-        for (int q = Q0; q < NQ; ++q) {
-          const int k0 = 2 * q, k1 = 2 * q + 1;
-          pv_d2 v;
-          v.x = (k0 >= KC && ti + 8 * k0 > c) ? s[k0][KC] : 0.0;
-          v.y = (k1 < NB && ti + 8 * k1 > c) ? s[k1 < NB ? k1 : 0][KC] : 0.0;
-          slot_w[q] = v;
-        }
-        // the pivot and the column's sequence tag, in a later instruction than the column itself (the LDS executes a
-        // wave's operations in order): wave U polls the tag of lane group ti = 0
-        slot_w[3] = pv_d2{piv, (double)(fbase + c + 1)};
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      double lr_[2 * NQ], lc_[2 * NQ];
-#pragma unroll
-      for (int q = Q0; q < NQ; ++q) {
-        const pv_d2 x = slot_w[q], y = slot_c[q];
-        lr_[2 * q] = x.x;
-        lr_[2 * q + 1] = x.y;
-        lc_[2 * q] = y.x;
-        lc_[2 * q + 1] = y.y;
-      }
-      notpd |= !(piv > 0.0);
-      const double dinv = traj_rsqrt(piv), winv = dinv * dinv;
-      // a_ij -= (a_ic / p) a_jc over the live tiles; finished rows / columns were published as zeros
-#pragma unroll
-      for (int ka = KC; ka < NB; ++ka) {
-        const double f = lr_[ka] * winv;
-#pragma unroll
-        for (int kb = KC; kb <= ka; ++kb) s[ka][kb] = fma(-f, lc_[kb], s[ka][kb]);
-      }
-      __builtin_amdgcn_wave_barrier();
-      if (c == C::JOINCOL) __syncthreads();    // the other waves' L20 products are complete (see the kernel)
-    }
-  };
-  phase(std::integral_constant<int, 0>{}, 0, D < 8 ? D : 8);
-  if constexpr (NB > 1) phase(std::integral_constant<int, 1>{}, 8, D < 16 ? D : 16);
-  if constexpr (NB > 2) phase(std::integral_constant<int, 2>{}, 16, D < 24 ? D : 24);
-  if constexpr (NB > 3) phase(std::integral_constant<int, 3>{}, 24, D < 32 ? D : 32);
-  if constexpr (NB > 4) phase(std::integral_constant<int, 4>{}, 32, D < 40 ? D : 40);
-  if constexpr (NB > 5) phase(std::integral_constant<int, 5>{}, 40, D < 48 ? D : 48);
-  if (notpd && lane == 0) *bad = 1;
-}
-
-template <int D>
-__device__ void blk_pivot_u(double *B00, double *ring, int fbase, double *cbu,
-                            int lane) {
-  using C = BlkCfg<D>;
-  constexpr int NB = C::NB8, LS = C::LS, DP = C::DP, NQ = (NB + 1) / 2;
-  const int ti = lane >> 3, tj = lane & 7;
-  double u[NB][NB];
-#pragma unroll
-  for (int ka = 0; ka < NB; ++ka)
-#pragma unroll
-    for (int kb = 0; kb < NB; ++kb) u[ka][kb] = (ka == kb && ti == tj && ti + 8 * ka < D) ? 1.0 : 0.0;
-  pv_d2 *cbu_w = reinterpret_cast<pv_d2 *>(cbu + ti * 8);
-  const double *cbu_row = cbu + (lane & 7) * 8 + (lane >> 3);
-  auto phase = [&](auto kc_tag, int c_lo, int c_hi) {
-    constexpr int KC = decltype(kc_tag)::value;
-    constexpr int Q0 = KC / 2;
-#pragma nounroll
-    for (int c = c_lo; c < c_hi; ++c) {
-      const int oc = c & 7;
-      if (tj == oc) {       // owners publish column c of U': rows i <= c (needs nothing from wave S)
-#pragma unroll
-        for (int q = 0; q <= Q0; ++q) {
-          const int k0 = 2 * q, k1 = 2 * q + 1;
-          pv_d2 v;
-          v.x = (ti + 8 * k0 <= c) ? u[k0][KC] : 0.0;
-          v.y = (k1 <= KC && ti + 8 * k1 <= c) ? u[k1 <= KC ? k1 : 0][KC] : 0.0;
-          cbu_w[q] = v;
-        }
-      }
-      {                                          // column c of S00 published?  (its tag is unique per block step and column)
-        unsigned long long *tagp = reinterpret_cast<unsigned long long *>(ring + c * 64 + 7);
-        const unsigned long long want = (unsigned long long)__double_as_longlong((double)(fbase + c + 1));
-        while (__hip_atomic_load(tagp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != want) __builtin_amdgcn_s_sleep(1);
-      }
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-      const pv_d2 *slot_c = reinterpret_cast<const pv_d2 *>(ring + c * 64 + tj * 8);
-      const double piv = ring[c * 64 + 6];
-      double lc_[2 * NQ], ur_[2 * NQ];
-#pragma unroll
-      for (int q = Q0; q < NQ; ++q) {
-        const pv_d2 y = slot_c[q];
-        lc_[2 * q] = y.x;
-        lc_[2 * q + 1] = y.y;
-      }
-#pragma unroll
-      for (int q = 0; q <= Q0; ++q) {
-        const pv_d2 x = cbu_w[q];
-        ur_[2 * q] = x.x;
-        ur_[2 * q + 1] = x.y;
-      }
-      const double urow = (lane <= c) ? *cbu_row : 0.0;
-      const double dinv = traj_rsqrt(piv), winv = dinv * dinv;
-#pragma unroll
-      for (int ka = 0; ka <= KC; ++ka) {
-        const double f = ur_[ka] * winv;
-#pragma unroll
-        for (int kb = KC; kb < NB; ++kb) u[ka][kb] = fma(-f, lc_[kb], u[ka][kb]);
-      }
-      if (lane < DP) B00[c * LS + lane] = urow * dinv;     // row c of U = column c of U', final
-      __builtin_amdgcn_wave_barrier();
-      if (c == C::JOINCOL) __syncthreads();
-    }
-  };
-  phase(std::integral_constant<int, 0>{}, 0, D < 8 ? D : 8);
-  if constexpr (NB > 1) phase(std::integral_constant<int, 1>{}, 8, D < 16 ? D : 16);
-  if constexpr (NB > 2) phase(std::integral_constant<int, 2>{}, 16, D < 24 ? D : 24);
-  if constexpr (NB > 3) phase(std::integral_constant<int, 3>{}, 24, D < 32 ? D : 32);
-  if constexpr (NB > 4) phase(std::integral_constant<int, 4>{}, 32, D < 40 ? D : 40);
-  if constexpr (NB > 5) phase(std::integral_constant<int, 5>{}, 40, D < 48 ? D : 48);
-}
-
 // ------------------------------------------------------------------------------------------------
-// Pivot phase, version 2: blocked.  The column-by-column scheme above pays ~600 cycles per pivot column whatever the
-// amount of arithmetic, because every column is published through LDS and read back (write -> read round trip, tag
-// polling) before the next one can start: 40 columns = 24k cycles of a 32k-cycle block step.  Here S00 is processed in
-// 16 x 16 diagonal blocks:
-//   wave 0, scalar chain per diagonal block: ONE LANE OWNS A WHOLE ROW of the block (16 values of the block and 16 of
-//     the identity that becomes its inverse) and a pivot column is applied with v_fmac_f64_dpp row_newbcast -- the
-//     multiply-add reads row c's value straight out of lane c's register, so the chain never touches LDS:
-//     pivot broadcast -> rsqrt -> multiplier -> 16 DPP multiply-adds, ~150-180 cycles per column;
+// Pivot phase, TWO waves, blocked.  B00 rows/cols < D hold S00 (lower tiles valid); on return they hold
+// U = chol(S00)^-1 (lower triangular, zeros above).  S00 is processed in 16 x 16 diagonal blocks:
+//   wave 0, scalar chain per diagonal block: ONE LANE OWNS A WHOLE ROW of the block and a pivot column is applied with
+//     v_fmac_f64_dpp row_newbcast -- the multiply-add reads row c's value straight out of lane c's register, so the
+//     chain never touches LDS: pivot broadcast -> reciprocal (hardware estimate + two Newton steps) -> multiplier ->
+//     DPP multiply-adds on the columns to its right and on the columns of the unit-lower inverse (each of the four
+//     16-lane groups keeps all of the block but only a quarter of the inverse's columns).  ~190 counts of s_memtime
+//     per column (tools/microbench_pivot.hip; one FP64 instruction issues per ~5 counts, tools/microbench_f64lat.hip);
+//     the column-by-column scheme of round 1, which published every column through LDS, paid ~600.
 //   wave 1, MFMA: the panel below a finished diagonal block  L_rk = A_rk U_kk'  and the rank-16 trailing update
-//     A_rc -= L_rk L_ck'  (the next diagonal tile first, so that wave 0 can go on), then U = L00^-1 block by block
-//     (U_rc = -U_rr sum_j L_rj U_jc), 16 x 16 x 16 products.
+//     A_rc -= L_rk L_ck'  (the next diagonal tile first, so that wave 0 can go on), then U = L00^-1 block row by block
+//     row (U_kc = -U_kk W_kc, W_kc = sum_j L_kj U_jc formed while wave 0 is busy with block k), 16 x 16 x 16 products.
 // The two waves hand over through counters in LDS.  Row D of the last tile row (the right-hand side living in the
 // tile padding) is never modified: L rows >= D are stored as zeros and U is written for rows < D only.
 // ------------------------------------------------------------------------------------------------
@@ -318,68 +160,71 @@ __device__ __forceinline__ void pv2_store(double *Tl, int ld, blk_d4 acc, double
 }
 
 // wave 0: the scalar chains of the diagonal blocks.  flags[0] counts finished stages of this block step (see pv2_wave1).
-template <int D>
+template <int D, bool kHandOver = true>      // kHandOver = false: no waiting for wave 1 (tools/microbench_pivot.hip)
 __device__ void pv2_wave0(double *B00, int *flags, int fbase, int lane, int *bad) {
   using C = BlkCfg<D>;
   using P = Pv2<D>;
   constexpr int LS = C::LS;
-  const int i = lane & 15;
+  const int i = lane & 15, g = lane >> 4;
   bool notpd = false;
 #pragma unroll 1
   for (int k = 0; k < P::NTD; ++k) {
-    if (k > 0) pv2_wait(flags, fbase + 2 * k);          // tile (k,k) has the updates of the blocks before it
+    if (kHandOver && k > 0) pv2_wait(flags, fbase + 2 * k);     // tile (k,k) has the updates of the blocks before it
     const int r0 = 16 * k, nb = (D - r0 < 16) ? D - r0 : 16;
-    double a[16], e[16];
+    // a[j]: row i of the block (all four 16-lane groups hold the same copy: the DPP broadcasts stay inside a group);
+    // e[q]: entry (i, 4q + g) of the unit-lower inverse -- its columns are independent, so each group keeps a quarter
+    double a[16], e[4];
+    // (a diagonal tile is updated as a whole by the MFMA products -- X X' is symmetric bit for bit -- so its upper
+    // triangle is as good as the lower one and row i is read as it lies: eight 16-byte loads)
+    {
+      const pv_d2 *row = reinterpret_cast<const pv_d2 *>(B00 + (r0 + i) * LS + r0);
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      const int rr = i >= j ? i : j, cc = i >= j ? j : i;     // the lower triangle holds the block
-      a[j] = (i < nb && j < nb) ? B00[(r0 + rr) * LS + r0 + cc] : ((i == j) ? 1.0 : 0.0);
-      e[j] = (i == j) ? 1.0 : 0.0;
+      for (int j = 0; j < 16; j += 2) {
+        const pv_d2 v = row[j / 2];
+        a[j] = (i < nb && j < nb) ? v.x : ((i == j) ? 1.0 : 0.0);
+        a[j + 1] = (i < nb && j + 1 < nb) ? v.y : ((i == j + 1) ? 1.0 : 0.0);
+      }
     }
-    double sc = 1.0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) e[q] = (i == 4 * q + g) ? 1.0 : 0.0;
+    double pvi = 1.0;                                       // the pivot of row i
 #pragma unroll
     for (int c = 0; c < 16; ++c) {
       if (c < nb) {                                        // wave-uniform
         double pv;
         asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(pv) : "v"(a[c]), "n"(c));
-        notpd |= !(pv > 0.0);
-        // 1/p for the multipliers (on the chain: hardware reciprocal + two Newton steps); 1/sqrt(p) only scales the
-        // finished row at the end (off the chain)
+        pvi = (i == c) ? pv : pvi;
+        // row i -= (a_ic / p) row c for the rows below c: 1/p by the hardware reciprocal and two Newton steps (the only
+        // arithmetic on the chain from one pivot to the next; 1/sqrt(p) scales the finished rows after the last column)
         double winv = __builtin_amdgcn_rcp(pv);
         winv = winv * fma(-pv, winv, 2.0);
         winv = winv * fma(-pv, winv, 2.0);
-        const double dinv = traj_rsqrt(pv);
-        const double m = (i > c) ? -(a[c] * winv) : 0.0;   // row i -= (a_ic / p) row c, for the rows below c
+        const double m = ((i > c) ? -a[c] : 0.0) * winv;
 #pragma unroll
         for (int j = c + 1; j < 16; ++j)
           asm volatile("v_fmac_f64_dpp %0, %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "+v"(a[j]) : "v"(m), "n"(c));
+        // columns 4q + g <= c of the inverse (for the others row c holds an exact zero: the product changes nothing)
 #pragma unroll
-        for (int j = 0; j <= c; ++j)
-          asm volatile("v_fmac_f64_dpp %0, %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "+v"(e[j]) : "v"(m), "n"(c));
-        sc = (i == c) ? dinv : sc;
+        for (int q = 0; q <= c / 4; ++q)
+          asm volatile("v_fmac_f64_dpp %0, %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "+v"(e[q]) : "v"(m), "n"(c));
       }
     }
-    // U_kk = D^-1/2 (unit-lower inverse): row i of the identity part scaled by 1/sqrt(p_i); zeros above the diagonal
-    if (lane < 16 && i < nb) {
+    // U_kk = D^-1/2 (unit-lower inverse): row i scaled by 1/sqrt(p_i); zeros above the diagonal
+    notpd |= !(pvi > 0.0);
+    if (i < nb) {
+      const double sc = traj_rsqrt(pvi);
 #pragma unroll
-      for (int j = 0; j < 16; ++j) B00[(r0 + i) * LS + r0 + j] = (j <= i) ? e[j] * sc : 0.0;
+      for (int q = 0; q < 4; ++q) B00[(r0 + i) * LS + r0 + 4 * q + g] = (4 * q + g <= i) ? e[q] * sc : 0.0;
     }
     pv2_signal(flags, fbase + 2 * k + 1, lane);
   }
-  if (notpd && lane == 0) *bad = 1;
+  if (__builtin_amdgcn_ballot_w64(notpd) != 0 && lane == 0) *bad = 1;      // any row's pivot
 }
 
 // wave 1: panels, trailing updates and the off-diagonal blocks of U on MFMA.  Stage counter flags[0] of block step
 // `fbase / 16`:  fbase + 2k + 1 = diagonal block k inverted (wave 0),  fbase + 2k + 2 = tile (k+1,k+1) updated (wave 1).
-// While wave 1 waits for a diagonal block it runs `job(0) .. job(njobs-1)` (independent pieces of the deferred team's
-// work on the previous block step).  The first `nfirst` jobs run before anything else (the deferred team waits for
-// them); then at most `TRAJ_W1_GAP` jobs per wait, re-checking the counter in between, so that a job never holds up
-// the chain for longer than its own length; what is left runs after the last product of the step.
-#ifndef TRAJ_W1_GAP
-#define TRAJ_W1_GAP 1
-#endif
-template <int D, class Job>
-__device__ void pv2_wave1(double *B00, double *scratch, int *flags, int fbase, int lane, int njobs, int nfirst, const Job &job) {
+template <int D>
+__device__ void pv2_wave1(double *B00, double *scratch, int *flags, int fbase, int lane) {
   using C = BlkCfg<D>;
   using P = Pv2<D>;
   constexpr int LS = C::LS, NTD = P::NTD, TS = P::TS;
@@ -387,17 +232,6 @@ __device__ void pv2_wave1(double *B00, double *scratch, int *flags, int fbase, i
   double *Ls = scratch, *Wt = scratch + P::NL * P::TILE;      // L tiles (r,k), r > k; W tiles of one block row
   auto tile = [&](int r, int c) { return B00 + 16 * r * LS + 16 * c; };
   auto rows_of = [&](int r) { return (D - 16 * r < 16) ? D - 16 * r : 16; };
-  int next_job = 0;
-  for (; next_job < nfirst && next_job < njobs; ++next_job) job(next_job);
-  auto wait_working = [&](int v, int budget) {
-    while (__hip_atomic_load(flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < v) {
-      if (next_job < njobs && budget > 0) {
-        job(next_job++);
-        --budget;
-      } else __builtin_amdgcn_s_sleep(1);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-  };
   auto wave_sync = [&]() {      // LDS stores of this wave -> loads by its other lanes
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -415,7 +249,7 @@ __device__ void pv2_wave1(double *B00, double *scratch, int *flags, int fbase, i
     for (int q = 0; q < 4; ++q) cp[4 * q * LS] = -acc[q];
   };
   for (int k = 0; k < NTD; ++k) {
-    wait_working(fbase + 2 * k + 1, k == 0 ? (nfirst > 0 ? 0 : 1) : TRAJ_W1_GAP);
+    pv2_wait(flags, fbase + 2 * k + 1);
     if (k + 1 < NTD) {
       // what wave 0 waits for: the panel tile below the block, L = A U_kk' (rows >= D stored as zeros), and the update
       // of the next diagonal tile
@@ -451,7 +285,6 @@ __device__ void pv2_wave1(double *B00, double *scratch, int *flags, int fbase, i
       wave_sync();
     }
   }
-  while (next_job < njobs) job(next_job++);
 }
 
 // The MFMA building blocks below share one shape: every LDS operand of the call is requested first (a few dozen
@@ -696,19 +529,34 @@ __device__ void blk_backsub(const double *__restrict__ ws, int T, double *buf, d
 //                         fetched and, after the barrier, written into the three freed buffers
 //   phase 2   all:        L10(t) = S10 U', then S11 -= L10 L10'   (-> S00 of step t+1)
 // Buffers: b00, b10, b11 (window of step t) and p0, p1, p2 = U, L10, S20 -> L20 of step t-1, then block row t+2.
-#ifndef TRAJ_DEFERRED_WAVES
-#ifndef TRAJ_W1_JOBS
-#define TRAJ_W1_JOBS 2            // M1 panel row tiles (of NT) formed by pivot wave 1 in its waiting gaps
-#endif
 #ifndef TRAJ_W1_L20
 #define TRAJ_W1_L20 1             // L20 row tiles formed by pivot wave 1 (when there are three)
 #endif
-#ifndef TRAJ_W1_M2
-#define TRAJ_W1_M2 0              // M2 panel row tiles formed by pivot wave 1
-#endif
 #define TRAJ_DEFERRED_WAVES 2     // waves of the deferred team (beside the two pivot waves); 4 was measured: the kernel
                                   // then has two waves per SIMD, spills 68 VGPRs and the scalar chain shares its FP64 pipe: 40.6 ms
+// Which wave runs job j of the deferred list (see the kernel) when the list is shared out statically.  At three tiles per
+// dimension (D = 32..46) by measured job lengths (tools/microbench_blkops.hip, counts: S21 row group 2.9k, S22 row
+// groups 2.9k / 2.0k / 1.4k, panel row tile 2.2k) and by when a wave becomes free: the deferred waves ~10k each, pivot
+// wave 1 (free after its last product) and pivot wave 0 (free after its last chain) ~4k each.
+template <int NT, int NPW, int NDW>
+__device__ constexpr int blk_job_owner(int j) {
+  if (NT == 3 && NDW == 2) {
+    //               S21 r0 r1 r2 | S22 r2 r1 r0 | M1 t0 t1 t2 | M2 t0 t1 t2
+#ifndef TRAJ_JOB_TABLE
+#define TRAJ_JOB_TABLE 0
 #endif
+#if TRAJ_JOB_TABLE == 0
+    constexpr int own[12] = {2, 3, 2, 3, 2, 3, 1, 1, 2, 3, 0, 0};
+#elif TRAJ_JOB_TABLE == 1
+    constexpr int own[12] = {2, 3, 2, 3, 2, 1, 2, 3, 3, 1, 0, 0};
+#else
+    constexpr int own[12] = {2, 3, 2, 3, 2, 3, 1, 2, 3, 1, 0, 0};
+#endif
+    return own[j];
+  }
+  return NPW + j % NDW;
+}
+
 static constexpr int kBlkThreads = 64 * (2 + TRAJ_DEFERRED_WAVES);
 
 template <int D>
@@ -720,9 +568,9 @@ traj_solve_blk_kernel(const TrajUtt *__restrict__ utts, int n, const double *__r
   constexpr int D2 = 2 * D, DP = C::DP, LS = C::LS, NT = C::NT, BUF = C::BUF;
   constexpr size_t PAN = C::PAN;
   constexpr int NLOW = NT * (NT + 1) / 2;
-  constexpr int NPW = 2, NDW = TRAJ_DEFERRED_WAVES, NDT = 64 * NDW, W1J = TRAJ_W1_JOBS < BlkCfg<D>::NT ? TRAJ_W1_JOBS : BlkCfg<D>::NT;
-  constexpr int W1L = BlkCfg<D>::NT >= 3 ? TRAJ_W1_L20 : 0, W1M2 = TRAJ_W1_M2 < BlkCfg<D>::NT ? TRAJ_W1_M2 : BlkCfg<D>::NT, W1N = W1L + W1J + W1M2;
-  static_assert(W1L == 0 || D / 16 >= W1L, "pivot wave 1 does not form the L20 row tile that holds the rhs row");   // pivot pair, deferred team
+  constexpr int NPW = 2, NDW = TRAJ_DEFERRED_WAVES, NDT = 64 * NDW;      // pivot pair, deferred team
+  constexpr int W1L = BlkCfg<D>::NT >= 3 ? TRAJ_W1_L20 : 0;
+  static_assert(W1L == 0 || D / 16 >= W1L, "pivot wave 1 does not form the L20 row tile that holds the rhs row");
   constexpr int NW = NPW + NDW, NTHR = 64 * NW;
   constexpr int VW = (D % 2 == 0) ? 2 : 1;                 // elements per access: 16-byte LDS / global accesses when D is even
   constexpr int NIT = (D * D / VW + NDT - 1) / NDT;        // element groups per thread
@@ -766,7 +614,7 @@ traj_solve_blk_kernel(const TrajUtt *__restrict__ utts, int n, const double *__r
       flags[0] = 0;
       flags[1] = 0;
     }
-    for (int e = tid; e < C::CB + C::RING; e += NTHR) cbu[e] = 0.0;   // cbu and the ring (stale tags of the previous utterance)
+    for (int e = tid; e < C::CB + C::RING; e += NTHR) cbu[e] = 0.0;   // the counters and wave 1's scratch tiles
     // p0, p1, p2 receive only D x D elements (+ the rhs row) per step: their padding stays zero from here on
     for (int e = tid; e < 3 * BUF; e += NTHR) p0[e] = 0.0;
     blk_assemble<D>(nullptr, nullptr, b00, 0, T, mh, g, Qall, tid, NTHR);
@@ -778,45 +626,62 @@ traj_solve_blk_kernel(const TrajUtt *__restrict__ utts, int n, const double *__r
       // ---------------- phase 1 ----------------
       ev_t vd[NIT], v1[NIT], v2[NIT];     // block row t+2 of the stencil, written to p0, p1, p2 during phase 2 (deferred team)
       double rv = 0.0;
-#ifndef TRAJ_PIVOT_COLUMNWISE
-      // Pivot wave 1's share of the deferred work on step t-1, run in the gaps in which it waits for wave 0's scalar chains:
-      // W1L row tiles of L20 (so that each of the three waves forms one at D = 40), W1J row tiles of the M1 panel (they
-      // read U(t-1) and L10(t-1) only) and W1M2 row tiles of the M2 panel (after the L20 tiles of all waves are complete).
-      int *mid = reinterpret_cast<int *>(cbu) + 2;
-      auto w1_job = [&](int j) {
-        double *pan1 = ws + (size_t)(t - 1) * PAN;
-        if (j < W1L) {
-          blk_trsm_rowtile<D>(p2, p0, j, lane);
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-          if (lane == 0) __hip_atomic_fetch_add(mid, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        } else if (j < W1L + W1J) {
-          blk_lu_rowtile_to_panel<D>(p1, p0, j - W1L, D + 1, pan1, lane);
-        } else {
-          pv2_wait(mid, (NDW + W1L) * t);
-          blk_lu_rowtile_to_panel<D>(p2, p0, j - W1L - W1J, D, pan1 + (D + 1) * D, lane);
-        }
+      // The deferred work on step t-1.  First L20(t-1) = S20 U' in place, one row tile per wave where there are three
+      // (W1L: pivot wave 1 forms tile 0 while it waits for wave 0's first chain); the waves that formed tiles meet on the
+      // arrival counter `mid` (the pivot pair is not held up by it).  Everything after that -- the S21 / S22 row groups
+      // and the row tiles of the panel -- is a list of independent jobs shared out by blk_job_owner: most to the
+      // deferred waves, the rest to wave 0 after the last chain of the step and to wave 1 after its last product (one
+      // wave alone runs these at ~90 % of the FP64 MFMA rate, so what matters is that no SIMD idles).  A queue in LDS
+      // from which the waves took jobs as they became free was measured too: 29.0 ms against 26.6 ms, the loop over
+      // run-time job numbers costs more than the balance gains.
+      const bool defer = t >= 1;
+      int *const mid = reinterpret_cast<int *>(cbu) + 2;
+      auto mid_arrive = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) __hip_atomic_fetch_add(mid, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       };
-#endif
+      auto l20_rowtile = [&](int it) {    // row D of S20 := r0(t-1) -> row D of L20 = z0
+        if (it == RT) {
+          if (lane < DP) p2[D * LS + lane] = (lane < D) ? p0[D * LS + lane] : 0.0;
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        blk_trsm_rowtile<D>(p2, p0, it, lane);
+      };
+      // jobs, the long ones first: S21 -= L20 L10' by row group (NT tiles each), S22 -= L20 L20' by row group (lower
+      // tiles), then the panel of step t-1 -> HBM: M1 = L10 U (row D: h = U' z0) and M2 = L20 U by row tile, formed here
+      // so that the back substitution is one product per step on a 2/3-size panel
+      auto run_job = [&](int j) {
+        double *pan = ws + (size_t)(t - 1) * PAN;
+        if (j < NT) blk_update_rowgroup<D>(b10, p2, p1, j, NT, lane);
+        else if (j < 2 * NT) blk_update_rowgroup<D>(b11, p2, p2, 2 * NT - 1 - j, 2 * NT - j, lane);
+        else if (j < 3 * NT) blk_lu_rowtile_to_panel<D>(p1, p0, j - 2 * NT, D + 1, pan, lane);
+        else blk_lu_rowtile_to_panel<D>(p2, p0, j - 3 * NT, D, pan + (D + 1) * D, lane);
+      };
       if (wave < NPW) {
         if (t < T) {
-#ifndef TRAJ_PIVOT_COLUMNWISE
-          if (wave == 0) pv2_wave0<D>(b00, reinterpret_cast<int *>(cbu), 16 * t, lane, &bad);
-          else pv2_wave1<D>(b00, ring, reinterpret_cast<int *>(cbu), 16 * t, lane, t >= 1 ? W1N : 0, W1L, w1_job);
-#else
-          if (wave == 0) blk_pivot_s<D>(b00, ring, t * D, lane, &bad);
-          else blk_pivot_u<D>(b00, ring, t * D, cbu, lane);
-#endif
+          if (wave == 0) {
+            pv2_wave0<D>(b00, reinterpret_cast<int *>(cbu), 16 * t, lane, &bad);
+          } else {
+            if (defer && W1L) {
+              l20_rowtile(0);
+              mid_arrive();
+            }
+            pv2_wave1<D>(b00, ring, reinterpret_cast<int *>(cbu), 16 * t, lane);
+          }
           BLK_PROF_AT(3, 0);
           BLK_PROF_AT(4, 64);
-        } else {
-#ifndef TRAJ_PIVOT_COLUMNWISE
-          if (wave == 1)                  // wave 1's share of the last step's deferred work
-            for (int j = 0; j < W1N; ++j) w1_job(j);
-#else
-          __syncthreads();
-#endif
+        } else if (wave == 1 && W1L) {
+          l20_rowtile(0);
+          mid_arrive();
         }
-        __syncthreads();                  // end of phase 1
+        if (defer) {                      // the pivot pair's share of the jobs
+          pv2_wait(mid, (NDW + W1L) * t);
+#pragma unroll
+          for (int j = 0; j < 4 * NT; ++j)
+            if (blk_job_owner<NT, NPW, NDW>(j) < NPW && blk_job_owner<NT, NPW, NDW>(j) == wave) run_job(j);
+        }
       } else {
         const int dw = wave - NPW;
         // mixtures of block rows t+1, t+2, t+3 (clamped), loaded before the products so that the stencil loads below
@@ -825,40 +690,20 @@ traj_solve_blk_kernel(const TrajUtt *__restrict__ utts, int n, const double *__r
         const bool live = a < T, hasp = a + 1 < T;
         const int ac = live ? a : T - 1, am = ac >= 1 ? ac - 1 : 0, ap = hasp ? a + 1 : ac;
         const int64_t mxa = mh[ac], mxm = mh[am], mxp = mh[ap];
-        const bool defer = t >= 1;
-        if (defer) {                      // L20(t-1) = S20 U' in place; row D of S20 := r0(t-1) -> row D of L20 = z0
-          for (int it = W1L + dw; it < NT; it += NDW) {
-            if (it == RT) {
-              if (lane < DP) p2[D * LS + lane] = (lane < D) ? p0[D * LS + lane] : 0.0;
-              __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-              __builtin_amdgcn_wave_barrier();
-              __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            }
-            blk_trsm_rowtile<D>(p2, p0, it, lane);
-          }
-        }
-        BLK_PROF_AT(8, 64 * NPW);
-#ifndef TRAJ_PIVOT_COLUMNWISE
-        // The row groups below read every wave's L20 tiles: the deferred waves meet on an arrival counter in LDS (the pivot
-        // pair does not take part, so neither side waits for the other in the middle of the phase).
         if (defer) {
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-          if (lane == 0) __hip_atomic_fetch_add(mid, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          for (int it = W1L + dw; it < NT; it += NDW) l20_rowtile(it);
+          mid_arrive();
+          BLK_PROF_AT(8, 64 * NPW);
           pv2_wait(mid, (NDW + W1L) * t);
-        }
-#else
-        __syncthreads();
-#endif
-        BLK_PROF_AT(9, 64 * NPW);
-        if (defer) {                      // S21 -= L20 L10' (all tiles), S22 -= L20 L20' (lower tiles), row group by row group
-          for (int it = 0; it < NT; ++it) {
-            if ((it % NDW) == dw) blk_update_rowgroup<D>(b10, p2, p1, it, NT, lane);
-            if (((it + 1) % NDW) == dw) blk_update_rowgroup<D>(b11, p2, p2, it, it + 1, lane);
-          }
+#pragma unroll
+          for (int j = 0; j < 2 * NT; ++j)
+            if (blk_job_owner<NT, NPW, NDW>(j) >= NPW && blk_job_owner<NT, NPW, NDW>(j) == wave) run_job(j);
         }
         BLK_PROF_AT(6, 64 * NPW);
         // Block row a = t+2 of the stencil.  Every load is unconditional on a clamped address (a select on a loaded
         // value would make the wave wait for each load in turn); masks are applied when the operands are combined.
+        // Issued between the row-group jobs and the panel jobs: early enough to be back in time, late enough that the
+        // 5 x NIT values in flight do not crowd the registers of the long jobs.
         ev_t q0[NIT], q1[NIT], q2[NIT], q3[NIT], q4[NIT];
         const double *Qss = Qall + (size_t)(mxa - 1) * D2 * D2, *Qsd = Qss + D;
         const double *Qds = Qall + (size_t)(mxm - 1) * D2 * D2 + (size_t)D * D2, *Qdd = Qds + D;
@@ -875,21 +720,10 @@ traj_solve_blk_kernel(const TrajUtt *__restrict__ utts, int n, const double *__r
         const int jr = dt < D ? dt : D - 1;
         const double g0 = g[(size_t)ac * D2 + jr], g1 = g[(size_t)am * D2 + D + jr], g2 = g[(size_t)ap * D2 + D + jr];
         BLK_PROF_AT(10, 64 * NPW);
-        if (defer) {   // panel t-1 -> HBM: M1 = L10 U (row D: h = U' z0) and M2 = L20 U, formed here so that the back
-                       // substitution is one product per step on a 2/3-size panel (reads only: no barrier needed)
-          double *pan = ws + (size_t)(t - 1) * PAN;
-#ifndef TRAJ_PIVOT_COLUMNWISE
-          int cnt = 0;                    // the row tiles pivot wave 1 does not form (see w1_job)
-          for (int j = W1J; j < NT; ++j, ++cnt)
-            if (cnt % NDW == dw) blk_lu_rowtile_to_panel<D>(p1, p0, j, D + 1, pan, lane);
-          for (int j = W1M2; j < NT; ++j, ++cnt)
-            if (cnt % NDW == dw) blk_lu_rowtile_to_panel<D>(p2, p0, j, D, pan + (D + 1) * D, lane);
-#else
-          for (int job = dw; job < 2 * NT; job += NDW) {
-            if (job < NT) blk_lu_rowtile_to_panel<D>(p1, p0, job, D + 1, pan, lane);
-            else blk_lu_rowtile_to_panel<D>(p2, p0, job - NT, D, pan + (D + 1) * D, lane);
-          }
-#endif
+        if (defer) {
+#pragma unroll
+          for (int j = 2 * NT; j < 4 * NT; ++j)
+            if (blk_job_owner<NT, NPW, NDW>(j) >= NPW && blk_job_owner<NT, NPW, NDW>(j) == wave) run_job(j);
         }
         BLK_PROF_AT(11, 64 * NPW);
         const double w4 = hasp ? 0.25 : 0.0, w2 = hasp ? 0.5 : 0.0, lv = live ? 1.0 : 0.0;
@@ -901,8 +735,8 @@ traj_solve_blk_kernel(const TrajUtt *__restrict__ utts, int n, const double *__r
         }
         rv = lv * ((g0 + 0.5 * g1) - w2 * g2);
         BLK_PROF_AT(7, 64 * NPW);
-        __syncthreads();                  // end of phase 1: every read of p0, p1, p2 is done
       }
+      __syncthreads();                    // end of phase 1: every read of p0, p1, p2 is done
       BLK_PROF(0);
       if (t == T) break;
       // ---------------- phase 2 ----------------
@@ -931,7 +765,6 @@ traj_solve_blk_kernel(const TrajUtt *__restrict__ utts, int n, const double *__r
       if (wave >= NPW && wave >= NT) write_row(0, NIT);
       __syncthreads();
       BLK_PROF(1);
-#ifndef TRAJ_PIVOT_COLUMNWISE
       // S11 -= L10 L10' (lower tiles) -> S00 of the next step.  Wave 0 forms tile (0,0) and goes straight on to the scalar
       // chain of the next step's first diagonal block (all it needs); the other waves share the remaining tiles and meet on
       // an arrival counter: wave 1's trailing updates and the deferred team need them (and the stencil rows) complete,
@@ -953,15 +786,6 @@ traj_solve_blk_kernel(const TrajUtt *__restrict__ utts, int n, const double *__r
         if (lane == 0) __hip_atomic_fetch_add(s11, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         pv2_wait(s11, (NW - 1) * (t + 1));
       }
-#else
-      for (int job = wave; job < NLOW; job += NW) {     // S11 -= L10 L10' (lower tiles) -> S00 of the next step
-        int q = job, it = 0;
-        while (q > it) { q -= it + 1; ++it; }
-        blk_update_tile<D>(b11, b10, b10, it, q, lane);
-      }
-      if (wave >= NPW && wave < NT) write_row(0, NIT);
-      __syncthreads();
-#endif
       BLK_PROF(2);
       {   // the window moves by one block
         double *f0 = p0, *f1 = p1;
