@@ -534,24 +534,17 @@ __device__ void blk_backsub(const double *__restrict__ ws, int T, double *buf, d
 #endif
 #define TRAJ_DEFERRED_WAVES 2     // waves of the deferred team (beside the two pivot waves); 4 was measured: the kernel
                                   // then has two waves per SIMD, spills 68 VGPRs and the scalar chain shares its FP64 pipe: 40.6 ms
-// Which wave runs job j of the deferred list (see the kernel) when the list is shared out statically.  At three tiles per
-// dimension (D = 32..46) by measured job lengths (tools/microbench_blkops.hip, counts: S21 row group 2.9k, S22 row
-// groups 2.9k / 2.0k / 1.4k, panel row tile 2.2k) and by when a wave becomes free: the deferred waves ~10k each, pivot
-// wave 1 (free after its last product) and pivot wave 0 (free after its last chain) ~4k each.
+// Which wave runs job j of the deferred list (see the kernel).  At three tiles per dimension (D = 32..46) by measured
+// job lengths (tools/microbench_blkops.hip, counts of s_memtime: S21 row group 2.9k, S22 row groups 2.9k / 2.0k / 1.4k,
+// panel row tile 2.2k alone, ~3k beside the other waves' stores) and by when a wave becomes free: the deferred waves
+// carry the row groups and one panel tile each, pivot wave 1 two M1 tiles after its last product, pivot wave 0 two M2
+// tiles after its last chain.  Other splits of the panel tiles between the four waves measured within 0.1 ms of this
+// one; without wave 1's L20 tile 0.7 ms slower; wave 0 leaving the barrier after the L10 row tiles out: no gain.
 template <int NT, int NPW, int NDW>
 __device__ constexpr int blk_job_owner(int j) {
   if (NT == 3 && NDW == 2) {
     //               S21 r0 r1 r2 | S22 r2 r1 r0 | M1 t0 t1 t2 | M2 t0 t1 t2
-#ifndef TRAJ_JOB_TABLE
-#define TRAJ_JOB_TABLE 0
-#endif
-#if TRAJ_JOB_TABLE == 0
     constexpr int own[12] = {2, 3, 2, 3, 2, 3, 1, 1, 2, 3, 0, 0};
-#elif TRAJ_JOB_TABLE == 1
-    constexpr int own[12] = {2, 3, 2, 3, 2, 1, 2, 3, 3, 1, 0, 0};
-#else
-    constexpr int own[12] = {2, 3, 2, 3, 2, 3, 1, 2, 3, 1, 0, 0};
-#endif
     return own[j];
   }
   return NPW + j % NDW;
