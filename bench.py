@@ -45,15 +45,19 @@ def estep_flops_per_frame(Dj, M):
     return 8 * Dj * M + 25 * M
 
 
-def pmc_traffic(fname, kernel_prefix, subdir="r02_pmc"):
+def pmc_traffic(fname, kernel_prefix, subdir="r02_pmc", wide_reads=False):
     """HBM bytes per bench step of a kernel from a committed PMC pass (profiles/r02_pmc/*.json, tools/pmc_traffic.sh: FETCH_SIZE
     and WRITE_SIZE in SEPARATE rocprofv3 passes of this same bench command); the counters cannot be collected inside the
-    timed run.  Raw (KB counters x 1024): see profiles/r02_pmc/README.txt for the guide's gfx950 correction."""
+    timed run.  KB counters x 1024; `wide_reads`: the kernel's reads are 16-byte-per-lane streams, for which FETCH_SIZE
+    reports half the bytes on gfx950 (MI355X_MICROARCH.md, HBM section) -- doubled here.  Other access widths are
+    uncalibrated and taken as they are (profiles/r02_pmc/README.txt)."""
     try:
         tr = json.load(open(os.path.join(ROOT, "profiles", subdir, fname)))
         for k, v in tr.items():
             if kernel_prefix in k:
-                return v.get("hbm_bytes_per_step_raw", v["hbm_bytes_per_launch_raw"])
+                f = v.get("FETCH_SIZE_KB_per_step", 0.0) * 1024.0
+                w = v.get("WRITE_SIZE_KB_per_step", 0.0) * 1024.0
+                return (2.0 * f if wide_reads else f) + w
     except (OSError, KeyError, ValueError):
         pass
     return None
@@ -261,6 +265,9 @@ def bench_convert(args, world, rank):
                                          f"{dt:.1f} s on 1 of {os.cpu_count()} host cores"}
         out["parity_max_rel_err_vs_oracle"] = err
         out["speedup_vs_cpu_baseline"] = frames_per_s / (n / dt)
+    # (profiling runs pass --cpu-seconds 0: nothing but the warm-up and the timed launches may reach the kernel trace and
+    # the PMC passes, so the host-pointer measurement and the strong CPU baseline below are skipped there)
+    if rank == 0 and args.cpu_seconds > 0:
         # the host-pointer (PCIe-inclusive) rate of the same call, measured -- never the reported `value`
         Xh = np.asfortranarray(X.T)
         vc.fvconvert(g, Xh)                                  # warm the library's staging buffers
@@ -325,15 +332,18 @@ def bench_estep(args, world, rank):
 
     wall, kernel_ms = timed_steps(step, args.steps, args.warmup, world)
     fps = world * N * args.steps / wall
+    mfma_path = Dj in (32, 48, 64, 80) and M <= 128           # estep.hip: estep_device
     achieved = estep_flops_per_frame(Dj, M) * N / (kernel_ms * 1e-3) / 1e12
-    out = {"metric": "diag-GMM E-step frames/sec (Dj=80, M=128)", "value": fps, "unit": "frames/s", "n_gpus": world,
+    out = {"metric": "diag-GMM E-step frames/sec (Dj=%d, M=%d)" % (Dj, M), "value": fps, "unit": "frames/s", "n_gpus": world,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True,
            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-           "config": {"workload": "diag E-step (BASELINE configs[2])" if Dj == 80 else f"diag E-step, Dj={Dj} (--add_delta features; generic kernels)", "Dj": Dj, "M": M, "frames_per_gpu": N,
+           "config": {"workload": "diag E-step (BASELINE configs[2])" if Dj == 80 else
+                      f"diag E-step, Dj={Dj} ({'MFMA kernel' if mfma_path else 'generic kernels'}; not a BASELINE config)",
+                      "Dj": Dj, "M": M, "frames_per_gpu": N,
                       "collective": "all-reduce(sum) of %d doubles per step" % vc.stats_len(Dj, M)},
-           "roofline": {"bound": "mfma", "kernel": ("estep_mfma_kernel<80>" if Dj == 80 else "estep_gamma_kernel + estep_stats_kernel (generic path)") + " (+ all-reduce)", "achieved": achieved,
+           "roofline": {"bound": "mfma", "kernel": (f"estep_mfma_kernel<{Dj}>" if mfma_path else "estep_gamma_kernel + estep_stats_kernel (generic path)") + " (+ all-reduce)", "achieved": achieved,
                         "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS,
-                        "traffic": pmc_traffic("estep_traffic.json", "estep_mfma_kernel", "r02_pmc") if (N == 1_250_000 and Dj == 80) else None,
+                        "traffic": pmc_traffic("estep_traffic.json", "estep_mfma_kernel", "r02_pmc", wide_reads=True) if (N == 1_250_000 and Dj == 80) else None,
                         "flop_per_frame": estep_flops_per_frame(Dj, M), "kernel_ms": kernel_ms}}
     if rank == 0:
         from oracle import c_oracle as co
@@ -661,7 +671,7 @@ def main():
     ap.add_argument("--utts", type=int, default=256, help="trajectory utterances per GPU")
     ap.add_argument("--chunk", type=int, default=0, help="traj: convert in vc() chunks of this many frames "
                     "(bin/vc.jl:18 default --T=100); 0 = whole 2000-frame utterances (BASELINE configs[4])")
-    ap.add_argument("--dj", type=int, default=80, help="estep: joint feature dimension (80 = BASELINE; 160 = --add_delta features, generic kernels)")
+    ap.add_argument("--dj", type=int, default=80, help="estep: joint feature dimension (80 = BASELINE; 32, 48, 64 also run the MFMA kernel; others, e.g. 160, the generic kernels)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU time budget of the cpu_baseline sample")
     ap.add_argument("--verify-allreduce", action="store_true",
                     help="estep: rank 0 recomputes the statistics of every rank's frames in one process and compares")

@@ -36,8 +36,13 @@ def test_golden(vc, generic):
     assert abs(S0.sum() - 2000) < 1e-6          # responsibilities sum to one per frame
 
 
-@pytest.mark.parametrize("N,Dj,M", [(5000, 80, 128), (777, 80, 100), (1, 80, 3), (300, 48, 8), (1000, 6, 2), (70000, 10, 4)])
-def test_vs_oracle(vc, N, Dj, M):
+@pytest.mark.parametrize("generic", [False, True])
+@pytest.mark.parametrize("N,Dj,M", [(5000, 80, 128), (777, 80, 100), (1, 80, 3), (300, 48, 8), (3000, 48, 128), (2000, 64, 100),
+                                    (1500, 32, 16), (600, 160, 24), (1000, 6, 2), (70000, 10, 4)])
+def test_vs_oracle(vc, N, Dj, M, generic):
+    """Dj = 32, 48, 64, 80 with M <= 128 run the MFMA kernel, everything else (and `generic`) the generic kernels."""
+    if generic and (Dj not in (32, 48, 64, 80) or N > 5000):
+        pytest.skip("the generic kernels are the only path for this shape")
     from oracle import c_oracle as co, np_oracle as npo
     w, mu, _ = npo.synth_model(3000 + N, Dj, M)
     rg = np.random.default_rng(N)
@@ -45,7 +50,11 @@ def test_vs_oracle(vc, N, Dj, M):
     comp = rg.choice(M, size=N, p=w)
     X = mu[comp] + rg.standard_normal((N, Dj)) * np.sqrt(var[comp])
     r0, r1, r2, rl = co.estep_diag(X, w, mu, var)
-    S0, S1, S2, ll = vc.estep_diag(X.T, w, mu.T, var.T)
+    _force_generic(vc, generic)
+    try:
+        S0, S1, S2, ll = vc.estep_diag(X.T, w, mu.T, var.T)
+    finally:
+        _force_generic(vc, False)
     assert relerr(S0, r0) < TOL and relerr(S1, r1.T) < TOL and relerr(S2, r2.T) < TOL
     assert abs(ll - rl) < TOL * abs(rl)
 
@@ -98,7 +107,7 @@ def _hard_case(seed, Dj, M, N, spread, lo, hi, overlap):
 
 
 @pytest.mark.parametrize("generic", [False, True])
-@pytest.mark.parametrize("Dj,M", [(80, 128), (80, 37), (48, 16)])
+@pytest.mark.parametrize("Dj,M", [(80, 128), (80, 37), (48, 16), (64, 40), (32, 128)])
 def test_tight_variances_far_means_overlapping_mixtures(vc, generic, Dj, M):
     """sigma^2 log-uniform in [1e-7, 1e-2], |mu| up to 10, overlapping mixtures -- within 1e-9 of the
     oracle (which evaluates (x - mu)^2 / sigma^2 term by term) for both device paths."""

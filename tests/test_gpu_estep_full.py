@@ -192,3 +192,15 @@ def test_empty_mixture_survives_the_mstep(vc):
     assert np.allclose(sg2[:, :, 2], 1e-7 * np.eye(Dj), rtol=0, atol=0)
     ll2 = em.mstep(em.estep(Xd))                                                   # and EM goes on
     assert np.isfinite(ll2) and ll2 >= ll - 1e-6 * abs(ll)
+
+
+def test_device_em_state_rejects_dimensions_beyond_its_staging(vc):
+    """vcmi_gmm_em_create stages the means of one mixture in a 256-double LDS array (M-step): larger joint dimensions are
+    refused with DimensionMismatch at construction instead of overrunning it."""
+    from voiceconversion_jl_amd.train import EMState
+    Dj, M = 260, 2
+    w = np.full(M, 1.0 / M)
+    mu = np.zeros((Dj, M), order="F")
+    sigma = np.asfortranarray(np.stack([np.eye(Dj)] * M, axis=2))
+    with pytest.raises(vc.DimensionMismatch):
+        EMState(w, mu, sigma)

@@ -180,3 +180,29 @@ def test_repeated_runs_are_bit_identical(vc):
     for _ in range(5):
         assert all(np.array_equal(a, b) for a, b in zip(t.fvconvert_batch(Xs), ref))
         assert all(np.array_equal(a, b) for a, b in zip(tgv.fvconvert_batch(Xs, epochs=4, alpha=1e-5), refg))
+
+
+def test_batch_of_empty_utterances_on_a_fresh_handle(vc):
+    """The device-resident batch entry points return OK for a batch whose utterances are all empty, also when nothing has
+    run on the handle yet (no status word allocated)."""
+    import ctypes as C
+    import torch
+    from oracle import np_oracle as npo
+    from voiceconversion_jl_amd import _lib
+    D, M = 12, 4
+    w, mu, sig = npo.synth_model(91, 4 * D, M)
+    g = vc.GMMMap(*julia_model(w, mu, sig))
+    t = vc.TrajectoryGMMMap(g, 50)
+    dX = torch.zeros(8, dtype=torch.float64, device="cuda")
+    dY = torch.zeros(8, dtype=torch.float64, device="cuda")
+    off = np.zeros(3, dtype=np.int64)
+    T = np.zeros(3, dtype=np.int64)
+    rc = _lib.lib.vcmi_traj_convert_batch_dev(t._h, 3, C.c_void_p(dX.data_ptr()), _lib.iptr(off), _lib.iptr(T),
+                                              C.c_void_p(dY.data_ptr()), _lib.iptr(off), None)
+    assert rc == 0
+    muv = np.ones(D)
+    tgv = vc.TrajectoryGVGMMMap(vc.TrajectoryGMMMap(g, 50), muv, np.eye(D))
+    rc = _lib.lib.vcmi_trajgv_convert_batch_dev(tgv._h, 3, C.c_void_p(dX.data_ptr()), _lib.iptr(off), _lib.iptr(T), 5, 1e-5,
+                                                C.c_void_p(dY.data_ptr()), _lib.iptr(off), None)
+    assert rc == 0
+    assert t.fvconvert_batch([np.zeros((2 * D, 0), order="F")])[0].shape == (D, 0)

@@ -10,7 +10,7 @@
 // path is ONE all-reduce(sum) of M(1+2Dj)+1 doubles over RCCL.
 //
 // Two implementations:
-//  * MFMA kernel (Dj = 80, M <= 128 here; v_mfma_f64_16x16x4_f64): both the log-density
+//  * MFMA kernel (Dj = 32, 48, 64, 80 and M <= 128; v_mfma_f64_16x16x4_f64): both the log-density
 //    l = [x^2, x] . [-iv/2 ; mu iv] + c  and the statistics  gamma' [x, x^2]  are dense FP64 contractions.
 //    A workgroup of 8 waves owns a strided set of 64-frame blocks; wave w owns mixtures 16w..16w+15: their
 //    weight fragments (80 VGPRs) and their 16 x 160 statistics accumulators (80 VGPRs) stay in registers for
@@ -106,7 +106,9 @@ estep_reduce_kernel(const double *__restrict__ part, int nrows, int64_t plen, do
 }
 
 // ------------------------------------------------------------------------------------------------
-// MFMA path, Dj = 80 (K = 160 = [x^2 | x], 40 k-steps; 10 statistic column tiles [x | x^2])
+// MFMA path, Dj a multiple of 16 up to 80 (at Dj = 80: K = 160 = [x^2 | x], 40 k-steps; 10 statistic column tiles
+// [x | x^2]).  Dj = 160 does not fit this shape: a workgroup keeps W (M x 2Dj) and the statistics (M x 2Dj) in registers,
+// 2 x 328 KB at M = 128 against the 512 KB register file of a CU -- it runs the generic kernels (4.7 % of the roof).
 // ------------------------------------------------------------------------------------------------
 template <int DJ>
 struct EstepCfg {
@@ -417,6 +419,50 @@ estep_prep_kernel(const double *__restrict__ raw, int M, double *__restrict__ Wp
   }
 }
 
+// The MFMA path for one joint dimension (parameters staged through pinned buffers, prep kernel, the E-step kernel with one
+// workgroup per CU, fixed-order reduction of the workgroups' partial statistics).
+template <int DJ>
+static int estep_mfma_launch(EstepScratch &sc, const double *dX, int64_t N, int M, const double *w, const double *mu,
+                             const double *var, double *dstats, int64_t plen, hipStream_t st) {
+  using C = EstepCfg<DJ>;
+  int dev = 0, cus = 256;
+  (void)hipGetDevice(&dev);
+  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  const int64_t nblocks = (N + C::FB - 1) / C::FB;
+  const int grid = (int)std::min<int64_t>(nblocks, cus);
+  const size_t nraw = (size_t)M * (1 + 2 * DJ);
+  VCMI_TRY(sc.raw.reserve(2 * nraw));                  // one device copy per staging buffer
+  VCMI_TRY(sc.Wpack.reserve((size_t)8 * C::KS * 64));
+  VCMI_TRY(sc.cinit.reserve((size_t)C::MMAX));
+  VCMI_TRY(sc.refiv.reserve((size_t)M * DJ));
+  VCMI_TRY(sc.refc.reserve((size_t)M));
+  VCMI_TRY(sc.part.reserve((size_t)grid * plen));
+  VCMI_TRY(sc.stage.reserve(nraw));
+  const int b = sc.stage.next;
+  sc.stage.next ^= 1;
+  VCMI_HIP(hipEventSynchronize(sc.stage.copied[b]));   // the copy that last used this buffer (two calls ago) is done
+  double *h = sc.stage.host[b], *draw = sc.raw.p + (size_t)b * nraw;
+  memcpy(h, w, sizeof(double) * M);
+  memcpy(h + M, mu, sizeof(double) * M * DJ);
+  memcpy(h + M + (size_t)M * DJ, var, sizeof(double) * M * DJ);
+  VCMI_HIP(hipMemcpyAsync(draw, h, nraw * sizeof(double), hipMemcpyHostToDevice, st));
+  VCMI_HIP(hipEventRecord(sc.stage.copied[b], st));
+  hipLaunchKernelGGL(estep_prep_kernel<DJ>, dim3((8 * C::KS * 64 + 255) / 256), dim3(256), 0, st, draw, M, sc.Wpack.p,
+                     sc.cinit.p, sc.refiv.p, sc.refc.p);
+  VCMI_HIP(hipGetLastError());
+  auto kern = estep_mfma_kernel<DJ>;
+  VCMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)C::LDS_BYTES));
+  // (the means of the re-evaluation are the uploaded parameters themselves: raw = [w | mu (Dj,M) | var (Dj,M)])
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), C::LDS_BYTES, st, dX, N, M, sc.Wpack.p, sc.cinit.p, sc.part.p, plen,
+                     draw + M, sc.refiv.p, sc.refc.p);
+  VCMI_HIP(hipGetLastError());
+  hipLaunchKernelGGL(estep_reduce_kernel, dim3((unsigned)((plen + 255) / 256)), dim3(256), 0, st, sc.part.p, grid, plen,
+                     dstats);
+  VCMI_HIP(hipGetLastError());
+  return VCMI_OK;
+}
+
 static int estep_device(const double *dX, int64_t N, int Dj, int M, const double *w, const double *mu, const double *var,
                         double *dstats, hipStream_t st) {
   if (N < 0 || Dj < 1 || M < 1) return fail(VCMI_ERR_DIM, "E-step: N=%lld Dj=%d M=%d invalid", (long long)N, Dj, M);
@@ -430,45 +476,17 @@ static int estep_device(const double *dX, int64_t N, int Dj, int M, const double
   VCMI_HIP(hipMemsetAsync(dstats, 0, plen * sizeof(double), st));
   if (N == 0) return VCMI_OK;
 
-  const bool mfma = (Dj == 80 && M <= EstepCfg<80>::MMAX && !debug_flag(kDbgEstepGeneric));
-  if (mfma) {
-    using C = EstepCfg<80>;
-    int dev = 0, cus = 256;
-    (void)hipGetDevice(&dev);
-    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    const int64_t nblocks = (N + C::FB - 1) / C::FB;
-    const int grid = (int)std::min<int64_t>(nblocks, cus);
-    const size_t nraw = (size_t)M * (1 + 2 * Dj);
-    VCMI_TRY(sc.raw.reserve(2 * nraw));                  // one device copy per staging buffer
-    VCMI_TRY(sc.Wpack.reserve((size_t)8 * C::KS * 64));
-    VCMI_TRY(sc.cinit.reserve((size_t)C::MMAX));
-    VCMI_TRY(sc.refiv.reserve((size_t)M * Dj));
-    VCMI_TRY(sc.refc.reserve((size_t)M));
-    VCMI_TRY(sc.part.reserve((size_t)grid * plen));
-    VCMI_TRY(sc.stage.reserve(nraw));
-    const int b = sc.stage.next;
-    sc.stage.next ^= 1;
-    VCMI_HIP(hipEventSynchronize(sc.stage.copied[b]));   // the copy that last used this buffer (two calls ago) is done
-    double *h = sc.stage.host[b], *draw = sc.raw.p + (size_t)b * nraw;
-    memcpy(h, w, sizeof(double) * M);
-    memcpy(h + M, mu, sizeof(double) * M * Dj);
-    memcpy(h + M + (size_t)M * Dj, var, sizeof(double) * M * Dj);
-    VCMI_HIP(hipMemcpyAsync(draw, h, nraw * sizeof(double), hipMemcpyHostToDevice, st));
-    VCMI_HIP(hipEventRecord(sc.stage.copied[b], st));
-    hipLaunchKernelGGL(estep_prep_kernel<80>, dim3((8 * C::KS * 64 + 255) / 256), dim3(256), 0, st, draw, M, sc.Wpack.p,
-                       sc.cinit.p, sc.refiv.p, sc.refc.p);
-    VCMI_HIP(hipGetLastError());
-    auto kern = estep_mfma_kernel<80>;
-    VCMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 (int)C::LDS_BYTES));
-    // (the means of the re-evaluation are the uploaded parameters themselves: raw = [w | mu (Dj,M) | var (Dj,M)])
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), C::LDS_BYTES, st, dX, N, M, sc.Wpack.p, sc.cinit.p, sc.part.p, plen,
-                       draw + M, sc.refiv.p, sc.refc.p);
-    VCMI_HIP(hipGetLastError());
-    hipLaunchKernelGGL(estep_reduce_kernel, dim3((unsigned)((plen + 255) / 256)), dim3(256), 0, st, sc.part.p, grid, plen,
-                       dstats);
-    VCMI_HIP(hipGetLastError());
-    return VCMI_OK;
+  // MFMA instantiations: the joint dimensions of the shipped configurations (Dj = 80: 40-dimensional joint features with
+  // deltas; 32, 48, 64: 8-, 12-, 16-dimensional mel-cepstra with deltas); any other Dj, and M > 128, take the generic
+  // kernels below.
+  if (M <= EstepCfg<80>::MMAX && !debug_flag(kDbgEstepGeneric)) {
+    switch (Dj) {
+      case 32: return estep_mfma_launch<32>(sc, dX, N, M, w, mu, var, dstats, plen, st);
+      case 48: return estep_mfma_launch<48>(sc, dX, N, M, w, mu, var, dstats, plen, st);
+      case 64: return estep_mfma_launch<64>(sc, dX, N, M, w, mu, var, dstats, plen, st);
+      case 80: return estep_mfma_launch<80>(sc, dX, N, M, w, mu, var, dstats, plen, st);
+      default: break;
+    }
   }
 
   std::vector<double> hiv((size_t)M * Dj), hc(M);
