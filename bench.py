@@ -53,11 +53,13 @@ def pmc_traffic(fname, kernel_prefix, subdir="r02_pmc", wide_reads=False):
     uncalibrated and taken as they are (profiles/r02_pmc/README.txt)."""
     try:
         tr = json.load(open(os.path.join(ROOT, "profiles", subdir, fname)))
+        total = None
         for k, v in tr.items():
-            if kernel_prefix in k:
+            if kernel_prefix in k:                       # every kernel of the family (e.g. dtw_fused_kernel + dtw_fused_finish_kernel)
                 f = v.get("FETCH_SIZE_KB_per_step", 0.0) * 1024.0
                 w = v.get("WRITE_SIZE_KB_per_step", 0.0) * 1024.0
-                return (2.0 * f if wide_reads else f) + w
+                total = (total or 0.0) + (2.0 * f if wide_reads else f) + w
+        return total
     except (OSError, KeyError, ValueError):
         pass
     return None
