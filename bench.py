@@ -334,7 +334,7 @@ def bench_estep(args, world, rank):
 
     wall, kernel_ms = timed_steps(step, args.steps, args.warmup, world)
     fps = world * N * args.steps / wall
-    mfma_path = Dj in (32, 48, 64, 80) and M <= 128           # estep.hip: estep_device
+    mfma_path = Dj in (32, 48, 64, 80, 160) and M <= 128           # estep.hip: estep_device
     achieved = estep_flops_per_frame(Dj, M) * N / (kernel_ms * 1e-3) / 1e12
     out = {"metric": "diag-GMM E-step frames/sec (Dj=%d, M=%d)" % (Dj, M), "value": fps, "unit": "frames/s", "n_gpus": world,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True,
@@ -673,7 +673,7 @@ def main():
     ap.add_argument("--utts", type=int, default=256, help="trajectory utterances per GPU")
     ap.add_argument("--chunk", type=int, default=0, help="traj: convert in vc() chunks of this many frames "
                     "(bin/vc.jl:18 default --T=100); 0 = whole 2000-frame utterances (BASELINE configs[4])")
-    ap.add_argument("--dj", type=int, default=80, help="estep: joint feature dimension (80 = BASELINE; 32, 48, 64 also run the MFMA kernel; others, e.g. 160, the generic kernels)")
+    ap.add_argument("--dj", type=int, default=80, help="estep: joint feature dimension (80 = BASELINE; 32, 48, 64 and 160 also run the MFMA kernel; others the generic kernels)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU time budget of the cpu_baseline sample")
     ap.add_argument("--verify-allreduce", action="store_true",
                     help="estep: rank 0 recomputes the statistics of every rank's frames in one process and compares")

@@ -38,10 +38,11 @@ def test_golden(vc, generic):
 
 @pytest.mark.parametrize("generic", [False, True])
 @pytest.mark.parametrize("N,Dj,M", [(5000, 80, 128), (777, 80, 100), (1, 80, 3), (300, 48, 8), (3000, 48, 128), (2000, 64, 100),
-                                    (1500, 32, 16), (600, 160, 24), (1000, 6, 2), (70000, 10, 4)])
+                                    (1500, 32, 16), (600, 160, 24), (4000, 160, 128), (33, 160, 5), (1000, 6, 2), (70000, 10, 4)])
 def test_vs_oracle(vc, N, Dj, M, generic):
-    """Dj = 32, 48, 64, 80 with M <= 128 run the MFMA kernel, everything else (and `generic`) the generic kernels."""
-    if generic and (Dj not in (32, 48, 64, 80) or N > 5000):
+    """Dj = 32, 48, 64, 80 with M <= 128 run the MFMA kernel, Dj = 160 its two-kernel form (responsibilities through
+    HBM), everything else (and `generic`) the generic kernels."""
+    if generic and (Dj not in (32, 48, 64, 80, 160) or N > 5000):
         pytest.skip("the generic kernels are the only path for this shape")
     from oracle import c_oracle as co, np_oracle as npo
     w, mu, _ = npo.synth_model(3000 + N, Dj, M)
@@ -107,13 +108,13 @@ def _hard_case(seed, Dj, M, N, spread, lo, hi, overlap):
 
 
 @pytest.mark.parametrize("generic", [False, True])
-@pytest.mark.parametrize("Dj,M", [(80, 128), (80, 37), (48, 16), (64, 40), (32, 128)])
+@pytest.mark.parametrize("Dj,M", [(80, 128), (80, 37), (48, 16), (64, 40), (32, 128), (160, 64)])
 def test_tight_variances_far_means_overlapping_mixtures(vc, generic, Dj, M):
     """sigma^2 log-uniform in [1e-7, 1e-2], |mu| up to 10, overlapping mixtures -- within 1e-9 of the
     oracle (which evaluates (x - mu)^2 / sigma^2 term by term) for both device paths."""
     from oracle import c_oracle as co
     from voiceconversion_jl_amd import _lib
-    w, mu, var, X = _hard_case(515 + Dj + M, Dj, M, 6000, 10.0, 1e-7, 1e-2, 3.0)
+    w, mu, var, X = _hard_case(515 + Dj + M, Dj, M, 6000, 10.0, 1e-7, 1e-2, 3.0 if Dj <= 80 else 1.5)
     r0, r1, r2, rl = co.estep_diag(X, w, mu, var)
     _lib.debug_force(_lib.DBG_ESTEP_GENERIC if generic else 0)
     try:

@@ -10,7 +10,7 @@
 // path is ONE all-reduce(sum) of M(1+2Dj)+1 doubles over RCCL.
 //
 // Two implementations:
-//  * MFMA kernel (Dj = 32, 48, 64, 80 and M <= 128; v_mfma_f64_16x16x4_f64): both the log-density
+//  * MFMA kernel (Dj = 32, 48, 64, 80, 160 and M <= 128; v_mfma_f64_16x16x4_f64): both the log-density
 //    l = [x^2, x] . [-iv/2 ; mu iv] + c  and the statistics  gamma' [x, x^2]  are dense FP64 contractions.
 //    A workgroup of 8 waves owns a strided set of 64-frame blocks; wave w owns mixtures 16w..16w+15: their
 //    weight fragments (80 VGPRs) and their 16 x 160 statistics accumulators (80 VGPRs) stay in registers for
@@ -106,62 +106,76 @@ estep_reduce_kernel(const double *__restrict__ part, int nrows, int64_t plen, do
 }
 
 // ------------------------------------------------------------------------------------------------
-// MFMA path, Dj a multiple of 16 up to 80 (at Dj = 80: K = 160 = [x^2 | x], 40 k-steps; 10 statistic column tiles
-// [x | x^2]).  Dj = 160 does not fit this shape: a workgroup keeps W (M x 2Dj) and the statistics (M x 2Dj) in registers,
-// 2 x 328 KB at M = 128 against the 512 KB register file of a CU -- it runs the generic kernels (4.7 % of the roof).
+// MFMA path, Dj a multiple of 16 (at Dj = 80: K = 160 = [x^2 | x], 40 k-steps; 10 statistic column tiles [x | x^2]).
+// Up to Dj = 80 one kernel; Dj = 160 as two (EstepCfg::SPLIT below).
 // ------------------------------------------------------------------------------------------------
 template <int DJ>
 struct EstepCfg {
   static constexpr int KS = 2 * DJ / 4;          // k-steps of the log-density contraction
   static constexpr int NDT = 2 * DJ / 16;        // 16-wide column tiles of the statistics [x | x^2]
-  static constexpr int FB = 64;                  // frames per block
-  static constexpr int RSX = DJ + 2;             // LDS row stride of x (doubles): a multiple of 16 bytes (LDS-DMA rows),
-                                                 // 164 dwords = 36 mod 64 -> step A's 16-row column reads hit distinct banks
+  // A workgroup keeps its slice of W (M x 2 DJ) and of the statistics (M x 2 DJ) in registers: 2 x 164 KB at DJ = 80,
+  // M = 128.  Beyond that the two do not fit the 512 KB register file of a CU together, and the E-step runs as TWO
+  // kernels -- responsibilities (W in registers), then statistics (accumulators in registers) -- with gamma (N x 128)
+  // through HBM in between: 2 x 1 KB per frame of extra traffic against 5 KB of x^2 / x operands per frame.
+  static constexpr bool SPLIT = DJ > 80;
+  static constexpr int FB = SPLIT ? 32 : 64;     // frames per block
+  // LDS row stride of x (doubles): a multiple of 16 bytes (LDS-DMA rows) and == 18 mod 32, i.e. 36 mod 64 in dwords ->
+  // step A's 16-row column reads hit distinct banks
+  static constexpr int RSX = (DJ + 2 + 13) / 32 * 32 + 18;
+  static constexpr int XBUF = (FB * RSX * 8 + 1023) / 1024 * 128;   // doubles per x buffer: whole 1 KB wave-instructions of the DMA
   static constexpr int MMAX = 128;               // 8 waves x 16 mixtures
   static constexpr int RSG = MMAX + 16;          // LDS row stride of gamma; == 16 mod 32 -> f-groups land 32 banks apart
   // two x buffers (block k+1 streams in by LDS-DMA while block k is processed) + l/gamma; the log-likelihood scratch of
   // the epilogue aliases the l/gamma area
-  static constexpr size_t LDS_BYTES = ((size_t)2 * FB * RSX + (size_t)FB * RSG) * sizeof(double);
+  static constexpr size_t LDS_BYTES = ((size_t)2 * XBUF + (size_t)FB * RSG) * sizeof(double);
+  static_assert(RSX >= DJ + 2 && RSX % 2 == 0, "row stride");
+  static_assert(LDS_BYTES <= 160 * 1024, "LDS");
 };
 
 // Wpack: [mt (8)][ks (KS)][lane (64)] A-operand fragments of W = [-iv/2 | mu*iv] (rows = mixtures), zero rows for m >= M
 // cinit: [128] log-density constants c_m (-inf rows for m >= M so that their gamma is exactly 0)
-template <int DJ>
+// PHASE 0: the whole E-step in one kernel.  PHASE 1 / 2 (EstepCfg::SPLIT): responsibilities -> G (frames x 128, row-major)
+// and the log-likelihood / statistics from G.
+template <int DJ, int PHASE>
 __global__ void __launch_bounds__(512)
 estep_mfma_kernel(const double *__restrict__ X, int64_t N, int M, const double *__restrict__ Wpack,
                   const double *__restrict__ cinit, double *__restrict__ part, int64_t plen,
-                  const double *__restrict__ refmu, const double *__restrict__ refiv, const double *__restrict__ refc) {
+                  const double *__restrict__ refmu, const double *__restrict__ refiv, const double *__restrict__ refc,
+                  double *__restrict__ G) {
   using C = EstepCfg<DJ>;
-  constexpr int KS = C::KS, NDT = C::NDT, FB = C::FB, RSX = C::RSX, RSG = C::RSG;
+  constexpr int KS = C::KS, NDT = C::NDT, FB = C::FB, RSX = C::RSX, RSG = C::RSG, XBUF = C::XBUF;
+  constexpr bool kGamma = PHASE != 2, kStats = PHASE != 1;
+  constexpr int kStepBUnroll = PHASE == 0 ? 4 : FB / 4;
   extern __shared__ double smem[];
-  double *xbuf = smem;                     // [2][FB][RSX]
-  double *lg = smem + 2 * FB * RSX;        // [FB][RSG]   l, then gamma
+  double *xbuf = smem;                     // [2][XBUF]: [FB][RSX] images
+  double *lg = smem + 2 * XBUF;            // [FB][RSG]   l, then gamma
   double *red = lg;                        // [8][64] scratch for the log-likelihood reduction (epilogue only)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lcol = lane & 15, lgrp = lane >> 4;
 
   // this wave's weight fragments and log-density constants stay in registers for the whole kernel
-  double wfrag[KS];
+  double wfrag[kGamma ? KS : 1];
+  if constexpr (kGamma) {
 #pragma unroll
-  for (int ks = 0; ks < KS; ++ks) wfrag[ks] = Wpack[((size_t)wave * KS + ks) * 64 + lane];
+    for (int ks = 0; ks < KS; ++ks) wfrag[ks] = Wpack[((size_t)wave * KS + ks) * 64 + lane];
+  }
   // step A computes the TRANSPOSED tile (rows = frames, cols = this wave's mixtures) by swapping the MFMA operands:
   // the result then lands in LDS with lanes along consecutive mixtures -> conflict-free stores
-  const double cm = cinit[16 * wave + lcol];
+  const double cm = kGamma ? cinit[16 * wave + lcol] : 0.0;
   const d4 cin = {cm, cm, cm, cm};
 
-  d4 sacc[NDT];   // statistics tiles: rows = this wave's 16 mixtures, cols = 16 of the 2*DJ columns [x | x^2]
+  d4 sacc[kStats ? NDT : 1];   // statistics tiles: rows = this wave's 16 mixtures, cols = 16 of the 2*DJ columns [x | x^2]
   double s0l = 0.0;   // sum over this lane's frames of gamma[f][m = 16 wave + lcol]
 #pragma unroll
-  for (int j = 0; j < NDT; ++j) sacc[j] = d4{0, 0, 0, 0};
+  for (int j = 0; j < (kStats ? NDT : 1); ++j) sacc[j] = d4{0, 0, 0, 0};
   double llacc = 0.0;
 
   const int64_t nblocks = (N + FB - 1) / FB;
   // ---- x staging by LDS-DMA (global_load_lds_dwordx4: 16 bytes per lane straight into LDS, no VGPRs -- the kernel has
   //      none to spare): a wave-instruction fills 1 KB of the padded [FB][RSX] image; lanes that fall into a row's
   //      16-byte pad, and frames beyond N, fetch a valid address (frame N-1 / the block start) and are never used ----
-  constexpr int ROWB = RSX * 8, NCHUNK = (FB * ROWB + 1023) / 1024;
-  static_assert(FB * ROWB % 1024 == 0, "the padded block image is a whole number of 1 KB wave-instructions");
+  constexpr int ROWB = RSX * 8, NCHUNK = XBUF / 128;      // (the last wave-instruction may run into the buffer's padding)
   auto stage = [&](int64_t f0, double *dst) {
     const char *base = reinterpret_cast<const char *>(X + f0 * DJ);          // workgroup-uniform 64-bit base,
     const int last = (int)((N - 1 - f0 < FB - 1) ? N - 1 - f0 : FB - 1);     // 32-bit per-lane offsets
@@ -175,7 +189,7 @@ estep_mfma_kernel(const double *__restrict__ X, int64_t N, int M, const double *
       const int q = wave + 8 * i;
       if (q < NCHUNK) {                                          // wave-uniform
         const int o = 1024 * q + 16 * lane_v, row = o / ROWB, col = o - row * ROWB;
-        const int rowc = row < last ? row : last;
+        const int rowc = row < last ? row : last;      // (also rows >= FB of the padding)
         const unsigned off = (col < DJ * 8) ? (unsigned)(rowc * (DJ * 8) + col) : 0u;
         const char *src = base + off;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
@@ -190,115 +204,142 @@ estep_mfma_kernel(const double *__restrict__ X, int64_t N, int M, const double *
   int cur = 0;
   for (int64_t blk = blockIdx.x; blk < nblocks; blk += gridDim.x, cur ^= 1) {
     const int64_t f0 = blk * FB;
-    const double *xs = xbuf + cur * FB * RSX;
-    // ---- step A: l[m][f] = c_m + sum_k W[m][k] Xe[k][f],  Xe = [x^2 ; x] ----
+    const double *xs = xbuf + cur * XBUF;
+    double gpre[kGamma ? 1 : FB / 4];         // PHASE 2: this lane's responsibilities of the block, fetched before the products
+    if constexpr (kGamma) {
+      // ---- step A: l[m][f] = c_m + sum_k W[m][k] Xe[k][f],  Xe = [x^2 ; x] ----
 #pragma unroll
-    for (int ft = 0; ft < FB / 16; ++ft) {
-      d4 acc = cin;
-      const double *xr = xs + (16 * ft + lcol) * RSX + lgrp;
+      for (int ft = 0; ft < FB / 16; ++ft) {
+        d4 acc = cin;
+        const double *xr = xs + (16 * ft + lcol) * RSX + lgrp;
 #pragma unroll
-      for (int ks = 0; ks < KS / 2; ++ks) {
-        const double x = xr[4 * ks];
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x * x, wfrag[ks], acc, 0, 0, 0);
+        for (int ks = 0; ks < KS / 2; ++ks) {
+          const double x = xr[4 * ks];
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x * x, wfrag[ks], acc, 0, 0, 0);
+          if constexpr (C::SPLIT) {         // 160 registers hold W: keep the operand reads from running far ahead
+            if ((ks & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+#pragma unroll
+        for (int ks = 0; ks < KS / 2; ++ks) {
+          const double x = xr[4 * ks];
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x, wfrag[KS / 2 + ks], acc, 0, 0, 0);
+          if constexpr (C::SPLIT) {
+            if ((ks & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) lg[(16 * ft + 4 * r + lgrp) * RSG + 16 * wave + lcol] = acc[r];
       }
+      __syncthreads();
+      // ---- softmax over the 128 mixture slots of each frame.  16 lanes per frame, lane lcol owns slots lcol + 16 i:
+      //      per instruction a 32-lane group touches 2 frame rows x 16 consecutive doubles, which with RSG == 16 mod 32
+      //      is conflict-free (same pattern as step B's gamma reads) ----
+      // the next block streams in from here on (issued in the phase with the lowest register pressure; it has the
+      // softmax and step B to land)
+      if (blk + gridDim.x < nblocks) stage((blk + gridDim.x) * FB, xbuf + (cur ^ 1) * XBUF);
 #pragma unroll
-      for (int ks = 0; ks < KS / 2; ++ks) {
-        const double x = xr[4 * ks];
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x, wfrag[KS / 2 + ks], acc, 0, 0, 0);
-      }
+      for (int ps = 0; ps < FB / 32; ++ps) {
+        const int f = 32 * ps + 4 * wave + lgrp;
+        double *row = lg + f * RSG + lcol;
+        double v[C::MMAX / 16];
+        double u = -INFINITY;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) lg[(16 * ft + 4 * r + lgrp) * RSG + 16 * wave + lcol] = acc[r];
-    }
-    __syncthreads();
-    // ---- softmax over the 128 mixture slots of each frame.  16 lanes per frame, lane lcol owns slots lcol + 16 i:
-    //      per instruction a 32-lane group touches 2 frame rows x 16 consecutive doubles, which with RSG == 16 mod 32
-    //      is conflict-free (same pattern as step B's gamma reads) ----
-    // the next block streams in from here on (issued in the phase with the lowest register pressure; it has the
-    // softmax and step B to land)
-    if (blk + gridDim.x < nblocks) stage((blk + gridDim.x) * FB, xbuf + (cur ^ 1) * FB * RSX);
+        for (int i = 0; i < C::MMAX / 16; ++i) {
+          v[i] = row[16 * i];
+          u = fmax(u, v[i]);
+        }
 #pragma unroll
-    for (int ps = 0; ps < FB / 32; ++ps) {
-      const int f = 32 * ps + 4 * wave + lgrp;
-      double *row = lg + f * RSG + lcol;
-      double v[C::MMAX / 16];
-      double u = -INFINITY;
+        for (int sh = 1; sh < 16; sh <<= 1) u = fmax(u, __shfl_xor(u, sh));
+        // ---- refinement.  The GEMM form  x^2 (-1/2var) + x (mu/var) + c  cancels: with var down to min_covar = 1e-7 and
+        //      |mu| ~ 10 its terms reach 1e9 and l carries an absolute error of ~1e-7.  That is harmless while one mixture
+        //      owns the frame (gamma = 1 whatever l is) and wrong when several compete: the responsibilities inherit the
+        //      error.  So when more than one mixture is within kRefine of the frame's maximum, exactly those are
+        //      re-evaluated term by term, (x - mu)^2 / var summed over d, as the reference formula reads.
+        //      The kernel sits at the register cap: the re-evaluation works on the LDS copy of l with run-time loops
+        //      (nothing of v[] stays live across it) and the softmax then reloads its eight values. ----
+        {
+          constexpr double kRefine = 36.0;   // e^-36 = 2e-16: a mixture further below the maximum cannot change a sum
+          int nc = 0;
 #pragma unroll
-      for (int i = 0; i < C::MMAX / 16; ++i) {
-        v[i] = row[16 * i];
-        u = fmax(u, v[i]);
-      }
+          for (int i = 0; i < C::MMAX / 16; ++i) nc += (v[i] > u - kRefine) ? 1 : 0;
 #pragma unroll
-      for (int sh = 1; sh < 16; sh <<= 1) u = fmax(u, __shfl_xor(u, sh));
-      // ---- refinement.  The GEMM form  x^2 (-1/2var) + x (mu/var) + c  cancels: with var down to min_covar = 1e-7 and
-      //      |mu| ~ 10 its terms reach 1e9 and l carries an absolute error of ~1e-7.  That is harmless while one mixture
-      //      owns the frame (gamma = 1 whatever l is) and wrong when several compete: the responsibilities inherit the
-      //      error.  So when more than one mixture is within kRefine of the frame's maximum, exactly those are
-      //      re-evaluated term by term, (x - mu)^2 / var summed over d, as the reference formula reads.
-      //      The kernel sits at the register cap: the re-evaluation works on the LDS copy of l with run-time loops
-      //      (nothing of v[] stays live across it) and the softmax then reloads its eight values. ----
-      {
-        constexpr double kRefine = 36.0;   // e^-36 = 2e-16: a mixture further below the maximum cannot change a sum
-        int nc = 0;
-#pragma unroll
-        for (int i = 0; i < C::MMAX / 16; ++i) nc += (v[i] > u - kRefine) ? 1 : 0;
-#pragma unroll
-        for (int sh = 1; sh < 16; sh <<= 1) nc += __shfl_xor(nc, sh);
-        if (nc > 1) {
-          const double thr = u - kRefine;
-          const double *xf = xs + f * RSX;
+          for (int sh = 1; sh < 16; sh <<= 1) nc += __shfl_xor(nc, sh);
+          if (nc > 1) {
+            const double thr = u - kRefine;
+            const double *xf = xs + f * RSX;
 #pragma unroll 1
-          for (int i = 0; i < C::MMAX / 16; ++i) {
-            const double li = row[16 * i];
-            if (li > thr) {
-              const int m = lcol + 16 * i;
-              const double *mp = refmu + (size_t)DJ * m, *ip = refiv + (size_t)DJ * m;
-              double q = 0.0;
+            for (int i = 0; i < C::MMAX / 16; ++i) {
+              const double li = row[16 * i];
+              if (li > thr) {
+                const int m = lcol + 16 * i;
+                const double *mp = refmu + (size_t)DJ * m, *ip = refiv + (size_t)DJ * m;
+                double q = 0.0;
 #pragma unroll 2
-              for (int d = 0; d < DJ; ++d) {
-                const double df = xf[d] - mp[d];
-                q = fma(df * df, ip[d], q);
+                for (int d = 0; d < DJ; ++d) {
+                  const double df = xf[d] - mp[d];
+                  q = fma(df * df, ip[d], q);
+                }
+                row[16 * i] = refc[m] - 0.5 * q;
               }
-              row[16 * i] = refc[m] - 0.5 * q;
             }
-          }
-          u = -INFINITY;
+            u = -INFINITY;
 #pragma unroll
-          for (int i = 0; i < C::MMAX / 16; ++i) {
-            v[i] = row[16 * i];
-            u = fmax(u, v[i]);
-          }
+            for (int i = 0; i < C::MMAX / 16; ++i) {
+              v[i] = row[16 * i];
+              u = fmax(u, v[i]);
+            }
 #pragma unroll
-          for (int sh = 1; sh < 16; sh <<= 1) u = fmax(u, __shfl_xor(u, sh));
+            for (int sh = 1; sh < 16; sh <<= 1) u = fmax(u, __shfl_xor(u, sh));
+          }
+        }
+        double s = 0.0;
+#pragma unroll
+        for (int i = 0; i < C::MMAX / 16; ++i) {
+          v[i] = exp(v[i] - u);
+          s += v[i];
+        }
+#pragma unroll
+        for (int sh = 1; sh < 16; sh <<= 1) s += __shfl_xor(s, sh);
+        const bool livef = (f0 + f < N);
+        const double inv = livef ? 1.0 / s : 0.0;          // frames beyond N contribute gamma = 0
+#pragma unroll
+        for (int i = 0; i < C::MMAX / 16; ++i) row[16 * i] = v[i] * inv;
+        if (lcol == 0 && livef) llacc += u + log(s);
+      }
+      __syncthreads();
+      if constexpr (PHASE == 1) {               // responsibilities -> G, rows of 128, coalesced
+#pragma unroll
+        for (int i = 0; i < FB * C::MMAX / 512; ++i) {
+          const int e = tid + 512 * i, f = e / C::MMAX, m = e - f * C::MMAX;
+          if (f0 + f < N) G[(f0 + f) * C::MMAX + m] = lg[f * RSG + m];
         }
       }
-      double s = 0.0;
+    } else {
+      if (blk + gridDim.x < nblocks) stage((blk + gridDim.x) * FB, xbuf + (cur ^ 1) * XBUF);
 #pragma unroll
-      for (int i = 0; i < C::MMAX / 16; ++i) {
-        v[i] = exp(v[i] - u);
-        s += v[i];
+      for (int ks = 0; ks < FB / 4; ++ks) {
+        const int64_t f = f0 + 4 * ks + lgrp;
+        gpre[ks] = (f < N) ? G[f * C::MMAX + 16 * wave + lcol] : 0.0;     // frames beyond N contribute gamma = 0
       }
-#pragma unroll
-      for (int sh = 1; sh < 16; sh <<= 1) s += __shfl_xor(s, sh);
-      const bool livef = (f0 + f < N);
-      const double inv = livef ? 1.0 / s : 0.0;          // frames beyond N contribute gamma = 0
-#pragma unroll
-      for (int i = 0; i < C::MMAX / 16; ++i) row[16 * i] = v[i] * inv;
-      if (lcol == 0 && livef) llacc += u + log(s);
     }
-    __syncthreads();
     // ---- step B: S[m][c] += sum_f gamma[f][m] Xe[f][c],  Xe = [x | x^2];  S0[m] += sum_f gamma[f][m] ----
-#pragma unroll 4
-    for (int ks = 0; ks < FB / 4; ++ks) {
-      const int f = 4 * ks + lgrp;
-      const double gm = lg[f * RSG + 16 * wave + lcol];
-      const double *xr = xs + f * RSX + lcol;
+    if constexpr (kStats) {
+#pragma unroll kStepBUnroll
+      for (int ks = 0; ks < FB / 4; ++ks) {
+        const int f = 4 * ks + lgrp;
+        double gm;
+        if constexpr (PHASE == 0) gm = lg[f * RSG + 16 * wave + lcol];
+        else gm = gpre[ks];
+        const double *xr = xs + f * RSX + lcol;
 #pragma unroll
-      for (int j = 0; j < NDT / 2; ++j) {
-        const double x = xr[16 * j];
-        sacc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(gm, x, sacc[j], 0, 0, 0);
-        sacc[NDT / 2 + j] = __builtin_amdgcn_mfma_f64_16x16x4f64(gm, x * x, sacc[NDT / 2 + j], 0, 0, 0);
+        for (int j = 0; j < NDT / 2; ++j) {
+          const double x = xr[16 * j];
+          sacc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(gm, x, sacc[j], 0, 0, 0);
+          sacc[NDT / 2 + j] = __builtin_amdgcn_mfma_f64_16x16x4f64(gm, x * x, sacc[NDT / 2 + j], 0, 0, 0);
+        }
+        s0l += gm;
       }
-      s0l += gm;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next block's LDS-DMA has landed
     __syncthreads();
@@ -306,28 +347,31 @@ estep_mfma_kernel(const double *__restrict__ X, int64_t N, int M, const double *
 
   // ---- write this workgroup's partial statistics: rows m = 16 wave + lgrp + 4 r, cols = 16 j + lcol ----
   double *P = part + (size_t)blockIdx.x * plen;
-  s0l += __shfl_xor(s0l, 16);
-  s0l += __shfl_xor(s0l, 32);
-  if (lgrp == 0 && 16 * wave + lcol < M) P[16 * wave + lcol] = s0l;
+  if constexpr (kStats) {
+    s0l += __shfl_xor(s0l, 16);
+    s0l += __shfl_xor(s0l, 32);
+    if (lgrp == 0 && 16 * wave + lcol < M) P[16 * wave + lcol] = s0l;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int m = 16 * wave + 4 * r + lgrp;
-    if (m < M) {
+    for (int r = 0; r < 4; ++r) {
+      const int m = 16 * wave + 4 * r + lgrp;
+      if (m < M) {
 #pragma unroll
-      for (int j = 0; j < NDT; ++j) {
-        const int c = 16 * j + lcol;   // column of [x | x^2]
-        if (c < DJ) P[M + (size_t)m * DJ + c] = sacc[j][r];
-        else P[M + (size_t)M * DJ + (size_t)m * DJ + (c - DJ)] = sacc[j][r];
+        for (int j = 0; j < NDT; ++j) {
+          const int c = 16 * j + lcol;   // column of [x | x^2]
+          if (c < DJ) P[M + (size_t)m * DJ + c] = sacc[j][r];
+          else P[M + (size_t)M * DJ + (size_t)m * DJ + (c - DJ)] = sacc[j][r];
+        }
       }
     }
   }
-  // log-likelihood: fixed-order reduction inside the workgroup
-  red[tid] = llacc;
-  __syncthreads();
-  if (tid == 0) {
-    double ll = 0.0;
-    for (int i = 0; i < 512; ++i) ll += red[i];
-    P[plen - 1] = ll;
+  if constexpr (kGamma) {   // log-likelihood: fixed-order reduction inside the workgroup
+    red[tid] = llacc;
+    __syncthreads();
+    if (tid == 0) {
+      double ll = 0.0;
+      for (int i = 0; i < 512; ++i) ll += red[i];
+      P[plen - 1] = ll;
+    }
   }
 }
 
@@ -450,16 +494,39 @@ static int estep_mfma_launch(EstepScratch &sc, const double *dX, int64_t N, int 
   hipLaunchKernelGGL(estep_prep_kernel<DJ>, dim3((8 * C::KS * 64 + 255) / 256), dim3(256), 0, st, draw, M, sc.Wpack.p,
                      sc.cinit.p, sc.refiv.p, sc.refc.p);
   VCMI_HIP(hipGetLastError());
-  auto kern = estep_mfma_kernel<DJ>;
-  VCMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)C::LDS_BYTES));
-  // (the means of the re-evaluation are the uploaded parameters themselves: raw = [w | mu (Dj,M) | var (Dj,M)])
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), C::LDS_BYTES, st, dX, N, M, sc.Wpack.p, sc.cinit.p, sc.part.p, plen,
-                     draw + M, sc.refiv.p, sc.refc.p);
-  VCMI_HIP(hipGetLastError());
-  hipLaunchKernelGGL(estep_reduce_kernel, dim3((unsigned)((plen + 255) / 256)), dim3(256), 0, st, sc.part.p, grid, plen,
-                     dstats);
-  VCMI_HIP(hipGetLastError());
+  const double *dmu = draw + M;      // (the means of the re-evaluation are the uploaded parameters themselves: raw = [w | mu (Dj,M) | var (Dj,M)])
+  if constexpr (!C::SPLIT) {
+    auto kern = estep_mfma_kernel<DJ, 0>;
+    VCMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)C::LDS_BYTES));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), C::LDS_BYTES, st, dX, N, M, sc.Wpack.p, sc.cinit.p, sc.part.p, plen, dmu,
+                       sc.refiv.p, sc.refc.p, (double *)nullptr);
+    VCMI_HIP(hipGetLastError());
+    hipLaunchKernelGGL(estep_reduce_kernel, dim3((unsigned)((plen + 255) / 256)), dim3(256), 0, st, sc.part.p, grid, plen,
+                       dstats);
+    VCMI_HIP(hipGetLastError());
+  } else {
+    // two kernels per chunk of frames, the responsibilities (frames x 128 doubles) through HBM in between
+    constexpr int64_t kSplitChunk = 1 << 20;
+    const int64_t ch = std::min<int64_t>(N, kSplitChunk);
+    VCMI_TRY(sc.G.reserve((size_t)ch * C::MMAX));
+    auto kg = estep_mfma_kernel<DJ, 1>;
+    auto ks = estep_mfma_kernel<DJ, 2>;
+    VCMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kg), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES));
+    VCMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ks), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES));
+    for (int64_t n0 = 0; n0 < N; n0 += kSplitChunk) {
+      const int64_t nfr = std::min<int64_t>(kSplitChunk, N - n0);
+      const int g2 = (int)std::min<int64_t>((nfr + C::FB - 1) / C::FB, cus);
+      hipLaunchKernelGGL(kg, dim3(g2), dim3(512), C::LDS_BYTES, st, dX + n0 * DJ, nfr, M, sc.Wpack.p, sc.cinit.p, sc.part.p, plen,
+                         dmu, sc.refiv.p, sc.refc.p, sc.G.p);
+      hipLaunchKernelGGL(ks, dim3(g2), dim3(512), C::LDS_BYTES, st, dX + n0 * DJ, nfr, M, sc.Wpack.p, sc.cinit.p, sc.part.p, plen,
+                         dmu, sc.refiv.p, sc.refc.p, sc.G.p);
+      VCMI_HIP(hipGetLastError());
+      hipLaunchKernelGGL(estep_reduce_kernel, dim3((unsigned)((plen + 255) / 256)), dim3(256), 0, st, sc.part.p, g2, plen,
+                         dstats);
+      VCMI_HIP(hipGetLastError());
+    }
+  }
   return VCMI_OK;
 }
 
@@ -476,8 +543,8 @@ static int estep_device(const double *dX, int64_t N, int Dj, int M, const double
   VCMI_HIP(hipMemsetAsync(dstats, 0, plen * sizeof(double), st));
   if (N == 0) return VCMI_OK;
 
-  // MFMA instantiations: the joint dimensions of the shipped configurations (Dj = 80: 40-dimensional joint features with
-  // deltas; 32, 48, 64: 8-, 12-, 16-dimensional mel-cepstra with deltas); any other Dj, and M > 128, take the generic
+  // MFMA instantiations: the joint dimensions of the shipped configurations (Dj = 80: 40-dimensional joint features; 160:
+  // the same with --add_delta; 32, 48, 64: lower mel-cepstrum orders); any other Dj, and M > 128, take the generic
   // kernels below.
   if (M <= EstepCfg<80>::MMAX && !debug_flag(kDbgEstepGeneric)) {
     switch (Dj) {
@@ -485,6 +552,7 @@ static int estep_device(const double *dX, int64_t N, int Dj, int M, const double
       case 48: return estep_mfma_launch<48>(sc, dX, N, M, w, mu, var, dstats, plen, st);
       case 64: return estep_mfma_launch<64>(sc, dX, N, M, w, mu, var, dstats, plen, st);
       case 80: return estep_mfma_launch<80>(sc, dX, N, M, w, mu, var, dstats, plen, st);
+      case 160: return estep_mfma_launch<160>(sc, dX, N, M, w, mu, var, dstats, plen, st);
       default: break;
     }
   }
