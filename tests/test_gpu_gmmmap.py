@@ -151,3 +151,22 @@ def test_linearity_at_full_size(vc):
     from oracle import c_oracle as co
     ref = co.GMMMap(w, mu, sig).fvconvert(base[:256])
     assert frame_relerr(first[:256].cpu().numpy().T, ref.T) < TOL
+
+
+@pytest.mark.parametrize("kernel", [0, 1])
+@pytest.mark.parametrize("D,M,T", [(160, 3, 333), (100, 4, 130), (84, 2, 1)])
+def test_posterior_beyond_80_dimensions(vc, D, M, T, kernel):
+    """80 < D <= 160 (e.g. the 160-dimensional joint GMM of delta-augmented features): the log-densities come from the
+    tiled MFMA kernel (whitening blocks streamed through LDS; kernel 0 = automatic choice) -- against the oracle and
+    against the generic kernel (kernel 1).  D = 100 and 84 end in a partial row tile."""
+    from oracle import np_oracle as npo
+    w, mu, sig = npo.synth_model(7000 + D, 2 * D, M, lam_lo=1e-3)
+    X = npo.sample_frames(7001 + D, w, mu, sig, T, 0, D)
+    ref = npo.GMMMap(w, mu, sig)
+    P_ref = ref.predict_proba(X)
+    g = vc.GMMMap(*julia_model(w, mu, sig))
+    g.set_kernel(kernel)
+    P = vc.predict_proba(g.px, X.T)
+    assert P.shape == (M, T)
+    assert np.max(np.abs(P - P_ref.T)) < 1e-9
+    assert np.array_equal(vc.predict(g.px, X.T), ref.predict(X))

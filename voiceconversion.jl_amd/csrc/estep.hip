@@ -19,6 +19,7 @@
 //  * generic kernels (any Dj, M): gamma to an HBM workspace in chunks, then per-(m,d) sequential accumulation
 //    over fixed frame segments, then a fixed-order reduction.
 #include "vcmi_common.hpp"
+#include <atomic>
 #include "gmmmap_handle.hpp"
 #include "devgroup.hpp"
 #include "hostpipe.hpp"
@@ -660,40 +661,67 @@ estep_sum_kernel(const double *__restrict__ v, int64_t n, double *__restrict__ o
 
 static constexpr int kFullFB = 32;   // frames per staged block (double-buffered in LDS)
 
-template <int DJ>
-__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
-estep_full_stats_kernel(const double *__restrict__ X, int64_t n0, int64_t n, int M, const double *__restrict__ G,
-                        double *__restrict__ part, int64_t plen) {
+// lower tiles of a (16 NTL)^2 symmetric matrix in row-major order: tile t -> (row tile a, column tile j <= a)
+__host__ __device__ constexpr int full_tile_a(int t) {
+  int a = 0;
+  while ((a + 1) * (a + 2) / 2 <= t) ++a;
+  return a;
+}
+__host__ __device__ constexpr int full_tile_j(int t) { return t - full_tile_a(t) * (full_tile_a(t) + 1) / 2; }
+
+// the tiles [T0, T0 + NTP) as compile-time tables: row / column tile of each, and which x tiles they read as rows / columns
+template <int T0, int NTP>
+struct FullTileList {
+  int a[NTP > 0 ? NTP : 1], j[NTP > 0 ? NTP : 1];
+  unsigned rows, cols;
+  constexpr FullTileList() : a{}, j{}, rows(0), cols(0) {
+    for (int t = 0; t < NTP; ++t) {
+      a[t] = full_tile_a(T0 + t);
+      j[t] = full_tile_j(T0 + t);
+      rows |= 1u << a[t];
+      cols |= 1u << j[t];
+    }
+  }
+};
+
+template <int DJ, int PARTS>
+struct FullStatsCfg {
+  static constexpr int NTL = DJ / 16, NTILES = NTL * (NTL + 1) / 2;
+  static constexpr int TPP = (NTILES + PARTS - 1) / PARTS;     // tiles per part (consecutive tiles: few distinct operands)
+  static constexpr int NM = 8 / PARTS;                          // mixtures per workgroup
   // row stride == 16 (mod 32) doubles: the four 16-lane groups of an operand read (4 consecutive frames) then fall in
   // disjoint halves of the 64 LDS banks per half-wave
-  constexpr int NTL = DJ / 16, RSX = (DJ % 32 == 16) ? DJ : DJ + 16, FB = kFullFB;
-  constexpr int NPF = (FB * DJ + 511) / 512;           // staged doubles per thread per block
-  static_assert(DJ % 16 == 0, "full-covariance MFMA statistics need Dj to be a multiple of 16");
-  __shared__ double xs[2][FB * RSX];
-  __shared__ double gs[2][FB * 8];
+  static constexpr int RSX = (DJ % 32 == 16) ? DJ : DJ + 16;
+  static constexpr size_t LDS_BYTES = ((size_t)2 * kFullFB * RSX + 2 * kFullFB * 8) * sizeof(double);
+};
+
+// The body of one wave: mixture `m`, tiles [PART TPP, (PART+1) TPP) of its S2 (and, for the last part, S0 and S1).
+// Wave w of an 8-wave workgroup owns mixture NM mg + w / PARTS and part w % PARTS: at DJ = 80 one wave holds all 15 lower
+// tiles of its mixture (PARTS = 1); at DJ = 160 the 55 tiles (220 accumulator registers) are shared by four waves.
+template <int DJ, int PARTS, int PART>
+__device__ __forceinline__ void estep_full_stats_body(const double *__restrict__ X, int64_t n0, int64_t f_begin, int64_t f_end,
+                                                      int M, int mg, const double *__restrict__ G, double *__restrict__ P,
+                                                      double *xs, double *gs) {
+  using C = FullStatsCfg<DJ, PARTS>;
+  constexpr int NTL = C::NTL, RSX = C::RSX, FB = kFullFB, NM = C::NM;
+  constexpr int T0 = PART * C::TPP, T1 = (T0 + C::TPP < C::NTILES) ? T0 + C::TPP : C::NTILES, NTP = T1 - T0;
+  constexpr bool kFirstMoments = PART == PARTS - 1;        // the last part has the fewest tiles: it also sums S0 and S1
+  constexpr int NPF = (FB * DJ + 511) / 512;               // staged doubles per thread per block
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lcol = lane & 15, lgrp = lane >> 4;
-  // grid = (frame segments, mixture groups): consecutive workgroups go to consecutive XCDs, so with the segment as the
-  // FAST index the mixture groups that read one segment of X share an XCD (when the segment count is a multiple of 8)
-  // and X reaches that L2 once instead of once per mixture group
-  const int mg = blockIdx.y, seg = blockIdx.x, nsegs = gridDim.x;
-  const int m = mg * 8 + wave;                         // this wave's mixture (may be >= M: then gamma is staged as 0)
-  const int64_t seglen = (n + nsegs - 1) / nsegs;
-  const int64_t f_begin = seg * seglen, f_end = (f_begin + seglen < n) ? f_begin + seglen : n;
+  const int ml = wave / PARTS, m = mg * NM + ml;           // this wave's mixture (may be >= M: then gamma is staged as 0)
 
-  d4 acc[NTL][NTL];                                    // lower tiles only (j <= a)
+  d4 acc[NTP > 0 ? NTP : 1];
 #pragma unroll
-  for (int a = 0; a < NTL; ++a)
-#pragma unroll
-    for (int j = 0; j <= a; ++j) acc[a][j] = d4{0, 0, 0, 0};
+  for (int t = 0; t < NTP; ++t) acc[t] = d4{0, 0, 0, 0};
   double s1[NTL], s0 = 0.0;
 #pragma unroll
   for (int a = 0; a < NTL; ++a) s1[a] = 0.0;
 
   double pf[NPF], pg = 0.0;
-  const int gf = tid >> 3, gq = tid & 7;               // gamma staging: 32 frames x 8 mixtures = threads 0..255
-  const int gm_idx = mg * 8 + gq;
-  auto fetch = [&](int64_t fb) {                       // global -> registers (the block's frames are contiguous in X)
+  const int gf = tid / NM, gq = tid % NM;                 // gamma staging: FB frames x NM mixtures
+  const int gm_idx = mg * NM + gq;
+  auto fetch = [&](int64_t fb) {                           // global -> registers (the block's frames are contiguous in X)
     const int64_t lim = (f_end - fb) * DJ;
     const double *src = X + (n0 + fb) * DJ;
 #pragma unroll
@@ -701,16 +729,17 @@ estep_full_stats_kernel(const double *__restrict__ X, int64_t n0, int64_t n, int
       const int e = tid + 512 * i;
       pf[i] = (e < FB * DJ && e < lim) ? src[e] : 0.0;
     }
-    pg = (tid < FB * 8 && fb + gf < f_end && gm_idx < M) ? G[(fb + gf) * M + gm_idx] : 0.0;
+    pg = (tid < FB * NM && fb + gf < f_end && gm_idx < M) ? G[(fb + gf) * M + gm_idx] : 0.0;
   };
-  auto stash = [&](int buf) {                          // registers -> LDS
+  auto stash = [&](int buf) {                              // registers -> LDS
 #pragma unroll
     for (int i = 0; i < NPF; ++i) {
       const int e = tid + 512 * i;
-      if (e < FB * DJ) xs[buf][(e / DJ) * RSX + (e % DJ)] = pf[i];
+      if (e < FB * DJ) xs[buf * FB * RSX + (e / DJ) * RSX + (e % DJ)] = pf[i];
     }
-    if (tid < FB * 8) gs[buf][gf * 8 + gq] = pg;
+    if (tid < FB * NM) gs[buf * FB * 8 + gf * NM + gq] = pg;
   };
+  constexpr FullTileList<T0, NTP> TL{};                   // which x tiles this part reads, which of them it scales by gamma
 
   if (f_begin < f_end) {
     fetch(f_begin);
@@ -721,54 +750,78 @@ estep_full_stats_kernel(const double *__restrict__ X, int64_t n0, int64_t n, int
   for (int64_t fb = f_begin; fb < f_end; fb += FB, buf ^= 1) {
     const bool more = fb + FB < f_end;
     if (more) fetch(fb + FB);
-    const double *xb = xs[buf], *gb = gs[buf];
+    const double *xb = xs + buf * FB * RSX, *gb = gs + buf * FB * 8;
 #pragma unroll 2
     for (int ks = 0; ks < FB / 4; ++ks) {
       const int f = 4 * ks + lgrp;
-      const double gm = gb[f * 8 + wave];
+      const double gm = gb[f * NM + ml];
       const double *xr = xb + f * RSX + lcol;
       double xv[NTL], ax[NTL];
 #pragma unroll
       for (int a = 0; a < NTL; ++a) {
-        xv[a] = xr[16 * a];
-        ax[a] = gm * xv[a];
-        s1[a] += ax[a];
+        if (kFirstMoments || (((TL.rows | TL.cols) >> a) & 1u)) xv[a] = xr[16 * a];
+        if (kFirstMoments || ((TL.rows >> a) & 1u)) ax[a] = gm * xv[a];
+        if (kFirstMoments) s1[a] += ax[a];
       }
-      s0 += gm;
+      if (kFirstMoments) s0 += gm;
 #pragma unroll
-      for (int a = 0; a < NTL; ++a)
-#pragma unroll
-        for (int j = 0; j <= a; ++j) acc[a][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(ax[a], xv[j], acc[a][j], 0, 0, 0);
+      for (int t = 0; t < NTP; ++t)
+        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(ax[TL.a[t]], xv[TL.j[t]], acc[t], 0, 0, 0);
     }
     if (more) stash(buf ^ 1);
     __syncthreads();
   }
   if (m >= M) return;
   // partial statistics of this (mixture, segment) in the final layout [S0 | S1 | S2 | loglik]
-  double *P = part + (size_t)seg * plen;
-  s0 += __shfl_xor(s0, 16);
-  s0 += __shfl_xor(s0, 32);
-  if (lane == 0) P[m] = s0;
+  if (kFirstMoments) {
+    s0 += __shfl_xor(s0, 16);
+    s0 += __shfl_xor(s0, 32);
+    if (lane == 0) P[m] = s0;
 #pragma unroll
-  for (int a = 0; a < NTL; ++a) {
-    double v = s1[a];
-    v += __shfl_xor(v, 16);
-    v += __shfl_xor(v, 32);
-    if (lgrp == 0) P[M + (size_t)m * DJ + 16 * a + lcol] = v;
+    for (int a = 0; a < NTL; ++a) {
+      double v = s1[a];
+      v += __shfl_xor(v, 16);
+      v += __shfl_xor(v, 32);
+      if (lgrp == 0) P[M + (size_t)m * DJ + 16 * a + lcol] = v;
+    }
   }
   double *S2 = P + M + (size_t)M * DJ + (size_t)m * DJ * DJ;      // (Dj,Dj) column-major
 #pragma unroll
-  for (int a = 0; a < NTL; ++a)
+  for (int t = 0; t < NTP; ++t) {
+    const int a = TL.a[t], j = TL.j[t];
 #pragma unroll
-    for (int j = 0; j <= a; ++j)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int i = 16 * a + lgrp + 4 * r, jc = 16 * j + lcol;  // D[i][jc]
-        if (a != j || i >= jc) {                                   // diagonal tiles: lower part only, then mirrored
-          S2[i + (size_t)DJ * jc] = acc[a][j][r];
-          S2[jc + (size_t)DJ * i] = acc[a][j][r];
-        }
+    for (int r = 0; r < 4; ++r) {
+      const int i = 16 * a + lgrp + 4 * r, jc = 16 * j + lcol;    // D[i][jc]
+      if (a != j || i >= jc) {                                     // diagonal tiles: lower part only, then mirrored
+        S2[i + (size_t)DJ * jc] = acc[t][r];
+        S2[jc + (size_t)DJ * i] = acc[t][r];
       }
+    }
+  }
+}
+
+template <int DJ, int PARTS>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+estep_full_stats_kernel(const double *__restrict__ X, int64_t n0, int64_t n, int M, const double *__restrict__ G,
+                        double *__restrict__ part, int64_t plen) {
+  static_assert(DJ % 16 == 0, "full-covariance MFMA statistics need Dj to be a multiple of 16");
+  static_assert(PARTS == 1 || PARTS == 2 || PARTS == 4, "waves per mixture");
+  using C = FullStatsCfg<DJ, PARTS>;
+  extern __shared__ double fsm[];
+  double *xs = fsm;                                     // [2][FB][RSX]
+  double *gs = fsm + 2 * kFullFB * C::RSX;              // [2][FB][8]
+  // grid = (frame segments, mixture groups): consecutive workgroups go to consecutive XCDs, so with the segment as the
+  // FAST index the mixture groups that read one segment of X share an XCD (when the segment count is a multiple of 8)
+  // and X reaches that L2 once instead of once per mixture group
+  const int mg = blockIdx.y, seg = blockIdx.x, nsegs = gridDim.x;
+  const int64_t seglen = (n + nsegs - 1) / nsegs;
+  const int64_t f_begin = seg * seglen, f_end = (f_begin + seglen < n) ? f_begin + seglen : n;
+  double *P = part + (size_t)seg * plen;
+  const int prt = (threadIdx.x >> 6) % PARTS;          // wave-uniform; every branch runs the same number of barriers
+  if (PARTS == 1 || prt == 0) estep_full_stats_body<DJ, PARTS, 0>(X, n0, f_begin, f_end, M, mg, G, P, xs, gs);
+  else if (PARTS == 2 || prt == 1) estep_full_stats_body<DJ, PARTS, 1>(X, n0, f_begin, f_end, M, mg, G, P, xs, gs);
+  else if (prt == 2) estep_full_stats_body<DJ, PARTS, (PARTS > 2 ? 2 : 0)>(X, n0, f_begin, f_end, M, mg, G, P, xs, gs);
+  else estep_full_stats_body<DJ, PARTS, (PARTS > 3 ? 3 : 0)>(X, n0, f_begin, f_end, M, mg, G, P, xs, gs);
 }
 
 // generic statistics (any Dj): thread per lower-triangle element of one mixture's S2 (+ S1, S0), sequential over the
@@ -823,11 +876,13 @@ static int estep_full_core(vcmi_gmmmap *px, const double *dX, int64_t N, int Dj,
   const int64_t chunk = std::min<int64_t>(N, (int64_t)1 << 20);
   VCMI_TRY(sc.LP.reserve((size_t)chunk * M));
   VCMI_TRY(sc.lse.reserve((size_t)kSoftmaxGrid));
-  // frame segments (grid.y): one 8-wave workgroup per CU in a single round, whatever the mixture count
-  const int mgroups = (M + 7) / 8;
+  // frame segments (grid.x): one 8-wave workgroup per CU in a single round, whatever the mixture count; a workgroup
+  // holds 8 mixtures up to Dj = 80 and 2 (four waves per mixture) beyond
+  const bool mfma = (Dj == 32 || Dj == 48 || Dj == 64 || Dj == 80 || Dj == 96 || Dj == 128 || Dj == 160) && !debug_flag(kDbgEstepGeneric);
+  const int nm = (!mfma || Dj <= 80) ? 8 : 2;
+  const int mgroups = (M + nm - 1) / nm;
   const int nseg = std::max(1, (256 + mgroups - 1) / mgroups);
   VCMI_TRY(sc.part.reserve((size_t)nseg * plen));
-  const bool mfma = (Dj == 32 || Dj == 48 || Dj == 64 || Dj == 80) && !debug_flag(kDbgEstepGeneric);
   for (int64_t n0 = 0; n0 < N; n0 += chunk) {
     const int64_t n = std::min<int64_t>(chunk, N - n0);
     VCMI_TRY(gmmmap_logdens_device(px, dX + n0 * Dj, Dj, n, sc.LP.p, st));
@@ -836,11 +891,25 @@ static int estep_full_core(vcmi_gmmmap *px, const double *dX, int64_t N, int Dj,
     VCMI_HIP(hipMemsetAsync(sc.part.p, 0, (size_t)nseg * plen * sizeof(double), st));
     const dim3 grid(nseg, mgroups);
     if (mfma) {
+      auto launch = [&](auto kern, size_t lds) -> int {
+        static std::atomic<bool> attr_done[64];           // per instantiation (the lambda is generic) and per device
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (!attr_done[dev & 63].load(std::memory_order_acquire)) {
+          VCMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+          attr_done[dev & 63].store(true, std::memory_order_release);
+        }
+        hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, dX, n0, n, M, sc.LP.p, sc.part.p, plen);
+        return VCMI_OK;
+      };
       switch (Dj) {
-        case 32: hipLaunchKernelGGL(estep_full_stats_kernel<32>, grid, dim3(512), 0, st, dX, n0, n, M, sc.LP.p, sc.part.p, plen); break;
-        case 48: hipLaunchKernelGGL(estep_full_stats_kernel<48>, grid, dim3(512), 0, st, dX, n0, n, M, sc.LP.p, sc.part.p, plen); break;
-        case 64: hipLaunchKernelGGL(estep_full_stats_kernel<64>, grid, dim3(512), 0, st, dX, n0, n, M, sc.LP.p, sc.part.p, plen); break;
-        default: hipLaunchKernelGGL(estep_full_stats_kernel<80>, grid, dim3(512), 0, st, dX, n0, n, M, sc.LP.p, sc.part.p, plen); break;
+        case 32: VCMI_TRY(launch(estep_full_stats_kernel<32, 1>, FullStatsCfg<32, 1>::LDS_BYTES)); break;
+        case 48: VCMI_TRY(launch(estep_full_stats_kernel<48, 1>, FullStatsCfg<48, 1>::LDS_BYTES)); break;
+        case 64: VCMI_TRY(launch(estep_full_stats_kernel<64, 1>, FullStatsCfg<64, 1>::LDS_BYTES)); break;
+        case 80: VCMI_TRY(launch(estep_full_stats_kernel<80, 1>, FullStatsCfg<80, 1>::LDS_BYTES)); break;
+        case 96: VCMI_TRY(launch(estep_full_stats_kernel<96, 4>, FullStatsCfg<96, 4>::LDS_BYTES)); break;
+        case 128: VCMI_TRY(launch(estep_full_stats_kernel<128, 4>, FullStatsCfg<128, 4>::LDS_BYTES)); break;
+        default: VCMI_TRY(launch(estep_full_stats_kernel<160, 4>, FullStatsCfg<160, 4>::LDS_BYTES)); break;
       }
     } else {
       hipLaunchKernelGGL(estep_full_stats_generic_kernel, dim3(M, nseg), dim3(256), 0, st, dX, n0, n, Dj, M, sc.LP.p,

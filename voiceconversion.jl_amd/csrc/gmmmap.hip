@@ -387,6 +387,188 @@ gmmmap_generic_kernel(const double *__restrict__ U, const double *__restrict__ A
 }
 
 // ------------------------------------------------------------------------------------------------
+// Log-weighted densities for 80 < D <= 16 NTMAX (e.g. the 160-dimensional joint GMM of delta-augmented features that
+// TrajectoryGMMMap is trained from): the x operands of the MFMA kernel above (D/4 k-steps x FT tiles) and a mixture's
+// whitening block (103 KB at D = 160) no longer fit registers / a double-buffered LDS block, so here
+//   * a workgroup owns 128 frames: wave w keeps the B-operand fragments of its 16 frames (D/4 doubles per lane) for the
+//     whole kernel;
+//   * the whitening blocks stream through LDS one 16-row tile at a time ("piece": rows 16r .. 16r+15, the 16(r+1)
+//     columns up to the diagonal, straight from the row-major U of the generic layout, zeros above the diagonal),
+//     double-buffered: the next piece travels global -> registers during the products of the current one;
+//   * z = U x - cz per row tile: accumulators start from -cz, 4(r+1) v_mfma_f64_16x16x4 per tile and wave, |z|^2 summed
+//     per frame across the row tiles and the four lane groups.
+// Row stride of a piece == 18 (mod 32) doubles: the 16-row fragment reads are conflict-free (as in estep.hip).
+// ------------------------------------------------------------------------------------------------
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F &f) {     // f(integral_constant<int, I>) for I .. N-1, unrolled at compile time
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
+// Stages of a mixture's whitening block: consecutive row tiles staged and multiplied together.  The first row tiles are
+// short (4, 8, 12 ... k-steps): taken one at a time their products do not cover the latency of the next piece's loads,
+// so the stages are cut to at least ~28 k-steps each (at NTMAX = 10: tiles 0-3 | 4-5 | 6 | 7 | 8 | 9).
+template <int NTMAX>
+struct TiledStages {
+  static constexpr int kMinSteps = 28;
+  int first[NTMAX], last[NTMAX], n;
+  constexpr TiledStages() : first{}, last{}, n(0) {
+    int r = 0;
+    while (r < NTMAX) {
+      int e = r, steps = 4 * (r + 1);
+      while (steps < kMinSteps && e + 1 < NTMAX) {
+        ++e;
+        steps += 4 * (e + 1);
+      }
+      first[n] = r;
+      last[n] = e;
+      ++n;
+      r = e + 1;
+    }
+  }
+  constexpr int rows(int s) const { return 16 * (last[s] - first[s] + 1); }
+  constexpr int cols(int s) const { return 16 * (last[s] + 1); }
+  constexpr int rs(int s) const { return (cols(s) + 13) / 32 * 32 + 18; }        // == 18 (mod 32): conflict-free fragment reads
+  constexpr int piece(int s) const { return rows(s) * rs(s) + rows(s); }         // + the rows' cz values
+  constexpr int max_piece() const {
+    int v = 0;
+    for (int s = 0; s < n; ++s) v = piece(s) > v ? piece(s) : v;
+    return v;
+  }
+};
+
+template <int NTMAX>
+__global__ void __launch_bounds__(512)
+logdens_tiled_kernel(const double *__restrict__ U, const double *__restrict__ cz, const double *__restrict__ lcv, int M, int D,
+                     int DP, const double *__restrict__ X, int64_t ldx, int64_t T, double *__restrict__ LP, int64_t ldy) {
+  constexpr int KSMAX = 4 * NTMAX;
+  constexpr TiledStages<NTMAX> ST{};
+  constexpr int PIECE = ST.max_piece();
+  constexpr int NPRE = 4;                               // staged pairs per thread: 512 x 4 x 2 doubles >= the largest stage
+  extern __shared__ double tsm[];                       // [2][PIECE]
+  typedef double d2 __attribute__((ext_vector_type(2)));
+  typedef double d4 __attribute__((ext_vector_type(4)));
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lcol = lane & 15, lgrp = lane >> 4;
+  const int NT = (D + 15) / 16;
+  const int64_t f = (int64_t)blockIdx.x * 128 + 16 * wave + lcol;
+  const int64_t fc = f < T ? f : T - 1;               // frames beyond T read a valid row and are not written
+
+  double xfrag[KSMAX];
+#pragma unroll
+  for (int ks = 0; ks < KSMAX; ++ks) {
+    const int k = 4 * ks + lgrp;
+    xfrag[ks] = (k < D) ? X[fc * ldx + k] : 0.0;
+  }
+
+  // staging of stage s of mixture m: element pairs (row, 2 c2) of the rows x cols block, zeros above the diagonal and
+  // beyond D
+  d2 pre[NPRE];
+  double precz = 0.0;
+  auto fetch = [&](int m, auto sc) {
+    constexpr int s = decltype(sc)::value;
+    constexpr int W2 = ST.cols(s) / 2, NP = (ST.rows(s) * W2 + 511) / 512, R0 = 16 * ST.first[s];
+    static_assert(NP <= NPRE, "stage larger than the staging registers");
+    const double *Um = U + (size_t)m * DP * DP;
+    // every load is unconditional on a clamped address (a branch or a select on the loaded value would make the wave
+    // wait for each load in turn); the zeros above the diagonal and beyond D are applied when the values go to LDS
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int e0 = tid + 512 * i, e = e0 < ST.rows(s) * W2 ? e0 : 0;
+      const int row = e / W2, c = 2 * (e - row * W2), gr = R0 + row;
+      const int grc = gr < D ? gr : D - 1, cc = c + 1 < DP ? c : DP - 2;
+      pre[i] = *reinterpret_cast<const d2 *>(Um + (size_t)grc * DP + cc);
+    }
+    const int zr = (tid < ST.rows(s) && R0 + tid < D) ? R0 + tid : 0;
+    precz = cz[(size_t)m * DP + zr];
+  };
+  auto stash = [&](double *dst, auto sc) {
+    constexpr int s = decltype(sc)::value;
+    constexpr int W2 = ST.cols(s) / 2, NP = (ST.rows(s) * W2 + 511) / 512, RS = ST.rs(s);
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int e = tid + 512 * i;
+      if (e < ST.rows(s) * W2) {
+        const int row = e / W2, c = 2 * (e - row * W2), gr = 16 * ST.first[s] + row;
+        d2 v = pre[i];
+        v.x = (gr < D && c <= gr) ? v.x : 0.0;
+        v.y = (gr < D && c + 1 <= gr) ? v.y : 0.0;
+        *reinterpret_cast<d2 *>(dst + row * RS + c) = v;
+      }
+    }
+    if (tid < ST.rows(s)) dst[ST.rows(s) * RS + tid] = (16 * ST.first[s] + tid < D) ? precz : 0.0;
+  };
+  // one stage: the next one -- (m, s+1), or (m+1, 0) -- travels global -> registers during the products, registers -> the
+  // other LDS buffer after them
+  auto step = [&](int m, auto sc, double *cur, double *nxt, double &q) {
+    constexpr int s = decltype(sc)::value;
+    constexpr int RS = ST.rs(s), SN = (s + 1 < ST.n) ? s + 1 : 0;
+    const bool more_here = (s + 1 < ST.n) && (ST.first[SN] < NT);
+    if (more_here) fetch(m, std::integral_constant<int, SN>{});
+    else if (m + 1 < M) fetch(m + 1, std::integral_constant<int, 0>{});
+#pragma unroll
+    for (int r = ST.first[s]; r <= ST.last[s]; ++r) {
+      if (r < NT) {                                     // workgroup-uniform
+        const int lr = 16 * (r - ST.first[s]);
+        // two accumulator chains (even / odd k-steps), the A fragments read four k-steps ahead of their products
+        d4 acc, acc2 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] = -cur[ST.rows(s) * RS + lr + 4 * i + lgrp];
+        const double *ap = cur + (lr + lcol) * RS + lgrp;
+        constexpr int NK = 4, AHEAD = 4;
+        const int nks = NK * (r + 1);
+        double af[AHEAD];
+#pragma unroll
+        for (int i = 0; i < AHEAD; ++i) af[i] = ap[4 * i];
+#pragma unroll
+        for (int ks = 0; ks < nks; ks += AHEAD) {
+          double an[AHEAD];
+#pragma unroll
+          for (int i = 0; i < AHEAD; ++i) an[i] = (ks + AHEAD + i < nks) ? ap[4 * (ks + AHEAD + i)] : 0.0;
+#pragma unroll
+          for (int i = 0; i < AHEAD; i += 2) {
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], xfrag[ks + i], acc, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i + 1], xfrag[ks + i + 1], acc2, 0, 0, 0);
+          }
+#pragma unroll
+          for (int i = 0; i < AHEAD; ++i) af[i] = an[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const double z = acc[i] + acc2[i];
+          q = fma(z, z, q);
+        }
+      }
+    }
+    if (more_here) stash(nxt, std::integral_constant<int, SN>{});
+    else if (m + 1 < M) stash(nxt, std::integral_constant<int, 0>{});
+    __syncthreads();
+  };
+
+  fetch(0, std::integral_constant<int, 0>{});
+  stash(tsm, std::integral_constant<int, 0>{});
+  __syncthreads();
+  int pc = 0;                                           // stages done: buffer parity
+  for (int m = 0; m < M; ++m) {
+    double q = 0.0;
+    auto run = [&](auto sc) {
+      constexpr int s = decltype(sc)::value;
+      if (s < ST.n && ST.first[s < ST.n ? s : 0] < NT) {     // workgroup-uniform
+        step(m, std::integral_constant<int, (s < ST.n ? s : 0)>{}, tsm + (pc & 1) * PIECE, tsm + ((pc & 1) ^ 1) * PIECE, q);
+        ++pc;
+      }
+    };
+    static_for<0, ST.n>(run);
+    q += __shfl_xor(q, 16);
+    q += __shfl_xor(q, 32);
+    const double lc = lcv[m];
+    if (lgrp == 0 && f < T) LP[f * ldy + m] = (lc == -INFINITY) ? -INFINITY : lc - 0.5 * q;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // (M,T) log-weighted densities -> posterior in place (MODE 0) or 1-based argmax (MODE 1).
 // One lane per frame.  Follows src/gmm.jl:28-29 (max-shifted log-sum-exp, exp(l - lse)) and :46 (first max).
 // ------------------------------------------------------------------------------------------------
@@ -495,6 +677,21 @@ int gmmmap_convert_device(vcmi_gmmmap *g, const double *dX, int64_t ldx, int64_t
 int gmmmap_logdens_device(vcmi_gmmmap *g, const double *dX, int64_t ldx, int64_t T, double *dLP, hipStream_t st) {
   if (T == 0) return VCMI_OK;
   if (use_mfma(g)) return dispatch_mfma<1>(g, dX, ldx, T, dLP, g->M, st);
+  if (g->kernel_choice != 1 && g->D > 80 && g->D <= 160) {      // tiles streamed through LDS (see logdens_tiled_kernel)
+    constexpr int NTMAX = 10;
+    constexpr TiledStages<NTMAX> ST{};
+    const size_t shmem = 2 * (size_t)ST.max_piece() * sizeof(double);
+    static std::atomic<bool> attr_done[64];
+    if (!attr_done[g->device & 63].load(std::memory_order_acquire)) {
+      VCMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(logdens_tiled_kernel<NTMAX>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+      attr_done[g->device & 63].store(true, std::memory_order_release);
+    }
+    hipLaunchKernelGGL(logdens_tiled_kernel<NTMAX>, dim3((unsigned)((T + 127) / 128)), dim3(512), shmem, st, g->U.p, g->cz.p,
+                       g->lc.p, g->M, g->D, g->DP, dX, ldx, T, dLP, (int64_t)g->M);
+    VCMI_HIP(hipGetLastError());
+    return VCMI_OK;
+  }
   return launch_generic<1>(g, dX, ldx, T, dLP, g->M, st);
 }
 
