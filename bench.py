@@ -378,7 +378,7 @@ def bench_estep_full(args, world, rank):
     import voiceconversion_jl_amd as vc
     from oracle import np_oracle as npo
 
-    Dj, M, N = 80, 64, args.frames if args.frames != 1_000_000 else 500_000
+    Dj, M, N = args.dj, 64, args.frames if args.frames != 1_000_000 else 500_000
     w, mu, sig = npo.synth_model(1005, Dj, M, lam_lo=1e-3)
     X = npo.sample_frames(1005 + rank, w, mu, sig, N, 0, Dj)
     Xd = torch.from_numpy(X).cuda()
@@ -392,20 +392,21 @@ def bench_estep_full(args, world, rank):
     wall, kernel_ms = timed_steps(step, args.steps, args.warmup, world)
     flop = 2 * M * Dj * (Dj + 1) + 2 * M * Dj
     achieved = flop * N / (kernel_ms * 1e-3) / 1e12
-    out = {"metric": "full-covariance GMM E-step frames/sec (Dj=80, M=64)", "value": world * N * args.steps / wall,
+    out = {"metric": "full-covariance GMM E-step frames/sec (Dj=%d, M=64)" % Dj, "value": world * N * args.steps / wall,
            "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "f64", "data": "synthetic",
            "config": {"workload": "full-covariance E-step (SURVEY 8f rank 1; bin/train_gmm.jl:84-103)", "Dj": Dj, "M": M,
                       "frames_per_gpu": N,
                       "collective": "all-reduce(sum) of %d doubles per step" % vc.full_stats_len(Dj, M)},
-           "roofline": {"bound": "mfma", "kernel": "whole step: gmmmap_mfma_kernel<MODE 1> + estep_full_stats_kernel<80>",
+           "roofline": {"bound": "mfma", "kernel": ("whole step: gmmmap_mfma_kernel<MODE 1> + estep_full_stats_kernel<%d,1>" % Dj) if Dj <= 80 else
+                                  ("whole step: logdens_tiled_kernel + estep_full_stats_kernel<%d,4> (+ host Cholesky of the %d-dim blocks)" % (Dj, Dj)),
                         "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                         "frac": achieved / FP64_PEAK_TFLOPS, "traffic": None, "flop_per_frame": flop, "kernel_ms": kernel_ms}}
     if rank == 0:
         from oracle import c_oracle as co
 
-        n = 40000
+        n = 40000 if Dj <= 80 else 10000
         t0 = time.perf_counter()
         r0, r1, r2, rl = co.estep_full(X[:n], w, mu, sig)
         dt = time.perf_counter() - t0
@@ -425,7 +426,7 @@ def bench_em_full(args, world, rank):
     import voiceconversion_jl_amd as vc
     from oracle import np_oracle as npo
 
-    Dj, M, N = 80, 64, args.frames if args.frames != 1_000_000 else 500_000
+    Dj, M, N = args.dj, 64, args.frames if args.frames != 1_000_000 else 500_000
     w, mu, sig = npo.synth_model(1005, Dj, M, lam_lo=1e-3)
     X = npo.sample_frames(1005 + rank, w, mu, sig, N, 0, Dj)
     Xd = torch.from_numpy(X).cuda()

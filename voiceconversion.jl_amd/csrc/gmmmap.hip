@@ -737,10 +737,19 @@ static int prepare(vcmi_gmmmap *g, const double *w, const double *mu, const doub
   g->h_mux.assign((size_t)D * M, 0.0);
   g->h_muy.assign((size_t)D * M, 0.0);
   std::vector<double> hU(pp * M, 0.0), hA(reg * pp * M, 0.0), hcz((size_t)DP * M, 0.0), hb(reg * DP * M, 0.0), hlc(M);
-  std::vector<double> Sxx(dd), Syx(dd), inv(dd), L(dd), Ui(dd);
   const int xo = (swap && !px_only) ? D : 0, yo = px_only ? 0 : (swap ? 0 : D);   // src/gmmmap.jl:74-78
   const double LOG2PI = 1.8378770664093454835606594728112;
-  for (int m = 0; m < M; ++m) {
+  // The mixtures are independent (an inverse, a Cholesky factorisation and a triangular inverse each: 64 x 160^3 flop for
+  // the joint model of delta features): they are shared out over the library's host threads.  The first failing mixture
+  // (lowest index) is reported, as the sequential loop would.
+  std::atomic<int> bad_singular{M}, bad_notpd{M};
+  auto lower_to = [](std::atomic<int> &a, int v) {
+    int cur = a.load();
+    while (v < cur && !a.compare_exchange_weak(cur, v)) {}
+  };
+  host_parallel_for(M, 1, [&](int64_t m_lo, int64_t m_hi) {
+  std::vector<double> Sxx(dd), Syx(dd), inv(dd), L(dd), Ui(dd);
+  for (int m = (int)m_lo; m < (int)m_hi; ++m) {
     const double *S = sigma + (size_t)Dj * Dj * m;   // column-major (Dj,Dj)
     double *mux = &g->h_mux[(size_t)D * m], *muy = &g->h_muy[(size_t)D * m];
     for (int d = 0; d < D; ++d) {
@@ -759,8 +768,10 @@ static int prepare(vcmi_gmmmap *g, const double *w, const double *mu, const doub
     // A_m = Syx inv(Sxx) on the raw block, src/gmmmap.jl:35
     double *Am = px_only ? nullptr : &g->h_A[dd * m];
     if (!px_only) {
-      if (!la::inverse(Sxx.data(), D, inv.data()))
-        return fail(VCMI_ERR_NOT_PD, "Sigma^xx of mixture %d is singular", m + 1);
+      if (!la::inverse(Sxx.data(), D, inv.data())) {
+        lower_to(bad_singular, m);
+        continue;
+      }
       la::matmul(Syx.data(), inv.data(), D, Am);
       for (int r = 0; r < D; ++r)
         for (int c = 0; c < D; ++c) {
@@ -769,8 +780,10 @@ static int prepare(vcmi_gmmmap *g, const double *w, const double *mu, const doub
         }
     }
     // p(x): Hermitian(Sxx) (upper triangle mirrored, src/gmm.jl:16) -> Cholesky -> U = inv(L)
-    if (!la::cholesky_from_upper(Sxx.data(), D, L.data()))
-      return fail(VCMI_ERR_NOT_PD, "Sigma^xx of mixture %d is not positive definite", m + 1);
+    if (!la::cholesky_from_upper(Sxx.data(), D, L.data())) {
+      lower_to(bad_notpd, m);
+      continue;
+    }
     la::lower_inverse(L.data(), D, Ui.data());
     double logdiag = 0.0;
     for (int d = 0; d < D; ++d) logdiag += std::log(L[(size_t)d * D + d]);
@@ -786,6 +799,12 @@ static int prepare(vcmi_gmmmap *g, const double *w, const double *mu, const doub
       hcz[(size_t)DP * m + r] = cz;
       if (!px_only) hb[(size_t)DP * m + r] = muy[r] - ba;
     }
+  }
+  });
+  {
+    const int bs = bad_singular.load(), bp = bad_notpd.load();
+    if (bs < M && bs <= bp) return fail(VCMI_ERR_NOT_PD, "Sigma^xx of mixture %d is singular", bs + 1);
+    if (bp < M) return fail(VCMI_ERR_NOT_PD, "Sigma^xx of mixture %d is not positive definite", bp + 1);
   }
   // row-major blocks for the generic kernels; a p(x)-only handle that takes the MFMA path needs only its packed blocks
   // (device buffers are grow-only so that a handle re-prepared every EM iteration does not re-allocate)
