@@ -334,7 +334,7 @@ def bench_estep(args, world, rank):
 
     wall, kernel_ms = timed_steps(step, args.steps, args.warmup, world)
     fps = world * N * args.steps / wall
-    mfma_path = Dj in (32, 48, 64, 80, 160) and M <= 128           # estep.hip: estep_device
+    mfma_path = Dj % 2 == 0 and Dj <= 160 and M <= 128           # estep.hip: estep_device
     achieved = estep_flops_per_frame(Dj, M) * N / (kernel_ms * 1e-3) / 1e12
     out = {"metric": "diag-GMM E-step frames/sec (Dj=%d, M=%d)" % (Dj, M), "value": fps, "unit": "frames/s", "n_gpus": world,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True,
@@ -343,7 +343,7 @@ def bench_estep(args, world, rank):
                       f"diag E-step, Dj={Dj} ({'MFMA kernel' if mfma_path else 'generic kernels'}; not a BASELINE config)",
                       "Dj": Dj, "M": M, "frames_per_gpu": N,
                       "collective": "all-reduce(sum) of %d doubles per step" % vc.stats_len(Dj, M)},
-           "roofline": {"bound": "mfma", "kernel": (f"estep_mfma_kernel<{Dj}>" if mfma_path else "estep_gamma_kernel + estep_stats_kernel (generic path)") + " (+ all-reduce)", "achieved": achieved,
+           "roofline": {"bound": "mfma", "kernel": (f"estep_mfma_kernel<{min(d for d in (32, 48, 64, 80, 160) if d >= Dj)}>" if mfma_path else "estep_gamma_kernel + estep_stats_kernel (generic path)") + " (+ all-reduce)", "achieved": achieved,
                         "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS,
                         "traffic": pmc_traffic("estep_traffic.json", "estep_mfma_kernel", "r02_pmc", wide_reads=True) if (N == 1_250_000 and Dj == 80) else None,
                         "flop_per_frame": estep_flops_per_frame(Dj, M), "kernel_ms": kernel_ms}}

@@ -36,7 +36,8 @@ def test_golden(vc):
 # a single frame, and a frame count that is not a multiple of the 64-frame block are the ragged cases.
 @pytest.mark.parametrize("N,Dj,M", [(3000, 80, 32), (777, 80, 13), (1, 80, 3), (1500, 48, 8), (900, 64, 5),
                                     (2000, 32, 16), (1000, 6, 2), (500, 50, 4), (40000, 10, 4),
-                                    (2500, 160, 6), (130, 160, 3), (700, 128, 4), (600, 96, 9), (300, 100, 3)])
+                                    (2500, 160, 6), (130, 160, 3), (700, 128, 4), (600, 96, 9), (300, 100, 3), (800, 66, 5), (450, 25, 3),
+                                    (350, 154, 2)])
 def test_vs_oracle(vc, N, Dj, M):
     from oracle import c_oracle as co, np_oracle as npo
     w, mu, sig = npo.synth_model(5000 + N + Dj, Dj, M, lam_lo=1e-3)

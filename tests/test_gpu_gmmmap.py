@@ -156,10 +156,10 @@ def test_linearity_at_full_size(vc):
 
 
 @pytest.mark.parametrize("kernel", [0, 1])
-@pytest.mark.parametrize("D,M,T", [(160, 3, 333), (100, 4, 130), (84, 2, 1)])
+@pytest.mark.parametrize("D,M,T", [(160, 3, 333), (100, 4, 130), (84, 2, 1), (66, 3, 150), (17, 2, 40)])
 def test_posterior_beyond_80_dimensions(vc, D, M, T, kernel):
-    """80 < D <= 160 (e.g. the 160-dimensional joint GMM of delta-augmented features): the log-densities come from the
-    tiled MFMA kernel (whitening blocks streamed through LDS; kernel 0 = automatic choice) -- against the oracle and
+    """Dimensions without an instantiation of the conversion kernel, above all 80 < D <= 160 (e.g. the 160-dimensional
+    joint GMM of delta-augmented features): the log-densities come from the tiled MFMA kernel (whitening blocks streamed through LDS; kernel 0 = automatic choice) -- against the oracle and
     against the generic kernel (kernel 1).  D = 100 and 84 end in a partial row tile."""
     from oracle import np_oracle as npo
     w, mu, sig = npo.synth_model(7000 + D, 2 * D, M, lam_lo=1e-3)

@@ -142,7 +142,10 @@ __global__ void __launch_bounds__(512)
 estep_mfma_kernel(const double *__restrict__ X, int64_t N, int M, const double *__restrict__ Wpack,
                   const double *__restrict__ cinit, double *__restrict__ part, int64_t plen,
                   const double *__restrict__ refmu, const double *__restrict__ refiv, const double *__restrict__ refc,
-                  double *__restrict__ G) {
+                  double *__restrict__ G, int dj) {
+  // dj <= DJ is the data's joint dimension (even: rows of X are 16-byte aligned), DJ the instantiated one: the columns
+  // dj .. DJ-1 of the LDS image hold other (finite) values of X, meet zero weights in step A and statistics in step B
+  // that are never written out
   using C = EstepCfg<DJ>;
   constexpr int KS = C::KS, NDT = C::NDT, FB = C::FB, RSX = C::RSX, RSG = C::RSG, XBUF = C::XBUF;
   constexpr bool kGamma = PHASE != 2, kStats = PHASE != 1;
@@ -178,7 +181,7 @@ estep_mfma_kernel(const double *__restrict__ X, int64_t N, int M, const double *
   //      16-byte pad, and frames beyond N, fetch a valid address (frame N-1 / the block start) and are never used ----
   constexpr int ROWB = RSX * 8, NCHUNK = XBUF / 128;      // (the last wave-instruction may run into the buffer's padding)
   auto stage = [&](int64_t f0, double *dst) {
-    const char *base = reinterpret_cast<const char *>(X + f0 * DJ);          // workgroup-uniform 64-bit base,
+    const char *base = reinterpret_cast<const char *>(X + f0 * dj);          // workgroup-uniform 64-bit base,
     const int last = (int)((N - 1 - f0 < FB - 1) ? N - 1 - f0 : FB - 1);     // 32-bit per-lane offsets
     // The per-lane (row, column) of every chunk is loop-invariant; hoisted out of the block loop it costs 9 VGPRs this
     // kernel does not have -- they were spilled and came back from scratch behind four exposed s_waitcnt vmcnt per
@@ -191,7 +194,7 @@ estep_mfma_kernel(const double *__restrict__ X, int64_t N, int M, const double *
       if (q < NCHUNK) {                                          // wave-uniform
         const int o = 1024 * q + 16 * lane_v, row = o / ROWB, col = o - row * ROWB;
         const int rowc = row < last ? row : last;      // (also rows >= FB of the padding)
-        const unsigned off = (col < DJ * 8) ? (unsigned)(rowc * (DJ * 8) + col) : 0u;
+        const unsigned off = (col < dj * 8) ? (unsigned)(rowc * (dj * 8) + col) : 0u;
         const char *src = base + off;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                          (__attribute__((address_space(3))) void *)(reinterpret_cast<char *>(dst) + 1024 * q),
@@ -274,10 +277,10 @@ estep_mfma_kernel(const double *__restrict__ X, int64_t N, int M, const double *
               const double li = row[16 * i];
               if (li > thr) {
                 const int m = lcol + 16 * i;
-                const double *mp = refmu + (size_t)DJ * m, *ip = refiv + (size_t)DJ * m;
+                const double *mp = refmu + (size_t)dj * m, *ip = refiv + (size_t)dj * m;
                 double q = 0.0;
 #pragma unroll 2
-                for (int d = 0; d < DJ; ++d) {
+                for (int d = 0; d < dj; ++d) {
                   const double df = xf[d] - mp[d];
                   q = fma(df * df, ip[d], q);
                 }
@@ -359,8 +362,11 @@ estep_mfma_kernel(const double *__restrict__ X, int64_t N, int M, const double *
 #pragma unroll
         for (int j = 0; j < NDT; ++j) {
           const int c = 16 * j + lcol;   // column of [x | x^2]
-          if (c < DJ) P[M + (size_t)m * DJ + c] = sacc[j][r];
-          else P[M + (size_t)M * DJ + (size_t)m * DJ + (c - DJ)] = sacc[j][r];
+          if (c < DJ) {
+            if (c < dj) P[M + (size_t)m * dj + c] = sacc[j][r];
+          } else if (c - DJ < dj) {
+            P[M + (size_t)M * dj + (size_t)m * dj + (c - DJ)] = sacc[j][r];
+          }
         }
       }
     }
@@ -425,27 +431,27 @@ static EstepScratch &scratch() {
 //   cinit[m] = log w - (DJ log 2pi + sum log var)/2 - sum mu^2/(2 var)   (-inf for m >= M and for zero weights)
 template <int DJ>
 __global__ void __launch_bounds__(256)
-estep_prep_kernel(const double *__restrict__ raw, int M, double *__restrict__ Wpack, double *__restrict__ cinit,
+estep_prep_kernel(const double *__restrict__ raw, int M, int dj, double *__restrict__ Wpack, double *__restrict__ cinit,
                   double *__restrict__ refiv, double *__restrict__ refc) {
   using C = EstepCfg<DJ>;
-  const double *w = raw, *mu = raw + M, *var = mu + (size_t)DJ * M;
+  const double *w = raw, *mu = raw + M, *var = mu + (size_t)dj * M;      // dj <= DJ: the data's dimension
   const int e = blockIdx.x * 256 + threadIdx.x;
-  // operands of the exact re-evaluation (estep_mfma_kernel, "refinement"): 1/var in the parameters' own (DJ,M) layout and
+  // operands of the exact re-evaluation (estep_mfma_kernel, "refinement"): 1/var in the parameters' own (dj,M) layout and
   // the constant WITHOUT the -mu^2/(2 var) term
-  if (e < M * DJ) refiv[e] = 1.0 / var[e];
+  if (e < M * dj) refiv[e] = 1.0 / var[e];
   if (e < M) {
     double sl = 0.0;
-    for (int d = 0; d < DJ; ++d) sl += log(var[d + (size_t)DJ * e]);
-    refc[e] = (w[e] > 0.0 ? log(w[e]) : -INFINITY) - 0.5 * (DJ * kLog2Pi + sl);
+    for (int d = 0; d < dj; ++d) sl += log(var[d + (size_t)dj * e]);
+    refc[e] = (w[e] > 0.0 ? log(w[e]) : -INFINITY) - 0.5 * (dj * kLog2Pi + sl);
   }
   if (e < 8 * C::KS * 64) {
     const int l = e & 63, ks = (e >> 6) % C::KS, mt = (e >> 6) / C::KS;
     const int m = 16 * mt + (l & 15), k = 4 * ks + (l >> 4);
     double v = 0.0;
-    if (m < M) {
-      const int d = k < DJ ? k : k - DJ;
-      const double ivv = 1.0 / var[d + (size_t)DJ * m];
-      v = k < DJ ? -0.5 * ivv : mu[d + (size_t)DJ * m] * ivv;
+    const int d = k < DJ ? k : k - DJ;
+    if (m < M && d < dj) {                      // zero weights for the padding dimensions dj .. DJ-1
+      const double ivv = 1.0 / var[d + (size_t)dj * m];
+      v = k < DJ ? -0.5 * ivv : mu[d + (size_t)dj * m] * ivv;
     }
     Wpack[e] = v;
   }
@@ -453,12 +459,12 @@ estep_prep_kernel(const double *__restrict__ raw, int M, double *__restrict__ Wp
     double c = -INFINITY;
     if (e < M) {
       double sl = 0.0, t = 0.0;
-      for (int d = 0; d < DJ; ++d) {
-        const double vv = var[d + (size_t)DJ * e], mm = mu[d + (size_t)DJ * e];
+      for (int d = 0; d < dj; ++d) {
+        const double vv = var[d + (size_t)dj * e], mm = mu[d + (size_t)dj * e];
         sl += log(vv);
         t += mm * mm * (1.0 / vv);
       }
-      c = (w[e] > 0.0 ? log(w[e]) : -INFINITY) - 0.5 * (DJ * kLog2Pi + sl) - 0.5 * t;
+      c = (w[e] > 0.0 ? log(w[e]) : -INFINITY) - 0.5 * (dj * kLog2Pi + sl) - 0.5 * t;
     }
     cinit[e] = c;
   }
@@ -467,7 +473,7 @@ estep_prep_kernel(const double *__restrict__ raw, int M, double *__restrict__ Wp
 // The MFMA path for one joint dimension (parameters staged through pinned buffers, prep kernel, the E-step kernel with one
 // workgroup per CU, fixed-order reduction of the workgroups' partial statistics).
 template <int DJ>
-static int estep_mfma_launch(EstepScratch &sc, const double *dX, int64_t N, int M, const double *w, const double *mu,
+static int estep_mfma_launch(EstepScratch &sc, const double *dX, int64_t N, int dj, int M, const double *w, const double *mu,
                              const double *var, double *dstats, int64_t plen, hipStream_t st) {
   using C = EstepCfg<DJ>;
   int dev = 0, cus = 256;
@@ -475,11 +481,11 @@ static int estep_mfma_launch(EstepScratch &sc, const double *dX, int64_t N, int 
   (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
   const int64_t nblocks = (N + C::FB - 1) / C::FB;
   const int grid = (int)std::min<int64_t>(nblocks, cus);
-  const size_t nraw = (size_t)M * (1 + 2 * DJ);
+  const size_t nraw = (size_t)M * (1 + 2 * dj);
   VCMI_TRY(sc.raw.reserve(2 * nraw));                  // one device copy per staging buffer
   VCMI_TRY(sc.Wpack.reserve((size_t)8 * C::KS * 64));
   VCMI_TRY(sc.cinit.reserve((size_t)C::MMAX));
-  VCMI_TRY(sc.refiv.reserve((size_t)M * DJ));
+  VCMI_TRY(sc.refiv.reserve((size_t)M * dj));
   VCMI_TRY(sc.refc.reserve((size_t)M));
   VCMI_TRY(sc.part.reserve((size_t)grid * plen));
   VCMI_TRY(sc.stage.reserve(nraw));
@@ -488,11 +494,11 @@ static int estep_mfma_launch(EstepScratch &sc, const double *dX, int64_t N, int 
   VCMI_HIP(hipEventSynchronize(sc.stage.copied[b]));   // the copy that last used this buffer (two calls ago) is done
   double *h = sc.stage.host[b], *draw = sc.raw.p + (size_t)b * nraw;
   memcpy(h, w, sizeof(double) * M);
-  memcpy(h + M, mu, sizeof(double) * M * DJ);
-  memcpy(h + M + (size_t)M * DJ, var, sizeof(double) * M * DJ);
+  memcpy(h + M, mu, sizeof(double) * M * dj);
+  memcpy(h + M + (size_t)M * dj, var, sizeof(double) * M * dj);
   VCMI_HIP(hipMemcpyAsync(draw, h, nraw * sizeof(double), hipMemcpyHostToDevice, st));
   VCMI_HIP(hipEventRecord(sc.stage.copied[b], st));
-  hipLaunchKernelGGL(estep_prep_kernel<DJ>, dim3((8 * C::KS * 64 + 255) / 256), dim3(256), 0, st, draw, M, sc.Wpack.p,
+  hipLaunchKernelGGL(estep_prep_kernel<DJ>, dim3((8 * C::KS * 64 + 255) / 256), dim3(256), 0, st, draw, M, dj, sc.Wpack.p,
                      sc.cinit.p, sc.refiv.p, sc.refc.p);
   VCMI_HIP(hipGetLastError());
   const double *dmu = draw + M;      // (the means of the re-evaluation are the uploaded parameters themselves: raw = [w | mu (Dj,M) | var (Dj,M)])
@@ -501,7 +507,7 @@ static int estep_mfma_launch(EstepScratch &sc, const double *dX, int64_t N, int 
     VCMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)C::LDS_BYTES));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), C::LDS_BYTES, st, dX, N, M, sc.Wpack.p, sc.cinit.p, sc.part.p, plen, dmu,
-                       sc.refiv.p, sc.refc.p, (double *)nullptr);
+                       sc.refiv.p, sc.refc.p, (double *)nullptr, dj);
     VCMI_HIP(hipGetLastError());
     hipLaunchKernelGGL(estep_reduce_kernel, dim3((unsigned)((plen + 255) / 256)), dim3(256), 0, st, sc.part.p, grid, plen,
                        dstats);
@@ -518,10 +524,10 @@ static int estep_mfma_launch(EstepScratch &sc, const double *dX, int64_t N, int 
     for (int64_t n0 = 0; n0 < N; n0 += kSplitChunk) {
       const int64_t nfr = std::min<int64_t>(kSplitChunk, N - n0);
       const int g2 = (int)std::min<int64_t>((nfr + C::FB - 1) / C::FB, cus);
-      hipLaunchKernelGGL(kg, dim3(g2), dim3(512), C::LDS_BYTES, st, dX + n0 * DJ, nfr, M, sc.Wpack.p, sc.cinit.p, sc.part.p, plen,
-                         dmu, sc.refiv.p, sc.refc.p, sc.G.p);
-      hipLaunchKernelGGL(ks, dim3(g2), dim3(512), C::LDS_BYTES, st, dX + n0 * DJ, nfr, M, sc.Wpack.p, sc.cinit.p, sc.part.p, plen,
-                         dmu, sc.refiv.p, sc.refc.p, sc.G.p);
+      hipLaunchKernelGGL(kg, dim3(g2), dim3(512), C::LDS_BYTES, st, dX + n0 * dj, nfr, M, sc.Wpack.p, sc.cinit.p, sc.part.p, plen,
+                         dmu, sc.refiv.p, sc.refc.p, sc.G.p, dj);
+      hipLaunchKernelGGL(ks, dim3(g2), dim3(512), C::LDS_BYTES, st, dX + n0 * dj, nfr, M, sc.Wpack.p, sc.cinit.p, sc.part.p, plen,
+                         dmu, sc.refiv.p, sc.refc.p, sc.G.p, dj);
       VCMI_HIP(hipGetLastError());
       hipLaunchKernelGGL(estep_reduce_kernel, dim3((unsigned)((plen + 255) / 256)), dim3(256), 0, st, sc.part.p, g2, plen,
                          dstats);
@@ -544,18 +550,15 @@ static int estep_device(const double *dX, int64_t N, int Dj, int M, const double
   VCMI_HIP(hipMemsetAsync(dstats, 0, plen * sizeof(double), st));
   if (N == 0) return VCMI_OK;
 
-  // MFMA instantiations: the joint dimensions of the shipped configurations (Dj = 80: 40-dimensional joint features; 160:
-  // the same with --add_delta; 32, 48, 64: lower mel-cepstrum orders); any other Dj, and M > 128, take the generic
-  // kernels below.
-  if (M <= EstepCfg<80>::MMAX && !debug_flag(kDbgEstepGeneric)) {
-    switch (Dj) {
-      case 32: return estep_mfma_launch<32>(sc, dX, N, M, w, mu, var, dstats, plen, st);
-      case 48: return estep_mfma_launch<48>(sc, dX, N, M, w, mu, var, dstats, plen, st);
-      case 64: return estep_mfma_launch<64>(sc, dX, N, M, w, mu, var, dstats, plen, st);
-      case 80: return estep_mfma_launch<80>(sc, dX, N, M, w, mu, var, dstats, plen, st);
-      case 160: return estep_mfma_launch<160>(sc, dX, N, M, w, mu, var, dstats, plen, st);
-      default: break;
-    }
+  // MFMA instantiations for Dj = 32, 48, 64, 80 (one kernel) and 160 (two kernels); any even Dj up to 160 runs in the next
+  // larger one with zero weights in the padding dimensions; odd Dj, Dj > 160 and M > 128 take the generic kernels below.
+  if (M <= EstepCfg<80>::MMAX && Dj % 2 == 0 && Dj <= 160 && !debug_flag(kDbgEstepGeneric)) {
+    // the smallest instantiation that holds Dj (an even Dj keeps the rows of X 16-byte aligned for the LDS-DMA)
+    if (Dj <= 32) return estep_mfma_launch<32>(sc, dX, N, Dj, M, w, mu, var, dstats, plen, st);
+    if (Dj <= 48) return estep_mfma_launch<48>(sc, dX, N, Dj, M, w, mu, var, dstats, plen, st);
+    if (Dj <= 64) return estep_mfma_launch<64>(sc, dX, N, Dj, M, w, mu, var, dstats, plen, st);
+    if (Dj <= 80) return estep_mfma_launch<80>(sc, dX, N, Dj, M, w, mu, var, dstats, plen, st);
+    return estep_mfma_launch<160>(sc, dX, N, Dj, M, w, mu, var, dstats, plen, st);
   }
 
   std::vector<double> hiv((size_t)M * Dj), hc(M);
@@ -701,7 +704,7 @@ struct FullStatsCfg {
 template <int DJ, int PARTS, int PART>
 __device__ __forceinline__ void estep_full_stats_body(const double *__restrict__ X, int64_t n0, int64_t f_begin, int64_t f_end,
                                                       int M, int mg, const double *__restrict__ G, double *__restrict__ P,
-                                                      double *xs, double *gs) {
+                                                      double *xs, double *gs, int dj) {
   using C = FullStatsCfg<DJ, PARTS>;
   constexpr int NTL = C::NTL, RSX = C::RSX, FB = kFullFB, NM = C::NM;
   constexpr int T0 = PART * C::TPP, T1 = (T0 + C::TPP < C::NTILES) ? T0 + C::TPP : C::NTILES, NTP = T1 - T0;
@@ -722,12 +725,12 @@ __device__ __forceinline__ void estep_full_stats_body(const double *__restrict__
   const int gf = tid / NM, gq = tid % NM;                 // gamma staging: FB frames x NM mixtures
   const int gm_idx = mg * NM + gq;
   auto fetch = [&](int64_t fb) {                           // global -> registers (the block's frames are contiguous in X)
-    const int64_t lim = (f_end - fb) * DJ;
-    const double *src = X + (n0 + fb) * DJ;
+    const int64_t lim = (f_end - fb) * dj;        // dj <= DJ: the data's dimension (the columns dj .. DJ-1 of the LDS image
+    const double *src = X + (n0 + fb) * dj;       // are never written: they only reach accumulators that are not stored)
 #pragma unroll
     for (int i = 0; i < NPF; ++i) {
       const int e = tid + 512 * i;
-      pf[i] = (e < FB * DJ && e < lim) ? src[e] : 0.0;
+      pf[i] = (e < FB * dj && e < lim) ? src[e] : 0.0;
     }
     pg = (tid < FB * NM && fb + gf < f_end && gm_idx < M) ? G[(fb + gf) * M + gm_idx] : 0.0;
   };
@@ -735,12 +738,16 @@ __device__ __forceinline__ void estep_full_stats_body(const double *__restrict__
 #pragma unroll
     for (int i = 0; i < NPF; ++i) {
       const int e = tid + 512 * i;
-      if (e < FB * DJ) xs[buf * FB * RSX + (e / DJ) * RSX + (e % DJ)] = pf[i];
+      if (e < FB * dj) xs[buf * FB * RSX + (e / dj) * RSX + (e % dj)] = pf[i];
     }
     if (tid < FB * NM) gs[buf * FB * 8 + gf * NM + gq] = pg;
   };
   constexpr FullTileList<T0, NTP> TL{};                   // which x tiles this part reads, which of them it scales by gamma
 
+  if (dj < DJ) {                                          // padding columns: finite values (they are multiplied, never stored)
+    for (int e = tid; e < 2 * FB * RSX; e += 512) xs[e] = 0.0;
+    __syncthreads();
+  }
   if (f_begin < f_end) {
     fetch(f_begin);
     stash(0);
@@ -782,19 +789,19 @@ __device__ __forceinline__ void estep_full_stats_body(const double *__restrict__
       double v = s1[a];
       v += __shfl_xor(v, 16);
       v += __shfl_xor(v, 32);
-      if (lgrp == 0) P[M + (size_t)m * DJ + 16 * a + lcol] = v;
+      if (lgrp == 0 && 16 * a + lcol < dj) P[M + (size_t)m * dj + 16 * a + lcol] = v;
     }
   }
-  double *S2 = P + M + (size_t)M * DJ + (size_t)m * DJ * DJ;      // (Dj,Dj) column-major
+  double *S2 = P + M + (size_t)M * dj + (size_t)m * dj * dj;      // (dj,dj) column-major
 #pragma unroll
   for (int t = 0; t < NTP; ++t) {
     const int a = TL.a[t], j = TL.j[t];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int i = 16 * a + lgrp + 4 * r, jc = 16 * j + lcol;    // D[i][jc]
-      if (a != j || i >= jc) {                                     // diagonal tiles: lower part only, then mirrored
-        S2[i + (size_t)DJ * jc] = acc[t][r];
-        S2[jc + (size_t)DJ * i] = acc[t][r];
+      if ((a != j || i >= jc) && i < dj && jc < dj) {              // diagonal tiles: lower part only, then mirrored
+        S2[i + (size_t)dj * jc] = acc[t][r];
+        S2[jc + (size_t)dj * i] = acc[t][r];
       }
     }
   }
@@ -803,7 +810,7 @@ __device__ __forceinline__ void estep_full_stats_body(const double *__restrict__
 template <int DJ, int PARTS>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 estep_full_stats_kernel(const double *__restrict__ X, int64_t n0, int64_t n, int M, const double *__restrict__ G,
-                        double *__restrict__ part, int64_t plen) {
+                        double *__restrict__ part, int64_t plen, int dj) {
   static_assert(DJ % 16 == 0, "full-covariance MFMA statistics need Dj to be a multiple of 16");
   static_assert(PARTS == 1 || PARTS == 2 || PARTS == 4, "waves per mixture");
   using C = FullStatsCfg<DJ, PARTS>;
@@ -818,10 +825,10 @@ estep_full_stats_kernel(const double *__restrict__ X, int64_t n0, int64_t n, int
   const int64_t f_begin = seg * seglen, f_end = (f_begin + seglen < n) ? f_begin + seglen : n;
   double *P = part + (size_t)seg * plen;
   const int prt = (threadIdx.x >> 6) % PARTS;          // wave-uniform; every branch runs the same number of barriers
-  if (PARTS == 1 || prt == 0) estep_full_stats_body<DJ, PARTS, 0>(X, n0, f_begin, f_end, M, mg, G, P, xs, gs);
-  else if (PARTS == 2 || prt == 1) estep_full_stats_body<DJ, PARTS, 1>(X, n0, f_begin, f_end, M, mg, G, P, xs, gs);
-  else if (prt == 2) estep_full_stats_body<DJ, PARTS, (PARTS > 2 ? 2 : 0)>(X, n0, f_begin, f_end, M, mg, G, P, xs, gs);
-  else estep_full_stats_body<DJ, PARTS, (PARTS > 3 ? 3 : 0)>(X, n0, f_begin, f_end, M, mg, G, P, xs, gs);
+  if (PARTS == 1 || prt == 0) estep_full_stats_body<DJ, PARTS, 0>(X, n0, f_begin, f_end, M, mg, G, P, xs, gs, dj);
+  else if (PARTS == 2 || prt == 1) estep_full_stats_body<DJ, PARTS, 1>(X, n0, f_begin, f_end, M, mg, G, P, xs, gs, dj);
+  else if (prt == 2) estep_full_stats_body<DJ, PARTS, (PARTS > 2 ? 2 : 0)>(X, n0, f_begin, f_end, M, mg, G, P, xs, gs, dj);
+  else estep_full_stats_body<DJ, PARTS, (PARTS > 3 ? 3 : 0)>(X, n0, f_begin, f_end, M, mg, G, P, xs, gs, dj);
 }
 
 // generic statistics (any Dj): thread per lower-triangle element of one mixture's S2 (+ S1, S0), sequential over the
@@ -878,7 +885,9 @@ static int estep_full_core(vcmi_gmmmap *px, const double *dX, int64_t N, int Dj,
   VCMI_TRY(sc.lse.reserve((size_t)kSoftmaxGrid));
   // frame segments (grid.x): one 8-wave workgroup per CU in a single round, whatever the mixture count; a workgroup
   // holds 8 mixtures up to Dj = 80 and 2 (four waves per mixture) beyond
-  const bool mfma = (Dj == 32 || Dj == 48 || Dj == 64 || Dj == 80 || Dj == 96 || Dj == 128 || Dj == 160) && !debug_flag(kDbgEstepGeneric);
+  // MFMA statistics for every Dj <= 160, in the smallest of the instantiations 32, 48, 64, 80 (one wave per mixture) and
+  // 96, 128, 160 (four) that holds it
+  const bool mfma = Dj <= 160 && !debug_flag(kDbgEstepGeneric);
   const int nm = (!mfma || Dj <= 80) ? 8 : 2;
   const int mgroups = (M + nm - 1) / nm;
   const int nseg = std::max(1, (256 + mgroups - 1) / mgroups);
@@ -899,18 +908,16 @@ static int estep_full_core(vcmi_gmmmap *px, const double *dX, int64_t N, int Dj,
           VCMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
           attr_done[dev & 63].store(true, std::memory_order_release);
         }
-        hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, dX, n0, n, M, sc.LP.p, sc.part.p, plen);
+        hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, dX, n0, n, M, sc.LP.p, sc.part.p, plen, Dj);
         return VCMI_OK;
       };
-      switch (Dj) {
-        case 32: VCMI_TRY(launch(estep_full_stats_kernel<32, 1>, FullStatsCfg<32, 1>::LDS_BYTES)); break;
-        case 48: VCMI_TRY(launch(estep_full_stats_kernel<48, 1>, FullStatsCfg<48, 1>::LDS_BYTES)); break;
-        case 64: VCMI_TRY(launch(estep_full_stats_kernel<64, 1>, FullStatsCfg<64, 1>::LDS_BYTES)); break;
-        case 80: VCMI_TRY(launch(estep_full_stats_kernel<80, 1>, FullStatsCfg<80, 1>::LDS_BYTES)); break;
-        case 96: VCMI_TRY(launch(estep_full_stats_kernel<96, 4>, FullStatsCfg<96, 4>::LDS_BYTES)); break;
-        case 128: VCMI_TRY(launch(estep_full_stats_kernel<128, 4>, FullStatsCfg<128, 4>::LDS_BYTES)); break;
-        default: VCMI_TRY(launch(estep_full_stats_kernel<160, 4>, FullStatsCfg<160, 4>::LDS_BYTES)); break;
-      }
+      if (Dj <= 32) VCMI_TRY(launch(estep_full_stats_kernel<32, 1>, FullStatsCfg<32, 1>::LDS_BYTES));
+      else if (Dj <= 48) VCMI_TRY(launch(estep_full_stats_kernel<48, 1>, FullStatsCfg<48, 1>::LDS_BYTES));
+      else if (Dj <= 64) VCMI_TRY(launch(estep_full_stats_kernel<64, 1>, FullStatsCfg<64, 1>::LDS_BYTES));
+      else if (Dj <= 80) VCMI_TRY(launch(estep_full_stats_kernel<80, 1>, FullStatsCfg<80, 1>::LDS_BYTES));
+      else if (Dj <= 96) VCMI_TRY(launch(estep_full_stats_kernel<96, 4>, FullStatsCfg<96, 4>::LDS_BYTES));
+      else if (Dj <= 128) VCMI_TRY(launch(estep_full_stats_kernel<128, 4>, FullStatsCfg<128, 4>::LDS_BYTES));
+      else VCMI_TRY(launch(estep_full_stats_kernel<160, 4>, FullStatsCfg<160, 4>::LDS_BYTES));
     } else {
       hipLaunchKernelGGL(estep_full_stats_generic_kernel, dim3(M, nseg), dim3(256), 0, st, dX, n0, n, Dj, M, sc.LP.p,
                          sc.part.p, plen);

@@ -387,9 +387,10 @@ gmmmap_generic_kernel(const double *__restrict__ U, const double *__restrict__ A
 }
 
 // ------------------------------------------------------------------------------------------------
-// Log-weighted densities for 80 < D <= 16 NTMAX (e.g. the 160-dimensional joint GMM of delta-augmented features that
-// TrajectoryGMMMap is trained from): the x operands of the MFMA kernel above (D/4 k-steps x FT tiles) and a mixture's
-// whitening block (103 KB at D = 160) no longer fit registers / a double-buffered LDS block, so here
+// Log-weighted densities for the dimensions the MFMA kernel above is not instantiated for, up to D = 16 NTMAX -- above all
+// 80 < D <= 160 (e.g. the 160-dimensional joint GMM of delta-augmented features that TrajectoryGMMMap is trained from):
+// the x operands of that kernel (D/4 k-steps x FT tiles) and a mixture's whitening block (103 KB at D = 160) no longer
+// fit registers / a double-buffered LDS block, so here
 //   * a workgroup owns 128 frames: wave w keeps the B-operand fragments of its 16 frames (D/4 doubles per lane) for the
 //     whole kernel;
 //   * the whitening blocks stream through LDS one 16-row tile at a time ("piece": rows 16r .. 16r+15, the 16(r+1)
@@ -678,7 +679,8 @@ int gmmmap_convert_device(vcmi_gmmmap *g, const double *dX, int64_t ldx, int64_t
 int gmmmap_logdens_device(vcmi_gmmmap *g, const double *dX, int64_t ldx, int64_t T, double *dLP, hipStream_t st) {
   if (T == 0) return VCMI_OK;
   if (use_mfma(g)) return dispatch_mfma<1>(g, dX, ldx, T, dLP, g->M, st);
-  if (g->kernel_choice != 1 && g->D > 80 && g->D <= 160) {      // tiles streamed through LDS (see logdens_tiled_kernel)
+  if (g->kernel_choice != 1 && g->D > 16 && g->D <= 160) {      // no instantiation of the kernel above (D > 80, or a padded
+                                                                // dimension outside its list): tiles streamed through LDS
     constexpr int NTMAX = 10;
     constexpr TiledStages<NTMAX> ST{};
     const size_t shmem = 2 * (size_t)ST.max_piece() * sizeof(double);
