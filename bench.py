@@ -443,7 +443,7 @@ def bench_em_full(args, world, rank):
     wall, kernel_ms = timed_steps(step, args.steps, args.warmup, world)
     flop = 2 * M * Dj * (Dj + 1) + 2 * M * Dj
     achieved = flop * N / (kernel_ms * 1e-3) / 1e12
-    out = {"metric": "full-covariance GMM EM iteration frames/sec (Dj=80, M=64)", "value": world * N * args.steps / wall,
+    out = {"metric": "full-covariance GMM EM iteration frames/sec (Dj=%d, M=64)" % Dj, "value": world * N * args.steps / wall,
            "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "f64", "data": "synthetic",

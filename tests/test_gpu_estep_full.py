@@ -145,6 +145,40 @@ def test_device_resident_em_matches_host_em(vc):
     assert relerr(got[0], ref[0]) < TOL and relerr(got[1], ref[1].T) < TOL and abs(got[3] - ref[3]) < TOL * abs(ref[3])
 
 
+@pytest.mark.parametrize("Dj,M,N", [(160, 3, 3000), (112, 2, 1500)])
+def test_device_resident_em_beyond_98_dimensions(vc, Dj, M, N):
+    """Joint dimensions whose covariance does not fit px_prep_kernel's two LDS images (e.g. the 160-dimensional model of
+    delta features) are prepared by px_prep_packed_kernel (packed lower triangle, in-place inverse): the device EM
+    follows the host-M-step EM, and a not-PD covariance is reported."""
+    import torch
+    from oracle import np_oracle as npo
+    w, mu, sig = npo.synth_model(50 + Dj, Dj, M, lam_lo=1e-2)
+    X = npo.sample_frames(51 + Dj, w, mu, sig, N, 0, Dj)
+    rg = np.random.default_rng(1)
+    mu0 = X[rg.choice(N, M, replace=False)].T
+    sig0 = np.repeat(np.cov(X.T)[:, :, None], M, axis=2)
+    w0 = np.full(M, 1.0 / M)
+    Xd = torch.from_numpy(X).cuda().t()
+    em = vc.EMState(w0, mu0, sig0, min_covar=1e-7)
+    hist = []
+    for _ in range(4):
+        hist.append(em.mstep(em.estep(Xd)) / N)
+    w1, mu1, sig1 = em.get()
+    wh, muh, sigh, hh = vc.fit_full(Xd, w0, mu0, sig0, n_iter=4, tol=0.0)
+    assert np.allclose(hist, hh, rtol=1e-9, atol=0)
+    assert relerr(w1, wh) < 1e-8 and relerr(mu1, muh) < 1e-8 and relerr(sig1, sigh) < 1e-8
+    # first E-step against the oracle
+    e2 = vc.EMState(w, mu.T, np.transpose(sig, (2, 1, 0)))
+    got = vc.unpack_full_stats(e2.estep(Xd).cpu().numpy(), Dj, M)
+    ref = npo.estep_full(X, w, mu, sig)
+    assert relerr(got[0], ref[0]) < TOL and relerr(got[1], ref[1].T) < TOL and abs(got[3] - ref[3]) < TOL * abs(ref[3])
+    bad = np.transpose(sig, (2, 1, 0)).copy()
+    bad[:, :, 1] = -bad[:, :, 1]
+    with pytest.raises(vc.PosDefException):           # the E-step is asynchronous: the flag is read by the M-step
+        eb = vc.EMState(w, mu.T, bad)
+        eb.mstep(eb.estep(Xd))
+
+
 def test_train_gmm_refine_and_init(vc):
     """train_gmm (bin/train_gmm.jl:84-103): refine keeps improving a pretrained model; a k-means-initialised fit is
     monotone, beats a single Gaussian and is reproducible for a fixed seed; a non-PD start raises PosDefException."""

@@ -1024,7 +1024,8 @@ static int em_prepare(vcmi_gmm_em *h, hipStream_t st) {
   if (gmm_px_device_prepare_supported(h->Dj)) {
     VCMI_TRY(gmm_px_prepare_device(&h->px, h->w(), h->mu(), h->sigma(), h->Dj, h->M, h->flag.p, st));
   } else {
-    // joint dimensions whose covariance does not fit the LDS of px_prep_kernel (Dj > 98): Cholesky on the host
+    // dimensions without a device preparation (Dj > 160, and 98 < Dj whose padded size has an MFMA instantiation --
+    // there is none today): Cholesky on the host
     const size_t dd = (size_t)h->Dj * h->Dj;
     std::vector<double> hw(h->M), hmu((size_t)h->M * h->Dj), hs((size_t)h->M * dd);
     VCMI_HIP(hipStreamSynchronize(st));

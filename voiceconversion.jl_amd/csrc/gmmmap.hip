@@ -977,8 +977,96 @@ px_prep_kernel(const double *__restrict__ w, const double *__restrict__ mu, cons
   }
 }
 
+// The same preparation for dimensions whose two D x (D+1) images do not fit LDS (D > 98, e.g. the 160-dimensional joint
+// model of delta features): ONE lower triangle in packed storage (D(D+1)/2 doubles: 103 KB at D = 160) holds the
+// covariance, then its Cholesky factor, then -- inverted in place, column by column from the last, with the column
+// being replaced kept in a D-vector -- U = L^-1.  Outputs: the generic layout only (U, cz, lc: what
+// logdens_tiled_kernel reads).
+__global__ void __launch_bounds__(512)
+px_prep_packed_kernel(const double *__restrict__ w, const double *__restrict__ mu, const double *__restrict__ sigma, int D,
+                      int DP, double *__restrict__ U, double *__restrict__ cz, double *__restrict__ lc,
+                      int *__restrict__ flag) {
+  extern __shared__ double smem_pp[];
+  const int tid = threadIdx.x, m = blockIdx.x, NTH = 512;
+  double *P = smem_pp;                                   // packed lower triangle: (i, j <= i) at i (i + 1) / 2 + j
+  double *col = P + (size_t)D * (D + 1) / 2;             // [D] the column being replaced (inverse), then cz
+  __shared__ double lcs;
+  __shared__ int bad;
+  auto at = [](int i, int j) { return i * (i + 1) / 2 + j; };
+  const double *Sg = sigma + (size_t)m * D * D;
+  // Hermitian(Sigma): the upper triangle of the column-major block is the matrix (src/gmm.jl:16): (i, j <= i) = Sg(j, i)
+  for (int e = tid; e < D * D; e += NTH) {
+    const int i = e / D, j = e - i * D;
+    if (j <= i) P[at(i, j)] = Sg[j + (size_t)D * i];
+  }
+  if (tid == 0) bad = 0;
+  __syncthreads();
+  // right-looking Cholesky
+  for (int j = 0; j < D; ++j) {
+    const double d = P[at(j, j)];
+    if (!(d > 0.0) && tid == 0) bad = 1;
+    const double sd = sqrt(d);
+    __syncthreads();                                     // every thread has read the pivot
+    for (int i = j + tid; i < D; i += NTH) P[at(i, j)] = (i == j) ? sd : P[at(i, j)] / sd;
+    __syncthreads();
+    const int n = D - 1 - j;
+    for (int e = tid; e < n * n; e += NTH) {
+      const int ii = e / n, kk = e - ii * n;
+      const int i = j + 1 + ii, k = j + 1 + kk;
+      if (i >= k) P[at(i, k)] = fma(-P[at(i, j)], P[at(k, j)], P[at(i, k)]);
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    double ld = 0.0;
+    for (int d = 0; d < D; ++d) ld += log(P[at(d, d)]);
+    const double LOG2PI = 1.8378770664093454835606594728112;
+    lcs = (w[m] > 0.0) ? log(w[m]) - 0.5 * (D * LOG2PI + 2.0 * ld) : -INFINITY;   // zero weight: posterior 0
+  }
+  // U = L^-1 in place: column j from the columns to its right (already inverse) and the original column j of L:
+  //   U_jj = 1 / L_jj,   U_ij = -(sum_{k=j+1..i} U_ik L_kj) U_jj   (i > j)
+  for (int j = D - 1; j >= 0; --j) {
+    for (int i = j + tid; i < D; i += NTH) col[i] = P[at(i, j)];
+    __syncthreads();
+    const double ujj = 1.0 / col[j];
+    for (int i = j + tid; i < D; i += NTH) {
+      double v = ujj;
+      if (i > j) {
+        double sacc = 0.0;
+        for (int k = j + 1; k <= i; ++k) sacc = fma(P[at(i, k)], col[k], sacc);
+        v = -sacc * ujj;
+      }
+      P[at(i, j)] = v;
+    }
+    __syncthreads();
+  }
+  // cz = U mu
+  for (int i = tid; i < D; i += NTH) {
+    double sacc = 0.0;
+    for (int c = 0; c <= i; ++c) sacc = fma(P[at(i, c)], mu[c + (size_t)D * m], sacc);
+    col[i] = sacc;
+  }
+  __syncthreads();
+  for (int e = tid; e < DP * DP; e += NTH) {
+    const int r = e / DP, c = e - r * DP;
+    U[(size_t)m * DP * DP + e] = (r < D && c <= r) ? P[at(r, c)] : 0.0;
+  }
+  for (int e = tid; e < DP; e += NTH) cz[(size_t)m * DP + e] = (e < D) ? col[e] : 0.0;
+  if (tid == 0) {
+    lc[m] = lcs;
+    if (bad) atomicMax(flag, m + 1);
+  }
+}
+
+static bool px_prep_fits_full(int D) {      // px_prep_kernel: two D x (D+1) images
+  return (size_t)2 * D * (D + 1) * sizeof(double) + 4096 <= (size_t)160 * 1024;
+}
 bool gmm_px_device_prepare_supported(int D) {
-  return D >= 1 && D <= 256 && (size_t)2 * D * (D + 1) * sizeof(double) + 4096 <= (size_t)160 * 1024;
+  if (D < 1 || D > 256) return false;
+  if (px_prep_fits_full(D)) return true;
+  // packed variant: only for dimensions whose log-densities do not need the MFMA operand blocks (logdens_tiled_kernel)
+  const int DP = (D + 3) / 4 * 4;
+  return !gmmmap_has_mfma(DP) && ((size_t)D * (D + 1) / 2 + D) * sizeof(double) + 4096 <= (size_t)160 * 1024;
 }
 
 int gmm_px_prepare_device(vcmi_gmmmap **inout, const double *d_w, const double *d_mu, const double *d_sigma, int D, int M,
@@ -1016,6 +1104,15 @@ int gmm_px_prepare_device(vcmi_gmmmap **inout, const double *d_w, const double *
       VCMI_HIP(hipMemcpy(g->px_table.p, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice));
       g->px_table_dp = DP;
     }
+  }
+  if (!px_prep_fits_full(D)) {
+    const size_t shp = ((size_t)D * (D + 1) / 2 + D) * sizeof(double);
+    VCMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(px_prep_packed_kernel),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)shp));
+    hipLaunchKernelGGL(px_prep_packed_kernel, dim3(M), dim3(512), shp, st, d_w, d_mu, d_sigma, D, DP, g->U.p, g->cz.p, g->lc.p,
+                       d_flag);
+    VCMI_HIP(hipGetLastError());
+    return VCMI_OK;
   }
   const size_t shmem = (size_t)2 * D * (D + 1) * sizeof(double);
   VCMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(px_prep_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
