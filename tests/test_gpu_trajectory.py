@@ -44,11 +44,13 @@ def test_golden_fixture_model(vc, fixture_model):
 
 
 @pytest.mark.parametrize("D,M,Ts", [(40, 8, [300]), (12, 4, [1, 2, 3, 4, 5, 50]), (20, 6, [64, 7, 129]),
-                                    (16, 4, [40, 3]), (25, 4, [33, 2]), (32, 3, [21])])
+                                    (16, 4, [40, 3]), (25, 4, [33, 2]), (32, 3, [21]),
+                                    (13, 3, [45, 1, 6]), (35, 4, [60, 17]), (7, 2, [30, 2]), (27, 3, [25])])
 def test_vs_oracle_batch(vc, D, M, Ts):
     """Config-5 shape (static D=40, X dim 80) at a length the oracle finishes in seconds, plus the short-utterance
     edge cases T = 1..5 where the stencil loses neighbours; D = 16 / 32 (the rhs row opens a tile of its own) and the
-    odd D = 25 (8-byte stencil / panel accesses) cover the other instantiations of the blocked solver."""
+    odd D = 25 (8-byte stencil / panel accesses) cover the other instantiations of the blocked solver; D = 13, 35, 7, 27
+    have none and run padded in the next larger one (16, 40, 12, 30)."""
     from oracle import c_oracle as co, np_oracle as npo
     w, mu, sig = npo.synth_model(500 + D, 4 * D, M, lam_lo=1e-3)
     ref = co.TrajectoryGMMMap(co.GMMMap(w, mu, sig))
@@ -66,6 +68,32 @@ def test_vs_oracle_batch(vc, D, M, Ts):
         assert relerr(y, yref.T) < TOL
     y0 = vc.fvconvert(t, Xs[0].T)
     assert np.array_equal(y0, Ys[0])                                 # batch == single, bit for bit
+
+
+@pytest.mark.parametrize("D", [13, 35])
+def test_padded_blocked_solver_against_the_runtime_dimension_kernel(vc, D):
+    """A static dimension without an instantiation of the blocked solver: solved in the next larger one with the extra
+    dimensions decoupled (unit diagonal, zero right-hand side) -- the same trajectories as the runtime-D kernel."""
+    from voiceconversion_jl_amd import _lib
+    from oracle import np_oracle as npo
+    M = 4
+    w, mu, sig = npo.synth_model(880 + D, 4 * D, M, lam_lo=1e-3)
+    g = vc.GMMMap(*julia_model(w, mu, sig))
+    t = vc.TrajectoryGMMMap(g, 90)
+    rng = np.random.default_rng(D)
+    Xs = []
+    for T in (90, 31, 2):
+        static = npo.sample_frames(int(rng.integers(1 << 30)), w, mu, sig, T, 0, D)
+        static = np.cumsum(static, axis=0) / np.sqrt(np.arange(1, T + 1))[:, None]
+        Xs.append(npo.push_delta(static).T)
+    Yb = t.fvconvert_batch(Xs)
+    _lib.debug_force(_lib.DBG_TRAJ_GENERIC)
+    try:
+        Yr = t.fvconvert_batch(Xs)
+    finally:
+        _lib.debug_force(0)
+    for a, b in zip(Yb, Yr):
+        assert a.shape == b.shape and relerr(a, b) < 1e-9
 
 
 def test_constructW_structure(vc):

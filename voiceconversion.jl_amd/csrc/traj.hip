@@ -36,6 +36,12 @@ struct vcmi_traj {
   vcmi::DevBuf<int> gperm;                // frames of every utterance grouped by mixture (traj_g_mfma_kernel)
   int NT = 0, KS = 0;                     // row tiles / k-steps of Qfrag
   vcmi::DevBuf<double> gbuf, ws, xbuf, ybuf;
+  // Static dimensions without an instantiation of the blocked solver run in the next larger one (Dpad): Qpad is Q with
+  // the extra static dimensions decoupled (unit diagonal in Qss, zeros elsewhere), gpad / ypad the padded right-hand
+  // sides and solutions of a call
+  int Dpad = 0;
+  vcmi::DevBuf<double> Qpad, gpad, ypad;
+  vcmi::DevBuf<unsigned char> uttpad;
   vcmi::DevBuf<int64_t> mhat;
   vcmi::DevBuf<int> status;
   vcmi::DevBuf<unsigned char> uttbuf;
@@ -952,9 +958,44 @@ vs_scale_kernel(const double *__restrict__ src, int D, int64_t n, const double *
   }
 }
 
+// g (frames x [gs (D); gd (D)]) -> gpad (frames x [gs (Dp); gd (Dp)]), zeros in the padding
+__global__ void __launch_bounds__(256)
+traj_pad_g_kernel(const double *__restrict__ g, int64_t nframes, int D, int Dp, double *__restrict__ gpad) {
+  const int64_t n = nframes * 2 * Dp;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
+    const int64_t f = e / (2 * Dp);
+    const int c = (int)(e - f * 2 * Dp), half = c / Dp, d = c - half * Dp;
+    gpad[e] = (d < D) ? g[f * 2 * D + half * D + d] : 0.0;
+  }
+}
+// ypad (frames x Dp) -> the utterances' own (T, D) outputs
+__global__ void __launch_bounds__(256)
+traj_unpad_y_kernel(const TrajUtt *__restrict__ utts, const double *__restrict__ ypad, int D, int Dp) {
+  const TrajUtt u = utts[blockIdx.x];
+  const int64_t n = (int64_t)u.T * D;
+  for (int64_t e = (int64_t)blockIdx.y * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.y * 256) {
+    const int64_t tt = e / D;
+    u.Y[e] = ypad[(u.frame0 + tt) * Dp + (e - tt * D)];
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
+// the blocked solver's instantiations (traj_run) and the one a static dimension without its own runs in (0: none)
+static bool traj_blk_has(int D) {
+  switch (D) {
+    case 12: case 16: case 20: case 24: case 25: case 30: case 32: case 40: return true;
+    default: return false;
+  }
+}
+static int traj_blk_padded_dim(int D) {
+  if (traj_blk_has(D) || D > 40) return 0;
+  for (int d = D + 1; d <= 40; ++d)
+    if (traj_blk_has(d)) return d;
+  return 0;
+}
+
 static size_t solve_lds_bytes(int D) {
   const size_t W3 = 3 * (size_t)D;
   const size_t NK = (W3 + 15) / 16;
@@ -1014,16 +1055,38 @@ static int traj_run(vcmi_traj *t, std::vector<TrajUtt> &utts, int64_t nframes, b
     VCMI_HIP(hipGetLastError());
   }
   bool launched = false;
+  // the dimension the blocked solver runs in, and its operands: the utterances' own, or the padded copies
+  const int Ds = t->Dpad ? t->Dpad : D;
+  const double *Qs = t->Q.p, *gs = t->gbuf.p;
+  const TrajUtt *dus = du;
+  int64_t ws_stride_s = ws_stride;
+  if (t->Dpad && !debug_flag(kDbgTrajGeneric)) {
+    const int Dp = t->Dpad;
+    VCMI_TRY(t->gpad.reserve((size_t)nframes * 2 * Dp));
+    VCMI_TRY(t->ypad.reserve((size_t)nframes * Dp));
+    VCMI_TRY(t->uttpad.reserve(sizeof(TrajUtt) * n));
+    std::vector<TrajUtt> up(utts);
+    for (auto &u : up) u.Y = t->ypad.p + (size_t)u.frame0 * Dp;
+    VCMI_HIP(hipMemcpy(t->uttpad.p, up.data(), sizeof(TrajUtt) * n, hipMemcpyHostToDevice));
+    ws_stride_s = (int64_t)Tmax * (3 * Dp + 1) * Dp;
+    VCMI_TRY(t->ws.reserve((size_t)grid * std::max(ws_stride, ws_stride_s)));
+    hipLaunchKernelGGL(traj_pad_g_kernel, dim3((unsigned)std::min<int64_t>((nframes * 2 * Dp + 255) / 256, 4096)), dim3(256), 0, st,
+                       t->gbuf.p, nframes, D, Dp, t->gpad.p);
+    VCMI_HIP(hipGetLastError());
+    Qs = t->Qpad.p;
+    gs = t->gpad.p;
+    dus = reinterpret_cast<const TrajUtt *>(t->uttpad.p);
+  }
   if (!debug_flag(kDbgTrajGeneric)) {
-    switch (D) {
+    switch (Ds) {
 #define VCMI_TRAJ_BLK_CASE(DV)                                                                                      \
   case DV: {                                                                                                        \
     auto kern = traj_solve_blk_kernel<DV>;                                                                          \
     const size_t shb = BlkCfg<DV>::lds_doubles * sizeof(double);                                                    \
     VCMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,  \
                                  (int)shb));                                                                        \
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlkThreads), shb, st, du, n, t->Q.p, t->mhat.p, t->gbuf.p, t->ws.p,   \
-                       ws_stride, t->status.p);                                                                     \
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlkThreads), shb, st, dus, n, Qs, t->mhat.p, gs, t->ws.p,             \
+                       ws_stride_s, t->status.p);                                                                   \
     launched = true;                                                                                                \
   } break;
       VCMI_TRAJ_BLK_CASE(12) VCMI_TRAJ_BLK_CASE(16) VCMI_TRAJ_BLK_CASE(20) VCMI_TRAJ_BLK_CASE(24) VCMI_TRAJ_BLK_CASE(25)
@@ -1031,6 +1094,10 @@ static int traj_run(vcmi_traj *t, std::vector<TrajUtt> &utts, int64_t nframes, b
 #undef VCMI_TRAJ_BLK_CASE
       default: break;
     }
+  }
+  if (launched && t->Dpad) {
+    hipLaunchKernelGGL(traj_unpad_y_kernel, dim3(n, 8), dim3(256), 0, st, du, t->ypad.p, D, t->Dpad);
+    VCMI_HIP(hipGetLastError());
   }
   if (!launched) {
     VCMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(traj_solve_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1249,6 +1316,26 @@ extern "C" int vcmi_traj_create(vcmi_gmmmap *g, int64_t T, vcmi_traj **out) {
             Af[(((size_t)m * t->NT + i) * t->KS + ks) * 64 + l] = g->h_A[nn * m + (size_t)r * D2 + k];
           }
         }
+  t->Dpad = traj_blk_padded_dim(D);
+  if (t->Dpad) {
+    const int Dp = t->Dpad, Dp2 = 2 * Dp;
+    std::vector<double> Qp((size_t)M * Dp2 * Dp2, 0.0);
+    for (int m = 0; m < M; ++m) {
+      double *q = &Qp[(size_t)m * Dp2 * Dp2];
+      for (int r = 0; r < D2; ++r)
+        for (int c = 0; c < D2; ++c) {
+          const int rp = (r / D) * Dp + r % D, cp = (c / D) * Dp + c % D;     // [static ; delta] halves keep their blocks
+          q[(size_t)rp * Dp2 + cp] = Q[nn * m + (size_t)r * D2 + c];
+        }
+      for (int d = D; d < Dp; ++d) q[(size_t)d * Dp2 + d] = 1.0;              // padding: P = I, r = 0 -> y = 0, decoupled
+    }
+    int rcp = t->Qpad.alloc(Qp.size());
+    if (rcp == VCMI_OK && hipMemcpy(t->Qpad.p, Qp.data(), Qp.size() * 8, hipMemcpyHostToDevice) != hipSuccess) rcp = VCMI_ERR_HIP;
+    if (rcp != VCMI_OK) {
+      delete t;
+      return rcp == VCMI_ERR_HIP ? fail(VCMI_ERR_HIP, "vcmi_traj_create: upload of the padded Q failed") : rcp;
+    }
+  }
   int rc = VCMI_OK;
   if ((rc = t->Q.alloc(Q.size())) || (rc = t->QT.alloc(QT.size())) || (rc = t->AT.alloc(AT.size())) ||
       (rc = t->bvec.alloc(bv.size())) || (rc = t->Qfrag.alloc(Qf.size())) || (rc = t->Afrag.alloc(Af.size()))) {
