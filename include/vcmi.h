@@ -87,8 +87,8 @@ int vcmi_gmmmap_posterior_dev(vcmi_gmmmap *g, const double *dX, int64_t ldx, int
 /* predict(g.px, X) -> idx (T), 1-based, first maximum wins; src/gmm.jl:44-58 */
 int vcmi_gmmmap_predict(vcmi_gmmmap *g, const double *X, int64_t ldx, int64_t T, int64_t *idx);
 int vcmi_gmmmap_predict_dev(vcmi_gmmmap *g, const double *dX, int64_t ldx, int64_t T, int64_t *didx, void *stream);
-/* Kernel selection: 0 = auto (MFMA tile kernel when dim(g), rounded up to a multiple of 4, is one of 16..64 in steps of
- * 4, 72, 80; posterior / predict for other dimensions up to 160: the tiled MFMA log-density kernel; else the generic
+/* Kernel selection: 0 = auto (MFMA tile kernel when dim(g), rounded up to a multiple of 4, is one of 16..80 in steps of
+ * 4; posterior / predict for other dimensions up to 160: the tiled MFMA log-density kernel; else the generic
  * VALU kernel), 1 = force the generic VALU kernel, 2 = force the MFMA tile kernel (VCMI_ERR_ARG if unavailable). */
 int vcmi_gmmmap_set_kernel(vcmi_gmmmap *g, int which);
 

@@ -630,7 +630,8 @@ static int dispatch_mfma(const vcmi_gmmmap *g, const double *dX, int64_t ldx, in
 #define VCMI_CASE(DPV) \
   case DPV: return launch_mfma<DPV, MODE, ((DPV) <= 48 ? 2 : 1), 4>(g, dX, ldx, T, dY, ldy, st);
     VCMI_CASE(16) VCMI_CASE(20) VCMI_CASE(24) VCMI_CASE(28) VCMI_CASE(32) VCMI_CASE(36) VCMI_CASE(40) VCMI_CASE(44)
-    VCMI_CASE(48) VCMI_CASE(52) VCMI_CASE(56) VCMI_CASE(60) VCMI_CASE(64) VCMI_CASE(72) VCMI_CASE(80)
+    VCMI_CASE(48) VCMI_CASE(52) VCMI_CASE(56) VCMI_CASE(60) VCMI_CASE(64) VCMI_CASE(68) VCMI_CASE(72) VCMI_CASE(76)
+    VCMI_CASE(80)
 #undef VCMI_CASE
     default: return fail(VCMI_ERR_ARG, "no MFMA instantiation for padded dimension %d", g->DP);
   }
@@ -639,7 +640,7 @@ static int dispatch_mfma(const vcmi_gmmmap *g, const double *dX, int64_t ldx, in
 bool gmmmap_has_mfma(int DP) {
   switch (DP) {
     case 16: case 20: case 24: case 28: case 32: case 36: case 40: case 44: case 48: case 52: case 56: case 60: case 64:
-    case 72: case 80: return true;
+    case 68: case 72: case 76: case 80: return true;
     default: return false;
   }
 }
