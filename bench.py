@@ -314,7 +314,7 @@ def bench_estep(args, world, rank):
     import voiceconversion_jl_amd as vc
     from oracle import np_oracle as npo
 
-    Dj, M, N = args.dj, 128, args.frames if args.frames != 1_000_000 else 1_250_000
+    Dj, M, N = args.dj, args.mixtures, args.frames if args.frames != 1_000_000 else 1_250_000
     w, mu, _ = npo.synth_model(1003, Dj, M)
     var = np.exp(np.random.default_rng(1003).uniform(np.log(1e-3), 0.0, (M, Dj)))   # the model: same on every rank
 
@@ -339,8 +339,8 @@ def bench_estep(args, world, rank):
     out = {"metric": "diag-GMM E-step frames/sec (Dj=%d, M=%d)" % (Dj, M), "value": fps, "unit": "frames/s", "n_gpus": world,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True,
            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-           "config": {"workload": "diag E-step (BASELINE configs[2])" if Dj == 80 else
-                      f"diag E-step, Dj={Dj} ({'MFMA kernel' if mfma_path else 'generic kernels'}; not a BASELINE config)",
+           "config": {"workload": "diag E-step (BASELINE configs[2])" if (Dj == 80 and M == 128) else
+                      f"diag E-step, Dj={Dj}, M={M} ({'MFMA kernel' if mfma_path else 'generic kernels'}; not a BASELINE config)",
                       "Dj": Dj, "M": M, "frames_per_gpu": N,
                       "collective": "all-reduce(sum) of %d doubles per step" % vc.stats_len(Dj, M)},
            "roofline": {"bound": "mfma", "kernel": (f"estep_mfma_kernel<{min(d for d in (32, 48, 64, 80, 160) if d >= Dj)}>" if mfma_path else "estep_gamma_kernel + estep_stats_kernel (generic path)") + " (+ all-reduce)", "achieved": achieved,
@@ -674,6 +674,7 @@ def main():
     ap.add_argument("--utts", type=int, default=256, help="trajectory utterances per GPU")
     ap.add_argument("--chunk", type=int, default=0, help="traj: convert in vc() chunks of this many frames "
                     "(bin/vc.jl:18 default --T=100); 0 = whole 2000-frame utterances (BASELINE configs[4])")
+    ap.add_argument("--mixtures", type=int, default=128, help="estep: number of mixtures (128 = BASELINE configs[2])")
     ap.add_argument("--dj", type=int, default=80, help="estep: joint feature dimension (80 = BASELINE; 32, 48, 64 and 160 also run the MFMA kernel; others the generic kernels)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU time budget of the cpu_baseline sample")
     ap.add_argument("--verify-allreduce", action="store_true",

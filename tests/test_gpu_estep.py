@@ -39,7 +39,8 @@ def test_golden(vc, generic):
 @pytest.mark.parametrize("generic", [False, True])
 @pytest.mark.parametrize("N,Dj,M", [(5000, 80, 128), (777, 80, 100), (1, 80, 3), (300, 48, 8), (3000, 48, 128), (2000, 64, 100),
                                     (1500, 32, 16), (600, 160, 24), (4000, 160, 128), (33, 160, 5), (1000, 6, 2), (70000, 10, 4),
-                                    (900, 50, 7), (400, 100, 5), (300, 126, 3), (257, 78, 128), (500, 25, 4)])
+                                    (900, 50, 7), (400, 100, 5), (300, 126, 3), (257, 78, 128), (500, 25, 4),
+                                    (3000, 80, 16), (3000, 80, 17), (2000, 80, 33), (2000, 80, 64), (1000, 160, 16), (999, 160, 40)])
 def test_vs_oracle(vc, N, Dj, M, generic):
     """Every even Dj <= 160 with M <= 128 runs the MFMA kernel (in the next larger of its instantiations 32, 48, 64, 80 and
     -- as two kernels, the responsibilities through HBM -- 160, with zero weights in the padding dimensions); odd Dj

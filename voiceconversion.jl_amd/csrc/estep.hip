@@ -137,12 +137,17 @@ struct EstepCfg {
 // cinit: [128] log-density constants c_m (-inf rows for m >= M so that their gamma is exactly 0)
 // PHASE 0: the whole E-step in one kernel.  PHASE 1 / 2 (EstepCfg::SPLIT): responsibilities -> G (frames x 128, row-major)
 // and the log-likelihood / statistics from G.
-template <int DJ, int PHASE>
+template <int DJ, int PHASE, bool SHARE>
 __global__ void __launch_bounds__(512)
 estep_mfma_kernel(const double *__restrict__ X, int64_t N, int M, const double *__restrict__ Wpack,
                   const double *__restrict__ cinit, double *__restrict__ part, int64_t plen,
                   const double *__restrict__ refmu, const double *__restrict__ refiv, const double *__restrict__ refc,
-                  double *__restrict__ G, int dj) {
+                  double *__restrict__ G, int dj, int mtp_arg) {
+  // mtp = 1, 2, 4 or 8 mixture tiles of 16 (>= M / 16): with fewer than eight (SHARE), 8 / mtp waves share a tile -- wave
+  // w takes tile w % mtp and every (8 / mtp)-th frame tile of step A / k-step of step B, and writes its own row of
+  // partial statistics -- so that a 16- or 64-mixture model does not pay for 128 slots.  (A template flag: the branches
+  // cost the full-width kernel 3.5 % when they are run-time decisions.)
+  const int mtp = SHARE ? mtp_arg : 8;
   // dj <= DJ is the data's joint dimension (even: rows of X are 16-byte aligned), DJ the instantiated one: the columns
   // dj .. DJ-1 of the LDS image hold other (finite) values of X, meet zero weights in step A and statistics in step B
   // that are never written out
@@ -157,16 +162,17 @@ estep_mfma_kernel(const double *__restrict__ X, int64_t N, int M, const double *
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lcol = lane & 15, lgrp = lane >> 4;
+  const int tile = SHARE ? (wave & (mtp - 1)) : wave, sub = SHARE ? wave / mtp : 0, wpt = SHARE ? 8 / mtp : 1;      // mixture tile, position among the tile's waves
 
   // this wave's weight fragments and log-density constants stay in registers for the whole kernel
   double wfrag[kGamma ? KS : 1];
   if constexpr (kGamma) {
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) wfrag[ks] = Wpack[((size_t)wave * KS + ks) * 64 + lane];
+    for (int ks = 0; ks < KS; ++ks) wfrag[ks] = Wpack[((size_t)tile * KS + ks) * 64 + lane];
   }
   // step A computes the TRANSPOSED tile (rows = frames, cols = this wave's mixtures) by swapping the MFMA operands:
   // the result then lands in LDS with lanes along consecutive mixtures -> conflict-free stores
-  const double cm = kGamma ? cinit[16 * wave + lcol] : 0.0;
+  const double cm = kGamma ? cinit[16 * tile + lcol] : 0.0;
   const d4 cin = {cm, cm, cm, cm};
 
   d4 sacc[kStats ? NDT : 1];   // statistics tiles: rows = this wave's 16 mixtures, cols = 16 of the 2*DJ columns [x | x^2]
@@ -214,6 +220,9 @@ estep_mfma_kernel(const double *__restrict__ X, int64_t N, int M, const double *
       // ---- step A: l[m][f] = c_m + sum_k W[m][k] Xe[k][f],  Xe = [x^2 ; x] ----
 #pragma unroll
       for (int ft = 0; ft < FB / 16; ++ft) {
+        if constexpr (SHARE) {
+          if ((ft & (wpt - 1)) != (sub & (wpt - 1)) || (wpt > FB / 16 && sub >= FB / 16)) continue;     // wave-uniform
+        }
         d4 acc = cin;
         const double *xr = xs + (16 * ft + lcol) * RSX + lgrp;
 #pragma unroll
@@ -233,7 +242,7 @@ estep_mfma_kernel(const double *__restrict__ X, int64_t N, int M, const double *
           }
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) lg[(16 * ft + 4 * r + lgrp) * RSG + 16 * wave + lcol] = acc[r];
+        for (int r = 0; r < 4; ++r) lg[(16 * ft + 4 * r + lgrp) * RSG + 16 * tile + lcol] = acc[r];
       }
       __syncthreads();
       // ---- softmax over the 128 mixture slots of each frame.  16 lanes per frame, lane lcol owns slots lcol + 16 i:
@@ -250,7 +259,7 @@ estep_mfma_kernel(const double *__restrict__ X, int64_t N, int M, const double *
         double u = -INFINITY;
 #pragma unroll
         for (int i = 0; i < C::MMAX / 16; ++i) {
-          v[i] = row[16 * i];
+          v[i] = (!SHARE || i < mtp) ? row[16 * i] : -INFINITY;          // slots of tiles that do not exist: gamma = 0
           u = fmax(u, v[i]);
         }
 #pragma unroll
@@ -273,7 +282,7 @@ estep_mfma_kernel(const double *__restrict__ X, int64_t N, int M, const double *
             const double thr = u - kRefine;
             const double *xf = xs + f * RSX;
 #pragma unroll 1
-            for (int i = 0; i < C::MMAX / 16; ++i) {
+            for (int i = 0; i < mtp; ++i) {
               const double li = row[16 * i];
               if (li > thr) {
                 const int m = lcol + 16 * i;
@@ -290,7 +299,7 @@ estep_mfma_kernel(const double *__restrict__ X, int64_t N, int M, const double *
             u = -INFINITY;
 #pragma unroll
             for (int i = 0; i < C::MMAX / 16; ++i) {
-              v[i] = row[16 * i];
+              v[i] = (!SHARE || i < mtp) ? row[16 * i] : -INFINITY;
               u = fmax(u, v[i]);
             }
 #pragma unroll
@@ -308,7 +317,8 @@ estep_mfma_kernel(const double *__restrict__ X, int64_t N, int M, const double *
         const bool livef = (f0 + f < N);
         const double inv = livef ? 1.0 / s : 0.0;          // frames beyond N contribute gamma = 0
 #pragma unroll
-        for (int i = 0; i < C::MMAX / 16; ++i) row[16 * i] = v[i] * inv;
+        for (int i = 0; i < C::MMAX / 16; ++i)
+          if (!SHARE || i < mtp) row[16 * i] = v[i] * inv;
         if (lcol == 0 && livef) llacc += u + log(s);
       }
       __syncthreads();
@@ -316,7 +326,7 @@ estep_mfma_kernel(const double *__restrict__ X, int64_t N, int M, const double *
 #pragma unroll
         for (int i = 0; i < FB * C::MMAX / 512; ++i) {
           const int e = tid + 512 * i, f = e / C::MMAX, m = e - f * C::MMAX;
-          if (f0 + f < N) G[(f0 + f) * C::MMAX + m] = lg[f * RSG + m];
+          if (f0 + f < N) G[(f0 + f) * C::MMAX + m] = (m < 16 * mtp) ? lg[f * RSG + m] : 0.0;
         }
       }
     } else {
@@ -324,16 +334,19 @@ estep_mfma_kernel(const double *__restrict__ X, int64_t N, int M, const double *
 #pragma unroll
       for (int ks = 0; ks < FB / 4; ++ks) {
         const int64_t f = f0 + 4 * ks + lgrp;
-        gpre[ks] = (f < N) ? G[f * C::MMAX + 16 * wave + lcol] : 0.0;     // frames beyond N contribute gamma = 0
+        gpre[ks] = (f < N) ? G[f * C::MMAX + 16 * tile + lcol] : 0.0;     // frames beyond N contribute gamma = 0
       }
     }
     // ---- step B: S[m][c] += sum_f gamma[f][m] Xe[f][c],  Xe = [x | x^2];  S0[m] += sum_f gamma[f][m] ----
     if constexpr (kStats) {
 #pragma unroll kStepBUnroll
       for (int ks = 0; ks < FB / 4; ++ks) {
+        if constexpr (SHARE) {
+          if ((ks & (wpt - 1)) != sub) continue;             // wave-uniform: this tile's waves share the k-steps
+        }
         const int f = 4 * ks + lgrp;
         double gm;
-        if constexpr (PHASE == 0) gm = lg[f * RSG + 16 * wave + lcol];
+        if constexpr (PHASE == 0) gm = lg[f * RSG + 16 * tile + lcol];
         else gm = gpre[ks];
         const double *xr = xs + f * RSX + lcol;
 #pragma unroll
@@ -350,14 +363,16 @@ estep_mfma_kernel(const double *__restrict__ X, int64_t N, int M, const double *
   }
 
   // ---- write this workgroup's partial statistics: rows m = 16 wave + lgrp + 4 r, cols = 16 j + lcol ----
-  double *P = part + (size_t)blockIdx.x * plen;
+  // row blockIdx.x * wpt + sub of the partial statistics: every mixture tile is written by the wave (tile, sub)
+  double *P = part + ((size_t)blockIdx.x * wpt + sub) * plen;
   if constexpr (kStats) {
     s0l += __shfl_xor(s0l, 16);
     s0l += __shfl_xor(s0l, 32);
-    if (lgrp == 0 && 16 * wave + lcol < M) P[16 * wave + lcol] = s0l;
+    if (lgrp == 0 && 16 * tile + lcol < M) P[16 * tile + lcol] = s0l;
+    if (lane == 0 && tile == 0 && sub > 0) P[plen - 1] = 0.0;        // the log-likelihood travels in row sub = 0
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int m = 16 * wave + 4 * r + lgrp;
+      const int m = 16 * tile + 4 * r + lgrp;
       if (m < M) {
 #pragma unroll
         for (int j = 0; j < NDT; ++j) {
@@ -371,7 +386,7 @@ estep_mfma_kernel(const double *__restrict__ X, int64_t N, int M, const double *
       }
     }
   }
-  if constexpr (kGamma) {   // log-likelihood: fixed-order reduction inside the workgroup
+  if constexpr (kGamma) {   // log-likelihood: fixed-order reduction inside the workgroup (thread 0: tile 0, sub 0)
     red[tid] = llacc;
     __syncthreads();
     if (tid == 0) {
@@ -487,7 +502,11 @@ static int estep_mfma_launch(EstepScratch &sc, const double *dX, int64_t N, int 
   VCMI_TRY(sc.cinit.reserve((size_t)C::MMAX));
   VCMI_TRY(sc.refiv.reserve((size_t)M * dj));
   VCMI_TRY(sc.refc.reserve((size_t)M));
-  VCMI_TRY(sc.part.reserve((size_t)grid * plen));
+  // mixture tiles of 16, rounded up to a power of two: 8 / mtp waves share a tile and each writes its own partial row
+  int mtp = 1;
+  while (16 * mtp < M) mtp *= 2;
+  const int wpt = 8 / mtp;
+  VCMI_TRY(sc.part.reserve((size_t)grid * wpt * plen));
   VCMI_TRY(sc.stage.reserve(nraw));
   const int b = sc.stage.next;
   sc.stage.next ^= 1;
@@ -503,13 +522,13 @@ static int estep_mfma_launch(EstepScratch &sc, const double *dX, int64_t N, int 
   VCMI_HIP(hipGetLastError());
   const double *dmu = draw + M;      // (the means of the re-evaluation are the uploaded parameters themselves: raw = [w | mu (Dj,M) | var (Dj,M)])
   if constexpr (!C::SPLIT) {
-    auto kern = estep_mfma_kernel<DJ, 0>;
+    auto kern = (mtp < 8) ? estep_mfma_kernel<DJ, 0, true> : estep_mfma_kernel<DJ, 0, false>;
     VCMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)C::LDS_BYTES));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), C::LDS_BYTES, st, dX, N, M, sc.Wpack.p, sc.cinit.p, sc.part.p, plen, dmu,
-                       sc.refiv.p, sc.refc.p, (double *)nullptr, dj);
+                       sc.refiv.p, sc.refc.p, (double *)nullptr, dj, mtp);
     VCMI_HIP(hipGetLastError());
-    hipLaunchKernelGGL(estep_reduce_kernel, dim3((unsigned)((plen + 255) / 256)), dim3(256), 0, st, sc.part.p, grid, plen,
+    hipLaunchKernelGGL(estep_reduce_kernel, dim3((unsigned)((plen + 255) / 256)), dim3(256), 0, st, sc.part.p, grid * wpt, plen,
                        dstats);
     VCMI_HIP(hipGetLastError());
   } else {
@@ -517,19 +536,19 @@ static int estep_mfma_launch(EstepScratch &sc, const double *dX, int64_t N, int 
     constexpr int64_t kSplitChunk = 1 << 20;
     const int64_t ch = std::min<int64_t>(N, kSplitChunk);
     VCMI_TRY(sc.G.reserve((size_t)ch * C::MMAX));
-    auto kg = estep_mfma_kernel<DJ, 1>;
-    auto ks = estep_mfma_kernel<DJ, 2>;
+    auto kg = (mtp < 8) ? estep_mfma_kernel<DJ, 1, true> : estep_mfma_kernel<DJ, 1, false>;
+    auto ks = (mtp < 8) ? estep_mfma_kernel<DJ, 2, true> : estep_mfma_kernel<DJ, 2, false>;
     VCMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kg), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES));
     VCMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ks), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES));
     for (int64_t n0 = 0; n0 < N; n0 += kSplitChunk) {
       const int64_t nfr = std::min<int64_t>(kSplitChunk, N - n0);
       const int g2 = (int)std::min<int64_t>((nfr + C::FB - 1) / C::FB, cus);
       hipLaunchKernelGGL(kg, dim3(g2), dim3(512), C::LDS_BYTES, st, dX + n0 * dj, nfr, M, sc.Wpack.p, sc.cinit.p, sc.part.p, plen,
-                         dmu, sc.refiv.p, sc.refc.p, sc.G.p, dj);
+                         dmu, sc.refiv.p, sc.refc.p, sc.G.p, dj, mtp);
       hipLaunchKernelGGL(ks, dim3(g2), dim3(512), C::LDS_BYTES, st, dX + n0 * dj, nfr, M, sc.Wpack.p, sc.cinit.p, sc.part.p, plen,
-                         dmu, sc.refiv.p, sc.refc.p, sc.G.p, dj);
+                         dmu, sc.refiv.p, sc.refc.p, sc.G.p, dj, mtp);
       VCMI_HIP(hipGetLastError());
-      hipLaunchKernelGGL(estep_reduce_kernel, dim3((unsigned)((plen + 255) / 256)), dim3(256), 0, st, sc.part.p, g2, plen,
+      hipLaunchKernelGGL(estep_reduce_kernel, dim3((unsigned)((plen + 255) / 256)), dim3(256), 0, st, sc.part.p, g2 * wpt, plen,
                          dstats);
       VCMI_HIP(hipGetLastError());
     }
