@@ -402,7 +402,12 @@ def bench_estep_full(args, world, rank):
            "roofline": {"bound": "mfma", "kernel": ("whole step: gmmmap_mfma_kernel<MODE 1> + estep_full_stats_kernel<%d,1>" % Dj) if Dj <= 80 else
                                   ("whole step: logdens_tiled_kernel + estep_full_stats_kernel<%d,4> (+ host Cholesky of the %d-dim blocks)" % (Dj, Dj)),
                         "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": achieved / FP64_PEAK_TFLOPS, "traffic": None, "flop_per_frame": flop, "kernel_ms": kernel_ms}}
+                        "frac": achieved / FP64_PEAK_TFLOPS,
+                        "traffic": ((pmc_traffic("estep_full_traffic.json", "gmmmap_mfma_kernel", "r02_pmc") or 0) +
+                                    (pmc_traffic("estep_full_traffic.json", "estep_full_stats_kernel", "r02_pmc") or 0) +
+                                    (pmc_traffic("estep_full_traffic.json", "estep_full_softmax_kernel", "r02_pmc") or 0)) or None
+                        if (N == 500_000 and Dj == 80) else None,
+                        "flop_per_frame": flop, "kernel_ms": kernel_ms}}
     if rank == 0:
         from oracle import c_oracle as co
 
@@ -455,9 +460,18 @@ def bench_em_full(args, world, rank):
                         "traffic": ((pmc_traffic("em_full_traffic.json", "gmmmap_mfma_kernel", "r02_pmc") or 0) +
                                     (pmc_traffic("em_full_traffic.json", "estep_full_stats_kernel", "r02_pmc") or 0) +
                                     (pmc_traffic("em_full_traffic.json", "estep_full_softmax_kernel", "r02_pmc") or 0)) or None
-                        if N == 500_000 else None,
+                        if (N == 500_000 and Dj == 80) else None,
                         "flop_per_frame": flop, "kernel_ms": kernel_ms},
            "loglik_monotone": bool(all(b >= a - 1e-6 * abs(a) for a, b in zip(hist, hist[1:])))}
+    if rank == 0 and args.cpu_seconds > 0:
+        from oracle import c_oracle as co
+
+        n = 40000 if Dj <= 80 else 10000          # the E-step is the iteration (the M-step is O(M Dj^2))
+        t0 = time.perf_counter()
+        co.estep_full(X[:n], w, mu, sig)
+        dt = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": n / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+                               "sample": f"E-step of the first {n} frames, C oracle, {dt:.1f} s on 1 of {os.cpu_count()} host cores"}
     return out
 
 
