@@ -59,7 +59,8 @@ def test_fixture_model_gv(vc, fixture_model):
         vc.TrajectoryGVGMMMap(t, -muv, Sv)
 
 
-@pytest.mark.parametrize("D,M,Ts,epochs", [(40, 8, [300, 37], 20), (12, 4, [2, 3, 17, 50], 100), (25, 5, [64, 129], 30)])
+@pytest.mark.parametrize("D,M,Ts,epochs", [(40, 8, [300, 37], 20), (12, 4, [2, 3, 17, 50], 100), (25, 5, [64, 129], 30),
+                                           (13, 3, [40, 9], 25), (35, 4, [70], 10)])
 def test_vs_oracle_batch(vc, D, M, Ts, epochs):
     """config-5 shape (static D=40) and ragged / tiny utterances (T=2: both stencil neighbours missing somewhere;
     tiles of 16 frames with several mixtures; D odd -> padded k-steps)"""
