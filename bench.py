@@ -702,9 +702,14 @@ def main():
         sys.exit(self_launch(sys.argv[1:], args.gpus))
 
     world, rank, _ = dist_setup(args.gpus)
+    if world > 1:
+        args.cpu_seconds = 0.0        # the CPU baseline is timed at N = 1 only (rank 0 keeps its small parity sample)
     out = {"convert": bench_convert, "estep": bench_estep, "estep_full": bench_estep_full, "em_full": bench_em_full,
            "dtw": bench_dtw, "traj": bench_traj, "trajgv": lambda a, w, r: bench_traj(a, w, r, gv=True),
            "selftest": bench_selftest}[args.workload](args, world, rank)
+    if world > 1:
+        for k in ("cpu_baseline", "cpu_baseline_strong", "speedup_vs_cpu_baseline", "host_inclusive"):
+            out.pop(k, None)
     out["n_gpus"] = world
     out["per_rank"] = dict(PER_RANK)
     out["collective_backend"] = BACKEND["name"]
