@@ -225,6 +225,14 @@ int vcmi_parallel_dataset_dev(int64_t n, const double *const *src, const int64_t
                               int remove_silence, int ignore0th, int add_delta, int diff, double *dXY,
                               int64_t capacity_frames, int64_t *nframes, int64_t *counts);
 
+/* GVDataset(path; ignore0th, add_delta, nmax) from in-memory feature matrices -- src/datasets.jl:134-183 (the file loop
+ * is the caller's): per utterance tgt = fm[i] (D,T[i]) without row 1 (ignore0th), with push_delta (add_delta);
+ * gv = var(tgt, 2) (corrected, Julia's default); an utterance whose variance has a NaN (T = 1) is skipped as the
+ * reference does.  out: (Dout, n) column-major, Dout = (D - ignore0th)(1 + add_delta), the kept utterances' columns in
+ * order; *nkept = how many.  Host-side helper (O(D sum T), shared out over the library's host threads). */
+int vcmi_gv_dataset(int64_t n, const double *const *fm, const int64_t *T, int D, int ignore0th, int add_delta, double *out,
+                    int64_t *nkept);
+
 #ifdef __cplusplus
 }
 #endif

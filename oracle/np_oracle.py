@@ -239,6 +239,24 @@ def constructW(D, T):
     return W.tocsc()
 
 
+def gv_dataset(feature_matrices, ignore0th=True, add_delta=False):
+    """GVDataset, src/datasets.jl:134-183 (the file loop replaced by in-memory matrices [T, D+1]): per utterance drop
+    column 0 (ignore0th, :157-159), push_delta (:161-163), gv = var(tgt, 2) -- Julia's default corrected variance (:165);
+    utterances whose variance has a NaN are skipped (:166-172).  Returns [nkept, Dout] (= Julia (Dout, nkept))."""
+    cols = []
+    for fm in feature_matrices:
+        tgt = np.asarray(fm, dtype=np.float64)
+        if ignore0th:
+            tgt = tgt[:, 1:]
+        if add_delta:
+            tgt = push_delta(tgt)
+        with np.errstate(invalid="ignore", divide="ignore"):
+            gv = np.var(tgt, axis=0, ddof=1) if tgt.shape[0] > 1 else np.full(tgt.shape[1], np.nan)
+        if not np.isnan(gv).any():
+            cols.append(gv)
+    return np.array(cols).reshape(len(cols), -1)
+
+
 def push_delta(src):
     """src/datasets.jl:6-13; src (T,D) -> (T,2D); first/last frames keep the static copy in the delta rows."""
     T, D = src.shape

@@ -66,6 +66,23 @@ def test_product_does_not_touch_the_oracle():
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", text, re.M), os.path.join(dirpath, f)
 
 
+@pytest.mark.parametrize("ignore0th,add_delta", [(True, False), (True, True), (False, True), (False, False)])
+def test_gv_dataset_host_helper(vc, ignore0th, add_delta):
+    """GVDataset (src/datasets.jl:134-183) from in-memory matrices against the numpy restatement: per-utterance corrected
+    variances, a single-frame utterance (NaN variance in the reference) skipped, nmax honoured, empty input -> 0 x 0."""
+    from oracle import np_oracle as npo
+    rng = np.random.default_rng(12)
+    fms = [rng.standard_normal((T, 26)) * (1 + i) for i, T in enumerate((50, 1, 333, 2, 17))]
+    ds = vc.GVDataset([f.T for f in fms], ignore0th=ignore0th, add_delta=add_delta)
+    ref = npo.gv_dataset(fms, ignore0th=ignore0th, add_delta=add_delta)
+    assert ds.totalphrases == 5 and ds.X.shape == ref.T.shape == ((26 - ignore0th) * (1 + add_delta), 4)
+    assert np.max(np.abs(ds.X - ref.T) / np.abs(ref.T)) < 1e-12
+    assert vc.GVDataset([f.T for f in fms], nmax=2).X.shape[1] == 1           # the second utterance has one frame
+    assert vc.GVDataset([]).X.shape == (0, 0)
+    with pytest.raises(vc.DimensionMismatch):
+        vc.GVDataset([fms[0].T, fms[2][:, :5].T])
+
+
 def test_push_delta_and_constructW_host_helpers(vc):
     from oracle import c_oracle as co
     rng = np.random.default_rng(1)

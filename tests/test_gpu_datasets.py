@@ -77,6 +77,13 @@ def test_parallel_dataset_on_device(vc, diff, ignore0th, add_delta):
                              remove_silence=False)
     want2 = np.concatenate([co.joint_features(a, b, ignore0th, add_delta, diff) for a, b in al], axis=0)
     assert np.array_equal(ds2.X.t().cpu().numpy(), want2)
+    # joint=false: the source and target halves as views (src/datasets.jl:92-96); standarize=true throws in the reference
+    ds3 = vc.ParallelDataset([(a.T, b.T) for a, b in al], diff=diff, ignore0th=ignore0th, add_delta=add_delta, align=False,
+                             remove_silence=False, joint=False)
+    half = want2.shape[1] // 2
+    assert np.array_equal(ds3.X.t().cpu().numpy(), want2[:, :half]) and np.array_equal(ds3.Y.t().cpu().numpy(), want2[:, half:])
+    with pytest.raises(vc.DimensionMismatch):
+        vc.ParallelDataset([(a.T, b.T) for a, b in al], align=False, standarize=True)
     # the matrix feeds the E-step as it is
     Dj, N = ds.X.shape
     r = vc.train_gmm(ds.X, n_components=2, n_iter=3, n_init=1, min_covar=1e-3, seed=1)

@@ -18,4 +18,4 @@ from .trajectory_gmmmap import TrajectoryGVGMMMap, TrajectoryGMMMap, constructW,
 from . import dist  # noqa: F401,E402
 from .train import EMState, train_gmm  # noqa: F401,E402
 from .gv import VarianceScaling, diffgmm, fvpostf, fvpostf_  # noqa: F401,E402
-from .datasets import ParallelDataset, align_mcep, mc2e  # noqa: F401,E402
+from .datasets import GVDataset, ParallelDataset, align_mcep, mc2e  # noqa: F401,E402

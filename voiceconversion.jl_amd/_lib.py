@@ -102,6 +102,7 @@ SIGNATURES = {
     "vcmi_align_mcep": (_int, [_dp, _i64, _dp, _i64, _int, C.c_double, _int, C.c_double, _int, _dp, _dp, _ip]),
     "vcmi_parallel_dataset_dev": (_int, [_i64, _dpp, _ip, _dpp, _ip, _int, _int, C.c_double, _int, C.c_double, _int, _int, _int,
                                          _int, _vp, _i64, _ip, _ip]),
+    "vcmi_gv_dataset": (_int, [_i64, _dpp, _ip, _int, _int, _int, _dp, _ip]),
 }
 
 for _name, (_res, _args) in SIGNATURES.items():

@@ -13,6 +13,7 @@
 //   * c2ir, h[0] = exp(g[0]), h[n] = (1/n) sum_{k=1..n} k g[k] h[n-k], is sequential in n; one wave per frame splits
 //     every sum over its 64 lanes (g and h in LDS) and reduces with cross-lane adds.
 #include "vcmi_common.hpp"
+#include "hostpipe.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -316,5 +317,55 @@ extern "C" int vcmi_align_mcep(const double *src, int64_t S, const double *tgt, 
     memcpy(newtgt_out + (size_t)D * k, &h[(size_t)2 * D * k + D], sizeof(double) * D);
   }
   *ncols = nfr;
+  return VCMI_OK;
+}
+
+// GVDataset from in-memory feature matrices -- src/datasets.jl:134-183.  Per utterance: drop row 1 (ignore0th), push_delta
+// (add_delta; the same rule as vcmi_push_delta: delta_t = (x_{t+1} - x_{t-1}) / 2 for 2 <= t <= T-1, the static value at
+// both ends), var(tgt, 2) = sum (x - mean)^2 / (T - 1) per row; utterances with a NaN in it (T = 1) are skipped.
+extern "C" int vcmi_gv_dataset(int64_t n, const double *const *fm, const int64_t *T, int D, int ignore0th, int add_delta,
+                               double *out, int64_t *nkept) {
+  if (n < 0 || (n > 0 && (!fm || !T || !out)) || !nkept) return fail(VCMI_ERR_ARG, "vcmi_gv_dataset: bad argument");
+  const int r0 = ignore0th ? 1 : 0, Ds = D - r0, Dout = Ds * (add_delta ? 2 : 1);
+  if (Ds < 1) return fail(VCMI_ERR_DIM, "vcmi_gv_dataset: feature dimension %d too small", D);
+  for (int64_t i = 0; i < n; ++i)
+    if (!fm[i] || T[i] < 0) return fail(VCMI_ERR_ARG, "vcmi_gv_dataset: utterance %lld invalid", (long long)(i + 1));
+  std::vector<double> gv((size_t)Dout * n);
+  std::vector<char> keep((size_t)n, 0);
+  host_parallel_for(n, 1, [&](int64_t lo, int64_t hi) {
+    for (int64_t i = lo; i < hi; ++i) {
+      const double *x = fm[i];
+      const int64_t Ti = T[i];
+      double *g = &gv[(size_t)Dout * i];
+      // value (row k of [static; delta], frame t) without materialising the matrix
+      auto val = [&](int k, int64_t t) -> double {
+        if (k < Ds) return x[r0 + k + (size_t)D * t];
+        const int d = k - Ds;
+        if (t == 0 || t + 1 >= Ti) return x[r0 + d + (size_t)D * t];
+        return -0.5 * x[r0 + d + (size_t)D * (t - 1)] + 0.5 * x[r0 + d + (size_t)D * (t + 1)];
+      };
+      bool ok = Ti >= 2;                      // var of fewer than two frames is NaN in the reference: skipped
+      for (int k = 0; k < Dout && ok; ++k) {
+        double m = 0.0;
+        for (int64_t t = 0; t < Ti; ++t) m += val(k, t);
+        m /= (double)Ti;
+        double s = 0.0;
+        for (int64_t t = 0; t < Ti; ++t) {
+          const double dv = val(k, t) - m;
+          s += dv * dv;
+        }
+        g[k] = s / (double)(Ti - 1);
+        if (std::isnan(g[k])) ok = false;
+      }
+      keep[i] = ok ? 1 : 0;
+    }
+  });
+  int64_t c = 0;
+  for (int64_t i = 0; i < n; ++i)
+    if (keep[i]) {
+      memcpy(out + (size_t)Dout * c, &gv[(size_t)Dout * i], sizeof(double) * Dout);
+      ++c;
+    }
+  *nkept = c;
   return VCMI_OK;
 }

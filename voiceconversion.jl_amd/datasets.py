@@ -36,8 +36,12 @@ class ParallelDataset:
     the E-step (train_gmm).  align=True runs align_mcep on every pair first (src/align.jl:38-55), so raw parallel
     utterances go in and the training matrix comes out without a host round trip."""
 
-    def __init__(self, pairs, diff=False, ignore0th=True, add_delta=False, align=True, alpha=0.41, fftlen=512,
-                 threshold=-14.0, remove_silence=True, nmax=100):
+    def __init__(self, pairs, diff=False, joint=True, ignore0th=True, add_delta=False, align=True, alpha=0.41, fftlen=512,
+                 threshold=-14.0, remove_silence=True, nmax=100, standarize=False):
+        if standarize:
+            # src/datasets.jl:105-108 writes `(X - Xmean) / Xstd` with a (D,N) and a (D,1) operand: in the reference's
+            # Julia 0.5 that is a DimensionMismatch, not a standardisation -- the branch cannot have been used
+            raise _lib.DimensionMismatch("standarize=true throws in the reference (src/datasets.jl:105-108); not provided")
         import torch
 
         pairs = list(pairs)[:nmax]                    # count >= nmax && break, src/datasets.jl:95-96
@@ -65,9 +69,42 @@ class ParallelDataset:
                                                       buf.data_ptr(), cap, _lib.iptr(nfr), _lib.iptr(counts)))
         N = int(nfr[0])
         self.X = buf[:N * Dj].view(N, Dj).t()         # (Dj, N), unit stride along Dj
+        self.Y = None
+        if not joint:                                 # X = XY[1:D,:], Y = XY[D+1:end,:], src/datasets.jl:92-96 (views)
+            self.X, self.Y = self.X[:Dj // 2], self.X[Dj // 2:]
         self.counts = counts
         self.diff = bool(diff)
         self.totalframes, self.totalphrases = N, n
 
     def __len__(self):
         return self.totalframes
+
+
+class GVDataset:
+    """GVDataset(path; ignore0th, add_delta, nmax) from in-memory feature matrices -- src/datasets.jl:134-183 (the loop
+    over `*.jld` files is the caller's): `X` is the (Dout, n) matrix of per-utterance variances `var(tgt, 2)` that
+    bin/train_gv.jl fits the GV model on; utterances whose variance is NaN (a single frame) are skipped as in the
+    reference."""
+
+    def __init__(self, feature_matrices, ignore0th=True, add_delta=False, nmax=100):
+        fms = [jl_matrix(f, "feature_matrix") for f in list(feature_matrices)[:nmax]]   # totalphrases >= nmax && break
+        n = len(fms)
+        if n == 0:
+            self.X = np.zeros((0, 0))                 # X = zeros(0, 0), src/datasets.jl:146
+            self.totalphrases = 0
+            return
+        D = fms[0].shape[0]
+        for f in fms:
+            if f.shape[0] != D:
+                raise _lib.DimensionMismatch("all feature matrices must share the feature dimension")
+        T = np.array([f.shape[1] for f in fms], dtype=np.int64)
+        Dout = (D - int(bool(ignore0th))) * (2 if add_delta else 1)
+        out = np.empty((Dout, n), order="F")
+        nk = np.zeros(1, dtype=np.int64)
+        dpp = C.POINTER(C.c_double) * n
+        _lib.check(_lib.lib.vcmi_gv_dataset(n, dpp(*[_lib.dptr(f) for f in fms]), _lib.iptr(T), D, int(bool(ignore0th)),
+                                            int(bool(add_delta)), _lib.dptr(out), _lib.iptr(nk)))
+        self.X = np.asfortranarray(out[:, :int(nk[0])])
+        self.totalphrases = n
+        if not np.all(np.isfinite(self.X)):            # @assert all(isfinite.(X)), src/datasets.jl:179
+            raise AssertionError("non-finite global variance")

@@ -21,7 +21,7 @@ import LinearAlgebra
 export FrameByFrameConverter, TrajectoryConverter, GMMMapParam, GMMMap, TrajectoryGMMMap, TrajectoryGVGMMMap,
        fvconvert, vc, ncomponents, dim,
        VarianceScaling, fvpostf!, fvpostf,
-       align, align_mcep, push_delta,
+       align, align_mcep, push_delta, GVDataset,
        DTW, fit!, update!, set_template!, backward,
        predict_proba, predict_proba!, predict, predict!, diffgmm,
        estep_diag, estep_full, GMMEM, estep!, mstep!, params, set_devices, device_count
@@ -479,6 +479,28 @@ function align_mcep(src::Matrix{Float64}, tgt::Matrix{Float64}, α::AbstractFloa
                 (Ptr{Float64}, Int64, Ptr{Float64}, Int64, Cint, Cdouble, Cint, Cdouble, Cint, Ptr{Float64}, Ptr{Float64}, Ref{Int64}),
                 src, S, tgt, size(tgt, 2), D, α, fftlen, threshold, remove_silence ? 1 : 0, so, to, k))
     so[:, 1:k[]], to[:, 1:k[]]
+end
+
+# GVDataset(path; ignore0th, add_delta, nmax) -- src/datasets.jl:134-183, from in-memory feature matrices (loading the
+# `.jld` files stays with the caller): X = the (Dout, n) matrix of per-utterance variances var(tgt, 2)
+immutable GVDataset
+    X::Matrix{Float64}
+    function GVDataset(fms::Vector{Matrix{Float64}}; ignore0th::Bool=true, add_delta::Bool=false, nmax::Int=100)
+        fms = fms[1:min(length(fms), nmax)]
+        n = length(fms)
+        n == 0 && return new(zeros(0, 0))
+        D = size(fms[1], 1)
+        all(f -> size(f, 1) == D, fms) || throw(DimensionMismatch("all feature matrices must share the feature dimension"))
+        T = Int64[size(f, 2) for f in fms]
+        Dout = (D - (ignore0th ? 1 : 0)) * (add_delta ? 2 : 1)
+        out = Array(Float64, Dout, n); k = Ref{Int64}(0)
+        check(ccall((:vcmi_gv_dataset, libvcmi), Cint,
+                    (Int64, Ptr{Ptr{Float64}}, Ptr{Int64}, Cint, Cint, Cint, Ptr{Float64}, Ref{Int64}),
+                    n, Ptr{Float64}[pointer(f) for f in fms], T, D, ignore0th ? 1 : 0, add_delta ? 1 : 0, out, k))
+        X = out[:, 1:k[]]
+        @assert all(isfinite.(X))
+        new(X)
+    end
 end
 
 # ------------------------------------------------------------------------------------- device-resident EM
