@@ -89,7 +89,7 @@ class GMMMap:
         self.D, self.M = Dj >> 1, M
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and lib is not None:      # (module globals may already be gone at interpreter exit)
             lib().vco_gmmmap_free(self._h)
             self._h = None
 
@@ -180,7 +180,7 @@ class TrajectoryGMMMap:
             raise np.linalg.LinAlgError("singular conditional covariance")
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and lib is not None:      # (module globals may already be gone at interpreter exit)
             lib().vco_traj_free(self._h)
             self._h = None
 

@@ -31,10 +31,10 @@ class GMMMap(FrameByFrameConverter):
         self._D, self._M = Dj >> 1, M
         self.px = GMM(self)                      # src/gmmmap.jl:87
 
-    def __del__(self):
+    def __del__(self, _destroy=_lib.lib.vcmi_gmmmap_destroy):     # bound at definition: module globals may be gone at exit
         h = getattr(self, "_h", None)
         if h:
-            _lib.lib.vcmi_gmmmap_destroy(h)
+            _destroy(h)
             self._h = None
 
     def __len__(self):                           # Base.length(g) = 1, src/gmmmap.jl:93

@@ -32,10 +32,10 @@ class EMState:
         _lib.check(_lib.lib.vcmi_gmm_em_create(Dj, M, _lib.dptr(w), _lib.dptr(mu), _lib.dptr(sigma), float(min_covar), C.byref(h)))
         self._h = h
 
-    def __del__(self):
+    def __del__(self, _destroy=_lib.lib.vcmi_gmm_em_destroy):     # bound at definition: module globals may be gone at exit
         h, self._h = getattr(self, "_h", None), None
         if h:
-            _lib.lib.vcmi_gmm_em_destroy(h)
+            _destroy(h)
 
     def estep(self, X, out=None):
         """Local statistics of the (Dj,N) device block X -> packed device tensor [S0 | S1 | S2 | loglik]."""

@@ -52,10 +52,10 @@ class TrajectoryGMMMap(TrajectoryConverter):
         _lib.check(_lib.lib.vcmi_traj_create(g._h, int(T), C.byref(h)))
         self._h = h
 
-    def __del__(self):
+    def __del__(self, _destroy=_lib.lib.vcmi_traj_destroy):       # bound at definition: module globals may be gone at exit
         h = getattr(self, "_h", None)
         if h:
-            _lib.lib.vcmi_traj_destroy(h)
+            _destroy(h)
             self._h = None
 
     def __len__(self):                      # Base.length(t) = size(W,2) / (dim/2) = T, src/trajectory_gmmmap.jl:34
@@ -123,10 +123,10 @@ class TrajectoryGVGMMMap(TrajectoryConverter):
         _lib.check(_lib.lib.vcmi_trajgv_create(tgmm._h, _lib.dptr(muv), _lib.dptr(sigmavv), C.byref(h)))
         self._h = h
 
-    def __del__(self):
+    def __del__(self, _destroy=_lib.lib.vcmi_trajgv_destroy):     # bound at definition: module globals may be gone at exit
         h = getattr(self, "_h", None)
         if h:
-            _lib.lib.vcmi_trajgv_destroy(h)
+            _destroy(h)
             self._h = None
 
     def __len__(self):                      # src/trajectory_gmmmap.jl:132
