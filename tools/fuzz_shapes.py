@@ -59,7 +59,27 @@ for _ in range(cases):
     y = t.fvconvert_batch([x.T])[0]
     yref, _, _ = reft.fvconvert(x)
     note("trajectory", relerr(y, yref.T), (D, M, T))
+# DTW: a ragged batch per seed (bit-exact paths and align outputs; strips for S > 512, every fused DMAX, both step windows)
+mism = 0
+for bs in (1, 2):
+    D = int(rg.integers(1, 48))
+    pairs = []
+    for _ in range(cases):
+        S, T = int(rg.integers(1, 1300)), int(rg.integers(1, 700))
+        tmpl = rg.standard_normal((S, D))
+        idx = np.clip(np.sort(rg.integers(0, S, T)), 0, S - 1)
+        pairs.append((tmpl, tmpl[idx] + 0.2 * rg.standard_normal((T, D))))
+    d = vc.DTW(fstep=0, bstep=bs)
+    paths = vc.fit_batch(d, [t.T for t, _ in pairs], [q.T for _, q in pairs])
+    for (t, q), pth in zip(pairs, paths):
+        mism += int(not np.array_equal(pth, co.dtw_fit(t, q, 0, bs, tables=False)))
+    if bs == 2:
+        outs = vc.align_batch([t.T for t, _ in pairs], [q.T for _, q in pairs])
+        for (t, q), (src, nt) in zip(pairs, outs):
+            mism += int(not np.array_equal(nt, co.align(t, q)[0].T))
+print(f"dtw          path / align mismatches {mism}")
+worst["dtw"] = (float(mism), None)
 for k, (v, shape) in worst.items():
     print(f"{k:12s} worst relative error {v:.2e} at {shape}")
-bad = [k for k, (v, _) in worst.items() if not v < (1e-6 if k == "trajectory" else 1e-9)]
+bad = [k for k, (v, _) in worst.items() if not v < (1e-6 if k == "trajectory" else 1e-9)]      # dtw: 0 mismatches
 print("FUZZ_OK" if not bad else f"FUZZ_FAIL {bad}")
