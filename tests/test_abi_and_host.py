@@ -142,3 +142,15 @@ def test_mstep_formulas(vc):
     S2 = (X * X).sum(0)[:, None]
     w, mu, var = vc.mstep_diag(S0, S1, S2, min_covar=0.0)
     assert np.allclose(w, 1.0) and np.allclose(mu[:, 0], X.mean(0)) and np.allclose(var[:, 0], X.var(0), rtol=1e-9)
+
+
+def test_generated_asm_includes_match_their_generators(tmp_path):
+    """csrc/dtw_fused_asm.inc and csrc/dtw_obs_asm.inc are generated files that are committed (the build has no Python
+    step): regenerate both and compare byte for byte, so that neither the generator nor the file can drift alone."""
+    import subprocess
+    import sys
+    for gen, inc in (("gen_dtw_fused_asm.py", "dtw_fused_asm.inc"), ("gen_dtw_obs_asm.py", "dtw_obs_asm.inc")):
+        out = tmp_path / inc
+        subprocess.run([sys.executable, os.path.join(ROOT, "tools", gen), str(out)], check=True)
+        committed = open(os.path.join(ROOT, "voiceconversion.jl_amd", "csrc", inc), "rb").read()
+        assert out.read_bytes() == committed, f"{inc} differs from what tools/{gen} generates"

@@ -181,3 +181,19 @@ def test_fused_kernel_more_workgroups_than_slots(vc):
         t, s = pairs[i]
         assert np.array_equal(paths[i], co.dtw_fit(t, s, 0, 2, tables=False)), i
         assert np.array_equal(outs[i][1], co.align(t, s)[0].T), i
+
+
+@pytest.mark.parametrize("S,T", [(60, 12000), (300, 9800)])
+def test_long_sequence_falls_back_to_two_kernels(vc, S, T):
+    """A sequence of more than ~9.7k frames (50 s at a 5 ms shift) exceeds the LDS budget of the fused forward kernel (it
+    keeps 16 bytes per column of strip-boundary costs in LDS); path-only calls must then take the observation + recurrence
+    kernels instead of failing, with the same bit-exact path; align included."""
+    from oracle import c_oracle as co
+    rng = np.random.default_rng(S + T)
+    t, s = _warped_pair(rng, S, T, 8)
+    d = vc.DTW(fstep=0, bstep=2)
+    ref = co.dtw_fit(t, s, 0, 2, tables=False)
+    assert np.array_equal(vc.fit_(d, t.T, s.T, tables=False), ref)
+    assert np.array_equal(vc.fit_batch(d, [t.T, t[:40].T], [s.T, s[:100].T])[0], ref)
+    src, newtgt = vc.align(t.T, s.T)
+    assert np.array_equal(newtgt, co.align(t, s)[0].T)

@@ -153,6 +153,15 @@ def test_linearity_at_full_size(vc):
     from oracle import c_oracle as co
     ref = co.GMMMap(w, mu, sig).fvconvert(base[:256])
     assert frame_relerr(first[:256].cpu().numpy().T, ref.T) < TOL
+    # the affine property, at full size: one mixture -> posterior 1, y = b + A x for every frame
+    g1 = vc.GMMMap(*julia_model(w[:1] / w[:1], mu[:1], sig[:1]))
+    T3 = T // 3
+    x1, x2, x3 = Xd[:T3], Xd[T3:2 * T3].flip(0), Xd[2 * T3:3 * T3] * 0.5
+    y1, y2, y3 = (vc.fvconvert(g1, x.contiguous().t()).t() for x in (x1, x2, x3))
+    yc = vc.fvconvert(g1, (x1 + x2 - x3).contiguous().t()).t()
+    torch.cuda.synchronize()
+    scale = float(torch.max(torch.abs(yc)))
+    assert float(torch.max(torch.abs(yc - (y1 + y2 - y3)))) < 1e-9 * scale
 
 
 @pytest.mark.parametrize("kernel", [0, 1])

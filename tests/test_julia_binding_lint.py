@@ -277,3 +277,51 @@ def test_reference_signatures_are_kept():
               "fvconvert", "vc", "ncomponents", "dim", "VarianceScaling", "fvpostf!", "fvpostf", "align", "align_mcep",
               "push_delta"):
         assert n in names, n
+
+
+# Julia 0.5-only syntax that no longer parses / dispatches on Julia >= 1.0 (the module targets >= 1.0: `mutable struct`,
+# `undef`, `GC.@preserve`).  One such token anywhere makes `include("VoiceConversionMI.jl")` fail as a whole.
+JULIA_05_TOKENS = [
+    (r"^\s*immutable\b", "`immutable` (write `struct`)"),
+    (r"^\s*type\s+\w", "`type` (write `mutable struct`)"),
+    (r"^\s*abstract\s+(?!type\b)\w", "`abstract X` (write `abstract type X end`)"),
+    (r"^\s*typealias\b", "`typealias`"),
+    (r"\bArray\(\s*[A-Z]\w*\s*,", "`Array(T, dims...)` (write `Array{T}(undef, dims...)`)"),
+    (r"\bVector\(\s*[A-Z]\w*\s*,", "`Vector(T, n)`"),
+    (r"\bMatrix\(\s*[A-Z]\w*\s*,", "`Matrix(T, m, n)`"),
+    (r"\bVoid\b", "`Void` (write `Cvoid` / `Nothing`)"),
+    (r"\b(sumabs2|indmax|indmin|repmat|blkdiag|speye|findin)\(", "a Base function removed in Julia 1.0"),
+    (r"\bfind\(", "`find(` (write `findall`)"),
+    (r"\bfunction\s+\w+\{", "`f{T}(...)` (write `f(...) where T`)"),
+    (r"\bfinalizer\(\s*[^\W\d]\w*\s*,\s*\w+\s*->", "`finalizer(obj, f)` (Julia >= 1.0 takes the function first)"),
+]
+
+
+def julia_05_errors(text):
+    code = re.sub(r"#[^\n]*", "", text)                   # comments may describe the old syntax
+    code = re.sub(r'"(?:[^"\\\n]|\\.)*"', '""', code)     # and so may strings
+    errors = []
+    for pat, what in JULIA_05_TOKENS:
+        for m in re.finditer(pat, code, flags=re.M):
+            errors.append(f"line {code.count(chr(10), 0, m.start()) + 1}: Julia 0.5-only {what}")
+    return errors
+
+
+def test_no_julia_05_only_syntax():
+    text = open(JL).read()
+    assert not julia_05_errors(text), "\n".join(julia_05_errors(text))
+    # the lint must catch what round 2 shipped (`immutable GVDataset`, `Array(Float64, Dout, n)`)
+    assert any("immutable" in e for e in julia_05_errors(text.replace("\nstruct GVDataset", "\nimmutable GVDataset")))
+    assert any("Array(T" in e for e in julia_05_errors(text.replace("Matrix{Float64}(undef, Dout, n)", "Array(Float64, Dout, n)")))
+
+
+def test_julia_block_structure_balances():
+    """Every block opener of the module has its `end` (a cheap stand-in for the parser that is not in the image)."""
+    code = re.sub(r"#[^\n]*", "", open(JL).read())
+    code = re.sub(r'"(?:[^"\\\n]|\\.)*"', '""', code)
+    code = re.sub(r"\[[^\[\]\n]*\bend\b[^\[\]\n]*\]", "[]", code)          # a[2:end]
+    # openers start a line (comprehension `for`s and `x = cond ? a : b` never do); `do` blocks end one
+    opens = len(re.findall(r"^[ \t]*(?:module|function|struct|mutable[ \t]+struct|abstract[ \t]+type|if|for|while|let|try|begin|macro)\b", code, flags=re.M))
+    opens += len(re.findall(r"\bdo\b[^\n]*$", code, flags=re.M)) + len(re.findall(r"\S[ \t]+begin[ \t]*$", code, flags=re.M))
+    ends = len(re.findall(r"(?<![\w.:])end\b", code))
+    assert opens == ends, (opens, ends)

@@ -17,13 +17,20 @@ COMMON = ["g++", "-std=c++17", "-O1", "-g", "-fno-omit-frame-pointer", "-D__HIP_
 LINK = ["-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib", "-lamdhip64", "-ldl", "-lpthread"]
 
 
-def _build_and_run(name, flags, env_extra):
+# devgroup.cpp with its HIP + RCCL hooks swapped (at compile time) for host-memory devices and an in-process collective:
+# four members, vcmi_set_devices racing with runs, a member that never joins the all-reduce
+GROUP_CMD = ["g++", "-std=c++17", "-O1", "-g", "-fno-omit-frame-pointer", "-D__HIP_PLATFORM_AMD__", "-DVCMI_DEVGROUP_TEST_BACKEND",
+             "-I/opt/rocm/include", os.path.join(ROOT, "tests", "c", "devgroup_stress.cpp"),
+             os.path.join(CSRC, "core.cpp"), os.path.join(CSRC, "devgroup.cpp")]
+
+
+def _build_and_run(name, flags, env_extra, cmd=COMMON, ok="host_stress: ok"):
     os.makedirs(OUT, exist_ok=True)
     exe = os.path.join(OUT, name)
-    subprocess.run(COMMON + flags + ["-o", exe] + LINK, check=True, capture_output=True, text=True)
+    subprocess.run(cmd + flags + ["-o", exe] + LINK, check=True, capture_output=True, text=True)
     env = dict(os.environ, **env_extra)
     p = subprocess.run([exe], capture_output=True, text=True, timeout=600, env=env)
-    assert p.returncode == 0 and "host_stress: ok" in p.stdout, (p.stdout[-2000:], p.stderr[-4000:])
+    assert p.returncode == 0 and ok in p.stdout, (p.stdout[-2000:], p.stderr[-4000:])
     assert "ERROR: AddressSanitizer" not in p.stderr and "WARNING: ThreadSanitizer" not in p.stderr and "runtime error" not in p.stderr, p.stderr[-4000:]
 
 
@@ -34,6 +41,23 @@ def test_host_code_under_asan_ubsan():
 
 def test_host_code_under_tsan():
     _build_and_run("host_stress_tsan", ["-fsanitize=thread"], {"TSAN_OPTIONS": "halt_on_error=0 report_signal_unsafe=0"})
+
+
+def test_device_group_four_members_under_asan_ubsan():
+    _build_and_run("devgroup_stress_asan", ["-fsanitize=address,undefined"], {"ASAN_OPTIONS": "detect_leaks=0", "UBSAN_OPTIONS": "print_stacktrace=1"},
+                   cmd=GROUP_CMD, ok="devgroup_stress: ok")
+
+
+def test_device_group_four_members_under_tsan():
+    _build_and_run("devgroup_stress_tsan", ["-fsanitize=thread"], {"TSAN_OPTIONS": "halt_on_error=0 report_signal_unsafe=0"},
+                   cmd=GROUP_CMD, ok="devgroup_stress: ok")
+
+
+def test_product_library_has_no_test_backend():
+    """The stub collective is a compile-time switch of the sanitizer build only: libvcmi.so must not contain it."""
+    lib = os.path.join(ROOT, "voiceconversion.jl_amd", "libvcmi.so")
+    syms = subprocess.run(["nm", "-D", "--defined-only", lib], capture_output=True, text=True).stdout
+    assert "devgroup_test_backend" not in syms and "vcmi_set_devices" in syms
 
 
 def test_oracle_under_asan_ubsan():

@@ -1,7 +1,7 @@
 import sys, time, numpy as np
 sys.path.insert(0, '/root/repo')
 import voiceconversion_jl_amd as vc
-from oracle import np_oracle as npo
+import synthdata as npo
 D, M, T = 40, 64, 1_000_000
 w, mu, sig = npo.synth_model(1002, 2 * D, M)
 g = vc.GMMMap(w, np.asfortranarray(mu.T), np.asfortranarray(np.transpose(sig, (2, 1, 0))))

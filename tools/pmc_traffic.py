@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""HBM traffic of a bench workload's kernels: FETCH_SIZE and WRITE_SIZE in SEPARATE rocprofv3 passes (they do not fit one
+pass: MI355X_MICROARCH.md, HBM section), kernel-trace only, of `python3 bench.py --workload <w> --steps 2 --warmup 1
+--cpu-seconds 0` (with --cpu-seconds 0 the bench launches nothing but the warm-up, the timed steps and a small parity
+sample).  Writes <out>/traffic.json: per kernel the KB counters per launch and per bench step, plus `_meta` with the hash
+of the library sources the passes were collected from -- bench.py refuses a table whose hash is not the current one.
+
+    python3 tools/pmc_traffic.py <workload> [--out DIR] [extra bench args]
+
+Never touches the GPU itself: rocprofv3 and the bench are child processes (the program after `--` is python3 itself)."""
+import collections
+import csv
+import glob
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+NSTEPS = 3            # 2 timed + 1 warm-up
+
+
+def main():
+    argv = sys.argv[1:]
+    w = argv.pop(0)
+    out = os.path.join(ROOT, "gpurun_out", "pmc_traffic", w)
+    if "--out" in argv:
+        i = argv.index("--out")
+        out = argv[i + 1]
+        del argv[i:i + 2]
+    import bench
+
+    res = collections.defaultdict(dict)
+    cmd_tail = ["--", sys.executable, os.path.join(ROOT, "bench.py"), "--workload", w, "--steps", "2", "--warmup", "1",
+                "--cpu-seconds", "0", "--pmc", "off"] + argv
+    for c in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = os.path.join(out, c)
+        os.makedirs(d, exist_ok=True)
+        env = dict(os.environ, TMPDIR="/tmp")
+        with open(os.path.join(d, "err.txt"), "w") as err:
+            subprocess.run(["rocprofv3", "--kernel-trace", "--pmc", c, "--output-format", "csv", "-d", d] + cmd_tail,
+                           stdout=subprocess.DEVNULL, stderr=err, timeout=400, cwd="/tmp", env=env, check=True)
+        f = glob.glob(os.path.join(d, "*", "*counter_collection.csv"))[0]
+        acc, n = collections.defaultdict(float), collections.Counter()
+        for r in csv.DictReader(open(f)):
+            k = r["Kernel_Name"].split("(")[0]
+            if r["Counter_Name"] == c:
+                acc[k] += float(r["Counter_Value"])
+                n[k] += 1
+        for k in acc:
+            res[k][c + "_KB_per_launch"] = acc[k] / n[k]
+            res[k][c + "_KB_per_step"] = acc[k] / NSTEPS
+            res[k]["launches_per_step"] = n[k] / NSTEPS
+    for k, d in res.items():
+        d["hbm_bytes_per_launch_raw"] = (d.get("FETCH_SIZE_KB_per_launch", 0) + d.get("WRITE_SIZE_KB_per_launch", 0)) * 1024
+        d["hbm_bytes_per_step_raw"] = (d.get("FETCH_SIZE_KB_per_step", 0) + d.get("WRITE_SIZE_KB_per_step", 0)) * 1024
+    res = dict(res)
+    res["_meta"] = {"source_hash": bench.source_hash(), "collected": time.strftime("%Y-%m-%dT%H:%M:%SZ", time.gmtime()),
+                    "command": "bench.py --workload %s --steps 2 --warmup 1 --cpu-seconds 0 %s" % (w, " ".join(argv)),
+                    "steps_per_pass": NSTEPS}
+    json.dump(res, open(os.path.join(out, "traffic.json"), "w"), indent=1)
+    print(json.dumps(res, indent=1))
+
+
+if __name__ == "__main__":
+    main()

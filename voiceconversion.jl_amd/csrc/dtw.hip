@@ -1118,7 +1118,7 @@ static int dtw_host_batch(int64_t n, const double *const *tmpl, const int64_t *S
   std::vector<int64_t> costs((size_t)n);
   for (int64_t p = 0; p < n; ++p) costs[(size_t)p] = S[p] * std::max<int64_t>(T[p], 1);
   const std::vector<int> part = shard_by_cost(costs, m);
-  return group_run([&](int i) -> int {
+  return group_run(m, [&](int i) -> int {
     std::vector<const double *> t2, s2;
     std::vector<int64_t> S2, T2;
     std::vector<int64_t *> p2;

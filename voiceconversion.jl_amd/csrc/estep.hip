@@ -434,6 +434,7 @@ struct EstepStaging {
 struct EstepScratch {
   DevBuf<double> mu, iv, cst, G, LSE, part, Wpack, cinit, X, stats, raw, refiv, refc;
   EstepStaging stage;
+  StreamOrder order;   // calls of one thread on different streams share the buffers above
 };
 static EstepScratch &scratch() {
   static thread_local EstepScratch s;
@@ -556,8 +557,20 @@ static int estep_mfma_launch(EstepScratch &sc, const double *dX, int64_t N, int 
   return VCMI_OK;
 }
 
+static int estep_device_run(const double *dX, int64_t N, int Dj, int M, const double *w, const double *mu, const double *var,
+                            double *dstats, hipStream_t st);
+
 static int estep_device(const double *dX, int64_t N, int Dj, int M, const double *w, const double *mu, const double *var,
                         double *dstats, hipStream_t st) {
+  EstepScratch &sc = scratch();
+  VCMI_TRY(sc.order.enter(st));
+  const int rc = estep_device_run(dX, N, Dj, M, w, mu, var, dstats, st);
+  (void)sc.order.leave(st);
+  return rc;
+}
+
+static int estep_device_run(const double *dX, int64_t N, int Dj, int M, const double *w, const double *mu, const double *var,
+                            double *dstats, hipStream_t st) {
   if (N < 0 || Dj < 1 || M < 1) return fail(VCMI_ERR_DIM, "E-step: N=%lld Dj=%d M=%d invalid", (long long)N, Dj, M);
   if (!w || !mu || !var || !dstats || (N > 0 && !dX)) return fail(VCMI_ERR_ARG, "E-step: NULL argument");
   EstepScratch &sc = scratch();
@@ -886,6 +899,7 @@ struct EstepFullScratch {
   DevBuf<double> LP, lse, part, X, stats, params;
   DevBuf<int> flag;
   vcmi_gmmmap *px = nullptr;
+  StreamOrder order;   // calls of one thread on different streams share the buffers above
   ~EstepFullScratch() { delete px; }
 };
 static EstepFullScratch &full_scratch() {
@@ -894,7 +908,17 @@ static EstepFullScratch &full_scratch() {
 }
 
 // statistics of N device-resident frames under the prepared p(x) handle -> dstats (zeroed here); asynchronous on st
+static int estep_full_core_run(vcmi_gmmmap *px, const double *dX, int64_t N, int Dj, int M, double *dstats, hipStream_t st);
+
 static int estep_full_core(vcmi_gmmmap *px, const double *dX, int64_t N, int Dj, int M, double *dstats, hipStream_t st) {
+  EstepFullScratch &sc = full_scratch();
+  VCMI_TRY(sc.order.enter(st));
+  const int rc = estep_full_core_run(px, dX, N, Dj, M, dstats, st);
+  (void)sc.order.leave(st);
+  return rc;
+}
+
+static int estep_full_core_run(vcmi_gmmmap *px, const double *dX, int64_t N, int Dj, int M, double *dstats, hipStream_t st) {
   const int64_t plen = (int64_t)M * (1 + Dj + (int64_t)Dj * Dj) + 1;
   VCMI_HIP(hipMemsetAsync(dstats, 0, plen * sizeof(double), st));
   if (N == 0) return VCMI_OK;
@@ -966,6 +990,7 @@ static int estep_full_device(const double *dX, int64_t N, int Dj, int M, const d
   if (!w || !mu || !sigma || !dstats || (N > 0 && !dX)) return fail(VCMI_ERR_ARG, "E-step: NULL argument");
   EstepFullScratch &sc = full_scratch();
   if (N == 0) return estep_full_core(nullptr, dX, 0, Dj, M, dstats, st);
+  VCMI_TRY(sc.order.enter(st));   // the parameter staging and the p(x) handle are rewritten before the core runs
   if (gmm_px_device_prepare_supported(Dj)) {
     const size_t dd = (size_t)Dj * Dj;
     VCMI_TRY(sc.params.reserve((size_t)M * (1 + Dj + dd)));
@@ -1093,12 +1118,12 @@ static int estep_host(Scratch &(*get_scratch)(), const double *X, int64_t N, int
     VCMI_HIP(hipMemcpy(h.data(), get_scratch().stats.p, (size_t)plen * 8, hipMemcpyDeviceToHost));
     return VCMI_OK;
   }
-  VCMI_TRY(group_run([&](int i) -> int {
+  VCMI_TRY(group_run(m, [&](int i) -> int {
     int64_t lo, hi;
     shard_range(N, i, m, &lo, &hi);
     return local(lo, hi);
   }));
-  return group_run([&](int i) -> int {
+  return group_run(m, [&](int i) -> int {
     Scratch &sc = get_scratch();
     VCMI_TRY(group_allreduce_sum(i, sc.stats.p, (size_t)plen, nullptr));
     if (i == 0) VCMI_HIP(hipMemcpy(h.data(), sc.stats.p, (size_t)plen * 8, hipMemcpyDeviceToHost));

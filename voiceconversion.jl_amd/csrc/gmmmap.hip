@@ -1178,7 +1178,7 @@ static int over_frames(vcmi_gmmmap *g, int64_t T, const PerShard &fn) {
   const int m = group_size();
   if (m == 0 || T < kGroupMinFrames) return fn(g, (int64_t)0, T);
   gmmmap_sync_replicas(g);
-  return group_run([&](int i) -> int {
+  return group_run(m, [&](int i) -> int {
     int64_t lo, hi;
     shard_range(T, i, m, &lo, &hi);
     if (hi == lo) return VCMI_OK;

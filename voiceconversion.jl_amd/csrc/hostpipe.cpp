@@ -378,9 +378,10 @@ int staged_pipeline(const void *hIn, size_t in_unit, size_t in_stride, void *hOu
   VCMI_TRY(r->init());
   const size_t wide = std::max(in_unit, out_unit);
   int64_t chunk = std::max<int64_t>(min_chunk_units, (int64_t)(kPipeChunk / std::max<size_t>(wide, 1)));
-  const int64_t nch = (units + chunk - 1) / chunk;
+  int64_t nch = (units + chunk - 1) / chunk;
   chunk = ((units + nch - 1) / nch + 255) / 256 * 256;
   chunk = std::min(chunk, (units + 255) / 256 * 256);
+  nch = (units + chunk - 1) / chunk;   // rounding the chunk up to 256 units can make the last chunk(s) empty: recount
   VCMI_TRY(r->reserve(r->pin_in, r->pin_in_cap, (size_t)chunk * in_unit, true));
   VCMI_TRY(r->reserve(r->pin_out, r->pin_out_cap, (size_t)chunk * out_unit, true));
   VCMI_TRY(r->reserve(r->dev_in, r->dev_in_cap, (size_t)chunk * in_unit, false));

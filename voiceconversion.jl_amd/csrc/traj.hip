@@ -1228,7 +1228,7 @@ static int traj_host_batch(vcmi_traj *t, int64_t n, const double *const *X, cons
   std::vector<int64_t> costs((size_t)n);
   for (int64_t u = 0; u < n; ++u) costs[(size_t)u] = T[u];
   const std::vector<int> part = shard_by_cost(costs, m);
-  return group_run([&](int i) -> int {
+  return group_run(m, [&](int i) -> int {
     std::vector<const double *> x2;
     std::vector<double *> y2;
     std::vector<int64_t> T2;

@@ -60,6 +60,38 @@ struct DevBuf {
 
 int check_device();  // VCMI_ERR_NO_DEVICE when no HIP device is visible
 
+// Orders the calls that share one thread-local device workspace.  The `_dev` entry points run on whatever stream the
+// caller passes; two calls of one host thread on DIFFERENT streams would otherwise overwrite each other's operands and
+// partial results while the first call's kernels still run.  enter(): the stream waits for the last kernel of the
+// previous call; leave(): marks the end of this call's work.  (Same stream twice: the wait is a no-op.)
+struct StreamOrder {
+  hipEvent_t last_use = nullptr;
+  int device = -1;
+  StreamOrder() = default;
+  StreamOrder(const StreamOrder &) = delete;
+  StreamOrder &operator=(const StreamOrder &) = delete;
+  ~StreamOrder() {
+    if (last_use) (void)hipEventDestroy(last_use);
+  }
+  int enter(hipStream_t st) {
+    int dev = 0;
+    VCMI_HIP(hipGetDevice(&dev));
+    if (!last_use || dev != device) {
+      if (last_use) (void)hipEventDestroy(last_use);
+      last_use = nullptr;
+      VCMI_HIP(hipEventCreateWithFlags(&last_use, hipEventDisableTiming));
+      device = dev;
+      return VCMI_OK;   // a new event has nothing recorded
+    }
+    VCMI_HIP(hipStreamWaitEvent(st, last_use, 0));
+    return VCMI_OK;
+  }
+  int leave(hipStream_t st) {
+    if (last_use) VCMI_HIP(hipEventRecord(last_use, st));
+    return VCMI_OK;
+  }
+};
+
 // Test hook (vcmi_debug_force, not part of include/vcmi.h): forces the fallback kernels that a given shape would not
 // select by itself, so that the parity tests cover them.  Nothing on the call path reads the environment.
 enum : unsigned {

@@ -483,7 +483,7 @@ end
 
 # GVDataset(path; ignore0th, add_delta, nmax) -- src/datasets.jl:134-183, from in-memory feature matrices (loading the
 # `.jld` files stays with the caller): X = the (Dout, n) matrix of per-utterance variances var(tgt, 2)
-immutable GVDataset
+struct GVDataset
     X::Matrix{Float64}
     function GVDataset(fms::Vector{Matrix{Float64}}; ignore0th::Bool=true, add_delta::Bool=false, nmax::Int=100)
         fms = fms[1:min(length(fms), nmax)]
@@ -493,7 +493,7 @@ immutable GVDataset
         all(f -> size(f, 1) == D, fms) || throw(DimensionMismatch("all feature matrices must share the feature dimension"))
         T = Int64[size(f, 2) for f in fms]
         Dout = (D - (ignore0th ? 1 : 0)) * (add_delta ? 2 : 1)
-        out = Array(Float64, Dout, n); k = Ref{Int64}(0)
+        out = Matrix{Float64}(undef, Dout, n); k = Ref{Int64}(0)
         check(ccall((:vcmi_gv_dataset, libvcmi), Cint,
                     (Int64, Ptr{Ptr{Float64}}, Ptr{Int64}, Cint, Cint, Cint, Ptr{Float64}, Ref{Int64}),
                     n, Ptr{Float64}[pointer(f) for f in fms], T, D, ignore0th ? 1 : 0, add_delta ? 1 : 0, out, k))
