@@ -88,7 +88,7 @@ def test_batch_ragged_and_align(vc):
         assert src.shape == newtgt.shape
 
 
-@pytest.mark.parametrize("D", [40, 13])
+@pytest.mark.parametrize("D", [40, 13, 41, 46])
 def test_device_resident_batch(vc, D):
     """vcmi_dtw_fit_batch_dev: features already in HBM, ragged pairs spanning several 256-frame row blocks and
     128-frame column blocks of the observation kernel; bit-exact paths."""
@@ -139,13 +139,17 @@ def test_fused_kernel_strips_ties_and_two_kernel_path(vc, bs):
     """The fused forward kernel (observation + recurrence in one hand-scheduled loop, two rows per lane, waves coupled
     through sequence-tagged LDS rings, long templates split into row strips that hand their top two rows over through
     HBM) against the oracle AND against the observation + recurrence kernels it replaced (still the path of tables,
-    D > 40 and wide windows).  Shapes: strip boundaries (512 / 513 / 549 / 1025 / 1537 rows), odd and even S, every
+    D > 48 and wide windows).  Shapes: strip boundaries (512 / 513 / 549 / 1025 / 1537 rows), odd and even S, every
     wave count, T not a multiple of 16, padded D, coarse features (exact cost ties exercise the strict '<' rule)."""
     from oracle import c_oracle as co
     from voiceconversion_jl_amd import _lib
     rng = np.random.default_rng(1234 + bs)
     shapes = [(512, 160, 40), (513, 97, 40), (549, 130, 40), (550, 33, 24), (1025, 70, 40), (1537, 40, 8), (127, 500, 40),
-              (128, 17, 40), (129, 16, 40), (255, 15, 13), (2, 300, 40), (3, 1, 40), (383, 64, 32), (64, 65, 1)]
+              (128, 17, 40), (129, 16, 40), (255, 15, 13), (2, 300, 40), (3, 1, 40), (383, 64, 32), (64, 65, 1),
+              # 40 < D <= 48: the three-chunk loops (two columns per iteration: odd and even T, T = 1); D = 41 reads the
+              # unpadded 41-double rows directly, 42..48 run padded in the DMAX = 48 kernel
+              (500, 500, 41), (549, 131, 41), (1025, 70, 41), (130, 1, 41), (2, 2, 41), (255, 16, 41), (64, 33, 41),
+              (513, 97, 48), (300, 64, 48), (127, 47, 45), (1100, 30, 42), (3, 9, 47), (129, 2, 44)]
     pairs = []
     for k, (S, T, D) in enumerate(shapes):
         t, s = _warped_pair(rng, S, T, D)

@@ -37,15 +37,28 @@ Operands: see dtw_fused_kernel in dtw.hip.  Fixed registers (all clobbered):
 """
 import sys
 
-O0, O1 = 160, 162
-T = [164, 166, 168, 170]
-C0, C1, P0, P1 = 172, 174, 176, 178
-X, Y = 180, 182
-W0, W1, K0, K1 = 184, 185, 186, 187
-M = 188
-VTAG, VA0, VA1, VA2, VA3 = 192, 193, 194, 195, 196
 BUF = {"A": 16, "B": 56}
 RING = 64            # outbox slots (columns); 16 bytes each, tag at byte RING*16
+NSTATE = 42          # state registers above the template rows (O0 .. OP1)
+
+
+def set_layout(base=160, bufs=(16, 56)):
+    """The state registers sit above the two template rows: base = 160 for every DMAX <= 40 (the register map in the
+    header), 2 * 2 * stride for the wider kernels (D = 41: rows of 42 registers -> base 168; DMAX = 48: base 192).
+    bufs: first SGPR of the two column buffers (40 SGPRs each for the two-chunk loops, 32 for the three-chunk ones)."""
+    global O0, O1, T, C0, C1, P0, P1, X, Y, W0, W1, K0, K1, M, VTAG, VA0, VA1, VA2, VA3, OP0, OP1
+    O0, O1 = base, base + 2
+    T = [base + 4, base + 6, base + 8, base + 10]
+    C0, C1, P0, P1 = base + 12, base + 14, base + 16, base + 18
+    X, Y = base + 20, base + 22
+    W0, W1, K0, K1 = base + 24, base + 25, base + 26, base + 27
+    M = base + 28
+    VTAG, VA0, VA1, VA2, VA3 = base + 32, base + 33, base + 34, base + 35, base + 36
+    OP0, OP1 = base + 38, base + 40      # observation costs of the previous column (the recurrence runs half a column late)
+    BUF["A"], BUF["B"] = bufs
+
+
+set_layout()
 
 
 def vp(r):
@@ -74,7 +87,7 @@ def sloads(buf, byte_off, ndbl):
 
 
 def chunk(buf, d0, d1, first, dmax, rpl):
-    """observation work of features d0..d1-1 for rpl rows per lane"""
+    """observation work of features d0..d1-1 for rpl rows per lane; dmax = registers pairs per template row"""
     out = []
     for d in range(d0, d1):
         s = sp(BUF[buf] + 2 * (d - d0))
@@ -168,9 +181,6 @@ def rec_row(c, o, pa, pb, k, steps):
 
 
 OUTBOX = RING * 16 + 16   # bytes of one wave's outbox: RING slots, then the tag (one dword)
-
-
-OP0, OP1 = 198, 200      # observation costs of the previous column (the recurrence runs half a column late)
 
 
 def rec_block(steps, role, nomail):
@@ -277,6 +287,99 @@ def fused_loop(dmax, steps, role, variant=0):
     return L
 
 
+def splits3(d):
+    """a column of d doubles in three chunks of at most 16 (two 32-SGPR buffers): [14, 14, 13] for 41, [16, 16, 16] for 48"""
+    a = (d + 2) // 3
+    a += a & 1 if 3 * (a + (a & 1)) - d <= (a + (a & 1)) else 0
+    b = min(a, d - a)
+    c = d - a - b
+    assert 0 < c <= a <= 16 and b <= 16
+    return [a, b, c]
+
+
+def template_loads_exact(d, stride, rpl):
+    """rows of exactly d doubles (not padded in memory): d // 2 16-byte loads and, for odd d, one 8-byte load"""
+    L = []
+    for q in range(rpl):
+        row = "%[rowA]" if q == 0 else "%[rowB]"
+        for k in range(d // 2):
+            b = 2 * stride * q + 4 * k
+            L.append(f"global_load_dwordx4 v[{b}:{b + 3}], {row}, off offset:{16 * k}")
+        if d & 1:
+            b = 2 * stride * q + 2 * (d - 1)
+            L.append(f"global_load_dwordx2 v[{b}:{b + 1}], {row}, off offset:{8 * (d - 1)}")
+    return L
+
+
+def fused_loop3(d, stride, steps, role):
+    """The column loop for 40 < d <= 48.  A column no longer fits two half-column SGPR buffers (84 SGPRs are all there
+    is), so it arrives in THREE chunks through two 32-SGPR buffers; with an odd chunk count the buffers swap roles from
+    one column to the next, hence the loop is unrolled twice (A,B,A | B,A,B).  The recurrence of the previous column
+    sits after the first chunk, as in the two-chunk loop: its LDS traffic completes under a third of a column of FP64
+    work.  Same arithmetic, same order: sequential in d, unfused."""
+    c = splits3(d)
+    col = 8 * d
+    L = ["1:"]
+    for X_, Y_ in (("A", "B"), ("B", "A")):
+        L.append("s_waitcnt lgkmcnt(0)")
+        L += sloads(Y_, 8 * c[0], c[1])
+        L += ["s_cmp_eq_u32 %[t], 0", "s_cbranch_scc1 10f"] + m_request(role) + ["10:"]
+        L += chunk(X_, 0, c[0], True, stride, 2)
+        L.append("s_waitcnt lgkmcnt(0)")
+        L += sloads(X_, 8 * (c[0] + c[1]), c[2])
+        L += ["s_cmp_eq_u32 %[t], 0", "s_cbranch_scc1 11f"] + m_check(role) + rec_block(steps, role, False) + ["11:"]
+        L += chunk(Y_, c[0], c[0] + c[1], False, stride, 2)
+        L += advance(col)
+        L.append("s_waitcnt lgkmcnt(0)")
+        L += sloads(Y_, 0, c[0])                 # the next column's first chunk
+        L += chunk(X_, c[0] + c[1], d, False, stride, 2)
+        L += [f"v_mov_b64 {vp(OP0)}, {vp(O0)}", f"v_mov_b64 {vp(OP1)}, {vp(O1)}"]
+        L += ["s_add_u32 %[t], %[t], 1", "s_sub_u32 %[n], %[n], 1", "s_cmp_lg_u32 %[n], 0"]
+        L += ["s_cbranch_scc0 2f"] if X_ == "A" else ["s_cbranch_scc1 1b"]
+    L += ["2:"]
+    L += m_request(role) + ["s_waitcnt lgkmcnt(0)"] + m_check(role) + rec_block(steps, role, False)
+    return L
+
+
+def body_fused3(d, stride, steps):
+    """dtw_fused_kernel for 40 < d <= 48; operands as body_fused except %[g0] (v32, the lane's first row in the pair) in
+    place of %[c0] %[c1] %[p0] %[p1].  stride = register pairs per template row: rows of
+    d = 41 doubles are read as they lie in memory (no padded copy: 20 x 16 bytes + 8 bytes per row, column stride 328
+    bytes for the scalar loads), d = 48 is the padded kernel of D = 42..48."""
+    set_layout(4 * stride, (16, 48))
+    c = splits3(d)
+    L = ["s_mov_b64 s[96:97], exec"]
+    L += template_loads_exact(d, stride, 2)
+    L += sloads("A", 0, c[0])
+    # The initial costs are formed here from the lane's first row %[g0] (v32) instead of arriving as four 64-bit operands:
+    # with 192 template registers every operand VGPR counts (256 = two waves per SIMD).  lazy_init! (src/dtw.jl:49):
+    # C0 = g0+1, C1 = g0+2; neighbours of column 1: P1 = g0 (row g0-1) if g0 >= 1, P0 = g0-1 (row g0-2) if g0 >= 2, else +inf
+    t0, t1 = T[0], T[0] + 1
+    L += [f"v_add_u32 v{t0}, 1, %[g0]", f"v_cvt_f64_u32 {vp(C0)}, v{t0}",
+          f"v_add_u32 v{t0}, 2, %[g0]", f"v_cvt_f64_u32 {vp(C1)}, v{t0}",
+          f"v_cvt_f64_u32 {vp(P1)}, %[g0]",
+          f"v_add_u32 v{t0}, -1, %[g0]", f"v_cvt_f64_u32 {vp(P0)}, v{t0}",
+          f"v_mov_b32 v{t0}, 0", f"v_mov_b32 v{t1}, 0x7ff00000",
+          "v_cmp_gt_u32 vcc, 1, %[g0]",
+          f"v_cndmask_b32 v{P1}, v{P1}, v{t0}, vcc", f"v_cndmask_b32 v{P1 + 1}, v{P1 + 1}, v{t1}, vcc",
+          "v_cmp_gt_u32 vcc, 2, %[g0]",
+          f"v_cndmask_b32 v{P0}, v{P0}, v{t0}, vcc", f"v_cndmask_b32 v{P0 + 1}, v{P0 + 1}, v{t1}, vcc"]
+    L += [f"v_mov_b32 v{W0}, 0", f"v_mov_b32 v{W1}, 0",
+          "s_sub_u32 s98, %[out], 16", f"v_mov_b32 v{VA1}, s98",
+          f"s_add_u32 s98, %[out], {RING * 16}", f"v_mov_b32 v{VA3}, s98"]
+    L.append("s_waitcnt vmcnt(0)")
+    L += ["s_bitcmp1_b32 %[mode], 0", "s_cbranch_scc1 100f", "s_bitcmp1_b32 %[mode], 1", "s_cbranch_scc1 200f"]
+    L += fused_loop3(d, stride, steps, 0) + ["s_branch 300f"]
+    L += ["100:"] + fused_loop3(d, stride, steps, 1) + ["s_branch 300f"]
+    L += ["200:"] + fused_loop3(d, stride, steps, 2)
+    L += ["300:"]
+    L += ["s_and_b32 s98, %[t], 15", "s_cmp_eq_u32 s98, 0", "s_cbranch_scc1 301f"]
+    L += flush_codes()
+    L += ["301:", f"ds_write_b128 %[clast], v[{C0}:{C0 + 3}]", "s_waitcnt vmcnt(0) lgkmcnt(0)"]
+    set_layout()
+    return L
+
+
 def flush_codes():
     return ["s_bfm_b64 s[98:99], %[cnt], 0", "s_cmp_eq_u32 %[cnt], 64", "s_cselect_b64 exec, s[96:97], s[98:99]",
             f"global_store_dwordx2 %[codes], v[{W0}:{W1}], off", "s_mov_b64 exec, s[96:97]",
@@ -333,6 +436,9 @@ def main():
            "// observation-only comparison loops of tools/microbench_obs2.hip (see the generator for schedule and register map)."]
     regs = [f'"v{i}"' for i in range(202)] + [f'"s{i}"' for i in range(16, 100)]
     out.append("#define VCMI_FUSED_ASM_CLOBBERS " + ", ".join(regs))
+    for name, stride in (("D41", 42), ("D48", 48)):
+        regs = [f'"v{i}"' for i in range(4 * stride + NSTATE)] + [f'"s{i}"' for i in range(16, 100)]
+        out.append(f"#define VCMI_FUSED_ASM_CLOBBERS_{name} " + ", ".join(regs))
     out.append(f"#define VCMI_FUSED_RING {RING}")
     out.append(f"#define VCMI_FUSED_OUTBOX {OUTBOX}")
     out.append("")
@@ -346,6 +452,9 @@ def main():
     for dmax in (8, 16, 24, 32, 40):
         for steps in (1, 2):
             emit(f"VCMI_DTW_FUSED_ASM_D{dmax}_S{steps}", body_fused(dmax, steps))
+    for steps in (1, 2):
+        emit(f"VCMI_DTW_FUSED_ASM_D41_S{steps}", body_fused3(41, 42, steps))
+        emit(f"VCMI_DTW_FUSED_ASM_D48_S{steps}", body_fused3(48, 48, steps))
     for v in (1, 2, 3):
         emit(f"VCMI_DTW_FUSED_ASM_D40_S2_V{v}", body_fused(40, 2, v))
     for rpl in (1, 2):

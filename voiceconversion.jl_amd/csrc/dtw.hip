@@ -458,20 +458,32 @@ dtw_fused_kernel(const double *__restrict__ base, int padded, const DtwPair *__r
     ncols = __builtin_amdgcn_readfirstlane(ncols);
     seq = reinterpret_cast<const double *>(uniform64(reinterpret_cast<uint64_t>(seq)));
     const uint64_t cstride_u = uniform64(cstride);
-#define VCMI_FUSED_ASM(BODY)                                                                                          \
+#define VCMI_FUSED_ASM(BODY) VCMI_FUSED_ASM_C(BODY, VCMI_FUSED_ASM_CLOBBERS)
+#define VCMI_FUSED_ASM_C(BODY, CLOBBERS)                                                                              \
   asm volatile(BODY                                                                                                   \
                : [seq] "+s"(seq), [off] "+s"(off), [n] "+s"(ncols), [t] "+s"(tcol), [codes] "+v"(codes), [gout] "+v"(gout) \
                : [cstride] "s"(cstride_u), [cnt] "s"(cnt), [out] "s"(out), [bnd] "s"(bndl), [mode] "s"(mode),          \
                  [explane] "s"(explane), [rowA] "v"(rowA), [rowB] "v"(rowB), [c0] "v"(c0), [c1] "v"(c1), [p0] "v"(p0), \
                  [p1] "v"(p1), [clast] "v"(clast_a)                                                                   \
-               : "memory", "vcc", "scc", VCMI_FUSED_ASM_CLOBBERS)
+               : "memory", "vcc", "scc", CLOBBERS)
+    // the wide kernels (40 < D <= 48) form the initial costs themselves from the lane's first row (operand VGPRs are scarce)
+#define VCMI_FUSED3_ASM(BODY, CLOBBERS)                                                                               \
+  asm volatile(BODY                                                                                                   \
+               : [seq] "+s"(seq), [off] "+s"(off), [n] "+s"(ncols), [t] "+s"(tcol), [codes] "+v"(codes), [gout] "+v"(gout) \
+               : [cstride] "s"(cstride_u), [cnt] "s"(cnt), [out] "s"(out), [bnd] "s"(bndl), [mode] "s"(mode),          \
+                 [explane] "s"(explane), [rowA] "v"(rowA), [rowB] "v"(rowB), [g0] "v"(gr0), [clast] "v"(clast_a)       \
+               : "memory", "vcc", "scc", CLOBBERS)
     if constexpr (STEPS == 1) {
       if constexpr (DMAX == 8) VCMI_FUSED_ASM(VCMI_DTW_FUSED_ASM_D8_S1);
       if constexpr (DMAX == 16) VCMI_FUSED_ASM(VCMI_DTW_FUSED_ASM_D16_S1);
       if constexpr (DMAX == 24) VCMI_FUSED_ASM(VCMI_DTW_FUSED_ASM_D24_S1);
       if constexpr (DMAX == 32) VCMI_FUSED_ASM(VCMI_DTW_FUSED_ASM_D32_S1);
       if constexpr (DMAX == 40) VCMI_FUSED_ASM(VCMI_DTW_FUSED_ASM_D40_S1);
+      if constexpr (DMAX == 41) VCMI_FUSED3_ASM(VCMI_DTW_FUSED_ASM_D41_S1, VCMI_FUSED_ASM_CLOBBERS_D41);
+      if constexpr (DMAX == 48) VCMI_FUSED3_ASM(VCMI_DTW_FUSED_ASM_D48_S1, VCMI_FUSED_ASM_CLOBBERS_D48);
     } else {
+      if constexpr (DMAX == 41) VCMI_FUSED3_ASM(VCMI_DTW_FUSED_ASM_D41_S2, VCMI_FUSED_ASM_CLOBBERS_D41);
+      if constexpr (DMAX == 48) VCMI_FUSED3_ASM(VCMI_DTW_FUSED_ASM_D48_S2, VCMI_FUSED_ASM_CLOBBERS_D48);
       if constexpr (DMAX == 8) VCMI_FUSED_ASM(VCMI_DTW_FUSED_ASM_D8_S2);
       if constexpr (DMAX == 16) VCMI_FUSED_ASM(VCMI_DTW_FUSED_ASM_D16_S2);
       if constexpr (DMAX == 24) VCMI_FUSED_ASM(VCMI_DTW_FUSED_ASM_D24_S2);
@@ -487,6 +499,8 @@ dtw_fused_kernel(const double *__restrict__ base, int padded, const DtwPair *__r
 #endif
     }
 #undef VCMI_FUSED_ASM
+#undef VCMI_FUSED_ASM_C
+#undef VCMI_FUSED3_ASM
   }
   __syncthreads();
   if (packed) {      // every wave finishes its own strip
@@ -757,10 +771,29 @@ static DtwScratch &scratch() {
 }
 
 // Fused path of dtw_run (see dtw_fused_kernel): strips, workspaces, the forward launch and the backward / align launch.
+// Dynamic LDS of the two fused kernels; the caller takes the observation + recurrence path when either exceeds the budget
+// (sequences beyond ~9.7k frames: the forward kernel keeps the boundary costs of a strip, 16 bytes per column, in LDS).
+static inline size_t dtw_fused_lds_forward(int Tmax) {
+  return (size_t)4 * VCMI_FUSED_OUTBOX + (size_t)kFusedRows * 8 + ((size_t)Tmax + 1) * 16;
+}
+static inline size_t dtw_fused_lds_finish(int Smax, int Tmax) {
+  const size_t SmaxE = (size_t)((Smax + 1) & ~1);
+  return SmaxE * 8 + (size_t)Tmax * 4 + SmaxE * 8;
+}
+static inline bool dtw_fused_fits(int Smax, int Tmax) {
+  return dtw_fused_lds_forward(Tmax) <= kLdsLimit && dtw_fused_lds_finish(Smax, Tmax) <= kLdsLimit;
+}
+
+// Row length the fused forward kernel works on.  D = 41 -- order-40 mel-cepstra WITH c0, what the reference's own pipeline
+// aligns (bin/mcep.jl:12 --order=40, bin/align.jl:42-45 -> src/align.jl:45 -> src/dtw.jl:33-35) -- has its own loop that
+// reads the 41-double rows as they lie in memory (no padded copy); every other D is padded up to the next instantiation.
+static constexpr int kFusedMaxD = 48;
+static int dtw_fused_row(int D) { return D == 41 ? 41 : dtw_dmax(D); }
+
 static int dtw_run_fused(const double *feats, std::vector<DtwPair> &pairs, int D, int bstep, DtwScratch &sc, hipStream_t st,
                          int Smax, int Tmax) {
   const int n = (int)pairs.size();
-  const int dmax = dtw_dmax(D);
+  const int dmax = dtw_fused_row(D);
   // single-strip pairs largest first (shortens the tail); the strips of long templates are ordered by level: all
   // bottom strips lead the grid -- they are what the upper strips wait for -- and the upper strips follow the
   // single-strip pairs, by which time their predecessors are done.
@@ -839,7 +872,7 @@ static int dtw_run_fused(const double *feats, std::vector<DtwPair> &pairs, int D
     hipLaunchKernelGGL(dtw_pad_kernel, dim3(n, 8), dim3(256), 0, st, feats, sc.dpairs.p, D, dmax, sc.spad.p);
   }
   const double *base = padded ? sc.spad.p : feats;
-  const size_t shf = (size_t)4 * VCMI_FUSED_OUTBOX + (size_t)kFusedRows * 8 + ((size_t)Tmax + 1) * 16;
+  const size_t shf = dtw_fused_lds_forward(Tmax);
   if (shf > kLdsLimit) return fail(VCMI_ERR_ARG, "DTW: sequence of %d frames exceeds the supported length", Tmax);
 #define VCMI_FUSED_LAUNCH(DM, STP)                                                                                    \
   do {                                                                                                                \
@@ -851,13 +884,16 @@ static int dtw_run_fused(const double *feats, std::vector<DtwPair> &pairs, int D
   } while (0)
 #define VCMI_FUSED_CASE(DM) \
   case DM: if (bstep == 1) VCMI_FUSED_LAUNCH(DM, 1); else VCMI_FUSED_LAUNCH(DM, 2); break;
-  switch (dmax) { VCMI_FUSED_CASE(8) VCMI_FUSED_CASE(16) VCMI_FUSED_CASE(24) VCMI_FUSED_CASE(32) VCMI_FUSED_CASE(40) }
+  switch (dmax) {
+    VCMI_FUSED_CASE(8) VCMI_FUSED_CASE(16) VCMI_FUSED_CASE(24) VCMI_FUSED_CASE(32) VCMI_FUSED_CASE(40) VCMI_FUSED_CASE(41)
+    VCMI_FUSED_CASE(48)
+  }
 #undef VCMI_FUSED_CASE
 #undef VCMI_FUSED_LAUNCH
   VCMI_HIP(hipGetLastError());
   // backward + align
   const size_t SmaxE = (size_t)((Smax + 1) & ~1);
-  const size_t shb = SmaxE * 8 + (size_t)Tmax * 4 + SmaxE * 8;
+  const size_t shb = dtw_fused_lds_finish(Smax, Tmax);
   const size_t shc = (size_t)((Tmax + 15) >> 4) * SmaxE * 4;
   if (shb > kLdsLimit) return fail(VCMI_ERR_ARG, "DTW: template of %d frames exceeds the supported length", Smax);
   if (shb + shc <= kLdsLimit) {
@@ -896,7 +932,8 @@ static int dtw_run(const double *feats, std::vector<DtwPair> &pairs, int D, int 
   {
     bool tables = false;
     for (auto &p : pairs) tables = tables || p.cost || p.bp;
-    if (fstep == 0 && (bstep == 1 || bstep == 2) && D <= 40 && !tables && !debug_flag(kDbgDtwTwoKernels))
+    if (fstep == 0 && (bstep == 1 || bstep == 2) && D <= kFusedMaxD && !tables && !debug_flag(kDbgDtwTwoKernels) &&
+        dtw_fused_fits(Smax, Tmax))
       return dtw_run_fused(feats, pairs, D, bstep, sc, st, Smax, Tmax);
   }
   // largest pairs first: shortens the tail when n is not a multiple of the resident workgroup count
