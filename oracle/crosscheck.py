@@ -18,10 +18,19 @@ This module checks the GOLDEN VECTORS (tests/golden/*.npz) against code the buil
                                                    score_samples (the successor of the sklearn.mixture.GMM the
                                                    reference calls; same log-density mathematics)
 
+  mc2e                  src/align.jl:48            frequency-domain evaluation (round 3): H(w) = exp(sum_m c(m) z~^-m) on a
+                                                   65536-point grid, numpy.fft.ifft -> impulse response, energy of its first
+                                                   `fftlen` samples; Parseval for the whole response.  No freqt / c2ir
+                                                   recursion (what the oracle restates from SPTK): check_mc2e
+  GV ascent             src/trajectory_gmmmap.jl:139-189  (round 3) dense numpy evaluation with W materialised through
+                                                   scipy.sparse, numpy.linalg.solve / inv, numpy.var(ddof=1): check_gv;
+                                                   `gvgrad` against central differences of log N(v(y); mu_v, Sigma_vv) in
+                                                   50-digit mpmath (it is (T-1)/T times that gradient: the reference writes
+                                                   2/T where d var/dy gives 2/(T-1)); one ascent step in 50-digit mpmath
+
 Used by oracle/gen_golden.py (asserted before a fixture is written) and by tests/test_oracle_thirdparty.py (re-verifies
 the committed fixtures on every CPU run).  This is the ceiling of what can be pinned without Julia: third-party
-implementations of the same published formulas, not the reference's own run-time output.  GV ascent and mc2e have no
-third-party implementation in this image and stay unpinned."""
+implementations of the same published formulas, not the reference's own run-time output."""
 import numpy as np
 
 
@@ -199,3 +208,194 @@ def check_estep_full(X, w, mu, sigma, S0, S1, S2, loglik, tol=1e-9):
            "loglik": abs(ll - float(loglik)) / abs(ll)}
     assert max(out.values()) < tol, out
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# mc2e (src/align.jl:48; MelGeneralizedCepstrums, third party) -- frequency-domain evaluation, no freqt / c2ir recursion
+# ---------------------------------------------------------------------------------------------------------------
+def mc2e_frequency_domain(mc, alpha, fftlen, nfft=1 << 16):
+    """Energy of the first `fftlen` samples of the impulse response of the spectrum a mel-cepstrum describes, evaluated
+    WITHOUT the SPTK recursions the oracle restates (freqt: mel -> linear cepstrum; c2ir: cepstrum -> impulse response).
+
+    The mel-cepstral model (Tokuda et al.; mgcep) is  H(z) = exp sum_m c~(m) z~^-m  with the first-order all-pass
+    z~^-1 = (z^-1 - alpha) / (1 - alpha z^-1).  On the unit circle, on a dense grid of `nfft` frequencies:
+        H(w_k) = exp( sum_m c~(m) * ((e^-jw_k - alpha) / (1 - alpha e^-jw_k))^m )
+    H is minimum phase (exp of a causal series), so its impulse response is causal and numpy.fft.ifft(H) returns it (time
+    aliasing: samples beyond nfft = 65536, far below 1e-16 here).  freqt(mc, fftlen-1, -alpha) truncates the linear
+    cepstrum to order fftlen-1, which cannot change h[0..fftlen-1] (h[n] depends on c[1..n] only), so
+        mc2e(mc, alpha, fftlen) = sum_{n < fftlen} h[n]^2      -- up to rounding, no truncation term.
+    Also returns the whole-response energy by Parseval, mean_k |H(w_k)|^2: the difference is the energy of the response
+    beyond `fftlen` samples, i.e. what the reference's fixed length leaves out (reported, not asserted as equal).
+    mc (T,D) -> (e_truncated (T,), e_parseval (T,))"""
+    mc = np.atleast_2d(np.asarray(mc, dtype=np.float64))
+    w = 2.0 * np.pi * np.arange(nfft) / nfft
+    zi = np.exp(-1j * w)
+    zt = (zi - alpha) / (1.0 - alpha * zi)                       # z~^-1 on the unit circle
+    powers = np.ones((mc.shape[1], nfft), dtype=np.complex128)
+    for m in range(1, mc.shape[1]):
+        powers[m] = powers[m - 1] * zt
+    H = np.exp(mc.astype(np.complex128) @ powers)                # (T, nfft)
+    h = np.fft.ifft(H, axis=1)
+    assert np.max(np.abs(h.imag)) < 1e-9 * np.max(np.abs(h.real))                       # real response
+    assert np.max(np.abs(h.real[:, nfft // 2:])) < 1e-12 * np.max(np.abs(h.real))       # causal: nothing at negative times
+    e_trunc = np.sum(h.real[:, :fftlen] ** 2, axis=1)
+    e_full = np.mean(np.abs(H) ** 2, axis=1)
+    return e_trunc, e_full
+
+
+def check_mc2e(mc, alpha, fftlen, energy, tol=1e-10):
+    """Golden energies (oracle: SPTK freqt + c2ir recursions) against the frequency-domain evaluation above."""
+    e_trunc, e_full = mc2e_frequency_domain(mc, alpha, fftlen)
+    err = float(np.max(np.abs(e_trunc - energy) / energy))
+    tail = float(np.max(np.abs(e_full - e_trunc) / e_full))
+    assert err < tol, err
+    assert np.all(e_full >= e_trunc * (1 - 1e-12))               # the truncated response cannot hold more energy
+    return {"mc2e_vs_frequency_domain": err, "energy_beyond_fftlen_relative": tail}
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# GV ascent (src/trajectory_gmmmap.jl:139-189): dense numpy / scipy.sparse evaluation and 50-digit mpmath
+# ---------------------------------------------------------------------------------------------------------------
+def _trajectory_system(w, mu, sig, X):
+    """(W, D^-1 blocks, E, mhat) of src/trajectory_gmmmap.jl:82-96 from third-party pieces only: sklearn predict,
+    numpy.linalg.inv, an explicit scipy.sparse W (src/trajectory_gmmmap.jl:39-61)."""
+    import scipy.sparse as sp
+
+    T, D2 = X.shape
+    D = D2 // 2
+    mux, muy, Sxx, Sxy, Syx, Syy = split_blocks(mu, sig, False)
+    gm = sklearn_gmm(w, mux, np.stack([hermitian_upper(s) for s in Sxx]))
+    mh = gm.predict(X)
+    E = np.empty((T, D2))
+    Dinv = []
+    for t in range(T):
+        m = mh[t]
+        A = Syx[m] @ np.linalg.inv(Sxx[m])
+        E[t] = muy[m] + A @ (X[t] - mux[m])
+        Dinv.append(np.linalg.inv(Syy[m] - A @ Sxy[m]))
+    W = sp.lil_matrix((2 * D * T, D * T))
+    for t in range(T):
+        for d in range(D):
+            W[2 * D * t + d, D * t + d] = 1.0
+            if t > 0:
+                W[2 * D * t + D + d, D * (t - 1) + d] = -0.5
+            if t < T - 1:
+                W[2 * D * t + D + d, D * (t + 1) + d] = 0.5
+    return W.tocsc(), Dinv, E, mh
+
+
+def gv_ascent_dense(w, mu, sig, X, muv, Sigvv, epochs, alpha):
+    """fvconvert(tgv, X) of src/trajectory_gmmmap.jl:139-168 with every operator materialised as a DENSE numpy matrix
+    (W from scipy.sparse, .toarray()), the initial trajectory from numpy.linalg.solve on the dense normal equations,
+    numpy.var(ddof=1) for Julia's `var`, numpy.linalg.inv for p_v.  Shares no code with oracle/np_oracle.py or
+    oracle/vc_oracle.c (stencil / banded Cholesky there; dense LU here).  X (T,2D) -> y (T,D), and the first gradient."""
+    import scipy.sparse as sp
+
+    W, Dinv, E, _ = _trajectory_system(w, mu, sig, X)
+    T, D2 = X.shape
+    D = D2 // 2
+    Wd = W.toarray()
+    Dd = sp.block_diag(Dinv).toarray()
+    WtD = Wd.T @ Dd
+    P = WtD @ Wd
+    r = WtD @ E.reshape(-1)
+    y = np.linalg.solve(P, r).reshape(T, D)                                   # :146 (dense LU instead of sparse `\`)
+    m0 = y.mean(axis=0)
+    y = np.sqrt(muv / np.var(y, axis=0, ddof=1)) * (y - m0) + m0              # :152, eq. (58)
+    pv = np.linalg.inv(Sigvv)                                                 # :127
+    omega = 1.0 / (2 * T)                                                     # :154
+    first = None
+    for _ in range(epochs):
+        gv = np.var(y, axis=0, ddof=1)                                        # :174
+        g = (-2.0 / T) * (pv.T @ (gv - muv)) * (y - y.mean(axis=0))           # :181-183
+        dy = omega * (-(P @ y.reshape(-1)) + r) + g.reshape(-1)               # :163
+        if first is None:
+            first = dy.reshape(T, D).copy()
+        y = y + alpha * dy.reshape(T, D)                                      # :166, eq. (52)
+    return y, first
+
+
+def check_gv(w, mu, sig, X, muv, Sigvv, Y_gv, epochs=100, alpha=1.0e-5, tol=1e-6):
+    """Golden GV trajectory against the dense evaluation.  Tolerance: the ascent starts from the trajectory solve, whose
+    two independent solutions differ by ~cond(P) eps (1e-11 here); the ascent itself is a contraction at this step."""
+    y, _ = gv_ascent_dense(w, mu, sig, X, muv, Sigvv, epochs, alpha)
+    err = float(np.max(np.abs(y - Y_gv)) / np.max(np.abs(Y_gv)))
+    assert err < tol, err
+    return {"gv_ascent_vs_dense_numpy": err, "epochs": epochs}
+
+
+def check_gvgrad_is_the_gv_likelihood_gradient(y, muv, Sigvv, gvgrad_fn, rel=1e-6):
+    """What `gvgrad` is, independently of any restatement: the reference's expression (src/trajectory_gmmmap.jl:181-183)
+    equals (T-1)/T times the gradient of  log N(v(y); mu_v, Sigma_vv)  with v = Julia's corrected variance -- the
+    reference writes 2/T where differentiating var(y,2) gives 2/(T-1).  Verified by central differences of the
+    log-density at 50 digits (mpmath), on a small y: pins the formula AND documents the quirk.
+    gvgrad_fn(pv, muv, y) -> (T,D): the implementation under test (an oracle restatement, or the HIP path's output)."""
+    import mpmath as mp
+
+    T, D = y.shape
+    pv = np.linalg.inv(Sigvv)
+    got = gvgrad_fn(pv, muv, y)
+    with mp.workdps(50):
+        Pv = mp.matrix(Sigvv.tolist()) ** -1
+
+        def logdens(Y):
+            v = []
+            for d in range(D):
+                col = [Y[t][d] for t in range(T)]
+                mean = sum(col) / T
+                v.append(sum((c - mean) ** 2 for c in col) / (T - 1))
+            dv = mp.matrix([v[d] - mp.mpf(float(muv[d])) for d in range(D)])
+            return -(dv.T * Pv * dv)[0] / 2
+
+        Y0 = [[mp.mpf(float(y[t, d])) for d in range(D)] for t in range(T)]
+        h = mp.mpf(10) ** -20
+        worst = 0.0
+        for t in range(T):
+            for d in range(D):
+                Yp = [row[:] for row in Y0]
+                Ym = [row[:] for row in Y0]
+                Yp[t][d] += h
+                Ym[t][d] -= h
+                num = (logdens(Yp) - logdens(Ym)) / (2 * h)
+                want = num * (T - 1) / T
+                worst = max(worst, float(abs(mp.mpf(float(got[t, d])) - want) / (abs(want) + mp.mpf(10) ** -30)))
+    assert worst < rel, worst
+    return {"gvgrad_vs_mpmath_gradient_times_(T-1)/T": worst}
+
+
+def check_gv_step_mpmath(w, mu, sig, X, muv, Sigvv, step_fn, dps=50, tol=1e-9):
+    """One ascent step (src/trajectory_gmmmap.jl:163-166) from the eq. (58) initial trajectory, evaluated in 50-digit
+    mpmath with dense W'D^-1W, against `step_fn(y0) -> y1` (the implementation under test started from the same y0).
+    Small cases only (dense mpmath products)."""
+    import mpmath as mp
+
+    W, Dinv, E, _ = _trajectory_system(w, mu, sig, X)
+    T, D2 = X.shape
+    D = D2 // 2
+    y_dense, _ = gv_ascent_dense(w, mu, sig, X, muv, Sigvv, 0, 0.0)            # eq. (58) initial value (double)
+    y1 = step_fn(y_dense)
+    with mp.workdps(dps):
+        import scipy.sparse as sp
+        Wm = mp.matrix(W.toarray().tolist())
+        Dm = mp.matrix(sp.block_diag(Dinv).toarray().tolist())
+        WtD = Wm.T * Dm
+        yv = mp.matrix([[mp.mpf(float(v))] for v in y_dense.reshape(-1)])
+        Ev = mp.matrix([[mp.mpf(float(v))] for v in E.reshape(-1)])
+        lin = -(WtD * (Wm * yv)) + WtD * Ev
+        Pv = mp.matrix(Sigvv.tolist()) ** -1
+        means = [sum(yv[D * t + d] for t in range(T)) / T for d in range(D)]
+        gv = [sum((yv[D * t + d] - means[d]) ** 2 for t in range(T)) / (T - 1) for d in range(D)]
+        dv = mp.matrix([gv[d] - mp.mpf(float(muv[d])) for d in range(D)])
+        pg = Pv.T * dv
+        omega = mp.mpf(1) / (2 * T)
+        alpha = mp.mpf(float(step_fn.alpha))
+        err = mp.mpf(0)
+        scale = max(abs(v) for v in yv)
+        for t in range(T):
+            for d in range(D):
+                g = mp.mpf(-2) / T * pg[d] * (yv[D * t + d] - means[d])
+                want = yv[D * t + d] + alpha * (omega * lin[D * t + d] + g)
+                err = max(err, abs(mp.mpf(float(y1[t, d])) - want))
+        out = float(err / scale)
+    assert out < tol, out
+    return {"gv_step_vs_mpmath": out, "digits": dps}

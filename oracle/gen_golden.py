@@ -179,6 +179,7 @@ def main():
     Sv = Ar @ Ar.T / (D // 2) * np.mean(muv) ** 2 * 0.1 + np.diag(muv ** 2 * 0.05)
     ygv = npo.trajgv_fvconvert(tn, Xd, muv, Sv, epochs=100, alpha=1.0e-5)
     assert _relmax(ygv, tc.fvconvert_gv(Xd, muv, Sv, 100, 1.0e-5)) < 1e-6
+    cc.check_gv(w, mu, sig, Xd, muv, Sv, ygv, epochs=100, alpha=1.0e-5)                # dense numpy / scipy.sparse, no shared code
     vs = npo.variance_scaling(Y, muv)
     assert _relmax(vs, co.variance_scaling(Y, muv)) < 1e-13
     dm, ds = npo.diffgmm(mu[:2], sig[:2])
@@ -193,6 +194,7 @@ def main():
     tgtm = srcm[np.sort(rg.integers(0, 60, 70))] + 0.01 * rg.standard_normal((70, 25))
     en = npo.mc2e(srcm, 0.41, 256)
     assert np.max(np.abs(en - co.mc2e(srcm, 0.41, 256)) / en) < 1e-12
+    cc.check_mc2e(srcm, 0.41, 256, en)                                                 # frequency-domain evaluation (numpy.fft)
     c0 = np.zeros((1, 5)); c0[0, 0] = 0.7
     assert abs(npo.mc2e(c0, 0.35, 64)[0] - np.exp(1.4)) < 1e-12
     sa, ta = npo.align_mcep(srcm, tgtm, 0.41, 256)

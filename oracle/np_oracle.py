@@ -13,8 +13,9 @@ fvconvert / predict_proba / trajectory / E-step numerics are PARITY UNPINNED BY 
 assert isfinite only, and no Julia exists here to run it); they are pinned instead against third-party
 implementations of the same published formulas -- sklearn GaussianMixture, scipy multivariate_normal /
 logsumexp / solveh_banded, LAPACK gesv, 50-digit mpmath -- in oracle/crosscheck.py, re-run on the
-committed fixtures by tests/test_oracle_thirdparty.py.  GV ascent and mc2e have no third-party
-counterpart in this image: unpinned.
+committed fixtures by tests/test_oracle_thirdparty.py.  Since round 3 the GV ascent (a dense numpy /
+scipy.sparse evaluation that shares no code with this file; gvgrad and one step in 50-digit mpmath) and mc2e (a
+frequency-domain evaluation with numpy.fft instead of the SPTK recursions) are checked there too.
 """
 import numpy as np
 import scipy.linalg as sla

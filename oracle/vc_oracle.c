@@ -13,7 +13,8 @@
  * floating-point (fvconvert, predict_proba, trajectory solve, E-steps) is PARITY UNPINNED BY THE REFERENCE
  * -- its tests assert isfinite only and no Julia exists here -- and is pinned instead against third-party
  * code (sklearn, scipy, LAPACK, 50-digit mpmath) through the golden vectors: oracle/crosscheck.py,
- * tests/test_oracle_thirdparty.py.  GV ascent and mc2e: unpinned.
+ * tests/test_oracle_thirdparty.py.  Since round 3 also the GV ascent (dense numpy / scipy.sparse evaluation,
+ * gvgrad and one step in 50-digit mpmath) and mc2e (frequency-domain evaluation with numpy.fft, no SPTK recursion).
  */
 #include "vc_oracle.h"
 #include <math.h>

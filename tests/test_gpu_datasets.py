@@ -31,6 +31,10 @@ def test_mc2e(vc):
         e = vc.mc2e(mc.T, alpha, fftlen)
         ref = co.mc2e(mc, alpha, fftlen)
         assert np.max(np.abs(e - ref) / ref) < 1e-12
+        # the HIP path against the frequency-domain evaluation (oracle/crosscheck.py: numpy.fft, no SPTK recursion)
+        from oracle import crosscheck as cc
+        e_t, _ = cc.mc2e_frequency_domain(mc, alpha, fftlen)
+        assert np.max(np.abs(e - e_t) / e_t) < 1e-11
     c = np.zeros((5, 1))
     c[0, 0] = 0.7                                      # only c0: h = [exp(c0), 0, ...] -> e = exp(2 c0)
     assert abs(vc.mc2e(c, 0.35, 64)[0] - np.exp(1.4)) < 1e-12

@@ -57,6 +57,36 @@ def test_fixture_model_gv(vc, fixture_model):
     assert relerr(init, vc.fvpostf(vc.VarianceScaling(muv), vc.fvconvert(t, z["X"].T))) < 1e-12
     with pytest.raises(AssertionError):
         vc.TrajectoryGVGMMMap(t, -muv, Sv)
+    # ... and the HIP path against the INDEPENDENT dense evaluation (oracle/crosscheck.py: scipy.sparse W, dense LU,
+    # numpy.var -- shares no code with either oracle restatement), golden GV statistics, and one ascent step against
+    # 50-digit mpmath on the library's own output
+    from oracle import crosscheck as cc
+    gz = load_golden("gv_fixture_model.npz")
+    tg = vc.TrajectoryGVGMMMap(t, gz["muv"], gz["sigmavv"])
+    got2 = vc.fvconvert(tg, z["X"].T)
+    out = cc.check_gv(w, mu, sig, z["X"], gz["muv"], gz["sigmavv"], got2.T, epochs=100, alpha=1.0e-5, tol=TOL)
+    assert out["gv_ascent_vs_dense_numpy"] < TOL
+
+
+def test_one_gv_step_vs_mpmath_50_digits(vc):
+    """One ascent step (src/trajectory_gmmmap.jl:163-166) of the HIP path against a dense 50-digit mpmath evaluation
+    (tiny case: static D = 3, M = 2, T = 6)."""
+    import synthdata as sd
+    from oracle import crosscheck as cc
+    w2, mu2, sig2 = sd.synth_model(77, 12, 2, lam_lo=1e-2)
+    st = np.cumsum(sd.sample_frames(78, w2, mu2, sig2, 6, 0, 3), axis=0)
+    X = np.ascontiguousarray(vc.push_delta(np.asfortranarray(st.T)).T)
+    muv2, Sv2 = np.array([0.8, 1.1, 0.6]), np.diag([0.2, 0.1, 0.3]) + 0.02
+    g = vc.GMMMap(*julia_model(w2, mu2, sig2))
+    tgv = vc.TrajectoryGVGMMMap(vc.TrajectoryGMMMap(g, 6), muv2, Sv2)
+
+    class Step:
+        alpha = 1e-3
+
+        def __call__(self, y0):
+            return vc.fvconvert(tgv, X.T, epochs=1, alpha=self.alpha).T
+
+    assert cc.check_gv_step_mpmath(w2, mu2, sig2, X, muv2, Sv2, Step())["gv_step_vs_mpmath"] < 1e-10
 
 
 @pytest.mark.parametrize("D,M,Ts,epochs", [(40, 8, [300, 37], 20), (12, 4, [2, 3, 17, 50], 100), (25, 5, [64, 129], 30),
