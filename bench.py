@@ -285,6 +285,8 @@ def bench_convert(args, world, rank):
     D, M, T = 40, 64, args.frames
     w, mu, sig = npo.synth_model(1002, 2 * D, M)
     g = vc.GMMMap(*julia_model(w, mu, sig))
+    if args.prune is not None:
+        g.set_prune(args.prune)
     X = npo.sample_frames(1002 + rank, w, mu, sig, T, 0, D)          # (T,D) == Julia (D,T) image
     Xd = torch.from_numpy(X).cuda()
     Yd = torch.empty_like(Xd)
@@ -319,6 +321,40 @@ def bench_convert(args, world, rank):
     # HBM traffic of the kernel: PMC passes of this same command, run as child processes before the timed run (LIVE_PMC)
     # or, failing that, the committed passes if they were collected from the same library sources
     attach_traffic(out, "convert_traffic.json", "gmmmap_mfma_kernel", standard=(T == 1_000_000), live=LIVE_PMC.get("convert"))
+    # What the timed kernel skipped, and the same K steps with nothing skipped.  The library's default (include/vcmi.h,
+    # vcmi_gmmmap_set_prune) does not evaluate the regression A_m x + b_m of a mixture whose posterior is below e^-46 = 1e-20
+    # on all 16 frames of a tile -- y changes by less than its own rounding error (the parity figure of this line is measured
+    # on the pruned kernel).  `roofline.achieved` is, as defined, ALGORITHMIC flops (every mixture) per second;
+    # `pruning.mfma_executed_frac` says how much of the dense MFMA work the kernel actually issued, and `dense` is the
+    # same measurement with pruning off (what rounds 1-2 reported).
+    if args.prune is None or args.prune < 1e300:
+        g.prune_stats(True)
+        step()
+        torch.cuda.synchronize()
+        ev = g.prune_stats(False)
+        tiles = -(-T // 16)
+        frac_reg = ev / float(tiles * M)
+        # v_mfma_f64_16x16x4 steps per (tile, mixture) at D = 40: 22 whitening steps (always) + 20 regression steps (if evaluated)
+        out["pruning"] = {"threshold_nats": 46.0 if args.prune is None else args.prune,
+                          "regressions_evaluated_frac": frac_reg,
+                          "mfma_executed_frac": (22.0 + 20.0 * frac_reg) / 42.0,
+                          "note": "posterior < e^-threshold on all 16 frames of a tile -> that mixture's regression tiles and softmax "
+                                  "update are skipped (wave-uniform); results equal the dense loop to < 1e-18 relative"}
+        g.set_prune(float("inf"))
+        wall_d, kernel_ms_d = timed_steps(step, args.steps, 2, world)
+        ach_d = flops / (kernel_ms_d * 1e-3) / 1e12
+        out["dense"] = {"value": world * T * args.steps / wall_d, "unit": "frames/s", "ms_per_step": wall_d / args.steps * 1e3,
+                        "kernel_ms": kernel_ms_d, "roofline_frac": ach_d / FP64_PEAK_TFLOPS, "achieved_TFLOPs": ach_d,
+                        "note": "pruning off (vcmi_gmmmap_set_prune(inf)): every mixture's regression for every frame"}
+        if rank == 0:
+            Yd_dense = Yd[:4096].clone()
+        g.set_prune(46.0 if args.prune is None else args.prune)
+        step()
+        if rank == 0:
+            a, b = Yd[:4096], Yd_dense
+            out["pruning"]["max_rel_diff_vs_dense_4096_frames"] = float((torch.linalg.norm(a - b, dim=1) / torch.linalg.norm(b, dim=1)).max())
+        PER_RANK["wall_s"] = gather_over_ranks(wall, world)
+        PER_RANK["kernel_ms"] = gather_over_ranks(kernel_ms, world)
     if rank == 0:
         from oracle import c_oracle as co
 
@@ -838,6 +874,10 @@ def main():
     ap.add_argument("--pmc", default="auto", choices=["auto", "off"],
                     help="auto: at N=1 measure the headline kernel's HBM traffic in this run (two rocprofv3 --pmc child passes, "
                          "before this process touches the GPU); off: only the committed, source-hash-stamped passes")
+    ap.add_argument("--prune", type=float, default=None,
+                    help="convert: posterior pruning threshold in nats of the timed kernel (default: the library's own default, 46 = "
+                         "regressions of mixtures with posterior < 1e-20 on a whole 16-frame tile are skipped; inf = every mixture "
+                         "for every frame; the `dense` object of the line reports that loop as well)")
     ap.add_argument("--cpu-seconds-sub", type=float, default=5.0, help="CPU budget of each non-headline workload's cpu_baseline")
     ap.add_argument("--frames", type=int, default=1_000_000, help="frames per GPU (BASELINE: 10^6)")
     ap.add_argument("--pairs", type=int, default=1000, help="DTW pairs per GPU")

@@ -91,6 +91,18 @@ int vcmi_gmmmap_predict_dev(vcmi_gmmmap *g, const double *dX, int64_t ldx, int64
  * 4; posterior / predict for other dimensions up to 160: the tiled MFMA log-density kernel; else the generic
  * VALU kernel), 1 = force the generic VALU kernel, 2 = force the MFMA tile kernel (VCMI_ERR_ARG if unavailable). */
 int vcmi_gmmmap_set_kernel(vcmi_gmmmap *g, int which);
+/* Posterior pruning of fvconvert (src/gmmmap.jl:109-117 sums over ALL mixtures; this changes which terms are evaluated,
+ * not the result): the regression A_m x + b_m of mixture m is skipped for a tile of 16 consecutive frames when
+ * l_m < max_k l_k - nats for every frame of the tile, i.e. when its posterior there is below e^-nats.  Default 46.0
+ * (1e-20: below the rounding error of the remaining terms; y changes by < 1e-18 relative).  +infinity (or any value
+ * >= 1e300) evaluates every mixture for every frame -- the dense loop the flop count of SURVEY 8(d) assumes.
+ * VCMI_ERR_ARG for nats < 40 (would be visible in y at double precision) or NaN. */
+int vcmi_gmmmap_set_prune(vcmi_gmmmap *g, double nats);
+/* Diagnostic counter of the pruning: *evaluated (may be NULL) receives the number of (16-frame tile, mixture) regressions
+ * the MFMA fvconvert kernel has evaluated on this handle's device since the counter was last enabled (the dense count is
+ * ceil(T / 16) * M per converted matrix); then enable != 0 (re)starts the counter at zero, enable == 0 switches it off
+ * (the default: the kernel then updates nothing).  Synchronises with the device. */
+int vcmi_gmmmap_prune_stats(vcmi_gmmmap *g, int enable, int64_t *evaluated);
 
 /* ---------------------------------------------------------------------------------------------
  * DTW -- src/dtw.jl:93-145 (fit! + backward), align -- src/align.jl:8-35

@@ -181,3 +181,46 @@ def test_posterior_beyond_80_dimensions(vc, D, M, T, kernel):
     assert P.shape == (M, T)
     assert np.max(np.abs(P - P_ref.T)) < 1e-9
     assert np.array_equal(vc.predict(g.px, X.T), ref.predict(X))
+
+
+def test_posterior_pruning_changes_nothing_visible(vc, fixture_model):
+    """vcmi_gmmmap_set_prune: the default (46 nats) skips the regression of mixtures whose posterior is below 1e-20 on a whole
+    16-frame tile.  Against the dense loop (prune = inf) on the reference's own model and on synthetic ones the outputs
+    agree to rounding; the counter shows that work was really skipped, and that nothing is skipped when nothing may be:
+    (a) pruning off, (b) a model of identical mixtures, where every posterior is 1/M."""
+    import torch
+    from oracle import np_oracle as npo
+    cases = [fixture_model + (40,)]
+    cases.append(npo.synth_model(1002, 80, 64) + (40,))
+    cases.append(npo.synth_model(7, 48, 5) + (24,))
+    for w, mu, sig, D in cases:
+        M = len(w)
+        g = vc.GMMMap(*julia_model(w, mu, sig))
+        X = npo.sample_frames(3, w, mu, sig, 3000, 0, D)
+        Xd = torch.from_numpy(X).cuda()
+        g.prune_stats(True)
+        Yp = vc.fvconvert(g, Xd.t()).t().clone()
+        n_pruned = g.prune_stats(True)
+        g.set_prune(float("inf"))
+        Yf = vc.fvconvert(g, Xd.t()).t().clone()
+        n_dense = g.prune_stats(False)
+        tiles = -(-3000 // 16)
+        assert n_dense == tiles * M
+        assert 0 < n_pruned < n_dense                       # something was skipped, and not everything
+        err = float((torch.linalg.norm(Yp - Yf, dim=1) / torch.linalg.norm(Yf, dim=1)).max())
+        assert err < 1e-15, err
+    # identical mixtures: every posterior is exactly 1/M, nothing may be skipped, y = the single-mixture map
+    w1, mu1, sig1 = npo.synth_model(11, 80, 1)
+    Mi = 9
+    g = vc.GMMMap(*julia_model(np.full(Mi, 1.0 / Mi), np.repeat(mu1, Mi, 0), np.repeat(sig1, Mi, 0)))
+    g1 = vc.GMMMap(*julia_model(w1, mu1, sig1))
+    X = npo.sample_frames(5, w1, mu1, sig1, 500, 0, 40)
+    g.prune_stats(True)
+    Y = vc.fvconvert(g, np.asfortranarray(X.T))
+    assert g.prune_stats(False) == -(-500 // 16) * Mi
+    assert frame_relerr(Y, vc.fvconvert(g1, np.asfortranarray(X.T))) < 1e-12
+    # a threshold that would show in y is refused
+    with pytest.raises(vc.VCMIError):
+        g.set_prune(20.0)
+    with pytest.raises(vc.VCMIError):
+        g.set_prune(float("nan"))

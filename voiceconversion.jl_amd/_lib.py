@@ -67,6 +67,8 @@ SIGNATURES = {
     "vcmi_gmmmap_predict": (_int, [_vp, _dp, _i64, _i64, _ip]),
     "vcmi_gmmmap_predict_dev": (_int, [_vp, _vp, _i64, _i64, _vp, _vp]),
     "vcmi_gmmmap_set_kernel": (_int, [_vp, _int]),
+    "vcmi_gmmmap_set_prune": (_int, [_vp, C.c_double]),
+    "vcmi_gmmmap_prune_stats": (_int, [_vp, _int, _ip]),
     "vcmi_dtw_fit": (_int, [_dp, _i64, _dp, _i64, _int, _int, _int, _ip, _dp, _ip]),
     "vcmi_dtw_fit_batch": (_int, [_i64, _dpp, _ip, _dpp, _ip, _int, _int, _int, _ipp]),
     "vcmi_dtw_fit_batch_dev": (_int, [_i64, _vp, _ip, _ip, _ip, _ip, _int, _int, _int, _vp, _ip, _vp]),

@@ -76,7 +76,44 @@ struct TilingRT {
 typedef double d4 __attribute__((ext_vector_type(4)));
 
 // exp for the softmax weights; arguments are <= 0 (or -inf).
-__device__ __forceinline__ double vc_exp(double x) { return exp(x); }
+#ifndef VCMI_LEAN_EXP
+#define VCMI_LEAN_EXP 1
+#endif
+// p * r + c with the constant c held in an SGPR pair (VOP3 takes it as an operand).  Left to itself the compiler emits
+// v_fmac_f64 and first copies the 64-bit literal into the destination -- two v_mov_b32 per Horner step, 45 % of the
+// VALU instructions of an exp; the scalar moves that replace them issue on the scalar port.
+__device__ __forceinline__ double vc_fma_sconst(double p, double r, double c) {
+  double d;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(p), "v"(r), "s"(c));
+  return d;
+}
+__device__ __forceinline__ double vc_exp(double x) {
+#if VCMI_LEAN_EXP
+  // e^x for x <= 0: n = rint(x log2 e), r = x - n ln 2 (two-term Cody-Waite), degree-13 Taylor series on |r| <= 0.347
+  // (truncation 4e-18), scaled by 2^n with v_ldexp_f64, which also delivers the underflow to 0.  The softmax epilogue
+  // shares the FP64 pipe with the MFMAs, and two exps per mixture are 45 % of its instructions.
+  x = fmax(x, -1000.0);                                  // also maps -inf; e^-1000 is 0 in double
+  const double n = rint(x * 1.4426950408889634074);
+  double r = fma(n, -6.93147180369123816490e-01, x);
+  r = fma(n, -1.90821492927058770002e-10, r);
+  double p = vc_fma_sconst(1.6059043836821613e-10, r, 2.08767569878681e-09);   // 1/13!, 1/12!
+  p = vc_fma_sconst(p, r, 2.505210838544172e-08);        // 1/11!
+  p = vc_fma_sconst(p, r, 2.755731922398589e-07);        // 1/10!
+  p = vc_fma_sconst(p, r, 2.7557319223985893e-06);       // 1/9!
+  p = vc_fma_sconst(p, r, 2.48015873015873e-05);         // 1/8!
+  p = vc_fma_sconst(p, r, 1.984126984126984e-04);        // 1/7!
+  p = vc_fma_sconst(p, r, 1.388888888888889e-03);        // 1/6!
+  p = vc_fma_sconst(p, r, 8.333333333333333e-03);        // 1/5!
+  p = vc_fma_sconst(p, r, 4.1666666666666664e-02);       // 1/4!
+  p = vc_fma_sconst(p, r, 1.6666666666666666e-01);       // 1/3!
+  p = fma(p, r, 0.5);
+  p = fma(p, r, 1.0);
+  p = fma(p, r, 1.0);
+  return ldexp(p, (int)n);
+#else
+  return exp(x);
+#endif
+}
 
 // ------------------------------------------------------------------------------------------------
 // MFMA tile kernel.  One wave owns FT tiles of 16 frames; a workgroup of WAVES waves shares the
@@ -88,7 +125,7 @@ __device__ __forceinline__ double vc_exp(double x) { return exp(x); }
 template <int DP, int FT, int WAVES, int MODE, int NBUF>
 __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(DP <= 40 ? (FT == 2 ? 3 : 4) : 2)))
 gmmmap_mfma_kernel(const double *__restrict__ packed, int M, int D, const double *__restrict__ X, int64_t ldx,
-                   int64_t T, double *__restrict__ Y, int64_t ldy) {
+                   int64_t T, double *__restrict__ Y, int64_t ldy, double prune, unsigned long long *__restrict__ nreg) {
   using TL = Tiling<DP, MODE >= 1>;
   constexpr int KS = TL::KS, NT = TL::NT, NU = TL::NU, BLK = TL::BLK;
   constexpr int NTHREADS = WAVES * 64;
@@ -120,6 +157,11 @@ gmmmap_mfma_kernel(const double *__restrict__ packed, int M, int D, const double
     }
   }
 
+  int nreg_wave = 0;              // MODE 0: (tile, mixture) regressions this wave evaluated (diagnostic counter, see nreg)
+  unsigned tiles_in_range = 0;    // the wave's tiles that hold at least one frame < T
+#pragma unroll
+  for (int f = 0; f < FT; ++f)
+    if (frame0 + 16 * f < T) tiles_in_range |= 1u << f;
   double yacc[FT][KS];
   double runmax[FT], den[FT];
   int bestm[FT];                  // MODE 2: runmax = the largest l_m so far, bestm = its (first) mixture
@@ -215,51 +257,64 @@ gmmmap_mfma_kernel(const double *__restrict__ packed, int M, int D, const double
           }
         }
       } else {
-        // ---------------- phase A: regression tiles, E = A x + b ----------------
-        int sa = s;
+        // Which of the wave's frame tiles can mixture m still contribute to?  p_m <= e^(l_m - runmax) for every frame, so
+        // when l_m < runmax - prune for all 16 frames of a tile, its posterior there is below e^-prune (default e^-46 =
+        // 1e-20, under the rounding error of the other terms) and neither the regression tiles A_m x + b_m nor the
+        // softmax update can change y: both are skipped for that tile (wave-uniform).  prune = +inf keeps the dense loop.
+        unsigned active = 0;
 #pragma unroll
-        for (int t = NU; t < NT; ++t) {
-          d4 c;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) c[r] = cur[TL::CINIT_OFF + 16 * t + 4 * r + lgrp];
-#pragma unroll
-          for (int f = 0; f < FT; ++f) acc[f][t] = c;
-        }
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
+        for (int f = 0; f < FT; ++f)
+          if (__builtin_amdgcn_ballot_w64(lc - 0.5 * q[f] > runmax[f] - prune) != 0) active |= 1u << f;
+        if (MODE == 0) nreg_wave += __builtin_popcount(active & tiles_in_range);
+        if (active) {
+          // ---------------- phase A: regression tiles, E = A x + b (wave-uniform branches around an idle tile's MFMAs) ----------------
+          int sa = s;
 #pragma unroll
           for (int t = NU; t < NT; ++t) {
-            const double a = cur[sa * 64 + lane];
-            ++sa;
+            d4 c;
 #pragma unroll
-            for (int f = 0; f < FT; ++f) acc[f][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, xb[f][ks], acc[f][t], 0, 0, 0);
+            for (int r = 0; r < 4; ++r) c[r] = cur[TL::CINIT_OFF + 16 * t + 4 * r + lgrp];
+#pragma unroll
+            for (int f = 0; f < FT; ++f) acc[f][t] = c;
           }
-        }
-        // online softmax update:  y <- y * e^(old-new) + e^(l-new) * E
 #pragma unroll
-        for (int f = 0; f < FT; ++f) {
-          const double l = lc - 0.5 * q[f];
+          for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+            for (int t = NU; t < NT; ++t) {
+              const double a = cur[sa * 64 + lane];
+              ++sa;
+#pragma unroll
+              for (int f = 0; f < FT; ++f)
+                if (FT == 1 || (active >> f & 1u)) acc[f][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, xb[f][ks], acc[f][t], 0, 0, 0);
+            }
+          }
+          // online softmax update:  y <- y * e^(old-new) + e^(l-new) * E
+#pragma unroll
+          for (int f = 0; f < FT; ++f) {
+            if (FT > 1 && !(active >> f & 1u)) continue;
+            const double l = lc - 0.5 * q[f];
 #ifndef VCMI_LAZY
 #define VCMI_LAZY 1
 #endif
-          if (!VCMI_LAZY || __builtin_amdgcn_ballot_w64(l > runmax[f]) != 0) {   // wave-uniform: some frame has a new maximum
-            const double nm = fmax(runmax[f], l);
-            const double sc = vc_exp(runmax[f] - nm);
-            den[f] *= sc;
-            runmax[f] = nm;
+            if (!VCMI_LAZY || __builtin_amdgcn_ballot_w64(l > runmax[f]) != 0) {   // wave-uniform: some frame has a new maximum
+              const double nm = fmax(runmax[f], l);
+              const double sc = vc_exp(runmax[f] - nm);
+              den[f] *= sc;
+              runmax[f] = nm;
 #pragma unroll
-            for (int j = 0; j < KS; ++j) yacc[f][j] *= sc;
-          }
-          const double wg = vc_exp(l - runmax[f]);
-          den[f] += wg;
+              for (int j = 0; j < KS; ++j) yacc[f][j] *= sc;
+            }
+            const double wg = vc_exp(l - runmax[f]);
+            den[f] += wg;
 #pragma unroll
-          for (int t = NU - 1; t < NT; ++t) {
+            for (int t = NU - 1; t < NT; ++t) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const int p0 = 16 * t + 4 * r;
-              if (p0 >= DP && p0 < 2 * DP) {
-                const int j = (p0 - DP) / 4;
-                yacc[f][j] = fma(wg, acc[f][t][r], yacc[f][j]);
+              for (int r = 0; r < 4; ++r) {
+                const int p0 = 16 * t + 4 * r;
+                if (p0 >= DP && p0 < 2 * DP) {
+                  const int j = (p0 - DP) / 4;
+                  yacc[f][j] = fma(wg, acc[f][t][r], yacc[f][j]);
+                }
               }
             }
           }
@@ -314,6 +369,7 @@ gmmmap_mfma_kernel(const double *__restrict__ packed, int M, int D, const double
     }
   }
   if (MODE == 0) {
+    if (nreg && lane == 0) atomicAdd(nreg, (unsigned long long)nreg_wave);
 #pragma unroll
     for (int f = 0; f < FT; ++f) {
       const int64_t fr = frame0 + 16 * f + lcol;
@@ -618,7 +674,7 @@ static int launch_mfma(const vcmi_gmmmap *g, const double *dX, int64_t ldx, int6
   const int64_t per_wg = (int64_t)16 * FT * WAVES;
   const int64_t blocks = (T + per_wg - 1) / per_wg;
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(WAVES * 64), shmem, st, MODE >= 1 ? g->packedU.p : g->packed.p, g->M,
-                     g->D, dX, ldx, T, dY, ldy);
+                     g->D, dX, ldx, T, dY, ldy, g->prune, MODE == 0 ? g->prune_count.p : nullptr);
   VCMI_HIP(hipGetLastError());
   return VCMI_OK;
 }
@@ -1163,6 +1219,7 @@ int gmmmap_member(vcmi_gmmmap *g, int member, vcmi_gmmmap **out) {
     r = n;
   }
   r->kernel_choice = g->kernel_choice;
+  r->prune = g->prune;
   *out = r;
   return VCMI_OK;
 }
@@ -1233,6 +1290,32 @@ extern "C" int vcmi_gmmmap_set_kernel(vcmi_gmmmap *g, int which) {
   if (!g || which < 0 || which > 2) return fail(VCMI_ERR_ARG, "vcmi_gmmmap_set_kernel: bad argument");
   if (which == 2 && !gmmmap_has_mfma(g->DP)) return fail(VCMI_ERR_ARG, "no MFMA instantiation for dimension %d", g->D);
   g->kernel_choice = which;
+  return VCMI_OK;
+}
+
+extern "C" int vcmi_gmmmap_prune_stats(vcmi_gmmmap *g, int enable, int64_t *evaluated) {
+  if (!g) return fail(VCMI_ERR_ARG, "vcmi_gmmmap_prune_stats: NULL handle");
+  if (evaluated) {
+    *evaluated = 0;
+    if (g->prune_count.p) {
+      unsigned long long h = 0;
+      VCMI_HIP(hipMemcpy(&h, g->prune_count.p, sizeof(h), hipMemcpyDeviceToHost));     // (synchronises with the null stream)
+      *evaluated = (int64_t)h;
+    }
+  }
+  if (enable) {
+    if (!g->prune_count.p) VCMI_TRY(g->prune_count.alloc(1));
+    VCMI_HIP(hipMemset(g->prune_count.p, 0, sizeof(unsigned long long)));
+  } else {
+    g->prune_count.release();
+  }
+  return VCMI_OK;
+}
+
+extern "C" int vcmi_gmmmap_set_prune(vcmi_gmmmap *g, double nats) {
+  if (!g) return fail(VCMI_ERR_ARG, "vcmi_gmmmap_set_prune: NULL handle");
+  if (!(nats >= 40.0)) return fail(VCMI_ERR_ARG, "vcmi_gmmmap_set_prune: threshold %g nats would change y at double precision (>= 40)", nats);
+  g->prune = nats >= 1e300 ? INFINITY : nats;
   return VCMI_OK;
 }
 

@@ -8,6 +8,10 @@ struct vcmi_gmmmap {
   int M = 0;    // ncomponents(g)
   int device = 0;
   int kernel_choice = 0;   // 0 auto, 1 generic VALU, 2 MFMA
+  // fvconvert skips the regression of mixture m for a 16-frame tile when l_m < max_l - prune (nats) for all its frames:
+  // the posterior there is below e^-prune (1e-20 at 46: under the rounding error of the sum).  +inf: dense loop.
+  double prune = 46.0;
+  vcmi::DevBuf<unsigned long long> prune_count;   // optional diagnostic counter (vcmi_gmmmap_prune_stats)
 
   // host copies kept for accessors and for TrajectoryGMMMap's constructor (row-major (D,D) per mixture)
   std::vector<double> h_A_julia;   // Julia memory image (D,D,M) of ΣʸˣΣˣˣ⁻¹

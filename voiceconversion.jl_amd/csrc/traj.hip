@@ -1141,8 +1141,8 @@ static int traj_check_status(vcmi_traj *t, hipStream_t st) {
     fprintf(stderr, "blk_prof cycles: phase1 %lld trsm %lld update %lld backsub %lld | pivot S done at %lld, pivot U at %lld, deferred: S21/S22 at %lld, panel+assembly at %lld\n",
             h[0], h[1], h[2], h[5], h[3], h[4], h[6], h[7]);
     fprintf(stderr, "   gv kernel: product phase %lld, update %lld, moments %lld\n", h[13], h[14], h[15]);
-    fprintf(stderr, "   deferred wave 2: L20 done %lld, past barrier %lld, S21/S22 done %lld, loads issued %lld, panel stored %lld, combined %lld\n", h[8], h[9],
-            h[6], h[10], h[11], h[7]);
+    fprintf(stderr, "   deferred wave 2: L20 done %lld, S21/S22 done %lld, loads issued %lld, panel stored %lld, combined %lld | wave 0 jobs done %lld, wave 1 jobs done %lld | wave 3: S21/S22 done %lld, combined %lld\n", h[8],
+            h[6], h[10], h[11], h[7], h[9], h[12], h[14], h[13]);
   }
 #endif
   int h = 0;

@@ -56,6 +56,17 @@ class GMMMap(FrameByFrameConverter):
         """0 auto, 1 generic VALU kernel, 2 MFMA tile kernel (used by the parity tests to cover both)."""
         _lib.check(_lib.lib.vcmi_gmmmap_set_kernel(self._h, int(which)))
 
+    def set_prune(self, nats):
+        """Posterior pruning threshold of fvconvert in nats (default 46: terms below 1e-20 of the sum are not evaluated);
+        float('inf') evaluates every mixture for every frame (include/vcmi.h: vcmi_gmmmap_set_prune)."""
+        _lib.check(_lib.lib.vcmi_gmmmap_set_prune(self._h, float(nats)))
+
+    def prune_stats(self, enable=True):
+        """(tile, mixture) regressions evaluated since the counter was last enabled; then restart (enable) or switch it off."""
+        n = C.c_int64(0)
+        _lib.check(_lib.lib.vcmi_gmmmap_prune_stats(self._h, 1 if enable else 0, C.byref(n)))
+        return int(n.value)
+
     def _fvconvert(self, x, out=None):
         if is_torch(x):
             import torch

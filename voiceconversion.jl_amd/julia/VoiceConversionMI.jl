@@ -24,7 +24,7 @@ export FrameByFrameConverter, TrajectoryConverter, GMMMapParam, GMMMap, Trajecto
        align, align_mcep, push_delta, GVDataset,
        DTW, fit!, update!, set_template!, backward,
        predict_proba, predict_proba!, predict, predict!, diffgmm,
-       estep_diag, estep_full, GMMEM, estep!, mstep!, params, set_devices, device_count
+       estep_diag, estep_full, GMMEM, estep!, mstep!, params, set_devices, device_count, set_prune!
 
 const libvcmi = get(ENV, "LIBVCMI", "libvcmi")
 
@@ -151,6 +151,8 @@ Base.length(g::GMMMap) = 1                                             # src/gmm
 dim(g::GMMMap) = Int(ccall((:vcmi_gmmmap_dim, libvcmi), Cint, (Ptr{Cvoid},), g.h))
 ncomponents(g::GMMMap) = Int(ccall((:vcmi_gmmmap_ncomponents, libvcmi), Cint, (Ptr{Cvoid},), g.h))
 Base.size(g::GMMMap) = (dim(g), length(g))
+# not in the reference: posterior pruning threshold of fvconvert in nats (default 46.0; Inf = evaluate every mixture)
+set_prune!(g::GMMMap, nats::Real) = check(ccall((:vcmi_gmmmap_set_prune, libvcmi), Cint, (Ptr{Cvoid}, Cdouble), g.h, Float64(nats)))
 
 # fvconvert(g, x) -- src/gmmmap.jl:101-118
 function fvconvert(g::GMMMap, x::Vector{Float64})
