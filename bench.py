@@ -163,6 +163,22 @@ def self_launch(argv, n_gpus):
     return subprocess.call(cmd, env=env)
 
 
+def host_facts():
+    """What the host-pointer path's speed depends on besides PCIe: sockets, huge pages, copy threads."""
+    import glob
+
+    def rd(path):
+        try:
+            return open(path).read().strip()
+        except OSError:
+            return None
+
+    return {"cores": os.cpu_count(), "numa_nodes": len(glob.glob("/sys/devices/system/node/node[0-9]*")),
+            "transparent_hugepage": rd("/sys/kernel/mm/transparent_hugepage/enabled"),
+            "copy_threads": os.environ.get("VCMI_HOST_THREADS", "default (min(16, cores/4))"),
+            "placement": os.environ.get("VCMI_HOST_NUMA", "default (copy workers and pinned slots on the calling thread's socket)")}
+
+
 BACKEND = {"name": None}
 LIVE_PMC = {}            # workload -> per-kernel traffic table measured by this run (measure_traffic_live)
 
@@ -396,7 +412,8 @@ def bench_convert(args, world, rank):
                                          "pinned staging, H2D / kernel / D2H of consecutive chunks overlapped; `value` "
                                          "allocates a fresh output per call like `similar(X)` (first-touch page faults "
                                          "included), `reused_output` writes into an existing array",
-                                 "parity_vs_device_path": bool(np.array_equal(Yh.T, Yd.cpu().numpy()))}
+                                 "parity_vs_device_path": bool(np.array_equal(Yh.T, Yd.cpu().numpy())),
+                                 "host": host_facts()}
         # the honest strong CPU baseline -- the same arithmetic on every host core (OpenMP over frames)
         try:
             ns = int(min(T, max(n, 8 * n)))

@@ -1,5 +1,5 @@
 import sys, time, numpy as np
-sys.path.insert(0, '/root/repo')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import voiceconversion_jl_amd as vc
 import synthdata as npo
 D, M, T = 40, 64, 1_000_000

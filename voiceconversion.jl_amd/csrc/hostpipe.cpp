@@ -11,7 +11,9 @@
 #include <mutex>
 #include <thread>
 
+#include <sched.h>
 #include <sys/mman.h>
+#include <sys/syscall.h>
 #include <unistd.h>
 
 namespace vcmi {
@@ -41,7 +43,79 @@ struct Task {
   const std::function<void(int64_t, int64_t)> *fn;
   int64_t lo, hi;
   std::shared_ptr<Latch> latch;
+  std::shared_ptr<const std::function<void(int64_t, int64_t)>> owned;   // fire-and-forget tasks keep their function alive
 };
+
+// ---- NUMA placement (no libnuma in the image: sysfs + raw syscalls; every failure just leaves the default placement) ----
+// The boxes have two sockets with four GPUs each; a staging slot or a copy thread on the other socket puts the
+// inter-socket link into every transfer (driver-run host path of round 2: 32 ms where the build box gave 15).
+int numa_node_of_device(int dev) {
+  char bdf[64] = {0};
+  if (hipDeviceGetPCIBusId(bdf, (int)sizeof(bdf), dev) != hipSuccess) return -1;
+  for (char *c = bdf; *c; ++c) *c = (char)tolower(*c);
+  char path[160];
+  snprintf(path, sizeof(path), "/sys/bus/pci/devices/%s/numa_node", bdf);
+  FILE *f = fopen(path, "r");
+  if (!f) return -1;
+  int node = -1;
+  if (fscanf(f, "%d", &node) != 1) node = -1;
+  fclose(f);
+  return node;
+}
+bool cpus_of_node(int node, cpu_set_t *set) {
+  char path[96];
+  snprintf(path, sizeof(path), "/sys/devices/system/node/node%d/cpulist", node);
+  FILE *f = fopen(path, "r");
+  if (!f) return false;
+  CPU_ZERO(set);
+  int a, b, n = 0;
+  while (fscanf(f, "%d", &a) == 1) {
+    b = a;
+    int c = fgetc(f);
+    if (c == '-') {
+      if (fscanf(f, "%d", &b) != 1) break;
+      c = fgetc(f);
+    }
+    for (int k = a; k <= b && k < CPU_SETSIZE; ++k) {
+      CPU_SET(k, set);
+      ++n;
+    }
+    if (c != ',') break;
+  }
+  fclose(f);
+  return n > 0;
+}
+// memory policy of the calling thread for the duration of a scope: allocations prefer `node` (MPOL_PREFERRED = 1)
+struct ScopedPreferNode {
+  bool active = false;
+  explicit ScopedPreferNode(int node) {
+    if (node < 0 || node >= 64) return;
+    unsigned long mask = 1ul << node;
+    active = syscall(SYS_set_mempolicy, 1 /*MPOL_PREFERRED*/, &mask, 65ul) == 0;
+  }
+  ~ScopedPreferNode() {
+    if (active) (void)syscall(SYS_set_mempolicy, 0 /*MPOL_DEFAULT*/, nullptr, 0ul);
+  }
+};
+// Which node the copy workers and the pinned slots of a device go to.  Measured on the two-socket boxes (tools/hostbench.py,
+// 2 x 320 MB per call): what matters is that the copies between the user's arrays and the pinned slots stay on ONE
+// socket -- the caller's, where its arrays were first touched; the DMA engines reach a slot on the other socket at full
+// rate.  Everything on the caller's socket: 11.2 ms; workers and slots on the GPU's socket with the caller on the other
+// one: 15.4 ms; unbound workers (rounds 1-2): 13.6-16.5 ms.  VCMI_HOST_NUMA=device|off overrides (read once).
+int node_of_calling_thread() {
+  unsigned cpu = 0, node = 0;
+  if (syscall(SYS_getcpu, &cpu, &node, nullptr) != 0) return -1;
+  return (int)node;
+}
+int placement_node(int dev) {
+  static const int mode = [] {
+    const char *e = getenv("VCMI_HOST_NUMA");
+    return !e ? 0 : !strcmp(e, "device") ? 1 : !strcmp(e, "off") ? 2 : 0;
+  }();
+  if (mode == 2) return -1;
+  return mode == 1 ? numa_node_of_device(dev) : node_of_calling_thread();
+}
+std::atomic<int> g_pool_node{-2};   // -2: never set; -1: no binding (devices on several nodes / unknown); >= 0: that node
 
 class Pool {
  public:
@@ -66,7 +140,7 @@ class Pool {
       q_.pop_front();
     }
     (*t.fn)(t.lo, t.hi);
-    t.latch->done();
+    if (t.latch) t.latch->done();
     return true;
   }
 
@@ -79,6 +153,7 @@ class Pool {
     for (int i = 0; i < n; ++i) std::thread([this] { loop(); }).detach();
   }
   void loop() {
+    int bound = -2;
     for (;;) {
       Task t;
       {
@@ -87,8 +162,22 @@ class Pool {
         t = q_.front();
         q_.pop_front();
       }
+      // follow the pool's NUMA binding (set when a staging ring is made): the workers run on the socket of the GPU they
+      // feed, so their copies and the pages they first touch stay off the inter-socket link
+      const int want = g_pool_node.load(std::memory_order_relaxed);
+      if (want != bound && want != -2) {
+        cpu_set_t set;
+        if (want >= 0 && cpus_of_node(want, &set)) {
+          (void)sched_setaffinity(0, sizeof(set), &set);
+        } else {
+          CPU_ZERO(&set);
+          for (int k = 0; k < CPU_SETSIZE; ++k) CPU_SET(k, &set);
+          (void)sched_setaffinity(0, sizeof(set), &set);
+        }
+        bound = want;
+      }
       (*t.fn)(t.lo, t.hi);
-      t.latch->done();
+      if (t.latch) t.latch->done();
     }
   }
   std::mutex mu_;
@@ -114,7 +203,7 @@ void host_parallel_for(int64_t n, int64_t grain, const std::function<void(int64_
   const int64_t per = (n + parts - 1) / parts;
   for (int64_t p = 1; p < parts; ++p) {
     const int64_t lo = p * per, hi = std::min(n, lo + per);
-    if (lo < hi) tasks.push_back(Task{&fn, lo, hi, lp});
+    if (lo < hi) tasks.push_back(Task{&fn, lo, hi, lp, nullptr});
   }
   latch.remaining = (int)tasks.size();
   if (!tasks.empty()) pool.push(tasks.data(), (int)tasks.size());
@@ -126,6 +215,18 @@ void host_parallel_for(int64_t n, int64_t grain, const std::function<void(int64_
   }
   std::unique_lock<std::mutex> lk(latch.m);
   latch.c.wait(lk, [&] { return latch.remaining == 0; });
+}
+
+// fn(lo, hi) over [0, n) in parts of `grain`, queued for the workers WITHOUT waiting (the caller goes on; nothing reports
+// completion): used to pre-fault output pages ahead of the pipeline.  fn must not touch anything that can go away.
+static void host_async_for(int64_t n, int64_t grain, std::function<void(int64_t, int64_t)> fn) {
+  if (n <= 0) return;
+  Pool &pool = Pool::get();
+  if (pool.workers() == 0) return;
+  auto owned = std::make_shared<const std::function<void(int64_t, int64_t)>>(std::move(fn));
+  std::vector<Task> tasks;
+  for (int64_t lo = 0; lo < n; lo += grain) tasks.push_back(Task{owned.get(), lo, std::min(n, lo + grain), nullptr, owned});
+  pool.push(tasks.data(), (int)tasks.size());
 }
 
 void host_copy(void *dst, const void *src, size_t bytes) {
@@ -166,6 +267,7 @@ constexpr size_t kPipeChunk = (size_t)32 << 20;        // pipeline chunks (bytes
 struct Ring {
   std::mutex mu;
   int device = -1;
+  int node = -1;                    // NUMA node of the device (-1: unknown)
   bool ready = false;
   hipStream_t up = nullptr, run = nullptr, down = nullptr;
   hipEvent_t ev_up[K] = {}, ev_run[K] = {}, ev_down[K] = {}, ev_tmp = nullptr;
@@ -202,6 +304,7 @@ struct Ring {
       slots[i] = nullptr;
     }
     cap = 0;
+    ScopedPreferNode prefer(pinned ? node : -1);   // pinned slots on the GPU's socket
     for (int i = 0; i < K; ++i) {
       hipError_t e = pinned ? hipHostMalloc(reinterpret_cast<void **>(&slots[i]), bytes, hipHostMallocPortable)
                             : hipMalloc(reinterpret_cast<void **>(&slots[i]), bytes);
@@ -229,6 +332,13 @@ int current_ring(Ring **out) {
     g_rings[dev] = new (std::nothrow) Ring();
     if (!g_rings[dev]) return fail(VCMI_ERR_OOM, "out of host memory");
     g_rings[dev]->device = dev;
+    g_rings[dev]->node = placement_node(dev);
+    // the copy workers follow the device while all rings of the process sit on one node; with devices on both sockets
+    // (a device group over the whole box) they stay unbound
+    int want = g_rings[dev]->node;
+    for (int d = 0; d < kMaxDevices; ++d)
+      if (g_rings[d] && g_rings[d]->node != want) want = -1;
+    g_pool_node.store(want, std::memory_order_relaxed);
   }
   *out = g_rings[dev];
   return VCMI_OK;
@@ -394,6 +504,25 @@ int staged_pipeline(const void *hIn, size_t in_unit, size_t in_stride, void *hOu
     if (span >= 16 * huge) {
       const uintptr_t a = ((uintptr_t)hOut + huge - 1) & ~(uintptr_t)(huge - 1), b = ((uintptr_t)hOut + span) & ~(uintptr_t)(huge - 1);
       if (b > a) (void)madvise(reinterpret_cast<void *>(a), b - a, MADV_HUGEPAGE);
+    }
+    // ... and fault the pages in AHEAD of the pipeline, on the workers, while the first chunks upload and compute:
+    // MADV_POPULATE_WRITE (Linux >= 5.14) takes the write faults of a range in one call without changing its contents
+    // (a strided output, vc's (D+1,T) matrix, keeps the rows it does not own).  Otherwise the faults are taken by the
+    // scatter copies at the end of the pipeline, on its critical path -- where THP compaction stalls showed up as
+    // 25-32 ms calls on some boxes against 14 ms on others.  Older kernels return EINVAL: nothing is lost.
+    if (span >= 4 * huge) {
+      char *base = reinterpret_cast<char *>(hOut);
+      constexpr size_t piece = (size_t)8 << 20;
+      host_async_for((int64_t)((span + piece - 1) / piece), 1, [base, span](int64_t lo, int64_t hi) {
+        constexpr size_t piece = (size_t)8 << 20;
+        const long pg = 4096;
+        for (int64_t k = lo; k < hi; ++k) {
+          uintptr_t a = (uintptr_t)(base + (size_t)k * piece), b = (uintptr_t)(base + std::min(span, (size_t)(k + 1) * piece));
+          a = (a + pg - 1) & ~(uintptr_t)(pg - 1);       // whole pages inside the range only
+          b &= ~(uintptr_t)(pg - 1);
+          if (b > a) (void)madvise(reinterpret_cast<void *>(a), b - a, 23 /*MADV_POPULATE_WRITE*/);
+        }
+      });
     }
   }
   constexpr int LAG = K - 1;
