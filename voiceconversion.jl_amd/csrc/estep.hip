@@ -348,6 +348,10 @@ estep_mfma_kernel(const double *__restrict__ X, int64_t N, int M, const double *
         double gm;
         if constexpr (PHASE == 0) gm = lg[f * RSG + 16 * tile + lcol];
         else gm = gpre[ks];
+        // responsibilities that underflowed to exactly 0 (l_m more than 745 nats under the frame's maximum: the usual case
+        // for all but a few of the 128 mixtures) add exactly nothing: when that holds for the tile's 16 mixtures on all
+        // four frames of the k-step, its 2 NDT/2 products are skipped (wave-uniform; the statistics are bit-identical)
+        if (__builtin_amdgcn_ballot_w64(gm != 0.0) == 0) continue;
         const double *xr = xs + f * RSX + lcol;
 #pragma unroll
         for (int j = 0; j < NDT / 2; ++j) {
@@ -794,6 +798,9 @@ __device__ __forceinline__ void estep_full_stats_body(const double *__restrict__
     for (int ks = 0; ks < FB / 4; ++ks) {
       const int f = 4 * ks + lgrp;
       const double gm = gb[f * NM + ml];
+      // the four frames of the k-step all have gamma == 0 exactly for this wave's mixture (l_m more than 745 nats under
+      // the frame's maximum): the products add exactly nothing -- skipped (wave-uniform; bit-identical statistics)
+      if (__builtin_amdgcn_ballot_w64(gm != 0.0) == 0) continue;
       const double *xr = xb + f * RSX + lcol;
       double xv[NTL], ax[NTL];
 #pragma unroll
