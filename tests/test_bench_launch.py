@@ -38,3 +38,36 @@ def test_dead_rank_fails_the_launch():
     p = _run(["--gpus", "2", "--workload", "selftest"], {"VCMI_BENCH_BACKEND": "gloo", "VCMI_SELFTEST_DIE_RANK": "1"})
     assert p.returncode != 0
     assert not [l for l in p.stdout.splitlines() if l.startswith("{")]
+
+
+def test_roofline_traffic_is_refused_when_collected_from_other_sources(tmp_path, monkeypatch):
+    """bench.py quotes a committed PMC pass only when it was collected from the library sources the loaded library was
+    built from (`_meta.source_hash`, tools/pmc_traffic.py); a stale file yields traffic = None and says why
+    (a stale file silently reported old traffic)."""
+    import json
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    csrc = tmp_path / "voiceconversion.jl_amd" / "csrc"
+    csrc.mkdir(parents=True)
+    (csrc / "k.hip").write_text("// kernel v1\n")
+    pm = tmp_path / "profiles" / bench.PMC_DIR
+    pm.mkdir(parents=True)
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    h1 = bench.source_hash()
+    table = {"void vcmi::some_kernel<40>": {"FETCH_SIZE_KB_per_step": 1000.0, "WRITE_SIZE_KB_per_step": 500.0},
+             "other": {"FETCH_SIZE_KB_per_step": 7.0}, "_meta": {"source_hash": h1, "collected": "now"}}
+    (pm / "x_traffic.json").write_text(json.dumps(table))
+    v, src = bench.pmc_traffic("x_traffic.json", "some_kernel")
+    assert v == 1500.0 * 1024 and src["source_hash"] == h1
+    v, _ = bench.pmc_traffic("x_traffic.json", "some_kernel", wide_reads=True)       # FETCH doubled (16-byte-per-lane reads)
+    assert v == 2500.0 * 1024
+    (csrc / "k.hip").write_text("// kernel v2\n")                                    # the sources moved on
+    assert bench.source_hash() != h1
+    v, src = bench.pmc_traffic("x_traffic.json", "some_kernel")
+    assert v is None and "REFUSED" in src["source"]
+    v, src = bench.pmc_traffic("missing.json", "some_kernel")
+    assert v is None and "missing" in src["source"]
+    # a table measured by this run is taken as it is
+    v, src = bench.pmc_traffic("x_traffic.json", "some_kernel", live=table)
+    assert v == 1500.0 * 1024 and "measured in this run" in src["source"]

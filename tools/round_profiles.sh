@@ -1,23 +1,29 @@
 #!/bin/bash
-# One round's evidence, collected on the GPU box:  bash tools/round_profiles.sh r02
+# One round's evidence, collected on the GPU box:  bash tools/round_profiles.sh r03
+#   the driver's default command (`bench.py` with no workload: headline + the `workloads` table over configs[1..4]);
 #   per workload: the bench JSON line, the rocprofv3 --kernel-trace --stats summary of the same command, the per-CALL
-#   kernel durations of that run (so that averages can be taken over the timed calls only), and the HBM traffic from
-#   separate --pmc FETCH_SIZE / --pmc WRITE_SIZE passes (tools/pmc_traffic.sh).
+#   kernel durations of that run (so that averages can be taken over the timed calls only), the HBM traffic from
+#   separate --pmc FETCH_SIZE / --pmc WRITE_SIZE passes (tools/pmc_traffic.py: stamped with the library's source hash)
+#   and the effective clock / MFMA-pipe occupancy pass (tools/clock_pmc.py).
 # Results land in gpurun_out/<tag>/; copy what is to be judged into profiles/.
 tag=${1:-rXX}; shift
 R=$GRAFT_REPO_ROOT
 out=$R/gpurun_out/$tag
-mkdir -p $out $out/pmc
+mkdir -p $out $out/pmc $out/clock
 cd /tmp && export TMPDIR=/tmp
-for w in ${@:-convert estep estep_full em_full dtw traj trajgv}; do
+( time python3 $R/bench.py --steps 20 --warmup 5 > $out/all_bench.json 2> $out/all_bench.err ) 2> $out/all_bench.time
+for spec in ${@:-convert estep estep_full em_full dtw dtw:d41 traj traj:chunk100 trajgv}; do
+  w=${spec%%:*}; var=${spec#*:}; [ "$var" = "$spec" ] && var=""
+  name=$w; extra=""
+  [ "$var" = d41 ] && { name=dtw_d41; extra="--dim 41"; }
+  [ "$var" = chunk100 ] && { name=traj_chunk100; extra="--chunk 100"; }
   steps=10; [ $w = trajgv ] && steps=3
-  extra=""
-  timeout 400 python3 $R/bench.py --workload $w --steps $steps --warmup 2 $extra 2>/dev/null | tail -1 > $out/${w}_bench.json
-  timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_$w -- python3 $R/bench.py --workload $w --steps $steps --warmup 2 --cpu-seconds 0 > /dev/null 2>&1
-  f=$(find $out/prof_$w -name "*kernel_stats.csv" | head -1)
-  [ -n "$f" ] && cp $f $out/${w}_kernel_stats.csv
-  t=$(find $out/prof_$w -name "*kernel_trace.csv" | head -1)
-  [ -n "$t" ] && python3 - "$t" > $out/${w}_kernel_calls.csv <<'PY'
+  timeout 400 python3 $R/bench.py --workload $w --steps $steps --warmup 2 --pmc off $extra 2>/dev/null | tail -1 > $out/${name}_bench.json
+  timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_$name -- python3 $R/bench.py --workload $w --steps $steps --warmup 2 --cpu-seconds 0 --pmc off $extra > /dev/null 2>&1
+  f=$(find $out/prof_$name -name "*kernel_stats.csv" | head -1)
+  [ -n "$f" ] && cp $f $out/${name}_kernel_stats.csv
+  t=$(find $out/prof_$name -name "*kernel_trace.csv" | head -1)
+  [ -n "$t" ] && python3 - "$t" > $out/${name}_kernel_calls.csv <<'PY'
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
@@ -26,8 +32,12 @@ print("call,kernel,start_us,duration_us")
 for i, r in enumerate(rows):
     print(f'{i},"{r["Kernel_Name"].split("(")[0][:70]}",{(int(r["Start_Timestamp"]) - t0) / 1e3:.1f},{(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3:.2f}')
 PY
-  rm -rf $out/prof_$w
-  bash $R/tools/pmc_traffic.sh $w > /dev/null 2>&1
-  [ -f $R/gpurun_out/pmc_traffic/$w/traffic.json ] && cp $R/gpurun_out/pmc_traffic/$w/traffic.json $out/pmc/${w}_traffic.json
-  echo "$w: $(cut -c1-200 $out/${w}_bench.json | grep -o '"value": [0-9.e+]*\|ms_per_step": [0-9.]*' | tr '\n' ' ')"
+  rm -rf $out/prof_$name
+  python3 $R/tools/pmc_traffic.py $w --out $out/pmc_$name $extra > /dev/null 2>&1
+  [ -f $out/pmc_$name/traffic.json ] && cp $out/pmc_$name/traffic.json $out/pmc/${name}_traffic.json
+  rm -rf $out/pmc_$name
+  python3 $R/tools/clock_pmc.py $w --out $out/clk_$name $extra > /dev/null 2>&1
+  [ -f $out/clk_$name/clock.json ] && cp $out/clk_$name/clock.json $out/clock/${name}_clock.json
+  rm -rf $out/clk_$name
+  echo "$name: $(cut -c1-200 $out/${name}_bench.json | grep -o '"value": [0-9.e+]*\|ms_per_step": [0-9.]*' | tr '\n' ' ')"
 done

@@ -23,17 +23,6 @@
 // Cycle counters per phase: build with -DTRAJ_BLK_PROF (make EXTRA=-DTRAJ_BLK_PROF), printed to stderr per call.
 #pragma once
 
-// What a block step leaves in the HBM workspace for the back substitution.
-//   1 (round 3): the factors themselves -- L10 (with z0 in its row D), L20 and U, copied out of the window by short store
-//      jobs.  The back substitution is y_t = U' (z0 - L10' y_{t+1} - L20' y_{t+2}): one 2D x D product split over the
-//      four waves and one D x D triangular product by wave 0.  38.7 KB per step at D = 40.
-//   0 (rounds 1-2): M1 = L10 U (last row h = U' z0) and M2 = L20 U, formed by 2 NT MFMA jobs per step (108 of the 506
-//      v_mfma_f64_16x16x4 of a step at D = 40, a fifth of the factorisation's products, two of them on the scalar-chain
-//      wave), so that the back substitution is one product per step on a 25.9 KB panel.
-#ifndef TRAJ_LU_PANEL
-#define TRAJ_LU_PANEL 0
-#endif
-
 template <int D>
 struct BlkCfg {
   static constexpr int DP = ((D + 1 + 15) / 16) * 16;   // rows / columns of a block buffer: 16-row tiles incl. the rhs row D
@@ -43,12 +32,7 @@ struct BlkCfg {
   static constexpr int BUF = DP * LS;                   // doubles per block buffer
   static constexpr int CB = 64;                         // counters of the workgroup (ints): [0] pivot stage, [2] L20 arrivals, [3] S11 arrivals
   static constexpr int RING = D * 64;                   // pivot wave 1's scratch tiles (Pv2<D>::SCRATCH doubles are used)
-#if TRAJ_LU_PANEL
-  // panel doubles per block step: L10 (D rows) + z0 (1 row) + L20 (D rows) + U (D rows, lower triangular), row stride D
-  static constexpr size_t PAN = (size_t)(3 * D + 1) * D;
-#else
   static constexpr size_t PAN = (size_t)(2 * D + 1) * D;   // panel doubles per block step: M1 = L10 U (D+1,D) incl. h = U' z0, M2 = L20 U (D,D)
-#endif
   static constexpr size_t WORK = 6 * (size_t)BUF > 3 * PAN ? 6 * (size_t)BUF : 3 * PAN;   // six window buffers / three staged panels
   static constexpr size_t lds_doubles = WORK + CB + RING + 2 * D + 768 + 2;
 };
@@ -458,50 +442,6 @@ __device__ __forceinline__ void blk_lu_rowtile_to_panel(const double *L, const d
   }
 }
 
-// rows [16 it, 16 it + 16) below `nrows` of a block buffer (row stride LS) -> the HBM panel `out` (row stride D), columns
-// < D, in 16-byte pieces when D is even: one of the store jobs that replace the panel products (TRAJ_LU_PANEL).  The
-// per-lane element offsets come from a table made once per kernel (BlkStoreTab): computed per element, the index
-// arithmetic cost more than a thousand counts per job -- a lone wave pays ~6 cycles per VALU instruction.
-template <int D>
-struct BlkStoreTab {
-  static constexpr int VW = (D % 2 == 0) ? 2 : 1;           // doubles per access
-  static constexpr int PER_ROW = D / VW;
-  static constexpr int N = (16 * PER_ROW + 63) / 64;        // accesses per lane and row tile
-  int so[N], go[N], row[N];                                 // LDS offset, panel offset, row within the tile (16: none)
-  __device__ void init(int lane) {
-    constexpr int LS = BlkCfg<D>::LS;
-#pragma unroll
-    for (int k = 0; k < N; ++k) {
-      const int e = lane + 64 * k, r = e / PER_ROW, c = (e - r * PER_ROW) * VW;
-      row[k] = r < 16 ? r : 16;
-      so[k] = (r < 16 ? r : 0) * LS + c;
-      go[k] = (r < 16 ? r : 0) * D + c;
-    }
-  }
-};
-template <int D>
-__device__ __forceinline__ void blk_store_rowtile(const BlkStoreTab<D> &tb, const double *B, int it, int nrows,
-                                                  double *__restrict__ out, int ncols = D) {   // columns >= ncols (a multiple of 16): zeros
-  using Tb = BlkStoreTab<D>;
-  typedef double sv_t __attribute__((ext_vector_type(Tb::VW)));
-  constexpr int LS = BlkCfg<D>::LS;
-  const int nr = nrows - 16 * it;                            // rows of the tile that exist (>= 16: all)
-  const double *src = B + 16 * it * LS;
-  double *dst = out + (size_t)16 * it * D;
-  sv_t v[Tb::N];
-#pragma unroll
-  for (int k = 0; k < Tb::N; ++k) v[k] = *reinterpret_cast<const sv_t *>(src + tb.so[k]);
-#pragma unroll
-  for (int k = 0; k < Tb::N; ++k)
-    if (tb.row[k] < nr && tb.row[k] < 16) {
-      const int c = tb.go[k] - tb.row[k] * D;
-      sv_t z;
-#pragma unroll
-      for (int q = 0; q < Tb::VW; ++q) z[q] = 0.0;
-      *reinterpret_cast<sv_t *>(dst + tb.go[k]) = (c < ncols) ? v[k] : z;
-    }
-}
-
 // Back substitution from the panels in the HBM workspace:
 //   y_t = U' (z0 - L10' y_{t+1} - L20' y_{t+2}) = h - M1' y_{t+1} - M2' y_{t+2},   M1 = L10 U, M2 = L20 U, h = U' z0
 // (formed by the deferred team of the factorisation): one product per step, split over the four waves (lane = column,
@@ -516,11 +456,7 @@ __device__ void blk_backsub(const double *__restrict__ ws, int T, double *buf, d
   using C = BlkCfg<D>;
   constexpr int PAN = (int)C::PAN;
   constexpr int NPRE = (PAN + 255) / 256;
-  constexpr int OH = D * D, OM2 = (D + 1) * D;      // row D of the first block (h, or z0 with TRAJ_LU_PANEL); second block
-#if TRAJ_LU_PANEL
-  constexpr int OU = (2 * D + 1) * D;               // U (lower triangular, zeros above the diagonal)
-  double *xs = part + 640;                          // [64] x = z0 - L10' y_{t+1} - L20' y_{t+2}
-#endif
+  constexpr int OH = D * D, OM2 = (D + 1) * D;
   constexpr int YB = 8;                    // steps per result flush
   const int tid = threadIdx.x, j = tid & 63, p = tid >> 6;
   double *ybuf = part + 320;               // [YB][D]
@@ -567,35 +503,11 @@ __device__ void blk_backsub(const double *__restrict__ ws, int T, double *buf, d
       if (p < 4) part[p * 64 + j] = s0 + s1;      // the product is split over four waves; further waves only stage panels
     }
     __syncthreads();
-#if TRAJ_LU_PANEL
-    if (p == 0) {     // wave 0: x = the four partial sums, then y_t = U' x (U lower triangular with explicit zeros above)
-      const double xv = ((part[j] + part[64 + j]) + part[128 + j]) + part[192 + j];
-      xs[j] = (j < D) ? xv : 0.0;
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      const double *ub = pb + OU + jc;
-      double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-#pragma unroll
-      for (int i = 0; i < D; i += 4) {
-        a0 = fma(ub[i * D], xs[i], a0);
-        if (i + 1 < D) a1 = fma(ub[(i + 1) * D], xs[i + 1], a1);
-        if (i + 2 < D) a2 = fma(ub[(i + 2) * D], xs[i + 2], a2);
-        if (i + 3 < D) a3 = fma(ub[(i + 3) * D], xs[i + 3], a3);
-      }
-      const double yv = (a0 + a1) + (a2 + a3);
-      if (j < D) {
-        y2[j] = yv;                       // becomes y_t; the slot of y_{t+2} is free now
-        ybuf[(t & (YB - 1)) * D + j] = yv;
-      }
-    }
-#else
     if (tid < D) {
       const double yv = ((part[tid] + part[64 + tid]) + part[128 + tid]) + part[192 + tid];
       y2[tid] = yv;                       // becomes y_t; the slot of y_{t+2} is free now
       ybuf[(t & (YB - 1)) * D + tid] = yv;
     }
-#endif
     if (t >= 1) stage(t - 1, cur);
     __syncthreads();
     if ((t & (YB - 1)) == 0) {            // rows t .. t+YB-1 of reshape(y, D, T), src/trajectory_gmmmap.jl:109
@@ -630,17 +542,6 @@ __device__ void blk_backsub(const double *__restrict__ ws, int T, double *buf, d
 // one; without wave 1's L20 tile 0.7 ms slower; wave 0 leaving the barrier after the L10 row tiles out: no gain.
 template <int NT, int NPW, int NDW>
 __device__ constexpr int blk_job_owner(int j) {
-#if TRAJ_LU_PANEL
-  // row groups to the deferred waves; the short store jobs (L10 | L20 | U row tiles) to pivot wave 1 after its last
-  // product and to the deferred waves; none to wave 0, whose scalar chains are the critical path
-  if (NT == 3 && NDW == 2) {
-    //               S21 r0 r1 r2 | S22 r2 r1 r0 | L10 t0 t1 t2 | L20 t0 t1 t2 | U t0 t1 t2
-    constexpr int own[15] = {2, 3, 0, 3, 2, 3, 1, 1, 1, 2, 3, 2, 3, 1, 1};
-    return own[j];
-  }
-  if (j >= 2 * NT) return 1 + (j - 2 * NT) % (1 + NDW);
-  return NPW + j % NDW;
-#endif
   if (NT == 3 && NDW == 2) {
     //               S21 r0 r1 r2 | S22 r2 r1 r0 | M1 t0 t1 t2 | M2 t0 t1 t2
     constexpr int own[12] = {2, 3, 2, 3, 2, 3, 1, 1, 2, 3, 0, 0};
@@ -693,10 +594,6 @@ traj_solve_blk_kernel(const TrajUtt *__restrict__ utts, int n, const double *__r
     eq[k] = i * D2 + j;
   }
   typedef double ev_t __attribute__((ext_vector_type(VW)));
-#if TRAJ_LU_PANEL
-  BlkStoreTab<D> stab;
-  stab.init(lane);
-#endif
 
   for (int u = blockIdx.x; u < n; u += gridDim.x) {
     const TrajUtt U = utts[u];
@@ -752,17 +649,9 @@ traj_solve_blk_kernel(const TrajUtt *__restrict__ utts, int n, const double *__r
         double *pan = ws + (size_t)(t - 1) * PAN;
         if (j < NT) blk_update_rowgroup<D>(b10, p2, p1, j, NT, lane);
         else if (j < 2 * NT) blk_update_rowgroup<D>(b11, p2, p2, 2 * NT - 1 - j, 2 * NT - j, lane);
-#if TRAJ_LU_PANEL
-        else if (j < 3 * NT) blk_store_rowtile<D>(stab, p1, j - 2 * NT, D + 1, pan);                       // L10, z0 in row D
-        else if (j < 4 * NT) blk_store_rowtile<D>(stab, p2, j - 3 * NT, D, pan + (D + 1) * D);             // L20
-        // U: only the tiles up to the diagonal one hold it (the tiles above are stale S00 values that no product reads)
-        else blk_store_rowtile<D>(stab, p0, j - 4 * NT, D, pan + (size_t)(2 * D + 1) * D, 16 * (j - 4 * NT + 1));
-#else
         else if (j < 3 * NT) blk_lu_rowtile_to_panel<D>(p1, p0, j - 2 * NT, D + 1, pan, lane);
         else blk_lu_rowtile_to_panel<D>(p2, p0, j - 3 * NT, D, pan + (D + 1) * D, lane);
-#endif
       };
-      constexpr int NJOBS = TRAJ_LU_PANEL ? 5 * NT : 4 * NT;
       if (wave < NPW) {
         if (t < T) {
           if (wave == 0) {
@@ -783,11 +672,9 @@ traj_solve_blk_kernel(const TrajUtt *__restrict__ utts, int n, const double *__r
         if (defer) {                      // the pivot pair's share of the jobs
           pv2_wait(mid, (NDW + W1L) * t);
 #pragma unroll
-          for (int j = 0; j < NJOBS; ++j)
+          for (int j = 0; j < 4 * NT; ++j)
             if (blk_job_owner<NT, NPW, NDW>(j) < NPW && blk_job_owner<NT, NPW, NDW>(j) == wave) run_job(j);
         }
-        BLK_PROF_AT(9, 0);
-        BLK_PROF_AT(12, 64);
       } else {
         const int dw = wave - NPW;
         // mixtures of block rows t+1, t+2, t+3 (clamped), loaded before the products so that the stencil loads below
@@ -806,7 +693,6 @@ traj_solve_blk_kernel(const TrajUtt *__restrict__ utts, int n, const double *__r
             if (blk_job_owner<NT, NPW, NDW>(j) >= NPW && blk_job_owner<NT, NPW, NDW>(j) == wave) run_job(j);
         }
         BLK_PROF_AT(6, 64 * NPW);
-        BLK_PROF_AT(14, 64 * NPW + 64);
         // Block row a = t+2 of the stencil.  Every load is unconditional on a clamped address (a select on a loaded
         // value would make the wave wait for each load in turn); masks are applied when the operands are combined.
         // Issued between the row-group jobs and the panel jobs: early enough to be back in time, late enough that the
@@ -829,7 +715,7 @@ traj_solve_blk_kernel(const TrajUtt *__restrict__ utts, int n, const double *__r
         BLK_PROF_AT(10, 64 * NPW);
         if (defer) {
 #pragma unroll
-          for (int j = 2 * NT; j < NJOBS; ++j)
+          for (int j = 2 * NT; j < 4 * NT; ++j)
             if (blk_job_owner<NT, NPW, NDW>(j) >= NPW && blk_job_owner<NT, NPW, NDW>(j) == wave) run_job(j);
         }
         BLK_PROF_AT(11, 64 * NPW);
@@ -842,7 +728,6 @@ traj_solve_blk_kernel(const TrajUtt *__restrict__ utts, int n, const double *__r
         }
         rv = lv * ((g0 + 0.5 * g1) - w2 * g2);
         BLK_PROF_AT(7, 64 * NPW);
-        BLK_PROF_AT(13, 64 * NPW + 64);
       }
       __syncthreads();                    // end of phase 1: every read of p0, p1, p2 is done
       BLK_PROF(0);
