@@ -343,7 +343,7 @@ def bench_convert(args, world, rank):
     # on the pruned kernel).  `roofline.achieved` is, as defined, ALGORITHMIC flops (every mixture) per second;
     # `pruning.mfma_executed_frac` says how much of the dense MFMA work the kernel actually issued, and `dense` is the
     # same measurement with pruning off (what rounds 1-2 reported).
-    if args.prune is None or args.prune < 1e300:
+    if (args.prune is None or args.prune < 1e300) and args.cpu_seconds > 0:      # (not in profiling runs: see below)
         g.prune_stats(True)
         step()
         torch.cuda.synchronize()
@@ -396,10 +396,15 @@ def bench_convert(args, world, rank):
         # the host-pointer (PCIe-inclusive) rate of the same call, measured -- never the reported `value`
         Xh = np.asfortranarray(X.T)
         vc.fvconvert(g, Xh)                                  # warm the library's staging buffers
-        t0 = time.perf_counter()
-        for _ in range(3):
-            vc.fvconvert(g, Xh)
+        keep = []                                            # the results stay alive while the calls are timed: releasing a
+        t0 = time.perf_counter()                             # 320 MB array is the caller's cost (munmap: 11-12 ms on these
+        for _ in range(3):                                   # boxes, the kernel clears pages when they are freed), timed apart
+            keep.append(vc.fvconvert(g, Xh))
         dth = (time.perf_counter() - t0) / 3
+        t0 = time.perf_counter()
+        while keep:
+            keep.pop()
+        dfree = (time.perf_counter() - t0) / 3
         Yh = np.empty_like(Xh, order="F")
         vc.fvconvert(g, Xh, out=Yh)
         t0 = time.perf_counter()
@@ -408,10 +413,12 @@ def bench_convert(args, world, rank):
         dtr = (time.perf_counter() - t0) / 3
         out["host_inclusive"] = {"value": T / dth, "unit": "frames/s", "ms_per_call": dth * 1e3,
                                  "reused_output": {"value": T / dtr, "ms_per_call": dtr * 1e3},
+                                 "releasing_one_result_ms": dfree * 1e3,
                                  "note": "vcmi_gmmmap_convert on pageable host arrays (what a Julia ccall passes): chunked "
                                          "pinned staging, H2D / kernel / D2H of consecutive chunks overlapped; `value` "
                                          "allocates a fresh output per call like `similar(X)` (first-touch page faults "
-                                         "included), `reused_output` writes into an existing array",
+                                         "included; releasing the previous result is timed apart: it is the caller's munmap), "
+                                         "`reused_output` writes into an existing array",
                                  "parity_vs_device_path": bool(np.array_equal(Yh.T, Yd.cpu().numpy())),
                                  "host": host_facts()}
         # the honest strong CPU baseline -- the same arithmetic on every host core (OpenMP over frames)

@@ -510,7 +510,11 @@ int staged_pipeline(const void *hIn, size_t in_unit, size_t in_stride, void *hOu
     // (a strided output, vc's (D+1,T) matrix, keeps the rows it does not own).  Otherwise the faults are taken by the
     // scatter copies at the end of the pipeline, on its critical path -- where THP compaction stalls showed up as
     // 25-32 ms calls on some boxes against 14 ms on others.  Older kernels return EINVAL: nothing is lost.
-    if (span >= 4 * huge) {
+    static const bool populate = [] {
+      const char *e = getenv("VCMI_HOST_POPULATE");      // read once; "0" switches the pre-faulting off
+      return !(e && e[0] == '0');
+    }();
+    if (populate && span >= 4 * huge) {
       char *base = reinterpret_cast<char *>(hOut);
       constexpr size_t piece = (size_t)8 << 20;
       host_async_for((int64_t)((span + piece - 1) / piece), 1, [base, span](int64_t lo, int64_t hi) {
