@@ -474,10 +474,13 @@ def bench_estep(args, world, rank):
     def step_allreduce():
         vc.dist.allreduce_sum_(out_t)
 
-    _, kernel_ms = timed_steps(step_kernels, args.steps, 1, world)
-    _, allreduce_ms = timed_steps(step_allreduce, args.steps, 1, world)
-    vc.estep_diag_dev(Xd.t(), w, muT, varT, out=out_t)          # leave the statistics of ONE pass in out_t for the checks below
-    vc.dist.allreduce_sum_(out_t)
+    if args.cpu_seconds > 0 or world > 1:
+        _, kernel_ms = timed_steps(step_kernels, args.steps, 1, world)
+        _, allreduce_ms = timed_steps(step_allreduce, args.steps, 1, world)
+        vc.estep_diag_dev(Xd.t(), w, muT, varT, out=out_t)          # leave the statistics of ONE pass in out_t for the checks below
+        vc.dist.allreduce_sum_(out_t)
+    else:       # profiling run (--cpu-seconds 0, one rank): nothing but the warm-up and the timed steps may reach the trace
+        kernel_ms, allreduce_ms = step_ms, None
     PER_RANK.update(per_rank_step)
     fps = world * N * args.steps / wall
     mfma_path = Dj % 2 == 0 and Dj <= 160 and M <= 128           # estep.hip: estep_device
