@@ -97,6 +97,32 @@ def test_two_pass_predict_matches_in_kernel_argmax(vc):
     assert np.array_equal(one, two) and np.array_equal(one, co.GMMMap(w, mu, sig).predict(X))
 
 
+@pytest.mark.parametrize("D,M,T", [(40, 64, 5000), (80, 32, 3000), (24, 9, 700), (17, 3, 50), (16, 2, 16)])
+def test_predict_early_exit_is_exact(vc, D, M, T):
+    """predict(px, X) stops the whitening of a mixture as soon as its partial |z|^2 shows that it cannot be the first
+    maximum of any of a tile's 16 frames (MODE 3: the tiles run last first).  The indices must equal those of the kernel
+    that evaluates every tile of every mixture, and the oracle's -- also with exact ties (duplicated mixtures: the first
+    one wins) and with a mixture of weight zero."""
+    from oracle import c_oracle as co, np_oracle as npo
+    from voiceconversion_jl_amd import _lib
+    w, mu, sig = npo.synth_model(900 + D + M, 2 * D, M)
+    if M >= 3:                                     # mixtures 0 and M-1 identical: every frame of either ties exactly
+        mu[M - 1], sig[M - 1] = mu[0], sig[0]
+        w = w.copy(); w[M - 1] = w[0]; w[1] = 0.0; w /= w.sum()
+    X = npo.sample_frames(901, w, mu, sig, T, 0, D)
+    g = vc.GMMMap(*julia_model(w, mu, sig))
+    fast = vc.predict(g.px, X.T)
+    _lib.debug_force(_lib.DBG_PREDICT_NO_EARLY_EXIT)
+    try:
+        full = vc.predict(g.px, X.T)
+    finally:
+        _lib.debug_force(0)
+    ref = co.GMMMap(w, mu, sig).predict(X)
+    assert np.array_equal(fast, full) and np.array_equal(fast, ref)
+    if M >= 3:
+        assert not np.any(fast == M) and not np.any(fast == 2)      # the duplicate never wins, the zero weight neither
+
+
 def test_zero_weight_component_has_zero_posterior(vc):
     from oracle import c_oracle as co, np_oracle as npo
     w, mu, sig = npo.synth_model(5, 32, 6)

@@ -45,6 +45,20 @@ struct Tiling {
   __host__ __device__ static constexpr int steps(int t) {  // k-steps tile t needs
     return (16 * t + 15 < DP) ? ((4 * (t + 1) < KS) ? 4 * (t + 1) : KS) : KS;
   }
+  // MODE 3 (predict with early exit) stores the whitening tiles one after the other in REVERSE order (tile NU-1 first):
+  // rtile_off(i) = first fragment of the i-th tile in that order
+  __host__ __device__ static constexpr int tile_off(int t) {      // fragments before tile t in the k-step-major order of the U tiles
+    int n = 0;
+    for (int ks = 0; ks < KS; ++ks)
+      for (int u = 0; u < NU && u < NT; ++u)
+        if (ks < steps(u)) ++n;
+    return t >= NU ? n : 0;
+  }
+  __host__ __device__ static constexpr int rtile_off(int i) {
+    int n = 0;
+    for (int u = 0; u < i; ++u) n += steps(NU - 1 - u);
+    return n;
+  }
   __host__ __device__ static constexpr int nsteps() {
     int n = 0;
     for (int t = 0; t < NT; ++t) n += steps(t);
@@ -120,7 +134,10 @@ __device__ __forceinline__ double vc_exp(double x) {
 // per-mixture operand block, double-buffered in LDS.
 // MODE 0: convert (writes Y).  MODE 1: log-weighted densities l_m (writes LP (M,T)), no A tiles used.
 // MODE 2: predict -- the 1-based index of the first maximum of l_m over m (src/gmm.jl:44-47) written as int64 to Y[frame];
-// the (M,T) matrix never exists.
+// the (M,T) matrix never exists.  MODE 3: the same result from fragments stored tile by tile, last tile first, with an
+// EXACT early exit: |z|^2 only grows as tiles are added, so once lc - |z partial|^2 / 2 <= runmax on all 16 frames of a
+// frame tile, mixture m cannot be its first maximum and the remaining tiles are skipped.  The LAST rows of the Cholesky
+// whitening carry the small conditional variances, i.e. most of a wrong mixture's distance: they go first.
 // ------------------------------------------------------------------------------------------------
 template <int DP, int FT, int WAVES, int MODE, int NBUF>
 __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(DP <= 40 ? (FT == 2 ? 3 : 4) : 2)))
@@ -204,6 +221,53 @@ gmmmap_mfma_kernel(const double *__restrict__ packed, int M, int D, const double
     if (lc != -INFINITY) {   // zero-weight mixtures have posterior exactly 0 (wave-uniform branch)
       // ---------------- phase U: whitening tiles, z = U x - cz ----------------
       d4 acc[FT][NT];
+      double q[FT];
+      unsigned live = (1u << FT) - 1u;      // MODE 3: frame tiles of this wave that mixture m can still be the maximum of
+      if constexpr (MODE == 3) {
+        double qp[FT];
+#pragma unroll
+        for (int f = 0; f < FT; ++f) qp[f] = 0.0;
+#pragma unroll
+        for (int i = 0; i < NU; ++i) {
+          const int t = NU - 1 - i;
+          if (!live) break;
+          d4 c;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) c[r] = cur[TL::CINIT_OFF + 16 * t + 4 * r + lgrp];
+#pragma unroll
+          for (int f = 0; f < FT; ++f) acc[f][t] = c;
+#pragma unroll
+          for (int ks = 0; ks < TL::steps(t); ++ks) {
+            const double a = cur[(TL::rtile_off(i) + ks) * 64 + lane];
+#pragma unroll
+            for (int f = 0; f < FT; ++f)
+              if (live >> f & 1u) acc[f][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, xb[f][ks], acc[f][t], 0, 0, 0);
+          }
+#pragma unroll
+          for (int f = 0; f < FT; ++f) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (16 * t + 4 * r < DP) qp[f] = fma(acc[f][t][r], acc[f][t][r], qp[f]);
+          }
+          if (i + 1 < NU) {
+#pragma unroll
+            for (int f = 0; f < FT; ++f) {
+              if (!(live >> f & 1u)) continue;
+              double qq = qp[f];
+              qq += __shfl_xor(qq, 16);
+              qq += __shfl_xor(qq, 32);
+              if (__builtin_amdgcn_ballot_w64(lc - 0.5 * qq > runmax[f]) == 0) live &= ~(1u << f);
+            }
+          }
+        }
+#pragma unroll
+        for (int f = 0; f < FT; ++f) {
+          double qq = qp[f];
+          qq += __shfl_xor(qq, 16);
+          qq += __shfl_xor(qq, 32);
+          q[f] = qq;
+        }
+      } else {
 #pragma unroll
       for (int t = 0; t < NU; ++t) {
         d4 c;
@@ -225,7 +289,6 @@ gmmmap_mfma_kernel(const double *__restrict__ packed, int M, int D, const double
           }
         }
       }
-      double q[FT];
 #pragma unroll
       for (int f = 0; f < FT; ++f) {
         double qq = 0.0;
@@ -240,6 +303,7 @@ gmmmap_mfma_kernel(const double *__restrict__ packed, int M, int D, const double
         qq += __shfl_xor(qq, 32);
         q[f] = qq;
       }
+      }
 
       if (MODE == 1) {
         // log-weighted density of mixture m for the wave's frames; one lane group writes
@@ -247,9 +311,10 @@ gmmmap_mfma_kernel(const double *__restrict__ packed, int M, int D, const double
 #pragma unroll
           for (int f = 0; f < FT; ++f) lstage[((wave * FT + f) * 16 + lcol) * LROW + (m & 7)] = lc - 0.5 * q[f];
         }
-      } else if (MODE == 2) {
+      } else if (MODE == 2 || MODE == 3) {
 #pragma unroll
         for (int f = 0; f < FT; ++f) {
+          if (MODE == 3 && !(live >> f & 1u)) continue;     // l_m <= runmax on the whole tile: not its first maximum
           const double l = lc - 0.5 * q[f];
           if (l > runmax[f]) {          // strict: the first maximum wins, as in posterior_finish_kernel<1>
             runmax[f] = l;
@@ -268,7 +333,7 @@ gmmmap_mfma_kernel(const double *__restrict__ packed, int M, int D, const double
         if (MODE == 0) nreg_wave += __builtin_popcount(active & tiles_in_range);
         if (active) {
           // ---------------- phase A: regression tiles, E = A x + b (wave-uniform branches around an idle tile's MFMAs) ----------------
-          int sa = s;
+          int sa = TL::tile_off(NU);
 #pragma unroll
           for (int t = NU; t < NT; ++t) {
             d4 c;
@@ -359,7 +424,7 @@ gmmmap_mfma_kernel(const double *__restrict__ packed, int M, int D, const double
     __syncthreads();
   }
 
-  if (MODE == 2) {
+  if (MODE == 2 || MODE == 3) {
     if (lgrp == 0) {
 #pragma unroll
       for (int f = 0; f < FT; ++f) {
@@ -673,7 +738,7 @@ static int launch_mfma(const vcmi_gmmmap *g, const double *dX, int64_t ldx, int6
   }
   const int64_t per_wg = (int64_t)16 * FT * WAVES;
   const int64_t blocks = (T + per_wg - 1) / per_wg;
-  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(WAVES * 64), shmem, st, MODE >= 1 ? g->packedU.p : g->packed.p, g->M,
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(WAVES * 64), shmem, st, MODE == 3 ? g->packedU2.p : (MODE >= 1 ? g->packedU.p : g->packed.p), g->M,
                      g->D, dX, ldx, T, dY, ldy, g->prune, MODE == 0 ? g->prune_count.p : nullptr);
   VCMI_HIP(hipGetLastError());
   return VCMI_OK;
@@ -766,8 +831,12 @@ int gmmmap_posterior_device(vcmi_gmmmap *g, const double *dX, int64_t ldx, int64
 
 int gmmmap_predict_device(vcmi_gmmmap *g, const double *dX, int64_t ldx, int64_t T, int64_t *didx, hipStream_t st) {
   if (T == 0) return VCMI_OK;
-  if (use_mfma(g) && !debug_flag(kDbgPredictTwoPass))      // argmax inside the MFMA kernel: no (M,T) matrix, one launch
+  if (use_mfma(g) && !debug_flag(kDbgPredictTwoPass)) {    // argmax inside the MFMA kernel: no (M,T) matrix, one launch
+    // host-prepared handles carry the reversed, tile-by-tile fragments: predict with the exact early exit (MODE 3)
+    if (g->packedU2.p && !debug_flag(kDbgPredictNoEarlyExit))
+      return dispatch_mfma<3>(g, dX, ldx, T, reinterpret_cast<double *>(didx), 0, st);
     return dispatch_mfma<2>(g, dX, ldx, T, reinterpret_cast<double *>(didx), 0, st);
+  }
   VCMI_TRY(g->scratch_lp.reserve((size_t)T * g->M));
   VCMI_TRY(gmmmap_logdens_device(g, dX, ldx, T, g->scratch_lp.p, st));
   hipLaunchKernelGGL(posterior_finish_kernel<1>, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, st, g->scratch_lp.p,
@@ -884,7 +953,9 @@ static int prepare(vcmi_gmmmap *g, const double *w, const double *mu, const doub
   }
 
   // packed operand blocks for the MFMA kernel (issue order: phase U k-major over U tiles, then phase A)
-  for (int uonly = px_only ? 1 : 0; uonly < 2 && gmmmap_has_mfma(DP); ++uonly) {
+  // variant 0: [U ; A] (convert), 1: U only (log-densities, predict), 2: U only, tile by tile with the LAST tile first
+  // (predict with early exit, MODE 3)
+  for (int uonly = px_only ? 1 : 0; uonly < 3 && gmmmap_has_mfma(DP); ++uonly) {
     TilingRT tl(DP, uonly != 0);
     std::vector<double> pk((size_t)tl.BLK * M, 0.0);
     auto wrow = [&](int m, int p, int k) -> double {   // row p of [U_m ; A_m], column k
@@ -896,14 +967,22 @@ static int prepare(vcmi_gmmmap *g, const double *w, const double *mu, const doub
     for (int m = 0; m < M; ++m) {
       double *blk = &pk[(size_t)tl.BLK * m];
       int s = 0;
-      for (int phase = 0; phase < 2; ++phase) {
-        const int t0 = phase == 0 ? 0 : tl.NU, t1 = phase == 0 ? std::min(tl.NU, tl.NT) : tl.NT;
-        for (int ks = 0; ks < tl.KS; ++ks)
-          for (int t = t0; t < t1; ++t) {
-            if (ks >= tl.steps(t)) continue;
+      if (uonly == 2) {
+        for (int t = std::min(tl.NU, tl.NT) - 1; t >= 0; --t)
+          for (int ks = 0; ks < tl.steps(t); ++ks) {
             for (int l = 0; l < 64; ++l) blk[(size_t)s * 64 + l] = wrow(m, 16 * t + (l & 15), 4 * ks + (l >> 4));
             ++s;
           }
+      } else {
+        for (int phase = 0; phase < 2; ++phase) {
+          const int t0 = phase == 0 ? 0 : tl.NU, t1 = phase == 0 ? std::min(tl.NU, tl.NT) : tl.NT;
+          for (int ks = 0; ks < tl.KS; ++ks)
+            for (int t = t0; t < t1; ++t) {
+              if (ks >= tl.steps(t)) continue;
+              for (int l = 0; l < 64; ++l) blk[(size_t)s * 64 + l] = wrow(m, 16 * t + (l & 15), 4 * ks + (l >> 4));
+              ++s;
+            }
+        }
       }
       for (int p = 0; p < tl.NT * 16; ++p) {
         double c = 0.0;
@@ -913,7 +992,7 @@ static int prepare(vcmi_gmmmap *g, const double *w, const double *mu, const doub
       }
       blk[tl.LC_OFF] = hlc[m];
     }
-    DevBuf<double> &dst = uonly ? g->packedU : g->packed;
+    DevBuf<double> &dst = uonly == 2 ? g->packedU2 : (uonly ? g->packedU : g->packed);
     VCMI_TRY(dst.reserve(pk.size()));
     VCMI_HIP(hipMemcpy(dst.p, pk.data(), pk.size() * 8, hipMemcpyHostToDevice));
   }

@@ -22,6 +22,7 @@ struct vcmi_gmmmap {
   // device parameters, MFMA fragment order: [M][Tiling::BLK]
   vcmi::DevBuf<double> packed;    // [U_m ; A_m] tiles (convert)
   vcmi::DevBuf<double> packedU;   // U_m tiles only (log-density / posterior / argmax)
+  vcmi::DevBuf<double> packedU2;  // U_m tiles only, tile by tile, last tile first (predict with early exit; host-prepared handles)
 
   // issue-order table of the U-only tiling (slot -> tile << 16 | k-step) for the on-device packer (gmm_px_prepare_device)
   vcmi::DevBuf<int> px_table;

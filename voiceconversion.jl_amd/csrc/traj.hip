@@ -698,6 +698,10 @@ traj_gv_kernel(const TrajUtt *__restrict__ utts, int n, int D, int M, int KS, co
 // bounds the utterance length; longer utterances take traj_gv_kernel.
 // ------------------------------------------------------------------------------------------------
 static constexpr int kGv2NB = 4;     // 16-frame tiles per round
+#ifndef VCMI_GV2_GB
+#define VCMI_GV2_GB 12
+#endif
+static constexpr int kGv2GB = VCMI_GV2_GB;   // elements of u a gather thread has in flight
 static constexpr int kGv2Threads = 768;   // 12 waves: NT = ceil(2D/16) MFMA waves, the rest gather (three waves per SIMD: 168 VGPRs)
 
 __global__ void __launch_bounds__(kGv2Threads)
@@ -808,11 +812,11 @@ traj_gv2_kernel(const TrajUtt *__restrict__ utts, int n, int D, int M, int KS, i
     auto gather = [&](int r, double *Ub0) {
       const int tile0 = r * kGv2NB, total = 16 * kGv2NB * D2;
       int sl = gsl0, k = gk0;
-      for (int e = gtid; e < total; e += 8 * ngth) {
-        double ya[8], yc[8];
-        int tt[8], oo[8];
+      for (int e = gtid; e < total; e += kGv2GB * ngth) {
+        double ya[kGv2GB], yc[kGv2GB];
+        int tt[kGv2GB], oo[kGv2GB];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < kGv2GB; ++i) {
           const bool in = e + i * ngth < total;
           const int idx = tile0 * 16 + sl;
           const int t = (in && idx < ntiles * 16) ? perm[idx] : -1;
@@ -831,7 +835,7 @@ traj_gv2_kernel(const TrajUtt *__restrict__ utts, int n, int D, int M, int KS, i
           }
         }
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
+        for (int i = 0; i < kGv2GB; ++i)
           if (oo[i] >= 0) {
             const bool ok = tt[i] >= 0, st = (tt[i] & (1 << 30)) == 0;
             const int t = tt[i] & ~(1 << 30);
