@@ -88,8 +88,9 @@ int vcmi_gmmmap_posterior_dev(vcmi_gmmmap *g, const double *dX, int64_t ldx, int
 int vcmi_gmmmap_predict(vcmi_gmmmap *g, const double *X, int64_t ldx, int64_t T, int64_t *idx);
 int vcmi_gmmmap_predict_dev(vcmi_gmmmap *g, const double *dX, int64_t ldx, int64_t T, int64_t *didx, void *stream);
 /* Kernel selection: 0 = auto (MFMA tile kernel when dim(g), rounded up to a multiple of 4, is one of 16..80 in steps of
- * 4; posterior / predict for other dimensions up to 160: the tiled MFMA log-density kernel; else the generic
- * VALU kernel), 1 = force the generic VALU kernel, 2 = force the MFMA tile kernel (VCMI_ERR_ARG if unavailable). */
+ * 4; other dimensions up to 160: the tiled MFMA log-density kernel, followed for fvconvert by a softmax / regression
+ * kernel over the mixtures that matter; else the generic VALU kernel), 1 = force the generic VALU kernel, 2 = force the
+ * MFMA tile kernel (VCMI_ERR_ARG if unavailable). */
 int vcmi_gmmmap_set_kernel(vcmi_gmmmap *g, int which);
 /* Posterior pruning of fvconvert (src/gmmmap.jl:109-117 sums over ALL mixtures; this changes which terms are evaluated,
  * not the result): the regression A_m x + b_m of mixture m is skipped for a tile of 16 consecutive frames when

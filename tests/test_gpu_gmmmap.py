@@ -250,3 +250,30 @@ def test_posterior_pruning_changes_nothing_visible(vc, fixture_model):
         g.set_prune(20.0)
     with pytest.raises(vc.VCMIError):
         g.set_prune(float("nan"))
+
+
+@pytest.mark.parametrize("D,M,T", [(82, 5, 300), (96, 8, 1000), (100, 3, 77), (160, 4, 130), (130, 70, 65)])
+def test_fvconvert_beyond_the_tile_kernel(vc, D, M, T):
+    """80 < D <= 160 (e.g. the 82..96-dimensional static + delta vectors of 41..48 coefficients): MFMA log-densities
+    (logdens_tiled_kernel) + the softmax / regression kernel, against the oracle, against the one-lane-per-frame generic
+    kernel it replaces on the automatic path, and with the pruning off; also through the host-pointer pipeline and vc()."""
+    from oracle import c_oracle as co, np_oracle as npo
+    w, mu, sig = npo.synth_model(300 + D, 2 * D, M, lam_lo=1e-3)
+    if M >= 3:
+        w = w.copy(); w[1] = 0.0; w /= w.sum()
+    X = npo.sample_frames(301, w, mu, sig, T, 0, D)
+    g = vc.GMMMap(*julia_model(w, mu, sig))
+    ref = co.GMMMap(w, mu, sig).fvconvert(X)
+    Y = vc.fvconvert(g, X.T)
+    assert frame_relerr(Y, ref.T) < TOL
+    g.set_prune(float("inf"))
+    Yd = vc.fvconvert(g, X.T)
+    g.set_prune(46.0)
+    assert frame_relerr(Y, Yd) < 1e-14
+    g.set_kernel(1)
+    Yg = vc.fvconvert(g, X.T)
+    g.set_kernel(0)
+    assert frame_relerr(Yg, ref.T) < TOL and frame_relerr(Y, Yg) < 1e-9
+    fm = np.asfortranarray(np.vstack([np.arange(T, dtype=np.float64)[None], X.T]))
+    out = vc.vc(g, fm)
+    assert np.array_equal(out[0], fm[0]) and frame_relerr(out[1:], ref.T) < TOL

@@ -715,6 +715,63 @@ posterior_finish_kernel(double *__restrict__ LP, int M, int64_t T, int64_t *__re
 }
 
 // ------------------------------------------------------------------------------------------------
+// fvconvert for dimensions the MFMA tile kernel has no instantiation for (80 < padded D <= 160, e.g. the 82..96-dimensional
+// static + delta vectors of 41..48 coefficients): log-weighted densities by logdens_tiled_kernel (MFMA), then this kernel --
+// one wave per frame: softmax over the mixtures, and  y = sum_m p_m (A_m x + b_m)  over the mixtures whose posterior
+// reaches e^-prune (the same rule as the tile kernel's pruning; prune = +inf: all of them), in mixture order.  A_m is read
+// TRANSPOSED (At[m][k][d]: lanes along d are contiguous); x sits in LDS and is broadcast per k.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+convert_from_logdens_kernel(const double *__restrict__ LP, int M, int D, int DP, const double *__restrict__ At,
+                            const double *__restrict__ b, const double *__restrict__ X, int64_t ldx, int64_t T,
+                            double *__restrict__ Y, int64_t ldy, double prune) {
+  __shared__ double xs_all[4][160];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double *xs = xs_all[wave];
+  for (int64_t fr = (int64_t)blockIdx.x * 4 + wave; fr < T; fr += (int64_t)gridDim.x * 4) {
+    const double *l = LP + fr * M;
+    double u = -INFINITY;
+    for (int m = lane; m < M; m += 64) u = fmax(u, l[m]);
+#pragma unroll
+    for (int sh = 1; sh < 64; sh <<= 1) u = fmax(u, __shfl_xor(u, sh));
+    double sden = 0.0;
+    for (int m0 = 0; m0 < M; m0 += 64) {        // fixed order: lanes' terms of a 64-mixture group summed by a butterfly
+      double e = (m0 + lane < M) ? vc_exp(l[m0 + lane] - u) : 0.0;
+#pragma unroll
+      for (int sh = 1; sh < 64; sh <<= 1) e += __shfl_xor(e, sh);
+      sden += e;
+    }
+    for (int k = lane; k < D; k += 64) xs[k] = X[fr * ldx + k];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    double y0 = 0.0, y1 = 0.0, y2 = 0.0;
+    for (int m = 0; m < M; ++m) {
+      const double lm = l[m];                                   // wave-uniform (same address on every lane)
+      if (!(lm > u - prune)) continue;
+      const double p = vc_exp(lm - u) / sden;
+      const double *am = At + (size_t)m * DP * DP + lane;
+      double a0 = (lane < D) ? b[(size_t)m * DP + lane] : 0.0, a1 = (lane + 64 < D) ? b[(size_t)m * DP + lane + 64] : 0.0,
+             a2 = (lane + 128 < D) ? b[(size_t)m * DP + lane + 128] : 0.0;
+      for (int k = 0; k < D; ++k) {
+        const double xk = xs[k];
+        const double *row = am + (size_t)k * DP;
+        if (lane < DP) a0 = fma(row[0], xk, a0);
+        if (lane + 64 < DP) a1 = fma(row[64], xk, a1);
+        if (lane + 128 < DP) a2 = fma(row[128], xk, a2);
+      }
+      y0 = fma(p, a0, y0);
+      y1 = fma(p, a1, y1);
+      y2 = fma(p, a2, y2);
+    }
+    if (lane < D) Y[fr * ldy + lane] = y0;
+    if (lane + 64 < D) Y[fr * ldy + lane + 64] = y1;
+    if (lane + 128 < D) Y[fr * ldy + lane + 128] = y2;
+    __builtin_amdgcn_wave_barrier();                            // xs is rewritten for the wave's next frame
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // launch helpers
 // ------------------------------------------------------------------------------------------------
 template <int DP, int MODE, int FTV, int WV>
@@ -794,6 +851,21 @@ int gmmmap_convert_device(vcmi_gmmmap *g, const double *dX, int64_t ldx, int64_t
   if (g->kernel_choice == 2 && !gmmmap_has_mfma(g->DP))
     return fail(VCMI_ERR_ARG, "MFMA kernel forced but dimension %d has no instantiation", g->D);
   if (use_mfma(g)) return dispatch_mfma<0>(g, dX, ldx, T, dY, ldy, st);
+  if (g->kernel_choice != 1 && g->At.p && g->D > 16 && g->D <= 160) {
+    // no tile-kernel instantiation (80 < padded D <= 160, or a padded dimension outside its list): MFMA log-densities
+    // (logdens_tiled_kernel) + softmax / regression over the mixtures that matter, in chunks that bound the (T,M) scratch
+    const int64_t chunk = std::max<int64_t>(4096, ((int64_t)1 << 24) / std::max(g->M, 1));
+    for (int64_t t0 = 0; t0 < T; t0 += chunk) {
+      const int64_t n = std::min(chunk, T - t0);
+      VCMI_TRY(g->scratch_lp.reserve((size_t)std::min(chunk, T) * g->M));
+      VCMI_TRY(gmmmap_logdens_device(g, dX + t0 * ldx, ldx, n, g->scratch_lp.p, st));
+      const unsigned blocks = (unsigned)std::min<int64_t>((n + 3) / 4, 16384);
+      hipLaunchKernelGGL(convert_from_logdens_kernel, dim3(blocks), dim3(256), 0, st, g->scratch_lp.p, g->M, g->D, g->DP, g->At.p,
+                         g->b.p, dX + t0 * ldx, ldx, n, dY + t0 * ldy, ldy, g->prune);
+      VCMI_HIP(hipGetLastError());
+    }
+    return VCMI_OK;
+  }
   return launch_generic<0>(g, dX, ldx, T, dY, ldy, st);
 }
 
@@ -950,6 +1022,14 @@ static int prepare(vcmi_gmmmap *g, const double *w, const double *mu, const doub
     VCMI_TRY(g->b.reserve(hb.size()));
     VCMI_HIP(hipMemcpy(g->A.p, hA.data(), hA.size() * 8, hipMemcpyHostToDevice));
     VCMI_HIP(hipMemcpy(g->b.p, hb.data(), hb.size() * 8, hipMemcpyHostToDevice));
+    if (!gmmmap_has_mfma(DP) && D > 16 && D <= 160) {      // convert_from_logdens_kernel reads A transposed
+      std::vector<double> hAt(hA.size());
+      for (int m = 0; m < M; ++m)
+        for (int r = 0; r < DP; ++r)
+          for (int k = 0; k < DP; ++k) hAt[pp * m + (size_t)k * DP + r] = hA[pp * m + (size_t)r * DP + k];
+      VCMI_TRY(g->At.reserve(hAt.size()));
+      VCMI_HIP(hipMemcpy(g->At.p, hAt.data(), hAt.size() * 8, hipMemcpyHostToDevice));
+    }
   }
 
   // packed operand blocks for the MFMA kernel (issue order: phase U k-major over U tiles, then phase A)

@@ -19,6 +19,7 @@ struct vcmi_gmmmap {
 
   // device parameters, generic layout: [M][DP][DP] row-major / [M][DP] / [M]
   vcmi::DevBuf<double> U, A, cz, b, lc;
+  vcmi::DevBuf<double> At;        // A transposed, [M][DP (k)][DP (row)]: only for dimensions without a tile-kernel instantiation
   // device parameters, MFMA fragment order: [M][Tiling::BLK]
   vcmi::DevBuf<double> packed;    // [U_m ; A_m] tiles (convert)
   vcmi::DevBuf<double> packedU;   // U_m tiles only (log-density / posterior / argmax)
