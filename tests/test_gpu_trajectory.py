@@ -186,6 +186,15 @@ def test_more_utterances_than_compute_units(vc):
     for i in list(range(0, 700, 37)) + [699]:
         assert np.array_equal(vc.fvconvert(t, Xs[i]), Ys[i])
         assert relerr(Ys[i], ref.fvconvert(Xs[i].T)[0].T) < TOL
+    # 700 solves on 256 CUs: up to static D = 30 the launch holds TWO workgroups per CU (two scalar chains share its SIMDs);
+    # forced back to one per CU the results must not move by a bit
+    from voiceconversion_jl_amd import _lib
+    _lib.debug_force(_lib.DBG_TRAJ_ONE_WG_PER_CU)
+    try:
+        Y1 = t.fvconvert_batch(Xs)
+    finally:
+        _lib.debug_force(0)
+    assert all(np.array_equal(a, b) for a, b in zip(Ys, Y1))
 
 
 def test_repeated_runs_are_bit_identical(vc):

@@ -165,6 +165,7 @@ def get_devices():
 # Test hook (NOT part of include/vcmi.h): force the fallback kernels a shape would not select by itself.
 DBG_TRAJ_GENERIC, DBG_TRAJ_G_SCALAR, DBG_GV_ONE_TEAM, DBG_PREDICT_TWO_PASS, DBG_ESTEP_GENERIC, DBG_DTW_TWO_KERNELS = 1, 2, 4, 8, 16, 32
 DBG_PREDICT_NO_EARLY_EXIT = 64
+DBG_TRAJ_ONE_WG_PER_CU = 128
 
 
 def debug_force(flags):

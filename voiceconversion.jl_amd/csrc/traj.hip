@@ -1089,7 +1089,14 @@ static int traj_run(vcmi_traj *t, std::vector<TrajUtt> &utts, int64_t nframes, b
     const size_t shb = BlkCfg<DV>::lds_doubles * sizeof(double);                                                    \
     VCMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,  \
                                  (int)shb));                                                                        \
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlkThreads), shb, st, dus, n, Qs, t->mhat.p, gs, t->ws.p,             \
+    /* as many workgroups as the device holds at once: two per CU where LDS and registers allow (static D <= 30) */ \
+    int occ = 1;                                                                                                    \
+    if (debug_flag(kDbgTrajOneWgPerCu) ||                                                                           \
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, kBlkThreads, shb) != hipSuccess || occ < 1)        \
+      occ = 1;                                                                                                      \
+    const int grid_blk = (int)std::min<int64_t>(n, (int64_t)cus * occ);                                             \
+    VCMI_TRY(t->ws.reserve((size_t)grid_blk * std::max(ws_stride, ws_stride_s)));                                   \
+    hipLaunchKernelGGL(kern, dim3(grid_blk), dim3(kBlkThreads), shb, st, dus, n, Qs, t->mhat.p, gs, t->ws.p,         \
                        ws_stride_s, t->status.p);                                                                   \
     launched = true;                                                                                                \
   } break;

@@ -552,8 +552,12 @@ __device__ constexpr int blk_job_owner(int j) {
 
 static constexpr int kBlkThreads = 64 * (2 + TRAJ_DEFERRED_WAVES);
 
+// Two workgroups per CU where they fit (static D <= 25: 16-row tiles up to 32 rows -> <= 70 KB of LDS; the second launch
+// bound caps the registers at 256): two independent scalar chains then share a CU's SIMDs, and a batch of more utterances
+// (or vc() chunks) than CUs runs 1.5-1.6x faster (tools/traj_occupancy_probe.py).  At D = 30..40 the window alone is
+// 115 KB: one workgroup per CU.
 template <int D>
-__global__ void __launch_bounds__(kBlkThreads)
+__global__ void __launch_bounds__(kBlkThreads, (BlkCfg<D>::lds_doubles * 8 <= 80 * 1024) ? 2 : 1)
 traj_solve_blk_kernel(const TrajUtt *__restrict__ utts, int n, const double *__restrict__ Qall,
                       const int64_t *__restrict__ mhat_all, const double *__restrict__ g_all, double *__restrict__ ws_all,
                       int64_t ws_stride, int *__restrict__ status) {
