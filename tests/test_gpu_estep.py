@@ -40,12 +40,17 @@ def test_golden(vc, generic):
 @pytest.mark.parametrize("N,Dj,M", [(5000, 80, 128), (777, 80, 100), (1, 80, 3), (300, 48, 8), (3000, 48, 128), (2000, 64, 100),
                                     (1500, 32, 16), (600, 160, 24), (4000, 160, 128), (33, 160, 5), (1000, 6, 2), (70000, 10, 4),
                                     (900, 50, 7), (400, 100, 5), (300, 126, 3), (257, 78, 128), (500, 25, 4),
-                                    (3000, 80, 16), (3000, 80, 17), (2000, 80, 33), (2000, 80, 64), (1000, 160, 16), (999, 160, 40)])
+                                    (3000, 80, 16), (3000, 80, 17), (2000, 80, 33), (2000, 80, 64), (1000, 160, 16), (999, 160, 40),
+                                    # more than 128 mixtures: groups of 128 (responsibilities per group, combined per frame)
+                                    (3000, 80, 129), (4000, 80, 256), (2500, 32, 200), (1200, 160, 130), (900, 50, 300), (65, 48, 257),
+                                    # odd joint dimensions: one zero dimension more, then the even kernels (161: generic kernels)
+                                    (3000, 79, 128), (1000, 81, 200), (50, 159, 3), (700, 1, 2), (300, 161, 4)])
 def test_vs_oracle(vc, N, Dj, M, generic):
-    """Every even Dj <= 160 with M <= 128 runs the MFMA kernel (in the next larger of its instantiations 32, 48, 64, 80 and
-    -- as two kernels, the responsibilities through HBM -- 160, with zero weights in the padding dimensions); odd Dj
-    (and `generic`) the generic kernels."""
-    if generic and (Dj % 2 == 1 or N > 5000):
+    """Every Dj <= 160 runs the MFMA kernel: in the next larger of its instantiations 32, 48, 64, 80 and -- as two kernels,
+    the responsibilities through HBM -- 160, with zero weights in the padding dimensions; more than 128 mixtures in
+    groups of 128; an odd Dj with one zero dimension more.  `generic` forces the generic kernels (the only path beyond
+    Dj = 160)."""
+    if generic and N > 5000:
         pytest.skip("the generic kernels are the only path for this shape")
     from oracle import c_oracle as co, np_oracle as npo
     w, mu, _ = npo.synth_model(3000 + N, Dj, M)

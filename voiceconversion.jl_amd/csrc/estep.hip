@@ -106,6 +106,78 @@ estep_reduce_kernel(const double *__restrict__ part, int nrows, int64_t plen, do
   stats[e] = s;
 }
 
+// More than 128 mixtures (groups of 128, one PHASE 3 launch each): the responsibilities G_g[f][.] are normalised within
+// group g and lse_g[f] is the group's log-sum-exp.  Here, per frame: L = log sum_g e^(lse_g) (max-shifted, groups in
+// order), G_g[f][.] *= e^(lse_g - L), and the frame's L goes into a per-workgroup partial of the log-likelihood (summed
+// in fixed order by estep_sum_kernel).  One wave per frame; G is [group][n][128], lse [group][n].
+__global__ void __launch_bounds__(256)
+estep_group_combine_kernel(double *__restrict__ G, const double *__restrict__ lse, int ngroups, int64_t n, int64_t gstride,
+                           double *__restrict__ llpart) {
+  __shared__ double red[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double acc = 0.0;
+  for (int64_t f = (int64_t)blockIdx.x * 4 + wave; f < n; f += (int64_t)gridDim.x * 4) {
+    double u = -INFINITY;
+    for (int g = 0; g < ngroups; ++g) u = fmax(u, lse[(size_t)g * n + f]);
+    double s = 0.0;
+    for (int g = 0; g < ngroups; ++g) s += exp(lse[(size_t)g * n + f] - u);
+    const double L = u + log(s);
+    for (int g = 0; g < ngroups; ++g) {
+      const double sc = exp(lse[(size_t)g * n + f] - L);
+      double *row = G + (size_t)g * gstride + f * 128;
+      row[lane] *= sc;
+      row[lane + 64] *= sc;
+    }
+    acc += L;                                   // (every lane holds the same value)
+  }
+  if (lane == 0) red[wave] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) llpart[blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
+}
+
+// partial statistics of one mixture group (rows of plen_g = Mg (1 + 2 dj) + 1 doubles: [S0 | S1 (dj,Mg) | S2 (dj,Mg) | unused])
+// summed in row order and added into the full layout at mixture m0
+__global__ void __launch_bounds__(256)
+estep_group_reduce_kernel(const double *__restrict__ part, int nrows, int64_t plen_g, int Mg, int dj, int m0, int M,
+                          double *__restrict__ stats) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x, per = (int64_t)Mg * dj;
+  if (e >= plen_g - 1) return;
+  double s = 0.0;
+  for (int r = 0; r < nrows; ++r) s += part[(size_t)r * plen_g + e];
+  const int64_t dst = e < Mg ? m0 + e : e < Mg + per ? M + (int64_t)m0 * dj + (e - Mg) : M + (int64_t)M * dj + (int64_t)m0 * dj + (e - Mg - per);
+  stats[dst] += s;
+}
+
+__global__ void estep_sum_kernel(const double *__restrict__ v, int64_t n, double *__restrict__ out);
+
+// Odd joint dimension: the MFMA kernels stream X by 16-byte LDS-DMA rows, i.e. need an even row length.  The frames are
+// copied with one extra dimension that is identically 0 under a unit-variance, zero-mean parameter: it adds
+// (0 - 0)^2 / 1 = 0 to every distance and log 1 = 0 to every log-determinant -- the statistics of the real dimensions are
+// those of the unpadded problem; its own statistics are dropped again and the extra -log(2 pi)/2 per frame is added back.
+__global__ void __launch_bounds__(256)
+estep_pad_x_kernel(const double *__restrict__ X, int64_t n, int dj, double *__restrict__ Xp) {
+  const int djp = dj + 1;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n * djp; e += (int64_t)gridDim.x * 256) {
+    const int64_t f = e / djp;
+    const int d = (int)(e - f * djp);
+    Xp[e] = d < dj ? X[f * dj + d] : 0.0;
+  }
+}
+// stats_p ([S0 (M) | S1 (dj+1,M) | S2 (dj+1,M) | ll]) added into stats ([S0 | S1 (dj,M) | S2 (dj,M) | ll])
+__global__ void __launch_bounds__(256)
+estep_unpad_stats_kernel(const double *__restrict__ sp, int M, int dj, int64_t nframes, double *__restrict__ stats) {
+  const int djp = dj + 1;
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x, per = (int64_t)M * dj;
+  if (e < M) stats[e] += sp[e];
+  if (e < per) {
+    const int64_t m = e / dj, d = e - m * dj;
+    stats[M + e] += sp[M + m * djp + d];
+    stats[M + per + e] += sp[M + (int64_t)M * djp + m * djp + d];
+  }
+  // the padding dimension put one more -log(2 pi)/2 into every frame's log-density
+  if (e == 0) stats[M + 2 * per] += sp[M + 2 * (int64_t)M * djp] + (double)nframes * (0.5 * kLog2Pi);
+}
+
 // ------------------------------------------------------------------------------------------------
 // MFMA path, Dj a multiple of 16 (at Dj = 80: K = 160 = [x^2 | x], 40 k-steps; 10 statistic column tiles [x | x^2]).
 // Up to Dj = 80 one kernel; Dj = 160 as two (EstepCfg::SPLIT below).
@@ -136,7 +208,9 @@ struct EstepCfg {
 // Wpack: [mt (8)][ks (KS)][lane (64)] A-operand fragments of W = [-iv/2 | mu*iv] (rows = mixtures), zero rows for m >= M
 // cinit: [128] log-density constants c_m (-inf rows for m >= M so that their gamma is exactly 0)
 // PHASE 0: the whole E-step in one kernel.  PHASE 1 / 2 (EstepCfg::SPLIT): responsibilities -> G (frames x 128, row-major)
-// and the log-likelihood / statistics from G.
+// and the log-likelihood / statistics from G.  PHASE 3 (more than 128 mixtures: one launch per GROUP of 128): as PHASE 1,
+// normalised within the group, plus the group's log-sum-exp of every frame written to `part[frame]`; the groups are
+// combined by estep_group_combine_kernel and the statistics taken per group by PHASE 2.
 template <int DJ, int PHASE, bool SHARE>
 __global__ void __launch_bounds__(512)
 estep_mfma_kernel(const double *__restrict__ X, int64_t N, int M, const double *__restrict__ Wpack,
@@ -153,7 +227,7 @@ estep_mfma_kernel(const double *__restrict__ X, int64_t N, int M, const double *
   // that are never written out
   using C = EstepCfg<DJ>;
   constexpr int KS = C::KS, NDT = C::NDT, FB = C::FB, RSX = C::RSX, RSG = C::RSG, XBUF = C::XBUF;
-  constexpr bool kGamma = PHASE != 2, kStats = PHASE != 1;
+  constexpr bool kGamma = PHASE != 2, kStats = (PHASE == 0 || PHASE == 2);
   constexpr int kStepBUnroll = PHASE == 0 ? 4 : FB / 4;
   extern __shared__ double smem[];
   double *xbuf = smem;                     // [2][XBUF]: [FB][RSX] images
@@ -319,10 +393,13 @@ estep_mfma_kernel(const double *__restrict__ X, int64_t N, int M, const double *
 #pragma unroll
         for (int i = 0; i < C::MMAX / 16; ++i)
           if (!SHARE || i < mtp) row[16 * i] = v[i] * inv;
-        if (lcol == 0 && livef) llacc += u + log(s);
+        if (lcol == 0 && livef) {
+          if constexpr (PHASE == 3) part[f0 + f] = u + log(s);      // the group's log-sum-exp of this frame
+          else llacc += u + log(s);
+        }
       }
       __syncthreads();
-      if constexpr (PHASE == 1) {               // responsibilities -> G, rows of 128, coalesced
+      if constexpr (PHASE == 1 || PHASE == 3) {  // responsibilities -> G, rows of 128, coalesced
 #pragma unroll
         for (int i = 0; i < FB * C::MMAX / 512; ++i) {
           const int e = tid + 512 * i, f = e / C::MMAX, m = e - f * C::MMAX;
@@ -390,7 +467,7 @@ estep_mfma_kernel(const double *__restrict__ X, int64_t N, int M, const double *
       }
     }
   }
-  if constexpr (kGamma) {   // log-likelihood: fixed-order reduction inside the workgroup (thread 0: tile 0, sub 0)
+  if constexpr (kGamma && PHASE != 3) {   // log-likelihood: fixed-order reduction inside the workgroup (thread 0: tile 0, sub 0)
     red[tid] = llacc;
     __syncthreads();
     if (tid == 0) {
@@ -436,7 +513,7 @@ struct EstepStaging {
 };
 
 struct EstepScratch {
-  DevBuf<double> mu, iv, cst, G, LSE, part, Wpack, cinit, X, stats, raw, refiv, refc;
+  DevBuf<double> mu, iv, cst, G, LSE, part, Wpack, cinit, X, stats, raw, refiv, refc, Xpad, statsp;
   EstepStaging stage;
   StreamOrder order;   // calls of one thread on different streams share the buffers above
 };
@@ -561,6 +638,82 @@ static int estep_mfma_launch(EstepScratch &sc, const double *dX, int64_t N, int 
   return VCMI_OK;
 }
 
+// More than 128 mixtures: groups of 128, each with its own operand blocks.  Per chunk of frames: PHASE 3 per group
+// (responsibilities within the group -> G_g, the group's log-sum-exp per frame), estep_group_combine_kernel (frame-wise
+// log-sum-exp over the groups, rescaling of G, log-likelihood), PHASE 2 per group (statistics from G_g, partials reduced
+// in fixed order into the full layout).  Competing mixtures are re-evaluated exactly within a group (the kernel's
+// refinement); a pair that competes ACROSS two groups keeps the GEMM form's ~1e-7 absolute error in l.
+template <int DJ>
+static int estep_mfma_groups_launch(EstepScratch &sc, const double *dX, int64_t N, int dj, int M, const double *w, const double *mu,
+                                    const double *var, double *dstats, int64_t plen, hipStream_t st) {
+  using C = EstepCfg<DJ>;
+  int dev = 0, cus = 256;
+  (void)hipGetDevice(&dev);
+  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  const int ng = (M + C::MMAX - 1) / C::MMAX;
+  const int64_t chunk = std::min<int64_t>(N, (int64_t)1 << 18);
+  const size_t nraw = (size_t)M * (1 + 2 * dj), wlen = (size_t)8 * C::KS * 64;
+  constexpr int kCombineGrid = 1024;
+  VCMI_TRY(sc.raw.reserve(2 * nraw));
+  VCMI_TRY(sc.Wpack.reserve(wlen * ng));
+  VCMI_TRY(sc.cinit.reserve((size_t)C::MMAX * ng));
+  VCMI_TRY(sc.refiv.reserve((size_t)M * dj));
+  VCMI_TRY(sc.refc.reserve((size_t)M));
+  VCMI_TRY(sc.G.reserve((size_t)ng * chunk * C::MMAX));
+  VCMI_TRY(sc.LSE.reserve((size_t)ng * chunk + kCombineGrid));
+  VCMI_TRY(sc.part.reserve((size_t)cus * ((size_t)C::MMAX * (1 + 2 * dj) + 1)));
+  VCMI_TRY(sc.stage.reserve(nraw));
+  const int b = sc.stage.next;
+  sc.stage.next ^= 1;
+  VCMI_HIP(hipEventSynchronize(sc.stage.copied[b]));
+  double *h = sc.stage.host[b], *draw = sc.raw.p + (size_t)b * nraw;
+  std::vector<size_t> goff((size_t)ng + 1, 0);
+  for (int g = 0; g < ng; ++g) {      // every group's [w | mu (dj,Mg) | var (dj,Mg)] contiguous
+    const int m0 = g * C::MMAX, Mg = std::min(C::MMAX, M - m0);
+    double *hg = h + goff[(size_t)g];
+    memcpy(hg, w + m0, sizeof(double) * Mg);
+    memcpy(hg + Mg, mu + (size_t)dj * m0, sizeof(double) * Mg * dj);
+    memcpy(hg + Mg + (size_t)Mg * dj, var + (size_t)dj * m0, sizeof(double) * Mg * dj);
+    goff[(size_t)g + 1] = goff[(size_t)g] + (size_t)Mg * (1 + 2 * dj);
+  }
+  VCMI_HIP(hipMemcpyAsync(draw, h, nraw * sizeof(double), hipMemcpyHostToDevice, st));
+  VCMI_HIP(hipEventRecord(sc.stage.copied[b], st));
+  for (int g = 0; g < ng; ++g) {
+    const int m0 = g * C::MMAX, Mg = std::min(C::MMAX, M - m0);
+    hipLaunchKernelGGL(estep_prep_kernel<DJ>, dim3((unsigned)((wlen + 255) / 256)), dim3(256), 0, st, draw + goff[(size_t)g], Mg, dj,
+                       sc.Wpack.p + wlen * g, sc.cinit.p + (size_t)C::MMAX * g, sc.refiv.p + (size_t)m0 * dj, sc.refc.p + m0);
+  }
+  VCMI_HIP(hipGetLastError());
+  auto k3 = estep_mfma_kernel<DJ, 3, false>;
+  auto k2 = estep_mfma_kernel<DJ, 2, false>;
+  VCMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k3), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES));
+  VCMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES));
+  double *llpart = sc.LSE.p + (size_t)ng * chunk;
+  for (int64_t n0 = 0; n0 < N; n0 += chunk) {
+    const int64_t nfr = std::min<int64_t>(chunk, N - n0);
+    const int g2 = (int)std::min<int64_t>((nfr + C::FB - 1) / C::FB, cus);
+    for (int g = 0; g < ng; ++g) {
+      const int m0 = g * C::MMAX, Mg = std::min(C::MMAX, M - m0);
+      hipLaunchKernelGGL(k3, dim3(g2), dim3(512), C::LDS_BYTES, st, dX + n0 * dj, nfr, Mg, sc.Wpack.p + wlen * g,
+                         sc.cinit.p + (size_t)C::MMAX * g, sc.LSE.p + (size_t)g * nfr, (int64_t)0, draw + goff[(size_t)g] + Mg,
+                         sc.refiv.p + (size_t)m0 * dj, sc.refc.p + m0, sc.G.p + (size_t)g * chunk * C::MMAX, dj, 8);
+    }
+    hipLaunchKernelGGL(estep_group_combine_kernel, dim3(kCombineGrid), dim3(256), 0, st, sc.G.p, sc.LSE.p, ng, nfr,
+                       (int64_t)chunk * C::MMAX, llpart);
+    hipLaunchKernelGGL(estep_sum_kernel, dim3(1), dim3(256), 0, st, llpart, (int64_t)kCombineGrid, dstats + (plen - 1));
+    for (int g = 0; g < ng; ++g) {
+      const int m0 = g * C::MMAX, Mg = std::min(C::MMAX, M - m0);
+      const int64_t plen_g = (int64_t)Mg * (1 + 2 * dj) + 1;
+      hipLaunchKernelGGL(k2, dim3(g2), dim3(512), C::LDS_BYTES, st, dX + n0 * dj, nfr, Mg, sc.Wpack.p, sc.cinit.p, sc.part.p, plen_g,
+                         draw, sc.refiv.p, sc.refc.p, sc.G.p + (size_t)g * chunk * C::MMAX, dj, 8);
+      hipLaunchKernelGGL(estep_group_reduce_kernel, dim3((unsigned)((plen_g + 255) / 256)), dim3(256), 0, st, sc.part.p, g2, plen_g, Mg,
+                         dj, m0, M, dstats);
+    }
+    VCMI_HIP(hipGetLastError());
+  }
+  return VCMI_OK;
+}
+
 static int estep_device_run(const double *dX, int64_t N, int Dj, int M, const double *w, const double *mu, const double *var,
                             double *dstats, hipStream_t st);
 
@@ -588,6 +741,37 @@ static int estep_device_run(const double *dX, int64_t N, int Dj, int M, const do
 
   // MFMA instantiations for Dj = 32, 48, 64, 80 (one kernel) and 160 (two kernels); any even Dj up to 160 runs in the next
   // larger one with zero weights in the padding dimensions; odd Dj, Dj > 160 and M > 128 take the generic kernels below.
+  if (Dj % 2 == 1 && Dj + 1 <= 160 && !debug_flag(kDbgEstepGeneric)) {
+    // odd joint dimension: one zero dimension more (see estep_pad_x_kernel), in chunks that bound the padded copy
+    const int djp = Dj + 1;
+    const int64_t plen_p = (int64_t)M * (1 + 2 * djp) + 1, chunk = std::min<int64_t>(N, (int64_t)1 << 20);
+    std::vector<double> mup((size_t)M * djp, 0.0), varp((size_t)M * djp, 1.0);
+    for (int m = 0; m < M; ++m)
+      for (int d = 0; d < Dj; ++d) {
+        mup[(size_t)m * djp + d] = mu[d + (size_t)Dj * m];
+        varp[(size_t)m * djp + d] = var[d + (size_t)Dj * m];
+      }
+    VCMI_TRY(sc.Xpad.reserve((size_t)chunk * djp));
+    VCMI_TRY(sc.statsp.reserve((size_t)plen_p));
+    for (int64_t n0 = 0; n0 < N; n0 += chunk) {
+      const int64_t nfr = std::min(chunk, N - n0);
+      hipLaunchKernelGGL(estep_pad_x_kernel, dim3((unsigned)std::min<int64_t>((nfr * djp + 255) / 256, 65536)), dim3(256), 0, st,
+                         dX + n0 * Dj, nfr, Dj, sc.Xpad.p);
+      VCMI_TRY(estep_device_run(sc.Xpad.p, nfr, djp, M, w, mup.data(), varp.data(), sc.statsp.p, st));     // (zeroes statsp first)
+      hipLaunchKernelGGL(estep_unpad_stats_kernel, dim3((unsigned)(((int64_t)M * Dj + 255) / 256)), dim3(256), 0, st, sc.statsp.p, M, Dj,
+                         nfr, dstats);
+      VCMI_HIP(hipGetLastError());
+    }
+    // (mup / varp are staged into pinned memory by the inner call before it returns)
+    return VCMI_OK;
+  }
+  if (M > EstepCfg<80>::MMAX && Dj % 2 == 0 && Dj <= 160 && !debug_flag(kDbgEstepGeneric)) {      // groups of 128 mixtures
+    if (Dj <= 32) return estep_mfma_groups_launch<32>(sc, dX, N, Dj, M, w, mu, var, dstats, plen, st);
+    if (Dj <= 48) return estep_mfma_groups_launch<48>(sc, dX, N, Dj, M, w, mu, var, dstats, plen, st);
+    if (Dj <= 64) return estep_mfma_groups_launch<64>(sc, dX, N, Dj, M, w, mu, var, dstats, plen, st);
+    if (Dj <= 80) return estep_mfma_groups_launch<80>(sc, dX, N, Dj, M, w, mu, var, dstats, plen, st);
+    return estep_mfma_groups_launch<160>(sc, dX, N, Dj, M, w, mu, var, dstats, plen, st);
+  }
   if (M <= EstepCfg<80>::MMAX && Dj % 2 == 0 && Dj <= 160 && !debug_flag(kDbgEstepGeneric)) {
     // the smallest instantiation that holds Dj (an even Dj keeps the rows of X 16-byte aligned for the LDS-DMA)
     if (Dj <= 32) return estep_mfma_launch<32>(sc, dX, N, Dj, M, w, mu, var, dstats, plen, st);
