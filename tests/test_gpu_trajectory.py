@@ -70,7 +70,7 @@ def test_vs_oracle_batch(vc, D, M, Ts):
     assert np.array_equal(y0, Ys[0])                                 # batch == single, bit for bit
 
 
-@pytest.mark.parametrize("D", [13, 35])
+@pytest.mark.parametrize("D", [13, 35, 41, 46])
 def test_padded_blocked_solver_against_the_runtime_dimension_kernel(vc, D):
     """A static dimension without an instantiation of the blocked solver: solved in the next larger one with the extra
     dimensions decoupled (unit diagonal, zero right-hand side) -- the same trajectories as the runtime-D kernel."""

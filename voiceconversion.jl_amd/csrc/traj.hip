@@ -989,13 +989,14 @@ traj_unpad_y_kernel(const TrajUtt *__restrict__ utts, const double *__restrict__
 // the blocked solver's instantiations (traj_run) and the one a static dimension without its own runs in (0: none)
 static bool traj_blk_has(int D) {
   switch (D) {
-    case 12: case 16: case 20: case 24: case 25: case 30: case 32: case 40: return true;
+    case 12: case 16: case 20: case 24: case 25: case 30: case 32: case 40: case 46: return true;
     default: return false;
   }
 }
 static int traj_blk_padded_dim(int D) {
-  if (traj_blk_has(D) || D > 40) return 0;
-  for (int d = D + 1; d <= 40; ++d)
+  if (traj_blk_has(D) || D > 46) return 0;      // (46: the largest static dimension whose window -- 47 rows in three 16-row
+                                                // tiles -- fits the LDS; D = 47 would put the rhs row into a fourth tile)
+  for (int d = D + 1; d <= 46; ++d)
     if (traj_blk_has(d)) return d;
   return 0;
 }
@@ -1101,7 +1102,7 @@ static int traj_run(vcmi_traj *t, std::vector<TrajUtt> &utts, int64_t nframes, b
     launched = true;                                                                                                \
   } break;
       VCMI_TRAJ_BLK_CASE(12) VCMI_TRAJ_BLK_CASE(16) VCMI_TRAJ_BLK_CASE(20) VCMI_TRAJ_BLK_CASE(24) VCMI_TRAJ_BLK_CASE(25)
-      VCMI_TRAJ_BLK_CASE(30) VCMI_TRAJ_BLK_CASE(32) VCMI_TRAJ_BLK_CASE(40)
+      VCMI_TRAJ_BLK_CASE(30) VCMI_TRAJ_BLK_CASE(32) VCMI_TRAJ_BLK_CASE(40) VCMI_TRAJ_BLK_CASE(46)
 #undef VCMI_TRAJ_BLK_CASE
       default: break;
     }
