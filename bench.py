@@ -271,20 +271,34 @@ PER_RANK = {}
 
 
 def timed_steps(step_fn, steps, warmup, world):
-    """W untimed warmups, then exactly K steps between barrier+sync; also per-step HIP-event durations."""
+    """W untimed warmups, then exactly K steps between barrier+sync; also per-step HIP-event durations.
+
+    The Python garbage collector is off inside the timed region (as `timeit` does): with torch imported a full collection
+    pauses the interpreter for ~40 ms (measured on a busy host with tools/dtw_host_probe.py: the pause sat in the argument
+    marshalling of one call, outside the library), which is the whole timed region of a 20 x 1.7 ms workload -- the GPU
+    runs dry while the host stands still."""
+    import gc
+
     import torch
 
     for _ in range(warmup):
         step_fn()
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
-    barrier_sync(world)
-    t0 = time.perf_counter()
-    for a, b in evs:
-        a.record()
-        step_fn()
-        b.record()
-    barrier_sync(world)
-    t1 = time.perf_counter()
+    gc.collect()
+    gc_was_on = gc.isenabled()
+    gc.disable()
+    try:
+        barrier_sync(world)
+        t0 = time.perf_counter()
+        for a, b in evs:
+            a.record()
+            step_fn()
+            b.record()
+        barrier_sync(world)
+        t1 = time.perf_counter()
+    finally:
+        if gc_was_on:
+            gc.enable()
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
     PER_RANK["wall_s"] = gather_over_ranks(t1 - t0, world)
     PER_RANK["kernel_ms"] = gather_over_ranks(kernel_ms, world)
@@ -681,7 +695,7 @@ def bench_dtw(args, world, rank):
                       f"DTW fit!+backward, path-only, D={D}" + (" (order-40 mel-cepstra with c0: bin/mcep.jl:12, src/align.jl:45)" if D == 41 else ""),
                       "D": D, "pairs_per_gpu": n,
                       "fstep": 0, "bstep": 2},
-           "roofline": {"bound": "valu", "kernel": ("dtw_fused_kernel<%d,2> (+ dtw_fused_finish_kernel)" % (-(-D // 8) * 8)) if D <= 48 else
+           "roofline": {"bound": "valu", "kernel": ("dtw_fused_%skernel<%d,2> (+ dtw_fused_finish_kernel)" % ("persistent_" if D <= 41 and n > 512 else "", 41 if D == 41 else -(-D // 8) * 8)) if D <= 48 else
                         "dtw_obs_asm_kernel + dtw_rec_kernel (D > 48: observation matrix through HBM)",
                         "achieved": achieved, "peak": FP64_PEAK_TFLOPS / 2, "unit": "TFLOP/s",
                         "frac": achieved / (FP64_PEAK_TFLOPS / 2),
@@ -914,6 +928,8 @@ def main():
     ap.add_argument("--mixtures", type=int, default=128, help="estep: number of mixtures (128 = BASELINE configs[2])")
     ap.add_argument("--dj", type=int, default=80, help="estep: joint feature dimension (80 = BASELINE; 32, 48, 64 and 160 also run the MFMA kernel; others the generic kernels)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU time budget of the cpu_baseline sample")
+    ap.add_argument("--debug-force", type=int, default=0, help="A/B experiments: bit mask for the library's vcmi_debug_force test hook "
+                    "(csrc/vcmi_common.hpp kDbg*: alternative launch strategies); the line is then marked `debug_force`")
     ap.add_argument("--verify-allreduce", action="store_true",
                     help="estep: rank 0 recomputes the statistics of every rank's frames in one process and compares")
     args = ap.parse_args()
@@ -932,6 +948,10 @@ def main():
             LIVE_PMC["convert"] = t
 
     world, rank, _ = dist_setup(args.gpus)
+    if args.debug_force:
+        from voiceconversion_jl_amd import _lib
+
+        _lib.debug_force(args.debug_force)
     if world > 1:
         args.cpu_seconds = 0.0        # the CPU baseline is timed at N = 1 only (rank 0 keeps its small parity sample)
         args.cpu_seconds_sub = 0.0
@@ -986,6 +1006,8 @@ def main():
     out["per_rank"] = dict(PER_RANK)
     out["collective_backend"] = BACKEND["name"]
     out["library_source_hash"] = source_hash()
+    if args.debug_force:
+        out["debug_force"] = args.debug_force      # not a product configuration
     if rank == 0:
         print(json.dumps(out), flush=True)
     import torch.distributed as dist

@@ -201,3 +201,71 @@ def test_long_sequence_falls_back_to_two_kernels(vc, S, T):
     assert np.array_equal(vc.fit_batch(d, [t.T, t[:40].T], [s.T, s[:100].T])[0], ref)
     src, newtgt = vc.align(t.T, s.T)
     assert np.array_equal(newtgt, co.align(t, s)[0].T)
+
+
+@pytest.mark.parametrize("D", [16, 41])
+def test_column_segments_and_persistent_workgroups(vc, D):
+    """More jobs than the device has slots and sequences long enough: every strip's columns are cut into segments (a segment
+    starts from the last cost column of its predecessor; upper strips take each segment's boundary costs from the strip
+    below) and persistent workgroups draw the jobs from a ticket counter.  Bit-exact against the oracle, against
+    whole-length jobs and against one workgroup per job in grid order; templates of one, two, three and four strips
+    (packed one-wave and wide bottom strips), T not a multiple of 16, exact ties."""
+    from oracle import c_oracle as co
+    from voiceconversion_jl_amd import _lib
+    rng = np.random.default_rng(4242 + D)
+    shapes = [(int(rng.integers(100, 500)), int(rng.integers(130, 330))) for _ in range(560)]
+    shapes += [(int(rng.integers(513, 640)), int(rng.integers(130, 300))) for _ in range(30)]      # packed bottom + upper
+    shapes += [(int(rng.integers(700, 1000)), int(rng.integers(130, 260))) for _ in range(10)]     # wide bottom + upper
+    shapes += [(1100, 143), (1537, 131)]                                                           # three / four strips
+    pairs = []
+    for k, (S, T) in enumerate(shapes):
+        t, s = _warped_pair(rng, S, T, D)
+        if k % 3 == 0:
+            t, s = np.round(t * 2) / 2, np.round(s * 2) / 2
+        pairs.append((t, s))
+    d = vc.DTW(fstep=0, bstep=2)
+    tl, sl = [t.T for t, _ in pairs], [s.T for _, s in pairs]
+    paths = vc.fit_batch(d, tl, sl)
+    for flag in (_lib.DBG_DTW_NO_SEGMENTS, _lib.DBG_DTW_GRID_ORDER, _lib.DBG_DTW_NO_SEGMENTS | _lib.DBG_DTW_GRID_ORDER):
+        _lib.debug_force(flag)
+        try:
+            other = vc.fit_batch(d, tl, sl)
+        finally:
+            _lib.debug_force(0)
+        assert all(np.array_equal(a, b) for a, b in zip(paths, other)), flag
+    for i in list(range(0, len(pairs), 29)) + list(range(560, len(pairs))):
+        t, s = pairs[i]
+        assert np.array_equal(paths[i], co.dtw_fit(t, s, 0, 2, tables=False)), (i, shapes[i])
+    outs = vc.align_batch(tl[550:], sl[550:])
+    for (t, s), (src, newtgt) in zip(pairs[550:], outs):
+        assert np.array_equal(newtgt, co.align(t, s)[0].T)
+
+
+@pytest.mark.gpu
+def test_segmented_jobs_at_benchmark_size_repeatedly(vc):
+    """The jobs of the fused kernel hand boundary pairs and last cost columns to each other through agent-scope (sc1) stores
+    and loads, ordered by hand, instead of acquire / release fences (csrc/dtw.hip, dtw_wait_flag): a race there would be a
+    rare event, so the benchmark batch (1000 pairs of ~500 x 500 frames: 5465 jobs drawn by 512 persistent workgroups on all
+    eight XCDs) runs several times, segmented and whole-length, and every path must come out the same each time; a sample
+    is checked against the oracle."""
+    from oracle import c_oracle as co
+    from voiceconversion_jl_amd import _lib
+    rng = np.random.default_rng(77)
+    pairs = []
+    for _ in range(1000):
+        S, T = int(rng.integers(450, 551)), int(rng.integers(450, 551))
+        pairs.append(_warped_pair(rng, S, T, 40))
+    d = vc.DTW(fstep=0, bstep=2)
+    tl, sl = [t.T for t, _ in pairs], [s.T for _, s in pairs]
+    _lib.debug_force(_lib.DBG_DTW_NO_SEGMENTS | _lib.DBG_DTW_GRID_ORDER)
+    try:
+        whole = vc.fit_batch(d, tl, sl)
+    finally:
+        _lib.debug_force(0)
+    for rep in range(6):
+        seg = vc.fit_batch(d, tl, sl)
+        bad = [i for i, (a, b) in enumerate(zip(whole, seg)) if not np.array_equal(a, b)]
+        assert not bad, (rep, bad[:10])
+    for i in range(0, 1000, 97):
+        t, s = pairs[i]
+        assert np.array_equal(whole[i], co.dtw_fit(t, s, 0, 2, tables=False)), i

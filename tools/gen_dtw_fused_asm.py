@@ -225,7 +225,9 @@ def rec_block(steps, role, nomail):
               "s_mov_b64 exec, s[96:97]",
               "s_cmp_lt_i32 %[explane], 0", "s_cbranch_scc1 50f",
               "s_lshl_b64 s[98:99], 1, %[explane]", "s_mov_b64 exec, s[98:99]",
-              f"global_store_dwordx4 %[gout], v[{C0}:{C0 + 3}], off", "s_mov_b64 exec, s[96:97]",
+              # sc1: written through to the agent-wide coherence point -- the strip above may run on another XCD, whose L2 is not
+              # coherent with this one; its loads carry sc1 too, and no job needs an L2-wide write-back / invalidate
+              f"global_store_dwordx4 %[gout], v[{C0}:{C0 + 3}], off sc1", "s_mov_b64 exec, s[96:97]",
               "v_lshl_add_u64 %[gout], %[gout], 0, 16",
               "50:"]
     return L
@@ -342,8 +344,7 @@ def fused_loop3(d, stride, steps, role):
 
 
 def body_fused3(d, stride, steps):
-    """dtw_fused_kernel for 40 < d <= 48; operands as body_fused except %[g0] (v32, the lane's first row in the pair) in
-    place of %[c0] %[c1] %[p0] %[p1].  stride = register pairs per template row: rows of
+    """dtw_fused_kernel for 40 < d <= 48; operands as body_fused without %[c0] %[c1] %[p0] %[p1] (read from LDS).  stride = register pairs per template row: rows of
     d = 41 doubles are read as they lie in memory (no padded copy: 20 x 16 bytes + 8 bytes per row, column stride 328
     bytes for the scalar loads), d = 48 is the padded kernel of D = 42..48."""
     set_layout(4 * stride, (16, 48))
@@ -351,19 +352,10 @@ def body_fused3(d, stride, steps):
     L = ["s_mov_b64 s[96:97], exec"]
     L += template_loads_exact(d, stride, 2)
     L += sloads("A", 0, c[0])
-    # The initial costs are formed here from the lane's first row %[g0] (v32) instead of arriving as four 64-bit operands:
-    # with 192 template registers every operand VGPR counts (256 = two waves per SIMD).  lazy_init! (src/dtw.jl:49):
-    # C0 = g0+1, C1 = g0+2; neighbours of column 1: P1 = g0 (row g0-1) if g0 >= 1, P0 = g0-1 (row g0-2) if g0 >= 2, else +inf
-    t0, t1 = T[0], T[0] + 1
-    L += [f"v_add_u32 v{t0}, 1, %[g0]", f"v_cvt_f64_u32 {vp(C0)}, v{t0}",
-          f"v_add_u32 v{t0}, 2, %[g0]", f"v_cvt_f64_u32 {vp(C1)}, v{t0}",
-          f"v_cvt_f64_u32 {vp(P1)}, %[g0]",
-          f"v_add_u32 v{t0}, -1, %[g0]", f"v_cvt_f64_u32 {vp(P0)}, v{t0}",
-          f"v_mov_b32 v{t0}, 0", f"v_mov_b32 v{t1}, 0x7ff00000",
-          "v_cmp_gt_u32 vcc, 1, %[g0]",
-          f"v_cndmask_b32 v{P1}, v{P1}, v{t0}, vcc", f"v_cndmask_b32 v{P1 + 1}, v{P1 + 1}, v{t1}, vcc",
-          "v_cmp_gt_u32 vcc, 2, %[g0]",
-          f"v_cndmask_b32 v{P0}, v{P0}, v{t0}, vcc", f"v_cndmask_b32 v{P0 + 1}, v{P0 + 1}, v{t1}, vcc"]
+    # The initial costs come from LDS -- (C0, C1) at %[clast], (P0, P1) 512 doubles behind, left there by the C++
+    # prologue -- instead of four 64-bit operands: with 192 template registers every operand VGPR counts (256 = two
+    # waves per SIMD).  (A lane reads back what it wrote itself; the LDS executes a wave's operations in order.)
+    L += [f"ds_read_b128 v[{C0}:{C0 + 3}], %[clast]", f"ds_read_b128 v[{P0}:{P0 + 3}], %[clast] offset:4096"]
     L += [f"v_mov_b32 v{W0}, 0", f"v_mov_b32 v{W1}, 0",
           "s_sub_u32 s98, %[out], 16", f"v_mov_b32 v{VA1}, s98",
           f"s_add_u32 s98, %[out], {RING * 16}", f"v_mov_b32 v{VA3}, s98"]

@@ -49,6 +49,10 @@ struct DtwStrip {
   int32_t pair, row0, nrows;
   int32_t flag_in, flag_out;     // indices into the flag array (-1: none): wait for / signal the neighbouring strip
   int64_t bnd_in, bnd_out;       // offsets (doubles) into bnd_ws of the (T,2) boundary arrays, -1: none
+  // column segment [col0, col0 + ncol) of the pair (a multiple of 16 columns unless it is the last): a strip's columns are
+  // cut into segments that run as separate jobs, so that the ~equal jobs of a batch do not come in a whole number per
+  // slot (see dtw_run_fused); flag_prev: the job of the same strip's previous segment (-1: first segment)
+  int32_t col0, ncol, flag_prev, packed;     // packed: member of a packed group of four one-wave strips
 };
 
 __device__ __forceinline__ double dtw_transition(int j, int i) {   // transition(d, j, i), src/dtw.jl:23-31
@@ -384,23 +388,48 @@ __device__ __forceinline__ uint32_t lds_addr(const void *p) {
   return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char *)p;
 }
 
+#ifdef VCMI_DTW_PROF
+__device__ unsigned long long dtw_prof[8];      // cycles summed over jobs: [0] prologue, [1] column loop (incl. the template loads), [2] epilogue, [3] jobs, [4] flag waits
+#define DTW_PROF_MARK(var) const long long var = (long long)__builtin_readcyclecounter()
+#else
+#define DTW_PROF_MARK(var)
+#endif
+// Synchronisation between jobs of the fused kernel (strip below -> strip above, column segment -> next segment).
+// The L2 caches of the eight XCDs are not coherent with each other, so an acquire / release at agent scope is an L2-WIDE
+// invalidate / write-back (buffer_inv sc1 / buffer_wbl2 sc1) -- which every other workgroup of the XCD pays for: with one
+// such pair per job a 100-column job took 325k cycles instead of 240k (cycle counter, VCMI_DTW_PROF).  Instead the few
+// values that cross jobs -- boundary pairs, last cost columns, flags -- are themselves accessed at agent scope (sc1: stores
+// write through to the device-wide coherence point, loads do not use a possibly stale cached copy), relaxed, and ordered by
+// hand: the producer waits until its stores are acknowledged (vmcnt(0)), then stores the flag; the consumer sees the flag,
+// then loads.  Everything else a job writes (step codes) is read by a later kernel.
+__device__ __forceinline__ void dtw_store_shared(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double dtw_load_shared(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void dtw_wait_flag(const int *flag, int epoch) {
+  while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) __builtin_amdgcn_s_sleep(32);
+}
+// all of this wave's stores have been acknowledged
+__device__ __forceinline__ void dtw_stores_done() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 template <int DMAX, int STEPS>
-__global__ void __launch_bounds__(kFusedThreads)
-dtw_fused_kernel(const double *__restrict__ base, int padded, const DtwPair *__restrict__ pairs,
-                 const DtwStrip *__restrict__ strips, uint32_t *__restrict__ fcodes_ws, double *__restrict__ bnd_ws,
-                 double *__restrict__ clast_ws, int *__restrict__ flags, int epoch, int npacked) {
+__device__ __forceinline__ void dtw_fused_job(const int sfirst, const double *__restrict__ base, int padded,
+                                              const DtwPair *__restrict__ pairs, const DtwStrip *__restrict__ strips,
+                                              uint32_t *__restrict__ fcodes_ws, double *__restrict__ bnd_ws,
+                                              double *__restrict__ clast_ws, int *__restrict__ flags, int epoch) {
+  DTW_PROF_MARK(pt0);
   extern __shared__ __attribute__((aligned(16))) unsigned char fsm[];
   unsigned char *outbox = fsm;                                                        // [4][VCMI_FUSED_OUTBOX]
   double *clast = reinterpret_cast<double *>(fsm + 4 * VCMI_FUSED_OUTBOX);            // [kFusedRows]
-  double *bnd = clast + kFusedRows;                                                   // [1 + T][2]
-  // The first `npacked` workgroups are PACKED: each of their waves runs its own one-wave strip (the short bottom strips
-  // of long templates, <= 128 rows), four unrelated strips per workgroup, so that no wave slot idles beside them.
+  double *pinit = clast + kFusedRows;                                                 // [kFusedRows] (DMAX > 40: initial neighbour costs)
+  double *bnd = pinit + kFusedRows;                                                   // [1 + T][2]
+  // A job is one strip segment (first descriptor `sfirst`), or a PACKED group: each of the four waves runs its own
+  // one-wave strip (the short bottom strips of long templates, <= 128 rows), four unrelated strips per workgroup, so that
+  // no wave slot idles beside them.
   const int tid = threadIdx.x, lane = tid & 63;
-  const bool packed = (int)blockIdx.x < npacked;
+  const bool packed = strips[sfirst].packed != 0;
   const int slotw = tid >> 6;                                  // wave slot in the workgroup (outbox, clast area)
-  const DtwStrip st = packed ? strips[4 * blockIdx.x + slotw] : strips[3 * npacked + blockIdx.x];
+  const DtwStrip st = packed ? strips[sfirst + slotw] : strips[sfirst];
   const DtwPair P = pairs[st.pair];
-  const int S = P.S, T = P.T;
+  const int S = P.S, T = st.ncol, col0 = st.col0;              // T: the columns of THIS job
   if (!packed && T == 0) return;
   const int wave = packed ? 0 : slotw;                         // wave index within the strip
   const int nw = (st.nrows + 127) >> 7;
@@ -409,6 +438,23 @@ dtw_fused_kernel(const double *__restrict__ base, int padded, const DtwPair *__r
   // lazy_init!: costtable[:,1] = 1:S (src/dtw.jl:49); the neighbours of column 1 are rows gr0-2, gr0-1
   double c0 = (double)(gr0 + 1), c1 = (double)(gr0 + 2);
   double p0 = gr0 >= 2 ? (double)(gr0 - 1) : INFINITY, p1 = gr0 >= 1 ? (double)gr0 : INFINITY;
+  if (__syncthreads_or(st.flag_prev >= 0)) {   // (a packed group: any of its four strips)
+    // a later column segment: the previous one (an earlier job: running or finished) left the costs of its last column,
+    // for every row of the strip, in clast_ws; rows below the strip belong to the strip below and reach lane 0 of wave 0
+    // through the boundary array, like every column's
+    if (lane == 0 && (packed || tid == 0) && st.flag_prev >= 0)
+      dtw_wait_flag(&flags[st.flag_prev], epoch);
+    __syncthreads();
+  }
+  DTW_PROF_MARK(ptw);
+  if (st.flag_prev >= 0) {
+    const double *cl = clast_ws + P.clast_off;
+    const int last = S - 1;
+    c0 = dtw_load_shared(cl + (gr0 < S ? gr0 : last));
+    c1 = dtw_load_shared(cl + (gr0 + 1 < S ? gr0 + 1 : last));
+    p0 = (gr0 - 2 >= st.row0) ? dtw_load_shared(cl + (gr0 - 2 < S ? gr0 - 2 : last)) : INFINITY;
+    p1 = (gr0 - 1 >= st.row0) ? dtw_load_shared(cl + (gr0 - 1 < S ? gr0 - 1 : last)) : INFINITY;
+  }
   if (tid < 4) *reinterpret_cast<uint32_t *>(outbox + tid * VCMI_FUSED_OUTBOX + VCMI_FUSED_RING * 16) = 0u;   // tags
   if (lane == 63) {   // what the next wave's lane 0 reads for column 0: the ring's last slot holds the initial costs
     double *slot = reinterpret_cast<double *>(outbox + slotw * VCMI_FUSED_OUTBOX + (VCMI_FUSED_RING - 1) * 16);
@@ -418,24 +464,28 @@ dtw_fused_kernel(const double *__restrict__ base, int padded, const DtwPair *__r
   if (!packed && st.flag_in >= 0) {
     // the strip below must be complete (it precedes this workgroup in the grid, so it is resident or finished)
     if (tid == 0)
-      while (__hip_atomic_load(&flags[st.flag_in], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != epoch) __builtin_amdgcn_s_sleep(32);
+      dtw_wait_flag(&flags[st.flag_in], epoch);
     __syncthreads();
     // entry 0: initial costs of the two rows below the strip; entry 1+t: their costs after column t
-    const double *src = bnd_ws + st.bnd_in;
+    // (of this job's columns: LDS entry e <-> the pair's entry col0 + e)
+    const double *src = bnd_ws + st.bnd_in + 2 * (int64_t)col0;
     if (tid == 0) {
-      bnd[0] = (double)(st.row0 - 1);
-      bnd[1] = (double)st.row0;
+      bnd[0] = col0 == 0 ? (double)(st.row0 - 1) : dtw_load_shared(src - 2);
+      bnd[1] = col0 == 0 ? (double)st.row0 : dtw_load_shared(src - 1);
     }
-    for (int i = tid; i < 2 * T; i += (int)blockDim.x) bnd[2 + i] = __builtin_nontemporal_load(src + i);
+    for (int i = tid; i < 2 * T; i += (int)blockDim.x) bnd[2 + i] = dtw_load_shared(src + i);
   }
   __syncthreads();
+  DTW_PROF_MARK(pt1);
   if (wave < nw && T > 0) {
+    // (the 40 loads of a lane's two rows touch 64 cache lines each; measured, they cost nothing: a packed, fully coalesced
+    // copy of the templates left the job time unchanged and its packing kernel took 85 us)
     const double *tmpl = base + (padded ? P.tpad_off : P.tmpl_off);
     const double *rowA = tmpl + (int64_t)DMAX * (gr0 < S ? gr0 : S - 1);
     const double *rowB = tmpl + (int64_t)DMAX * (gr0 + 1 < S ? gr0 + 1 : S - 1);
-    const double *seq = base + (padded ? P.spad_off : P.seq_off);
+    const double *seq = base + (padded ? P.spad_off : P.seq_off) + (int64_t)DMAX * col0;
     const int Se = (S + 1) & ~1;
-    uint32_t *codes = fcodes_ws + P.fcodes_off + gr0;
+    uint32_t *codes = fcodes_ws + P.fcodes_off + gr0 + (int64_t)(col0 >> 4) * Se;
     const uint64_t cstride = (uint64_t)Se * 4;
     int cnt = (st.nrows - 128 * wave + 1) >> 1;
     cnt = cnt > 64 ? 64 : cnt;
@@ -445,9 +495,15 @@ dtw_fused_kernel(const double *__restrict__ base, int padded, const DtwPair *__r
     double *gout = bnd_ws;
     if (st.bnd_out >= 0 && wave == nw - 1) {          // non-final strips have an even number of rows
       explane = (st.nrows >> 1) - 1 - 64 * wave;
-      gout = bnd_ws + st.bnd_out;
+      gout = bnd_ws + st.bnd_out + 2 * (int64_t)col0;
     }
     uint32_t clast_a = lds_addr(clast + 128 * slotw + 2 * lane);
+    if constexpr (DMAX > 40) {     // the wide kernels read their initial costs from LDS (operand VGPRs are scarce there)
+      clast[128 * slotw + 2 * lane] = c0;
+      clast[128 * slotw + 2 * lane + 1] = c1;
+      pinit[128 * slotw + 2 * lane] = p0;
+      pinit[128 * slotw + 2 * lane + 1] = p1;
+    }
     uint32_t ncols = (uint32_t)T, off = 0, tcol = 0;
     // every operand the loop reads is wave-uniform or per-lane as declared; force the uniform ones into SGPRs
     cnt = __builtin_amdgcn_readfirstlane(cnt);
@@ -466,12 +522,12 @@ dtw_fused_kernel(const double *__restrict__ base, int padded, const DtwPair *__r
                  [explane] "s"(explane), [rowA] "v"(rowA), [rowB] "v"(rowB), [c0] "v"(c0), [c1] "v"(c1), [p0] "v"(p0), \
                  [p1] "v"(p1), [clast] "v"(clast_a)                                                                   \
                : "memory", "vcc", "scc", CLOBBERS)
-    // the wide kernels (40 < D <= 48) form the initial costs themselves from the lane's first row (operand VGPRs are scarce)
+    // the wide kernels (40 < D <= 48) read the initial costs from LDS: (C0, C1) at %[clast], (P0, P1) kFusedRows doubles behind
 #define VCMI_FUSED3_ASM(BODY, CLOBBERS)                                                                               \
   asm volatile(BODY                                                                                                   \
                : [seq] "+s"(seq), [off] "+s"(off), [n] "+s"(ncols), [t] "+s"(tcol), [codes] "+v"(codes), [gout] "+v"(gout) \
                : [cstride] "s"(cstride_u), [cnt] "s"(cnt), [out] "s"(out), [bnd] "s"(bndl), [mode] "s"(mode),          \
-                 [explane] "s"(explane), [rowA] "v"(rowA), [rowB] "v"(rowB), [g0] "v"(gr0), [clast] "v"(clast_a)       \
+                 [explane] "s"(explane), [rowA] "v"(rowA), [rowB] "v"(rowB), [clast] "v"(clast_a)                      \
                : "memory", "vcc", "scc", CLOBBERS)
     if constexpr (STEPS == 1) {
       if constexpr (DMAX == 8) VCMI_FUSED_ASM(VCMI_DTW_FUSED_ASM_D8_S1);
@@ -503,21 +559,72 @@ dtw_fused_kernel(const double *__restrict__ base, int padded, const DtwPair *__r
 #undef VCMI_FUSED3_ASM
   }
   __syncthreads();
+  DTW_PROF_MARK(pt2);
+#ifdef VCMI_DTW_PROF
+  auto prof_end = [&]() {
+    const long long pt3 = (long long)__builtin_readcyclecounter();
+    if (tid == 0) {
+      atomicAdd(&dtw_prof[0], (unsigned long long)(pt1 - pt0));
+      atomicAdd(&dtw_prof[1], (unsigned long long)(pt2 - pt1));
+      atomicAdd(&dtw_prof[2], (unsigned long long)(pt3 - pt2));
+      atomicAdd(&dtw_prof[3], 1ull);
+      atomicAdd(&dtw_prof[4], (unsigned long long)(ptw - pt0));
+    }
+  };
+#endif
   if (packed) {      // every wave finishes its own strip
     if (T > 0) {
-      for (int i = lane; i < st.nrows; i += 64) clast_ws[P.clast_off + st.row0 + i] = clast[128 * slotw + i];
+      for (int i = lane; i < st.nrows; i += 64) dtw_store_shared(&clast_ws[P.clast_off + st.row0 + i], clast[128 * slotw + i]);
       if (st.flag_out >= 0) {
-        __threadfence();
-        if (lane == 0) __hip_atomic_store(&flags[st.flag_out], epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        dtw_stores_done();      // (also the boundary pairs the column loop exported)
+        if (lane == 0) __hip_atomic_store(&flags[st.flag_out], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
+#ifdef VCMI_DTW_PROF
+    prof_end();
+#endif
     return;
   }
-  for (int i = tid; i < st.nrows; i += (int)blockDim.x) clast_ws[P.clast_off + st.row0 + i] = clast[i];
+  for (int i = tid; i < st.nrows; i += (int)blockDim.x) dtw_store_shared(&clast_ws[P.clast_off + st.row0 + i], clast[i]);
   if (st.flag_out >= 0) {
-    __threadfence();
+    dtw_stores_done();
     __syncthreads();
-    if (tid == 0) __hip_atomic_store(&flags[st.flag_out], epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) __hip_atomic_store(&flags[st.flag_out], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+#ifdef VCMI_DTW_PROF
+  prof_end();
+#endif
+}
+
+// One job per workgroup, in grid order.
+template <int DMAX, int STEPS>
+__global__ void __launch_bounds__(kFusedThreads)
+dtw_fused_kernel(const double *__restrict__ base, int padded, const DtwPair *__restrict__ pairs,
+                 const DtwStrip *__restrict__ strips, uint32_t *__restrict__ fcodes_ws, double *__restrict__ bnd_ws,
+                 double *__restrict__ clast_ws, int *__restrict__ flags, int epoch, const int *__restrict__ job_first) {
+  dtw_fused_job<DMAX, STEPS>(job_first[blockIdx.x], base, padded, pairs, strips, fcodes_ws, bnd_ws, clast_ws, flags, epoch);
+}
+
+// Persistent form: as many workgroups as the device holds at once, each drawing the next job from a ticket counter until
+// the list is exhausted.  A workgroup that waits on a flag waits for a job with a LOWER ticket (the list is in dependency
+// order), i.e. for a job some running workgroup already holds: no deadlock, whatever the residency.  With the columns cut
+// into segments the jobs are short; drawing them inside the kernel removes the gap the hardware dispatcher leaves
+// between a finished workgroup and its successor.
+template <int DMAX, int STEPS>
+__global__ void __launch_bounds__(kFusedThreads, 2)      // two workgroups per CU: 256 registers
+dtw_fused_persistent_kernel(const double *__restrict__ base, int padded, const DtwPair *__restrict__ pairs,
+                            const DtwStrip *__restrict__ strips, uint32_t *__restrict__ fcodes_ws, double *__restrict__ bnd_ws,
+                            double *__restrict__ clast_ws, int *__restrict__ flags, int epoch, const int *__restrict__ job_first,
+                            int njobs, int *__restrict__ ticket) {
+  __shared__ int job_s;
+  for (;;) {
+    if (threadIdx.x == 0) job_s = atomicAdd(ticket, 1);
+    __syncthreads();
+    const int job = __builtin_amdgcn_readfirstlane(job_s);     // uniform: the job's descriptors stay in SGPRs
+    __syncthreads();                // (job_s is rewritten by the next draw)
+    if (job >= njobs) break;
+    dtw_fused_job<DMAX, STEPS>(job_first[job], base, padded, pairs, strips, fcodes_ws, bnd_ws, clast_ws, flags, epoch);
+    __syncthreads();                // the next job reuses the outboxes, the boundary array and the last-column area
   }
 }
 
@@ -701,13 +808,17 @@ struct DtwScratch {
   // Stream ordering of the shared workspaces (descriptors, observation costs, step codes): a call on ANY stream first
   // waits for the previous call's last kernel (`last_use`), and the descriptors travel to the device by an asynchronous
   // copy on the caller's stream from a small ring of pinned slots (a slot is reused only after its copy completed).
-  static constexpr int kSlots = 6;
+  // The ring is DEEP on purpose: a caller that issues calls back to back blocks in stage() once every slot is in flight, and
+  // a blocked host thread wakes up late when the machine is busy (measured on a box with load average 30: 3-4.5 ms per
+  // call instead of the GPU's 1.6 ms with 6 slots = two calls in flight) -- with 24 slots the GPU has many calls queued
+  // and a late wake-up costs nothing.  (256 KB of pinned memory per slot at the benchmark batch.)
+  static constexpr int kSlots = 24;
   hipEvent_t last_use = nullptr, slot_done[kSlots] = {};
   unsigned char *slot[kSlots] = {};
   size_t slot_cap[kSlots] = {};
   int next_slot = 0, device = -1;
   // fused path: strip descriptors, packed step codes, strip boundaries, last cost columns, strip-completion flags
-  DevBuf<DtwStrip> dstrips;
+  DevBuf<unsigned char> ddesc;   // fused path: pair, strip and job descriptors of the call (one upload)
   DevBuf<uint32_t> fcodes;
   DevBuf<double> bnd, clast;
   DevBuf<int> flags;
@@ -725,9 +836,17 @@ struct DtwScratch {
   // pinned copy of `n` descriptors, valid until the returned slot's event (recorded by the caller) completes
   template <typename Desc>
   int stage(const Desc *src, size_t n, Desc **out, hipEvent_t *ev) {
+    unsigned char *raw = nullptr;
+    VCMI_TRY(stage_raw(n * sizeof(Desc), &raw, ev));
+    memcpy(raw, src, n * sizeof(Desc));
+    *out = reinterpret_cast<Desc *>(raw);
+    return VCMI_OK;
+  }
+  // `bytes` of the next pinned slot (to be filled by the caller), valid until the slot's event -- recorded by the caller
+  // after the copy it issues -- completes
+  int stage_raw(size_t bytes, unsigned char **out, hipEvent_t *ev) {
     const int s = next_slot;
     next_slot = (next_slot + 1) % kSlots;
-    const size_t bytes = n * sizeof(Desc);
     VCMI_HIP(hipEventSynchronize(slot_done[s]));
     if (bytes > slot_cap[s]) {
       if (slot[s]) (void)hipHostFree(slot[s]);
@@ -737,8 +856,7 @@ struct DtwScratch {
       VCMI_HIP(hipHostMalloc(reinterpret_cast<void **>(&slot[s]), cap, hipHostMallocDefault));
       slot_cap[s] = cap;
     }
-    memcpy(slot[s], src, bytes);
-    *out = reinterpret_cast<Desc *>(slot[s]);
+    *out = slot[s];
     *ev = slot_done[s];
     return VCMI_OK;
   }
@@ -774,7 +892,7 @@ static DtwScratch &scratch() {
 // Dynamic LDS of the two fused kernels; the caller takes the observation + recurrence path when either exceeds the budget
 // (sequences beyond ~9.7k frames: the forward kernel keeps the boundary costs of a strip, 16 bytes per column, in LDS).
 static inline size_t dtw_fused_lds_forward(int Tmax) {
-  return (size_t)4 * VCMI_FUSED_OUTBOX + (size_t)kFusedRows * 8 + ((size_t)Tmax + 1) * 16;
+  return (size_t)4 * VCMI_FUSED_OUTBOX + (size_t)2 * kFusedRows * 8 + ((size_t)Tmax + 1) * 16;
 }
 static inline size_t dtw_fused_lds_finish(int Smax, int Tmax) {
   const size_t SmaxE = (size_t)((Smax + 1) & ~1);
@@ -802,6 +920,8 @@ static int dtw_run_fused(const double *feats, std::vector<DtwPair> &pairs, int D
   });
   size_t ncodes = 0, nclast = 0, nbnd = 0, padn = 0;
   int nflags = 0;
+  // pass 1: the row strips of every pair, whole-length (col0 = 0, ncol = T): one-wave or wider bottom strips of long
+  // templates (levels[0]), single-strip pairs, the strips above by level.
   std::vector<std::vector<DtwStrip>> levels;
   std::vector<DtwStrip> singles;
   for (int k = 0; k < n; ++k) {
@@ -818,7 +938,7 @@ static int dtw_run_fused(const double *feats, std::vector<DtwPair> &pairs, int D
     if (p.T == 0) continue;
     const int nstr = (p.S + kFusedRows - 1) / kFusedRows;
     if (nstr == 1) {
-      singles.push_back(DtwStrip{k, 0, p.S, -1, -1, -1, -1});
+      singles.push_back(DtwStrip{k, 0, p.S, -1, -1, -1, -1, 0, p.T, -1, 0});
       continue;
     }
     int first = p.S - kFusedRows * (nstr - 1);      // remainder strip at the bottom, an even number of rows
@@ -826,13 +946,9 @@ static int dtw_run_fused(const double *feats, std::vector<DtwPair> &pairs, int D
     int row = 0;
     for (int s = 0; s < nstr; ++s) {
       const int rows = (s == 0) ? first : std::min(kFusedRows, p.S - row);
-      DtwStrip ds{k, row, rows, -1, -1, -1, -1};
-      if (s > 0) {
-        ds.flag_in = nflags - 1;
-        ds.bnd_in = (int64_t)(nbnd - (size_t)2 * p.T);
-      }
+      DtwStrip ds{k, row, rows, -1, -1, -1, -1, 0, p.T, -1, 0};
+      if (s > 0) ds.bnd_in = (int64_t)(nbnd - (size_t)2 * p.T);
       if (s + 1 < nstr) {
-        ds.flag_out = nflags++;
         ds.bnd_out = (int64_t)nbnd;
         nbnd += (size_t)2 * p.T;
       }
@@ -841,17 +957,120 @@ static int dtw_run_fused(const double *feats, std::vector<DtwPair> &pairs, int D
       row += rows;
     }
   }
-  // grid order: packed groups of one-wave bottom strips (four per workgroup, padded with empty strips), the other
-  // bottom strips, the single-strip pairs, then the upper strips level by level
-  std::vector<DtwStrip> strips, wide;
+  // Column segments.  The jobs of a batch take about the same time (T columns each), so with one whole-length job per
+  // workgroup a slot runs a whole number of them and the batch takes ceil(jobs / slots) job times: 1093 jobs on 512 slots
+  // = 3, for 2.13 job times of work.  Cutting every strip's columns into `nseg` segments (a segment starts from the last
+  // cost column its predecessor left in clast_ws) makes the unit smaller: 5 x 1093 jobs = 10.7 fifth-rounds.  A 100-column
+  // segment costs what a 100-column sequence costs (7k cycles of prologue + 2.3k per column, cycle counter) PROVIDED the
+  // jobs synchronise without agent-scope fences (see dtw_wait_flag): with one acquire / release pair per job the same
+  // segment took 350k cycles instead of 250k and segments did not pay (1.72 / 1.68 / 1.74 / 1.82 / 2.43 ms for nseg = 1 / 2
+  // / 3 / 4 / 8) -- which an earlier revision of this comment blamed on workgroup dispatch.  Now 1.69 / 1.52 / 1.50 / 1.51 /
+  // 1.49 / 1.50 / 1.52 / 1.57 ms for nseg = 1 / 2 / 3 / 4 / 5 / 6 / 8 / 10.  nseg minimises ceil(jobs / slots) / nseg with 2 % per
+  // extra segment for its prologue, segments of at least 64 columns, nothing cut when everything fits one round.  The
+  // segments are drawn from a ticket counter by persistent workgroups, one per slot (dtw_fused_persistent_kernel: 1.49 ms
+  // against 1.53 ms with one workgroup per job in grid order at D = 40; the D = 48 kernel, whose persistent form spills 16
+  // registers, stays with grid order: 1.77 against 1.80 ms).
+  std::vector<DtwStrip> packed, wide;
   if (!levels.empty())
-    for (const DtwStrip &ds : levels[0]) (ds.nrows <= 128 ? strips : wide).push_back(ds);
-  while (strips.size() % 4) strips.push_back(DtwStrip{strips.empty() ? 0 : strips.back().pair, 0, 0, -1, -1, -1, -1});
-  const int npacked = (int)(strips.size() / 4);
-  strips.insert(strips.end(), wide.begin(), wide.end());
-  strips.insert(strips.end(), singles.begin(), singles.end());
-  for (size_t l = 1; l < levels.size(); ++l) strips.insert(strips.end(), levels[l].begin(), levels[l].end());
-  const unsigned ngroups = (unsigned)(strips.size() - 3 * (size_t)npacked);
+    for (const DtwStrip &ds : levels[0]) (ds.nrows <= 128 ? packed : wide).push_back(ds);
+  size_t nwhole = wide.size() + singles.size();
+  for (size_t l = 1; l < levels.size(); ++l) nwhole += levels[l].size();
+  int slots = 512;
+  {
+    int dev = 0, cus = 256;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    slots = 2 * cus;                              // two workgroups per CU (set by the registers)
+  }
+  int nseg = 1;
+  const bool segments_allowed = !debug_flag(kDbgDtwNoSegments);
+  {
+    int64_t tsum = 0, tcnt = 0;
+    for (const DtwPair &p : pairs)
+      if (p.T > 0) {
+        tsum += p.T;
+        ++tcnt;
+      }
+    const int tavg = (int)(tsum / std::max<int64_t>(tcnt, 1));
+    const double base_jobs = (double)((packed.size() + 3) / 4) + (double)nwhole;
+    double best = 1e30;
+    for (int c : {1, 2, 3, 4, 5, 6, 8}) {
+      if (c > 1 && (!segments_allowed || tavg / c < 64 || base_jobs <= slots)) break;
+      const double t = std::ceil(base_jobs * c / slots) / c * (1.0 + 0.02 * (c - 1));
+      if (t < best - 1e-9) {
+        best = t;
+        nseg = c;
+      }
+    }
+  }
+  if (const char *e = getenv("VCMI_DTW_NSEG")) nseg = std::max(1, atoi(e));      // experiments
+  // pass 2: job order, segment by segment: packed groups of one-wave bottom strips (four per workgroup, padded with empty
+  // strips), the other bottom strips, the single-strip pairs (largest first), the upper strips level by level.  A job
+  // waits only for jobs earlier in the order: the strip below (same segment) and its own previous segment.
+  while (packed.size() % 4) packed.push_back(DtwStrip{packed.empty() ? 0 : packed.back().pair, 0, 0, -1, -1, -1, -1, 0, 0, -1, 0});
+  std::vector<DtwStrip> whole = wide;
+  whole.insert(whole.end(), singles.begin(), singles.end());
+  for (size_t l = 1; l < levels.size(); ++l) whole.insert(whole.end(), levels[l].begin(), levels[l].end());
+  auto seg_bounds = [&](int T, int k) {            // first column of segment k (multiples of 16), k = nseg -> T
+    if (k >= nseg) return T;
+    return (int)((int64_t)T * k / nseg) & ~15;
+  };
+  // the strip below every upper strip: a packed bottom or a whole-length strip of the same pair that ends where it starts
+  std::vector<int> below(whole.size(), -1);
+  std::vector<char> below_packed(whole.size(), 0);
+  {
+    std::vector<std::vector<int>> by_pair_packed((size_t)n), by_pair_whole((size_t)n);
+    for (size_t i = 0; i < packed.size(); ++i)
+      if (packed[i].nrows > 0) by_pair_packed[(size_t)packed[i].pair].push_back((int)i);
+    for (size_t i = 0; i < whole.size(); ++i) by_pair_whole[(size_t)whole[i].pair].push_back((int)i);
+    for (size_t i = 0; i < whole.size(); ++i) {
+      const DtwStrip &ds = whole[i];
+      if (ds.bnd_in < 0) continue;
+      for (int j : by_pair_packed[(size_t)ds.pair])
+        if (packed[(size_t)j].row0 + packed[(size_t)j].nrows == ds.row0) {
+          below[i] = j;
+          below_packed[i] = 1;
+        }
+      for (int j : by_pair_whole[(size_t)ds.pair])
+        if (whole[(size_t)j].row0 + whole[(size_t)j].nrows == ds.row0) below[i] = j;
+    }
+  }
+  std::vector<std::vector<int>> pflag(packed.size(), std::vector<int>((size_t)nseg, -1));
+  std::vector<std::vector<int>> wflag(whole.size(), std::vector<int>((size_t)nseg, -1));
+  std::vector<DtwStrip> strips;
+  std::vector<int> job_first;
+  auto segment_of = [&](DtwStrip ds, int k, std::vector<int> &flags_of, bool has_consumer_above) {
+    const int T = ds.nrows > 0 ? pairs[(size_t)ds.pair].T : 0;
+    ds.col0 = seg_bounds(T, k);
+    ds.ncol = std::max(0, seg_bounds(T, k + 1) - ds.col0);
+    ds.flag_prev = -1;
+    for (int kp = k - 1; kp >= 0 && ds.flag_prev < 0; --kp) ds.flag_prev = flags_of[(size_t)kp];
+    if (ds.ncol > 0 && (has_consumer_above || seg_bounds(T, k + 1) < T)) flags_of[(size_t)k] = ds.flag_out = nflags++;
+    return ds;
+  };
+  for (int k = 0; k < nseg; ++k) {
+    for (size_t i = 0; i + 3 < packed.size(); i += 4) {
+      bool any = false;
+      DtwStrip g4[4];
+      for (int q = 0; q < 4; ++q) {
+        g4[q] = segment_of(packed[i + q], k, pflag[i + q], packed[i + q].bnd_out >= 0);
+        g4[q].packed = 1;
+        any = any || g4[q].ncol > 0;
+      }
+      if (!any) continue;
+      job_first.push_back((int)strips.size());
+      strips.insert(strips.end(), g4, g4 + 4);
+    }
+    for (size_t i = 0; i < whole.size(); ++i) {
+      DtwStrip ds = segment_of(whole[i], k, wflag[i], whole[i].bnd_out >= 0);
+      if (ds.ncol <= 0) continue;                  // (short sequences: fewer segments than nseg)
+      // (the strip below has the same T, hence the same segment boundaries: its segment k exists whenever this one does)
+      if (below[i] >= 0) ds.flag_in = below_packed[i] ? pflag[(size_t)below[i]][(size_t)k] : wflag[(size_t)below[i]][(size_t)k];
+      job_first.push_back((int)strips.size());
+      strips.push_back(ds);
+    }
+  }
+  const unsigned ngroups = (unsigned)job_first.size();
   if (strips.empty()) return VCMI_OK;
   VCMI_TRY(sc.fcodes.reserve(ncodes));
   VCMI_TRY(sc.clast.reserve(nclast));
@@ -862,25 +1081,51 @@ static int dtw_run_fused(const double *feats, std::vector<DtwPair> &pairs, int D
     sc.epoch = 0;
   }
   const int epoch = ++sc.epoch;
-  VCMI_TRY(sc.dpairs.reserve((size_t)n));
-  VCMI_TRY(sc.dstrips.reserve(strips.size()));
-  VCMI_TRY(sc.upload(sc.dpairs.p, pairs.data(), (size_t)n, st));
-  VCMI_TRY(sc.upload(sc.dstrips.p, strips.data(), strips.size(), st));
+  // one upload for everything the kernels read: [pairs | strips | first descriptor of every job, ticket counter = 0]
+  const size_t o_strips = ((size_t)n * sizeof(DtwPair) + 255) & ~(size_t)255;
+  const size_t o_jobs = (o_strips + strips.size() * sizeof(DtwStrip) + 255) & ~(size_t)255;
+  const size_t desc_bytes = o_jobs + (job_first.size() + 1) * sizeof(int);
+  VCMI_TRY(sc.ddesc.reserve(desc_bytes));
+  unsigned char *descp = sc.ddesc.p;
+  {
+    unsigned char *pinned = nullptr;
+    hipEvent_t copied = nullptr;
+    VCMI_TRY(sc.stage_raw(desc_bytes, &pinned, &copied));
+    memcpy(pinned, pairs.data(), (size_t)n * sizeof(DtwPair));
+    memcpy(pinned + o_strips, strips.data(), strips.size() * sizeof(DtwStrip));
+    memcpy(pinned + o_jobs, job_first.data(), job_first.size() * sizeof(int));
+    memset(pinned + o_jobs + job_first.size() * sizeof(int), 0, sizeof(int));
+    VCMI_HIP(hipMemcpyAsync(sc.ddesc.p, pinned, desc_bytes, hipMemcpyHostToDevice, st));
+    VCMI_HIP(hipEventRecord(copied, st));
+  }
+  const DtwPair *dpairs = reinterpret_cast<const DtwPair *>(descp);
+  const DtwStrip *dstrips = reinterpret_cast<const DtwStrip *>(descp + o_strips);
+  int *djobs = reinterpret_cast<int *>(descp + o_jobs);
+  int *ticket = djobs + job_first.size();
   const bool padded = (D != dmax);
   if (padded) {
     VCMI_TRY(sc.spad.reserve(padn));
-    hipLaunchKernelGGL(dtw_pad_kernel, dim3(n, 8), dim3(256), 0, st, feats, sc.dpairs.p, D, dmax, sc.spad.p);
+    hipLaunchKernelGGL(dtw_pad_kernel, dim3(n, 8), dim3(256), 0, st, feats, dpairs, D, dmax, sc.spad.p);
   }
   const double *base = padded ? sc.spad.p : feats;
   const size_t shf = dtw_fused_lds_forward(Tmax);
   if (shf > kLdsLimit) return fail(VCMI_ERR_ARG, "DTW: sequence of %d frames exceeds the supported length", Tmax);
 #define VCMI_FUSED_LAUNCH(DM, STP)                                                                                    \
   do {                                                                                                                \
-    auto kern = dtw_fused_kernel<DM, STP>;                                                                            \
-    VCMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,    \
-                                 (int)shf));                                                                          \
-    hipLaunchKernelGGL(kern, dim3(ngroups), dim3(kFusedThreads), shf, st, base, (int)padded, sc.dpairs.p,             \
-                       sc.dstrips.p, sc.fcodes.p, sc.bnd.p, sc.clast.p, sc.flags.p, epoch, npacked);                  \
+    if ((int)ngroups > slots && DM <= 41 && !debug_flag(kDbgDtwGridOrder)) { /* more jobs than slots: ticket-drawn */ \
+      auto kernp = dtw_fused_persistent_kernel<DM, STP>;                                                              \
+      VCMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kernp), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                   (int)shf));                                                                        \
+      hipLaunchKernelGGL(kernp, dim3((unsigned)slots), dim3(kFusedThreads), shf, st, base, (int)padded, dpairs,  \
+                         dstrips, sc.fcodes.p, sc.bnd.p, sc.clast.p, sc.flags.p, epoch, djobs, (int)ngroups, \
+                         ticket);                                                                                     \
+    } else {                                                                                                          \
+      auto kern = dtw_fused_kernel<DM, STP>;                                                                          \
+      VCMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,  \
+                                   (int)shf));                                                                        \
+      hipLaunchKernelGGL(kern, dim3(ngroups), dim3(kFusedThreads), shf, st, base, (int)padded, dpairs,           \
+                         dstrips, sc.fcodes.p, sc.bnd.p, sc.clast.p, sc.flags.p, epoch, djobs);             \
+    }                                                                                                                 \
   } while (0)
 #define VCMI_FUSED_CASE(DM) \
   case DM: if (bstep == 1) VCMI_FUSED_LAUNCH(DM, 1); else VCMI_FUSED_LAUNCH(DM, 2); break;
@@ -899,14 +1144,25 @@ static int dtw_run_fused(const double *feats, std::vector<DtwPair> &pairs, int D
   if (shb + shc <= kLdsLimit) {
     auto kern = dtw_fused_finish_kernel<true>;
     VCMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(shb + shc)));
-    hipLaunchKernelGGL(kern, dim3(n), dim3(256), shb + shc, st, feats, sc.dpairs.p, D, Smax, Tmax, sc.fcodes.p, sc.clast.p);
+    hipLaunchKernelGGL(kern, dim3(n), dim3(256), shb + shc, st, feats, dpairs, D, Smax, Tmax, sc.fcodes.p, sc.clast.p);
   } else {
     auto kern = dtw_fused_finish_kernel<false>;
     VCMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shb));
-    hipLaunchKernelGGL(kern, dim3(n), dim3(256), shb, st, feats, sc.dpairs.p, D, Smax, Tmax, sc.fcodes.p, sc.clast.p);
+    hipLaunchKernelGGL(kern, dim3(n), dim3(256), shb, st, feats, dpairs, D, Smax, Tmax, sc.fcodes.p, sc.clast.p);
   }
   VCMI_HIP(hipGetLastError());
   VCMI_HIP(hipEventRecord(sc.last_use, st));
+#ifdef VCMI_DTW_PROF
+  {
+    unsigned long long h[8], z[8] = {0};
+    (void)hipStreamSynchronize(st);
+    (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(dtw_prof), sizeof(h));
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(dtw_prof), z, sizeof(z));
+    if (h[3])
+      fprintf(stderr, "dtw_prof: %llu jobs (nseg %d); cycles per job: prologue %.0f (of which flag wait %.0f), column loop %.0f, epilogue %.0f\n",
+              h[3], nseg, (double)h[0] / h[3], (double)h[4] / h[3], (double)h[1] / h[3], (double)h[2] / h[3]);
+  }
+#endif
   return VCMI_OK;
 }
 

@@ -101,6 +101,8 @@ enum : unsigned {
   kDbgPredictTwoPass = 8u,   // (M,T) log-density matrix + argmax kernel instead of the in-kernel argmax
   kDbgEstepGeneric = 16u,    // generic diagonal E-step kernels instead of the MFMA one
   kDbgDtwTwoKernels = 32u,   // observation + recurrence kernels (the path of tables / D > 48 / wide windows) instead of the fused one
+  kDbgDtwNoSegments = 256u,   // fused DTW: whole-length jobs (no column segments)
+  kDbgDtwGridOrder = 512u,    // fused DTW: one workgroup per job in grid order instead of persistent workgroups drawing tickets
   kDbgTrajOneWgPerCu = 128u,  // blocked trajectory solver: one workgroup per CU even where two fit
   kDbgPredictNoEarlyExit = 64u   // predict / trajectory argmax: every whitening tile of every mixture (MODE 2) instead of the early exit (MODE 3)
 };
