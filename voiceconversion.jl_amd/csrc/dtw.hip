@@ -354,9 +354,10 @@ dtw_rec_kernel(const double *__restrict__ feats, const DtwPair *__restrict__ pai
     for (int k = 0; k < PF; ++k)
       if (t0 + PF + k < T) column(t0 + PF + k, ob[k]);
   }
-  if (!LDSCODES) {
-    __threadfence();
+  if (!LDSCODES) {      // the codes in HBM were written by this workgroup: workgroup scope (an agent-scope fence is L2-wide)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
   }
   dtw_finish<LDSCODES, BITS>(P, feats + P.seq_off, D, fstep, cbuf + (T & 1) * Smax, path32, owner, holes, codes, Smax);
 }
@@ -700,8 +701,9 @@ dtw_generic_kernel(const double *__restrict__ feats, const DtwPair *__restrict__
     }
     __syncthreads();
   }
-  __threadfence();
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
   dtw_finish<false, 8>(P, feats + P.seq_off, D, fstep, cbuf + (T & 1) * Smax, path32, owner, holes, nullptr, Smax);
 }
 
