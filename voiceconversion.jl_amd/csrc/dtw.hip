@@ -38,6 +38,7 @@ struct DtwPair {
   int64_t tpad_off;     // offset of the zero-padded template copy (same workspace)
   int64_t fcodes_off;   // fused path: this pair's packed step codes, [ceil(T/16)][Se] dwords at fcodes_ws + fcodes_off
   int64_t clast_off;    // fused path: last cost column (S doubles) at clast_ws + clast_off
+  int64_t path32_off;   // fused path: the pair's 0-based path (T ints) at path32_ws + path32_off
   int32_t S, T;
 };
 
@@ -57,6 +58,35 @@ struct DtwStrip {
 
 __device__ __forceinline__ double dtw_transition(int j, int i) {   // transition(d, j, i), src/dtw.jl:23-31
   return (i == j + 1) ? 0.0 : ((i == j) ? 1.0 : 2.0);
+}
+
+// align() post-processing, src/align.jl:20-32, from the 0-based path in LDS (one workgroup per pair)
+__device__ void dtw_align_post(const DtwPair &P, const double *__restrict__ seq, int D, const int32_t *path32, int32_t *owner, int32_t *holes) {
+  const int S = P.S, T = P.T, tid = threadIdx.x, nthr = blockDim.x;
+  if (!P.newtgt) return;
+  for (int i = tid; i < S; i += nthr) owner[i] = -1;
+  __syncthreads();
+  for (int t = tid; t < T; t += nthr) atomicMax(&owner[path32[t]], t);   // newtgt[:,path] = tgt: later frames win
+  __syncthreads();
+  for (int64_t e = tid; e < (int64_t)S * D; e += nthr) {
+    const int i = (int)(e / D), d = (int)(e % D);
+    const int k = owner[i];
+    P.newtgt[e] = (k >= 0) ? seq[(size_t)D * k + d] : 0.0;
+  }
+  __shared__ int nholes;
+  if (tid == 0) {                                   // hole = setdiff(path[1]:path[end], path), increasing order
+    int n = 0;
+    for (int i = path32[0]; i <= path32[T - 1]; ++i)
+      if (owner[i] < 0 && i > 0 && i < S - 1) holes[n++] = i;   // 1 < i < S in 1-based terms
+    nholes = n;
+  }
+  __syncthreads();
+  // each thread owns feature rows d, d+nthr, ...; a row's holes are filled in increasing i, as the reference does
+  for (int d = tid; d < D; d += nthr)
+    for (int h = 0; h < nholes; ++h) {
+      const int i = holes[h];
+      P.newtgt[(size_t)D * i + d] = (P.newtgt[(size_t)D * (i - 1) + d] + P.newtgt[(size_t)D * (i + 1) + d]) / 2.0;
+    }
 }
 
 // shared epilogue: argmin of the last column, backward pass, path output, align post-processing.
@@ -104,31 +134,7 @@ __device__ void dtw_finish(const DtwPair &P, const double *__restrict__ seq, int
   __syncthreads();
   if (P.path)
     for (int t = tid; t < T; t += nthr) P.path[t] = (int64_t)path32[t] + 1;
-  if (!P.newtgt) return;
-  // ---- align(), src/align.jl:20-32 ----
-  for (int i = tid; i < S; i += nthr) owner[i] = -1;
-  __syncthreads();
-  for (int t = tid; t < T; t += nthr) atomicMax(&owner[path32[t]], t);   // newtgt[:,path] = tgt: later frames win
-  __syncthreads();
-  for (int64_t e = tid; e < (int64_t)S * D; e += nthr) {
-    const int i = (int)(e / D), d = (int)(e % D);
-    const int k = owner[i];
-    P.newtgt[e] = (k >= 0) ? seq[(size_t)D * k + d] : 0.0;
-  }
-  __shared__ int nholes;
-  if (tid == 0) {                                   // hole = setdiff(path[1]:path[end], path), increasing order
-    int n = 0;
-    for (int i = path32[0]; i <= path32[T - 1]; ++i)
-      if (owner[i] < 0 && i > 0 && i < S - 1) holes[n++] = i;   // 1 < i < S in 1-based terms
-    nholes = n;
-  }
-  __syncthreads();
-  // each thread owns feature rows d, d+nthr, ...; a row's holes are filled in increasing i, as the reference does
-  for (int d = tid; d < D; d += nthr)
-    for (int h = 0; h < nholes; ++h) {
-      const int i = holes[h];
-      P.newtgt[(size_t)D * i + d] = (P.newtgt[(size_t)D * (i - 1) + d] + P.newtgt[(size_t)D * (i + 1) + d]) / 2.0;
-    }
+  dtw_align_post(P, seq, D, path32, owner, holes);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -629,30 +635,121 @@ dtw_fused_persistent_kernel(const double *__restrict__ base, int padded, const D
   }
 }
 
-// Backward pass + align epilogue of the fused path: one workgroup per pair.  The pair's packed step codes come back
-// from HBM / the Infinity Cache into LDS with coalesced loads (the backward pass is a chain of T dependent reads: it
-// has to run out of LDS), then dtw_finish does what it does for the other kernels.
-template <bool LDSCODES>
-__global__ void __launch_bounds__(256)
-dtw_fused_finish_kernel(const double *__restrict__ feats, const DtwPair *__restrict__ pairs, int D, int Smax, int Tmax,
-                        const uint32_t *__restrict__ fcodes_ws, const double *__restrict__ clast_ws) {
+// Backward pass of the fused path: ONE WAVE per pair, no LDS.  (Round 2's epilogue copied the pair's 64 KB of packed step
+// codes into LDS and let one thread chase T dependent LDS reads: 110 us for 1000 pairs, two workgroups per CU.)  The path
+// moves down by at most two rows per column (bstep <= 2, fstep = 0), so over the 16 columns of one code-word row it stays
+// within 33 rows: a wave keeps a WINDOW of 192 rows of that word row in three registers per lane (coalesced loads), the
+// walk itself is scalar -- v_readlane with the uniform row, shift, mask, subtract -- and the windows of the next three word
+// rows are in flight meanwhile (a window anchored at the current row r covers [r - 191, r]; the word row three blocks
+// ahead is entered at r - 64 or above and left at r - 96 or above).  Path values are collected one per lane, parked in LDS
+// per 64 columns (no global store inside the walk: loads and stores share vmcnt and complete out of order with respect
+// to each other, so with a store pending the compiler waits for vmcnt(0) before every block and the look-ahead is lost)
+// and leave at the end as coalesced stores: 0-based to path32_ws (for the align kernel), 1-based Int64 to the caller's path.
+__device__ __forceinline__ void dtw_window_load(const uint32_t *__restrict__ gc, int Se, int tb, int anchor, int lane, uint32_t (&w)[3]) {
+  // (unconditional -- beyond the first word row it re-reads row 0: the compiler can then count the loads in flight, with
+  // a conditional load it waits for vmcnt(0) before every block and the look-ahead is lost)
+  const uint32_t *rowp = gc + (size_t)(tb < 0 ? 0 : tb) * Se;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    int r = anchor - 191 + 64 * k + lane;
+    r = r < 0 ? 0 : (r >= Se ? Se - 1 : r);            // (rows the walk cannot reach)
+    w[k] = rowp[r];
+  }
+}
+
+__global__ void __launch_bounds__(64)
+dtw_fused_backward_kernel(const DtwPair *__restrict__ pairs, const uint32_t *__restrict__ fcodes_ws,
+                          const double *__restrict__ clast_ws, int32_t *__restrict__ path32_ws) {
+  extern __shared__ int32_t path_lds[];                 // [Tmax]
+  const int lane = threadIdx.x;
   const DtwPair P = pairs[blockIdx.x];
-  const int S = P.S, T = P.T, tid = threadIdx.x;
+  const int S = P.S, T = P.T;
   if (T == 0) return;
+  // indmin of the last column, first minimum wins (src/dtw.jl:137)
+  int row;
+  {
+    const double *cl = clast_ws + P.clast_off;
+    double bv = INFINITY;
+    int bi = 0x7fffffff;
+    for (int i = lane; i < S; i += 64) {
+      const double c = cl[i];
+      if (c < bv) { bv = c; bi = i; }
+    }
+#pragma unroll
+    for (int sh = 1; sh < 64; sh <<= 1) {
+      const double ov = __shfl_xor(bv, sh);
+      const int oi = __shfl_xor(bi, sh);
+      if (ov < bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    row = __builtin_amdgcn_readfirstlane(bi);
+  }
+  const int Se = (S + 1) & ~1;
+  const uint32_t *gc = fcodes_ws + P.fcodes_off;
+  int32_t *p32 = path32_ws + P.path32_off;
+  int64_t *p64 = P.path;
+  int acc = 0;                                          // lane l: path value of column 64 q + l of the current group q
+  auto flush = [&](int q) {
+    const int col = 64 * q + lane;
+    if (col < T) path_lds[col] = acc;
+  };
+  // path[c] = row, then the code of column c (for c >= 1) leads to path[c - 1] (src/dtw.jl:140-142)
+  auto walk = [&](int tb, const uint32_t (&w)[3], int anchor) {
+    const int thi = (16 * tb + 15 < T - 1) ? 16 * tb + 15 : T - 1, tlo = (16 * tb > 1) ? 16 * tb : 1;
+    for (int t = thi; t >= tlo; --t) {
+      const int idx = row - (anchor - 191);
+      const int l = idx & 63;
+      const uint32_t w0 = (uint32_t)__builtin_amdgcn_readlane((int)w[0], l), w1 = (uint32_t)__builtin_amdgcn_readlane((int)w[1], l),
+                     w2 = (uint32_t)__builtin_amdgcn_readlane((int)w[2], l);
+      const uint32_t word = (idx < 64) ? w0 : ((idx < 128) ? w1 : w2);
+      row -= (int)((word >> (2 * (t & 15))) & 3u);
+      const int c = t - 1;
+      if ((c & 63) == 63) flush((c + 1) >> 6);          // column c opens a new group: the finished one leaves
+      acc = (lane == (c & 63)) ? row : acc;
+    }
+  };
+  acc = (lane == ((T - 1) & 63)) ? row : acc;
+  uint32_t wa[3] = {0, 0, 0}, wb[3] = {0, 0, 0}, wc[3] = {0, 0, 0};
+  int aa = row, ab = row, ac = row;
+  int tb = (T - 1) >> 4;
+  dtw_window_load(gc, Se, tb, row, lane, wa);
+  dtw_window_load(gc, Se, tb - 1, row, lane, wb);
+  dtw_window_load(gc, Se, tb - 2, row, lane, wc);
+  for (; tb >= 0; tb -= 3) {
+    walk(tb, wa, aa);
+    aa = row;
+    dtw_window_load(gc, Se, tb - 3, row, lane, wa);
+    if (tb - 1 < 0) break;
+    walk(tb - 1, wb, ab);
+    ab = row;
+    dtw_window_load(gc, Se, tb - 4, row, lane, wb);
+    if (tb - 2 < 0) break;
+    walk(tb - 2, wc, ac);
+    ac = row;
+    dtw_window_load(gc, Se, tb - 5, row, lane, wc);
+  }
+  flush(0);
+  __syncthreads();
+  for (int col = lane; col < T; col += 64) {
+    const int v = path_lds[col];
+    p32[col] = v;
+    if (p64) p64[col] = (int64_t)v + 1;
+  }
+}
+
+// align() of the fused path: one workgroup per pair that wants `newtgt`, the path from path32_ws.
+__global__ void __launch_bounds__(256)
+dtw_fused_align_kernel(const double *__restrict__ feats, const DtwPair *__restrict__ pairs, int D, int Smax, int Tmax,
+                       const int32_t *__restrict__ path32_ws) {
+  const DtwPair P = pairs[blockIdx.x];
+  if (!P.newtgt || P.T == 0) return;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  const int Se = (S + 1) & ~1, SmaxE = (Smax + 1) & ~1;
-  double *clast = reinterpret_cast<double *>(smem_raw);               // [SmaxE]
-  int32_t *path32 = reinterpret_cast<int32_t *>(clast + SmaxE);       // [Tmax]
+  const int SmaxE = (Smax + 1) & ~1;
+  int32_t *path32 = reinterpret_cast<int32_t *>(smem_raw);            // [Tmax]
   int32_t *owner = path32 + Tmax;                                     // [SmaxE]
   int32_t *holes = owner + SmaxE;                                     // [SmaxE]
-  uint32_t *codes = reinterpret_cast<uint32_t *>(holes + SmaxE);      // [ceil(T/16)][Se] when LDSCODES
-  for (int i = tid; i < S; i += 256) clast[i] = clast_ws[P.clast_off + i];
-  const uint32_t *gc = fcodes_ws + P.fcodes_off;
-  const int nwords = ((T + 15) >> 4) * Se;
-  if (LDSCODES)
-    for (int i = tid; i < nwords; i += 256) codes[i] = gc[i];
+  for (int t = threadIdx.x; t < P.T; t += 256) path32[t] = path32_ws[P.path32_off + t];
   __syncthreads();
-  dtw_finish<LDSCODES, 2, true>(P, feats + P.seq_off, D, 0, clast, path32, owner, holes, LDSCODES ? codes : gc, Se);
+  dtw_align_post(P, feats + P.seq_off, D, path32, owner, holes);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -823,6 +920,7 @@ struct DtwScratch {
   DevBuf<unsigned char> ddesc;   // fused path: pair, strip and job descriptors of the call (one upload)
   DevBuf<uint32_t> fcodes;
   DevBuf<double> bnd, clast;
+  DevBuf<int32_t> path32;        // fused path: 0-based paths (dtw_fused_backward_kernel -> dtw_fused_align_kernel)
   DevBuf<int> flags;
   int epoch = 0;
   int init() {
@@ -896,9 +994,9 @@ static DtwScratch &scratch() {
 static inline size_t dtw_fused_lds_forward(int Tmax) {
   return (size_t)4 * VCMI_FUSED_OUTBOX + (size_t)2 * kFusedRows * 8 + ((size_t)Tmax + 1) * 16;
 }
-static inline size_t dtw_fused_lds_finish(int Smax, int Tmax) {
+static inline size_t dtw_fused_lds_finish(int Smax, int Tmax) {      // dtw_fused_align_kernel: path, owner, holes
   const size_t SmaxE = (size_t)((Smax + 1) & ~1);
-  return SmaxE * 8 + (size_t)Tmax * 4 + SmaxE * 8;
+  return (size_t)Tmax * 4 + SmaxE * 8;
 }
 static inline bool dtw_fused_fits(int Smax, int Tmax) {
   return dtw_fused_lds_forward(Tmax) <= kLdsLimit && dtw_fused_lds_finish(Smax, Tmax) <= kLdsLimit;
@@ -920,7 +1018,8 @@ static int dtw_run_fused(const double *feats, std::vector<DtwPair> &pairs, int D
   std::stable_sort(pairs.begin(), pairs.end(), [](const DtwPair &a, const DtwPair &b) {
     return (int64_t)a.S * a.T > (int64_t)b.S * b.T;
   });
-  size_t ncodes = 0, nclast = 0, nbnd = 0, padn = 0;
+  size_t ncodes = 0, nclast = 0, nbnd = 0, padn = 0, npath = 0;
+  bool any_align = false;
   int nflags = 0;
   // pass 1: the row strips of every pair, whole-length (col0 = 0, ncol = T): one-wave or wider bottom strips of long
   // templates (levels[0]), single-strip pairs, the strips above by level.
@@ -933,6 +1032,9 @@ static int dtw_run_fused(const double *feats, std::vector<DtwPair> &pairs, int D
     ncodes += (size_t)((p.T + 15) >> 4) * Se;
     p.clast_off = (int64_t)nclast;
     nclast += (size_t)p.S;
+    p.path32_off = (int64_t)npath;
+    npath += (size_t)p.T;
+    any_align = any_align || p.newtgt != nullptr;
     p.spad_off = (int64_t)padn;
     padn += (size_t)p.T * dmax;
     p.tpad_off = (int64_t)padn;
@@ -1076,6 +1178,7 @@ static int dtw_run_fused(const double *feats, std::vector<DtwPair> &pairs, int D
   if (strips.empty()) return VCMI_OK;
   VCMI_TRY(sc.fcodes.reserve(ncodes));
   VCMI_TRY(sc.clast.reserve(nclast));
+  VCMI_TRY(sc.path32.reserve(std::max<size_t>(npath, 1)));
   VCMI_TRY(sc.bnd.reserve(std::max<size_t>(nbnd, 1)));
   if ((size_t)nflags > sc.flags.n) {
     VCMI_TRY(sc.flags.reserve(std::max<size_t>((size_t)nflags, 1024)));
@@ -1138,19 +1241,15 @@ static int dtw_run_fused(const double *feats, std::vector<DtwPair> &pairs, int D
 #undef VCMI_FUSED_CASE
 #undef VCMI_FUSED_LAUNCH
   VCMI_HIP(hipGetLastError());
-  // backward + align
-  const size_t SmaxE = (size_t)((Smax + 1) & ~1);
-  const size_t shb = dtw_fused_lds_finish(Smax, Tmax);
-  const size_t shc = (size_t)((Tmax + 15) >> 4) * SmaxE * 4;
-  if (shb > kLdsLimit) return fail(VCMI_ERR_ARG, "DTW: template of %d frames exceeds the supported length", Smax);
-  if (shb + shc <= kLdsLimit) {
-    auto kern = dtw_fused_finish_kernel<true>;
-    VCMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(shb + shc)));
-    hipLaunchKernelGGL(kern, dim3(n), dim3(256), shb + shc, st, feats, dpairs, D, Smax, Tmax, sc.fcodes.p, sc.clast.p);
-  } else {
-    auto kern = dtw_fused_finish_kernel<false>;
+  // backward (a wave per pair), then align() for the pairs that want it
+  hipLaunchKernelGGL(dtw_fused_backward_kernel, dim3((unsigned)n), dim3(64), (size_t)Tmax * 4, st, dpairs, sc.fcodes.p, sc.clast.p,
+                     sc.path32.p);
+  if (any_align) {
+    const size_t shb = dtw_fused_lds_finish(Smax, Tmax);
+    if (shb > kLdsLimit) return fail(VCMI_ERR_ARG, "DTW: template of %d frames exceeds the supported length", Smax);
+    auto kern = dtw_fused_align_kernel;
     VCMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shb));
-    hipLaunchKernelGGL(kern, dim3(n), dim3(256), shb, st, feats, dpairs, D, Smax, Tmax, sc.fcodes.p, sc.clast.p);
+    hipLaunchKernelGGL(kern, dim3(n), dim3(256), shb, st, feats, dpairs, D, Smax, Tmax, sc.path32.p);
   }
   VCMI_HIP(hipGetLastError());
   VCMI_HIP(hipEventRecord(sc.last_use, st));
