@@ -695,7 +695,7 @@ def bench_dtw(args, world, rank):
                       f"DTW fit!+backward, path-only, D={D}" + (" (order-40 mel-cepstra with c0: bin/mcep.jl:12, src/align.jl:45)" if D == 41 else ""),
                       "D": D, "pairs_per_gpu": n,
                       "fstep": 0, "bstep": 2},
-           "roofline": {"bound": "valu", "kernel": ("dtw_fused_%skernel<%d,2> (+ dtw_fused_finish_kernel)" % ("persistent_" if D <= 41 and n > 512 else "", 41 if D == 41 else -(-D // 8) * 8)) if D <= 48 else
+           "roofline": {"bound": "valu", "kernel": ("dtw_fused_%skernel<%d,2> (+ dtw_fused_backward_kernel)" % ("persistent_" if D <= 41 and n > 512 else "", 41 if D == 41 else -(-D // 8) * 8)) if D <= 48 else
                         "dtw_obs_asm_kernel + dtw_rec_kernel (D > 48: observation matrix through HBM)",
                         "achieved": achieved, "peak": FP64_PEAK_TFLOPS / 2, "unit": "TFLOP/s",
                         "frac": achieved / (FP64_PEAK_TFLOPS / 2),
