@@ -949,6 +949,7 @@ def main():
 
     world, rank, _ = dist_setup(args.gpus)
     if args.debug_force:
+        os.environ["VCMI_TEST_HOOKS"] = "1"        # the hook is inert in a process started without it
         from voiceconversion_jl_amd import _lib
 
         _lib.debug_force(args.debug_force)

@@ -4,6 +4,7 @@ import sys
 import numpy as np
 import pytest
 
+os.environ.setdefault("VCMI_TEST_HOOKS", "1")       # enables the library's vcmi_debug_force test hook for this process
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

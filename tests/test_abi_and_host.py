@@ -154,3 +154,15 @@ def test_generated_asm_includes_match_their_generators(tmp_path):
         subprocess.run([sys.executable, os.path.join(ROOT, "tools", gen), str(out)], check=True)
         committed = open(os.path.join(ROOT, "voiceconversion.jl_amd", "csrc", inc), "rb").read()
         assert out.read_bytes() == committed, f"{inc} differs from what tools/{gen} generates"
+
+
+def test_debug_hook_is_inert_without_the_test_environment():
+    """vcmi_debug_force is a process-global switch of kernel selection that the product library exports for the parity tests
+    (VERDICT r2 hygiene): it must refuse unless the process was started with VCMI_TEST_HOOKS=1."""
+    import subprocess
+    import sys
+    code = ("import ctypes, sys; lib = ctypes.CDLL(%r); lib.vcmi_debug_force.argtypes = [ctypes.c_uint]; "
+            "sys.exit(0 if lib.vcmi_debug_force(32) == 0 else 3)" % os.path.join(ROOT, "voiceconversion.jl_amd", "libvcmi.so"))
+    env = {k: v for k, v in os.environ.items() if k != "VCMI_TEST_HOOKS"}
+    assert subprocess.run([sys.executable, "-c", code], env=env).returncode == 3
+    assert subprocess.run([sys.executable, "-c", code], env=dict(env, VCMI_TEST_HOOKS="1")).returncode == 0

@@ -1,3 +1,6 @@
+import os
+
+os.environ.setdefault("VCMI_TEST_HOOKS", "1")       # vcmi_debug_force is inert without it
 import sys; sys.path.insert(0,'.'); sys.path.insert(0,'tests')
 import numpy as np
 import voiceconversion_jl_amd as vc

@@ -1,5 +1,8 @@
 """Diagonal E-step outside the one-kernel shape (more than 128 mixtures, odd joint dimension): the MFMA paths against the
 generic kernels they replace on the automatic route.  (tools, GPU box.)"""
+import os
+
+os.environ.setdefault("VCMI_TEST_HOOKS", "1")       # vcmi_debug_force is inert without it
 import sys, time
 import numpy as np, torch
 sys.path.insert(0, ".")

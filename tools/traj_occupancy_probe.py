@@ -2,6 +2,9 @@
 VGPRs and ~67 KB of LDS, so two workgroups fit a CU; at D = 40 (428 VGPRs, 143 KB) only one does.  Times n = 256 and n = 512
 utterances of 2000 frames at D = 16: if 512 take about as long as 256, two independent scalar chains per CU overlap --
 what a two-solves-per-CU design at D = 40 would buy."""
+import os
+
+os.environ.setdefault("VCMI_TEST_HOOKS", "1")       # vcmi_debug_force is inert without it
 import sys, time
 import numpy as np, torch
 sys.path.insert(0, ".")

@@ -162,7 +162,8 @@ def get_devices():
     return [arr[i] for i in range(n.value)]
 
 
-# Test hook (NOT part of include/vcmi.h): force the fallback kernels a shape would not select by itself.
+# Test hook (NOT part of include/vcmi.h; inert unless VCMI_TEST_HOOKS=1 is in the environment when the library first sees
+# the call): force the fallback kernels a shape would not select by itself.
 DBG_TRAJ_GENERIC, DBG_TRAJ_G_SCALAR, DBG_GV_ONE_TEAM, DBG_PREDICT_TWO_PASS, DBG_ESTEP_GENERIC, DBG_DTW_TWO_KERNELS = 1, 2, 4, 8, 16, 32
 DBG_PREDICT_NO_EARLY_EXIT = 64
 DBG_TRAJ_ONE_WG_PER_CU = 128
@@ -172,4 +173,4 @@ DBG_DTW_NO_SEGMENTS, DBG_DTW_GRID_ORDER = 256, 512
 def debug_force(flags):
     lib.vcmi_debug_force.argtypes = [C.c_uint]
     lib.vcmi_debug_force.restype = _int
-    lib.vcmi_debug_force(int(flags))
+    check(lib.vcmi_debug_force(int(flags)))       # fails unless the process was started with VCMI_TEST_HOOKS=1

@@ -1,4 +1,5 @@
 // core.cpp -- error plumbing, device selection, version string of libvcmi.
+#include <cstdlib>
 #include "vcmi_common.hpp"
 
 #include <atomic>
@@ -33,8 +34,15 @@ bool debug_flag(unsigned which) { return (g_debug_flags.load(std::memory_order_r
 
 }  // namespace vcmi
 
-// test hook, deliberately absent from include/vcmi.h
+// Test hook, deliberately absent from include/vcmi.h: forces kernels a shape would not select by itself (A/B partners in
+// the parity tests, `bench.py --debug-force`).  It is a process-global switch, so it is inert unless the PROCESS was started
+// with VCMI_TEST_HOOKS=1 in its environment (tests/conftest.py sets it): a product process cannot be switched by accident.
 extern "C" int vcmi_debug_force(unsigned flags) {
+  static const bool enabled = [] {
+    const char *e = getenv("VCMI_TEST_HOOKS");
+    return e && e[0] == '1';
+  }();
+  if (!enabled) return vcmi::fail(VCMI_ERR_ARG, "vcmi_debug_force: test hooks are disabled (start the process with VCMI_TEST_HOOKS=1)");
   vcmi::g_debug_flags.store(flags);
   return VCMI_OK;
 }
