@@ -1107,7 +1107,6 @@ static int dtw_run_fused(const double *feats, std::vector<DtwPair> &pairs, int D
       }
     }
   }
-  if (const char *e = getenv("VCMI_DTW_NSEG")) nseg = std::max(1, atoi(e));      // experiments
   // pass 2: job order, segment by segment: packed groups of one-wave bottom strips (four per workgroup, padded with empty
   // strips), the other bottom strips, the single-strip pairs (largest first), the upper strips level by level.  A job
   // waits only for jobs earlier in the order: the strip below (same segment) and its own previous segment.
