@@ -1069,8 +1069,11 @@ static int dtw_run_fused(const double *feats, std::vector<DtwPair> &pairs, int D
   // jobs synchronise without agent-scope fences (see dtw_wait_flag): with one acquire / release pair per job the same
   // segment took 350k cycles instead of 250k and segments did not pay (1.72 / 1.68 / 1.74 / 1.82 / 2.43 ms for nseg = 1 / 2
   // / 3 / 4 / 8) -- which an earlier revision of this comment blamed on workgroup dispatch.  Now 1.69 / 1.52 / 1.50 / 1.51 /
-  // 1.49 / 1.50 / 1.52 / 1.57 ms for nseg = 1 / 2 / 3 / 4 / 5 / 6 / 8 / 10.  nseg minimises ceil(jobs / slots) / nseg with 2 % per
-  // extra segment for its prologue, segments of at least 64 columns, nothing cut when everything fits one round.  The
+  // 1.49 / 1.50 / 1.52 / 1.57 ms for nseg = 1 / 2 / 3 / 4 / 5 / 6 / 8 / 10.  nseg minimises ceil(jobs / slots) / nseg with 4 % per
+  // extra segment -- its prologue, and above all its TRAFFIC: every segment job loads its strip's template rows again, 0.1 GB
+  // per 1000 pairs and segment (0.39 GB at nseg = 1, 0.78 GB at nseg = 5, against 0.32 GB algorithmic), while the measured
+  // times are flat from nseg = 2 to 8, so fewer is better (3 for the benchmark batch) --, segments of at least 64 columns,
+  // nothing cut when everything fits one round.  The
   // segments are drawn from a ticket counter by persistent workgroups, one per slot (dtw_fused_persistent_kernel: 1.49 ms
   // against 1.53 ms with one workgroup per job in grid order at D = 40; the D = 48 kernel, whose persistent form spills 16
   // registers, stays with grid order: 1.77 against 1.80 ms).
@@ -1100,7 +1103,7 @@ static int dtw_run_fused(const double *feats, std::vector<DtwPair> &pairs, int D
     double best = 1e30;
     for (int c : {1, 2, 3, 4, 5, 6, 8}) {
       if (c > 1 && (!segments_allowed || tavg / c < 64 || base_jobs <= slots)) break;
-      const double t = std::ceil(base_jobs * c / slots) / c * (1.0 + 0.02 * (c - 1));
+      const double t = std::ceil(base_jobs * c / slots) / c * (1.0 + 0.04 * (c - 1));
       if (t < best - 1e-9) {
         best = t;
         nseg = c;
