@@ -17,9 +17,9 @@ for spec in ${@:-convert estep estep_full em_full dtw dtw:d41 traj traj:chunk100
   name=$w; extra=""
   [ "$var" = d41 ] && { name=dtw_d41; extra="--dim 41"; }
   [ "$var" = chunk100 ] && { name=traj_chunk100; extra="--chunk 100"; }
-  steps=10; [ $w = trajgv ] && steps=3
-  timeout 400 python3 $R/bench.py --workload $w --steps $steps --warmup 2 --pmc off $extra 2>/dev/null | tail -1 > $out/${name}_bench.json
-  timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_$name -- python3 $R/bench.py --workload $w --steps $steps --warmup 2 --cpu-seconds 0 --pmc off $extra > /dev/null 2>&1
+  steps=20; warm=5; [ $w = trajgv ] && { steps=5; warm=2; }     # as the driver's default run: two warm-up steps leave the clock ramping
+  timeout 400 python3 $R/bench.py --workload $w --steps $steps --warmup $warm --pmc off $extra 2>/dev/null | tail -1 > $out/${name}_bench.json
+  timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_$name -- python3 $R/bench.py --workload $w --steps $steps --warmup $warm --cpu-seconds 0 --pmc off $extra > /dev/null 2>&1
   f=$(find $out/prof_$name -name "*kernel_stats.csv" | head -1)
   [ -n "$f" ] && cp $f $out/${name}_kernel_stats.csv
   t=$(find $out/prof_$name -name "*kernel_trace.csv" | head -1)
