@@ -67,22 +67,36 @@ def source_hash():
     return h.hexdigest()[:16]
 
 
-def traffic_from_table(tr, kernel_prefix, wide_reads=False):
+# What FETCH_SIZE reports per byte actually fetched, by load type -- MI355X_MICROARCH.md (HBM section) gives the 16-byte
+# streaming case (half); tools/microbench_fetch.hip + tools/fetch_calibration.py replay the patterns of this library's
+# kernels on buffers of known size (profiles/r03_pmc/fetch_calibration.json): EVERY vector-memory load pattern tried (16
+# and 8 bytes per lane, streaming or 16 rows 320 bytes apart) reports exactly half, scalar loads (s_load) and every store
+# pattern report the bytes.  So FETCH is doubled for kernels that read through vector loads; the fused DTW kernel mixes
+# both (template rows by vector loads, sequence columns by scalar loads) and gets the share measured for it once.
+VECTOR_FETCH_FACTOR = 2.0
+# fused DTW kernel: of its FETCH_SIZE, the part that is vector loads (a probe build that points every lane's template loads at
+# one row leaves 227 of the 487 MB at D = 40 with three segments; 222 of 310 MB with whole-length jobs): 0.53 -> x 1.53
+DTW_FUSED_FETCH_FACTOR = 1.53
+
+
+def traffic_from_table(tr, kernel_prefix, fetch_factor=VECTOR_FETCH_FACTOR):
     """FETCH + WRITE bytes per bench step of every kernel whose name contains `kernel_prefix`, from a table made by
-    tools/pmc_traffic.sh.  KB counters x 1024; `wide_reads`: the kernel's reads are 16-byte-per-lane streams, for which
-    FETCH_SIZE reports half the bytes on gfx950 (MI355X_MICROARCH.md, HBM section) -- doubled here.  Other access widths
-    are uncalibrated and taken as they are (profiles/r03_pmc/README.txt)."""
+    tools/pmc_traffic.py.  KB counters x 1024, FETCH times `fetch_factor` (a number, or {substring of the kernel name:
+    factor} with "" as the default)."""
     total = None
     for k, v in tr.items():
         if k.startswith("_") or kernel_prefix not in k:
             continue
+        ff = fetch_factor
+        if isinstance(fetch_factor, dict):
+            ff = next((x for key, x in fetch_factor.items() if key and key in k), fetch_factor.get("", VECTOR_FETCH_FACTOR))
         f = v.get("FETCH_SIZE_KB_per_step", 0.0) * 1024.0
         w = v.get("WRITE_SIZE_KB_per_step", 0.0) * 1024.0
-        total = (total or 0.0) + (2.0 * f if wide_reads else f) + w
+        total = (total or 0.0) + ff * f + w
     return total
 
 
-def pmc_traffic(fname, kernel_prefixes, wide_reads=False, live=None):
+def pmc_traffic(fname, kernel_prefixes, fetch_factor=VECTOR_FETCH_FACTOR, live=None):
     """`roofline.traffic` and where it came from.  `live`: a table measured by THIS run (measure_traffic_live); otherwise
     the committed file profiles/r03_pmc/<fname> -- used only when its `_meta.source_hash` equals the hash of the sources
     the loaded library was built from; a stale file yields traffic = None and says so."""
@@ -101,20 +115,23 @@ def pmc_traffic(fname, kernel_prefixes, wide_reads=False, live=None):
             return None, {"source": f"profiles/{PMC_DIR}/{fname} REFUSED: collected at source hash {meta.get('source_hash')}, "
                                     f"the library sources are now {src}"}
         origin = {"source": f"profiles/{PMC_DIR}/{fname}", "source_hash": src, "collected": meta.get("collected")}
-    vals = [traffic_from_table(tr, k, wide_reads) for k in kernel_prefixes]
+    vals = [traffic_from_table(tr, k, fetch_factor) for k in kernel_prefixes]
     vals = [v for v in vals if v is not None]
     return (sum(vals) if vals else None), origin
 
 
-def attach_traffic(out, fname, kernel_prefixes, wide_reads=False, standard=True, live=None):
+def attach_traffic(out, fname, kernel_prefixes, fetch_factor=VECTOR_FETCH_FACTOR, standard=True, live=None):
     """Fill roofline.traffic (+ traffic_source).  `standard`: the run has the sizes the PMC passes were collected at."""
     roof = out["roofline"]
     if not standard and live is None:
         roof["traffic"], roof["traffic_source"] = None, {"source": "non-standard size: no PMC pass"}
         return
-    roof["traffic"], roof["traffic_source"] = pmc_traffic(fname, kernel_prefixes, wide_reads, live)
-    roof["traffic_unit"] = "HBM bytes per step, rocprofv3 FETCH_SIZE + WRITE_SIZE in separate passes" + \
-                           (", FETCH doubled (16-byte-per-lane reads, gfx950)" if wide_reads else ", raw")
+    roof["traffic"], roof["traffic_source"] = pmc_traffic(fname, kernel_prefixes, fetch_factor, live)
+    roof["traffic_raw"], _ = pmc_traffic(fname, kernel_prefixes, 1.0, live)
+    roof["traffic_unit"] = ("HBM bytes per step, rocprofv3 FETCH_SIZE + WRITE_SIZE in separate passes; FETCH x %s: on gfx950 the "
+                            "counter reports half the bytes of vector-memory loads (MI355X_MICROARCH.md for 16-byte streams; every "
+                            "pattern of this library in profiles/r03_pmc/fetch_calibration.json) and all the bytes of scalar loads; "
+                            "`traffic_raw` = FETCH + WRITE as counted" % (json.dumps(fetch_factor),))
 
 
 def measure_traffic_live(workload, extra=(), timeout=240):
@@ -512,7 +529,7 @@ def bench_estep(args, world, rank):
                         "flop_per_frame": estep_flops_per_frame(Dj, M), "kernel_ms": kernel_ms},
            "collective": {"op": "all-reduce(sum), %d doubles" % vc.stats_len(Dj, M), "allreduce_ms": allreduce_ms,
                           "step_ms_with_allreduce": step_ms, "ranks": world, "backend": BACKEND["name"]}}
-    attach_traffic(out, "estep_traffic.json", "estep_mfma_kernel", wide_reads=True, standard=(N == 1_250_000 and Dj == 80 and M == 128),
+    attach_traffic(out, "estep_traffic.json", "estep_mfma_kernel", standard=(N == 1_250_000 and Dj == 80 and M == 128),
                    live=LIVE_PMC.get("estep"))
     if rank == 0:
         from oracle import c_oracle as co
@@ -706,7 +723,9 @@ def bench_dtw(args, world, rank):
                                 "GEMM form, so the roof is one flop per lane-instruction = half the FMA/MFMA figure; "
                                 "`achieved` prices the whole step (forward + backward kernels) at 3*D+10 flop per cell",
                         "cells_per_s": cells / (kernel_ms * 1e-3), "kernel_ms": kernel_ms}}
-    attach_traffic(out, f"dtw{'' if D == 40 else '_d%d' % D}_traffic.json", "dtw_fused", standard=(n == 1000), live=LIVE_PMC.get("dtw"))
+    attach_traffic(out, f"dtw{'' if D == 40 else '_d%d' % D}_traffic.json", "dtw_fused",
+                   fetch_factor={"dtw_fused_persistent_kernel": DTW_FUSED_FETCH_FACTOR, "dtw_fused_kernel": DTW_FUSED_FETCH_FACTOR, "": VECTOR_FETCH_FACTOR},
+                   standard=(n == 1000), live=LIVE_PMC.get("dtw"))
     if rank == 0:
         from oracle import c_oracle as co
 

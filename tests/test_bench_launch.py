@@ -58,10 +58,12 @@ def test_roofline_traffic_is_refused_when_collected_from_other_sources(tmp_path,
     table = {"void vcmi::some_kernel<40>": {"FETCH_SIZE_KB_per_step": 1000.0, "WRITE_SIZE_KB_per_step": 500.0},
              "other": {"FETCH_SIZE_KB_per_step": 7.0}, "_meta": {"source_hash": h1, "collected": "now"}}
     (pm / "x_traffic.json").write_text(json.dumps(table))
-    v, src = bench.pmc_traffic("x_traffic.json", "some_kernel")
+    v, src = bench.pmc_traffic("x_traffic.json", "some_kernel", 1.0)                 # the counters as they are
     assert v == 1500.0 * 1024 and src["source_hash"] == h1
-    v, _ = bench.pmc_traffic("x_traffic.json", "some_kernel", wide_reads=True)       # FETCH doubled (16-byte-per-lane reads)
+    v, _ = bench.pmc_traffic("x_traffic.json", "some_kernel")                        # FETCH doubled: vector-memory loads (default)
     assert v == 2500.0 * 1024
+    v, _ = bench.pmc_traffic("x_traffic.json", "some_kernel", {"some_kernel<40>": 1.5, "": 2.0})     # per-kernel factor
+    assert v == 2000.0 * 1024
     (csrc / "k.hip").write_text("// kernel v2\n")                                    # the sources moved on
     assert bench.source_hash() != h1
     v, src = bench.pmc_traffic("x_traffic.json", "some_kernel")
@@ -69,5 +71,5 @@ def test_roofline_traffic_is_refused_when_collected_from_other_sources(tmp_path,
     v, src = bench.pmc_traffic("missing.json", "some_kernel")
     assert v is None and "missing" in src["source"]
     # a table measured by this run is taken as it is
-    v, src = bench.pmc_traffic("x_traffic.json", "some_kernel", live=table)
+    v, src = bench.pmc_traffic("x_traffic.json", "some_kernel", 1.0, live=table)
     assert v == 1500.0 * 1024 and "measured in this run" in src["source"]
