@@ -96,14 +96,31 @@ estep_stats_kernel(const double *__restrict__ X, int64_t n0, int64_t nfr, int Dj
   }
 }
 
-// stats[e] += sum over partial rows, in row order (deterministic)
+// stats[e] += sum over the partial rows, in a FIXED order (deterministic): four threads per element each add up every
+// fourth row in increasing order, then ((p0 + p1) + (p2 + p3)).  (One thread per element walking all rows one after the
+// other left two thirds of the CUs idle and took 64 us for the 256 rows of the benchmark E-step -- 4 % of the step.)
 __global__ void __launch_bounds__(256)
 estep_reduce_kernel(const double *__restrict__ part, int nrows, int64_t plen, double *__restrict__ stats) {
-  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (e >= plen) return;
-  double s = stats[e];
-  for (int r = 0; r < nrows; ++r) s += part[(size_t)r * plen + e];
-  stats[e] = s;
+  __shared__ double psum[4][64];
+  const int el = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int64_t e = (int64_t)blockIdx.x * 64 + el;
+  double s = 0.0;
+  if (e < plen) {
+    const double *p = part + e;
+    int r = q;
+    for (; r + 28 < nrows; r += 32) {              // eight independent loads in flight, added in row order
+      const double v0 = p[(size_t)r * plen], v1 = p[(size_t)(r + 4) * plen], v2 = p[(size_t)(r + 8) * plen], v3 = p[(size_t)(r + 12) * plen],
+                   v4 = p[(size_t)(r + 16) * plen], v5 = p[(size_t)(r + 20) * plen], v6 = p[(size_t)(r + 24) * plen], v7 = p[(size_t)(r + 28) * plen];
+      s += v0; s += v1; s += v2; s += v3; s += v4; s += v5; s += v6; s += v7;
+    }
+    for (; r < nrows; r += 4) s += p[(size_t)r * plen];
+  }
+  psum[q][el] = s;
+  __syncthreads();
+  if (q == 0 && e < plen) stats[e] += (psum[0][el] + psum[1][el]) + (psum[2][el] + psum[3][el]);
+}
+static inline void estep_reduce_launch(const double *part, int nrows, int64_t plen, double *stats, hipStream_t st) {
+  hipLaunchKernelGGL(estep_reduce_kernel, dim3((unsigned)((plen + 63) / 64)), dim3(256), 0, st, part, nrows, plen, stats);
 }
 
 // More than 128 mixtures (groups of 128, one PHASE 3 launch each): the responsibilities G_g[f][.] are normalised within
@@ -481,19 +498,22 @@ estep_mfma_kernel(const double *__restrict__ X, int64_t N, int M, const double *
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
-// Pinned, double-buffered staging for the (tiny) model parameters of the MFMA path: the copy to the device is a real
+// Pinned staging (a ring of slots) for the (tiny) model parameters of the MFMA path: the copy to the device is a real
 // asynchronous copy, the host buffers outlive the call, and nothing in the call waits for the GPU -- consecutive
 // E-steps queue back to back (the first version packed on the host and drained the stream before every launch:
 // 0.4 ms of a 2.3 ms step).
 struct EstepStaging {
-  double *host[2] = {nullptr, nullptr};
-  hipEvent_t copied[2] = {nullptr, nullptr};
+  // a ring of eight: a caller issuing E-steps back to back blocks on the event of the slot it is about to reuse, and a
+  // blocked host thread wakes up late on a busy machine -- with eight calls queued the GPU does not run dry meanwhile
+  static constexpr int kSlots = 8;
+  double *host[kSlots] = {};
+  hipEvent_t copied[kSlots] = {};
   size_t cap = 0;
   int next = 0;
   int reserve(size_t n) {
     if (n <= cap) return VCMI_OK;
     release();
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < kSlots; ++i) {
       VCMI_HIP(hipHostMalloc(reinterpret_cast<void **>(&host[i]), n * sizeof(double), hipHostMallocDefault));
       VCMI_HIP(hipEventCreateWithFlags(&copied[i], hipEventDisableTiming));
     }
@@ -501,7 +521,7 @@ struct EstepStaging {
     return VCMI_OK;
   }
   void release() {
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < kSlots; ++i) {
       if (host[i]) (void)hipHostFree(host[i]);
       if (copied[i]) (void)hipEventDestroy(copied[i]);
       host[i] = nullptr;
@@ -536,11 +556,6 @@ estep_prep_kernel(const double *__restrict__ raw, int M, int dj, double *__restr
   // operands of the exact re-evaluation (estep_mfma_kernel, "refinement"): 1/var in the parameters' own (dj,M) layout and
   // the constant WITHOUT the -mu^2/(2 var) term
   if (e < M * dj) refiv[e] = 1.0 / var[e];
-  if (e < M) {
-    double sl = 0.0;
-    for (int d = 0; d < dj; ++d) sl += log(var[d + (size_t)dj * e]);
-    refc[e] = (w[e] > 0.0 ? log(w[e]) : -INFINITY) - 0.5 * (dj * kLog2Pi + sl);
-  }
   if (e < 8 * C::KS * 64) {
     const int l = e & 63, ks = (e >> 6) % C::KS, mt = (e >> 6) / C::KS;
     const int m = 16 * mt + (l & 15), k = 4 * ks + (l >> 4);
@@ -552,18 +567,27 @@ estep_prep_kernel(const double *__restrict__ raw, int M, int dj, double *__restr
     }
     Wpack[e] = v;
   }
-  if (e < C::MMAX) {
-    double c = -INFINITY;
-    if (e < M) {
-      double sl = 0.0, t = 0.0;
-      for (int d = 0; d < dj; ++d) {
-        const double vv = var[d + (size_t)dj * e], mm = mu[d + (size_t)dj * e];
+  // the constants: sixteen lanes per mixture share the sums over d (log var is the expensive part: one thread per mixture
+  // walking all dj dimensions, twice, took 50 us), combined by xor butterflies -- a fixed order, the same in every lane
+  if (e < 16 * C::MMAX) {
+    const int m = e >> 4, l = e & 15;
+    double sl = 0.0, t = 0.0;
+    if (m < M)
+      for (int d = l; d < dj; d += 16) {
+        const double vv = var[d + (size_t)dj * m], mm = mu[d + (size_t)dj * m];
         sl += log(vv);
         t += mm * mm * (1.0 / vv);
       }
-      c = (w[e] > 0.0 ? log(w[e]) : -INFINITY) - 0.5 * (dj * kLog2Pi + sl) - 0.5 * t;
+#pragma unroll
+    for (int sh = 8; sh >= 1; sh >>= 1) {
+      sl += __shfl_xor(sl, sh);
+      t += __shfl_xor(t, sh);
     }
-    cinit[e] = c;
+    if (l == 0) {
+      const double base = (m < M) ? (w[m] > 0.0 ? log(w[m]) : -INFINITY) - 0.5 * (dj * kLog2Pi + sl) : -INFINITY;
+      if (m < M) refc[m] = base;            // the constant WITHOUT the -mu^2/(2 var) term (exact re-evaluation)
+      cinit[m] = (m < M) ? base - 0.5 * t : -INFINITY;
+    }
   }
 }
 
@@ -579,7 +603,7 @@ static int estep_mfma_launch(EstepScratch &sc, const double *dX, int64_t N, int 
   const int64_t nblocks = (N + C::FB - 1) / C::FB;
   const int grid = (int)std::min<int64_t>(nblocks, cus);
   const size_t nraw = (size_t)M * (1 + 2 * dj);
-  VCMI_TRY(sc.raw.reserve(2 * nraw));                  // one device copy per staging buffer
+  VCMI_TRY(sc.raw.reserve(EstepStaging::kSlots * nraw));                  // one device copy per staging buffer
   VCMI_TRY(sc.Wpack.reserve((size_t)8 * C::KS * 64));
   VCMI_TRY(sc.cinit.reserve((size_t)C::MMAX));
   VCMI_TRY(sc.refiv.reserve((size_t)M * dj));
@@ -591,8 +615,8 @@ static int estep_mfma_launch(EstepScratch &sc, const double *dX, int64_t N, int 
   VCMI_TRY(sc.part.reserve((size_t)grid * wpt * plen));
   VCMI_TRY(sc.stage.reserve(nraw));
   const int b = sc.stage.next;
-  sc.stage.next ^= 1;
-  VCMI_HIP(hipEventSynchronize(sc.stage.copied[b]));   // the copy that last used this buffer (two calls ago) is done
+  sc.stage.next = (sc.stage.next + 1) % EstepStaging::kSlots;
+  VCMI_HIP(hipEventSynchronize(sc.stage.copied[b]));   // the copy that last used this slot (eight calls ago) is done
   double *h = sc.stage.host[b], *draw = sc.raw.p + (size_t)b * nraw;
   memcpy(h, w, sizeof(double) * M);
   memcpy(h + M, mu, sizeof(double) * M * dj);
@@ -610,8 +634,7 @@ static int estep_mfma_launch(EstepScratch &sc, const double *dX, int64_t N, int 
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), C::LDS_BYTES, st, dX, N, M, sc.Wpack.p, sc.cinit.p, sc.part.p, plen, dmu,
                        sc.refiv.p, sc.refc.p, (double *)nullptr, dj, mtp);
     VCMI_HIP(hipGetLastError());
-    hipLaunchKernelGGL(estep_reduce_kernel, dim3((unsigned)((plen + 255) / 256)), dim3(256), 0, st, sc.part.p, grid * wpt, plen,
-                       dstats);
+    estep_reduce_launch(sc.part.p, grid * wpt, plen, dstats, st);
     VCMI_HIP(hipGetLastError());
   } else {
     // two kernels per chunk of frames, the responsibilities (frames x 128 doubles) through HBM in between
@@ -630,8 +653,7 @@ static int estep_mfma_launch(EstepScratch &sc, const double *dX, int64_t N, int 
       hipLaunchKernelGGL(ks, dim3(g2), dim3(512), C::LDS_BYTES, st, dX + n0 * dj, nfr, M, sc.Wpack.p, sc.cinit.p, sc.part.p, plen,
                          dmu, sc.refiv.p, sc.refc.p, sc.G.p, dj, mtp);
       VCMI_HIP(hipGetLastError());
-      hipLaunchKernelGGL(estep_reduce_kernel, dim3((unsigned)((plen + 255) / 256)), dim3(256), 0, st, sc.part.p, g2 * wpt, plen,
-                         dstats);
+      estep_reduce_launch(sc.part.p, g2 * wpt, plen, dstats, st);
       VCMI_HIP(hipGetLastError());
     }
   }
@@ -654,7 +676,7 @@ static int estep_mfma_groups_launch(EstepScratch &sc, const double *dX, int64_t 
   const int64_t chunk = std::min<int64_t>(N, (int64_t)1 << 18);
   const size_t nraw = (size_t)M * (1 + 2 * dj), wlen = (size_t)8 * C::KS * 64;
   constexpr int kCombineGrid = 1024;
-  VCMI_TRY(sc.raw.reserve(2 * nraw));
+  VCMI_TRY(sc.raw.reserve(EstepStaging::kSlots * nraw));
   VCMI_TRY(sc.Wpack.reserve(wlen * ng));
   VCMI_TRY(sc.cinit.reserve((size_t)C::MMAX * ng));
   VCMI_TRY(sc.refiv.reserve((size_t)M * dj));
@@ -664,7 +686,7 @@ static int estep_mfma_groups_launch(EstepScratch &sc, const double *dX, int64_t 
   VCMI_TRY(sc.part.reserve((size_t)cus * ((size_t)C::MMAX * (1 + 2 * dj) + 1)));
   VCMI_TRY(sc.stage.reserve(nraw));
   const int b = sc.stage.next;
-  sc.stage.next ^= 1;
+  sc.stage.next = (sc.stage.next + 1) % EstepStaging::kSlots;
   VCMI_HIP(hipEventSynchronize(sc.stage.copied[b]));
   double *h = sc.stage.host[b], *draw = sc.raw.p + (size_t)b * nraw;
   std::vector<size_t> goff((size_t)ng + 1, 0);
@@ -819,8 +841,7 @@ static int estep_device_run(const double *dX, int64_t N, int Dj, int M, const do
                        sc.mu.p, sc.iv.p, sc.cst.p, sc.G.p, sc.LSE.p);
     hipLaunchKernelGGL(estep_stats_kernel, dim3(nseg, (M * Dj + 255) / 256), dim3(256), 0, st, dX, n0, nfr, Dj, M, sc.G.p,
                        sc.LSE.p, sc.part.p, plen);
-    hipLaunchKernelGGL(estep_reduce_kernel, dim3((unsigned)((plen + 255) / 256)), dim3(256), 0, st, sc.part.p, nseg, plen,
-                       dstats);
+    estep_reduce_launch(sc.part.p, nseg, plen, dstats, st);
     VCMI_HIP(hipGetLastError());
   }
   return VCMI_OK;
@@ -1157,8 +1178,7 @@ static int estep_full_core_run(vcmi_gmmmap *px, const double *dX, int64_t N, int
                          sc.part.p, plen);
     }
     // the loglik slot of the partial rows is zero, so the generic reduction leaves dstats[plen-1] (set above) intact
-    hipLaunchKernelGGL(estep_reduce_kernel, dim3((unsigned)((plen + 255) / 256)), dim3(256), 0, st, sc.part.p, nseg, plen,
-                       dstats);
+    estep_reduce_launch(sc.part.p, nseg, plen, dstats, st);
     VCMI_HIP(hipGetLastError());
   }
   return VCMI_OK;
