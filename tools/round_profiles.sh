@@ -11,12 +11,16 @@ R=$GRAFT_REPO_ROOT
 out=$R/gpurun_out/$tag
 mkdir -p $out $out/pmc $out/clock
 cd /tmp && export TMPDIR=/tmp
-( time python3 $R/bench.py --steps 20 --warmup 5 > $out/all_bench.json 2> $out/all_bench.err ) 2> $out/all_bench.time
 for spec in ${@:-convert estep estep_full em_full dtw dtw:d41 traj traj:chunk100 trajgv}; do
   w=${spec%%:*}; var=${spec#*:}; [ "$var" = "$spec" ] && var=""
   name=$w; extra=""
   [ "$var" = d41 ] && { name=dtw_d41; extra="--dim 41"; }
   [ "$var" = chunk100 ] && { name=traj_chunk100; extra="--chunk 100"; }
+  # the PMC passes first: installed into this box's copy of profiles/<tag>_pmc/, so that the bench lines below (and the
+  # default command at the end) quote traffic stamped with the hash of the sources they run
+  python3 $R/tools/pmc_traffic.py $w --out $out/pmc_$name $extra > /dev/null 2>&1
+  [ -f $out/pmc_$name/traffic.json ] && { cp $out/pmc_$name/traffic.json $out/pmc/${name}_traffic.json; mkdir -p $R/profiles/${tag}_pmc; cp $out/pmc_$name/traffic.json $R/profiles/${tag}_pmc/${name}_traffic.json; }
+  rm -rf $out/pmc_$name
   steps=20; warm=5; [ $w = trajgv ] && { steps=5; warm=2; }     # as the driver's default run: two warm-up steps leave the clock ramping
   timeout 400 python3 $R/bench.py --workload $w --steps $steps --warmup $warm --pmc off $extra 2>/dev/null | tail -1 > $out/${name}_bench.json
   timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_$name -- python3 $R/bench.py --workload $w --steps $steps --warmup $warm --cpu-seconds 0 --pmc off $extra > /dev/null 2>&1
@@ -33,11 +37,10 @@ for i, r in enumerate(rows):
     print(f'{i},"{r["Kernel_Name"].split("(")[0][:70]}",{(int(r["Start_Timestamp"]) - t0) / 1e3:.1f},{(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3:.2f}')
 PY
   rm -rf $out/prof_$name
-  python3 $R/tools/pmc_traffic.py $w --out $out/pmc_$name $extra > /dev/null 2>&1
-  [ -f $out/pmc_$name/traffic.json ] && cp $out/pmc_$name/traffic.json $out/pmc/${name}_traffic.json
-  rm -rf $out/pmc_$name
   python3 $R/tools/clock_pmc.py $w --out $out/clk_$name $extra > /dev/null 2>&1
   [ -f $out/clk_$name/clock.json ] && cp $out/clk_$name/clock.json $out/clock/${name}_clock.json
   rm -rf $out/clk_$name
   echo "$name: $(cut -c1-200 $out/${name}_bench.json | grep -o '"value": [0-9.e+]*\|ms_per_step": [0-9.]*' | tr '\n' ' ')"
 done
+( time python3 $R/bench.py --steps 20 --warmup 5 > $out/all_bench.json 2> $out/all_bench.err ) 2> $out/all_bench.time
+echo "default command: $(cat $out/all_bench.time | tr '\n' ' ')"
