@@ -543,6 +543,12 @@ static EstepScratch &scratch() {
 }
 
 
+// model parameters: pinned host slot -> device
+__global__ void __launch_bounds__(256) estep_param_copy_kernel(const double *__restrict__ src, double *__restrict__ dst, size_t n) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) dst[i] = src[i];
+}
+
 // raw = [w (M) | mu (DJ,M) | var (DJ,M)] on the device -> the MFMA kernel's operands:
 //   Wpack[mt][ks][lane]: A-operand fragments of W[m][k], k < DJ -> -1/(2 var) (multiplies x^2), k >= DJ -> mu/var
 //   cinit[m] = log w - (DJ log 2pi + sum log var)/2 - sum mu^2/(2 var)   (-inf for m >= M and for zero weights)
@@ -621,7 +627,9 @@ static int estep_mfma_launch(EstepScratch &sc, const double *dX, int64_t N, int 
   memcpy(h, w, sizeof(double) * M);
   memcpy(h + M, mu, sizeof(double) * M * dj);
   memcpy(h + M + (size_t)M * dj, var, sizeof(double) * M * dj);
-  VCMI_HIP(hipMemcpyAsync(draw, h, nraw * sizeof(double), hipMemcpyHostToDevice, st));
+  // (a copy kernel reading the pinned slot, not hipMemcpyAsync: the copy engine's hand-over to the compute queue costs
+  // ~20 us of idle GPU per call, a kernel on the same queue a few)
+  hipLaunchKernelGGL(estep_param_copy_kernel, dim3((unsigned)((nraw + 255) / 256)), dim3(256), 0, st, h, draw, nraw);
   VCMI_HIP(hipEventRecord(sc.stage.copied[b], st));
   hipLaunchKernelGGL(estep_prep_kernel<DJ>, dim3((8 * C::KS * 64 + 255) / 256), dim3(256), 0, st, draw, M, dj, sc.Wpack.p,
                      sc.cinit.p, sc.refiv.p, sc.refc.p);
@@ -698,7 +706,9 @@ static int estep_mfma_groups_launch(EstepScratch &sc, const double *dX, int64_t 
     memcpy(hg + Mg + (size_t)Mg * dj, var + (size_t)dj * m0, sizeof(double) * Mg * dj);
     goff[(size_t)g + 1] = goff[(size_t)g] + (size_t)Mg * (1 + 2 * dj);
   }
-  VCMI_HIP(hipMemcpyAsync(draw, h, nraw * sizeof(double), hipMemcpyHostToDevice, st));
+  // (a copy kernel reading the pinned slot, not hipMemcpyAsync: the copy engine's hand-over to the compute queue costs
+  // ~20 us of idle GPU per call, a kernel on the same queue a few)
+  hipLaunchKernelGGL(estep_param_copy_kernel, dim3((unsigned)((nraw + 255) / 256)), dim3(256), 0, st, h, draw, nraw);
   VCMI_HIP(hipEventRecord(sc.stage.copied[b], st));
   for (int g = 0; g < ng; ++g) {
     const int m0 = g * C::MMAX, Mg = std::min(C::MMAX, M - m0);
