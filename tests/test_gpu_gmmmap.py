@@ -97,7 +97,7 @@ def test_two_pass_predict_matches_in_kernel_argmax(vc):
     assert np.array_equal(one, two) and np.array_equal(one, co.GMMMap(w, mu, sig).predict(X))
 
 
-@pytest.mark.parametrize("D,M,T", [(40, 64, 5000), (80, 32, 3000), (24, 9, 700), (17, 3, 50), (16, 2, 16)])
+@pytest.mark.parametrize("D,M,T", [(40, 64, 5000), (80, 32, 3000), (80, 64, 4097), (24, 9, 700), (17, 3, 50), (16, 2, 16), (40, 200, 333)])
 def test_predict_early_exit_is_exact(vc, D, M, T):
     """predict(px, X) stops the whitening of a mixture as soon as its partial |z|^2 shows that it cannot be the first
     maximum of any of a tile's 16 frames (MODE 3: the tiles run last first).  The indices must equal those of the kernel
