@@ -1135,11 +1135,10 @@ px_prep_kernel(const double *__restrict__ w, const double *__restrict__ mu, cons
     const double sd = sqrt(d);
     for (int i = j + tid; i < D; i += 256) S[i * LD + j] = (i == j) ? sd : S[i * LD + j] / sd;
     __syncthreads();
-    const int n = D - 1 - j;
-    for (int e = tid; e < n * n; e += 256) {
-      const int ii = e / n, kk = e - ii * n;
-      const int i = j + 1 + ii, k = j + 1 + kk;
-      if (i >= k) S[i * LD + k] = fma(-S[i * LD + j], S[k * LD + j], S[i * LD + k]);
+    // trailing update of the lower triangle, threads as a 16 x 16 grid over (row, column): no division per element
+    for (int i = j + 1 + (tid >> 4); i < D; i += 16) {
+      const double lij = S[i * LD + j];
+      for (int k = j + 1 + (tid & 15); k <= i; k += 16) S[i * LD + k] = fma(-lij, S[k * LD + j], S[i * LD + k]);
     }
     __syncthreads();
   }
@@ -1147,9 +1146,18 @@ px_prep_kernel(const double *__restrict__ w, const double *__restrict__ mu, cons
     const int c = tid;
     V[c * LD + c] = 1.0 / S[c * LD + c];
     for (int i = c + 1; i < D; ++i) {
-      double s = 0.0;
-      for (int k = c; k < i; ++k) s = fma(S[i * LD + k], V[k * LD + c], s);
-      V[i * LD + c] = -s / S[i * LD + i];
+      // four partial sums: the LDS reads of a run of k are independent of each other and stay in flight together (one sum:
+      // every multiply-add waited for its own two reads, ~130 cycles each, 3200 of them per column)
+      double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+      int k = c;
+      for (; k + 3 < i; k += 4) {
+        s0 = fma(S[i * LD + k], V[k * LD + c], s0);
+        s1 = fma(S[i * LD + k + 1], V[(k + 1) * LD + c], s1);
+        s2 = fma(S[i * LD + k + 2], V[(k + 2) * LD + c], s2);
+        s3 = fma(S[i * LD + k + 3], V[(k + 3) * LD + c], s3);
+      }
+      for (; k < i; ++k) s0 = fma(S[i * LD + k], V[k * LD + c], s0);
+      V[i * LD + c] = -((s0 + s1) + (s2 + s3)) / S[i * LD + i];
     }
   }
   __syncthreads();
