@@ -167,6 +167,7 @@ def get_devices():
 DBG_TRAJ_GENERIC, DBG_TRAJ_G_SCALAR, DBG_GV_ONE_TEAM, DBG_PREDICT_TWO_PASS, DBG_ESTEP_GENERIC, DBG_DTW_TWO_KERNELS = 1, 2, 4, 8, 16, 32
 DBG_PREDICT_NO_EARLY_EXIT = 64
 DBG_TRAJ_ONE_WG_PER_CU = 128
+DBG_CONVERT_NO_GROUPING = 2048
 DBG_DTW_NO_SEGMENTS, DBG_DTW_GRID_ORDER = 256, 512
 
 

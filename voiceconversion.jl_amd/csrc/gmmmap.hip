@@ -142,7 +142,12 @@ __device__ __forceinline__ double vc_exp(double x) {
 template <int DP, int FT, int WAVES, int MODE, int NBUF>
 __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(DP <= 40 ? (FT == 2 ? 3 : 4) : 2)))
 gmmmap_mfma_kernel(const double *__restrict__ packed, int M, int D, const double *__restrict__ X, int64_t ldx,
-                   int64_t T, double *__restrict__ Y, int64_t ldy, double prune, unsigned long long *__restrict__ nreg) {
+                   int64_t T, double *__restrict__ Y, int64_t ldy, double prune, unsigned long long *__restrict__ nreg,
+                   const int *__restrict__ perm, const int *__restrict__ gkey) {
+  // perm / gkey (MODE 0, optional): frames GROUPED by (approximate) mixture -- position fr of the launch is frame perm[fr],
+  // gkey[frame] its group -- see gmmmap_group_* below: a 16-frame tile then holds frames of one mixture, the workgroup starts
+  // its mixture loop at that mixture, the running maximum is tight from the first iteration and the pruning removes (almost)
+  // every other regression.  Frames are independent of each other, so the results do not depend on the grouping.
   using TL = Tiling<DP, MODE >= 1>;
   constexpr int KS = TL::KS, NT = TL::NT, NU = TL::NU, BLK = TL::BLK;
   constexpr int NTHREADS = WAVES * 64;
@@ -164,14 +169,23 @@ gmmmap_mfma_kernel(const double *__restrict__ packed, int M, int D, const double
 
   // B operands: xb[f][ks] = X[k = 4 ks + lgrp][frame = frame0 + 16 f + lcol], zero outside (D, T)
   double xb[FT][KS];
+  int64_t frow[FT];              // the frame a tile column stands for (perm: grouped launch)
 #pragma unroll
   for (int f = 0; f < FT; ++f) {
     const int64_t fr = frame0 + 16 * f + lcol;
+    frow[f] = (MODE == 0 && perm != nullptr && fr < T) ? (int64_t)perm[fr] : fr;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       const int k = 4 * ks + lgrp;
-      xb[f][ks] = (fr < T && k < D) ? X[fr * ldx + k] : 0.0;
+      xb[f][ks] = (fr < T && k < D) ? X[frow[f] * ldx + k] : 0.0;
     }
+  }
+  // first mixture of the loop: the group of the workgroup's first frame (grouped launch), else 0
+  int mfirst = 0;
+  if (MODE == 0 && perm != nullptr) {
+    const int64_t f0 = (int64_t)blockIdx.x * WAVES * (16 * FT);
+    mfirst = (f0 < T) ? gkey[perm[f0]] : 0;
+    mfirst = (mfirst >= 0 && mfirst < M) ? mfirst : 0;
   }
 
   int nreg_wave = 0;              // MODE 0: (tile, mixture) regressions this wave evaluated (diagnostic counter, see nreg)
@@ -191,9 +205,9 @@ gmmmap_mfma_kernel(const double *__restrict__ packed, int M, int D, const double
     for (int j = 0; j < KS; ++j) yacc[f][j] = 0.0;
   }
 
-  // stage block 0
+  // stage the first block
   {
-    const double2 *src = reinterpret_cast<const double2 *>(packed);
+    const double2 *src = reinterpret_cast<const double2 *>(packed + (size_t)mfirst * BLK);
     double2 *dst = reinterpret_cast<double2 *>(smem);
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -203,15 +217,16 @@ gmmmap_mfma_kernel(const double *__restrict__ packed, int M, int D, const double
   }
   __syncthreads();
 
-  for (int m = 0; m < M; ++m) {
-    const double *cur = smem + (NBUF == 2 ? (m & 1) * BLK : 0);
-    double2 *nxt = reinterpret_cast<double2 *>(smem + (NBUF == 2 ? ((m + 1) & 1) * BLK : 0));
+  for (int mi = 0; mi < M; ++mi) {
+    const int m = (mfirst + mi < M) ? mfirst + mi : mfirst + mi - M;       // mixtures in rotated order (mfirst = 0: index order)
+    const double *cur = smem + (NBUF == 2 ? (mi & 1) * BLK : 0);
+    double2 *nxt = reinterpret_cast<double2 *>(smem + (NBUF == 2 ? ((mi + 1) & 1) * BLK : 0));
     // prefetch block m+1 into registers (global -> VGPR), written to LDS after the MFMA work
     // (unconditional: the last iteration re-reads its own block, which keeps `pre` in registers and the loop
     // body free of exec-mask branches)
     double2 pre[NV];
     {
-      const int mn = (m + 1 < M) ? m + 1 : m;
+      const int mn = (mi + 1 < M) ? ((m + 1 < M) ? m + 1 : 0) : m;
       const double2 *src = reinterpret_cast<const double2 *>(packed + (size_t)mn * BLK);
 #pragma unroll
       for (int i = 0; i < NV; ++i) pre[i] = src[tid + i * NTHREADS];
@@ -443,7 +458,7 @@ gmmmap_mfma_kernel(const double *__restrict__ packed, int M, int D, const double
 #pragma unroll
         for (int j = 0; j < KS; ++j) {
           const int row = 4 * j + lgrp;
-          if (row < D) Y[fr * ldy + row] = yacc[f][j] * inv;
+          if (row < D) Y[frow[f] * ldy + row] = yacc[f][j] * inv;
         }
       }
     }
@@ -772,11 +787,117 @@ convert_from_logdens_kernel(const double *__restrict__ LP, int M, int D, int DP,
 }
 
 // ------------------------------------------------------------------------------------------------
+// Grouping of the frames before fvconvert (gmmmap_mfma_kernel MODE 0 with perm / gkey).
+// The pruning of the convert kernel works per 16-frame tile: a regression is skipped when NONE of the tile's frames gives the
+// mixture a posterior above e^-prune.  Frames that arrive in an order unrelated to their mixtures (the benchmark draws them
+// independently: ~14 of 64 mixtures own a frame of a tile, and the loop meets ~24 before its running maximum is tight) make
+// that union large; the same frames grouped by mixture leave one or two.  The grouping does not have to be right -- any
+// permutation gives the same y, frame by frame -- only cheap and mostly right: the NEAREST SOURCE MEAN (Euclidean), one
+// small MFMA product per tile ([-2 mu | |mu|^2] x [x ; 1], 44 MFMAs per 16 frames at D = 40, M = 64 against 2400 for the
+// conversion).  Three kernels: keys + histogram, prefix, counting-sort scatter (ranks inside a workgroup from LDS atomics,
+// one global atomic per workgroup and mixture; the order inside a group is arbitrary and does not matter).
+// gfrag[mt][ks][lane]: A-operand fragments, rows = mixtures 16 mt + (lane & 15), k = 4 ks + (lane >> 4); the last k-step
+// carries |mu|^2 (rows >= M: 1e300, never the minimum).
+// ------------------------------------------------------------------------------------------------
+template <int DP>
+__global__ void __launch_bounds__(256)
+gmmmap_group_key_kernel(const double *__restrict__ gfrag, int M, int D, const double *__restrict__ X, int64_t ldx, int64_t T,
+                        int *__restrict__ key, int *__restrict__ cnt) {
+  constexpr int KS = DP / 4, KS1 = KS + 1;
+  extern __shared__ double gsm[];
+  const int MT = (M + 15) / 16, nfrag = MT * KS1 * 64;
+  int *hist = reinterpret_cast<int *>(gsm + nfrag);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lcol = lane & 15, lgrp = lane >> 4;
+  for (int e = tid; e < nfrag; e += 256) gsm[e] = gfrag[e];
+  for (int m = tid; m < M; m += 256) hist[m] = 0;
+  __syncthreads();
+  const double one = (lgrp == 0) ? 1.0 : 0.0;
+  for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile * 16 < T; tile += (int64_t)gridDim.x * 4) {
+    const int64_t fr = tile * 16 + lcol;
+    double xb[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int k = 4 * ks + lgrp;
+      xb[ks] = (fr < T && k < D) ? X[fr * ldx + k] : 0.0;
+    }
+    double best = INFINITY;
+    int bm = 0;
+    for (int mt = 0; mt < MT; ++mt) {
+      const double *A = gsm + (size_t)mt * KS1 * 64 + lane;
+      d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(A[ks * 64], xb[ks], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(A[KS * 64], one, acc, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (acc[r] < best) {
+          best = acc[r];
+          bm = 16 * mt + 4 * r + lgrp;
+        }
+    }
+#pragma unroll
+    for (int sh = 16; sh < 64; sh <<= 1) {
+      const double ov = __shfl_xor(best, sh);
+      const int om = __shfl_xor(bm, sh);
+      if (ov < best || (ov == best && om < bm)) {
+        best = ov;
+        bm = om;
+      }
+    }
+    if (lgrp == 0 && fr < T) {
+      bm = bm < M ? bm : 0;
+      key[fr] = bm;
+      atomicAdd(&hist[bm], 1);
+    }
+  }
+  __syncthreads();
+  for (int m = tid; m < M; m += 256)
+    if (hist[m]) atomicAdd(&cnt[m], hist[m]);
+}
+
+// cursor[m] = first position of group m (exclusive prefix of the counts)
+__global__ void __launch_bounds__(64) gmmmap_group_scan_kernel(const int *__restrict__ cnt, int M, int *__restrict__ cursor) {
+  if (threadIdx.x == 0) {
+    int pos = 0;
+    for (int m = 0; m < M; ++m) {
+      cursor[m] = pos;
+      pos += cnt[m];
+    }
+  }
+}
+
+// perm: frames in group order.  1024 frames per workgroup: local ranks by LDS atomics, one range per (workgroup, group)
+__global__ void __launch_bounds__(256)
+gmmmap_group_scatter_kernel(const int *__restrict__ key, int64_t T, int M, int *__restrict__ cursor, int *__restrict__ perm) {
+  extern __shared__ int lcnt[];            // [M] counts, then [M] bases
+  int *base = lcnt + M;
+  const int tid = threadIdx.x;
+  for (int m = tid; m < M; m += 256) lcnt[m] = 0;
+  __syncthreads();
+  const int64_t f0 = (int64_t)blockIdx.x * 1024;
+  int k[4], r[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int64_t fr = f0 + tid + 256 * i;
+    k[i] = fr < T ? key[fr] : -1;
+    r[i] = k[i] >= 0 ? atomicAdd(&lcnt[k[i]], 1) : 0;
+  }
+  __syncthreads();
+  for (int m = tid; m < M; m += 256) base[m] = lcnt[m] ? atomicAdd(&cursor[m], lcnt[m]) : 0;
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int64_t fr = f0 + tid + 256 * i;
+    if (k[i] >= 0) perm[base[k[i]] + r[i]] = (int)fr;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // launch helpers
 // ------------------------------------------------------------------------------------------------
 template <int DP, int MODE, int FTV, int WV>
 static int launch_mfma(const vcmi_gmmmap *g, const double *dX, int64_t ldx, int64_t T, double *dY, int64_t ldy,
-                       hipStream_t st) {
+                       hipStream_t st, const int *perm = nullptr, const int *gkey = nullptr) {
   constexpr int FT = (MODE >= 1) ? 2 : FTV;
   constexpr int WAVES = WV;
   using TL = Tiling<DP, MODE >= 1>;
@@ -796,17 +917,18 @@ static int launch_mfma(const vcmi_gmmmap *g, const double *dX, int64_t ldx, int6
   const int64_t per_wg = (int64_t)16 * FT * WAVES;
   const int64_t blocks = (T + per_wg - 1) / per_wg;
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(WAVES * 64), shmem, st, MODE == 3 ? g->packedU2.p : (MODE >= 1 ? g->packedU.p : g->packed.p), g->M,
-                     g->D, dX, ldx, T, dY, ldy, g->prune, MODE == 0 ? g->prune_count.p : nullptr);
+                     g->D, dX, ldx, T, dY, ldy, g->prune, MODE == 0 ? g->prune_count.p : nullptr, MODE == 0 ? perm : nullptr,
+                     MODE == 0 ? gkey : nullptr);
   VCMI_HIP(hipGetLastError());
   return VCMI_OK;
 }
 
 template <int MODE>
 static int dispatch_mfma(const vcmi_gmmmap *g, const double *dX, int64_t ldx, int64_t T, double *dY, int64_t ldy,
-                         hipStream_t st) {
+                         hipStream_t st, const int *perm = nullptr, const int *gkey = nullptr) {
   switch (g->DP) {
 #define VCMI_CASE(DPV) \
-  case DPV: return launch_mfma<DPV, MODE, ((DPV) <= 48 ? 2 : 1), 4>(g, dX, ldx, T, dY, ldy, st);
+  case DPV: return launch_mfma<DPV, MODE, ((DPV) <= 48 ? 2 : 1), 4>(g, dX, ldx, T, dY, ldy, st, perm, gkey);
     VCMI_CASE(16) VCMI_CASE(20) VCMI_CASE(24) VCMI_CASE(28) VCMI_CASE(32) VCMI_CASE(36) VCMI_CASE(40) VCMI_CASE(44)
     VCMI_CASE(48) VCMI_CASE(52) VCMI_CASE(56) VCMI_CASE(60) VCMI_CASE(64) VCMI_CASE(68) VCMI_CASE(72) VCMI_CASE(76)
     VCMI_CASE(80)
@@ -850,7 +972,39 @@ int gmmmap_convert_device(vcmi_gmmmap *g, const double *dX, int64_t ldx, int64_t
   if (T == 0) return VCMI_OK;
   if (g->kernel_choice == 2 && !gmmmap_has_mfma(g->DP))
     return fail(VCMI_ERR_ARG, "MFMA kernel forced but dimension %d has no instantiation", g->D);
-  if (use_mfma(g)) return dispatch_mfma<0>(g, dX, ldx, T, dY, ldy, st);
+  if (use_mfma(g)) {
+    // frames grouped by their nearest source mean first (see gmmmap_group_key_kernel): worth its three small kernels from a
+    // few thousand frames on; the prune = +inf (dense) setting has nothing to gain from it
+    const int MT = (g->M + 15) / 16;
+    const size_t gshmem = (size_t)MT * (g->DP / 4 + 1) * 64 * sizeof(double) + (size_t)g->M * sizeof(int);
+    if (T >= 8192 && T < ((int64_t)1 << 31) && g->M >= 4 && g->gfrag.p && gshmem <= 64 * 1024 && g->prune < 1e300 &&
+        !debug_flag(kDbgConvertNoGrouping)) {
+      VCMI_TRY(g->grp.reserve((size_t)2 * T + 2 * g->M));
+      VCMI_TRY(g->grp_order.enter(st));
+      int *key = g->grp.p, *perm = key + T, *cnt = perm + T, *cursor = cnt + g->M;
+      VCMI_HIP(hipMemsetAsync(cnt, 0, (size_t)g->M * sizeof(int), st));
+      int cus = 256;
+      (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, g->device);
+      const unsigned kgrid = (unsigned)std::min<int64_t>((T + 63) / 64, (int64_t)cus * 8);
+      switch (g->DP) {
+#define VCMI_CASE(DPV) \
+  case DPV: hipLaunchKernelGGL(gmmmap_group_key_kernel<DPV>, dim3(kgrid), dim3(256), gshmem, st, g->gfrag.p, g->M, g->D, dX, ldx, T, key, cnt); break;
+        VCMI_CASE(16) VCMI_CASE(20) VCMI_CASE(24) VCMI_CASE(28) VCMI_CASE(32) VCMI_CASE(36) VCMI_CASE(40) VCMI_CASE(44)
+        VCMI_CASE(48) VCMI_CASE(52) VCMI_CASE(56) VCMI_CASE(60) VCMI_CASE(64) VCMI_CASE(68) VCMI_CASE(72) VCMI_CASE(76)
+        VCMI_CASE(80)
+#undef VCMI_CASE
+        default: return fail(VCMI_ERR_ARG, "no MFMA instantiation for padded dimension %d", g->DP);
+      }
+      hipLaunchKernelGGL(gmmmap_group_scan_kernel, dim3(1), dim3(64), 0, st, cnt, g->M, cursor);
+      hipLaunchKernelGGL(gmmmap_group_scatter_kernel, dim3((unsigned)((T + 1023) / 1024)), dim3(256), (size_t)2 * g->M * sizeof(int), st,
+                         key, T, g->M, cursor, perm);
+      VCMI_HIP(hipGetLastError());
+      const int rc = dispatch_mfma<0>(g, dX, ldx, T, dY, ldy, st, perm, key);
+      (void)g->grp_order.leave(st);
+      return rc;
+    }
+    return dispatch_mfma<0>(g, dX, ldx, T, dY, ldy, st);
+  }
   if (g->kernel_choice != 1 && g->At.p && g->D > 16 && g->D <= 160) {
     // no tile-kernel instantiation (80 < padded D <= 160, or a padded dimension outside its list): MFMA log-densities
     // (logdens_tiled_kernel) + softmax / regression over the mixtures that matter, in chunks that bound the (T,M) scratch
@@ -1075,6 +1229,28 @@ static int prepare(vcmi_gmmmap *g, const double *w, const double *mu, const doub
     DevBuf<double> &dst = uonly == 2 ? g->packedU2 : (uonly ? g->packedU : g->packed);
     VCMI_TRY(dst.reserve(pk.size()));
     VCMI_HIP(hipMemcpy(dst.p, pk.data(), pk.size() * 8, hipMemcpyHostToDevice));
+  }
+  if (!g->h_mux.empty()) {     // operand of the frame grouping (gmmmap_group_key_kernel): [-2 mu^x | |mu^x|^2], fragment order
+    const int KS1 = DP / 4 + 1, MT = (M + 15) / 16;
+    std::vector<double> gf((size_t)MT * KS1 * 64, 0.0);
+    for (int mt = 0; mt < MT; ++mt)
+      for (int ks = 0; ks < KS1; ++ks)
+        for (int l = 0; l < 64; ++l) {
+          const int m = 16 * mt + (l & 15), k = 4 * ks + (l >> 4);
+          double v = 0.0;
+          if (ks < KS1 - 1) {
+            if (m < M && k < D) v = -2.0 * g->h_mux[(size_t)D * m + k];
+          } else if ((l >> 4) == 0) {
+            v = 1e300;
+            if (m < M) {
+              v = 0.0;
+              for (int d = 0; d < D; ++d) v += g->h_mux[(size_t)D * m + d] * g->h_mux[(size_t)D * m + d];
+            }
+          }
+          gf[((size_t)mt * KS1 + ks) * 64 + l] = v;
+        }
+    VCMI_TRY(g->gfrag.reserve(gf.size()));
+    VCMI_HIP(hipMemcpy(g->gfrag.p, gf.data(), gf.size() * 8, hipMemcpyHostToDevice));
   }
   return VCMI_OK;
 }

@@ -104,6 +104,7 @@ enum : unsigned {
   kDbgDtwNoSegments = 256u,   // fused DTW: whole-length jobs (no column segments)
   kDbgDtwGridOrder = 512u,    // fused DTW: one workgroup per job in grid order instead of persistent workgroups drawing tickets
   kDbgTrajOneWgPerCu = 128u,  // blocked trajectory solver: one workgroup per CU even where two fit
+  kDbgConvertNoGrouping = 2048u,  // fvconvert: frames in the caller's order (no grouping by nearest source mean)
   kDbgPredictNoEarlyExit = 64u   // predict / trajectory argmax: every whitening tile of every mixture (MODE 2) instead of the early exit (MODE 3)
 };
 bool debug_flag(unsigned which);
