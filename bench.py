@@ -386,7 +386,14 @@ def bench_convert(args, world, rank):
                           "regressions_evaluated_frac": frac_reg,
                           "mfma_executed_frac": (22.0 + 20.0 * frac_reg) / 42.0,
                           "note": "posterior < e^-threshold on all 16 frames of a tile -> that mixture's regression tiles and softmax "
-                                  "update are skipped (wave-uniform); results equal the dense loop to < 1e-18 relative"}
+                                  "update are skipped (wave-uniform); results equal the dense loop to < 1e-18 relative",
+                          "grouping": "from 8192 frames on the library first groups the frames by their nearest source mean (3 small "
+                                      "kernels inside the timed call, ~0.15 ms; frames are independent, outputs unchanged), so that a "
+                                      "16-frame tile holds frames of one mixture: the synthetic frames are drawn independently, so "
+                                      "without grouping ~14 of the 64 mixtures own a frame of a tile and the loop meets ~24 before its "
+                                      "running maximum is tight (regressions_evaluated_frac 0.376, 4.40 ms: `bench.py --debug-force "
+                                      "2048`); grouped, one (1/64).  roofline.frac is ALGORITHMIC flops (all 64 regressions of every "
+                                      "frame, SURVEY 8d) over the FP64 roof, so it exceeds 1 when 65 % of them are provably not needed"}
         g.set_prune(float("inf"))
         wall_d, kernel_ms_d = timed_steps(step, args.steps, 2, world)
         ach_d = flops / (kernel_ms_d * 1e-3) / 1e12

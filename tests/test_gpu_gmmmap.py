@@ -277,3 +277,44 @@ def test_fvconvert_beyond_the_tile_kernel(vc, D, M, T):
     fm = np.asfortranarray(np.vstack([np.arange(T, dtype=np.float64)[None], X.T]))
     out = vc.vc(g, fm)
     assert np.array_equal(out[0], fm[0]) and frame_relerr(out[1:], ref.T) < TOL
+
+
+@pytest.mark.parametrize("D,M,T,lam_lo", [(40, 64, 20000, 1e-5), (24, 9, 8192, 1e-1), (80, 16, 9000, 1e-5), (16, 4, 8193, 3e-1)])
+def test_frame_grouping_changes_nothing_visible(vc, D, M, T, lam_lo):
+    """From 8192 frames on fvconvert first groups the frames by their nearest source mean (three small kernels, index
+    indirection in the MFMA kernel, mixture loop started at the workgroup's group), so that a 16-frame tile holds frames of
+    one mixture and the pruning leaves one or two regressions per tile.  Frames are independent of each other: the outputs
+    must equal those of the caller's order -- to rounding where several mixtures share a frame (broad covariances: the
+    rotated mixture order changes the order of the sum), bit for bit where one mixture owns it --, and the oracle's; the
+    counter shows the regressions that were saved; shuffled and time-ordered input give the same frames."""
+    import torch
+    from oracle import c_oracle as co, np_oracle as npo
+    from voiceconversion_jl_amd import _lib
+    w, mu, sig = npo.synth_model(77 + D + M, 2 * D, M, lam_lo=lam_lo)
+    X = npo.sample_frames(78, w, mu, sig, T, 0, D)
+    g = vc.GMMMap(*julia_model(w, mu, sig))
+    Xd = torch.from_numpy(X).cuda()
+    g.prune_stats(True)
+    Yg = vc.fvconvert(g, Xd.t()).t().clone()
+    n_grouped = g.prune_stats(True)
+    _lib.debug_force(_lib.DBG_CONVERT_NO_GROUPING)
+    try:
+        Yu = vc.fvconvert(g, Xd.t()).t().clone()
+    finally:
+        _lib.debug_force(0)
+    n_plain = g.prune_stats(False)
+    err = float((torch.linalg.norm(Yg - Yu, dim=1) / torch.linalg.norm(Yu, dim=1)).max())
+    assert err < 1e-13, err
+    if lam_lo <= 1e-4:
+        assert torch.equal(Yg, Yu)                      # peaked covariances: one mixture per frame, nothing to reorder
+        assert n_grouped < n_plain                      # and the grouping saved regressions
+    ref = co.GMMMap(w, mu, sig).fvconvert(X[:300])
+    assert frame_relerr(Yg[:300].cpu().numpy().T, ref.T) < TOL
+    # the same frames in another order come out the same, frame by frame
+    perm = torch.randperm(T, generator=torch.Generator().manual_seed(5)).cuda()
+    Ys = vc.fvconvert(g, Xd[perm].contiguous().t()).t()
+    back = torch.empty_like(Ys)
+    back[perm] = Ys
+    assert float((torch.linalg.norm(back - Yg, dim=1) / torch.linalg.norm(Yg, dim=1)).max()) < 1e-13
+    # repeat runs are bit-identical although the order inside a group is not fixed
+    assert torch.equal(vc.fvconvert(g, Xd.t()).t(), Yg)
