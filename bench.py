@@ -368,6 +368,11 @@ def bench_convert(args, world, rank):
     # HBM traffic of the kernel: PMC passes of this same command, run as child processes before the timed run (LIVE_PMC)
     # or, failing that, the committed passes if they were collected from the same library sources
     attach_traffic(out, "convert_traffic.json", "gmmmap_mfma_kernel", standard=(T == 1_000_000), live=LIVE_PMC.get("convert"))
+    if out["roofline"].get("traffic") is not None:
+        # `traffic` is the dominant kernel's, as the roofline object is defined; the three grouping kernels in front of it read x
+        # once more (the nearest-mean keys) and write the permutation
+        tot, _ = pmc_traffic("convert_traffic.json", ("gmmmap_mfma_kernel", "gmmmap_group_"), live=LIVE_PMC.get("convert"))
+        out["roofline"]["traffic_whole_step"] = tot
     # What the timed kernel skipped, and the same K steps with nothing skipped.  The library's default (include/vcmi.h,
     # vcmi_gmmmap_set_prune) does not evaluate the regression A_m x + b_m of a mixture whose posterior is below e^-46 = 1e-20
     # on all 16 frames of a tile -- y changes by less than its own rounding error (the parity figure of this line is measured
