@@ -314,8 +314,10 @@ gmmmap_mfma_kernel(const double *__restrict__ packed, int M, int D, const double
             if (16 * t + 4 * r < DP) qq = fma(acc[f][t][r], acc[f][t][r], qq);
           }
         }
-        qq += __shfl_xor(qq, 16);
-        qq += __shfl_xor(qq, 32);
+        if (MODE != 0) {                      // (MODE 0 reduces over the four lane groups only when it has to: see below)
+          qq += __shfl_xor(qq, 16);
+          qq += __shfl_xor(qq, 32);
+        }
         q[f] = qq;
       }
       }
@@ -341,10 +343,22 @@ gmmmap_mfma_kernel(const double *__restrict__ packed, int M, int D, const double
         // when l_m < runmax - prune for all 16 frames of a tile, its posterior there is below e^-prune (default e^-46 =
         // 1e-20, under the rounding error of the other terms) and neither the regression tiles A_m x + b_m nor the
         // softmax update can change y: both are skipped for that tile (wave-uniform).  prune = +inf keeps the dense loop.
+        // q[f] still holds each lane GROUP's share of |z|^2 (lane = 16 group + frame).  |z|^2 is at least any one share, so a
+        // frame is already out when one of its four lanes says so: only tiles with a frame that no single share rules out pay
+        // for the cross-lane sum (two LDS round trips) -- for a wrong mixture every share is enormous.
         unsigned active = 0;
 #pragma unroll
-        for (int f = 0; f < FT; ++f)
-          if (__builtin_amdgcn_ballot_w64(lc - 0.5 * q[f] > runmax[f] - prune) != 0) active |= 1u << f;
+        for (int f = 0; f < FT; ++f) {
+          if (prune < 1e300) {                  // (the dense loop, prune = +inf, has nothing to decide)
+            const unsigned long long undecided = __builtin_amdgcn_ballot_w64(lc - 0.5 * q[f] > runmax[f] - prune);
+            if ((undecided & (undecided >> 16) & (undecided >> 32) & (undecided >> 48) & 0xffffull) == 0) continue;
+          }
+          double qq = q[f];
+          qq += __shfl_xor(qq, 16);
+          qq += __shfl_xor(qq, 32);
+          q[f] = qq;
+          if (__builtin_amdgcn_ballot_w64(lc - 0.5 * qq > runmax[f] - prune) != 0) active |= 1u << f;
+        }
         if (MODE == 0) nreg_wave += __builtin_popcount(active & tiles_in_range);
         if (active) {
           // ---------------- phase A: regression tiles, E = A x + b (wave-uniform branches around an idle tile's MFMAs) ----------------
