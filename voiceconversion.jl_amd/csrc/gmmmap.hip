@@ -54,6 +54,16 @@ struct Tiling {
         if (ks < steps(u)) ++n;
     return t >= NU ? n : 0;
   }
+  // position of fragment (k-step ks, U tile t) in the k-step-major order of the U tiles (the order the packer writes them in)
+  __host__ __device__ static constexpr int ufrag_pos(int ks, int t) {
+    int n = 0;
+    for (int k = 0; k < ks; ++k)
+      for (int u = 0; u < NU && u < NT; ++u)
+        if (k < steps(u)) ++n;
+    for (int u = 0; u < t; ++u)
+      if (ks < steps(u)) ++n;
+    return n;
+  }
   __host__ __device__ static constexpr int rtile_off(int i) {
     int n = 0;
     for (int u = 0; u < i; ++u) n += steps(NU - 1 - u);
@@ -238,6 +248,7 @@ gmmmap_mfma_kernel(const double *__restrict__ packed, int M, int D, const double
       d4 acc[FT][NT];
       double q[FT];
       unsigned live = (1u << FT) - 1u;      // MODE 3: frame tiles of this wave that mixture m can still be the maximum of
+      unsigned ulive = (1u << FT) - 1u;     // MODE 0: frame tiles whose whitening was completed (the others are decided: out)
       if constexpr (MODE == 3) {
         double qp[FT];
 #pragma unroll
@@ -281,6 +292,65 @@ gmmmap_mfma_kernel(const double *__restrict__ packed, int M, int D, const double
           qq += __shfl_xor(qq, 16);
           qq += __shfl_xor(qq, 32);
           q[f] = qq;
+        }
+      } else if constexpr (MODE == 0 && (TL::NU > 1)) {
+        // fvconvert: the LAST whitening tile first (it spans all k-steps and carries the rows with the small conditional
+        // variances, i.e. most of a wrong mixture's distance).  Its share of |z|^2 alone usually puts the mixture e^-prune
+        // under every frame's running maximum -- certainly on grouped frames, where the maximum is the winner's from the
+        // first iteration -- and then the other whitening tiles of this mixture are not computed at all (tested on the lane
+        // groups' shares, no cross-lane sum; wave-uniform per frame tile).  Every tile keeps its own accumulation order.
+        constexpr int TLAST = NU - 1;
+#pragma unroll
+        for (int t = 0; t < NU; ++t) {
+          d4 c;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) c[r] = cur[TL::CINIT_OFF + 16 * t + 4 * r + lgrp];
+#pragma unroll
+          for (int f = 0; f < FT; ++f) acc[f][t] = c;
+        }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const double a = cur[TL::ufrag_pos(ks, TLAST) * 64 + lane];
+#pragma unroll
+          for (int f = 0; f < FT; ++f) acc[f][TLAST] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, xb[f][ks], acc[f][TLAST], 0, 0, 0);
+        }
+        unsigned und = (1u << FT) - 1u;        // frame tiles on which the mixture is still undecided
+#pragma unroll
+        for (int f = 0; f < FT; ++f) {
+          double qq = 0.0;
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (16 * TLAST + 4 * r < DP) qq = fma(acc[f][TLAST][r], acc[f][TLAST][r], qq);
+          q[f] = qq;
+          if (prune < 1e300) {
+            const unsigned long long u = __builtin_amdgcn_ballot_w64(lc - 0.5 * qq > runmax[f] - prune);
+            if ((u & (u >> 16) & (u >> 32) & (u >> 48) & 0xffffull) == 0) und &= ~(1u << f);
+          }
+        }
+        ulive = und;
+        if (und) {
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+            for (int t = 0; t < TLAST; ++t) {
+              if (ks < TL::steps(t)) {
+                const double a = cur[TL::ufrag_pos(ks, t) * 64 + lane];
+#pragma unroll
+                for (int f = 0; f < FT; ++f)
+                  if (FT == 1 || (und >> f & 1u)) acc[f][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, xb[f][ks], acc[f][t], 0, 0, 0);
+              }
+            }
+          }
+#pragma unroll
+          for (int f = 0; f < FT; ++f) {
+            double qq = q[f];
+#pragma unroll
+            for (int t = 0; t < TLAST; ++t) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) qq = fma(acc[f][t][r], acc[f][t][r], qq);
+            }
+            q[f] = qq;                         // still the lane group's share (see the pruning test below)
+          }
         }
       } else {
 #pragma unroll
@@ -349,6 +419,7 @@ gmmmap_mfma_kernel(const double *__restrict__ packed, int M, int D, const double
         unsigned active = 0;
 #pragma unroll
         for (int f = 0; f < FT; ++f) {
+          if (!(ulive >> f & 1u)) continue;     // decided on the last tile's share alone
           if (prune < 1e300) {                  // (the dense loop, prune = +inf, has nothing to decide)
             const unsigned long long undecided = __builtin_amdgcn_ballot_w64(lc - 0.5 * q[f] > runmax[f] - prune);
             if ((undecided & (undecided >> 16) & (undecided >> 32) & (undecided >> 48) & 0xffffull) == 0) continue;
