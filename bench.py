@@ -377,7 +377,7 @@ def bench_convert(args, world, rank):
     # vcmi_gmmmap_set_prune) does not evaluate the regression A_m x + b_m of a mixture whose posterior is below e^-46 = 1e-20
     # on all 16 frames of a tile -- y changes by less than its own rounding error (the parity figure of this line is measured
     # on the pruned kernel).  `roofline.achieved` is, as defined, ALGORITHMIC flops (every mixture) per second;
-    # `pruning.mfma_executed_frac` says how much of the dense MFMA work the kernel actually issued, and `dense` is the
+    # `pruning` says how much of the dense MFMA work the kernel actually issues, and `dense` is the
     # same measurement with pruning off (what rounds 1-2 reported).
     if (args.prune is None or args.prune < 1e300) and args.cpu_seconds > 0:      # (not in profiling runs: see below)
         g.prune_stats(True)
@@ -386,10 +386,12 @@ def bench_convert(args, world, rank):
         ev = g.prune_stats(False)
         tiles = -(-T // 16)
         frac_reg = ev / float(tiles * M)
-        # v_mfma_f64_16x16x4 steps per (tile, mixture) at D = 40: 22 whitening steps (always) + 20 regression steps (if evaluated)
         out["pruning"] = {"threshold_nats": 46.0 if args.prune is None else args.prune,
                           "regressions_evaluated_frac": frac_reg,
-                          "mfma_executed_frac": (22.0 + 20.0 * frac_reg) / 42.0,
+                          "whitening": "22 of the 42 v_mfma_f64_16x16x4 steps per (tile, mixture) at D = 40 are whitening, 20 regression; the "
+                                       "last whitening tile (10 steps) runs first and its share of |z|^2 alone usually decides a wrong "
+                                       "mixture out, so that on grouped frames ~10.2 + 20 x regressions_evaluated_frac of the 42 steps "
+                                       "are issued (a diagnostic build of the same rule counted 10.19 whitening steps per pair)",
                           "note": "posterior < e^-threshold on all 16 frames of a tile -> that mixture's regression tiles and softmax "
                                   "update are skipped (wave-uniform); results equal the dense loop to < 1e-18 relative",
                           "grouping": "from 8192 frames on the library first groups the frames by their nearest source mean (3 small "
