@@ -401,6 +401,16 @@ def bench_convert(args, world, rank):
                                       "running maximum is tight (regressions_evaluated_frac 0.376, 4.40 ms: `bench.py --debug-force "
                                       "2048`); grouped, one (1/64).  roofline.frac is ALGORITHMIC flops (all 64 regressions of every "
                                       "frame, SURVEY 8d) over the FP64 roof, so it exceeds 1 when 65 % of them are provably not needed"}
+        if D == 40:
+            # the matrix pipe's own view of the same step (PMC: profiles/r03_clock/convert_clock.json, SQ_INSTS_MFMA x 64 cycles):
+            # issued v_mfma_f64_16x16x4 steps per (tile, mixture) ~ 10.2 (last whitening tile; counted by a diagnostic build) + 32 x
+            # the fraction that goes on (12 more whitening + 20 regression steps), 2048 flop each
+            issued = (10.2 + 32.0 * frac_reg) * 2048.0 * tiles * M
+            out["roofline"]["issued_mfma_frac"] = issued / (kernel_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS
+            out["roofline"]["note"] = ("frac = ALGORITHMIC flop (SURVEY 8d: every mixture's whitening and regression for every frame) per second "
+                                       "over the FP64 roof, as the roofline object is defined; the grouped, pruned loop provably needs a quarter "
+                                       "of the dense loop's MFMA steps, so frac exceeds 1 while the matrix pipe is ~0.6 busy "
+                                       "(`issued_mfma_frac`; PMC: 0.64).  `dense` below is the same kernel with every step issued")
         g.set_prune(float("inf"))
         wall_d, kernel_ms_d = timed_steps(step, args.steps, 2, world)
         ach_d = flops / (kernel_ms_d * 1e-3) / 1e12
