@@ -49,7 +49,7 @@ def estep_flops_per_frame(Dj, M):
     return 8 * Dj * M + 25 * M
 
 
-PMC_DIR = "r03_pmc"
+PMC_DIR = "r04_pmc"
 SOURCE_FILES = ("*.hip", "*.hpp", "*.inc", "*.cpp", "Makefile")
 
 
@@ -323,14 +323,72 @@ def timed_steps(step_fn, steps, warmup, world):
 
 
 # ------------------------------------------------------------------------------------------- convert
-def bench_convert(args, world, rank):
+MFMA_FLOP = 2048.0        # one v_mfma_f64_16x16x4_f64: 16 x 16 x 4 multiply-adds
+
+CONVERT_VARIANTS = {
+    # BASELINE configs[1] / SURVEY 8(d): the prescribed synthetic model (eigenvalues of the covariances log-uniform in [1e-5, 1]):
+    # peaked -- one mixture owns every frame
+    "synthetic": {"label": "GMMMap fvconvert (BASELINE configs[1])", "M": 64, "lam_lo": 1e-5, "seed": 1002},
+    # the same generator with eigenvalues in [1e-1, 1]: overlapping mixtures of similar shape
+    "broad": {"label": "GMMMap fvconvert, synthetic model with covariance eigenvalues in [1e-1, 1] (not a BASELINE config)", "M": 64,
+              "lam_lo": 1e-1, "seed": 1002},
+    # the reference's own trained model (test/models/clb_to_slt_gmm32_order40_diff.jld -> tests/golden/model_*.npz): M = 32
+    "fixture": {"label": "GMMMap fvconvert, the reference's trained model clb_to_slt_gmm32_order40_diff (M = 32; not a BASELINE config)",
+                "M": 32, "seed": 1002},
+}
+
+
+def convert_model(variant):
+    import synthdata as npo
+
+    v = CONVERT_VARIANTS[variant]
+    if variant == "fixture":
+        z = np.load(os.path.join(ROOT, "tests", "golden", "model_clb_to_slt_gmm32_order40_diff.npz"))
+        return z["weights"], z["means"], z["covars"]
+    return npo.synth_model(v["seed"], 80, v["M"], lam_lo=v["lam_lo"])
+
+
+def pcie_roof(nbytes=320_000_000):
+    """What the link gives: pinned host memory <-> HBM, one direction at a time and both at once (two streams).  GB/s."""
+    import torch
+
+    h_in = torch.empty(nbytes // 8, dtype=torch.float64).pin_memory()
+    h_out = torch.empty(nbytes // 8, dtype=torch.float64).pin_memory()
+    d_in = torch.empty(nbytes // 8, dtype=torch.float64, device="cuda")
+    d_out = torch.empty(nbytes // 8, dtype=torch.float64, device="cuda")
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+
+    def run(h2d, d2h, reps=3):
+        best = 1e30
+        for _ in range(reps + 1):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            if h2d:
+                with torch.cuda.stream(s1):
+                    d_in.copy_(h_in, non_blocking=True)
+            if d2h:
+                with torch.cuda.stream(s2):
+                    h_out.copy_(d_out, non_blocking=True)
+            torch.cuda.synchronize()
+            best = min(best, time.perf_counter() - t0)
+        return best
+
+    th, td, tb = run(True, False), run(False, True), run(True, True)
+    return {"h2d_GBps": nbytes / th / 1e9, "d2h_GBps": nbytes / td / 1e9, "duplex_GBps_per_direction": nbytes / tb / 1e9,
+            "duplex_ms_for_2x%dMB" % (nbytes // 1_000_000): tb * 1e3,
+            "how": "torch pinned tensors, copy_(non_blocking) on one / two streams, best of 3"}
+
+
+def bench_convert(args, world, rank, variant="synthetic"):
     import torch
 
     import voiceconversion_jl_amd as vc
     import synthdata as npo
 
-    D, M, T = 40, 64, args.frames
-    w, mu, sig = npo.synth_model(1002, 2 * D, M)
+    headline = variant == "synthetic"
+    D, T = 40, args.frames
+    w, mu, sig = convert_model(variant)
+    M = len(w)
     g = vc.GMMMap(*julia_model(w, mu, sig))
     if args.prune is not None:
         g.set_prune(args.prune)
@@ -344,9 +402,23 @@ def bench_convert(args, world, rank):
     wall, kernel_ms = timed_steps(step, args.steps, args.warmup, world)
     frames_per_s = world * T * args.steps / wall
     flops = convert_flops_per_frame(D, M) * T
-    achieved = flops / (kernel_ms * 1e-3) / 1e12
+    tiles = -(-T // 16)
+    # What the matrix pipe was actually given: the kernel counts its own v_mfma_f64_16x16x4 instructions (wave-uniform scalar
+    # adds; vcmi_gmmmap_convert_plan) in one extra, untimed launch on the same frames; profiles/r04_clock/ holds the same
+    # number from the SQ_INSTS_MFMA counter.
+    g.prune_stats(True)
+    step()
+    torch.cuda.synchronize()
+    issued_mfma, shape, active_frac, undecided_frac = g.convert_plan()
+    nreg = g.prune_stats(False)
+    per_pair_dense = 42 if D == 40 else None               # MFMA steps per (16-frame tile, mixture) with nothing skipped, D = 40
+    issued_flops = issued_mfma * MFMA_FLOP
+    alg_tflops = flops / (kernel_ms * 1e-3) / 1e12
+    iss_tflops = issued_flops / (kernel_ms * 1e-3) / 1e12
+    achieved = min(alg_tflops, iss_tflops)
     out = {
-        "metric": "converted frames/sec (D=40, M=64) at 1/2/4/8 MI355X vs CPU ref",
+        "metric": "converted frames/sec (D=40, M=64) at 1/2/4/8 MI355X vs CPU ref" if headline else
+                  "converted frames/sec (D=40, M=%d), %s model" % (M, variant),
         "value": frames_per_s,
         "unit": "frames/s",
         "n_gpus": world,
@@ -357,73 +429,57 @@ def bench_convert(args, world, rank):
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": "f64",
-        "data": "synthetic",
-        "config": {"workload": "GMMMap fvconvert (BASELINE configs[1])", "D": D, "M": M, "frames_per_gpu": T,
+        "data": "synthetic" if variant != "fixture" else "synthetic frames drawn from the reference's trained model",
+        "config": {"workload": CONVERT_VARIANTS[variant]["label"], "D": D, "M": M, "frames_per_gpu": T,
                    "sharding": f"frames x{world}, no collective"},
-        "roofline": {"bound": "mfma", "kernel": "gmmmap_mfma_kernel<40,...>", "achieved": achieved,
+        "roofline": {"bound": "mfma", "kernel": "gmmmap_mfma_kernel<40,2,4,0,2,%d>" % shape, "achieved": achieved,
                      "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS,
-                     "traffic": None, "flop_per_frame": convert_flops_per_frame(D, M), "kernel_ms": kernel_ms,
+                     "traffic": None, "kernel_ms": kernel_ms,
+                     "frac_definition": "min(algorithmic flop, flop of the MFMAs the kernel issued) / kernel time / peak: work the kernel "
+                                        "skips is not credited (algorithmic_frac would exceed 1) and tile padding is not credited "
+                                        "either (the dense loop issues 344,064 flop per frame for 324,160 algorithmic)",
+                     "flop_per_frame": convert_flops_per_frame(D, M),
+                     "algorithmic_frac": alg_tflops / FP64_PEAK_TFLOPS,
+                     "issued_mfma_frac": iss_tflops / FP64_PEAK_TFLOPS,
+                     "mfma_issued_per_launch": issued_mfma,
+                     "mfma_issued_source": "in-kernel count (vcmi_gmmmap_convert_plan); SQ_INSTS_MFMA of the same kernel: profiles/r04_clock/",
+                     "work_skipped": (1.0 - issued_mfma / float(per_pair_dense * tiles * M)) if per_pair_dense else None,
+                     "regressions_evaluated_frac": nreg / float(tiles * M),
+                     "loop_shape": {0: "dense", 1: "broad", 2: "peaked"}.get(shape, str(shape)),
+                     "model_active_frac": active_frac, "model_undecided_frac": undecided_frac,
                      "hbm_GBps_algorithmic": 2 * D * 8 * T / (kernel_ms * 1e-3) / 1e9},
     }
     # HBM traffic of the kernel: PMC passes of this same command, run as child processes before the timed run (LIVE_PMC)
     # or, failing that, the committed passes if they were collected from the same library sources
-    attach_traffic(out, "convert_traffic.json", "gmmmap_mfma_kernel", standard=(T == 1_000_000), live=LIVE_PMC.get("convert"))
-    if out["roofline"].get("traffic") is not None:
-        # `traffic` is the dominant kernel's, as the roofline object is defined; the three grouping kernels in front of it read x
-        # once more (the nearest-mean keys) and write the permutation
-        tot, _ = pmc_traffic("convert_traffic.json", ("gmmmap_mfma_kernel", "gmmmap_group_"), live=LIVE_PMC.get("convert"))
-        out["roofline"]["traffic_whole_step"] = tot
-    # What the timed kernel skipped, and the same K steps with nothing skipped.  The library's default (include/vcmi.h,
-    # vcmi_gmmmap_set_prune) does not evaluate the regression A_m x + b_m of a mixture whose posterior is below e^-46 = 1e-20
-    # on all 16 frames of a tile -- y changes by less than its own rounding error (the parity figure of this line is measured
-    # on the pruned kernel).  `roofline.achieved` is, as defined, ALGORITHMIC flops (every mixture) per second;
-    # `pruning` says how much of the dense MFMA work the kernel actually issues, and `dense` is the
-    # same measurement with pruning off (what rounds 1-2 reported).
-    if (args.prune is None or args.prune < 1e300) and args.cpu_seconds > 0:      # (not in profiling runs: see below)
-        g.prune_stats(True)
-        step()
-        torch.cuda.synchronize()
-        ev = g.prune_stats(False)
-        tiles = -(-T // 16)
-        frac_reg = ev / float(tiles * M)
-        out["pruning"] = {"threshold_nats": 46.0 if args.prune is None else args.prune,
-                          "regressions_evaluated_frac": frac_reg,
-                          "whitening": "22 of the 42 v_mfma_f64_16x16x4 steps per (tile, mixture) at D = 40 are whitening, 20 regression; the "
-                                       "last whitening tile (10 steps) runs first and its share of |z|^2 alone usually decides a wrong "
-                                       "mixture out, so that on grouped frames ~10.2 + 20 x regressions_evaluated_frac of the 42 steps "
-                                       "are issued (a diagnostic build of the same rule counted 10.19 whitening steps per pair)",
-                          "note": "posterior < e^-threshold on all 16 frames of a tile -> that mixture's regression tiles and softmax "
-                                  "update are skipped (wave-uniform); results equal the dense loop to < 1e-18 relative",
-                          "grouping": "from 8192 frames on the library first groups the frames by their nearest source mean (3 small "
-                                      "kernels inside the timed call, ~0.15 ms; frames are independent, outputs unchanged), so that a "
-                                      "16-frame tile holds frames of one mixture: the synthetic frames are drawn independently, so "
-                                      "without grouping ~14 of the 64 mixtures own a frame of a tile and the loop meets ~24 before its "
-                                      "running maximum is tight (regressions_evaluated_frac 0.376, 4.40 ms: `bench.py --debug-force "
-                                      "2048`); grouped, one (1/64).  roofline.frac is ALGORITHMIC flops (all 64 regressions of every "
-                                      "frame, SURVEY 8d) over the FP64 roof, so it exceeds 1 when 65 % of them are provably not needed"}
-        if D == 40:
-            # the matrix pipe's own view of the same step (PMC: profiles/r03_clock/convert_clock.json, SQ_INSTS_MFMA x 64 cycles):
-            # issued v_mfma_f64_16x16x4 steps per (tile, mixture) ~ 10.2 (last whitening tile; counted by a diagnostic build) + 32 x
-            # the fraction that goes on (12 more whitening + 20 regression steps), 2048 flop each
-            issued = (10.2 + 32.0 * frac_reg) * 2048.0 * tiles * M
-            out["roofline"]["issued_mfma_frac"] = issued / (kernel_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS
-            out["roofline"]["note"] = ("frac = ALGORITHMIC flop (SURVEY 8d: every mixture's whitening and regression for every frame) per second "
-                                       "over the FP64 roof, as the roofline object is defined; the grouped, pruned loop provably needs a quarter "
-                                       "of the dense loop's MFMA steps, so frac exceeds 1 while the matrix pipe is ~0.6 busy "
-                                       "(`issued_mfma_frac`; PMC: 0.64).  `dense` below is the same kernel with every step issued")
+    if headline:
+        attach_traffic(out, "convert_traffic.json", "gmmmap_mfma_kernel", standard=(T == 1_000_000), live=LIVE_PMC.get("convert"))
+        if out["roofline"].get("traffic") is not None:
+            # `traffic` is the dominant kernel's, as the roofline object is defined; the three grouping kernels in front of it read x
+            # once more (the nearest-mean keys) and write the permutation
+            tot, _ = pmc_traffic("convert_traffic.json", ("gmmmap_mfma_kernel", "gmmmap_group_"), live=LIVE_PMC.get("convert"))
+            out["roofline"]["traffic_whole_step"] = tot
+        live = LIVE_PMC.get("convert") or {}
+        for k, v in live.items():
+            if "gmmmap_mfma_kernel" in k and "SQ_INSTS_MFMA_per_launch" in v:
+                out["roofline"]["SQ_INSTS_MFMA_per_launch"] = v["SQ_INSTS_MFMA_per_launch"]
+    # The same K steps with nothing skipped (vcmi_gmmmap_set_prune(inf): every mixture's whitening and regression for every
+    # frame, the dense loop the flop count of SURVEY 8(d) assumes), and the pruned output against it.
+    if (args.prune is None or args.prune < 1e300) and args.cpu_seconds > 0:      # (not in profiling runs)
         g.set_prune(float("inf"))
         wall_d, kernel_ms_d = timed_steps(step, args.steps, 2, world)
         ach_d = flops / (kernel_ms_d * 1e-3) / 1e12
-        out["dense"] = {"value": world * T * args.steps / wall_d, "unit": "frames/s", "ms_per_step": wall_d / args.steps * 1e3,
-                        "kernel_ms": kernel_ms_d, "roofline_frac": ach_d / FP64_PEAK_TFLOPS, "achieved_TFLOPs": ach_d,
-                        "note": "pruning off (vcmi_gmmmap_set_prune(inf)): every mixture's regression for every frame"}
+        out["roofline"]["dense"] = {"kernel_ms": kernel_ms_d, "frac": ach_d / FP64_PEAK_TFLOPS, "achieved": ach_d,
+                                    "value": world * T * args.steps / wall_d, "unit": "frames/s",
+                                    "ms_per_step": wall_d / args.steps * 1e3,
+                                    "note": "vcmi_gmmmap_set_prune(inf): gmmmap_mfma_kernel<40,2,4,0,2,0>, every MFMA step of every "
+                                            "mixture for every frame; frac = algorithmic flop / time / peak"}
         if rank == 0:
             Yd_dense = Yd[:4096].clone()
         g.set_prune(46.0 if args.prune is None else args.prune)
         step()
         if rank == 0:
             a, b = Yd[:4096], Yd_dense
-            out["pruning"]["max_rel_diff_vs_dense_4096_frames"] = float((torch.linalg.norm(a - b, dim=1) / torch.linalg.norm(b, dim=1)).max())
+            out["roofline"]["max_rel_diff_vs_dense_4096_frames"] = float((torch.linalg.norm(a - b, dim=1) / torch.linalg.norm(b, dim=1)).max())
         PER_RANK["wall_s"] = gather_over_ranks(wall, world)
         PER_RANK["kernel_ms"] = gather_over_ranks(kernel_ms, world)
     if rank == 0:
@@ -447,7 +503,7 @@ def bench_convert(args, world, rank):
         out["speedup_vs_cpu_baseline"] = frames_per_s / (n / dt)
     # (profiling runs pass --cpu-seconds 0: nothing but the warm-up and the timed launches may reach the kernel trace and
     # the PMC passes, so the host-pointer measurement and the strong CPU baseline below are skipped there)
-    if rank == 0 and args.cpu_seconds > 0:
+    if rank == 0 and args.cpu_seconds > 0 and headline:
         # the host-pointer (PCIe-inclusive) rate of the same call, measured -- never the reported `value`
         Xh = np.asfortranarray(X.T)
         vc.fvconvert(g, Xh)                                  # warm the library's staging buffers
@@ -466,14 +522,24 @@ def bench_convert(args, world, rank):
         for _ in range(3):
             vc.fvconvert(g, Xh, out=Yh)
         dtr = (time.perf_counter() - t0) / 3
+        try:
+            pcie = pcie_roof(Xh.nbytes)
+            floor_ms = pcie["duplex_ms_for_2x%dMB" % (Xh.nbytes // 1_000_000)]
+        except Exception as e:  # noqa: BLE001
+            pcie, floor_ms = {"error": repr(e)}, None
         out["host_inclusive"] = {"value": T / dth, "unit": "frames/s", "ms_per_call": dth * 1e3,
-                                 "reused_output": {"value": T / dtr, "ms_per_call": dtr * 1e3},
+                                 "reused_output": {"value": T / dtr, "ms_per_call": dtr * 1e3,
+                                                   "frac_of_pcie": (floor_ms / (dtr * 1e3)) if floor_ms else None},
+                                 "frac_of_pcie": (floor_ms / (dth * 1e3)) if floor_ms else None,
+                                 "pcie": pcie,
                                  "releasing_one_result_ms": dfree * 1e3,
                                  "note": "vcmi_gmmmap_convert on pageable host arrays (what a Julia ccall passes): chunked "
                                          "pinned staging, H2D / kernel / D2H of consecutive chunks overlapped; `value` "
                                          "allocates a fresh output per call like `similar(X)` (first-touch page faults "
                                          "included; releasing the previous result is timed apart: it is the caller's munmap), "
-                                         "`reused_output` writes into an existing array",
+                                         "`reused_output` writes into an existing array; frac_of_pcie = the time the link needs "
+                                         "for the same 2 x 320 MB from PINNED memory, both directions at once, measured in this "
+                                         "run (`pcie`), over the call's time",
                                  "parity_vs_device_path": bool(np.array_equal(Yh.T, Yd.cpu().numpy())),
                                  "host": host_facts()}
         # the honest strong CPU baseline -- the same arithmetic on every host core (OpenMP over frames)
@@ -905,7 +971,7 @@ def bench_selftest(args, world, rank):
 
 def summarize(out):
     """What the `workloads` table keeps of a workload's line."""
-    keep = ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "config", "roofline", "cpu_baseline", "collective",
+    keep = ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "config", "data", "roofline", "cpu_baseline", "collective",
             "parity_max_rel_err_vs_oracle", "parity_bit_exact_vs_oracle", "speedup_vs_cpu_baseline", "allreduce_check")
     d = {k: out[k] for k in keep if k in out}
     d["kernel_ms"] = out.get("roofline", {}).get("kernel_ms")
@@ -938,9 +1004,9 @@ def cpu_baseline_cached(workload):
     except (OSError, KeyError, ValueError):
         pass
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", f"r03_{workload}_bench.json")))
+        d = json.load(open(os.path.join(ROOT, "profiles", f"r04_{workload}_bench.json")))
         b = dict(d["cpu_baseline"])
-        b["cached"] = f"from the committed N=1 profile profiles/r03_{workload}_bench.json (another box); not re-timed at N>1"
+        b["cached"] = f"from the committed N=1 profile profiles/r04_{workload}_bench.json (another box); not re-timed at N>1"
         return b
     except (OSError, KeyError, ValueError):
         return None
@@ -952,7 +1018,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="all",
-                    choices=["all", "convert", "estep", "estep_full", "em_full", "dtw", "traj", "trajgv", "selftest"],
+                    choices=["all", "convert", "convert_fixture", "convert_broad", "estep", "estep_full", "em_full", "dtw", "traj", "trajgv",
+                             "selftest"],
                     help="all (default): the headline line of configs[1] plus a `workloads` table over configs[1..4]")
     ap.add_argument("--dim", type=int, default=40, help="dtw: feature dimension (40 = BASELINE; 41 = order-40 mel-cepstra with c0)")
     ap.add_argument("--pmc", default="auto", choices=["auto", "off"],
@@ -1001,6 +1068,8 @@ def main():
         args.cpu_seconds_sub = 0.0
     fns = {"convert": bench_convert, "estep": bench_estep, "estep_full": bench_estep_full, "em_full": bench_em_full,
            "dtw": bench_dtw, "traj": bench_traj, "trajgv": lambda a, w, r: bench_traj(a, w, r, gv=True),
+           "convert_fixture": lambda a, w, r: bench_convert(a, w, r, variant="fixture"),
+           "convert_broad": lambda a, w, r: bench_convert(a, w, r, variant="broad"),
            "selftest": bench_selftest}
     if args.workload == "all":
         import copy
@@ -1012,7 +1081,7 @@ def main():
         table = {"convert": summarize(out)}
         sub = copy.copy(args)
         sub.cpu_seconds = args.cpu_seconds_sub
-        for name in ("estep", "dtw", "traj"):
+        for name in ("convert_fixture", "convert_broad", "estep", "dtw", "traj"):
             gc.collect()
             torch.cuda.empty_cache()
             PER_RANK.clear()
@@ -1052,6 +1121,19 @@ def main():
     out["library_source_hash"] = source_hash()
     if args.debug_force:
         out["debug_force"] = args.debug_force      # not a product configuration
+    # last key of the line (the driver keeps the line's tail): per workload [ms_per_step, roofline.frac, parity]
+    def _row(d):
+        par = d.get("parity_max_rel_err_vs_oracle")
+        if par is None and "parity_bit_exact_vs_oracle" in d:
+            par = "bit-exact" if d["parity_bit_exact_vs_oracle"] else "MISMATCH"
+        r = d.get("roofline", {})
+        row = [round(d.get("ms_per_step", 0.0), 4), round(r.get("frac", 0.0), 4), par if isinstance(par, str) or par is None else float("%.2g" % par)]
+        if "dense" in r:
+            row.append({"dense_ms": round(r["dense"]["kernel_ms"], 4), "dense_frac": round(r["dense"]["frac"], 4),
+                        "regressions": round(r.get("regressions_evaluated_frac", 0.0), 4)})
+        return row
+    out["summary"] = {"columns": ["ms_per_step", "roofline.frac (<= 1: issued or algorithmic work, whichever is less)", "parity vs oracle"],
+                      **{name: _row(d) for name, d in table.items() if isinstance(d, dict) and "ms_per_step" in d}}
     if rank == 0:
         print(json.dumps(out), flush=True)
     import torch.distributed as dist

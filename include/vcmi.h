@@ -104,6 +104,18 @@ int vcmi_gmmmap_set_prune(vcmi_gmmmap *g, double nats);
  * ceil(T / 16) * M per converted matrix); then enable != 0 (re)starts the counter at zero, enable == 0 switches it off
  * (the default: the kernel then updates nothing).  Synchronises with the device. */
 int vcmi_gmmmap_prune_stats(vcmi_gmmmap *g, int enable, int64_t *evaluated);
+/* What fvconvert does with this handle, for measurement (bench.py prices the matrix pipe with it):
+ *   *mfma_issued (may be NULL)  v_mfma_f64_16x16x4 instructions (2048 flop each) the MFMA fvconvert kernel has issued since
+ *                               vcmi_gmmmap_prune_stats last enabled the counters (0 while they are off); synchronises;
+ *   *shape (may be NULL)        the loop the library chose for this model: 0 dense (prune = +inf), 1 "broad" (every
+ *                               whitening tile, one branch around the regression), 2 "peaked" (a wrong mixture is decided
+ *                               out on its last whitening tile), -1 no MFMA tile kernel for this dimension;
+ *   *model_active_frac, *model_undecided_frac (may be NULL)  the model properties behind that choice, estimated once at
+ *                               creation on 256 frames drawn from the model itself: the mean fraction of the mixtures within
+ *                               e^-46 of the best one, and the fraction that the last 16-row whitening tile's share of |z|^2
+ *                               alone does NOT put e^-46 under the best one ("peaked" is chosen below 0.35). */
+int vcmi_gmmmap_convert_plan(vcmi_gmmmap *g, int64_t *mfma_issued, int *shape, double *model_active_frac,
+                             double *model_undecided_frac);
 
 /* ---------------------------------------------------------------------------------------------
  * DTW -- src/dtw.jl:93-145 (fit! + backward), align -- src/align.jl:8-35

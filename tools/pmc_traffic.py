@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """HBM traffic of a bench workload's kernels: FETCH_SIZE and WRITE_SIZE in SEPARATE rocprofv3 passes (they do not fit one
-pass: MI355X_MICROARCH.md, HBM section), kernel-trace only, of `python3 bench.py --workload <w> --steps 2 --warmup 1
+pass: MI355X_MICROARCH.md, HBM section), plus a third pass for SQ_INSTS_MFMA (the matrix instructions each kernel issued:
+what bench.py prices the MFMA pipe with), kernel-trace only, of `python3 bench.py --workload <w> --steps 2 --warmup 1
 --cpu-seconds 0` (with --cpu-seconds 0 the bench launches nothing but the warm-up, the timed steps and a small parity
 sample).  Writes <out>/traffic.json: per kernel the KB counters per launch and per bench step, plus `_meta` with the hash
 of the library sources the passes were collected from -- bench.py refuses a table whose hash is not the current one.
@@ -35,7 +36,7 @@ def main():
     res = collections.defaultdict(dict)
     cmd_tail = ["--", sys.executable, os.path.join(ROOT, "bench.py"), "--workload", w, "--steps", "2", "--warmup", "1",
                 "--cpu-seconds", "0", "--pmc", "off"] + argv
-    for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    for c in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_MFMA"):
         d = os.path.join(out, c)
         os.makedirs(d, exist_ok=True)
         env = dict(os.environ, TMPDIR="/tmp")
@@ -50,6 +51,9 @@ def main():
                 acc[k] += float(r["Counter_Value"])
                 n[k] += 1
         for k in acc:
+            if c == "SQ_INSTS_MFMA":      # matrix instructions per launch (per wave: 2048 flop each for v_mfma_f64_16x16x4)
+                res[k]["SQ_INSTS_MFMA_per_launch"] = acc[k] / n[k]
+                continue
             res[k][c + "_KB_per_launch"] = acc[k] / n[k]
             res[k][c + "_KB_per_step"] = acc[k] / NSTEPS
             res[k]["launches_per_step"] = n[k] / NSTEPS

@@ -69,6 +69,7 @@ SIGNATURES = {
     "vcmi_gmmmap_set_kernel": (_int, [_vp, _int]),
     "vcmi_gmmmap_set_prune": (_int, [_vp, C.c_double]),
     "vcmi_gmmmap_prune_stats": (_int, [_vp, _int, _ip]),
+    "vcmi_gmmmap_convert_plan": (_int, [_vp, _ip, C.POINTER(_int), _dp, _dp]),
     "vcmi_dtw_fit": (_int, [_dp, _i64, _dp, _i64, _int, _int, _int, _ip, _dp, _ip]),
     "vcmi_dtw_fit_batch": (_int, [_i64, _dpp, _ip, _dpp, _ip, _int, _int, _int, _ipp]),
     "vcmi_dtw_fit_batch_dev": (_int, [_i64, _vp, _ip, _ip, _ip, _ip, _int, _int, _int, _vp, _ip, _vp]),

@@ -23,6 +23,7 @@
 #include "gmmmap_handle.hpp"
 #include "devgroup.hpp"
 #include "hostpipe.hpp"
+#include "fp64_exp.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -217,7 +218,9 @@ struct EstepCfg {
   static constexpr int RSG = MMAX + 16;          // LDS row stride of gamma; == 16 mod 32 -> f-groups land 32 banks apart
   // two x buffers (block k+1 streams in by LDS-DMA while block k is processed) + l/gamma; the log-likelihood scratch of
   // the epilogue aliases the l/gamma area
-  static constexpr size_t LDS_BYTES = ((size_t)2 * XBUF + (size_t)FB * RSG) * sizeof(double);
+  // + the 2^(j/64) table of vc_exp_tab (64 doubles) + step B's frame order: winning tile per frame (FB ints) and one
+  // permutation per wave (8 x FB ints)
+  static constexpr size_t LDS_BYTES = ((size_t)2 * XBUF + (size_t)FB * RSG + 64) * sizeof(double) + (size_t)9 * FB * sizeof(int);
   static_assert(RSX >= DJ + 2 && RSX % 2 == 0, "row stride");
   static_assert(LDS_BYTES <= 160 * 1024, "LDS");
 };
@@ -250,9 +253,19 @@ estep_mfma_kernel(const double *__restrict__ X, int64_t N, int M, const double *
   double *xbuf = smem;                     // [2][XBUF]: [FB][RSX] images
   double *lg = smem + 2 * XBUF;            // [FB][RSG]   l, then gamma
   double *red = lg;                        // [8][64] scratch for the log-likelihood reduction (epilogue only)
+  double *etab = lg + FB * RSG;            // [64] 2^(j/64) for vc_exp_tab (fp64_exp.hpp)
+  // PHASE 0: step B takes the block's frames GROUPED BY THE MIXTURE TILE THAT WINS THEM.  Its k-steps are 4 frames x the wave's
+  // 16 mixtures and are skipped when all 64 responsibilities are exactly zero; in the order the frames arrive, a tile's
+  // few frames are spread over most k-steps (BASELINE data: 41 % of the k-steps survive), grouped they sit in two or three.
+  // A sum over frames does not depend on their order (rounding aside: the statistics stay deterministic, run to run).
+  // (fkey / fperm / kSortB: below, after the lane indices)
+  if (threadIdx.x < 64) etab[threadIdx.x] = kExp2Tab[threadIdx.x];       // (visible after the barrier behind the first stage)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lcol = lane & 15, lgrp = lane >> 4;
+  int *fkey = reinterpret_cast<int *>(etab + 64);   // [FB] winning tile of each frame (softmax phase)
+  int *fperm = fkey + FB + wave * FB;               // [FB] this wave's copy of the grouped order
+  constexpr bool kSortB = (PHASE == 0);
   const int tile = SHARE ? (wave & (mtp - 1)) : wave, sub = SHARE ? wave / mtp : 0, wpt = SHARE ? 8 / mtp : 1;      // mixture tile, position among the tile's waves
 
   // this wave's weight fragments and log-density constants stay in registers for the whole kernel
@@ -270,7 +283,8 @@ estep_mfma_kernel(const double *__restrict__ X, int64_t N, int M, const double *
   double s0l = 0.0;   // sum over this lane's frames of gamma[f][m = 16 wave + lcol]
 #pragma unroll
   for (int j = 0; j < (kStats ? NDT : 1); ++j) sacc[j] = d4{0, 0, 0, 0};
-  double llacc = 0.0;
+  double llacc = 0.0, sprod = 1.0;
+  int nprod = 0;
 
   const int64_t nblocks = (N + FB - 1) / FB;
   // ---- x staging by LDS-DMA (global_load_lds_dwordx4: 16 bytes per lane straight into LDS, no VGPRs -- the kernel has
@@ -303,7 +317,16 @@ estep_mfma_kernel(const double *__restrict__ X, int64_t N, int M, const double *
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   int cur = 0;
+#ifdef VCMI_ESTEP_PROF
+  unsigned long long pt_[6] = {0, 0, 0, 0, 0, 0};     // probe build: s_memtime counts in A | barrier | softmax | barrier | B | barrier
+#define VCMI_PT(i) { const unsigned long long t_ = __builtin_readcyclecounter(); pt_[i] += t_ - tl_; tl_ = t_; }
+#else
+#define VCMI_PT(i)
+#endif
   for (int64_t blk = blockIdx.x; blk < nblocks; blk += gridDim.x, cur ^= 1) {
+#ifdef VCMI_ESTEP_PROF
+    unsigned long long tl_ = __builtin_readcyclecounter();
+#endif
     const int64_t f0 = blk * FB;
     const double *xs = xbuf + cur * XBUF;
     double gpre[kGamma ? 1 : FB / 4];         // PHASE 2: this lane's responsibilities of the block, fetched before the products
@@ -335,7 +358,9 @@ estep_mfma_kernel(const double *__restrict__ X, int64_t N, int M, const double *
 #pragma unroll
         for (int r = 0; r < 4; ++r) lg[(16 * ft + 4 * r + lgrp) * RSG + 16 * tile + lcol] = acc[r];
       }
+      VCMI_PT(0)
       __syncthreads();
+      VCMI_PT(1)
       // ---- softmax over the 128 mixture slots of each frame.  16 lanes per frame, lane lcol owns slots lcol + 16 i:
       //      per instruction a 32-lane group touches 2 frame rows x 16 consecutive doubles, which with RSG == 16 mod 32
       //      is conflict-free (same pattern as step B's gamma reads) ----
@@ -353,8 +378,18 @@ estep_mfma_kernel(const double *__restrict__ X, int64_t N, int M, const double *
           v[i] = (!SHARE || i < mtp) ? row[16 * i] : -INFINITY;          // slots of tiles that do not exist: gamma = 0
           u = fmax(u, v[i]);
         }
+        int wtile = 0;                        // (kSortB) the first slot of this lane that attains its maximum
+        if constexpr (kSortB) {
+          const double ul = u;
 #pragma unroll
-        for (int sh = 1; sh < 16; sh <<= 1) u = fmax(u, __shfl_xor(u, sh));
+          for (int i = C::MMAX / 16 - 1; i >= 0; --i) wtile = (v[i] == ul) ? i : wtile;
+        }
+        const double ulane = u;
+        u = row16_max(u);                    // (DPP: no LDS round trips; fp64_exp.hpp)
+        if constexpr (kSortB) {
+          wtile = row16_min((ulane == u) ? wtile : 99);
+          if (lcol == 0) fkey[f] = wtile < 8 ? wtile : 0;
+        }
         // ---- refinement.  The GEMM form  x^2 (-1/2var) + x (mu/var) + c  cancels: with var down to min_covar = 1e-7 and
         //      |mu| ~ 10 its terms reach 1e9 and l carries an absolute error of ~1e-7.  That is harmless while one mixture
         //      owns the frame (gamma = 1 whatever l is) and wrong when several compete: the responsibilities inherit the
@@ -367,8 +402,7 @@ estep_mfma_kernel(const double *__restrict__ X, int64_t N, int M, const double *
           int nc = 0;
 #pragma unroll
           for (int i = 0; i < C::MMAX / 16; ++i) nc += (v[i] > u - kRefine) ? 1 : 0;
-#pragma unroll
-          for (int sh = 1; sh < 16; sh <<= 1) nc += __shfl_xor(nc, sh);
+          nc = row16_sum(nc);
           if (nc > 1) {
             const double thr = u - kRefine;
             const double *xf = xs + f * RSX;
@@ -393,29 +427,58 @@ estep_mfma_kernel(const double *__restrict__ X, int64_t N, int M, const double *
               v[i] = (!SHARE || i < mtp) ? row[16 * i] : -INFINITY;
               u = fmax(u, v[i]);
             }
-#pragma unroll
-            for (int sh = 1; sh < 16; sh <<= 1) u = fmax(u, __shfl_xor(u, sh));
+            u = row16_max(u);
           }
         }
         double s = 0.0;
 #pragma unroll
         for (int i = 0; i < C::MMAX / 16; ++i) {
-          v[i] = exp(v[i] - u);
+          v[i] = vc_exp_tab(v[i] - u, etab);   // 20 instructions against the 42 of exp(); -inf and < -745 give exactly 0
           s += v[i];
         }
-#pragma unroll
-        for (int sh = 1; sh < 16; sh <<= 1) s += __shfl_xor(s, sh);
+        s = row16_sum(s);
         const bool livef = (f0 + f < N);
         const double inv = livef ? 1.0 / s : 0.0;          // frames beyond N contribute gamma = 0
 #pragma unroll
         for (int i = 0; i < C::MMAX / 16; ++i)
           if (!SHARE || i < mtp) row[16 * i] = v[i] * inv;
-        if (lcol == 0 && livef) {
-          if constexpr (PHASE == 3) part[f0 + f] = u + log(s);      // the group's log-sum-exp of this frame
-          else llacc += u + log(s);
+        if constexpr (PHASE == 3) {
+          if (lcol == 0 && livef) part[f0 + f] = u + log(s);      // the group's log-sum-exp of this frame
+        } else {
+          // log-likelihood: sum of u + log s over the frames.  log() is ~100 instructions and s lies in [1, 128], so the
+          // s of a lane's frames are multiplied up (16 of them stay below 1e34) and ONE log is taken per eight blocks
+          if (lcol == 0 && livef) {
+            llacc += u;
+            sprod *= s;
+          }
         }
       }
+      if constexpr (PHASE != 3) {
+        if (++nprod == 8) {                   // (wave-uniform)
+          llacc += log(sprod);
+          sprod = 1.0;
+          nprod = 0;
+        }
+      }
+      VCMI_PT(2)
       __syncthreads();
+      VCMI_PT(3)
+      if constexpr (kSortB) {
+        // counting sort of the block's FB frames by winning tile, every wave for itself (lane = frame; ballots + mbcnt):
+        // fperm[position] = frame.  Stable, so the order -- and with it every sum -- is a function of the data alone.
+        static_assert(FB == 64, "one lane per frame");
+        const int k = fkey[lane];
+        int base = 0, pos = 0;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+          const unsigned long long bt = __builtin_amdgcn_ballot_w64(k == t);
+          const int below = __builtin_amdgcn_mbcnt_hi((unsigned)(bt >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bt, 0));
+          pos = (k == t) ? base + below : pos;
+          base += __builtin_popcountll(bt);
+        }
+        fperm[pos] = lane;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the wave's own LDS writes are visible to its reads below
+      }
       if constexpr (PHASE == 1 || PHASE == 3) {  // responsibilities -> G, rows of 128, coalesced
 #pragma unroll
         for (int i = 0; i < FB * C::MMAX / 512; ++i) {
@@ -438,7 +501,7 @@ estep_mfma_kernel(const double *__restrict__ X, int64_t N, int M, const double *
         if constexpr (SHARE) {
           if ((ks & (wpt - 1)) != sub) continue;             // wave-uniform: this tile's waves share the k-steps
         }
-        const int f = 4 * ks + lgrp;
+        const int f = kSortB ? fperm[4 * ks + lgrp] : 4 * ks + lgrp;
         double gm;
         if constexpr (PHASE == 0) gm = lg[f * RSG + 16 * tile + lcol];
         else gm = gpre[ks];
@@ -456,9 +519,16 @@ estep_mfma_kernel(const double *__restrict__ X, int64_t N, int M, const double *
         s0l += gm;
       }
     }
+    VCMI_PT(4)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next block's LDS-DMA has landed
     __syncthreads();
+    VCMI_PT(5)
   }
+#ifdef VCMI_ESTEP_PROF
+  if (blockIdx.x == 3 && (tid & 63) == 0)
+    printf("estep prof wave %d: A %llu | bar %llu | softmax %llu | bar %llu | B %llu | bar %llu\n", wave, pt_[0], pt_[1], pt_[2], pt_[3], pt_[4], pt_[5]);
+#endif
+#undef VCMI_PT
 
   // ---- write this workgroup's partial statistics: rows m = 16 wave + lgrp + 4 r, cols = 16 j + lcol ----
   // row blockIdx.x * wpt + sub of the partial statistics: every mixture tile is written by the wave (tile, sub)
@@ -485,6 +555,7 @@ estep_mfma_kernel(const double *__restrict__ X, int64_t N, int M, const double *
     }
   }
   if constexpr (kGamma && PHASE != 3) {   // log-likelihood: fixed-order reduction inside the workgroup (thread 0: tile 0, sub 0)
+    llacc += log(sprod);
     red[tid] = llacc;
     __syncthreads();
     if (tid == 0) {

@@ -25,6 +25,11 @@
 #include "gmmmap_handle.hpp"
 #include "devgroup.hpp"
 #include "hostpipe.hpp"
+#include "fp64_exp.hpp"
+#ifndef VCMI_CONVERT_PRIO
+#define VCMI_CONVERT_PRIO 1        // s_setprio: 1 = a wave's stretches WITHOUT MFMAs (|z|^2, the test, the y update, the barrier) at high
+                                   // priority, so that it is back in an MFMA stream sooner (+1..2 % on one box); 2 = the reverse; 0 = none
+#endif
 
 #include <atomic>
 #include <cmath>
@@ -99,44 +104,20 @@ struct TilingRT {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 
-// exp for the softmax weights; arguments are <= 0 (or -inf).
-#ifndef VCMI_LEAN_EXP
-#define VCMI_LEAN_EXP 1
-#endif
-// p * r + c with the constant c held in an SGPR pair (VOP3 takes it as an operand).  Left to itself the compiler emits
-// v_fmac_f64 and first copies the 64-bit literal into the destination -- two v_mov_b32 per Horner step, 45 % of the
-// VALU instructions of an exp; the scalar moves that replace them issue on the scalar port.
-__device__ __forceinline__ double vc_fma_sconst(double p, double r, double c) {
-  double d;
-  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(p), "v"(r), "s"(c));
-  return d;
-}
-__device__ __forceinline__ double vc_exp(double x) {
-#if VCMI_LEAN_EXP
-  // e^x for x <= 0: n = rint(x log2 e), r = x - n ln 2 (two-term Cody-Waite), degree-13 Taylor series on |r| <= 0.347
-  // (truncation 4e-18), scaled by 2^n with v_ldexp_f64, which also delivers the underflow to 0.  The softmax epilogue
-  // shares the FP64 pipe with the MFMAs, and two exps per mixture are 45 % of its instructions.
-  x = fmax(x, -1000.0);                                  // also maps -inf; e^-1000 is 0 in double
-  const double n = rint(x * 1.4426950408889634074);
-  double r = fma(n, -6.93147180369123816490e-01, x);
-  r = fma(n, -1.90821492927058770002e-10, r);
-  double p = vc_fma_sconst(1.6059043836821613e-10, r, 2.08767569878681e-09);   // 1/13!, 1/12!
-  p = vc_fma_sconst(p, r, 2.505210838544172e-08);        // 1/11!
-  p = vc_fma_sconst(p, r, 2.755731922398589e-07);        // 1/10!
-  p = vc_fma_sconst(p, r, 2.7557319223985893e-06);       // 1/9!
-  p = vc_fma_sconst(p, r, 2.48015873015873e-05);         // 1/8!
-  p = vc_fma_sconst(p, r, 1.984126984126984e-04);        // 1/7!
-  p = vc_fma_sconst(p, r, 1.388888888888889e-03);        // 1/6!
-  p = vc_fma_sconst(p, r, 8.333333333333333e-03);        // 1/5!
-  p = vc_fma_sconst(p, r, 4.1666666666666664e-02);       // 1/4!
-  p = vc_fma_sconst(p, r, 1.6666666666666666e-01);       // 1/3!
-  p = fma(p, r, 0.5);
-  p = fma(p, r, 1.0);
-  p = fma(p, r, 1.0);
-  return ldexp(p, (int)n);
-#else
-  return exp(x);
-#endif
+// q[lane] -> the sum over the four lanes {lane % 16 + 16 g} (the lane groups of an MFMA result column), in every lane.
+// v_permlane16_swap / v_permlane32_swap (gfx950) exchange 16-lane rows / wave halves between two registers, so each level is
+// two moves, two swaps per 32-bit half and one add -- no LDS round trip (__shfl_xor compiles to ds_bpermute_b32 pairs with an
+// s_waitcnt each).  Same pairs added in the same association as q += shfl_xor(q, 16); q += shfl_xor(q, 32): bit-identical.
+__device__ __forceinline__ double sum_lane_groups(double q) {
+  unsigned lo = __double2loint(q), hi = __double2hiint(q);
+  auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+  auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+  const double x = __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
+  lo = __double2loint(x);
+  hi = __double2hiint(x);
+  auto c = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+  auto d = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+  return __hiloint2double(d[0], c[0]) + __hiloint2double(d[1], c[1]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -149,7 +130,15 @@ __device__ __forceinline__ double vc_exp(double x) {
 // frame tile, mixture m cannot be its first maximum and the remaining tiles are skipped.  The LAST rows of the Cholesky
 // whitening carry the small conditional variances, i.e. most of a wrong mixture's distance: they go first.
 // ------------------------------------------------------------------------------------------------
-template <int DP, int FT, int WAVES, int MODE, int NBUF>
+// PRUNE (MODE 0 only) -- three code shapes of the same arithmetic:
+//   2  "peaked": everything the round-3 loop does (last whitening tile first, tests on the lane groups' shares, per-tile
+//      branches around idle MFMAs) -- pays when almost every (tile, mixture) pair is decided out early;
+//   1  "broad": every whitening tile of every mixture, ONE wave-uniform branch around the regression + softmax update of a
+//      mixture that no frame of the wave's tiles gives a posterior above e^-prune -- the loop body is two straight blocks;
+//   0  dense (prune = +inf): no test at all.
+// In shapes 0 and 1 the weight e^(l - max) is formed BEFORE the regression tiles, so that its dependent chain issues in
+// the shadow of their MFMAs instead of after them.
+template <int DP, int FT, int WAVES, int MODE, int NBUF, int PRUNE = 2>
 __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(DP <= 40 ? (FT == 2 ? 3 : 4) : 2)))
 gmmmap_mfma_kernel(const double *__restrict__ packed, int M, int D, const double *__restrict__ X, int64_t ldx,
                    int64_t T, double *__restrict__ Y, int64_t ldy, double prune, unsigned long long *__restrict__ nreg,
@@ -169,6 +158,10 @@ gmmmap_mfma_kernel(const double *__restrict__ packed, int M, int D, const double
   // matrix).  Values of 8 consecutive mixtures are parked here and then leave as 64-byte rows.
   constexpr int LROW = 10;                                  // 8 values + pad: 16-byte aligned, conflict-free for 16 lanes
   __shared__ __attribute__((aligned(16))) double lstage[(MODE == 1) ? WAVES * FT * 16 * LROW : 2];
+  __shared__ double etab[(MODE == 0 && PRUNE < 2) ? 64 : 1];   // 2^(j/64) for vc_exp_tab
+  if constexpr (MODE == 0 && PRUNE < 2) {
+    if (threadIdx.x < 64) etab[threadIdx.x] = kExp2Tab[threadIdx.x];   // (visible after the barrier that follows the first stage)
+  }
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -199,6 +192,7 @@ gmmmap_mfma_kernel(const double *__restrict__ packed, int M, int D, const double
   }
 
   int nreg_wave = 0;              // MODE 0: (tile, mixture) regressions this wave evaluated (diagnostic counter, see nreg)
+  int nmfma_wave = 0;             // MODE 0: v_mfma_f64_16x16x4 instructions this wave issued (nreg[1]; wave-uniform scalar adds)
   unsigned tiles_in_range = 0;    // the wave's tiles that hold at least one frame < T
 #pragma unroll
   for (int f = 0; f < FT; ++f)
@@ -227,6 +221,10 @@ gmmmap_mfma_kernel(const double *__restrict__ packed, int M, int D, const double
   }
   __syncthreads();
 
+#ifdef VCMI_CONVERT_PROF
+  unsigned long long prof_barrier_ = 0;
+  const unsigned long long prof_t0_ = __builtin_readcyclecounter();
+#endif
   for (int mi = 0; mi < M; ++mi) {
     const int m = (mfirst + mi < M) ? mfirst + mi : mfirst + mi - M;       // mixtures in rotated order (mfirst = 0: index order)
     const double *cur = smem + (NBUF == 2 ? (mi & 1) * BLK : 0);
@@ -234,15 +232,178 @@ gmmmap_mfma_kernel(const double *__restrict__ packed, int M, int D, const double
     // prefetch block m+1 into registers (global -> VGPR), written to LDS after the MFMA work
     // (unconditional: the last iteration re-reads its own block, which keeps `pre` in registers and the loop
     // body free of exec-mask branches)
-    double2 pre[NV];
-    {
-      const int mn = (mi + 1 < M) ? ((m + 1 < M) ? m + 1 : 0) : m;
-      const double2 *src = reinterpret_cast<const double2 *>(packed + (size_t)mn * BLK);
+    // How block m+1 gets into LDS.  A whole-block prefetch into registers issued here is sunk by the compiler down to the LDS
+    // stores at the end of the iteration (24 registers it does not have at 3 waves per SIMD): the full L2 latency then stands
+    // in front of every barrier.  STAGE_DMA (two buffers): global_load_lds_dwordx4 -- 16 bytes per lane straight into the other
+    // buffer, no registers; a wave instruction fills 1 KB; issued here, waited for (vmcnt) just before the barrier.  The
+    // target buffer was last read in the previous iteration, before that iteration's barrier.
+#ifndef VCMI_CONVERT_STAGE
+#define VCMI_CONVERT_STAGE 2
+#endif
+    constexpr bool STAGE_DMA = (VCMI_CONVERT_STAGE == 2 && NBUF == 2);
+    double2 pre[STAGE_DMA ? 1 : NV];
+    const int mn = (mi + 1 < M) ? ((m + 1 < M) ? m + 1 : 0) : m;
+    if constexpr (STAGE_DMA) {
+      const char *gsrc = reinterpret_cast<const char *>(packed + (size_t)mn * BLK) + 16 * tid;
+      char *ldst = reinterpret_cast<char *>(nxt) + 1024 * wave;
 #pragma unroll
-      for (int i = 0; i < NV; ++i) pre[i] = src[tid + i * NTHREADS];
+      for (int i = 0; i < NV; ++i)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gsrc + 16 * NTHREADS * i),
+                                         (__attribute__((address_space(3))) void *)(ldst + 16 * NTHREADS * i), 16, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    } else {
+      const double2 *nsrc = reinterpret_cast<const double2 *>(packed + (size_t)mn * BLK);
+#pragma unroll
+      for (int i = 0; i < NV; ++i) pre[i] = nsrc[tid + i * NTHREADS];
     }
 
     const double lc = cur[TL::LC_OFF];
+    if constexpr (MODE == 0 && PRUNE < 2) {
+      if (lc != -INFINITY) {
+        d4 acc[FT][NT];
+#pragma unroll
+        for (int t = 0; t < NU; ++t) {
+          d4 c;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) c[r] = cur[TL::CINIT_OFF + 16 * t + 4 * r + lgrp];
+#pragma unroll
+          for (int f = 0; f < FT; ++f) acc[f][t] = c;
+        }
+        // ---------------- phase U: whitening tiles, z = U x - cz (k-step major: NU x FT independent chains) ----------------
+        // the fragment of step s+1 is requested before the MFMAs of step s
+        constexpr int NUS = TL::tile_off(NU);                 // fragments of the whitening phase
+#if VCMI_CONVERT_PRIO == 1
+        __builtin_amdgcn_s_setprio(0);
+#elif VCMI_CONVERT_PRIO == 2
+        __builtin_amdgcn_s_setprio(3);
+#endif
+        int s = 0;
+        double a_cur = cur[lane];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+          for (int t = 0; t < NU; ++t) {
+            if (ks < TL::steps(t)) {
+              const double a = a_cur;
+              ++s;
+              if (s < NUS) a_cur = cur[s * 64 + lane];
+#pragma unroll
+              for (int f = 0; f < FT; ++f) acc[f][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, xb[f][ks], acc[f][t], 0, 0, 0);
+            }
+          }
+        }
+        nmfma_wave += FT * NUS;
+#if VCMI_CONVERT_PRIO == 1
+        __builtin_amdgcn_s_setprio(3);      // A/B: the non-MFMA stretches of a wave at high priority
+#elif VCMI_CONVERT_PRIO == 2
+        __builtin_amdgcn_s_setprio(0);
+#endif
+        double l[FT];
+#pragma unroll
+        for (int f = 0; f < FT; ++f) {
+          double qq = 0.0;
+#pragma unroll
+          for (int t = 0; t < NU; ++t) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (16 * t + 4 * r < DP) qq = fma(acc[f][t][r], acc[f][t][r], qq);
+          }
+          l[f] = lc - 0.5 * sum_lane_groups(qq);
+        }
+        bool go = true;
+        if constexpr (PRUNE == 1) {
+          // p_m <= e^(l_m - runmax): below e^-prune on every frame of the wave's tiles -> neither the regression nor the softmax
+          // update can change y (the term is under the rounding error of those that are kept)
+          unsigned long long any = 0;
+#pragma unroll
+          for (int f = 0; f < FT; ++f) any |= __builtin_amdgcn_ballot_w64(l[f] > runmax[f] - prune);
+          go = any != 0;
+        }
+        if (go) {
+          nreg_wave += __builtin_popcount(tiles_in_range);
+          nmfma_wave += FT * (TL::NSTEPS - NUS);
+          // lazy rescale: only when some frame of the wave has a new maximum (wave-uniform; sc = 1 exactly for the others)
+          unsigned long long newmax = 0;
+#pragma unroll
+          for (int f = 0; f < FT; ++f) newmax |= __builtin_amdgcn_ballot_w64(l[f] > runmax[f]);
+          if (newmax) {
+#pragma unroll
+            for (int f = 0; f < FT; ++f) {
+              const double nm = fmax(runmax[f], l[f]);
+              const double sc = vc_exp(runmax[f] - nm);
+              den[f] *= sc;
+              runmax[f] = nm;
+#pragma unroll
+              for (int j = 0; j < KS; ++j) yacc[f][j] *= sc;
+            }
+          }
+          double wg[FT];
+#ifndef VCMI_PAIR_EXP
+#define VCMI_PAIR_EXP 1
+#endif
+          if constexpr (FT == 2 && VCMI_PAIR_EXP) {
+            // every lane group of a column would compute the same e^(l - max): the even groups take frame tile 0, the odd
+            // ones tile 1, and one exchange of 16-lane rows (v_permlane16_swap) hands each its other weight
+            const double dsel = (lgrp & 1) ? l[1] - runmax[1] : l[0] - runmax[0];
+            const double e = vc_exp_tab(dsel, etab);
+            const unsigned elo = __double2loint(e), ehi = __double2hiint(e);
+            auto a = __builtin_amdgcn_permlane16_swap(elo, elo, false, false);
+            auto b = __builtin_amdgcn_permlane16_swap(ehi, ehi, false, false);
+            wg[0] = __hiloint2double(b[0], a[0]);
+            wg[1] = __hiloint2double(b[1], a[1]);
+          } else {
+#pragma unroll
+            for (int f = 0; f < FT; ++f) wg[f] = vc_exp_tab(l[f] - runmax[f], etab);
+          }
+#pragma unroll
+          for (int f = 0; f < FT; ++f) den[f] += wg[f];
+          // ---------------- phase A: regression tiles, E = A x + b ----------------
+#if VCMI_CONVERT_PRIO == 1
+          __builtin_amdgcn_s_setprio(0);
+#elif VCMI_CONVERT_PRIO == 2
+          __builtin_amdgcn_s_setprio(3);
+#endif
+#pragma unroll
+          for (int t = NU; t < NT; ++t) {
+            d4 c;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) c[r] = cur[TL::CINIT_OFF + 16 * t + 4 * r + lgrp];
+#pragma unroll
+            for (int f = 0; f < FT; ++f) acc[f][t] = c;
+          }
+          int sa = NUS;
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+            for (int t = NU; t < NT; ++t) {
+              const double a = cur[sa * 64 + lane];
+              ++sa;
+#pragma unroll
+              for (int f = 0; f < FT; ++f) acc[f][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, xb[f][ks], acc[f][t], 0, 0, 0);
+            }
+          }
+#if VCMI_CONVERT_PRIO == 1
+          __builtin_amdgcn_s_setprio(3);
+#elif VCMI_CONVERT_PRIO == 2
+          __builtin_amdgcn_s_setprio(0);
+#endif
+#pragma unroll
+          for (int f = 0; f < FT; ++f) {
+#pragma unroll
+            for (int t = NU - 1; t < NT; ++t) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const int p0 = 16 * t + 4 * r;
+                if (p0 >= DP && p0 < 2 * DP) {
+                  const int j = (p0 - DP) / 4;
+                  yacc[f][j] = fma(wg[f], acc[f][t][r], yacc[f][j]);
+                }
+              }
+            }
+          }
+        }
+      }
+    } else
     if (lc != -INFINITY) {   // zero-weight mixtures have posterior exactly 0 (wave-uniform branch)
       // ---------------- phase U: whitening tiles, z = U x - cz ----------------
       d4 acc[FT][NT];
@@ -280,8 +441,7 @@ gmmmap_mfma_kernel(const double *__restrict__ packed, int M, int D, const double
             for (int f = 0; f < FT; ++f) {
               if (!(live >> f & 1u)) continue;
               double qq = qp[f];
-              qq += __shfl_xor(qq, 16);
-              qq += __shfl_xor(qq, 32);
+              qq = sum_lane_groups(qq);
               if (__builtin_amdgcn_ballot_w64(lc - 0.5 * qq > runmax[f]) == 0) live &= ~(1u << f);
             }
           }
@@ -289,8 +449,7 @@ gmmmap_mfma_kernel(const double *__restrict__ packed, int M, int D, const double
 #pragma unroll
         for (int f = 0; f < FT; ++f) {
           double qq = qp[f];
-          qq += __shfl_xor(qq, 16);
-          qq += __shfl_xor(qq, 32);
+          qq = sum_lane_groups(qq);
           q[f] = qq;
         }
       } else if constexpr (MODE == 0 && (TL::NU > 1)) {
@@ -314,6 +473,7 @@ gmmmap_mfma_kernel(const double *__restrict__ packed, int M, int D, const double
 #pragma unroll
           for (int f = 0; f < FT; ++f) acc[f][TLAST] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, xb[f][ks], acc[f][TLAST], 0, 0, 0);
         }
+        nmfma_wave += FT * KS;
         unsigned und = (1u << FT) - 1u;        // frame tiles on which the mixture is still undecided
 #pragma unroll
         for (int f = 0; f < FT; ++f) {
@@ -329,6 +489,7 @@ gmmmap_mfma_kernel(const double *__restrict__ packed, int M, int D, const double
         }
         ulive = und;
         if (und) {
+          nmfma_wave += __builtin_popcount(und) * (TL::tile_off(NU) - KS);
 #pragma unroll
           for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
@@ -362,6 +523,7 @@ gmmmap_mfma_kernel(const double *__restrict__ packed, int M, int D, const double
         for (int f = 0; f < FT; ++f) acc[f][t] = c;
       }
       int s = 0;
+      if (MODE == 0) nmfma_wave += FT * TL::tile_off(NU);
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
@@ -385,8 +547,7 @@ gmmmap_mfma_kernel(const double *__restrict__ packed, int M, int D, const double
           }
         }
         if (MODE != 0) {                      // (MODE 0 reduces over the four lane groups only when it has to: see below)
-          qq += __shfl_xor(qq, 16);
-          qq += __shfl_xor(qq, 32);
+          qq = sum_lane_groups(qq);
         }
         q[f] = qq;
       }
@@ -425,13 +586,13 @@ gmmmap_mfma_kernel(const double *__restrict__ packed, int M, int D, const double
             if ((undecided & (undecided >> 16) & (undecided >> 32) & (undecided >> 48) & 0xffffull) == 0) continue;
           }
           double qq = q[f];
-          qq += __shfl_xor(qq, 16);
-          qq += __shfl_xor(qq, 32);
+          qq = sum_lane_groups(qq);
           q[f] = qq;
           if (__builtin_amdgcn_ballot_w64(lc - 0.5 * qq > runmax[f] - prune) != 0) active |= 1u << f;
         }
         if (MODE == 0) nreg_wave += __builtin_popcount(active & tiles_in_range);
         if (active) {
+          if (MODE == 0) nmfma_wave += __builtin_popcount(active) * (TL::NSTEPS - TL::tile_off(NU));
           // ---------------- phase A: regression tiles, E = A x + b (wave-uniform branches around an idle tile's MFMAs) ----------------
           int sa = TL::tile_off(NU);
 #pragma unroll
@@ -519,9 +680,19 @@ gmmmap_mfma_kernel(const double *__restrict__ packed, int M, int D, const double
     }
 
     if (NBUF == 1) __syncthreads();   // single buffer: everyone is done reading before it is overwritten
+#ifdef VCMI_CONVERT_PROF
+    const unsigned long long tb0_ = __builtin_readcyclecounter();
+#endif
+    if constexpr (STAGE_DMA) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
 #pragma unroll
-    for (int i = 0; i < NV; ++i) nxt[tid + i * NTHREADS] = pre[i];
+      for (int i = 0; i < NV; ++i) nxt[tid + i * NTHREADS] = pre[i];
+    }
     __syncthreads();
+#ifdef VCMI_CONVERT_PROF
+    prof_barrier_ += __builtin_readcyclecounter() - tb0_;      // probe build: cycles between arriving at the barrier and leaving it
+#endif
   }
 
   if (MODE == 2 || MODE == 3) {
@@ -534,7 +705,16 @@ gmmmap_mfma_kernel(const double *__restrict__ packed, int M, int D, const double
     }
   }
   if (MODE == 0) {
-    if (nreg && lane == 0) atomicAdd(nreg, (unsigned long long)nreg_wave);
+    if (nreg && lane == 0) {
+#ifdef VCMI_CONVERT_PROF
+      // probe build: the counters carry s_memtime counts instead -- [0] waiting at the loop's barrier, [1] the whole loop
+      atomicAdd(nreg, prof_barrier_);
+      atomicAdd(nreg + 1, __builtin_readcyclecounter() - prof_t0_);
+#else
+      atomicAdd(nreg, (unsigned long long)nreg_wave);
+      atomicAdd(nreg + 1, (unsigned long long)nmfma_wave);
+#endif
+    }
 #pragma unroll
     for (int f = 0; f < FT; ++f) {
       const int64_t fr = frame0 + 16 * f + lcol;
@@ -980,7 +1160,7 @@ gmmmap_group_scatter_kernel(const int *__restrict__ key, int64_t T, int M, int *
 // ------------------------------------------------------------------------------------------------
 // launch helpers
 // ------------------------------------------------------------------------------------------------
-template <int DP, int MODE, int FTV, int WV>
+template <int DP, int MODE, int FTV, int WV, int PRUNE = 2>
 static int launch_mfma(const vcmi_gmmmap *g, const double *dX, int64_t ldx, int64_t T, double *dY, int64_t ldy,
                        hipStream_t st, const int *perm = nullptr, const int *gkey = nullptr) {
   constexpr int FT = (MODE >= 1) ? 2 : FTV;
@@ -989,7 +1169,7 @@ static int launch_mfma(const vcmi_gmmmap *g, const double *dX, int64_t ldx, int6
   // double-buffer the per-mixture block when two copies fit in half of the CU's 160 KiB LDS
   constexpr int NBUF = (2 * (size_t)TL::BLK * sizeof(double) <= 80 * 1024) ? 2 : 1;
   const size_t shmem = NBUF * (size_t)TL::BLK * sizeof(double);
-  auto kern = gmmmap_mfma_kernel<DP, FT, WAVES, MODE, NBUF>;
+  auto kern = gmmmap_mfma_kernel<DP, FT, WAVES, MODE, NBUF, PRUNE>;
   // the attribute is per DEVICE: one flag per device, so a host that drives several GPUs sets it on each of them
   static std::atomic<bool> attr_done[64];
   int dev = 0;
@@ -1008,12 +1188,18 @@ static int launch_mfma(const vcmi_gmmmap *g, const double *dX, int64_t ldx, int6
   return VCMI_OK;
 }
 
-template <int MODE>
+#ifndef VCMI_CONVERT_FT
+#define VCMI_CONVERT_FT 2          // frame tiles per wave and waves per workgroup of the D <= 48 convert kernels (A/B builds)
+#endif
+#ifndef VCMI_CONVERT_WAVES
+#define VCMI_CONVERT_WAVES 4
+#endif
+template <int MODE, int PRUNE = 2>
 static int dispatch_mfma(const vcmi_gmmmap *g, const double *dX, int64_t ldx, int64_t T, double *dY, int64_t ldy,
                          hipStream_t st, const int *perm = nullptr, const int *gkey = nullptr) {
   switch (g->DP) {
 #define VCMI_CASE(DPV) \
-  case DPV: return launch_mfma<DPV, MODE, ((DPV) <= 48 ? 2 : 1), 4>(g, dX, ldx, T, dY, ldy, st, perm, gkey);
+  case DPV: return launch_mfma<DPV, MODE, ((DPV) <= 48 ? VCMI_CONVERT_FT : 1), ((DPV) <= 48 && MODE == 0 ? VCMI_CONVERT_WAVES : 4), PRUNE>(g, dX, ldx, T, dY, ldy, st, perm, gkey);
     VCMI_CASE(16) VCMI_CASE(20) VCMI_CASE(24) VCMI_CASE(28) VCMI_CASE(32) VCMI_CASE(36) VCMI_CASE(40) VCMI_CASE(44)
     VCMI_CASE(48) VCMI_CASE(52) VCMI_CASE(56) VCMI_CASE(60) VCMI_CASE(64) VCMI_CASE(68) VCMI_CASE(72) VCMI_CASE(76)
     VCMI_CASE(80)
@@ -1051,6 +1237,17 @@ static bool use_mfma(const vcmi_gmmmap *g) {
   return gmmmap_has_mfma(g->DP);
 }
 
+static constexpr double kBroadModelFrac = 0.35;
+// Which loop shape converts with this handle (gmmmap_mfma_kernel's PRUNE): 2 "peaked" when, for the model's own frames, the
+// last whitening tile's share of |z|^2 alone puts most mixtures e^-prune under the best one (model_undecided_frac, estimated
+// once by prepare(): 0.02 on the SURVEY 8d synthetic models) -- the loop that looks at that tile first then skips the other
+// whitening tiles; 1 "broad" otherwise (every whitening tile is needed anyway: the straight loop is faster).
+static int convert_shape(const vcmi_gmmmap *g) {
+  if (debug_flag(kDbgConvertShapeBroad)) return 1;
+  if (debug_flag(kDbgConvertShapePeaked)) return 2;
+  return g->model_undecided_frac > kBroadModelFrac ? 1 : 2;
+}
+
 // convert on device pointers
 int gmmmap_convert_device(vcmi_gmmmap *g, const double *dX, int64_t ldx, int64_t T, double *dY, int64_t ldy,
                           hipStream_t st) {
@@ -1084,11 +1281,13 @@ int gmmmap_convert_device(vcmi_gmmmap *g, const double *dX, int64_t ldx, int64_t
       hipLaunchKernelGGL(gmmmap_group_scatter_kernel, dim3((unsigned)((T + 1023) / 1024)), dim3(256), (size_t)2 * g->M * sizeof(int), st,
                          key, T, g->M, cursor, perm);
       VCMI_HIP(hipGetLastError());
-      const int rc = dispatch_mfma<0>(g, dX, ldx, T, dY, ldy, st, perm, key);
+      const int rc = convert_shape(g) == 1 ? dispatch_mfma<0, 1>(g, dX, ldx, T, dY, ldy, st, perm, key)
+                                           : dispatch_mfma<0, 2>(g, dX, ldx, T, dY, ldy, st, perm, key);
       (void)g->grp_order.leave(st);
       return rc;
     }
-    return dispatch_mfma<0>(g, dX, ldx, T, dY, ldy, st);
+    if (!(g->prune < 1e300) && !debug_flag(kDbgConvertShapePeaked)) return dispatch_mfma<0, 0>(g, dX, ldx, T, dY, ldy, st);
+    return convert_shape(g) == 1 ? dispatch_mfma<0, 1>(g, dX, ldx, T, dY, ldy, st) : dispatch_mfma<0, 2>(g, dX, ldx, T, dY, ldy, st);
   }
   if (g->kernel_choice != 1 && g->At.p && g->D > 16 && g->D <= 160) {
     // no tile-kernel instantiation (80 < padded D <= 160, or a padded dimension outside its list): MFMA log-densities
@@ -1159,6 +1358,81 @@ int gmmmap_predict_device(vcmi_gmmmap *g, const double *dX, int64_t ldx, int64_t
 // ------------------------------------------------------------------------------------------------
 // model preparation (host) and upload
 // ------------------------------------------------------------------------------------------------
+// How broad is the model?  256 frames are drawn from p(x) itself (stratified over the weights, fixed-seed normal deviates:
+// x = mu_m + L_m z, i.e. U_m (x - mu_m) = z solved by forward substitution) and for each the mixtures within e^-46 of the best
+// one are counted.  Returns the mean fraction of the M mixtures.  A property of the model only; it selects the loop SHAPE of
+// fvconvert (convert_shape), never a result.
+static double model_active_fraction(const std::vector<double> &hU, const std::vector<double> &hcz, const std::vector<double> &hlc,
+                                    const std::vector<double> &hmux, const double *w, int D, int DP, int M,
+                                    double *undecided_frac) {
+  constexpr int S = 256;
+  const size_t pp = (size_t)DP * DP;
+  std::vector<double> cdf(M);
+  double tot = 0.0;
+  for (int m = 0; m < M; ++m) cdf[m] = (tot += (w[m] > 0.0 ? w[m] : 0.0));
+  if (undecided_frac) *undecided_frac = 0.0;
+  if (!(tot > 0.0) || M < 2) return 0.0;
+  std::vector<int> counts(S, 0), undecided(S, 0);
+  const int r_last = 16 * ((DP + 15) / 16 - 1);                       // first row of the last whitening tile
+  host_parallel_for(S, 8, [&](int64_t lo, int64_t hi) {
+    std::vector<double> x(D), z(D);
+    for (int s = (int)lo; s < (int)hi; ++s) {
+      const double u = (s + 0.5) / S * tot;
+      int m = 0;
+      while (m + 1 < M && cdf[m] < u) ++m;
+      uint64_t st = 0x9E3779B97F4A7C15ull * (uint64_t)(s + 1);          // splitmix64 stream per frame
+      auto rnd = [&]() {
+        st += 0x9E3779B97F4A7C15ull;
+        uint64_t v = st;
+        v = (v ^ (v >> 30)) * 0xBF58476D1CE4E5B9ull;
+        v = (v ^ (v >> 27)) * 0x94D049BB133111EBull;
+        v ^= v >> 31;
+        return ((double)(v >> 11) + 0.5) * (1.0 / 9007199254740992.0);
+      };
+      for (int d = 0; d < D; d += 2) {                                  // Box-Muller
+        const double r = std::sqrt(-2.0 * std::log(rnd())), a = 6.283185307179586 * rnd();
+        z[d] = r * std::cos(a);
+        if (d + 1 < D) z[d + 1] = r * std::sin(a);
+      }
+      const double *Um = &hU[pp * m];
+      for (int r = 0; r < D; ++r) {                                     // U_m (x - mu_m) = z, U_m lower triangular
+        double acc = z[r];
+        for (int c = 0; c < r; ++c) acc -= Um[(size_t)r * DP + c] * x[c];
+        x[r] = acc / Um[(size_t)r * DP + r];
+      }
+      for (int d = 0; d < D; ++d) x[d] += hmux[(size_t)D * m + d];
+      double best = -INFINITY;
+      std::vector<double> l(M), qlast(M);
+      for (int n = 0; n < M; ++n) {
+        const double *Un = &hU[pp * n];
+        double q = 0.0, ql = 0.0;
+        for (int r = 0; r < D; ++r) {
+          double zz = -hcz[(size_t)DP * n + r];
+          for (int c = 0; c <= r; ++c) zz += Un[(size_t)r * DP + c] * x[c];
+          q += zz * zz;
+          if (r >= r_last) ql += zz * zz;
+        }
+        l[n] = hlc[n] - 0.5 * q;
+        qlast[n] = ql;
+        best = std::max(best, l[n]);
+      }
+      int cnt = 0;
+      for (int n = 0; n < M; ++n) cnt += (l[n] > best - 46.0);
+      counts[s] = cnt;
+      int und = 0;                                                     // ... and on the last 16-row whitening tile's share alone
+      for (int n = 0; n < M; ++n) und += (hlc[n] - 0.5 * qlast[n] > best - 46.0);
+      undecided[s] = und;
+    }
+  });
+  double sum = 0.0, sumu = 0.0;
+  for (int s = 0; s < S; ++s) {
+    sum += counts[s];
+    sumu += undecided[s];
+  }
+  if (undecided_frac) *undecided_frac = sumu / ((double)S * M);
+  return sum / ((double)S * M);
+}
+
 // px_only: (mu, sigma) describe a plain GMM p(x) of dimension Dj (no target half): only the whitening side is prepared
 // (used by the full-covariance E-step, estep.hip); the regression blocks stay zero and the convert layouts are skipped.
 static int prepare(vcmi_gmmmap *g, const double *w, const double *mu, const double *sigma, int Dj, int M, int swap,
@@ -1246,6 +1520,7 @@ static int prepare(vcmi_gmmmap *g, const double *w, const double *mu, const doub
     if (bs < M && bs <= bp) return fail(VCMI_ERR_NOT_PD, "Sigma^xx of mixture %d is singular", bs + 1);
     if (bp < M) return fail(VCMI_ERR_NOT_PD, "Sigma^xx of mixture %d is not positive definite", bp + 1);
   }
+  if (!px_only) g->model_active_frac = model_active_fraction(hU, hcz, hlc, g->h_mux, w, D, DP, M, &g->model_undecided_frac);
   // row-major blocks for the generic kernels; a p(x)-only handle that takes the MFMA path needs only its packed blocks
   // (device buffers are grow-only so that a handle re-prepared every EM iteration does not re-allocate)
   if (!(px_only && gmmmap_has_mfma(DP))) {
@@ -1732,11 +2007,28 @@ extern "C" int vcmi_gmmmap_prune_stats(vcmi_gmmmap *g, int enable, int64_t *eval
     }
   }
   if (enable) {
-    if (!g->prune_count.p) VCMI_TRY(g->prune_count.alloc(1));
-    VCMI_HIP(hipMemset(g->prune_count.p, 0, sizeof(unsigned long long)));
+    if (!g->prune_count.p) VCMI_TRY(g->prune_count.alloc(2));
+    VCMI_HIP(hipMemset(g->prune_count.p, 0, 2 * sizeof(unsigned long long)));
   } else {
     g->prune_count.release();
   }
+  return VCMI_OK;
+}
+
+extern "C" int vcmi_gmmmap_convert_plan(vcmi_gmmmap *g, int64_t *mfma_issued, int *shape, double *model_active_frac,
+                                        double *model_undecided_frac) {
+  if (!g) return fail(VCMI_ERR_ARG, "vcmi_gmmmap_convert_plan: NULL handle");
+  if (mfma_issued) {
+    *mfma_issued = 0;
+    if (g->prune_count.p) {
+      unsigned long long h = 0;
+      VCMI_HIP(hipMemcpy(&h, g->prune_count.p + 1, sizeof(h), hipMemcpyDeviceToHost));
+      *mfma_issued = (int64_t)h;
+    }
+  }
+  if (shape) *shape = !use_mfma(g) ? -1 : (!(g->prune < 1e300) ? 0 : convert_shape(g));
+  if (model_active_frac) *model_active_frac = g->model_active_frac;
+  if (model_undecided_frac) *model_undecided_frac = g->model_undecided_frac;
   return VCMI_OK;
 }
 

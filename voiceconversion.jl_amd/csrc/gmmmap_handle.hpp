@@ -11,7 +11,14 @@ struct vcmi_gmmmap {
   // fvconvert skips the regression of mixture m for a 16-frame tile when l_m < max_l - prune (nats) for all its frames:
   // the posterior there is below e^-prune (1e-20 at 46: under the rounding error of the sum).  +inf: dense loop.
   double prune = 46.0;
-  vcmi::DevBuf<unsigned long long> prune_count;   // optional diagnostic counter (vcmi_gmmmap_prune_stats)
+  vcmi::DevBuf<unsigned long long> prune_count;   // optional diagnostic counters (vcmi_gmmmap_prune_stats): [0] (tile, mixture) regressions, [1] MFMAs issued
+  // Mean fraction of the mixtures that lie within e^-46 of the best one for a frame drawn from the model itself (256 frames
+  // sampled on the host by prepare(), fixed seed).  Reported by vcmi_gmmmap_convert_plan (synthetic SURVEY 8d models: 1/M;
+  // the reference's trained 32-mixture model: 0.37).
+  double model_active_frac = 0.0;
+  // ... and the mean fraction of the mixtures that the LAST 16-row whitening tile's share of |z|^2 alone does not put
+  // e^-46 under the best one: what the "peaked" loop's first test leaves undecided.  Selects the loop shape (convert_shape).
+  double model_undecided_frac = 0.0;
 
   // host copies kept for accessors and for TrajectoryGMMMap's constructor (row-major (D,D) per mixture)
   std::vector<double> h_A_julia;   // Julia memory image (D,D,M) of ΣʸˣΣˣˣ⁻¹

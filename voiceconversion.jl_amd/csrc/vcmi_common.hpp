@@ -105,6 +105,8 @@ enum : unsigned {
   kDbgDtwGridOrder = 512u,    // fused DTW: one workgroup per job in grid order instead of persistent workgroups drawing tickets
   kDbgTrajOneWgPerCu = 128u,  // blocked trajectory solver: one workgroup per CU even where two fit
   kDbgConvertNoGrouping = 2048u,  // fvconvert: frames in the caller's order (no grouping by nearest source mean)
+  kDbgConvertShapeBroad = 4096u,  // fvconvert: the "broad model" loop (every whitening tile, one branch around the regression) whatever the model
+  kDbgConvertShapePeaked = 8192u, // fvconvert: the "peaked model" loop (last whitening tile first, per-tile tests) whatever the model
   kDbgPredictNoEarlyExit = 64u   // predict / trajectory argmax: every whitening tile of every mixture (MODE 2) instead of the early exit (MODE 3)
 };
 bool debug_flag(unsigned which);

@@ -67,6 +67,13 @@ class GMMMap(FrameByFrameConverter):
         _lib.check(_lib.lib.vcmi_gmmmap_prune_stats(self._h, 1 if enable else 0, C.byref(n)))
         return int(n.value)
 
+    def convert_plan(self):
+        """(MFMA instructions issued since prune_stats(True), loop shape 0 dense / 1 broad / 2 peaked / -1 no tile kernel,
+        model_active_frac, model_undecided_frac) -- include/vcmi.h: vcmi_gmmmap_convert_plan."""
+        n, shape, frac, und = C.c_int64(0), C.c_int(0), C.c_double(0.0), C.c_double(0.0)
+        _lib.check(_lib.lib.vcmi_gmmmap_convert_plan(self._h, C.byref(n), C.byref(shape), C.byref(frac), C.byref(und)))
+        return int(n.value), int(shape.value), float(frac.value), float(und.value)
+
     def _fvconvert(self, x, out=None):
         if is_torch(x):
             import torch
