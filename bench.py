@@ -134,7 +134,7 @@ def attach_traffic(out, fname, kernel_prefixes, fetch_factor=VECTOR_FETCH_FACTOR
                             "`traffic_raw` = FETCH + WRITE as counted" % (json.dumps(fetch_factor),))
 
 
-def measure_traffic_live(workload, extra=(), timeout=240):
+def measure_traffic_live(workload, extra=(), timeout=360):
     """Run tools/pmc_traffic.py for `workload` as CHILD processes (two rocprofv3 --pmc passes of this same bench command,
     kernel-trace only).  Must be called before this process has touched the GPU.  Returns the per-kernel table or None."""
     import shutil
@@ -349,34 +349,20 @@ def convert_model(variant):
 
 
 def pcie_roof(nbytes=320_000_000):
-    """What the link gives: pinned host memory <-> HBM, one direction at a time and both at once (two streams).  GB/s."""
-    import torch
+    """What the link gives the library's own staging path: its pinned slots, its upload / download streams, the chunks
+    staged_pipeline moves -- without host memcpy or kernels (vcmi_debug_pcie_probe).  GB/s."""
+    import ctypes as C
 
-    h_in = torch.empty(nbytes // 8, dtype=torch.float64).pin_memory()
-    h_out = torch.empty(nbytes // 8, dtype=torch.float64).pin_memory()
-    d_in = torch.empty(nbytes // 8, dtype=torch.float64, device="cuda")
-    d_out = torch.empty(nbytes // 8, dtype=torch.float64, device="cuda")
-    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    from voiceconversion_jl_amd import _lib
 
-    def run(h2d, d2h, reps=3):
-        best = 1e30
-        for _ in range(reps + 1):
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            if h2d:
-                with torch.cuda.stream(s1):
-                    d_in.copy_(h_in, non_blocking=True)
-            if d2h:
-                with torch.cuda.stream(s2):
-                    h_out.copy_(d_out, non_blocking=True)
-            torch.cuda.synchronize()
-            best = min(best, time.perf_counter() - t0)
-        return best
-
-    th, td, tb = run(True, False), run(False, True), run(True, True)
-    return {"h2d_GBps": nbytes / th / 1e9, "d2h_GBps": nbytes / td / 1e9, "duplex_GBps_per_direction": nbytes / tb / 1e9,
-            "duplex_ms_for_2x%dMB" % (nbytes // 1_000_000): tb * 1e3,
-            "how": "torch pinned tensors, copy_(non_blocking) on one / two streams, best of 3"}
+    out = (C.c_double * 3)()
+    fn = _lib.lib.vcmi_debug_pcie_probe
+    fn.argtypes, fn.restype = [C.c_size_t, C.POINTER(C.c_double)], C.c_int
+    _lib.check(fn(nbytes, out))
+    return {"h2d_GBps": out[0], "d2h_GBps": out[1], "duplex_GBps_per_direction": out[2],
+            "duplex_ms_for_2x%dMB" % (nbytes // 1_000_000): nbytes / out[2] / 1e6,
+            "how": "vcmi_debug_pcie_probe: hipMemcpyAsync of the pipeline's chunks between the ring's pinned slots and HBM on its "
+                   "upload / download streams, alone and both at once, best of 4"}
 
 
 def bench_convert(args, world, rank, variant="synthetic"):
@@ -984,13 +970,34 @@ def summarize(out):
 CPU_CACHE = os.path.join(__import__("tempfile").gettempdir(), "vcmi_bench_cpu_baseline.json")
 
 
-def cpu_baseline_cache_store(table):
-    """N = 1 measured the CPU baselines; keep them for the N > 1 runs that follow on the same box."""
+def cpu_baseline_cache_store(table, values=None):
+    """N = 1 measured the CPU baselines; keep them for the N > 1 runs that follow on the same box -- and the N = 1 `value`
+    of every workload with the hash of the library it came from, which an N > 1 line of the same library compares its
+    per-rank rate with (`n1_consistency`)."""
     try:
         json.dump({"measured": time.strftime("%Y-%m-%dT%H:%M:%SZ", time.gmtime()), "host_cores": os.cpu_count(),
-                   "cpu_baseline": table}, open(CPU_CACHE, "w"))
+                   "cpu_baseline": table, "n1_values": values or {}, "library_source_hash": source_hash()}, open(CPU_CACHE, "w"))
     except OSError:
         pass
+
+
+def n1_consistency(table, world):
+    """Weak scaling with no data-path collective: a rank of an N-GPU run does what the N = 1 run did, so value / N must be
+    the N = 1 value of the same library on the same box (to a few per cent: clocks, PCIe root sharing).  Reported, not
+    enforced -- a failed assertion would cost the line itself."""
+    try:
+        c = json.load(open(CPU_CACHE))
+    except (OSError, ValueError):
+        return {"available": False, "why": "no N=1 run of this library on this box before this one"}
+    if c.get("library_source_hash") != source_hash():
+        return {"available": False, "why": "the cached N=1 run used another build of the library"}
+    out = {"available": True, "n1_measured": c.get("measured")}
+    for name, d in table.items():
+        v1 = c.get("n1_values", {}).get(name)
+        if v1 and isinstance(d, dict) and d.get("value"):
+            ratio = d["value"] / world / v1
+            out[name] = {"n1_value": v1, "per_rank_value": d["value"] / world, "ratio": ratio, "within_5pct": bool(abs(ratio - 1.0) <= 0.05)}
+    return out
 
 
 def cpu_baseline_cached(workload):
@@ -1106,6 +1113,8 @@ def main():
                 d.pop("cpu_baseline", None)
         if args.workload == "all" and "cpu_baseline" in table["convert"]:
             out["cpu_baseline"] = table["convert"]["cpu_baseline"]
+        if rank == 0:
+            out["n1_consistency"] = n1_consistency(table, world)
     elif rank == 0 and args.workload != "selftest" and args.cpu_seconds > 0:
         have = {name: d["cpu_baseline"] for name, d in table.items() if isinstance(d.get("cpu_baseline"), dict) and "value" in d["cpu_baseline"]}
         if have:
@@ -1114,7 +1123,12 @@ def main():
             except (OSError, KeyError, ValueError):
                 prev = {}
             prev.update(have)
-            cpu_baseline_cache_store(prev)
+            try:
+                prev_vals = json.load(open(CPU_CACHE)).get("n1_values", {})
+            except (OSError, KeyError, ValueError):
+                prev_vals = {}
+            prev_vals.update({name: d["value"] for name, d in table.items() if isinstance(d, dict) and d.get("value")})
+            cpu_baseline_cache_store(prev, prev_vals)
     out["n_gpus"] = world
     out["per_rank"] = dict(PER_RANK)
     out["collective_backend"] = BACKEND["name"]

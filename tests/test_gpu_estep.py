@@ -68,6 +68,29 @@ def test_vs_oracle(vc, N, Dj, M, generic):
     assert abs(ll - rl) < TOL * abs(rl)
 
 
+@pytest.mark.parametrize("M", [129, 256])
+def test_group_of_mixtures_without_weight(vc, M):
+    """More than 128 mixtures run in groups of 128.  A group whose mixtures ALL have zero weight (a padded model: M = 129
+    with w[129] = 0, or a whole second group of zeros) has every l = -inf: its responsibilities are exactly zero and its
+    log-sum-exp -inf -- not NaN in every statistic."""
+    from oracle import c_oracle as co, np_oracle as npo
+    N, Dj = 3000, 80
+    w, mu, _ = npo.synth_model(4100 + M, Dj, M)
+    w = w.copy()
+    w[128:] = 0.0
+    w /= w.sum()
+    rg = np.random.default_rng(M)
+    var = np.exp(rg.uniform(np.log(1e-3), 0.0, (M, Dj)))
+    comp = rg.choice(M, size=N, p=w)
+    X = mu[comp] + rg.standard_normal((N, Dj)) * np.sqrt(var[comp])
+    r0, r1, r2, rl = co.estep_diag(X, w, mu, var)
+    S0, S1, S2, ll = vc.estep_diag(X.T, w, mu.T, var.T)
+    assert np.all(np.isfinite(S0)) and np.all(np.isfinite(S1)) and np.all(np.isfinite(S2)) and np.isfinite(ll)
+    assert np.all(S0[128:] == 0.0) and np.all(S1[:, 128:] == 0.0)
+    assert relerr(S0, r0) < TOL and relerr(S1, r1.T) < TOL and relerr(S2, r2.T) < TOL
+    assert abs(ll - rl) < TOL * abs(rl)
+
+
 def test_device_resident_deterministic_and_additive(vc):
     """Run-to-run bit-identical (fixed-order reductions, no atomics) and additive over frame shards -- the
     property the multi-GPU all-reduce relies on."""

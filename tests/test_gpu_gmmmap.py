@@ -316,5 +316,55 @@ def test_frame_grouping_changes_nothing_visible(vc, D, M, T, lam_lo):
     back = torch.empty_like(Ys)
     back[perm] = Ys
     assert float((torch.linalg.norm(back - Yg, dim=1) / torch.linalg.norm(Yg, dim=1)).max()) < 1e-13
-    # repeat runs are bit-identical although the order inside a group is not fixed
-    assert torch.equal(vc.fvconvert(g, Xd.t()).t(), Yg)
+    # repeat runs are bit-identical: the grouping is a stable counting sort (round 4), so the tiles, the rotated mixture
+    # order of every workgroup and with them every sum are a function of the data alone
+    for _ in range(4):
+        assert torch.equal(vc.fvconvert(g, Xd.t()).t(), Yg)
+
+
+@pytest.mark.parametrize("which", ["synthetic", "broad", "fixture"])
+def test_loop_shapes_agree_and_the_model_picks_one(vc, fixture_model, which):
+    """gmmmap_mfma_kernel has three code shapes for fvconvert (include/vcmi.h: vcmi_gmmmap_convert_plan): 0 dense
+    (set_prune(inf)), 1 "broad" (every whitening tile, one branch around the regression), 2 "peaked" (last whitening tile
+    first).  Which of 1 / 2 runs is a property of the MODEL, estimated at creation from 256 frames drawn from it; the test
+    hook forces either.  All of them give the dense loop's y to rounding and the oracle's to TOL; the counters add up."""
+    import torch
+    from oracle import c_oracle as co, np_oracle as npo
+    from voiceconversion_jl_amd import _lib
+    if which == "fixture":
+        w, mu, sig = fixture_model
+        expect = 1
+    else:
+        w, mu, sig = npo.synth_model(1002, 80, 64, lam_lo=1e-5 if which == "synthetic" else 1e-1)
+        expect = 2 if which == "synthetic" else 1
+    M, T, D = len(w), 20000, 40
+    X = npo.sample_frames(9, w, mu, sig, T, 0, D)
+    Xd = torch.from_numpy(X).cuda()
+    g = vc.GMMMap(*julia_model(w, mu, sig))
+    _, shape, active, undecided = g.convert_plan()
+    assert shape == expect, (shape, active, undecided)
+    assert 1.0 / M - 1e-9 <= active <= 1.0 and 0.0 <= undecided <= 1.0
+    g.set_prune(float("inf"))
+    assert g.convert_plan()[1] == 0
+    g.prune_stats(True)
+    Yd = vc.fvconvert(g, Xd.t()).t().clone()
+    issued, _, _, _ = g.convert_plan()
+    tiles = -(-T // 16)
+    assert g.prune_stats(False) == tiles * M
+    assert issued == 2 * 42 * M * 4 * (-(-T // 128))     # 42 MFMAs per (tile, mixture) at D = 40, two tiles per wave, four waves per workgroup
+    g.set_prune(46.0)
+    ref = co.GMMMap(w, mu, sig).fvconvert(X[:400])
+    for force in (_lib.DBG_CONVERT_SHAPE_BROAD, _lib.DBG_CONVERT_SHAPE_PEAKED, 0):
+        _lib.debug_force(force)
+        try:
+            g.prune_stats(True)
+            Y = vc.fvconvert(g, Xd.t()).t().clone()
+            n_issued, sh, _, _ = g.convert_plan()
+            n_reg = g.prune_stats(False)
+        finally:
+            _lib.debug_force(0)
+        assert sh == (1 if force == _lib.DBG_CONVERT_SHAPE_BROAD else 2 if force == _lib.DBG_CONVERT_SHAPE_PEAKED else expect)
+        assert 0 < n_issued <= issued and 0 < n_reg <= tiles * M
+        err = float((torch.linalg.norm(Y - Yd, dim=1) / torch.linalg.norm(Yd, dim=1)).max())
+        assert err < 1e-13, (force, err)
+        assert frame_relerr(Y[:400].cpu().numpy().T, ref.T) < TOL

@@ -154,6 +154,36 @@ def test_estep_through_rccl_single_rank(vc):
         assert relerr(np.atleast_1d(a), np.atleast_1d(b)) <= 1e-12
 
 
+def test_two_physical_devices_when_the_box_has_them(vc):
+    """Runs by itself wherever two GPUs are visible (the 1-GPU boxes of this pool skip it): the group [0, 1] shards
+    fvconvert over both devices (bit-identical to one device) and the E-step's local statistics meet in ONE ncclAllReduce
+    between two single-process communicators (ncclCommInitAll) -- equal to one device to 1e-12 (the sum's order differs)."""
+    if vc.device_count() < 2:
+        pytest.skip(f"needs 2 GPUs; this box has {vc.device_count()}")
+    from oracle import np_oracle as npo
+    rng = np.random.default_rng(5)
+    Dj, M, N = 80, 128, 200_000
+    w, mu, sig = npo.synth_model(31, Dj, 16)
+    g = vc.GMMMap(*julia_model(w, mu, sig))
+    X = np.asfortranarray(npo.sample_frames(32, w, mu, sig, 50_000, 0, 40).T)
+    vc.set_devices([])
+    y1 = vc.fvconvert(g, X)
+    we, mue, _ = npo.synth_model(33, Dj, M)
+    var = np.exp(rng.uniform(np.log(1e-3), 0.0, (M, Dj)))
+    comp = rng.choice(M, size=N, p=we)
+    Xe = mue[comp] + rng.standard_normal((N, Dj)) * np.sqrt(var[comp])
+    one = vc.estep_diag(Xe.T, we, mue.T, var.T)
+    try:
+        vc.set_devices([0, 1])
+        y2 = vc.fvconvert(g, X)
+        two = vc.estep_diag(Xe.T, we, mue.T, var.T)
+    finally:
+        vc.set_devices([])
+    assert np.array_equal(y1, y2)
+    for a, b in zip(one, two):
+        assert relerr(np.atleast_1d(a), np.atleast_1d(b)) <= 1e-12
+
+
 def test_estep_refuses_duplicate_devices(vc):
     vc.set_devices([0, 0])
     with pytest.raises(vc.VCMIError, match="distinct devices"):

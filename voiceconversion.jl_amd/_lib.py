@@ -169,6 +169,7 @@ DBG_TRAJ_GENERIC, DBG_TRAJ_G_SCALAR, DBG_GV_ONE_TEAM, DBG_PREDICT_TWO_PASS, DBG_
 DBG_PREDICT_NO_EARLY_EXIT = 64
 DBG_TRAJ_ONE_WG_PER_CU = 128
 DBG_CONVERT_NO_GROUPING = 2048
+DBG_CONVERT_SHAPE_BROAD, DBG_CONVERT_SHAPE_PEAKED = 4096, 8192
 DBG_DTW_NO_SEGMENTS, DBG_DTW_GRID_ORDER = 256, 512
 
 

@@ -1109,6 +1109,7 @@ static int dtw_run_fused(const double *feats, std::vector<DtwPair> &pairs, int D
     double best = 1e30;
     for (int c : {1, 2, 3, 4, 5, 6, 8}) {
       if (c > 1 && (!segments_allowed || tavg / c < 64 || base_jobs <= slots)) break;
+      if (c > 2 && debug_flag(kDbgDtwTwoSegments)) break;
       const double t = std::ceil(base_jobs * c / slots) / c * (1.0 + 0.04 * (c - 1));
       if (t < best - 1e-9) {
         best = t;

@@ -141,8 +141,14 @@ estep_group_combine_kernel(double *__restrict__ G, const double *__restrict__ ls
     for (int g = 0; g < ngroups; ++g) s += exp(lse[(size_t)g * n + f] - u);
     const double L = u + log(s);
     for (int g = 0; g < ngroups; ++g) {
-      const double sc = exp(lse[(size_t)g * n + f] - L);
+      const double lg = lse[(size_t)g * n + f];
       double *row = G + (size_t)g * gstride + f * 128;
+      if (lg == -INFINITY) {                    // a group without any weight: its responsibilities are exactly zero
+        row[lane] = 0.0;
+        row[lane + 64] = 0.0;
+        continue;
+      }
+      const double sc = exp(lg - L);
       row[lane] *= sc;
       row[lane + 64] *= sc;
     }
@@ -438,7 +444,9 @@ estep_mfma_kernel(const double *__restrict__ X, int64_t N, int M, const double *
         }
         s = row16_sum(s);
         const bool livef = (f0 + f < N);
-        const double inv = livef ? 1.0 / s : 0.0;          // frames beyond N contribute gamma = 0
+        // frames beyond N contribute gamma = 0; so does a slot group whose mixtures ALL have zero weight (every l = -inf:
+        // u = -inf, s = 0 -- a 128-group of a padded model, M = 129 with w[129] = 0): gamma = 0 and log-sum-exp = -inf, not NaN
+        const double inv = (livef && s > 0.0) ? 1.0 / s : 0.0;
 #pragma unroll
         for (int i = 0; i < C::MMAX / 16; ++i)
           if (!SHARE || i < mtp) row[16 * i] = v[i] * inv;

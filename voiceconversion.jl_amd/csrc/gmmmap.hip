@@ -1059,101 +1059,158 @@ convert_from_logdens_kernel(const double *__restrict__ LP, int M, int D, int DP,
 // that union large; the same frames grouped by mixture leave one or two.  The grouping does not have to be right -- any
 // permutation gives the same y, frame by frame -- only cheap and mostly right: the NEAREST SOURCE MEAN (Euclidean), one
 // small MFMA product per tile ([-2 mu | |mu|^2] x [x ; 1], 44 MFMAs per 16 frames at D = 40, M = 64 against 2400 for the
-// conversion).  Three kernels: keys + histogram, prefix, counting-sort scatter (ranks inside a workgroup from LDS atomics,
-// one global atomic per workgroup and mixture; the order inside a group is arbitrary and does not matter).
+// conversion).  Three kernels: keys + a histogram per chunk of 1024 frames, a prefix over (group, chunk), and a STABLE
+// counting-sort scatter (round 4; the first version ranked with LDS / global atomics, which left the order inside a group --
+// hence the tiles, the rotated mixture order of a boundary workgroup and the last bit of a frame shared by several
+// mixtures -- to the scheduler).
 // gfrag[mt][ks][lane]: A-operand fragments, rows = mixtures 16 mt + (lane & 15), k = 4 ks + (lane >> 4); the last k-step
 // carries |mu|^2 (rows >= M: 1e300, never the minimum).
 // ------------------------------------------------------------------------------------------------
+constexpr int kGroupChunk = 1024;     // frames per chunk of the grouping sort (64 tiles of 16; 16 wave rows of 64)
+
+// keys + one histogram per CHUNK of 1024 consecutive frames (chunkhist[c][m]); a workgroup walks chunks blockIdx.x,
+// blockIdx.x + gridDim.x, ... with the operand fragments staged once.  The counts are integers: whatever order the LDS
+// atomics arrive in, the histogram is the same.
 template <int DP>
 __global__ void __launch_bounds__(256)
 gmmmap_group_key_kernel(const double *__restrict__ gfrag, int M, int D, const double *__restrict__ X, int64_t ldx, int64_t T,
-                        int *__restrict__ key, int *__restrict__ cnt) {
+                        int *__restrict__ key, int *__restrict__ chunkhist) {
   constexpr int KS = DP / 4, KS1 = KS + 1;
   extern __shared__ double gsm[];
   const int MT = (M + 15) / 16, nfrag = MT * KS1 * 64;
   int *hist = reinterpret_cast<int *>(gsm + nfrag);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lcol = lane & 15, lgrp = lane >> 4;
   for (int e = tid; e < nfrag; e += 256) gsm[e] = gfrag[e];
-  for (int m = tid; m < M; m += 256) hist[m] = 0;
-  __syncthreads();
   const double one = (lgrp == 0) ? 1.0 : 0.0;
-  for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile * 16 < T; tile += (int64_t)gridDim.x * 4) {
-    const int64_t fr = tile * 16 + lcol;
-    double xb[KS];
+  const int64_t nchunks = (T + kGroupChunk - 1) / kGroupChunk;
+  for (int64_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
+    for (int m = tid; m < M; m += 256) hist[m] = 0;
+    __syncthreads();
+    for (int i = 0; i < kGroupChunk / 64; ++i) {
+      const int64_t fr = c * kGroupChunk + 16 * (4 * i + wave) + lcol;
+      if (fr - lcol >= T) break;                                    // (wave-uniform)
+      double xb[KS];
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      const int k = 4 * ks + lgrp;
-      xb[ks] = (fr < T && k < D) ? X[fr * ldx + k] : 0.0;
-    }
-    double best = INFINITY;
-    int bm = 0;
-    for (int mt = 0; mt < MT; ++mt) {
-      const double *A = gsm + (size_t)mt * KS1 * 64 + lane;
-      d4 acc = {0.0, 0.0, 0.0, 0.0};
+      for (int ks = 0; ks < KS; ++ks) {
+        const int k = 4 * ks + lgrp;
+        xb[ks] = (fr < T && k < D) ? X[fr * ldx + k] : 0.0;
+      }
+      double best = INFINITY;
+      int bm = 0;
+      for (int mt = 0; mt < MT; ++mt) {
+        const double *A = gsm + (size_t)mt * KS1 * 64 + lane;
+        d4 acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(A[ks * 64], xb[ks], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(A[KS * 64], one, acc, 0, 0, 0);
+        for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(A[ks * 64], xb[ks], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(A[KS * 64], one, acc, 0, 0, 0);
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-        if (acc[r] < best) {
-          best = acc[r];
-          bm = 16 * mt + 4 * r + lgrp;
+        for (int r = 0; r < 4; ++r)
+          if (acc[r] < best) {
+            best = acc[r];
+            bm = 16 * mt + 4 * r + lgrp;
+          }
+      }
+#pragma unroll
+      for (int sh = 16; sh < 64; sh <<= 1) {
+        const double ov = __shfl_xor(best, sh);
+        const int om = __shfl_xor(bm, sh);
+        if (ov < best || (ov == best && om < bm)) {
+          best = ov;
+          bm = om;
         }
-    }
-#pragma unroll
-    for (int sh = 16; sh < 64; sh <<= 1) {
-      const double ov = __shfl_xor(best, sh);
-      const int om = __shfl_xor(bm, sh);
-      if (ov < best || (ov == best && om < bm)) {
-        best = ov;
-        bm = om;
+      }
+      if (lgrp == 0 && fr < T) {
+        bm = bm < M ? bm : 0;
+        key[fr] = bm;
+        atomicAdd(&hist[bm], 1);
       }
     }
-    if (lgrp == 0 && fr < T) {
-      bm = bm < M ? bm : 0;
-      key[fr] = bm;
-      atomicAdd(&hist[bm], 1);
-    }
-  }
-  __syncthreads();
-  for (int m = tid; m < M; m += 256)
-    if (hist[m]) atomicAdd(&cnt[m], hist[m]);
-}
-
-// cursor[m] = first position of group m (exclusive prefix of the counts)
-__global__ void __launch_bounds__(64) gmmmap_group_scan_kernel(const int *__restrict__ cnt, int M, int *__restrict__ cursor) {
-  if (threadIdx.x == 0) {
-    int pos = 0;
-    for (int m = 0; m < M; ++m) {
-      cursor[m] = pos;
-      pos += cnt[m];
-    }
+    __syncthreads();
+    for (int m = tid; m < M; m += 256) chunkhist[c * M + m] = hist[m];
+    __syncthreads();
   }
 }
 
-// perm: frames in group order.  1024 frames per workgroup: local ranks by LDS atomics, one range per (workgroup, group)
+// One workgroup per group m: chunkhist[c][m] -> its exclusive prefix over the chunks (in place) and total[m].
 __global__ void __launch_bounds__(256)
-gmmmap_group_scatter_kernel(const int *__restrict__ key, int64_t T, int M, int *__restrict__ cursor, int *__restrict__ perm) {
-  extern __shared__ int lcnt[];            // [M] counts, then [M] bases
-  int *base = lcnt + M;
-  const int tid = threadIdx.x;
-  for (int m = tid; m < M; m += 256) lcnt[m] = 0;
+gmmmap_group_scan_kernel(int *__restrict__ chunkhist, int64_t nchunks, int M, int *__restrict__ total) {
+  __shared__ int part[256];
+  const int m = blockIdx.x, tid = threadIdx.x;
+  const int64_t per = (nchunks + 255) / 256, lo = std::min<int64_t>(nchunks, tid * per), hi = std::min<int64_t>(nchunks, lo + per);
+  int sum = 0;
+  for (int64_t c = lo; c < hi; ++c) sum += chunkhist[c * M + m];
+  part[tid] = sum;
   __syncthreads();
-  const int64_t f0 = (int64_t)blockIdx.x * 1024;
-  int k[4], r[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int64_t fr = f0 + tid + 256 * i;
-    k[i] = fr < T ? key[fr] : -1;
-    r[i] = k[i] >= 0 ? atomicAdd(&lcnt[k[i]], 1) : 0;
+  if (tid == 0) {
+    int run = 0;
+    for (int i = 0; i < 256; ++i) {
+      const int v = part[i];
+      part[i] = run;
+      run += v;
+    }
+    total[m] = run;
   }
   __syncthreads();
-  for (int m = tid; m < M; m += 256) base[m] = lcnt[m] ? atomicAdd(&cursor[m], lcnt[m]) : 0;
+  int run = part[tid];
+  for (int64_t c = lo; c < hi; ++c) {
+    const int v = chunkhist[c * M + m];
+    chunkhist[c * M + m] = run;
+    run += v;
+  }
+}
+
+// perm: frames in group order, and inside a group in FRAME order (a stable counting sort: the permutation, hence every tile
+// of the convert kernel and every sum it forms, is a function of the data alone -- repeat runs are bit-identical).  One
+// workgroup per chunk; position = sum of the smaller groups' totals + the group's frames in earlier chunks (chunkhist after
+// the scan) + those in earlier 64-frame rows of this chunk + those on lower lanes of the row.
+__global__ void __launch_bounds__(256)
+gmmmap_group_scatter_kernel(const int *__restrict__ key, int64_t T, int M, const int *__restrict__ chunkhist,
+                            const int *__restrict__ total, int *__restrict__ perm) {
+  extern __shared__ int lsm[];             // [M] group bases, then [16][M] row counts -> row bases
+  int *base = lsm, *rowcnt = lsm + M;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t c = blockIdx.x, f0 = c * kGroupChunk;
+  if (tid == 0) {
+    int run = 0;
+    for (int m = 0; m < M; ++m) {
+      base[m] = run + chunkhist[c * M + m];
+      run += total[m];
+    }
+  }
+  for (int e = tid; e < 16 * M; e += 256) rowcnt[e] = 0;
+  __syncthreads();
+  int k[4], rank[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = wave + 4 * i;                                   // row of 64 consecutive frames
+    const int64_t fr = f0 + 64 * r + lane;
+    k[i] = fr < T ? key[fr] : -1;
+    rank[i] = 0;
+    unsigned long long rem = __builtin_amdgcn_ballot_w64(k[i] >= 0);
+    while (rem) {                                                  // one turn per distinct key of the row
+      const int lead = __builtin_ctzll(rem);
+      const int k0 = __builtin_amdgcn_readlane(k[i], lead);
+      const unsigned long long mask = __builtin_amdgcn_ballot_w64(k[i] == k0);
+      if (k[i] == k0) rank[i] = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
+      if (lane == lead) rowcnt[r * M + k0] = __builtin_popcountll(mask);
+      rem &= ~mask;
+    }
+  }
+  __syncthreads();
+  for (int m = tid; m < M; m += 256) {
+    int run = 0;
+    for (int r = 0; r < 16; ++r) {
+      const int v = rowcnt[r * M + m];
+      rowcnt[r * M + m] = run;
+      run += v;
+    }
+  }
   __syncthreads();
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int64_t fr = f0 + tid + 256 * i;
-    if (k[i] >= 0) perm[base[k[i]] + r[i]] = (int)fr;
+    const int r = wave + 4 * i;
+    const int64_t fr = f0 + 64 * r + lane;
+    if (k[i] >= 0) perm[base[k[i]] + rowcnt[r * M + k[i]] + rank[i]] = (int)fr;
   }
 }
 
@@ -1199,7 +1256,7 @@ static int dispatch_mfma(const vcmi_gmmmap *g, const double *dX, int64_t ldx, in
                          hipStream_t st, const int *perm = nullptr, const int *gkey = nullptr) {
   switch (g->DP) {
 #define VCMI_CASE(DPV) \
-  case DPV: return launch_mfma<DPV, MODE, ((DPV) <= 48 ? VCMI_CONVERT_FT : 1), ((DPV) <= 48 && MODE == 0 ? VCMI_CONVERT_WAVES : 4), PRUNE>(g, dX, ldx, T, dY, ldy, st, perm, gkey);
+  case DPV: return launch_mfma<DPV, MODE, ((DPV) <= 48 ? VCMI_CONVERT_FT : 1), ((DPV) == 40 && MODE == 0 ? VCMI_CONVERT_WAVES : 4), PRUNE>(g, dX, ldx, T, dY, ldy, st, perm, gkey);
     VCMI_CASE(16) VCMI_CASE(20) VCMI_CASE(24) VCMI_CASE(28) VCMI_CASE(32) VCMI_CASE(36) VCMI_CASE(40) VCMI_CASE(44)
     VCMI_CASE(48) VCMI_CASE(52) VCMI_CASE(56) VCMI_CASE(60) VCMI_CASE(64) VCMI_CASE(68) VCMI_CASE(72) VCMI_CASE(76)
     VCMI_CASE(80)
@@ -1261,25 +1318,25 @@ int gmmmap_convert_device(vcmi_gmmmap *g, const double *dX, int64_t ldx, int64_t
     const size_t gshmem = (size_t)MT * (g->DP / 4 + 1) * 64 * sizeof(double) + (size_t)g->M * sizeof(int);
     if (T >= 8192 && T < ((int64_t)1 << 31) && g->M >= 4 && g->gfrag.p && gshmem <= 64 * 1024 && g->prune < 1e300 &&
         !debug_flag(kDbgConvertNoGrouping)) {
-      VCMI_TRY(g->grp.reserve((size_t)2 * T + 2 * g->M));
+      const int64_t nchunks = (T + kGroupChunk - 1) / kGroupChunk;
+      VCMI_TRY(g->grp.reserve((size_t)2 * T + (size_t)(nchunks + 1) * g->M));
       VCMI_TRY(g->grp_order.enter(st));
-      int *key = g->grp.p, *perm = key + T, *cnt = perm + T, *cursor = cnt + g->M;
-      VCMI_HIP(hipMemsetAsync(cnt, 0, (size_t)g->M * sizeof(int), st));
+      int *key = g->grp.p, *perm = key + T, *chunkhist = perm + T, *total = chunkhist + nchunks * g->M;
       int cus = 256;
       (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, g->device);
-      const unsigned kgrid = (unsigned)std::min<int64_t>((T + 63) / 64, (int64_t)cus * 8);
+      const unsigned kgrid = (unsigned)std::min<int64_t>(nchunks, (int64_t)cus * 4);
       switch (g->DP) {
 #define VCMI_CASE(DPV) \
-  case DPV: hipLaunchKernelGGL(gmmmap_group_key_kernel<DPV>, dim3(kgrid), dim3(256), gshmem, st, g->gfrag.p, g->M, g->D, dX, ldx, T, key, cnt); break;
+  case DPV: hipLaunchKernelGGL(gmmmap_group_key_kernel<DPV>, dim3(kgrid), dim3(256), gshmem, st, g->gfrag.p, g->M, g->D, dX, ldx, T, key, chunkhist); break;
         VCMI_CASE(16) VCMI_CASE(20) VCMI_CASE(24) VCMI_CASE(28) VCMI_CASE(32) VCMI_CASE(36) VCMI_CASE(40) VCMI_CASE(44)
         VCMI_CASE(48) VCMI_CASE(52) VCMI_CASE(56) VCMI_CASE(60) VCMI_CASE(64) VCMI_CASE(68) VCMI_CASE(72) VCMI_CASE(76)
         VCMI_CASE(80)
 #undef VCMI_CASE
         default: return fail(VCMI_ERR_ARG, "no MFMA instantiation for padded dimension %d", g->DP);
       }
-      hipLaunchKernelGGL(gmmmap_group_scan_kernel, dim3(1), dim3(64), 0, st, cnt, g->M, cursor);
-      hipLaunchKernelGGL(gmmmap_group_scatter_kernel, dim3((unsigned)((T + 1023) / 1024)), dim3(256), (size_t)2 * g->M * sizeof(int), st,
-                         key, T, g->M, cursor, perm);
+      hipLaunchKernelGGL(gmmmap_group_scan_kernel, dim3((unsigned)g->M), dim3(256), 0, st, chunkhist, nchunks, g->M, total);
+      hipLaunchKernelGGL(gmmmap_group_scatter_kernel, dim3((unsigned)nchunks), dim3(256), (size_t)17 * g->M * sizeof(int), st,
+                         key, T, g->M, chunkhist, total, perm);
       VCMI_HIP(hipGetLastError());
       const int rc = convert_shape(g) == 1 ? dispatch_mfma<0, 1>(g, dX, ldx, T, dY, ldy, st, perm, key)
                                            : dispatch_mfma<0, 2>(g, dX, ldx, T, dY, ldy, st, perm, key);

@@ -1,6 +1,10 @@
 // hostpipe.cpp -- pinned staging rings, worker-thread copies and the chunked upload / kernel / download pipeline
 // behind the host-pointer entry points (see hostpipe.hpp).
 #include "hostpipe.hpp"
+#include <chrono>
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
 
 #include <algorithm>
 #include <atomic>
@@ -86,15 +90,22 @@ bool cpus_of_node(int node, cpu_set_t *set) {
   return n > 0;
 }
 // memory policy of the calling thread for the duration of a scope: allocations prefer `node` (MPOL_PREFERRED = 1)
+// The caller's own policy (an inherited `numactl --membind / --interleave`) is read first and put back afterwards; when it
+// cannot be read nothing is changed at all.
 struct ScopedPreferNode {
   bool active = false;
+  int old_mode = 0;
+  unsigned long old_mask[16] = {};            // 1024 nodes
   explicit ScopedPreferNode(int node) {
     if (node < 0 || node >= 64) return;
+    if (syscall(SYS_get_mempolicy, &old_mode, old_mask, (unsigned long)(sizeof(old_mask) * 8 + 1), nullptr, 0ul) != 0) return;
     unsigned long mask = 1ul << node;
     active = syscall(SYS_set_mempolicy, 1 /*MPOL_PREFERRED*/, &mask, 65ul) == 0;
   }
   ~ScopedPreferNode() {
-    if (active) (void)syscall(SYS_set_mempolicy, 0 /*MPOL_DEFAULT*/, nullptr, 0ul);
+    if (!active) return;
+    if (syscall(SYS_set_mempolicy, old_mode, old_mask, (unsigned long)(sizeof(old_mask) * 8 + 1)) != 0)
+      (void)syscall(SYS_set_mempolicy, 0 /*MPOL_DEFAULT*/, nullptr, 0ul);
   }
 };
 // Which node the copy workers and the pinned slots of a device go to.  Measured on the two-socket boxes (tools/hostbench.py,
@@ -146,6 +157,10 @@ class Pool {
 
  private:
   Pool() {
+    if (sched_getaffinity(0, sizeof(inherited_), &inherited_) != 0) {
+      CPU_ZERO(&inherited_);
+      for (int k = 0; k < CPU_SETSIZE; ++k) CPU_SET(k, &inherited_);
+    }
     unsigned hw = std::thread::hardware_concurrency();
     int n = (int)std::min(16u, std::max(2u, hw / 4));
     if (const char *e = getenv("VCMI_HOST_THREADS")) n = std::max(0, std::min(64, atoi(e)));
@@ -166,14 +181,15 @@ class Pool {
       // feed, so their copies and the pages they first touch stay off the inter-socket link
       const int want = g_pool_node.load(std::memory_order_relaxed);
       if (want != bound && want != -2) {
-        cpu_set_t set;
+        // never outside the CPU set the process was started with (taskset / numactl / a container's cpuset): the node's
+        // CPUs are intersected with the mask the pool inherited, and "no binding" means that mask again, not all CPUs
+        cpu_set_t set, both;
+        bool narrowed = false;
         if (want >= 0 && cpus_of_node(want, &set)) {
-          (void)sched_setaffinity(0, sizeof(set), &set);
-        } else {
-          CPU_ZERO(&set);
-          for (int k = 0; k < CPU_SETSIZE; ++k) CPU_SET(k, &set);
-          (void)sched_setaffinity(0, sizeof(set), &set);
+          CPU_AND(&both, &set, &inherited_);
+          narrowed = CPU_COUNT(&both) > 0;
         }
+        (void)sched_setaffinity(0, sizeof(cpu_set_t), narrowed ? &both : &inherited_);
         bound = want;
       }
       (*t.fn)(t.lo, t.hi);
@@ -184,6 +200,7 @@ class Pool {
   std::condition_variable cv_;
   std::deque<Task> q_;
   int nworkers_ = 0;
+  cpu_set_t inherited_;      // affinity of the thread that created the pool: the workers stay inside it
 };
 
 }  // namespace
@@ -217,16 +234,67 @@ void host_parallel_for(int64_t n, int64_t grain, const std::function<void(int64_
   latch.c.wait(lk, [&] { return latch.remaining == 0; });
 }
 
-// fn(lo, hi) over [0, n) in parts of `grain`, queued for the workers WITHOUT waiting (the caller goes on; nothing reports
-// completion): used to pre-fault output pages ahead of the pipeline.  fn must not touch anything that can go away.
-static void host_async_for(int64_t n, int64_t grain, std::function<void(int64_t, int64_t)> fn) {
-  if (n <= 0) return;
+// fn(lo, hi) over [0, n) in parts of `grain`, queued for the workers; the caller goes on and MUST call host_async_wait on
+// the returned latch before the memory fn touches can go away (used to pre-fault output pages ahead of the pipeline: the
+// caller's array must not be freed, unmapped and its range reused while pieces are still queued -- ADVICE r3).
+static std::shared_ptr<Latch> host_async_for(int64_t n, int64_t grain, std::function<void(int64_t, int64_t)> fn) {
+  if (n <= 0) return nullptr;
   Pool &pool = Pool::get();
-  if (pool.workers() == 0) return;
+  if (pool.workers() == 0) return nullptr;
   auto owned = std::make_shared<const std::function<void(int64_t, int64_t)>>(std::move(fn));
+  auto latch = std::make_shared<Latch>();
   std::vector<Task> tasks;
-  for (int64_t lo = 0; lo < n; lo += grain) tasks.push_back(Task{owned.get(), lo, std::min(n, lo + grain), nullptr, owned});
+  for (int64_t lo = 0; lo < n; lo += grain) tasks.push_back(Task{owned.get(), lo, std::min(n, lo + grain), latch, owned});
+  latch->remaining = (int)tasks.size();
   pool.push(tasks.data(), (int)tasks.size());
+  return latch;
+}
+// Runs queued pieces itself until none is left, then waits for the ones the workers hold.
+static void host_async_wait(const std::shared_ptr<Latch> &latch) {
+  if (!latch) return;
+  Pool &pool = Pool::get();
+  while (!latch->finished() && pool.try_run_one()) {
+  }
+  std::unique_lock<std::mutex> lk(latch->m);
+  latch->c.wait(lk, [&] { return latch->remaining == 0; });
+}
+
+// memcpy whose stores bypass the caches (AVX2 vmovntdq on 32-byte aligned destinations).  The pipeline's copies are
+// parts of a few hundred KB -- under glibc's own non-temporal threshold -- so plain memcpy writes them with ordinary stores:
+// every destination line is first READ from memory (read-for-ownership), three transfers per byte copied instead of two,
+// on a socket whose memory the two DMA streams are using as well.  VCMI_HOST_NT=0 (read once) goes back to memcpy.
+#if defined(__x86_64__)
+__attribute__((target("avx2"))) static void copy_stream_avx2(char *d, const char *s, size_t n) {
+  while (n && ((uintptr_t)d & 31)) {      // head: up to the destination's alignment
+    *d++ = *s++;
+    --n;
+  }
+  size_t v = n / 128;
+  for (; v; --v, d += 128, s += 128) {
+    const __m256i a = _mm256_loadu_si256((const __m256i *)s), b = _mm256_loadu_si256((const __m256i *)(s + 32)),
+                  c = _mm256_loadu_si256((const __m256i *)(s + 64)), e = _mm256_loadu_si256((const __m256i *)(s + 96));
+    _mm256_stream_si256((__m256i *)d, a);
+    _mm256_stream_si256((__m256i *)(d + 32), b);
+    _mm256_stream_si256((__m256i *)(d + 64), c);
+    _mm256_stream_si256((__m256i *)(d + 96), e);
+  }
+  _mm_sfence();
+  n &= 127;
+  if (n) memcpy(d, s, n);
+}
+#endif
+static void copy_bytes(void *dst, const void *src, size_t n) {
+#if defined(__x86_64__)
+  static const bool nt = [] {
+    const char *e = getenv("VCMI_HOST_NT");
+    return !(e && e[0] == '0') && __builtin_cpu_supports("avx2");
+  }();
+  if (nt && n >= 4096) {
+    copy_stream_avx2((char *)dst, (const char *)src, n);
+    return;
+  }
+#endif
+  memcpy(dst, src, n);
 }
 
 void host_copy(void *dst, const void *src, size_t bytes) {
@@ -238,7 +306,7 @@ void host_copy(void *dst, const void *src, size_t bytes) {
   const int64_t nblk = (int64_t)((bytes + blk - 1) / blk);
   host_parallel_for(nblk, 2, [=](int64_t lo, int64_t hi) {
     const size_t a = (size_t)lo * blk, b = std::min(bytes, (size_t)hi * blk);
-    memcpy((char *)dst + a, (const char *)src + a, b - a);
+    copy_bytes((char *)dst + a, (const char *)src + a, b - a);
   });
 }
 
@@ -499,6 +567,7 @@ int staged_pipeline(const void *hIn, size_t in_unit, size_t in_stride, void *hOu
   VCMI_TRY(r->quiesce());
   // A large output array is usually fresh (`similar(X)`, numpy.empty): its first touch is ~80k page faults per 320 MB.
   // Ask for huge pages on the 2 MB-aligned interior before the workers touch it (a hint; ignored where unsupported).
+  std::shared_ptr<Latch> prefault;     // joined before this function returns, on the error path too
   {
     const size_t span = (size_t)(units - 1) * out_stride + out_unit, huge = (size_t)2 << 20;
     if (span >= 16 * huge) {
@@ -517,7 +586,7 @@ int staged_pipeline(const void *hIn, size_t in_unit, size_t in_stride, void *hOu
     if (populate && span >= 4 * huge) {
       char *base = reinterpret_cast<char *>(hOut);
       constexpr size_t piece = (size_t)8 << 20;
-      host_async_for((int64_t)((span + piece - 1) / piece), 1, [base, span](int64_t lo, int64_t hi) {
+      prefault = host_async_for((int64_t)((span + piece - 1) / piece), 1, [base, span](int64_t lo, int64_t hi) {
         constexpr size_t piece = (size_t)8 << 20;
         const long pg = 4096;
         for (int64_t k = lo; k < hi; ++k) {
@@ -531,6 +600,9 @@ int staged_pipeline(const void *hIn, size_t in_unit, size_t in_stride, void *hOu
   }
   constexpr int LAG = K - 1;
   int rc = VCMI_OK;
+  // (Round 4 tried to run the gather of chunk c+1 on the workers BESIDE the caller's scatter of chunk c-LAG instead of one
+  // after the other: 15-19 ms per 10^6 frames against 9.2-9.8 ms on the same box -- two host copies and two DMA streams at
+  // once saturate the socket's memory, and the DMAs are what gets slower.  One host copy at a time it stays.)
   auto body = [&]() -> int {
     for (int64_t c = 0; c < nch + LAG; ++c) {
       if (c < nch) {
@@ -562,10 +634,48 @@ int staged_pipeline(const void *hIn, size_t in_unit, size_t in_stride, void *hOu
   };
   rc = body();
   if (rc != VCMI_OK) (void)r->quiesce();   // leave nothing in flight on the slots
+  host_async_wait(prefault);               // no pre-fault piece outlives the call (the caller may free hOut right away)
   return rc;
 }
 
 }  // namespace vcmi
+
+// Measurement hook (not part of include/vcmi.h; bench.py's `host_inclusive.pcie`): what the link gives THIS library's own
+// staging path -- the ring's pinned slots and its upload / download streams, chunk by chunk as staged_pipeline moves them,
+// without any host memcpy or kernel: out[0] = H2D alone, out[1] = D2H alone, out[2] = both directions at once (GB/s per
+// direction), for `bytes` per direction.
+extern "C" int vcmi_debug_pcie_probe(size_t bytes, double *out) {
+  using namespace vcmi;
+  if (!out || bytes == 0) return fail(VCMI_ERR_ARG, "vcmi_debug_pcie_probe: bad argument");
+  Ring *r = nullptr;
+  VCMI_TRY(current_ring(&r));
+  std::lock_guard<std::mutex> lk(r->mu);
+  VCMI_TRY(r->init());
+  const size_t chunk = kPipeChunk;
+  VCMI_TRY(r->reserve(r->pin_in, r->pin_in_cap, chunk, true));
+  VCMI_TRY(r->reserve(r->pin_out, r->pin_out_cap, chunk, true));
+  VCMI_TRY(r->reserve(r->dev_in, r->dev_in_cap, chunk, false));
+  VCMI_TRY(r->reserve(r->dev_out, r->dev_out_cap, chunk, false));
+  VCMI_TRY(r->quiesce());
+  const int64_t nch = (int64_t)((bytes + chunk - 1) / chunk);
+  for (int mode = 0; mode < 3; ++mode) {
+    double best = 1e30;
+    for (int rep = 0; rep < 4; ++rep) {
+      VCMI_TRY(r->quiesce());
+      const auto t0 = std::chrono::steady_clock::now();
+      for (int64_t c = 0; c < nch; ++c) {
+        const int s = (int)(c % K);
+        const size_t n = std::min(chunk, bytes - (size_t)c * chunk);
+        if (mode != 1) VCMI_HIP(hipMemcpyAsync(r->dev_in[s], r->pin_in[s], n, hipMemcpyHostToDevice, r->up));
+        if (mode != 0) VCMI_HIP(hipMemcpyAsync(r->pin_out[s], r->dev_out[s], n, hipMemcpyDeviceToHost, r->down));
+      }
+      VCMI_TRY(r->quiesce());
+      best = std::min(best, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+    }
+    out[mode] = (double)bytes / best / 1e9;
+  }
+  return VCMI_OK;
+}
 
 // test hooks (not part of include/vcmi.h): the worker-thread copies without a device, for the CPU stress / sanitizer tests
 extern "C" int vcmi_debug_host_copy(void *dst, const void *src, size_t bytes) {
