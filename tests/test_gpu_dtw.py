@@ -226,7 +226,10 @@ def test_column_segments_and_persistent_workgroups(vc, D):
     d = vc.DTW(fstep=0, bstep=2)
     tl, sl = [t.T for t, _ in pairs], [s.T for _, s in pairs]
     paths = vc.fit_batch(d, tl, sl)
-    for flag in (_lib.DBG_DTW_NO_SEGMENTS, _lib.DBG_DTW_GRID_ORDER, _lib.DBG_DTW_NO_SEGMENTS | _lib.DBG_DTW_GRID_ORDER):
+    # (DBG_DTW_WHOLE_FIRST: round 4's schedule experiment -- a full round's worth of single-strip pairs as whole-length jobs,
+    # only the rest cut; DBG_DTW_TWO_SEGMENTS: at most two segments per strip)
+    for flag in (_lib.DBG_DTW_NO_SEGMENTS, _lib.DBG_DTW_GRID_ORDER, _lib.DBG_DTW_NO_SEGMENTS | _lib.DBG_DTW_GRID_ORDER,
+                 _lib.DBG_DTW_WHOLE_FIRST, _lib.DBG_DTW_TWO_SEGMENTS):
         _lib.debug_force(flag)
         try:
             other = vc.fit_batch(d, tl, sl)
@@ -263,7 +266,11 @@ def test_segmented_jobs_at_benchmark_size_repeatedly(vc):
     finally:
         _lib.debug_force(0)
     for rep in range(6):
-        seg = vc.fit_batch(d, tl, sl)
+        _lib.debug_force(_lib.DBG_DTW_WHOLE_FIRST if rep >= 4 else 0)       # the last two: whole-length jobs first (round 4 experiment)
+        try:
+            seg = vc.fit_batch(d, tl, sl)
+        finally:
+            _lib.debug_force(0)
         bad = [i for i, (a, b) in enumerate(zip(whole, seg)) if not np.array_equal(a, b)]
         assert not bad, (rep, bad[:10])
     for i in range(0, 1000, 97):

@@ -1155,6 +1155,21 @@ static int dtw_run_fused(const double *feats, std::vector<DtwPair> &pairs, int D
         if (whole[(size_t)j].row0 + whole[(size_t)j].nrows == ds.row0) below[i] = j;
     }
   }
+  // Round 4 experiment (off by default: `vcmi_debug_force` kDbgDtwWholeFirst): whole-length jobs for the first rounds,
+  // segments only where they balance.  Cutting EVERY strip makes every strip's template rows travel nseg times (2.7 x the
+  // algorithmic bytes at nseg = 3), and the segments earn their keep in the last round only: with J jobs on S slots the first
+  // floor(J / S) - 1 rounds are full whatever the unit is.  So that many slots' worth of single-strip pairs ran as ONE job
+  // each, ahead of everything else, and only the rest was cut -- the same number of (1 / nseg)-rounds on paper, a third of
+  // the re-reads (2.06 template loads per strip instead of 3: 1.55 x the algorithmic bytes).  Measured, 1000 pairs, one box,
+  // alternating: 1.455 / 1.477 ms against 1.419 / 1.424 ms with every strip cut (two segments at most: 1.515): the long jobs
+  // of the first round end ragged, and the slots that finish early find only segments whose predecessors are still running.
+  // The re-reads are what the balance costs; every strip stays cut.
+  std::vector<char> run_whole(whole.size(), 0);
+  if (nseg > 1 && debug_flag(kDbgDtwWholeFirst)) {
+    const double base_jobs = (double)(packed.size() / 4) + (double)whole.size();
+    int64_t quota = (int64_t)slots * std::max<int64_t>(0, (int64_t)std::floor(base_jobs / slots) - 1);
+    for (size_t i = wide.size(); i < wide.size() + singles.size() && quota > 0; ++i, --quota) run_whole[i] = 1;
+  }
   std::vector<std::vector<int>> pflag(packed.size(), std::vector<int>((size_t)nseg, -1));
   std::vector<std::vector<int>> wflag(whole.size(), std::vector<int>((size_t)nseg, -1));
   std::vector<DtwStrip> strips;
@@ -1183,6 +1198,13 @@ static int dtw_run_fused(const double *feats, std::vector<DtwPair> &pairs, int D
     }
     for (size_t i = 0; i < whole.size(); ++i) {
       DtwStrip ds = segment_of(whole[i], k, wflag[i], whole[i].bnd_out >= 0);
+      if (run_whole[i]) {                          // one job over all columns, in the first pass
+        if (k > 0) continue;
+        ds = whole[i];
+        ds.col0 = 0;
+        ds.ncol = pairs[(size_t)ds.pair].T;
+        ds.flag_prev = ds.flag_in = ds.flag_out = -1;      // a single strip: nobody waits for it, it waits for nobody
+      }
       if (ds.ncol <= 0) continue;                  // (short sequences: fewer segments than nseg)
       // (the strip below has the same T, hence the same segment boundaries: its segment k exists whenever this one does)
       if (below[i] >= 0) ds.flag_in = below_packed[i] ? pflag[(size_t)below[i]][(size_t)k] : wflag[(size_t)below[i]][(size_t)k];

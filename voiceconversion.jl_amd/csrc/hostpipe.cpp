@@ -555,7 +555,12 @@ int staged_pipeline(const void *hIn, size_t in_unit, size_t in_stride, void *hOu
   std::lock_guard<std::mutex> lk(r->mu);
   VCMI_TRY(r->init());
   const size_t wide = std::max(in_unit, out_unit);
-  int64_t chunk = std::max<int64_t>(min_chunk_units, (int64_t)(kPipeChunk / std::max<size_t>(wide, 1)));
+  static const size_t pipe_chunk = [] {          // A/B hook, read once: VCMI_HOST_CHUNK_MB (default: kPipeChunk)
+    const char *e = getenv("VCMI_HOST_CHUNK_MB");
+    const long mb = e ? atol(e) : 0;
+    return (mb >= 1 && mb <= 256) ? (size_t)mb << 20 : kPipeChunk;
+  }();
+  int64_t chunk = std::max<int64_t>(min_chunk_units, (int64_t)(pipe_chunk / std::max<size_t>(wide, 1)));
   int64_t nch = (units + chunk - 1) / chunk;
   chunk = ((units + nch - 1) / nch + 255) / 256 * 256;
   chunk = std::min(chunk, (units + 255) / 256 * 256);
