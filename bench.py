@@ -392,16 +392,19 @@ def bench_convert(args, world, rank, variant="synthetic"):
     # What the matrix pipe was actually given: the kernel counts its own v_mfma_f64_16x16x4 instructions (wave-uniform scalar
     # adds; vcmi_gmmmap_convert_plan) in one extra, untimed launch on the same frames; profiles/r04_clock/ holds the same
     # number from the SQ_INSTS_MFMA counter.
-    g.prune_stats(True)
-    step()
-    torch.cuda.synchronize()
-    issued_mfma, shape, active_frac, undecided_frac = g.convert_plan()
-    nreg = g.prune_stats(False)
+    # (profiling runs, --cpu-seconds 0, launch nothing but the warm-up and the timed steps: the PMC passes count there)
+    _, shape, active_frac, undecided_frac = g.convert_plan()
+    issued_mfma, nreg = None, None
+    if args.cpu_seconds > 0:
+        g.prune_stats(True)
+        step()
+        torch.cuda.synchronize()
+        issued_mfma = g.convert_plan()[0]
+        nreg = g.prune_stats(False)
     per_pair_dense = 42 if D == 40 else None               # MFMA steps per (16-frame tile, mixture) with nothing skipped, D = 40
-    issued_flops = issued_mfma * MFMA_FLOP
     alg_tflops = flops / (kernel_ms * 1e-3) / 1e12
-    iss_tflops = issued_flops / (kernel_ms * 1e-3) / 1e12
-    achieved = min(alg_tflops, iss_tflops)
+    iss_tflops = (issued_mfma * MFMA_FLOP / (kernel_ms * 1e-3) / 1e12) if issued_mfma else None
+    achieved = min(alg_tflops, iss_tflops) if iss_tflops else alg_tflops
     out = {
         "metric": "converted frames/sec (D=40, M=64) at 1/2/4/8 MI355X vs CPU ref" if headline else
                   "converted frames/sec (D=40, M=%d), %s model" % (M, variant),
@@ -426,11 +429,11 @@ def bench_convert(args, world, rank, variant="synthetic"):
                                         "either (the dense loop issues 344,064 flop per frame for 324,160 algorithmic)",
                      "flop_per_frame": convert_flops_per_frame(D, M),
                      "algorithmic_frac": alg_tflops / FP64_PEAK_TFLOPS,
-                     "issued_mfma_frac": iss_tflops / FP64_PEAK_TFLOPS,
+                     "issued_mfma_frac": (iss_tflops / FP64_PEAK_TFLOPS) if iss_tflops else None,
                      "mfma_issued_per_launch": issued_mfma,
                      "mfma_issued_source": "in-kernel count (vcmi_gmmmap_convert_plan); SQ_INSTS_MFMA of the same kernel: profiles/r04_clock/",
-                     "work_skipped": (1.0 - issued_mfma / float(per_pair_dense * tiles * M)) if per_pair_dense else None,
-                     "regressions_evaluated_frac": nreg / float(tiles * M),
+                     "work_skipped": (1.0 - issued_mfma / float(per_pair_dense * tiles * M)) if (per_pair_dense and issued_mfma) else None,
+                     "regressions_evaluated_frac": (nreg / float(tiles * M)) if nreg is not None else None,
                      "loop_shape": {0: "dense", 1: "broad", 2: "peaked"}.get(shape, str(shape)),
                      "model_active_frac": active_frac, "model_undecided_frac": undecided_frac,
                      "hbm_GBps_algorithmic": 2 * D * 8 * T / (kernel_ms * 1e-3) / 1e9},
@@ -591,7 +594,31 @@ def bench_estep(args, world, rank):
     PER_RANK.update(per_rank_step)
     fps = world * N * args.steps / wall
     mfma_path = Dj % 2 == 0 and Dj <= 160 and M <= 128           # estep.hip: estep_device
-    achieved = estep_flops_per_frame(Dj, M) * N / (kernel_ms * 1e-3) / 1e12
+    # what the matrix pipe was given: the kernel counts its own MFMAs in one extra, untimed step (vcmi_debug_estep_mfma) --
+    # step B skips k-steps whose responsibilities are all exactly zero, so the algorithmic flop count is not what is issued
+    issued_mfma = None
+    try:
+        if not (args.cpu_seconds > 0 or world > 1):
+            raise RuntimeError("profiling run: nothing but the warm-up and the timed steps is launched")
+        import ctypes as C
+
+        from voiceconversion_jl_amd import _lib
+
+        fn = _lib.lib.vcmi_debug_estep_mfma
+        fn.argtypes, fn.restype = [C.c_int, C.POINTER(C.c_int64)], C.c_int
+        _lib.check(fn(1, None))
+        step_kernels()
+        torch.cuda.synchronize()
+        cnt = C.c_int64(0)
+        _lib.check(fn(0, C.byref(cnt)))
+        issued_mfma = int(cnt.value) or None
+        step_kernels()
+        vc.dist.allreduce_sum_(out_t)
+    except Exception:  # noqa: BLE001  (an older library: the line keeps its algorithmic figure, labelled)
+        issued_mfma = None
+    alg_tflops = estep_flops_per_frame(Dj, M) * N / (kernel_ms * 1e-3) / 1e12
+    iss_tflops = issued_mfma * MFMA_FLOP / (kernel_ms * 1e-3) / 1e12 if issued_mfma else None
+    achieved = min(alg_tflops, iss_tflops) if iss_tflops else alg_tflops
     out = {"metric": "diag-GMM E-step frames/sec (Dj=%d, M=%d)" % (Dj, M), "value": fps, "unit": "frames/s", "n_gpus": world,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True,
            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
@@ -602,6 +629,11 @@ def bench_estep(args, world, rank):
            "roofline": {"bound": "mfma", "kernel": (f"estep_mfma_kernel<{min(d for d in (32, 48, 64, 80, 160) if d >= Dj)}>" if mfma_path else "estep_gamma_kernel + estep_stats_kernel (generic path)") + " (+ all-reduce)", "achieved": achieved,
                         "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS,
                         "traffic": None,
+                        "frac_definition": "min(algorithmic flop, flop of the MFMAs the kernels issued) / kernel time / peak",
+                        "algorithmic_frac": alg_tflops / FP64_PEAK_TFLOPS,
+                        "issued_mfma_frac": (iss_tflops / FP64_PEAK_TFLOPS) if iss_tflops else None,
+                        "mfma_issued_per_step": issued_mfma,
+                        "mfma_issued_source": "in-kernel count (vcmi_debug_estep_mfma); SQ_INSTS_MFMA: profiles/r04_clock/estep_clock.json",
                         "flop_per_frame": estep_flops_per_frame(Dj, M), "kernel_ms": kernel_ms},
            "collective": {"op": "all-reduce(sum), %d doubles" % vc.stats_len(Dj, M), "allreduce_ms": allreduce_ms,
                           "step_ms_with_allreduce": step_ms, "ranks": world, "backend": BACKEND["name"]}}

@@ -47,6 +47,32 @@ def test_vs_oracle(vc, N, Dj, M):
     _check(got, ref, N)
 
 
+@pytest.mark.parametrize("N,Dj,M,lam_lo", [(20000, 80, 64, 1e-5), (9000, 80, 16, 1e-1), (5000, 160, 6, 1e-3), (4096, 48, 40, 1e-4),
+                                          (12000, 64, 200, 1e-5), (7000, 32, 300, 1e-3)])
+def test_frame_lists_of_the_statistics_kernel(vc, N, Dj, M, lam_lo):
+    """From 4096 frames on (and up to 32 mixture groups) the statistics kernel walks, per mixture group, the list of the
+    frames that have a responsibility != 0 there (built in frame order from the softmax kernel's group mask) instead of
+    staging every frame once per group.  Against the oracle, against the all-frames path (test hook) and run to run; peaked
+    models (short lists), broad ones (every frame in every list) and mixture counts beyond 32 groups (lists off)."""
+    import torch
+    from oracle import c_oracle as co, np_oracle as npo
+    from voiceconversion_jl_amd import _lib
+    w, mu, sig = npo.synth_model(6100 + N, Dj, M, lam_lo=lam_lo)
+    X = npo.sample_frames(N, w, mu, sig, N, 0, Dj)
+    sg = np.transpose(sig, (2, 1, 0))
+    Xd = torch.from_numpy(X).cuda()
+    a = vc.estep_full_dev(Xd.t(), w, mu.T, sg)
+    assert torch.equal(a, vc.estep_full_dev(Xd.t(), w, mu.T, sg))
+    _lib.debug_force(_lib.DBG_ESTEP_FULL_NO_LISTS)
+    try:
+        b = vc.estep_full_dev(Xd.t(), w, mu.T, sg)
+    finally:
+        _lib.debug_force(0)
+    assert float((a - b).abs().max() / b.abs().max()) < 1e-12
+    if N * M <= 600_000:
+        _check(vc.estep_full(X.T, w, mu.T, sg), co.estep_full(X, w, mu, sig), N)
+
+
 def test_zero_weight_and_not_pd(vc):
     from oracle import c_oracle as co, np_oracle as npo
     w, mu, sig = npo.synth_model(9, 80, 6, lam_lo=1e-3)

@@ -242,7 +242,8 @@ __global__ void __launch_bounds__(512)
 estep_mfma_kernel(const double *__restrict__ X, int64_t N, int M, const double *__restrict__ Wpack,
                   const double *__restrict__ cinit, double *__restrict__ part, int64_t plen,
                   const double *__restrict__ refmu, const double *__restrict__ refiv, const double *__restrict__ refc,
-                  double *__restrict__ G, int dj, int mtp_arg) {
+                  double *__restrict__ G, int dj, int mtp_arg, unsigned long long *__restrict__ mfma_count) {
+  // mfma_count (optional, measurement): v_mfma_f64_16x16x4 instructions issued, counted by wave-uniform scalar adds
   // mtp = 1, 2, 4 or 8 mixture tiles of 16 (>= M / 16): with fewer than eight (SHARE), 8 / mtp waves share a tile -- wave
   // w takes tile w % mtp and every (8 / mtp)-th frame tile of step A / k-step of step B, and writes its own row of
   // partial statistics -- so that a 16- or 64-mixture model does not pay for 128 slots.  (A template flag: the branches
@@ -291,6 +292,7 @@ estep_mfma_kernel(const double *__restrict__ X, int64_t N, int M, const double *
   for (int j = 0; j < (kStats ? NDT : 1); ++j) sacc[j] = d4{0, 0, 0, 0};
   double llacc = 0.0, sprod = 1.0;
   int nprod = 0;
+  int nmfma = 0;
 
   const int64_t nblocks = (N + FB - 1) / FB;
   // ---- x staging by LDS-DMA (global_load_lds_dwordx4: 16 bytes per lane straight into LDS, no VGPRs -- the kernel has
@@ -344,6 +346,7 @@ estep_mfma_kernel(const double *__restrict__ X, int64_t N, int M, const double *
           if ((ft & (wpt - 1)) != (sub & (wpt - 1)) || (wpt > FB / 16 && sub >= FB / 16)) continue;     // wave-uniform
         }
         d4 acc = cin;
+        nmfma += KS;
         const double *xr = xs + (16 * ft + lcol) * RSX + lgrp;
 #pragma unroll
         for (int ks = 0; ks < KS / 2; ++ks) {
@@ -517,6 +520,7 @@ estep_mfma_kernel(const double *__restrict__ X, int64_t N, int M, const double *
         // for all but a few of the 128 mixtures) add exactly nothing: when that holds for the tile's 16 mixtures on all
         // four frames of the k-step, its 2 NDT/2 products are skipped (wave-uniform; the statistics are bit-identical)
         if (__builtin_amdgcn_ballot_w64(gm != 0.0) == 0) continue;
+        nmfma += NDT;
         const double *xr = xs + f * RSX + lcol;
 #pragma unroll
         for (int j = 0; j < NDT / 2; ++j) {
@@ -538,6 +542,7 @@ estep_mfma_kernel(const double *__restrict__ X, int64_t N, int M, const double *
 #endif
 #undef VCMI_PT
 
+  if (mfma_count && lane == 0) atomicAdd(mfma_count, (unsigned long long)nmfma);
   // ---- write this workgroup's partial statistics: rows m = 16 wave + lgrp + 4 r, cols = 16 j + lcol ----
   // row blockIdx.x * wpt + sub of the partial statistics: every mixture tile is written by the wave (tile, sub)
   double *P = part + ((size_t)blockIdx.x * wpt + sub) * plen;
@@ -613,6 +618,7 @@ struct EstepStaging {
 
 struct EstepScratch {
   DevBuf<double> mu, iv, cst, G, LSE, part, Wpack, cinit, X, stats, raw, refiv, refc, Xpad, statsp;
+  DevBuf<unsigned long long> mfma_count;      // optional measurement counter (vcmi_debug_estep_mfma); null: the kernels count nothing
   EstepStaging stage;
   StreamOrder order;   // calls of one thread on different streams share the buffers above
 };
@@ -719,7 +725,7 @@ static int estep_mfma_launch(EstepScratch &sc, const double *dX, int64_t N, int 
     VCMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)C::LDS_BYTES));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), C::LDS_BYTES, st, dX, N, M, sc.Wpack.p, sc.cinit.p, sc.part.p, plen, dmu,
-                       sc.refiv.p, sc.refc.p, (double *)nullptr, dj, mtp);
+                       sc.refiv.p, sc.refc.p, (double *)nullptr, dj, mtp, sc.mfma_count.p);
     VCMI_HIP(hipGetLastError());
     estep_reduce_launch(sc.part.p, grid * wpt, plen, dstats, st);
     VCMI_HIP(hipGetLastError());
@@ -736,9 +742,9 @@ static int estep_mfma_launch(EstepScratch &sc, const double *dX, int64_t N, int 
       const int64_t nfr = std::min<int64_t>(kSplitChunk, N - n0);
       const int g2 = (int)std::min<int64_t>((nfr + C::FB - 1) / C::FB, cus);
       hipLaunchKernelGGL(kg, dim3(g2), dim3(512), C::LDS_BYTES, st, dX + n0 * dj, nfr, M, sc.Wpack.p, sc.cinit.p, sc.part.p, plen,
-                         dmu, sc.refiv.p, sc.refc.p, sc.G.p, dj, mtp);
+                         dmu, sc.refiv.p, sc.refc.p, sc.G.p, dj, mtp, sc.mfma_count.p);
       hipLaunchKernelGGL(ks, dim3(g2), dim3(512), C::LDS_BYTES, st, dX + n0 * dj, nfr, M, sc.Wpack.p, sc.cinit.p, sc.part.p, plen,
-                         dmu, sc.refiv.p, sc.refc.p, sc.G.p, dj, mtp);
+                         dmu, sc.refiv.p, sc.refc.p, sc.G.p, dj, mtp, sc.mfma_count.p);
       VCMI_HIP(hipGetLastError());
       estep_reduce_launch(sc.part.p, g2 * wpt, plen, dstats, st);
       VCMI_HIP(hipGetLastError());
@@ -807,7 +813,7 @@ static int estep_mfma_groups_launch(EstepScratch &sc, const double *dX, int64_t 
       const int m0 = g * C::MMAX, Mg = std::min(C::MMAX, M - m0);
       hipLaunchKernelGGL(k3, dim3(g2), dim3(512), C::LDS_BYTES, st, dX + n0 * dj, nfr, Mg, sc.Wpack.p + wlen * g,
                          sc.cinit.p + (size_t)C::MMAX * g, sc.LSE.p + (size_t)g * nfr, (int64_t)0, draw + goff[(size_t)g] + Mg,
-                         sc.refiv.p + (size_t)m0 * dj, sc.refc.p + m0, sc.G.p + (size_t)g * chunk * C::MMAX, dj, 8);
+                         sc.refiv.p + (size_t)m0 * dj, sc.refc.p + m0, sc.G.p + (size_t)g * chunk * C::MMAX, dj, 8, sc.mfma_count.p);
     }
     hipLaunchKernelGGL(estep_group_combine_kernel, dim3(kCombineGrid), dim3(256), 0, st, sc.G.p, sc.LSE.p, ng, nfr,
                        (int64_t)chunk * C::MMAX, llpart);
@@ -816,7 +822,7 @@ static int estep_mfma_groups_launch(EstepScratch &sc, const double *dX, int64_t 
       const int m0 = g * C::MMAX, Mg = std::min(C::MMAX, M - m0);
       const int64_t plen_g = (int64_t)Mg * (1 + 2 * dj) + 1;
       hipLaunchKernelGGL(k2, dim3(g2), dim3(512), C::LDS_BYTES, st, dX + n0 * dj, nfr, Mg, sc.Wpack.p, sc.cinit.p, sc.part.p, plen_g,
-                         draw, sc.refiv.p, sc.refc.p, sc.G.p + (size_t)g * chunk * C::MMAX, dj, 8);
+                         draw, sc.refiv.p, sc.refc.p, sc.G.p + (size_t)g * chunk * C::MMAX, dj, 8, sc.mfma_count.p);
       hipLaunchKernelGGL(estep_group_reduce_kernel, dim3((unsigned)((plen_g + 255) / 256)), dim3(256), 0, st, sc.part.p, g2, plen_g, Mg,
                          dj, m0, M, dstats);
     }
@@ -954,7 +960,10 @@ static int estep_device_run(const double *dX, int64_t N, int Dj, int M, const do
 // The per-frame log-sum-exp values are summed per wave in frame order, then per workgroup: lsepart[blockIdx.x].
 static constexpr int kSoftmaxGrid = 2048;
 __global__ void __launch_bounds__(256)
-estep_full_softmax_kernel(double *__restrict__ LP, int M, int64_t n, double *__restrict__ lsepart) {
+estep_full_softmax_kernel(double *__restrict__ LP, int M, int64_t n, double *__restrict__ lsepart, unsigned *__restrict__ fmask,
+                          int nm) {
+  // fmask (optional; mixture groups of nm, at most 32 of them): bit g of fmask[frame] = some mixture of group g has a
+  // responsibility that is not exactly zero -- the statistics kernel then visits, per group, only those frames
   __shared__ double wsum[4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   double acc = 0.0;
@@ -969,7 +978,17 @@ estep_full_softmax_kernel(double *__restrict__ LP, int M, int64_t n, double *__r
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) sm += __shfl_xor(sm, o);
     const double ls = u + log(sm);
-    for (int m = lane; m < M; m += 64) l[m] = exp(l[m] - ls);
+    unsigned bits = 0;
+    for (int m = lane; m < M; m += 64) {
+      const double gm = exp(l[m] - ls);
+      l[m] = gm;
+      if (gm != 0.0) bits |= 1u << ((m / nm) & 31);
+    }
+    if (fmask) {
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) bits |= (unsigned)__shfl_xor((int)bits, o);
+      if (lane == 0) fmask[fr] = bits;
+    }
     acc += ls;
   }
   if (lane == 0) wsum[wave] = acc;
@@ -989,6 +1008,99 @@ estep_sum_kernel(const double *__restrict__ v, int64_t n, double *__restrict__ o
     double t = out[0];
     for (int i = 0; i < 256; ++i) t += part[i];
     out[0] = t;
+  }
+}
+
+// ---- frame lists of the statistics kernel (round 4).  Its workgroup (a mixture group, a frame segment) used to stage EVERY
+// frame of its segment -- X travels once per mixture group, 8 x 320 MB through the L2 at M = 64 -- to find that 94 % of the
+// 4-frame k-steps carry only exact zeros for its mixtures: the kernel was bound by the fetch / stash / barrier chain of the
+// blocks it then skipped.  With fmask (softmax kernel) the frames of a group are listed once -- in frame order: chunk
+// histograms, a prefix per group, a stable compaction by ballot / mbcnt, nothing depends on the scheduler -- and the
+// statistics kernel walks its group's list.  list[g * n + pos] = frame; total[g] = length.
+constexpr int kListChunk = 1024;
+__global__ void __launch_bounds__(256)
+estep_full_list_count_kernel(const unsigned *__restrict__ fmask, int64_t n, int G, int *__restrict__ chunkcnt) {
+  __shared__ int hist[32];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid < 32) hist[tid] = 0;
+  __syncthreads();
+  const int64_t f0 = (int64_t)blockIdx.x * kListChunk;
+  for (int i = 0; i < kListChunk / 256; ++i) {
+    const int64_t fr = f0 + 64 * (wave + 4 * i) + lane;
+    const unsigned b = fr < n ? fmask[fr] : 0u;
+    for (int g = 0; g < G; ++g) {
+      const int c = __builtin_popcountll(__builtin_amdgcn_ballot_w64((b >> g) & 1u));
+      if (lane == 0 && c) atomicAdd(&hist[g], c);
+    }
+  }
+  __syncthreads();
+  if (tid < G) chunkcnt[(size_t)blockIdx.x * G + tid] = hist[tid];
+}
+// one workgroup per group: exclusive prefix of chunkcnt[.][g] over the chunks (in place), total[g]
+__global__ void __launch_bounds__(256)
+estep_full_list_scan_kernel(int *__restrict__ chunkcnt, int64_t nchunks, int G, int *__restrict__ total) {
+  __shared__ int part[256];
+  const int g = blockIdx.x, tid = threadIdx.x;
+  const int64_t per = (nchunks + 255) / 256, lo = std::min<int64_t>(nchunks, tid * per), hi = std::min<int64_t>(nchunks, lo + per);
+  int sum = 0;
+  for (int64_t c = lo; c < hi; ++c) sum += chunkcnt[c * G + g];
+  part[tid] = sum;
+  __syncthreads();
+  if (tid == 0) {
+    int run = 0;
+    for (int i = 0; i < 256; ++i) {
+      const int v = part[i];
+      part[i] = run;
+      run += v;
+    }
+    total[g] = run;
+  }
+  __syncthreads();
+  int run = part[tid];
+  for (int64_t c = lo; c < hi; ++c) {
+    const int v = chunkcnt[c * G + g];
+    chunkcnt[c * G + g] = run;
+    run += v;
+  }
+}
+__global__ void __launch_bounds__(256)
+estep_full_list_fill_kernel(const unsigned *__restrict__ fmask, int64_t n, int G, const int *__restrict__ chunkoff,
+                            int *__restrict__ list) {
+  __shared__ int rowcnt[16][32];           // frames of group g in row r of the chunk -> exclusive prefix over the rows
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t f0 = (int64_t)blockIdx.x * kListChunk;
+  unsigned b[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = wave + 4 * i;
+    const int64_t fr = f0 + 64 * r + lane;
+    b[i] = fr < n ? fmask[fr] : 0u;
+    for (int g = 0; g < G; ++g) {
+      const int c = __builtin_popcountll(__builtin_amdgcn_ballot_w64((b[i] >> g) & 1u));
+      if (lane == 0) rowcnt[r][g] = c;
+    }
+  }
+  __syncthreads();
+  if (tid < G) {
+    int run = 0;
+    for (int r = 0; r < 16; ++r) {
+      const int v = rowcnt[r][tid];
+      rowcnt[r][tid] = run;
+      run += v;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = wave + 4 * i;
+    const int64_t fr = f0 + 64 * r + lane;
+    for (int g = 0; g < G; ++g) {
+      const unsigned long long mask = __builtin_amdgcn_ballot_w64((b[i] >> g) & 1u);
+      if ((b[i] >> g) & 1u) {
+        const int below = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
+        list[(size_t)g * n + chunkoff[(size_t)blockIdx.x * G + g] + rowcnt[r][g] + below] = (int)fr;
+      }
+    }
   }
 }
 
@@ -1034,7 +1146,8 @@ struct FullStatsCfg {
 template <int DJ, int PARTS, int PART>
 __device__ __forceinline__ void estep_full_stats_body(const double *__restrict__ X, int64_t n0, int64_t f_begin, int64_t f_end,
                                                       int M, int mg, const double *__restrict__ G, double *__restrict__ P,
-                                                      double *xs, double *gs, int dj) {
+                                                      double *xs, double *gs, int dj, const int *__restrict__ lst) {
+  // lst (optional): positions [f_begin, f_end) index this mixture group's frame list instead of the frames themselves
   using C = FullStatsCfg<DJ, PARTS>;
   constexpr int NTL = C::NTL, RSX = C::RSX, FB = kFullFB, NM = C::NM;
   constexpr int T0 = PART * C::TPP, T1 = (T0 + C::TPP < C::NTILES) ? T0 + C::TPP : C::NTILES, NTP = T1 - T0;
@@ -1054,22 +1167,35 @@ __device__ __forceinline__ void estep_full_stats_body(const double *__restrict__
   double pf[NPF], pg = 0.0;
   const int gf = tid / NM, gq = tid % NM;                 // gamma staging: FB frames x NM mixtures
   const int gm_idx = mg * NM + gq;
-  auto fetch = [&](int64_t fb) {                           // global -> registers (the block's frames are contiguous in X)
-    const int64_t lim = (f_end - fb) * dj;        // dj <= DJ: the data's dimension (the columns dj .. DJ-1 of the LDS image
-    const double *src = X + (n0 + fb) * dj;       // are never written: they only reach accumulators that are not stored)
+  // element i of this thread: row (frame of the block) and column of the staged image (dj <= DJ is the data's dimension;
+  // the columns dj .. DJ-1 of the LDS image are never written: they only reach accumulators that are not stored)
+  int rowi[NPF], coli[NPF];
+#pragma unroll
+  for (int i = 0; i < NPF; ++i) {
+    const int e = tid + 512 * i;
+    rowi[i] = e / dj;
+    coli[i] = e - rowi[i] * dj;
+  }
+  // the frames of the block that is fetched NEXT (list mode: read one block ahead of the rows they address)
+  int fidx[NPF], gfidx = 0;                               // (a call's chunk has at most 2^20 frames)
+  auto load_idx = [&](int64_t fb) {
 #pragma unroll
     for (int i = 0; i < NPF; ++i) {
-      const int e = tid + 512 * i;
-      pf[i] = (e < FB * dj && e < lim) ? src[e] : 0.0;
+      const int64_t pos = fb + rowi[i];
+      fidx[i] = (lst && rowi[i] < FB && pos < f_end) ? lst[pos] : (int)pos;
     }
-    pg = (tid < FB * NM && fb + gf < f_end && gm_idx < M) ? G[(fb + gf) * M + gm_idx] : 0.0;
+    gfidx = (lst && tid < FB * NM && fb + gf < f_end) ? lst[fb + gf] : (int)(fb + gf);
+  };
+  auto fetch = [&](int64_t fb) {                           // global -> registers
+#pragma unroll
+    for (int i = 0; i < NPF; ++i)
+      pf[i] = (rowi[i] < FB && fb + rowi[i] < f_end) ? X[(n0 + (int64_t)fidx[i]) * dj + coli[i]] : 0.0;
+    pg = (tid < FB * NM && fb + gf < f_end && gm_idx < M) ? G[(int64_t)gfidx * M + gm_idx] : 0.0;
   };
   auto stash = [&](int buf) {                              // registers -> LDS
 #pragma unroll
-    for (int i = 0; i < NPF; ++i) {
-      const int e = tid + 512 * i;
-      if (e < FB * dj) xs[buf * FB * RSX + (e / dj) * RSX + (e % dj)] = pf[i];
-    }
+    for (int i = 0; i < NPF; ++i)
+      if (rowi[i] < FB) xs[buf * FB * RSX + rowi[i] * RSX + coli[i]] = pf[i];
     if (tid < FB * NM) gs[buf * FB * 8 + gf * NM + gq] = pg;
   };
   constexpr FullTileList<T0, NTP> TL{};                   // which x tiles this part reads, which of them it scales by gamma
@@ -1079,14 +1205,19 @@ __device__ __forceinline__ void estep_full_stats_body(const double *__restrict__
     __syncthreads();
   }
   if (f_begin < f_end) {
+    load_idx(f_begin);
     fetch(f_begin);
     stash(0);
+    load_idx(f_begin + FB);
   }
   __syncthreads();
   int buf = 0;
   for (int64_t fb = f_begin; fb < f_end; fb += FB, buf ^= 1) {
     const bool more = fb + FB < f_end;
-    if (more) fetch(fb + FB);
+    if (more) {
+      fetch(fb + FB);
+      load_idx(fb + 2 * FB);
+    }
     const double *xb = xs + buf * FB * RSX, *gb = gs + buf * FB * 8;
 #pragma unroll 2
     for (int ks = 0; ks < FB / 4; ++ks) {
@@ -1143,7 +1274,8 @@ __device__ __forceinline__ void estep_full_stats_body(const double *__restrict__
 template <int DJ, int PARTS>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 estep_full_stats_kernel(const double *__restrict__ X, int64_t n0, int64_t n, int M, const double *__restrict__ G,
-                        double *__restrict__ part, int64_t plen, int dj) {
+                        double *__restrict__ part, int64_t plen, int dj, const int *__restrict__ lists,
+                        const int *__restrict__ totals) {
   static_assert(DJ % 16 == 0, "full-covariance MFMA statistics need Dj to be a multiple of 16");
   static_assert(PARTS == 1 || PARTS == 2 || PARTS == 4, "waves per mixture");
   using C = FullStatsCfg<DJ, PARTS>;
@@ -1154,14 +1286,17 @@ estep_full_stats_kernel(const double *__restrict__ X, int64_t n0, int64_t n, int
   // FAST index the mixture groups that read one segment of X share an XCD (when the segment count is a multiple of 8)
   // and X reaches that L2 once instead of once per mixture group
   const int mg = blockIdx.y, seg = blockIdx.x, nsegs = gridDim.x;
-  const int64_t seglen = (n + nsegs - 1) / nsegs;
-  const int64_t f_begin = seg * seglen, f_end = (f_begin + seglen < n) ? f_begin + seglen : n;
+  // with frame lists the segment is a range of POSITIONS in this mixture group's list (its length is on the device)
+  const int64_t len = lists ? (int64_t)totals[mg] : n;
+  const int *lst = lists ? lists + (size_t)mg * n : nullptr;
+  const int64_t seglen = (len + nsegs - 1) / nsegs;
+  const int64_t f_begin = std::min<int64_t>(len, seg * seglen), f_end = (f_begin + seglen < len) ? f_begin + seglen : len;
   double *P = part + (size_t)seg * plen;
   const int prt = (threadIdx.x >> 6) % PARTS;          // wave-uniform; every branch runs the same number of barriers
-  if (PARTS == 1 || prt == 0) estep_full_stats_body<DJ, PARTS, 0>(X, n0, f_begin, f_end, M, mg, G, P, xs, gs, dj);
-  else if (PARTS == 2 || prt == 1) estep_full_stats_body<DJ, PARTS, 1>(X, n0, f_begin, f_end, M, mg, G, P, xs, gs, dj);
-  else if (prt == 2) estep_full_stats_body<DJ, PARTS, (PARTS > 2 ? 2 : 0)>(X, n0, f_begin, f_end, M, mg, G, P, xs, gs, dj);
-  else estep_full_stats_body<DJ, PARTS, (PARTS > 3 ? 3 : 0)>(X, n0, f_begin, f_end, M, mg, G, P, xs, gs, dj);
+  if (PARTS == 1 || prt == 0) estep_full_stats_body<DJ, PARTS, 0>(X, n0, f_begin, f_end, M, mg, G, P, xs, gs, dj, lst);
+  else if (PARTS == 2 || prt == 1) estep_full_stats_body<DJ, PARTS, 1>(X, n0, f_begin, f_end, M, mg, G, P, xs, gs, dj, lst);
+  else if (prt == 2) estep_full_stats_body<DJ, PARTS, (PARTS > 2 ? 2 : 0)>(X, n0, f_begin, f_end, M, mg, G, P, xs, gs, dj, lst);
+  else estep_full_stats_body<DJ, PARTS, (PARTS > 3 ? 3 : 0)>(X, n0, f_begin, f_end, M, mg, G, P, xs, gs, dj, lst);
 }
 
 // generic statistics (any Dj): thread per lower-triangle element of one mixture's S2 (+ S1, S0), sequential over the
@@ -1199,6 +1334,7 @@ estep_full_stats_generic_kernel(const double *__restrict__ X, int64_t n0, int64_
 struct EstepFullScratch {
   DevBuf<double> LP, lse, part, X, stats, params;
   DevBuf<int> flag;
+  DevBuf<int> lists;        // frame lists of the statistics kernel: [fmask (n) | chunk counts (nchunks, G) | totals (G) | lists (G, n)]
   vcmi_gmmmap *px = nullptr;
   StreamOrder order;   // calls of one thread on different streams share the buffers above
   ~EstepFullScratch() { delete px; }
@@ -1239,8 +1375,25 @@ static int estep_full_core_run(vcmi_gmmmap *px, const double *dX, int64_t N, int
   for (int64_t n0 = 0; n0 < N; n0 += chunk) {
     const int64_t n = std::min<int64_t>(chunk, N - n0);
     VCMI_TRY(gmmmap_logdens_device(px, dX + n0 * Dj, Dj, n, sc.LP.p, st));
-    hipLaunchKernelGGL(estep_full_softmax_kernel, dim3(kSoftmaxGrid), dim3(256), 0, st, sc.LP.p, M, n, sc.lse.p);
+    // frame lists per mixture group (MFMA statistics, at most 32 groups, enough frames to matter)
+    const bool use_lists = mfma && mgroups <= 32 && n >= 4096 && !debug_flag(kDbgEstepFullNoLists);
+    unsigned *fmask = nullptr;
+    int *chunkcnt = nullptr, *totals = nullptr, *lists = nullptr;
+    const int64_t nlc = (n + kListChunk - 1) / kListChunk;
+    if (use_lists) {
+      VCMI_TRY(sc.lists.reserve((size_t)n + (size_t)nlc * mgroups + mgroups + (size_t)mgroups * n));
+      fmask = reinterpret_cast<unsigned *>(sc.lists.p);
+      chunkcnt = sc.lists.p + n;
+      totals = chunkcnt + (size_t)nlc * mgroups;
+      lists = totals + mgroups;
+    }
+    hipLaunchKernelGGL(estep_full_softmax_kernel, dim3(kSoftmaxGrid), dim3(256), 0, st, sc.LP.p, M, n, sc.lse.p, fmask, nm);
     hipLaunchKernelGGL(estep_sum_kernel, dim3(1), dim3(256), 0, st, sc.lse.p, (int64_t)kSoftmaxGrid, dstats + (plen - 1));
+    if (use_lists) {
+      hipLaunchKernelGGL(estep_full_list_count_kernel, dim3((unsigned)nlc), dim3(256), 0, st, fmask, n, mgroups, chunkcnt);
+      hipLaunchKernelGGL(estep_full_list_scan_kernel, dim3((unsigned)mgroups), dim3(256), 0, st, chunkcnt, nlc, mgroups, totals);
+      hipLaunchKernelGGL(estep_full_list_fill_kernel, dim3((unsigned)nlc), dim3(256), 0, st, fmask, n, mgroups, chunkcnt, lists);
+    }
     VCMI_HIP(hipMemsetAsync(sc.part.p, 0, (size_t)nseg * plen * sizeof(double), st));
     const dim3 grid(nseg, mgroups);
     if (mfma) {
@@ -1252,7 +1405,8 @@ static int estep_full_core_run(vcmi_gmmmap *px, const double *dX, int64_t N, int
           VCMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
           attr_done[dev & 63].store(true, std::memory_order_release);
         }
-        hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, dX, n0, n, M, sc.LP.p, sc.part.p, plen, Dj);
+        hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, dX, n0, n, M, sc.LP.p, sc.part.p, plen, Dj, (const int *)lists,
+                           (const int *)totals);
         return VCMI_OK;
       };
       if (Dj <= 32) VCMI_TRY(launch(estep_full_stats_kernel<32, 1>, FullStatsCfg<32, 1>::LDS_BYTES));
@@ -1541,5 +1695,28 @@ extern "C" int vcmi_gmm_em_get(vcmi_gmm_em *h, double *w, double *mu, double *si
   VCMI_HIP(hipMemcpy(w, h->w(), sizeof(double) * h->M, hipMemcpyDeviceToHost));
   VCMI_HIP(hipMemcpy(mu, h->mu(), sizeof(double) * h->M * h->Dj, hipMemcpyDeviceToHost));
   VCMI_HIP(hipMemcpy(sigma, h->sigma(), sizeof(double) * h->M * dd, hipMemcpyDeviceToHost));
+  return VCMI_OK;
+}
+
+// Measurement hook (not part of include/vcmi.h; bench.py prices the diagonal E-step's matrix pipe with it): *issued (may be
+// NULL) receives the v_mfma_f64_16x16x4 instructions the MFMA E-step kernels of THIS host thread have issued since the
+// counter was last enabled; then enable != 0 (re)starts it at zero, enable == 0 switches it off.  Synchronises.
+extern "C" int vcmi_debug_estep_mfma(int enable, int64_t *issued) {
+  using namespace vcmi;
+  EstepScratch &sc = scratch();
+  if (issued) {
+    *issued = 0;
+    if (sc.mfma_count.p) {
+      unsigned long long h = 0;
+      VCMI_HIP(hipMemcpy(&h, sc.mfma_count.p, sizeof(h), hipMemcpyDeviceToHost));
+      *issued = (int64_t)h;
+    }
+  }
+  if (enable) {
+    if (!sc.mfma_count.p) VCMI_TRY(sc.mfma_count.alloc(1));
+    VCMI_HIP(hipMemset(sc.mfma_count.p, 0, sizeof(unsigned long long)));
+  } else {
+    sc.mfma_count.release();
+  }
   return VCMI_OK;
 }

@@ -565,6 +565,48 @@ int staged_pipeline(const void *hIn, size_t in_unit, size_t in_stride, void *hOu
   chunk = ((units + nch - 1) / nch + 255) / 256 * 256;
   chunk = std::min(chunk, (units + 255) / 256 * 256);
   nch = (units + chunk - 1) / chunk;   // rounding the chunk up to 256 units can make the last chunk(s) empty: recount
+  // Chunk boundaries.  With equal chunks the link idles in one direction for the whole first chunk (gather, upload, kernel)
+  // and for the whole last one (download, scatter): ~2 ms of a 8.7 ms call at 32 MB chunks, while uniformly small chunks pay
+  // their hand-overs forty times (measured: no better).  So the FIRST and LAST chunks are short -- 1/4, 1/2 of a chunk,
+  // then full ones, then 1/2, 1/4 -- and only the ramps shrink.  VCMI_HOST_RAMP=0 (read once) keeps equal chunks.
+  std::vector<int64_t> start;           // start[c] = first unit of chunk c; start[nch] = units
+  {
+    static const bool ramp = [] {
+      const char *e = getenv("VCMI_HOST_RAMP");
+      return !(e && e[0] == '0');
+    }();
+    if (ramp && nch >= 6) {
+      const int64_t q = std::max<int64_t>(256, chunk / 4 / 256 * 256), h = std::max<int64_t>(256, chunk / 2 / 256 * 256);
+      int64_t pos = 0;
+      const int64_t tail = q + h;                          // units of the two short chunks at the end
+      for (int64_t step : {q, h}) {
+        start.push_back(pos);
+        pos += step;
+      }
+      while (units - pos > tail + chunk) {
+        start.push_back(pos);
+        pos += chunk;
+      }
+      // what is left before the tail: one chunk of at most `chunk` units (or two halves of it)
+      if (units - pos > tail) {
+        const int64_t mid = units - pos - tail;
+        if (mid > chunk) {
+          start.push_back(pos);
+          pos += (mid / 2 + 255) / 256 * 256;
+        }
+        start.push_back(pos);
+        pos = units - tail;
+      }
+      start.push_back(pos);
+      pos += h;
+      start.push_back(pos);
+      start.push_back(units);
+    } else {
+      for (int64_t c = 0; c < nch; ++c) start.push_back(c * chunk);
+      start.push_back(units);
+    }
+    nch = (int64_t)start.size() - 1;
+  }
   VCMI_TRY(r->reserve(r->pin_in, r->pin_in_cap, (size_t)chunk * in_unit, true));
   VCMI_TRY(r->reserve(r->pin_out, r->pin_out_cap, (size_t)chunk * out_unit, true));
   VCMI_TRY(r->reserve(r->dev_in, r->dev_in_cap, (size_t)chunk * in_unit, false));
@@ -612,7 +654,7 @@ int staged_pipeline(const void *hIn, size_t in_unit, size_t in_stride, void *hOu
     for (int64_t c = 0; c < nch + LAG; ++c) {
       if (c < nch) {
         const int s = (int)(c % K);
-        const int64_t first = c * chunk, n = std::min(chunk, units - first);
+        const int64_t first = start[(size_t)c], n = start[(size_t)c + 1] - first;
         if (c >= K) VCMI_HIP(hipEventSynchronize(r->ev_up[s]));                 // pinned slot: upload of chunk c-K done
         host_copy_rows(r->pin_in[s], in_unit, (const char *)hIn + (size_t)first * in_stride, in_stride, in_unit, n);
         if (c >= K) VCMI_HIP(hipStreamWaitEvent(r->up, r->ev_run[s], 0));        // device slot: kernels of chunk c-K done
@@ -630,7 +672,7 @@ int staged_pipeline(const void *hIn, size_t in_unit, size_t in_stride, void *hOu
       const int64_t j = c - LAG;
       if (j >= 0 && j < nch) {
         const int s = (int)(j % K);
-        const int64_t first = j * chunk, n = std::min(chunk, units - first);
+        const int64_t first = start[(size_t)j], n = start[(size_t)j + 1] - first;
         VCMI_HIP(hipEventSynchronize(r->ev_down[s]));
         host_copy_rows((char *)hOut + (size_t)first * out_stride, out_stride, r->pin_out[s], out_unit, out_unit, n);
       }
