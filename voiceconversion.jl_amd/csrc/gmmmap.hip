@@ -120,6 +120,29 @@ __device__ __forceinline__ double sum_lane_groups(double q) {
   return __hiloint2double(d[0], c[0]) + __hiloint2double(d[1], c[1]);
 }
 
+// Two columns' worth at once: q0[lane], q1[lane] -> in the EVEN lane groups the lane-group sum of q0, in the ODD ones that of
+// q1.  The first exchange swaps 16-lane rows between the two registers themselves (no copies): six moves / swaps and two adds
+// instead of the sixteen and four of two sum_lane_groups calls -- and every VALU instruction of a wave, FP64 or not, waits
+// for the FP64 MFMAs of the SIMD's other waves.  Association: (q_g + q_g^1) + (the other pair), as in sum_lane_groups.
+__device__ __forceinline__ double sum_lane_groups_pair(double q0, double q1) {
+  const unsigned l0 = __double2loint(q0), h0 = __double2hiint(q0), l1 = __double2loint(q1), h1 = __double2hiint(q1);
+  auto a = __builtin_amdgcn_permlane16_swap(l0, l1, false, false);     // {rows (q0 r0, q1 r0, q0 r2, q1 r2), rows (q0 r1, q1 r1, q0 r3, q1 r3)}
+  auto b = __builtin_amdgcn_permlane16_swap(h0, h1, false, false);
+  const double x = __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
+  const unsigned lo = __double2loint(x), hi = __double2hiint(x);
+  auto c = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+  auto d = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+  return __hiloint2double(d[0], c[0]) + __hiloint2double(d[1], c[1]);
+}
+// v (selected layout: tile 0's value in the even lane groups, tile 1's in the odd ones) -> {tile 0's, tile 1's} in every lane
+__device__ __forceinline__ void unpair_lane_groups(double v, double &v0, double &v1) {
+  const unsigned lo = __double2loint(v), hi = __double2hiint(v);
+  auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+  auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+  v0 = __hiloint2double(b[0], a[0]);
+  v1 = __hiloint2double(b[1], a[1]);
+}
+
 // ------------------------------------------------------------------------------------------------
 // MFMA tile kernel.  One wave owns FT tiles of 16 frames; a workgroup of WAVES waves shares the
 // per-mixture operand block, double-buffered in LDS.
@@ -166,6 +189,8 @@ gmmmap_mfma_kernel(const double *__restrict__ packed, int M, int D, const double
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);     // the same number in a scalar register (uniform address arithmetic)
+  const unsigned lane_off = 16u * (unsigned)lane;               // this lane's 16 bytes of a 1 KB LDS-DMA wave instruction
   const int lcol = lane & 15;   // frame within a 16-frame tile (MFMA column)
   const int lgrp = lane >> 4;   // k within a k-step (operands) / row offset within a register group (results)
   const int64_t frame0 = ((int64_t)blockIdx.x * WAVES + wave) * (16 * FT);
@@ -221,14 +246,38 @@ gmmmap_mfma_kernel(const double *__restrict__ packed, int M, int D, const double
   }
   __syncthreads();
 
+  // (the constant address space makes a uniform-address load a scalar load; the blocks are read-only for the kernel)
+  const __attribute__((address_space(4))) double *packed_c = (const __attribute__((address_space(4))) double *)packed;
+  double lc_next = (MODE == 0) ? packed_c[(size_t)mfirst * BLK + TL::LC_OFF] : 0.0;
 #ifdef VCMI_CONVERT_PROF
   unsigned long long prof_barrier_ = 0;
   const unsigned long long prof_t0_ = __builtin_readcyclecounter();
 #endif
-  for (int mi = 0; mi < M; ++mi) {
+#ifdef VCMI_CONVERT_PROF2
+  // phase probe (s_memtime counts; reading it waits for the wave's outstanding LDS / scalar operations, which the phase
+  // boundaries do anyway): [0] loop top -> lc known, [1] first part of the mixture (peaked: last whitening tile + test;
+  // dense / broad: whitening + |z|^2), [2] the rest up to the barrier, [3] vmcnt + barrier
+  unsigned long long pp_[4] = {0, 0, 0, 0};
+  unsigned long long pt_ = __builtin_readcyclecounter();
+#define VCMI_PP(i) { const unsigned long long n_ = __builtin_readcyclecounter(); pp_[i] += n_ - pt_; pt_ = n_; }
+#else
+#define VCMI_PP(i)
+#endif
+  // Two copies of the loop body, one per staging buffer (the inner loop is unrolled): the buffer's offset is then a
+  // compile-time constant that goes into the immediate offsets of the LDS reads, instead of a run-time base that costs two or
+  // three VALU address instructions at the start of every MFMA stream.
+  // (Measured, one box: dense 5.10 -> 5.08 ms, peaked 1.700 -> 1.674; the broad shape spills four registers in this form and
+  // loses 2 %: it keeps the single copy.)
+  constexpr int UNR = (MODE == 0 && PRUNE == 1) ? 1 : 2;
+  for (int mo = 0; mo < M; mo += UNR) {
+#pragma unroll
+  for (int u = 0; u < UNR; ++u) {
+    const int mi = mo + u;
+    if (UNR > 1 && mi >= M) break;                                         // (odd M: wave-uniform)
+    const int par = (UNR > 1) ? u : (mi & 1);
     const int m = (mfirst + mi < M) ? mfirst + mi : mfirst + mi - M;       // mixtures in rotated order (mfirst = 0: index order)
-    const double *cur = smem + (NBUF == 2 ? (mi & 1) * BLK : 0);
-    double2 *nxt = reinterpret_cast<double2 *>(smem + (NBUF == 2 ? ((mi + 1) & 1) * BLK : 0));
+    const double *cur = smem + (NBUF == 2 ? par * BLK : 0);
+    double2 *nxt = reinterpret_cast<double2 *>(smem + (NBUF == 2 ? (par ^ 1) * BLK : 0));
     // prefetch block m+1 into registers (global -> VGPR), written to LDS after the MFMA work
     // (unconditional: the last iteration re-reads its own block, which keeps `pre` in registers and the loop
     // body free of exec-mask branches)
@@ -244,12 +293,22 @@ gmmmap_mfma_kernel(const double *__restrict__ packed, int M, int D, const double
     double2 pre[STAGE_DMA ? 1 : NV];
     const int mn = (mi + 1 < M) ? ((m + 1 < M) ? m + 1 : 0) : m;
     if constexpr (STAGE_DMA) {
-      const char *gsrc = reinterpret_cast<const char *>(packed + (size_t)mn * BLK) + 16 * tid;
-      char *ldst = reinterpret_cast<char *>(nxt) + 1024 * wave;
+      // Addresses: a UNIFORM base (scalar registers, scalar arithmetic) plus one loop-invariant 32-bit lane offset.  Written
+      // with per-lane pointers (base + 16 tid), every one of the NV instructions cost a 64-bit VALU add, a VALU add for the
+      // LDS address and a v_readfirstlane to get it into M0 -- and a VALU instruction of any kind waits for the FP64 MFMAs of
+      // the SIMD's other waves: the phase probe (-DVCMI_CONVERT_PROF2) showed loop top -> first MFMA taking as long as the 20
+      // MFMAs of the peaked loop's first stage.
+      // (The builtin does not select the scalar-base form -- it folds the lane offset into a per-lane 64-bit pointer again --
+      // so the instruction is written out: M0 = LDS byte address of the wave's 1 KB, saddr = uniform global address,
+      // vaddr = the lane's 16-byte offset.)
+      const char *gbase = reinterpret_cast<const char *>(packed + (size_t)mn * BLK) + 1024 * wave_u;
+      const unsigned lbase = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)(reinterpret_cast<char *>(nxt)) + 1024u * wave_u;
 #pragma unroll
-      for (int i = 0; i < NV; ++i)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gsrc + 16 * NTHREADS * i),
-                                         (__attribute__((address_space(3))) void *)(ldst + 16 * NTHREADS * i), 16, 0, 0);
+      for (int i = 0; i < NV; ++i) {
+        const char *ga = gbase + 16 * NTHREADS * i;
+        const unsigned la = lbase + 16u * NTHREADS * i;
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(lane_off), "s"(ga), "s"(la) : "memory", "m0");
+      }
       __builtin_amdgcn_sched_barrier(0);
     } else {
       const double2 *nsrc = reinterpret_cast<const double2 *>(packed + (size_t)mn * BLK);
@@ -257,9 +316,28 @@ gmmmap_mfma_kernel(const double *__restrict__ packed, int M, int D, const double
       for (int i = 0; i < NV; ++i) pre[i] = nsrc[tid + i * NTHREADS];
     }
 
-    const double lc = cur[TL::LC_OFF];
+    // lc_m: a scalar load from the block's copy in global memory, requested one iteration ahead (MODE 0; a uniform address:
+    // s_load, no VALU, no LDS round trip at the top of the iteration), compared as an integer (-inf = zero weight)
+    double lc;
+    // Where the NEXT lc is requested matters: an outstanding scalar load turns the compiler's s_waitcnt on LDS reads into
+    // lgkmcnt(0) (scalar loads return out of order), and the barrier waits for it too.  So: right after the first stage's
+    // |z|^2 arithmetic -- its LDS reads are done, ~30 VALU instructions and a branch follow -- (VCMI_LC_NEXT below).
+    if constexpr (MODE == 0) lc = lc_next;
+    else lc = cur[TL::LC_OFF];
+    bool lcn_done = false;
+#define VCMI_LC_NEXT                                             \
+  if constexpr (MODE == 0) {                                     \
+    lc_next = packed_c[(size_t)mn * BLK + TL::LC_OFF];           \
+    lcn_done = true;                                             \
+  }
+    // the high word of -inf (lc is never NaN): a scalar compare
+    const bool has_weight = (MODE == 0) ? ((unsigned)((unsigned long long)__double_as_longlong(lc) >> 32) != 0xFFF00000u) : (lc != -INFINITY);
+#ifdef VCMI_CONVERT_PROF2
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    VCMI_PP(0)
+#endif
     if constexpr (MODE == 0 && PRUNE < 2) {
-      if (lc != -INFINITY) {
+      if (has_weight) {
         d4 acc[FT][NT];
 #pragma unroll
         for (int t = 0; t < NU; ++t) {
@@ -298,7 +376,10 @@ gmmmap_mfma_kernel(const double *__restrict__ packed, int M, int D, const double
 #elif VCMI_CONVERT_PRIO == 2
         __builtin_amdgcn_s_setprio(0);
 #endif
-        double l[FT];
+        // |z|^2 per frame tile, then everything scalar about the softmax in the SELECTED layout when the wave has two tiles:
+        // the even lane groups carry tile 0's l, running maximum and denominator, the odd ones tile 1's (psel picks) -- one
+        // reduction, one test, one exp for both tiles
+        double qv[FT];
 #pragma unroll
         for (int f = 0; f < FT; ++f) {
           double qq = 0.0;
@@ -308,55 +389,45 @@ gmmmap_mfma_kernel(const double *__restrict__ packed, int M, int D, const double
             for (int r = 0; r < 4; ++r)
               if (16 * t + 4 * r < DP) qq = fma(acc[f][t][r], acc[f][t][r], qq);
           }
-          l[f] = lc - 0.5 * sum_lane_groups(qq);
+          qv[f] = qq;
         }
+        VCMI_LC_NEXT
+        constexpr bool PAIRED = (FT == 2);
+        double lsel;                                   // PAIRED: l of this lane's tile; else l of tile 0
+        if constexpr (PAIRED) lsel = lc - 0.5 * sum_lane_groups_pair(qv[0], qv[1]);
+        else lsel = lc - 0.5 * sum_lane_groups(qv[0]);
+        VCMI_PP(1)
         bool go = true;
         if constexpr (PRUNE == 1) {
           // p_m <= e^(l_m - runmax): below e^-prune on every frame of the wave's tiles -> neither the regression nor the softmax
           // update can change y (the term is under the rounding error of those that are kept)
-          unsigned long long any = 0;
-#pragma unroll
-          for (int f = 0; f < FT; ++f) any |= __builtin_amdgcn_ballot_w64(l[f] > runmax[f] - prune);
-          go = any != 0;
+          go = __builtin_amdgcn_ballot_w64(lsel > runmax[0] - prune) != 0;
         }
         if (go) {
           nreg_wave += __builtin_popcount(tiles_in_range);
           nmfma_wave += FT * (TL::NSTEPS - NUS);
           // lazy rescale: only when some frame of the wave has a new maximum (wave-uniform; sc = 1 exactly for the others)
-          unsigned long long newmax = 0;
-#pragma unroll
-          for (int f = 0; f < FT; ++f) newmax |= __builtin_amdgcn_ballot_w64(l[f] > runmax[f]);
-          if (newmax) {
+          if (__builtin_amdgcn_ballot_w64(lsel > runmax[0]) != 0) {
+            const double nm = fmax(runmax[0], lsel);
+            const double scs = vc_exp(runmax[0] - nm);
+            den[0] *= scs;
+            runmax[0] = nm;
+            double sc[FT];
+            if constexpr (PAIRED) unpair_lane_groups(scs, sc[0], sc[1]);
+            else sc[0] = scs;
 #pragma unroll
             for (int f = 0; f < FT; ++f) {
-              const double nm = fmax(runmax[f], l[f]);
-              const double sc = vc_exp(runmax[f] - nm);
-              den[f] *= sc;
-              runmax[f] = nm;
 #pragma unroll
-              for (int j = 0; j < KS; ++j) yacc[f][j] *= sc;
+              for (int j = 0; j < KS; ++j) yacc[f][j] *= sc[f];
             }
           }
           double wg[FT];
-#ifndef VCMI_PAIR_EXP
-#define VCMI_PAIR_EXP 1
-#endif
-          if constexpr (FT == 2 && VCMI_PAIR_EXP) {
-            // every lane group of a column would compute the same e^(l - max): the even groups take frame tile 0, the odd
-            // ones tile 1, and one exchange of 16-lane rows (v_permlane16_swap) hands each its other weight
-            const double dsel = (lgrp & 1) ? l[1] - runmax[1] : l[0] - runmax[0];
-            const double e = vc_exp_tab(dsel, etab);
-            const unsigned elo = __double2loint(e), ehi = __double2hiint(e);
-            auto a = __builtin_amdgcn_permlane16_swap(elo, elo, false, false);
-            auto b = __builtin_amdgcn_permlane16_swap(ehi, ehi, false, false);
-            wg[0] = __hiloint2double(b[0], a[0]);
-            wg[1] = __hiloint2double(b[1], a[1]);
-          } else {
-#pragma unroll
-            for (int f = 0; f < FT; ++f) wg[f] = vc_exp_tab(l[f] - runmax[f], etab);
+          {
+            const double e = vc_exp_tab(lsel - runmax[0], etab);
+            den[0] += e;
+            if constexpr (PAIRED) unpair_lane_groups(e, wg[0], wg[1]);
+            else wg[0] = e;
           }
-#pragma unroll
-          for (int f = 0; f < FT; ++f) den[f] += wg[f];
           // ---------------- phase A: regression tiles, E = A x + b ----------------
 #if VCMI_CONVERT_PRIO == 1
           __builtin_amdgcn_s_setprio(0);
@@ -404,7 +475,7 @@ gmmmap_mfma_kernel(const double *__restrict__ packed, int M, int D, const double
         }
       }
     } else
-    if (lc != -INFINITY) {   // zero-weight mixtures have posterior exactly 0 (wave-uniform branch)
+    if (has_weight) {   // zero-weight mixtures have posterior exactly 0 (wave-uniform branch)
       // ---------------- phase U: whitening tiles, z = U x - cz ----------------
       d4 acc[FT][NT];
       double q[FT];
@@ -459,21 +530,27 @@ gmmmap_mfma_kernel(const double *__restrict__ packed, int M, int D, const double
         // first iteration -- and then the other whitening tiles of this mixture are not computed at all (tested on the lane
         // groups' shares, no cross-lane sum; wave-uniform per frame tile).  Every tile keeps its own accumulation order.
         constexpr int TLAST = NU - 1;
-#pragma unroll
-        for (int t = 0; t < NU; ++t) {
+        {
+          // (round 4) the last tile's KS operand fragments are all requested before its first MFMA -- the compiler's order was
+          // read, wait, FT MFMAs, read, wait, ...: an LDS round trip per k-step pair in a stage of only FT * KS MFMAs -- and
+          // the other tiles' initial values are read only when they are needed (below)
           d4 c;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) c[r] = cur[TL::CINIT_OFF + 16 * t + 4 * r + lgrp];
+          for (int r = 0; r < 4; ++r) c[r] = cur[TL::CINIT_OFF + 16 * TLAST + 4 * r + lgrp];
 #pragma unroll
-          for (int f = 0; f < FT; ++f) acc[f][t] = c;
-        }
+          for (int f = 0; f < FT; ++f) acc[f][TLAST] = c;
+          double afr[KS];
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-          const double a = cur[TL::ufrag_pos(ks, TLAST) * 64 + lane];
+          for (int ks = 0; ks < KS; ++ks) afr[ks] = cur[TL::ufrag_pos(ks, TLAST) * 64 + lane];
+          __builtin_amdgcn_sched_barrier(0);       // (the scheduler sinks the reads back to their MFMAs otherwise)
 #pragma unroll
-          for (int f = 0; f < FT; ++f) acc[f][TLAST] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, xb[f][ks], acc[f][TLAST], 0, 0, 0);
+          for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+            for (int f = 0; f < FT; ++f) acc[f][TLAST] = __builtin_amdgcn_mfma_f64_16x16x4f64(afr[ks], xb[f][ks], acc[f][TLAST], 0, 0, 0);
+          }
         }
         nmfma_wave += FT * KS;
+        VCMI_LC_NEXT
         unsigned und = (1u << FT) - 1u;        // frame tiles on which the mixture is still undecided
 #pragma unroll
         for (int f = 0; f < FT; ++f) {
@@ -488,8 +565,17 @@ gmmmap_mfma_kernel(const double *__restrict__ packed, int M, int D, const double
           }
         }
         ulive = und;
+        VCMI_PP(1)
         if (und) {
           nmfma_wave += __builtin_popcount(und) * (TL::tile_off(NU) - KS);
+#pragma unroll
+          for (int t = 0; t < TLAST; ++t) {
+            d4 c;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) c[r] = cur[TL::CINIT_OFF + 16 * t + 4 * r + lgrp];
+#pragma unroll
+            for (int f = 0; f < FT; ++f) acc[f][t] = c;
+          }
 #pragma unroll
           for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
@@ -524,6 +610,7 @@ gmmmap_mfma_kernel(const double *__restrict__ packed, int M, int D, const double
       }
       int s = 0;
       if (MODE == 0) nmfma_wave += FT * TL::tile_off(NU);
+      // (MODE 0 with a single whitening tile: lc_next is requested at the end of the iteration)
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
@@ -679,7 +766,11 @@ gmmmap_mfma_kernel(const double *__restrict__ packed, int M, int D, const double
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // reads done before the next group's ds_writes reuse the rows
     }
 
+    if constexpr (MODE == 0) {
+      if (!lcn_done) lc_next = packed_c[(size_t)mn * BLK + TL::LC_OFF];       // (a mixture without weight: nothing ran above)
+    }
     if (NBUF == 1) __syncthreads();   // single buffer: everyone is done reading before it is overwritten
+    VCMI_PP(2)
 #ifdef VCMI_CONVERT_PROF
     const unsigned long long tb0_ = __builtin_readcyclecounter();
 #endif
@@ -693,7 +784,16 @@ gmmmap_mfma_kernel(const double *__restrict__ packed, int M, int D, const double
 #ifdef VCMI_CONVERT_PROF
     prof_barrier_ += __builtin_readcyclecounter() - tb0_;      // probe build: cycles between arriving at the barrier and leaving it
 #endif
+    VCMI_PP(3)
   }
+  }
+#undef VCMI_LC_NEXT
+#ifdef VCMI_CONVERT_PROF2
+  if (MODE == 0 && blockIdx.x == 1000 && lane == 0)
+    printf("convert prof shape %d wave %d: top %llu | first %llu | rest %llu | barrier %llu (s_memtime counts over %d mixtures)\n", PRUNE, wave, pp_[0],
+           pp_[1], pp_[2], pp_[3], M);
+#endif
+#undef VCMI_PP
 
   if (MODE == 2 || MODE == 3) {
     if (lgrp == 0) {
@@ -715,6 +815,10 @@ gmmmap_mfma_kernel(const double *__restrict__ packed, int M, int D, const double
       atomicAdd(nreg + 1, (unsigned long long)nmfma_wave);
 #endif
     }
+    if constexpr (PRUNE < 2 && FT == 2) {        // the dense / broad loops kept the denominators in the selected layout
+      const double ds = den[0];
+      unpair_lane_groups(ds, den[0], den[1]);
+    }
 #pragma unroll
     for (int f = 0; f < FT; ++f) {
       const int64_t fr = frame0 + 16 * f + lcol;
@@ -725,6 +829,262 @@ gmmmap_mfma_kernel(const double *__restrict__ packed, int M, int D, const double
           const int row = 4 * j + lgrp;
           if (row < D) Y[frow[f] * ldy + row] = yacc[f][j] * inv;
         }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// fvconvert for PEAKED models, several mixtures per barrier (round 4; D <= 40 < ... instantiated for DP = 40).
+// In the peaked shape of gmmmap_mfma_kernel almost every (tile, mixture) pair ends after the last whitening tile: FT * KS
+// MFMAs (20 at D = 40), a test -- and then a DMA issue, a vmcnt wait and a workgroup barrier for the NEXT mixture's 24 KB
+// block, of which 5 KB were read.  Here a stage holds only what that first step needs -- per mixture a SLICE: the last
+// whitening tile's KS operand fragments, its 16 initial values and lc -- for G consecutive mixtures (4 x 6 KB at D = 40), so
+// the per-stage costs are paid once per G mixtures; the rare pair that goes on (on grouped frames the tile's own mixture,
+// 1 / M) takes the rest of its operands -- the other whitening tiles, the regression tiles -- straight from the mixture's
+// block in global memory (L2): slower per operand, and 1 / M of the pairs.  Same arithmetic, same order per frame as the
+// peaked shape: outputs bit-identical to it.
+// slices: [M][SLICE] doubles: [KS * 64 fragments of U tile NU-1 | 16 initial values | lc | pad to a whole KB].
+// ------------------------------------------------------------------------------------------------
+template <int DP>
+struct PeakedSlice {
+  static constexpr int KS = DP / 4;
+  static constexpr int CI_OFF = KS * 64, LC_OFF = CI_OFF + 16;
+  static constexpr int SLICE = ((LC_OFF + 1 + 127) / 128) * 128;     // doubles; whole KB
+  static constexpr int G = 3072 / SLICE;                              // mixtures per stage (~24 KB)
+  static constexpr bool OK = G >= 2 && (G * SLICE / 128) % 4 == 0 && (DP + 15) / 16 > 1;
+};
+
+template <int DP, int FT, int WAVES>
+__global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(3)))
+gmmmap_peaked_stage_kernel(const double *__restrict__ packed, const double *__restrict__ slices, int M, int D,
+                           const double *__restrict__ X, int64_t ldx, int64_t T, double *__restrict__ Y, int64_t ldy, double prune,
+                           unsigned long long *__restrict__ nreg, const int *__restrict__ perm, const int *__restrict__ gkey) {
+  using TL = Tiling<DP, false>;
+  using SC = PeakedSlice<DP>;
+  constexpr int KS = TL::KS, NT = TL::NT, NU = TL::NU, BLK = TL::BLK, TLAST = NU - 1;
+  constexpr int SLICE = SC::SLICE, G = SC::G, STAGE = G * SLICE, KB_PER_SLICE = SLICE / 128, NV = G * KB_PER_SLICE / WAVES;
+  extern __shared__ double smem[];                          // 2 * STAGE doubles
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lcol = lane & 15, lgrp = lane >> 4;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const unsigned lane_off = 16u * (unsigned)lane;
+  const int64_t frame0 = ((int64_t)blockIdx.x * WAVES + wave) * (16 * FT);
+  const __attribute__((address_space(4))) double *slices_c = (const __attribute__((address_space(4))) double *)slices;
+
+  double xb[FT][KS];
+  int64_t frow[FT];
+#pragma unroll
+  for (int f = 0; f < FT; ++f) {
+    const int64_t fr = frame0 + 16 * f + lcol;
+    frow[f] = (perm != nullptr && fr < T) ? (int64_t)perm[fr] : fr;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int k = 4 * ks + lgrp;
+      xb[f][ks] = (fr < T && k < D) ? X[frow[f] * ldx + k] : 0.0;
+    }
+  }
+  int mfirst = 0;
+  if (perm != nullptr) {
+    const int64_t f0 = (int64_t)blockIdx.x * WAVES * (16 * FT);
+    mfirst = (f0 < T) ? gkey[perm[f0]] : 0;
+    mfirst = (mfirst >= 0 && mfirst < M) ? mfirst : 0;
+  }
+  int nreg_wave = 0, nmfma_wave = 0;
+  unsigned tiles_in_range = 0;
+#pragma unroll
+  for (int f = 0; f < FT; ++f)
+    if (frame0 + 16 * f < T) tiles_in_range |= 1u << f;
+  double yacc[FT][KS], runmax[FT], den[FT];
+#pragma unroll
+  for (int f = 0; f < FT; ++f) {
+    runmax[f] = -INFINITY;
+    den[f] = 0.0;
+#pragma unroll
+    for (int j = 0; j < KS; ++j) yacc[f][j] = 0.0;
+  }
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)(reinterpret_cast<char *>(smem));
+  // the stage of group `grp` (mixtures mfirst + G grp + j, wrapping at M) -> buffer `buf`: wave w moves the KBs w, w + WAVES, ...
+  auto stage_dma = [&](int grp, int buf) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int kb = wave_u + WAVES * i, j = kb / KB_PER_SLICE, within = kb - j * KB_PER_SLICE;
+      int mj = mfirst + G * grp + j;
+      mj = mj % M;                                           // (scalar; slots beyond the M-th mixture re-read a valid slice, unused)
+      const char *ga = reinterpret_cast<const char *>(slices + (size_t)mj * SLICE) + 1024 * within;
+      const unsigned la = lds0 + (unsigned)(buf * STAGE * 8) + 1024u * kb;
+      asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(lane_off), "s"(ga), "s"(la) : "memory", "m0");
+    }
+  };
+  const int ngroups = (M + G - 1) / G;
+  stage_dma(0, 0);
+  // lc of the group's mixtures: scalar loads (uniform addresses), requested one group ahead -- at the END of the previous
+  // group's work, so that no scalar load is outstanding while LDS reads are waited for
+  double lcn[G];
+#pragma unroll
+  for (int j = 0; j < G; ++j) lcn[j] = slices_c[(size_t)((mfirst + j) % M) * SLICE + SC::LC_OFF];
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  for (int go = 0; go < ngroups; go += 2) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int gi = go + u;
+      if (gi >= ngroups) break;
+      if (gi + 1 < ngroups) stage_dma(gi + 1, u ^ 1);
+      __builtin_amdgcn_sched_barrier(0);
+      const double *stg = smem + u * STAGE;
+      double lcg[G];
+#pragma unroll
+      for (int j = 0; j < G; ++j) lcg[j] = lcn[j];
+#pragma unroll
+      for (int j = 0; j < G; ++j) {
+        const int mi = G * gi + j;
+        if (mi >= M) break;                                    // (wave-uniform)
+        const int m = (mfirst + mi < M) ? mfirst + mi : mfirst + mi - M;
+        const double *sl = stg + j * SLICE;
+        const double lc = lcg[j];
+        if ((unsigned)((unsigned long long)__double_as_longlong(lc) >> 32) == 0xFFF00000u) continue;   // no weight
+        d4 acc[FT][NT];
+        double q[FT];
+        {
+          d4 c;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) c[r] = sl[SC::CI_OFF + 4 * r + lgrp];
+#pragma unroll
+          for (int f = 0; f < FT; ++f) acc[f][TLAST] = c;
+          double afr[KS];
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) afr[ks] = sl[ks * 64 + lane];
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+            for (int f = 0; f < FT; ++f) acc[f][TLAST] = __builtin_amdgcn_mfma_f64_16x16x4f64(afr[ks], xb[f][ks], acc[f][TLAST], 0, 0, 0);
+          }
+        }
+        nmfma_wave += FT * KS;
+        unsigned und = (1u << FT) - 1u;
+#pragma unroll
+        for (int f = 0; f < FT; ++f) {
+          double qq = 0.0;
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (16 * TLAST + 4 * r < DP) qq = fma(acc[f][TLAST][r], acc[f][TLAST][r], qq);
+          q[f] = qq;
+          const unsigned long long ub = __builtin_amdgcn_ballot_w64(lc - 0.5 * qq > runmax[f] - prune);
+          if ((ub & (ub >> 16) & (ub >> 32) & (ub >> 48) & 0xffffull) == 0) und &= ~(1u << f);
+        }
+        if (!und) continue;
+        // ---- the pair goes on: the rest of mixture m's operands from its block in global memory ----
+        const double *gb = packed + (size_t)m * BLK;
+        nmfma_wave += __builtin_popcount(und) * (TL::tile_off(NU) - KS);
+#pragma unroll
+        for (int t = 0; t < TLAST; ++t) {
+          d4 c;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) c[r] = gb[TL::CINIT_OFF + 16 * t + 4 * r + lgrp];
+#pragma unroll
+          for (int f = 0; f < FT; ++f) acc[f][t] = c;
+        }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+          for (int t = 0; t < TLAST; ++t) {
+            if (ks < TL::steps(t)) {
+              const double a = gb[TL::ufrag_pos(ks, t) * 64 + lane];
+#pragma unroll
+              for (int f = 0; f < FT; ++f)
+                if (FT == 1 || (und >> f & 1u)) acc[f][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, xb[f][ks], acc[f][t], 0, 0, 0);
+            }
+          }
+        }
+        unsigned active = 0;
+#pragma unroll
+        for (int f = 0; f < FT; ++f) {
+          if (!(und >> f & 1u)) continue;
+          double qq = q[f];
+#pragma unroll
+          for (int t = 0; t < TLAST; ++t) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) qq = fma(acc[f][t][r], acc[f][t][r], qq);
+          }
+          const unsigned long long ub = __builtin_amdgcn_ballot_w64(lc - 0.5 * qq > runmax[f] - prune);
+          if ((ub & (ub >> 16) & (ub >> 32) & (ub >> 48) & 0xffffull) == 0) continue;
+          qq = sum_lane_groups(qq);
+          q[f] = qq;
+          if (__builtin_amdgcn_ballot_w64(lc - 0.5 * qq > runmax[f] - prune) != 0) active |= 1u << f;
+        }
+        nreg_wave += __builtin_popcount(active & tiles_in_range);
+        if (!active) continue;
+        nmfma_wave += __builtin_popcount(active) * (TL::NSTEPS - TL::tile_off(NU));
+        int sa = TL::tile_off(NU);
+#pragma unroll
+        for (int t = NU; t < NT; ++t) {
+          d4 c;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) c[r] = gb[TL::CINIT_OFF + 16 * t + 4 * r + lgrp];
+#pragma unroll
+          for (int f = 0; f < FT; ++f) acc[f][t] = c;
+        }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+          for (int t = NU; t < NT; ++t) {
+            const double a = gb[sa * 64 + lane];
+            ++sa;
+#pragma unroll
+            for (int f = 0; f < FT; ++f)
+              if (FT == 1 || (active >> f & 1u)) acc[f][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, xb[f][ks], acc[f][t], 0, 0, 0);
+          }
+        }
+#pragma unroll
+        for (int f = 0; f < FT; ++f) {
+          if (FT > 1 && !(active >> f & 1u)) continue;
+          const double l = lc - 0.5 * q[f];
+          if (__builtin_amdgcn_ballot_w64(l > runmax[f]) != 0) {
+            const double nm = fmax(runmax[f], l);
+            const double sc = vc_exp(runmax[f] - nm);
+            den[f] *= sc;
+            runmax[f] = nm;
+#pragma unroll
+            for (int jj = 0; jj < KS; ++jj) yacc[f][jj] *= sc;
+          }
+          const double wg = vc_exp(l - runmax[f]);
+          den[f] += wg;
+#pragma unroll
+          for (int t = NU - 1; t < NT; ++t) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int p0 = 16 * t + 4 * r;
+              if (p0 >= DP && p0 < 2 * DP) {
+                const int jj = (p0 - DP) / 4;
+                yacc[f][jj] = fma(wg, acc[f][t][r], yacc[f][jj]);
+              }
+            }
+          }
+        }
+      }
+      if (gi + 1 < ngroups) {
+#pragma unroll
+        for (int j = 0; j < G; ++j) lcn[j] = slices_c[(size_t)((mfirst + G * (gi + 1) + j) % M) * SLICE + SC::LC_OFF];
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+  }
+  if (nreg && lane == 0) {
+    atomicAdd(nreg, (unsigned long long)nreg_wave);
+    atomicAdd(nreg + 1, (unsigned long long)nmfma_wave);
+  }
+#pragma unroll
+  for (int f = 0; f < FT; ++f) {
+    const int64_t fr = frame0 + 16 * f + lcol;
+    const double inv = 1.0 / den[f];
+    if (fr < T) {
+#pragma unroll
+      for (int j = 0; j < KS; ++j) {
+        const int row = 4 * j + lgrp;
+        if (row < D) Y[frow[f] * ldy + row] = yacc[f][j] * inv;
       }
     }
   }
@@ -1294,6 +1654,30 @@ static bool use_mfma(const vcmi_gmmmap *g) {
   return gmmmap_has_mfma(g->DP);
 }
 
+// the peaked loop with G mixtures per stage (gmmmap_peaked_stage_kernel), where it is instantiated and the handle has slices
+static bool peaked_stage_available(const vcmi_gmmmap *g) {
+  return g->DP == 40 && PeakedSlice<40>::OK && g->slices.p && g->M >= 2 && g->prune < 1e300 && !debug_flag(kDbgConvertNoStage);
+}
+static int launch_peaked_stage(const vcmi_gmmmap *g, const double *dX, int64_t ldx, int64_t T, double *dY, int64_t ldy,
+                               hipStream_t st, const int *perm, const int *gkey) {
+  constexpr int DP = 40, FT = 2, WAVES = 4;
+  using SC = PeakedSlice<DP>;
+  const size_t shmem = (size_t)2 * SC::G * SC::SLICE * sizeof(double);
+  auto kern = gmmmap_peaked_stage_kernel<DP, FT, WAVES>;
+  static std::atomic<bool> attr_done[64];
+  int dev = 0;
+  VCMI_HIP(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 64 || !attr_done[dev].load(std::memory_order_acquire)) {
+    VCMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    if (dev >= 0 && dev < 64) attr_done[dev].store(true, std::memory_order_release);
+  }
+  const int64_t per_wg = (int64_t)16 * FT * WAVES, blocks = (T + per_wg - 1) / per_wg;
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(WAVES * 64), shmem, st, g->packed.p, g->slices.p, g->M, g->D, dX, ldx, T, dY, ldy,
+                     g->prune, g->prune_count.p, perm, gkey);
+  VCMI_HIP(hipGetLastError());
+  return VCMI_OK;
+}
+
 static constexpr double kBroadModelFrac = 0.35;
 // Which loop shape converts with this handle (gmmmap_mfma_kernel's PRUNE): 2 "peaked" when, for the model's own frames, the
 // last whitening tile's share of |z|^2 alone puts most mixtures e^-prune under the best one (model_undecided_frac, estimated
@@ -1339,12 +1723,15 @@ int gmmmap_convert_device(vcmi_gmmmap *g, const double *dX, int64_t ldx, int64_t
                          key, T, g->M, chunkhist, total, perm);
       VCMI_HIP(hipGetLastError());
       const int rc = convert_shape(g) == 1 ? dispatch_mfma<0, 1>(g, dX, ldx, T, dY, ldy, st, perm, key)
-                                           : dispatch_mfma<0, 2>(g, dX, ldx, T, dY, ldy, st, perm, key);
+                     : peaked_stage_available(g) ? launch_peaked_stage(g, dX, ldx, T, dY, ldy, st, perm, key)
+                                                 : dispatch_mfma<0, 2>(g, dX, ldx, T, dY, ldy, st, perm, key);
       (void)g->grp_order.leave(st);
       return rc;
     }
     if (!(g->prune < 1e300) && !debug_flag(kDbgConvertShapePeaked)) return dispatch_mfma<0, 0>(g, dX, ldx, T, dY, ldy, st);
-    return convert_shape(g) == 1 ? dispatch_mfma<0, 1>(g, dX, ldx, T, dY, ldy, st) : dispatch_mfma<0, 2>(g, dX, ldx, T, dY, ldy, st);
+    if (convert_shape(g) == 1) return dispatch_mfma<0, 1>(g, dX, ldx, T, dY, ldy, st);
+    if (peaked_stage_available(g)) return launch_peaked_stage(g, dX, ldx, T, dY, ldy, st, nullptr, nullptr);
+    return dispatch_mfma<0, 2>(g, dX, ldx, T, dY, ldy, st);
   }
   if (g->kernel_choice != 1 && g->At.p && g->D > 16 && g->D <= 160) {
     // no tile-kernel instantiation (80 < padded D <= 160, or a padded dimension outside its list): MFMA log-densities
@@ -1646,6 +2033,29 @@ static int prepare(vcmi_gmmmap *g, const double *w, const double *mu, const doub
     DevBuf<double> &dst = uonly == 2 ? g->packedU2 : (uonly ? g->packedU : g->packed);
     VCMI_TRY(dst.reserve(pk.size()));
     VCMI_HIP(hipMemcpy(dst.p, pk.data(), pk.size() * 8, hipMemcpyHostToDevice));
+  }
+  if (!px_only && DP == 40) {   // last-tile slices of gmmmap_peaked_stage_kernel: [KS * 64 fragments of U tile NU-1 | its 16 initial values | lc | pad]
+    using SC = PeakedSlice<40>;
+    TilingRT tl(DP, false);
+    std::vector<double> sl((size_t)SC::SLICE * M, 0.0);
+    const int tlast = tl.NU - 1;
+    for (int m = 0; m < M; ++m) {
+      double *blk = &sl[(size_t)SC::SLICE * m];
+      for (int ks = 0; ks < tl.KS; ++ks)
+        for (int l = 0; l < 64; ++l) {
+          const int prow = 16 * tlast + (l & 15), k = 4 * ks + (l >> 4);
+          double v = 0.0;
+          if (k < DP) v = prow < DP ? hU[pp * m + (size_t)prow * DP + k] : (prow < 2 * DP ? hA[pp * m + (size_t)(prow - DP) * DP + k] : 0.0);
+          blk[(size_t)ks * 64 + l] = v;
+        }
+      for (int i = 0; i < 16; ++i) {
+        const int prow = 16 * tlast + i;
+        blk[SC::CI_OFF + i] = prow < DP ? -hcz[(size_t)DP * m + prow] : (prow < 2 * DP ? hb[(size_t)DP * m + (prow - DP)] : 0.0);
+      }
+      blk[SC::LC_OFF] = hlc[m];
+    }
+    VCMI_TRY(g->slices.reserve(sl.size()));
+    VCMI_HIP(hipMemcpy(g->slices.p, sl.data(), sl.size() * 8, hipMemcpyHostToDevice));
   }
   if (!g->h_mux.empty()) {     // operand of the frame grouping (gmmmap_group_key_kernel): [-2 mu^x | |mu^x|^2], fragment order
     const int KS1 = DP / 4 + 1, MT = (M + 15) / 16;
