@@ -665,6 +665,35 @@ def bench_estep(args, world, rank):
     return out
 
 
+def full_estep_issued_mfma(step_fn, N, Dj, M):
+    """v_mfma_f64_16x16x4 instructions of one full-covariance E-step: the log-density kernel's are a fixed number (two frame
+    tiles per wave, four waves per workgroup, every whitening tile of every mixture: U-only tiling of csrc/gmmmap.hip), the
+    statistics kernel counts its own (vcmi_debug_estep_full_mfma).  None when the library has no counter / another path."""
+    import ctypes as C
+
+    import torch
+
+    from voiceconversion_jl_amd import _lib
+
+    if Dj > 80 or Dj % 4:
+        return None
+    try:
+        fn = _lib.lib.vcmi_debug_estep_full_mfma
+        fn.argtypes, fn.restype = [C.c_int, C.POINTER(C.c_int64)], C.c_int
+        _lib.check(fn(1, None))
+        step_fn()
+        torch.cuda.synchronize()
+        cnt = C.c_int64(0)
+        _lib.check(fn(0, C.byref(cnt)))
+    except Exception:  # noqa: BLE001
+        return None
+    DP, KS = Dj, Dj // 4
+    nu = -(-DP // 16)
+    steps_u = sum((min(4 * (t + 1), KS) if 16 * t + 15 < DP else KS) for t in range(nu))
+    logdens = 2 * steps_u * M * 4 * (-(-N // 128))
+    return logdens + int(cnt.value)
+
+
 def bench_estep_full(args, world, rank):
     """full-covariance E-step (what bin/train_gmm.jl:84-103 runs), Dj=80, M=64, 5e5 frames per
     GPU (weak scaling) + ONE all-reduce of the packed statistics.  Algorithmic flops per frame: triangular
@@ -687,7 +716,10 @@ def bench_estep_full(args, world, rank):
 
     wall, kernel_ms = timed_steps(step, args.steps, args.warmup, world)
     flop = 2 * M * Dj * (Dj + 1) + 2 * M * Dj
-    achieved = flop * N / (kernel_ms * 1e-3) / 1e12
+    alg_tflops = flop * N / (kernel_ms * 1e-3) / 1e12
+    issued = full_estep_issued_mfma(step, N, Dj, M) if args.cpu_seconds > 0 else None
+    iss_tflops = issued * MFMA_FLOP / (kernel_ms * 1e-3) / 1e12 if issued else None
+    achieved = min(alg_tflops, iss_tflops) if iss_tflops else alg_tflops
     out = {"metric": "full-covariance GMM E-step frames/sec (Dj=%d, M=64)" % Dj, "value": world * N * args.steps / wall,
            "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -699,6 +731,10 @@ def bench_estep_full(args, world, rank):
                                   ("whole step: logdens_tiled_kernel + estep_full_stats_kernel<%d,4> (+ host Cholesky of the %d-dim blocks)" % (Dj, Dj)),
                         "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                         "frac": achieved / FP64_PEAK_TFLOPS,
+                        "frac_definition": "min(algorithmic flop, flop of the MFMAs issued) / step time / peak (the statistics of "
+                                           "responsibilities that are exactly zero are not multiplied)",
+                        "algorithmic_frac": alg_tflops / FP64_PEAK_TFLOPS,
+                        "issued_mfma_frac": (iss_tflops / FP64_PEAK_TFLOPS) if iss_tflops else None, "mfma_issued_per_step": issued,
                         "traffic": None,
                         "flop_per_frame": flop, "kernel_ms": kernel_ms}}
     attach_traffic(out, "estep_full_traffic.json", ("gmmmap_mfma_kernel", "estep_full_stats_kernel", "estep_full_softmax_kernel"),
@@ -742,7 +778,10 @@ def bench_em_full(args, world, rank):
 
     wall, kernel_ms = timed_steps(step, args.steps, args.warmup, world)
     flop = 2 * M * Dj * (Dj + 1) + 2 * M * Dj
-    achieved = flop * N / (kernel_ms * 1e-3) / 1e12
+    alg_tflops = flop * N / (kernel_ms * 1e-3) / 1e12
+    issued = full_estep_issued_mfma(lambda: em.estep(Xd.t(), out=stats), N, Dj, M) if args.cpu_seconds > 0 else None
+    iss_tflops = issued * MFMA_FLOP / (kernel_ms * 1e-3) / 1e12 if issued else None
+    achieved = min(alg_tflops, iss_tflops) if iss_tflops else alg_tflops
     out = {"metric": "full-covariance GMM EM iteration frames/sec (Dj=%d, M=64)" % Dj, "value": world * N * args.steps / wall,
            "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -752,6 +791,8 @@ def bench_em_full(args, world, rank):
            "roofline": {"bound": "mfma", "kernel": "whole iteration: log-densities + second moments + M-step + whitening",
                         "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                         "frac": achieved / FP64_PEAK_TFLOPS,
+                        "algorithmic_frac": alg_tflops / FP64_PEAK_TFLOPS,
+                        "issued_mfma_frac": (iss_tflops / FP64_PEAK_TFLOPS) if iss_tflops else None, "mfma_issued_per_step": issued,
                         "traffic": None,
                         "flop_per_frame": flop, "kernel_ms": kernel_ms},
            "loglik_monotone": bool(all(b >= a - 1e-6 * abs(a) for a, b in zip(hist, hist[1:])))}

@@ -1146,7 +1146,8 @@ struct FullStatsCfg {
 template <int DJ, int PARTS, int PART>
 __device__ __forceinline__ void estep_full_stats_body(const double *__restrict__ X, int64_t n0, int64_t f_begin, int64_t f_end,
                                                       int M, int mg, const double *__restrict__ G, double *__restrict__ P,
-                                                      double *xs, double *gs, int dj, const int *__restrict__ lst) {
+                                                      double *xs, double *gs, int dj, const int *__restrict__ lst,
+                                                      unsigned long long *__restrict__ mfma_count) {
   // lst (optional): positions [f_begin, f_end) index this mixture group's frame list instead of the frames themselves
   using C = FullStatsCfg<DJ, PARTS>;
   constexpr int NTL = C::NTL, RSX = C::RSX, FB = kFullFB, NM = C::NM;
@@ -1163,6 +1164,7 @@ __device__ __forceinline__ void estep_full_stats_body(const double *__restrict__
   double s1[NTL], s0 = 0.0;
 #pragma unroll
   for (int a = 0; a < NTL; ++a) s1[a] = 0.0;
+  int nmfma = 0;               // MFMAs this wave issued (measurement: mfma_count, optional)
 
   double pf[NPF], pg = 0.0;
   const int gf = tid / NM, gq = tid % NM;                 // gamma staging: FB frames x NM mixtures
@@ -1226,6 +1228,7 @@ __device__ __forceinline__ void estep_full_stats_body(const double *__restrict__
       // the four frames of the k-step all have gamma == 0 exactly for this wave's mixture (l_m more than 745 nats under
       // the frame's maximum): the products add exactly nothing -- skipped (wave-uniform; bit-identical statistics)
       if (__builtin_amdgcn_ballot_w64(gm != 0.0) == 0) continue;
+      nmfma += NTP;
       const double *xr = xb + f * RSX + lcol;
       double xv[NTL], ax[NTL];
 #pragma unroll
@@ -1242,6 +1245,7 @@ __device__ __forceinline__ void estep_full_stats_body(const double *__restrict__
     if (more) stash(buf ^ 1);
     __syncthreads();
   }
+  if (mfma_count && lane == 0) atomicAdd(mfma_count, (unsigned long long)nmfma);
   if (m >= M) return;
   // partial statistics of this (mixture, segment) in the final layout [S0 | S1 | S2 | loglik]
   if (kFirstMoments) {
@@ -1275,7 +1279,7 @@ template <int DJ, int PARTS>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 estep_full_stats_kernel(const double *__restrict__ X, int64_t n0, int64_t n, int M, const double *__restrict__ G,
                         double *__restrict__ part, int64_t plen, int dj, const int *__restrict__ lists,
-                        const int *__restrict__ totals) {
+                        const int *__restrict__ totals, unsigned long long *__restrict__ mfma_count) {
   static_assert(DJ % 16 == 0, "full-covariance MFMA statistics need Dj to be a multiple of 16");
   static_assert(PARTS == 1 || PARTS == 2 || PARTS == 4, "waves per mixture");
   using C = FullStatsCfg<DJ, PARTS>;
@@ -1293,10 +1297,10 @@ estep_full_stats_kernel(const double *__restrict__ X, int64_t n0, int64_t n, int
   const int64_t f_begin = std::min<int64_t>(len, seg * seglen), f_end = (f_begin + seglen < len) ? f_begin + seglen : len;
   double *P = part + (size_t)seg * plen;
   const int prt = (threadIdx.x >> 6) % PARTS;          // wave-uniform; every branch runs the same number of barriers
-  if (PARTS == 1 || prt == 0) estep_full_stats_body<DJ, PARTS, 0>(X, n0, f_begin, f_end, M, mg, G, P, xs, gs, dj, lst);
-  else if (PARTS == 2 || prt == 1) estep_full_stats_body<DJ, PARTS, 1>(X, n0, f_begin, f_end, M, mg, G, P, xs, gs, dj, lst);
-  else if (prt == 2) estep_full_stats_body<DJ, PARTS, (PARTS > 2 ? 2 : 0)>(X, n0, f_begin, f_end, M, mg, G, P, xs, gs, dj, lst);
-  else estep_full_stats_body<DJ, PARTS, (PARTS > 3 ? 3 : 0)>(X, n0, f_begin, f_end, M, mg, G, P, xs, gs, dj, lst);
+  if (PARTS == 1 || prt == 0) estep_full_stats_body<DJ, PARTS, 0>(X, n0, f_begin, f_end, M, mg, G, P, xs, gs, dj, lst, mfma_count);
+  else if (PARTS == 2 || prt == 1) estep_full_stats_body<DJ, PARTS, 1>(X, n0, f_begin, f_end, M, mg, G, P, xs, gs, dj, lst, mfma_count);
+  else if (prt == 2) estep_full_stats_body<DJ, PARTS, (PARTS > 2 ? 2 : 0)>(X, n0, f_begin, f_end, M, mg, G, P, xs, gs, dj, lst, mfma_count);
+  else estep_full_stats_body<DJ, PARTS, (PARTS > 3 ? 3 : 0)>(X, n0, f_begin, f_end, M, mg, G, P, xs, gs, dj, lst, mfma_count);
 }
 
 // generic statistics (any Dj): thread per lower-triangle element of one mixture's S2 (+ S1, S0), sequential over the
@@ -1334,6 +1338,7 @@ estep_full_stats_generic_kernel(const double *__restrict__ X, int64_t n0, int64_
 struct EstepFullScratch {
   DevBuf<double> LP, lse, part, X, stats, params;
   DevBuf<int> flag;
+  DevBuf<unsigned long long> mfma_count;   // optional measurement counter of the statistics kernel (vcmi_debug_estep_full_mfma)
   DevBuf<int> lists;        // frame lists of the statistics kernel: [fmask (n) | chunk counts (nchunks, G) | totals (G) | lists (G, n)]
   vcmi_gmmmap *px = nullptr;
   StreamOrder order;   // calls of one thread on different streams share the buffers above
@@ -1406,7 +1411,7 @@ static int estep_full_core_run(vcmi_gmmmap *px, const double *dX, int64_t N, int
           attr_done[dev & 63].store(true, std::memory_order_release);
         }
         hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, dX, n0, n, M, sc.LP.p, sc.part.p, plen, Dj, (const int *)lists,
-                           (const int *)totals);
+                           (const int *)totals, sc.mfma_count.p);
         return VCMI_OK;
       };
       if (Dj <= 32) VCMI_TRY(launch(estep_full_stats_kernel<32, 1>, FullStatsCfg<32, 1>::LDS_BYTES));
@@ -1704,6 +1709,27 @@ extern "C" int vcmi_gmm_em_get(vcmi_gmm_em *h, double *w, double *mu, double *si
 extern "C" int vcmi_debug_estep_mfma(int enable, int64_t *issued) {
   using namespace vcmi;
   EstepScratch &sc = scratch();
+  if (issued) {
+    *issued = 0;
+    if (sc.mfma_count.p) {
+      unsigned long long h = 0;
+      VCMI_HIP(hipMemcpy(&h, sc.mfma_count.p, sizeof(h), hipMemcpyDeviceToHost));
+      *issued = (int64_t)h;
+    }
+  }
+  if (enable) {
+    if (!sc.mfma_count.p) VCMI_TRY(sc.mfma_count.alloc(1));
+    VCMI_HIP(hipMemset(sc.mfma_count.p, 0, sizeof(unsigned long long)));
+  } else {
+    sc.mfma_count.release();
+  }
+  return VCMI_OK;
+}
+
+// The same for the full-covariance STATISTICS kernel (its log-density kernel issues a fixed, known number of MFMAs).
+extern "C" int vcmi_debug_estep_full_mfma(int enable, int64_t *issued) {
+  using namespace vcmi;
+  EstepFullScratch &sc = full_scratch();
   if (issued) {
     *issued = 0;
     if (sc.mfma_count.p) {

@@ -248,7 +248,7 @@ gmmmap_mfma_kernel(const double *__restrict__ packed, int M, int D, const double
 
   // (the constant address space makes a uniform-address load a scalar load; the blocks are read-only for the kernel)
   const __attribute__((address_space(4))) double *packed_c = (const __attribute__((address_space(4))) double *)packed;
-  double lc_next = (MODE == 0) ? packed_c[(size_t)mfirst * BLK + TL::LC_OFF] : 0.0;
+  double lc_next = packed_c[(size_t)mfirst * BLK + TL::LC_OFF];      // (every mode; mfirst = 0 outside MODE 0)
 #ifdef VCMI_CONVERT_PROF
   unsigned long long prof_barrier_ = 0;
   const unsigned long long prof_t0_ = __builtin_readcyclecounter();
@@ -322,16 +322,15 @@ gmmmap_mfma_kernel(const double *__restrict__ packed, int M, int D, const double
     // Where the NEXT lc is requested matters: an outstanding scalar load turns the compiler's s_waitcnt on LDS reads into
     // lgkmcnt(0) (scalar loads return out of order), and the barrier waits for it too.  So: right after the first stage's
     // |z|^2 arithmetic -- its LDS reads are done, ~30 VALU instructions and a branch follow -- (VCMI_LC_NEXT below).
-    if constexpr (MODE == 0) lc = lc_next;
-    else lc = cur[TL::LC_OFF];
+    lc = lc_next;
     bool lcn_done = false;
 #define VCMI_LC_NEXT                                             \
-  if constexpr (MODE == 0) {                                     \
+  {                                                              \
     lc_next = packed_c[(size_t)mn * BLK + TL::LC_OFF];           \
     lcn_done = true;                                             \
   }
     // the high word of -inf (lc is never NaN): a scalar compare
-    const bool has_weight = (MODE == 0) ? ((unsigned)((unsigned long long)__double_as_longlong(lc) >> 32) != 0xFFF00000u) : (lc != -INFINITY);
+    const bool has_weight = (unsigned)((unsigned long long)__double_as_longlong(lc) >> 32) != 0xFFF00000u;
 #ifdef VCMI_CONVERT_PROF2
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     VCMI_PP(0)
@@ -517,6 +516,7 @@ gmmmap_mfma_kernel(const double *__restrict__ packed, int M, int D, const double
             }
           }
         }
+        VCMI_LC_NEXT
 #pragma unroll
         for (int f = 0; f < FT; ++f) {
           double qq = qp[f];
@@ -610,7 +610,6 @@ gmmmap_mfma_kernel(const double *__restrict__ packed, int M, int D, const double
       }
       int s = 0;
       if (MODE == 0) nmfma_wave += FT * TL::tile_off(NU);
-      // (MODE 0 with a single whitening tile: lc_next is requested at the end of the iteration)
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
@@ -623,6 +622,7 @@ gmmmap_mfma_kernel(const double *__restrict__ packed, int M, int D, const double
           }
         }
       }
+      VCMI_LC_NEXT
 #pragma unroll
       for (int f = 0; f < FT; ++f) {
         double qq = 0.0;
@@ -633,16 +633,20 @@ gmmmap_mfma_kernel(const double *__restrict__ packed, int M, int D, const double
             if (16 * t + 4 * r < DP) qq = fma(acc[f][t][r], acc[f][t][r], qq);
           }
         }
-        if (MODE != 0) {                      // (MODE 0 reduces over the four lane groups only when it has to: see below)
-          qq = sum_lane_groups(qq);
+        if (MODE == 2 || (MODE == 1 && FT != 2)) {   // (MODE 0 reduces over the four lane groups only when it has to: see below;
+          qq = sum_lane_groups(qq);                  //  MODE 1 with two tiles: both in one exchange, below)
         }
         q[f] = qq;
       }
       }
 
       if (MODE == 1) {
-        // log-weighted density of mixture m for the wave's frames; one lane group writes
-        if (lgrp == 0) {
+        // log-weighted density of mixture m for the wave's frames.  Two tiles: ONE exchange sequence sums both (the even lane
+        // groups end with tile 0's |z|^2, the odd ones with tile 1's) and lane groups 0 and 1 write their tile's value
+        if constexpr (FT == 2) {
+          const double lsel = lc - 0.5 * sum_lane_groups_pair(q[0], q[1]);
+          if (lgrp < 2) lstage[((wave * FT + lgrp) * 16 + lcol) * LROW + (m & 7)] = lsel;
+        } else if (lgrp == 0) {
 #pragma unroll
           for (int f = 0; f < FT; ++f) lstage[((wave * FT + f) * 16 + lcol) * LROW + (m & 7)] = lc - 0.5 * q[f];
         }
@@ -766,9 +770,7 @@ gmmmap_mfma_kernel(const double *__restrict__ packed, int M, int D, const double
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // reads done before the next group's ds_writes reuse the rows
     }
 
-    if constexpr (MODE == 0) {
-      if (!lcn_done) lc_next = packed_c[(size_t)mn * BLK + TL::LC_OFF];       // (a mixture without weight: nothing ran above)
-    }
+    if (!lcn_done) lc_next = packed_c[(size_t)mn * BLK + TL::LC_OFF];       // (e.g. a mixture without weight: nothing ran above)
     if (NBUF == 1) __syncthreads();   // single buffer: everyone is done reading before it is overwritten
     VCMI_PP(2)
 #ifdef VCMI_CONVERT_PROF
@@ -829,262 +831,6 @@ gmmmap_mfma_kernel(const double *__restrict__ packed, int M, int D, const double
           const int row = 4 * j + lgrp;
           if (row < D) Y[frow[f] * ldy + row] = yacc[f][j] * inv;
         }
-      }
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
-// fvconvert for PEAKED models, several mixtures per barrier (round 4; D <= 40 < ... instantiated for DP = 40).
-// In the peaked shape of gmmmap_mfma_kernel almost every (tile, mixture) pair ends after the last whitening tile: FT * KS
-// MFMAs (20 at D = 40), a test -- and then a DMA issue, a vmcnt wait and a workgroup barrier for the NEXT mixture's 24 KB
-// block, of which 5 KB were read.  Here a stage holds only what that first step needs -- per mixture a SLICE: the last
-// whitening tile's KS operand fragments, its 16 initial values and lc -- for G consecutive mixtures (4 x 6 KB at D = 40), so
-// the per-stage costs are paid once per G mixtures; the rare pair that goes on (on grouped frames the tile's own mixture,
-// 1 / M) takes the rest of its operands -- the other whitening tiles, the regression tiles -- straight from the mixture's
-// block in global memory (L2): slower per operand, and 1 / M of the pairs.  Same arithmetic, same order per frame as the
-// peaked shape: outputs bit-identical to it.
-// slices: [M][SLICE] doubles: [KS * 64 fragments of U tile NU-1 | 16 initial values | lc | pad to a whole KB].
-// ------------------------------------------------------------------------------------------------
-template <int DP>
-struct PeakedSlice {
-  static constexpr int KS = DP / 4;
-  static constexpr int CI_OFF = KS * 64, LC_OFF = CI_OFF + 16;
-  static constexpr int SLICE = ((LC_OFF + 1 + 127) / 128) * 128;     // doubles; whole KB
-  static constexpr int G = 3072 / SLICE;                              // mixtures per stage (~24 KB)
-  static constexpr bool OK = G >= 2 && (G * SLICE / 128) % 4 == 0 && (DP + 15) / 16 > 1;
-};
-
-template <int DP, int FT, int WAVES>
-__global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(3)))
-gmmmap_peaked_stage_kernel(const double *__restrict__ packed, const double *__restrict__ slices, int M, int D,
-                           const double *__restrict__ X, int64_t ldx, int64_t T, double *__restrict__ Y, int64_t ldy, double prune,
-                           unsigned long long *__restrict__ nreg, const int *__restrict__ perm, const int *__restrict__ gkey) {
-  using TL = Tiling<DP, false>;
-  using SC = PeakedSlice<DP>;
-  constexpr int KS = TL::KS, NT = TL::NT, NU = TL::NU, BLK = TL::BLK, TLAST = NU - 1;
-  constexpr int SLICE = SC::SLICE, G = SC::G, STAGE = G * SLICE, KB_PER_SLICE = SLICE / 128, NV = G * KB_PER_SLICE / WAVES;
-  extern __shared__ double smem[];                          // 2 * STAGE doubles
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lcol = lane & 15, lgrp = lane >> 4;
-  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-  const unsigned lane_off = 16u * (unsigned)lane;
-  const int64_t frame0 = ((int64_t)blockIdx.x * WAVES + wave) * (16 * FT);
-  const __attribute__((address_space(4))) double *slices_c = (const __attribute__((address_space(4))) double *)slices;
-
-  double xb[FT][KS];
-  int64_t frow[FT];
-#pragma unroll
-  for (int f = 0; f < FT; ++f) {
-    const int64_t fr = frame0 + 16 * f + lcol;
-    frow[f] = (perm != nullptr && fr < T) ? (int64_t)perm[fr] : fr;
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      const int k = 4 * ks + lgrp;
-      xb[f][ks] = (fr < T && k < D) ? X[frow[f] * ldx + k] : 0.0;
-    }
-  }
-  int mfirst = 0;
-  if (perm != nullptr) {
-    const int64_t f0 = (int64_t)blockIdx.x * WAVES * (16 * FT);
-    mfirst = (f0 < T) ? gkey[perm[f0]] : 0;
-    mfirst = (mfirst >= 0 && mfirst < M) ? mfirst : 0;
-  }
-  int nreg_wave = 0, nmfma_wave = 0;
-  unsigned tiles_in_range = 0;
-#pragma unroll
-  for (int f = 0; f < FT; ++f)
-    if (frame0 + 16 * f < T) tiles_in_range |= 1u << f;
-  double yacc[FT][KS], runmax[FT], den[FT];
-#pragma unroll
-  for (int f = 0; f < FT; ++f) {
-    runmax[f] = -INFINITY;
-    den[f] = 0.0;
-#pragma unroll
-    for (int j = 0; j < KS; ++j) yacc[f][j] = 0.0;
-  }
-  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)(reinterpret_cast<char *>(smem));
-  // the stage of group `grp` (mixtures mfirst + G grp + j, wrapping at M) -> buffer `buf`: wave w moves the KBs w, w + WAVES, ...
-  auto stage_dma = [&](int grp, int buf) {
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      const int kb = wave_u + WAVES * i, j = kb / KB_PER_SLICE, within = kb - j * KB_PER_SLICE;
-      int mj = mfirst + G * grp + j;
-      mj = mj % M;                                           // (scalar; slots beyond the M-th mixture re-read a valid slice, unused)
-      const char *ga = reinterpret_cast<const char *>(slices + (size_t)mj * SLICE) + 1024 * within;
-      const unsigned la = lds0 + (unsigned)(buf * STAGE * 8) + 1024u * kb;
-      asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(lane_off), "s"(ga), "s"(la) : "memory", "m0");
-    }
-  };
-  const int ngroups = (M + G - 1) / G;
-  stage_dma(0, 0);
-  // lc of the group's mixtures: scalar loads (uniform addresses), requested one group ahead -- at the END of the previous
-  // group's work, so that no scalar load is outstanding while LDS reads are waited for
-  double lcn[G];
-#pragma unroll
-  for (int j = 0; j < G; ++j) lcn[j] = slices_c[(size_t)((mfirst + j) % M) * SLICE + SC::LC_OFF];
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-
-  for (int go = 0; go < ngroups; go += 2) {
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int gi = go + u;
-      if (gi >= ngroups) break;
-      if (gi + 1 < ngroups) stage_dma(gi + 1, u ^ 1);
-      __builtin_amdgcn_sched_barrier(0);
-      const double *stg = smem + u * STAGE;
-      double lcg[G];
-#pragma unroll
-      for (int j = 0; j < G; ++j) lcg[j] = lcn[j];
-#pragma unroll
-      for (int j = 0; j < G; ++j) {
-        const int mi = G * gi + j;
-        if (mi >= M) break;                                    // (wave-uniform)
-        const int m = (mfirst + mi < M) ? mfirst + mi : mfirst + mi - M;
-        const double *sl = stg + j * SLICE;
-        const double lc = lcg[j];
-        if ((unsigned)((unsigned long long)__double_as_longlong(lc) >> 32) == 0xFFF00000u) continue;   // no weight
-        d4 acc[FT][NT];
-        double q[FT];
-        {
-          d4 c;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) c[r] = sl[SC::CI_OFF + 4 * r + lgrp];
-#pragma unroll
-          for (int f = 0; f < FT; ++f) acc[f][TLAST] = c;
-          double afr[KS];
-#pragma unroll
-          for (int ks = 0; ks < KS; ++ks) afr[ks] = sl[ks * 64 + lane];
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int ks = 0; ks < KS; ++ks) {
-#pragma unroll
-            for (int f = 0; f < FT; ++f) acc[f][TLAST] = __builtin_amdgcn_mfma_f64_16x16x4f64(afr[ks], xb[f][ks], acc[f][TLAST], 0, 0, 0);
-          }
-        }
-        nmfma_wave += FT * KS;
-        unsigned und = (1u << FT) - 1u;
-#pragma unroll
-        for (int f = 0; f < FT; ++f) {
-          double qq = 0.0;
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (16 * TLAST + 4 * r < DP) qq = fma(acc[f][TLAST][r], acc[f][TLAST][r], qq);
-          q[f] = qq;
-          const unsigned long long ub = __builtin_amdgcn_ballot_w64(lc - 0.5 * qq > runmax[f] - prune);
-          if ((ub & (ub >> 16) & (ub >> 32) & (ub >> 48) & 0xffffull) == 0) und &= ~(1u << f);
-        }
-        if (!und) continue;
-        // ---- the pair goes on: the rest of mixture m's operands from its block in global memory ----
-        const double *gb = packed + (size_t)m * BLK;
-        nmfma_wave += __builtin_popcount(und) * (TL::tile_off(NU) - KS);
-#pragma unroll
-        for (int t = 0; t < TLAST; ++t) {
-          d4 c;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) c[r] = gb[TL::CINIT_OFF + 16 * t + 4 * r + lgrp];
-#pragma unroll
-          for (int f = 0; f < FT; ++f) acc[f][t] = c;
-        }
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-#pragma unroll
-          for (int t = 0; t < TLAST; ++t) {
-            if (ks < TL::steps(t)) {
-              const double a = gb[TL::ufrag_pos(ks, t) * 64 + lane];
-#pragma unroll
-              for (int f = 0; f < FT; ++f)
-                if (FT == 1 || (und >> f & 1u)) acc[f][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, xb[f][ks], acc[f][t], 0, 0, 0);
-            }
-          }
-        }
-        unsigned active = 0;
-#pragma unroll
-        for (int f = 0; f < FT; ++f) {
-          if (!(und >> f & 1u)) continue;
-          double qq = q[f];
-#pragma unroll
-          for (int t = 0; t < TLAST; ++t) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) qq = fma(acc[f][t][r], acc[f][t][r], qq);
-          }
-          const unsigned long long ub = __builtin_amdgcn_ballot_w64(lc - 0.5 * qq > runmax[f] - prune);
-          if ((ub & (ub >> 16) & (ub >> 32) & (ub >> 48) & 0xffffull) == 0) continue;
-          qq = sum_lane_groups(qq);
-          q[f] = qq;
-          if (__builtin_amdgcn_ballot_w64(lc - 0.5 * qq > runmax[f] - prune) != 0) active |= 1u << f;
-        }
-        nreg_wave += __builtin_popcount(active & tiles_in_range);
-        if (!active) continue;
-        nmfma_wave += __builtin_popcount(active) * (TL::NSTEPS - TL::tile_off(NU));
-        int sa = TL::tile_off(NU);
-#pragma unroll
-        for (int t = NU; t < NT; ++t) {
-          d4 c;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) c[r] = gb[TL::CINIT_OFF + 16 * t + 4 * r + lgrp];
-#pragma unroll
-          for (int f = 0; f < FT; ++f) acc[f][t] = c;
-        }
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-#pragma unroll
-          for (int t = NU; t < NT; ++t) {
-            const double a = gb[sa * 64 + lane];
-            ++sa;
-#pragma unroll
-            for (int f = 0; f < FT; ++f)
-              if (FT == 1 || (active >> f & 1u)) acc[f][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, xb[f][ks], acc[f][t], 0, 0, 0);
-          }
-        }
-#pragma unroll
-        for (int f = 0; f < FT; ++f) {
-          if (FT > 1 && !(active >> f & 1u)) continue;
-          const double l = lc - 0.5 * q[f];
-          if (__builtin_amdgcn_ballot_w64(l > runmax[f]) != 0) {
-            const double nm = fmax(runmax[f], l);
-            const double sc = vc_exp(runmax[f] - nm);
-            den[f] *= sc;
-            runmax[f] = nm;
-#pragma unroll
-            for (int jj = 0; jj < KS; ++jj) yacc[f][jj] *= sc;
-          }
-          const double wg = vc_exp(l - runmax[f]);
-          den[f] += wg;
-#pragma unroll
-          for (int t = NU - 1; t < NT; ++t) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const int p0 = 16 * t + 4 * r;
-              if (p0 >= DP && p0 < 2 * DP) {
-                const int jj = (p0 - DP) / 4;
-                yacc[f][jj] = fma(wg, acc[f][t][r], yacc[f][jj]);
-              }
-            }
-          }
-        }
-      }
-      if (gi + 1 < ngroups) {
-#pragma unroll
-        for (int j = 0; j < G; ++j) lcn[j] = slices_c[(size_t)((mfirst + G * (gi + 1) + j) % M) * SLICE + SC::LC_OFF];
-      }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-    }
-  }
-  if (nreg && lane == 0) {
-    atomicAdd(nreg, (unsigned long long)nreg_wave);
-    atomicAdd(nreg + 1, (unsigned long long)nmfma_wave);
-  }
-#pragma unroll
-  for (int f = 0; f < FT; ++f) {
-    const int64_t fr = frame0 + 16 * f + lcol;
-    const double inv = 1.0 / den[f];
-    if (fr < T) {
-#pragma unroll
-      for (int j = 0; j < KS; ++j) {
-        const int row = 4 * j + lgrp;
-        if (row < D) Y[frow[f] * ldy + row] = yacc[f][j] * inv;
       }
     }
   }
@@ -1654,30 +1400,6 @@ static bool use_mfma(const vcmi_gmmmap *g) {
   return gmmmap_has_mfma(g->DP);
 }
 
-// the peaked loop with G mixtures per stage (gmmmap_peaked_stage_kernel), where it is instantiated and the handle has slices
-static bool peaked_stage_available(const vcmi_gmmmap *g) {
-  return g->DP == 40 && PeakedSlice<40>::OK && g->slices.p && g->M >= 2 && g->prune < 1e300 && !debug_flag(kDbgConvertNoStage);
-}
-static int launch_peaked_stage(const vcmi_gmmmap *g, const double *dX, int64_t ldx, int64_t T, double *dY, int64_t ldy,
-                               hipStream_t st, const int *perm, const int *gkey) {
-  constexpr int DP = 40, FT = 2, WAVES = 4;
-  using SC = PeakedSlice<DP>;
-  const size_t shmem = (size_t)2 * SC::G * SC::SLICE * sizeof(double);
-  auto kern = gmmmap_peaked_stage_kernel<DP, FT, WAVES>;
-  static std::atomic<bool> attr_done[64];
-  int dev = 0;
-  VCMI_HIP(hipGetDevice(&dev));
-  if (dev < 0 || dev >= 64 || !attr_done[dev].load(std::memory_order_acquire)) {
-    VCMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-    if (dev >= 0 && dev < 64) attr_done[dev].store(true, std::memory_order_release);
-  }
-  const int64_t per_wg = (int64_t)16 * FT * WAVES, blocks = (T + per_wg - 1) / per_wg;
-  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(WAVES * 64), shmem, st, g->packed.p, g->slices.p, g->M, g->D, dX, ldx, T, dY, ldy,
-                     g->prune, g->prune_count.p, perm, gkey);
-  VCMI_HIP(hipGetLastError());
-  return VCMI_OK;
-}
-
 static constexpr double kBroadModelFrac = 0.35;
 // Which loop shape converts with this handle (gmmmap_mfma_kernel's PRUNE): 2 "peaked" when, for the model's own frames, the
 // last whitening tile's share of |z|^2 alone puts most mixtures e^-prune under the best one (model_undecided_frac, estimated
@@ -1723,15 +1445,12 @@ int gmmmap_convert_device(vcmi_gmmmap *g, const double *dX, int64_t ldx, int64_t
                          key, T, g->M, chunkhist, total, perm);
       VCMI_HIP(hipGetLastError());
       const int rc = convert_shape(g) == 1 ? dispatch_mfma<0, 1>(g, dX, ldx, T, dY, ldy, st, perm, key)
-                     : peaked_stage_available(g) ? launch_peaked_stage(g, dX, ldx, T, dY, ldy, st, perm, key)
-                                                 : dispatch_mfma<0, 2>(g, dX, ldx, T, dY, ldy, st, perm, key);
+                                           : dispatch_mfma<0, 2>(g, dX, ldx, T, dY, ldy, st, perm, key);
       (void)g->grp_order.leave(st);
       return rc;
     }
     if (!(g->prune < 1e300) && !debug_flag(kDbgConvertShapePeaked)) return dispatch_mfma<0, 0>(g, dX, ldx, T, dY, ldy, st);
-    if (convert_shape(g) == 1) return dispatch_mfma<0, 1>(g, dX, ldx, T, dY, ldy, st);
-    if (peaked_stage_available(g)) return launch_peaked_stage(g, dX, ldx, T, dY, ldy, st, nullptr, nullptr);
-    return dispatch_mfma<0, 2>(g, dX, ldx, T, dY, ldy, st);
+    return convert_shape(g) == 1 ? dispatch_mfma<0, 1>(g, dX, ldx, T, dY, ldy, st) : dispatch_mfma<0, 2>(g, dX, ldx, T, dY, ldy, st);
   }
   if (g->kernel_choice != 1 && g->At.p && g->D > 16 && g->D <= 160) {
     // no tile-kernel instantiation (80 < padded D <= 160, or a padded dimension outside its list): MFMA log-densities
@@ -2033,29 +1752,6 @@ static int prepare(vcmi_gmmmap *g, const double *w, const double *mu, const doub
     DevBuf<double> &dst = uonly == 2 ? g->packedU2 : (uonly ? g->packedU : g->packed);
     VCMI_TRY(dst.reserve(pk.size()));
     VCMI_HIP(hipMemcpy(dst.p, pk.data(), pk.size() * 8, hipMemcpyHostToDevice));
-  }
-  if (!px_only && DP == 40) {   // last-tile slices of gmmmap_peaked_stage_kernel: [KS * 64 fragments of U tile NU-1 | its 16 initial values | lc | pad]
-    using SC = PeakedSlice<40>;
-    TilingRT tl(DP, false);
-    std::vector<double> sl((size_t)SC::SLICE * M, 0.0);
-    const int tlast = tl.NU - 1;
-    for (int m = 0; m < M; ++m) {
-      double *blk = &sl[(size_t)SC::SLICE * m];
-      for (int ks = 0; ks < tl.KS; ++ks)
-        for (int l = 0; l < 64; ++l) {
-          const int prow = 16 * tlast + (l & 15), k = 4 * ks + (l >> 4);
-          double v = 0.0;
-          if (k < DP) v = prow < DP ? hU[pp * m + (size_t)prow * DP + k] : (prow < 2 * DP ? hA[pp * m + (size_t)(prow - DP) * DP + k] : 0.0);
-          blk[(size_t)ks * 64 + l] = v;
-        }
-      for (int i = 0; i < 16; ++i) {
-        const int prow = 16 * tlast + i;
-        blk[SC::CI_OFF + i] = prow < DP ? -hcz[(size_t)DP * m + prow] : (prow < 2 * DP ? hb[(size_t)DP * m + (prow - DP)] : 0.0);
-      }
-      blk[SC::LC_OFF] = hlc[m];
-    }
-    VCMI_TRY(g->slices.reserve(sl.size()));
-    VCMI_HIP(hipMemcpy(g->slices.p, sl.data(), sl.size() * 8, hipMemcpyHostToDevice));
   }
   if (!g->h_mux.empty()) {     // operand of the frame grouping (gmmmap_group_key_kernel): [-2 mu^x | |mu^x|^2], fragment order
     const int KS1 = DP / 4 + 1, MT = (M + 15) / 16;

@@ -31,7 +31,6 @@ struct vcmi_gmmmap {
   vcmi::DevBuf<double> packed;    // [U_m ; A_m] tiles (convert)
   vcmi::DevBuf<double> packedU;   // U_m tiles only (log-density / posterior / argmax)
   vcmi::DevBuf<double> packedU2;  // U_m tiles only, tile by tile, last tile first (predict with early exit; host-prepared handles)
-  vcmi::DevBuf<double> slices;    // last whitening tile + its initial values + lc per mixture (gmmmap_peaked_stage_kernel; D = 40)
   // fvconvert's frame grouping (gmmmap_group_key_kernel): nearest-source-mean operand [-2 mu | |mu|^2] in MFMA fragment order,
   // and the call's scratch: key (T), perm (T), counts (M), cursors (M)
   vcmi::DevBuf<double> gfrag;

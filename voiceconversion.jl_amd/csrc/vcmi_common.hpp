@@ -108,7 +108,6 @@ enum : unsigned {
   kDbgConvertShapeBroad = 4096u,  // fvconvert: the "broad model" loop (every whitening tile, one branch around the regression) whatever the model
   kDbgConvertShapePeaked = 8192u, // fvconvert: the "peaked model" loop (last whitening tile first, per-tile tests) whatever the model
   kDbgDtwWholeFirst = 32768u,     // fused DTW: whole-length jobs for the full rounds, segments for the rest (round 4 experiment: 3 % slower)
-  kDbgConvertNoStage = 131072u,   // fvconvert, peaked shape: one mixture per stage (gmmmap_mfma_kernel<.., 2>) instead of gmmmap_peaked_stage_kernel
   kDbgEstepFullNoLists = 65536u,  // full-covariance statistics: every workgroup stages every frame of its segment (rounds 1-3) instead of its group's frame list
   kDbgDtwTwoSegments = 16384u,    // fused DTW: at most two column segments per strip (A/B of the traffic / balance trade)
   kDbgPredictNoEarlyExit = 64u   // predict / trajectory argmax: every whitening tile of every mixture (MODE 2) instead of the early exit (MODE 3)
