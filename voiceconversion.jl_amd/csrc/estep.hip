@@ -24,6 +24,9 @@
 #include "devgroup.hpp"
 #include "hostpipe.hpp"
 #include "fp64_exp.hpp"
+#ifndef VCMI_ESTEP_EXP_SKIP
+#define VCMI_ESTEP_EXP_SKIP 1      // wave-uniform skip of the softmax exps of slot groups that are hopeless for the four frames of a pass (A/B: -0.9 %)
+#endif
 
 #include <algorithm>
 #include <cmath>
@@ -442,6 +445,13 @@ estep_mfma_kernel(const double *__restrict__ X, int64_t N, int M, const double *
         double s = 0.0;
 #pragma unroll
         for (int i = 0; i < C::MMAX / 16; ++i) {
+#if VCMI_ESTEP_EXP_SKIP
+          // the 16 mixtures of slot group i are hopeless for all four frames of the pass (e^x = 0 below -745.2): no exp at all
+          if (__builtin_amdgcn_ballot_w64(v[i] - u > -745.2) == 0) {
+            v[i] = 0.0;
+            continue;
+          }
+#endif
           v[i] = vc_exp_tab(v[i] - u, etab);   // 20 instructions against the 42 of exp(); -inf and < -745 give exactly 0
           s += v[i];
         }

@@ -24,7 +24,7 @@ export FrameByFrameConverter, TrajectoryConverter, GMMMapParam, GMMMap, Trajecto
        align, align_mcep, push_delta, GVDataset,
        DTW, fit!, update!, set_template!, backward,
        predict_proba, predict_proba!, predict, predict!, diffgmm,
-       estep_diag, estep_full, GMMEM, estep!, mstep!, params, set_devices, device_count, set_prune!
+       estep_diag, estep_full, GMMEM, estep!, mstep!, params, set_devices, device_count, set_prune!, convert_plan
 
 const libvcmi = get(ENV, "LIBVCMI", "libvcmi")
 
@@ -153,6 +153,14 @@ ncomponents(g::GMMMap) = Int(ccall((:vcmi_gmmmap_ncomponents, libvcmi), Cint, (P
 Base.size(g::GMMMap) = (dim(g), length(g))
 # not in the reference: posterior pruning threshold of fvconvert in nats (default 46.0; Inf = evaluate every mixture)
 set_prune!(g::GMMMap, nats::Real) = check(ccall((:vcmi_gmmmap_set_prune, libvcmi), Cint, (Ptr{Cvoid}, Cdouble), g.h, Float64(nats)))
+# not in the reference: which loop the library runs for this model (0 dense, 1 "broad", 2 "peaked", -1 no tile kernel) and the
+# two model properties the choice rests on (measurement; include/vcmi.h: vcmi_gmmmap_convert_plan)
+function convert_plan(g::GMMMap)
+    issued = Ref{Int64}(0); shape = Ref{Cint}(0); active = Ref{Float64}(0.0); undecided = Ref{Float64}(0.0)
+    check(ccall((:vcmi_gmmmap_convert_plan, libvcmi), Cint, (Ptr{Cvoid}, Ptr{Int64}, Ptr{Cint}, Ptr{Float64}, Ptr{Float64}),
+                g.h, issued, shape, active, undecided))
+    (Int(shape[]), active[], undecided[], issued[])
+end
 
 # fvconvert(g, x) -- src/gmmmap.jl:101-118
 function fvconvert(g::GMMMap, x::Vector{Float64})
