@@ -427,6 +427,9 @@ def bench_convert(args, world, rank, variant="synthetic"):
                      "frac_definition": "min(algorithmic flop, flop of the MFMAs the kernel issued) / kernel time / peak: work the kernel "
                                         "skips is not credited (algorithmic_frac would exceed 1) and tile padding is not credited "
                                         "either (the dense loop issues 344,064 flop per frame for 324,160 algorithmic)",
+                     "kernel_ms_definition": "HIP events around the whole vcmi_gmmmap_convert_dev call on its stream: the three grouping "
+                                             "kernels (~0.12 ms per 10^6 frames) and the MFMA kernel; profiles/r04_clock/ times the MFMA "
+                                             "kernel alone, so issued / that time is higher (0.68 against 0.62 for the headline)",
                      "flop_per_frame": convert_flops_per_frame(D, M),
                      "algorithmic_frac": alg_tflops / FP64_PEAK_TFLOPS,
                      "issued_mfma_frac": (iss_tflops / FP64_PEAK_TFLOPS) if iss_tflops else None,
