@@ -395,7 +395,7 @@ def bench_convert(args, world, rank, variant="synthetic"):
     # (profiling runs, --cpu-seconds 0, launch nothing but the warm-up and the timed steps: the PMC passes count there)
     _, shape, active_frac, undecided_frac = g.convert_plan()
     issued_mfma, nreg = None, None
-    if args.cpu_seconds > 0:
+    if args.cpu_seconds > 0 or world > 1:            # (N > 1 lines run with --cpu-seconds 0 too, but are no profiling runs)
         g.prune_stats(True)
         step()
         torch.cuda.synchronize()
@@ -720,7 +720,7 @@ def bench_estep_full(args, world, rank):
     wall, kernel_ms = timed_steps(step, args.steps, args.warmup, world)
     flop = 2 * M * Dj * (Dj + 1) + 2 * M * Dj
     alg_tflops = flop * N / (kernel_ms * 1e-3) / 1e12
-    issued = full_estep_issued_mfma(step, N, Dj, M) if args.cpu_seconds > 0 else None
+    issued = full_estep_issued_mfma(step, N, Dj, M) if (args.cpu_seconds > 0 or world > 1) else None
     iss_tflops = issued * MFMA_FLOP / (kernel_ms * 1e-3) / 1e12 if issued else None
     achieved = min(alg_tflops, iss_tflops) if iss_tflops else alg_tflops
     out = {"metric": "full-covariance GMM E-step frames/sec (Dj=%d, M=64)" % Dj, "value": world * N * args.steps / wall,
@@ -782,7 +782,7 @@ def bench_em_full(args, world, rank):
     wall, kernel_ms = timed_steps(step, args.steps, args.warmup, world)
     flop = 2 * M * Dj * (Dj + 1) + 2 * M * Dj
     alg_tflops = flop * N / (kernel_ms * 1e-3) / 1e12
-    issued = full_estep_issued_mfma(lambda: em.estep(Xd.t(), out=stats), N, Dj, M) if args.cpu_seconds > 0 else None
+    issued = full_estep_issued_mfma(lambda: em.estep(Xd.t(), out=stats), N, Dj, M) if (args.cpu_seconds > 0 or world > 1) else None
     iss_tflops = issued * MFMA_FLOP / (kernel_ms * 1e-3) / 1e12 if issued else None
     achieved = min(alg_tflops, iss_tflops) if iss_tflops else alg_tflops
     out = {"metric": "full-covariance GMM EM iteration frames/sec (Dj=%d, M=64)" % Dj, "value": world * N * args.steps / wall,
