@@ -278,14 +278,13 @@ gmmmap_mfma_kernel(const double *__restrict__ packed, int M, int D, const double
     const int m = (mfirst + mi < M) ? mfirst + mi : mfirst + mi - M;       // mixtures in rotated order (mfirst = 0: index order)
     const double *cur = smem + (NBUF == 2 ? par * BLK : 0);
     double2 *nxt = reinterpret_cast<double2 *>(smem + (NBUF == 2 ? (par ^ 1) * BLK : 0));
-    // prefetch block m+1 into registers (global -> VGPR), written to LDS after the MFMA work
-    // (unconditional: the last iteration re-reads its own block, which keeps `pre` in registers and the loop
-    // body free of exec-mask branches)
-    // How block m+1 gets into LDS.  A whole-block prefetch into registers issued here is sunk by the compiler down to the LDS
-    // stores at the end of the iteration (24 registers it does not have at 3 waves per SIMD): the full L2 latency then stands
-    // in front of every barrier.  STAGE_DMA (two buffers): global_load_lds_dwordx4 -- 16 bytes per lane straight into the other
-    // buffer, no registers; a wave instruction fills 1 KB; issued here, waited for (vmcnt) just before the barrier.  The
-    // target buffer was last read in the previous iteration, before that iteration's barrier.
+    // How block m+1 gets into LDS (unconditionally: the last iteration re-reads its own block, so the loop body has no
+    // exec-mask branch).  Rounds 1-3 requested the whole block into registers here and stored it to LDS after the MFMA work:
+    // the compiler sinks those loads down to the LDS stores (24 registers it does not have at 3 waves per SIMD), so the full
+    // L2 latency stood in front of every barrier.  STAGE_DMA (two buffers): global_load_lds_dwordx4 -- 16 bytes per lane
+    // straight into the other buffer, no registers; a wave instruction fills 1 KB; issued here, waited for (vmcnt) just
+    // before the barrier.  The target buffer was last read in the previous iteration, before that iteration's barrier.
+    // (A single buffer, NBUF = 1 -- blocks beyond 40 KB -- keeps the register path.)
 #ifndef VCMI_CONVERT_STAGE
 #define VCMI_CONVERT_STAGE 2
 #endif
