@@ -287,24 +287,45 @@ def gather_over_ranks(x, world):
 PER_RANK = {}
 
 
+CLOCK_WARM_MS = 100.0     # --clock-warm-ms
+CLOCK_WARM = {}           # what the last timed_steps() did about it (goes into the line)
+
+
 def timed_steps(step_fn, steps, warmup, world):
     """W untimed warmups, then exactly K steps between barrier+sync; also per-step HIP-event durations.
 
     The Python garbage collector is off inside the timed region (as `timeit` does): with torch imported a full collection
     pauses the interpreter for ~40 ms (measured on a busy host with tools/dtw_host_probe.py: the pause sat in the argument
     marshalling of one call, outside the library), which is the whole timed region of a 20 x 1.7 ms workload -- the GPU
-    runs dry while the host stands still."""
+    runs dry while the host stands still.  The collection and the event objects come BEFORE the warmup steps, so that
+    nothing but the contract's barrier + synchronize separates the warmup from the timed steps.
+
+    Clock warm-up (`--clock-warm-ms`, default 100; 0 = off): the MI355X raises its shader clock over the first ~30-40 ms of
+    back-to-back kernels and drops it again after a few tens of ms of idling (profiles/r04_convert_kernel_calls.csv: the
+    same launch takes 1.85 ms at the start of a burst and 1.52 ms from the 20th on; 1.55 -> 1.19 ms for the DTW fill), so
+    `--warmup 5` of a 1.7 ms step ends inside the ramp and times the power state, not the kernel.  Untimed steps of the SAME
+    workload are therefore enqueued for that many ms of GPU time ahead of the W warmup steps; how many is in the line
+    (`clock_warm`), and so are the first and last timed step (`step_ms_first_last`)."""
     import gc
 
     import torch
 
-    for _ in range(warmup):
-        step_fn()
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
     gc.collect()
     gc_was_on = gc.isenabled()
     gc.disable()
     try:
+        n_warm = 0
+        if CLOCK_WARM_MS > 0:
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            while time.perf_counter() - t < CLOCK_WARM_MS * 1e-3 and n_warm < 4000:
+                for _ in range(4):          # a synchronize between batches idles the GPU for microseconds: no clock step
+                    step_fn()
+                n_warm += 4
+                torch.cuda.synchronize()
+        for _ in range(warmup):
+            step_fn()
         barrier_sync(world)
         t0 = time.perf_counter()
         for a, b in evs:
@@ -316,7 +337,11 @@ def timed_steps(step_fn, steps, warmup, world):
     finally:
         if gc_was_on:
             gc.enable()
-    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
+    per_step = [a.elapsed_time(b) for a, b in evs]
+    kernel_ms = float(np.mean(per_step))
+    CLOCK_WARM.clear()
+    CLOCK_WARM.update({"ms": CLOCK_WARM_MS, "untimed_steps_before_the_warmup": n_warm,
+                       "step_ms_first_last": [round(per_step[0], 4), round(per_step[-1], 4)] if per_step else None})
     PER_RANK["wall_s"] = gather_over_ranks(t1 - t0, world)
     PER_RANK["kernel_ms"] = gather_over_ranks(kernel_ms, world)
     return max_over_ranks(t1 - t0, world), kernel_ms
@@ -386,6 +411,8 @@ def bench_convert(args, world, rank, variant="synthetic"):
         vc.fvconvert(g, Xd.t(), out=Yd.t())
 
     wall, kernel_ms = timed_steps(step, args.steps, args.warmup, world)
+
+    clock_warm = dict(CLOCK_WARM)
     frames_per_s = world * T * args.steps / wall
     flops = convert_flops_per_frame(D, M) * T
     tiles = -(-T // 16)
@@ -412,7 +439,7 @@ def bench_convert(args, world, rank, variant="synthetic"):
         "unit": "frames/s",
         "n_gpus": world,
         "steps": args.steps,
-        "warmup": args.warmup,
+        "warmup": args.warmup, "clock_warm": clock_warm,
         "ms_per_step": wall / args.steps * 1e3,
         "higher_is_better": True,
         "scaling": "weak",
@@ -577,6 +604,8 @@ def bench_estep(args, world, rank):
         vc.dist.allreduce_sum_(out_t)
 
     wall, step_ms = timed_steps(step, args.steps, args.warmup, world)
+
+    clock_warm = dict(CLOCK_WARM)
     # the same K steps again without the collective (kernels only), and K collectives alone: `kernel_ms` prices the E-step
     # kernels, `allreduce_ms` the RCCL all-reduce of the packed statistics (zero work with one rank and no process group)
     per_rank_step = dict(PER_RANK)
@@ -623,7 +652,7 @@ def bench_estep(args, world, rank):
     iss_tflops = issued_mfma * MFMA_FLOP / (kernel_ms * 1e-3) / 1e12 if issued_mfma else None
     achieved = min(alg_tflops, iss_tflops) if iss_tflops else alg_tflops
     out = {"metric": "diag-GMM E-step frames/sec (Dj=%d, M=%d)" % (Dj, M), "value": fps, "unit": "frames/s", "n_gpus": world,
-           "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True,
+           "steps": args.steps, "warmup": args.warmup, "clock_warm": clock_warm, "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True,
            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
            "config": {"workload": "diag E-step (BASELINE configs[2])" if (Dj == 80 and M == 128) else
                       f"diag E-step, Dj={Dj}, M={M} ({'MFMA kernel' if mfma_path else 'generic kernels'}; not a BASELINE config)",
@@ -718,13 +747,15 @@ def bench_estep_full(args, world, rank):
         vc.dist.allreduce_sum_(out_t)
 
     wall, kernel_ms = timed_steps(step, args.steps, args.warmup, world)
+
+    clock_warm = dict(CLOCK_WARM)
     flop = 2 * M * Dj * (Dj + 1) + 2 * M * Dj
     alg_tflops = flop * N / (kernel_ms * 1e-3) / 1e12
     issued = full_estep_issued_mfma(step, N, Dj, M) if (args.cpu_seconds > 0 or world > 1) else None
     iss_tflops = issued * MFMA_FLOP / (kernel_ms * 1e-3) / 1e12 if issued else None
     achieved = min(alg_tflops, iss_tflops) if iss_tflops else alg_tflops
     out = {"metric": "full-covariance GMM E-step frames/sec (Dj=%d, M=64)" % Dj, "value": world * N * args.steps / wall,
-           "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+           "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "clock_warm": clock_warm,
            "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "f64", "data": "synthetic",
            "config": {"workload": "full-covariance E-step (SURVEY 8f rank 1; bin/train_gmm.jl:84-103)", "Dj": Dj, "M": M,
@@ -780,13 +811,15 @@ def bench_em_full(args, world, rank):
         hist.append(em.mstep(stats))
 
     wall, kernel_ms = timed_steps(step, args.steps, args.warmup, world)
+
+    clock_warm = dict(CLOCK_WARM)
     flop = 2 * M * Dj * (Dj + 1) + 2 * M * Dj
     alg_tflops = flop * N / (kernel_ms * 1e-3) / 1e12
     issued = full_estep_issued_mfma(lambda: em.estep(Xd.t(), out=stats), N, Dj, M) if (args.cpu_seconds > 0 or world > 1) else None
     iss_tflops = issued * MFMA_FLOP / (kernel_ms * 1e-3) / 1e12 if issued else None
     achieved = min(alg_tflops, iss_tflops) if iss_tflops else alg_tflops
     out = {"metric": "full-covariance GMM EM iteration frames/sec (Dj=%d, M=64)" % Dj, "value": world * N * args.steps / wall,
-           "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+           "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "clock_warm": clock_warm,
            "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "f64", "data": "synthetic",
            "config": {"workload": "EM iteration, full covariance (SURVEY 8f rank 1; bin/train_gmm.jl:84-103)", "Dj": Dj, "M": M,
@@ -854,11 +887,13 @@ def bench_dtw(args, world, rank):
                                                    D, 0, 2, pd.data_ptr(), _lib.iptr(poff), torch.cuda.current_stream().cuda_stream))
 
     wall, kernel_ms = timed_steps(step, args.steps, args.warmup, world)
+
+    clock_warm = dict(CLOCK_WARM)
     cells = float(np.sum(S * T))
     flops = cells * (3 * D + 10)
     achieved = flops / (kernel_ms * 1e-3) / 1e12
     out = {"metric": "DTW aligned pairs/sec (~500x500 frames, D=%d)" % D, "value": world * n * args.steps / wall, "unit": "pairs/s",
-           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3,
+           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "clock_warm": clock_warm, "ms_per_step": wall / args.steps * 1e3,
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
            "config": {"workload": "DTW fit!+backward, path-only (BASELINE configs[3])" if D == 40 else
                       f"DTW fit!+backward, path-only, D={D}" + (" (order-40 mel-cepstra with c0: bin/mcep.jl:12, src/align.jl:45)" if D == 41 else ""),
@@ -953,11 +988,13 @@ def bench_traj(args, world, rank, gv=False):
                                                             _lib.iptr(yoff), torch.cuda.current_stream().cuda_stream))
 
     wall, kernel_ms = timed_steps(step, args.steps, args.warmup, world)
+
+    clock_warm = dict(CLOCK_WARM)
     flops_per_utt = 2.0e9 + (epochs * T * 2.0 * (2 * D) ** 2 if gv else 0.0)
     achieved = flops_per_utt * n / (kernel_ms * 1e-3) / 1e12
     out = {"metric": ("trajectory+GV-converted" if gv else "trajectory-converted") + " frames/sec (static D=40, M=64, T=2000)",
            "value": world * n * T * args.steps / wall,
-           "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+           "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "clock_warm": clock_warm,
            "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "f64", "data": "synthetic",
            "config": {"workload": ("TrajectoryGVGMMMap fvconvert, 100 epochs (SURVEY 8f rank 2)" if gv else
@@ -1033,7 +1070,7 @@ def bench_selftest(args, world, rank):
 
 def summarize(out):
     """What the `workloads` table keeps of a workload's line."""
-    keep = ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "config", "data", "roofline", "cpu_baseline", "collective",
+    keep = ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "clock_warm", "config", "data", "roofline", "cpu_baseline", "collective",
             "parity_max_rel_err_vs_oracle", "parity_bit_exact_vs_oracle", "speedup_vs_cpu_baseline", "allreduce_check")
     d = {k: out[k] for k in keep if k in out}
     d["kernel_ms"] = out.get("roofline", {}).get("kernel_ms")
@@ -1123,9 +1160,14 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU time budget of the cpu_baseline sample")
     ap.add_argument("--debug-force", type=int, default=0, help="A/B experiments: bit mask for the library's vcmi_debug_force test hook "
                     "(csrc/vcmi_common.hpp kDbg*: alternative launch strategies); the line is then marked `debug_force`")
+    ap.add_argument("--clock-warm-ms", type=float, default=100.0,
+                    help="ms of untimed steps of the same workload enqueued ahead of the W warmup steps so that the timed steps run "
+                         "at the steady shader clock (see timed_steps); 0 = only the W warmup steps")
     ap.add_argument("--verify-allreduce", action="store_true",
                     help="estep: rank 0 recomputes the statistics of every rank's frames in one process and compares")
     args = ap.parse_args()
+    global CLOCK_WARM_MS
+    CLOCK_WARM_MS = max(args.clock_warm_ms, 0.0)
 
     if args.gpus < 1:
         ap.error("--gpus must be >= 1")
