@@ -317,13 +317,18 @@ def timed_steps(step_fn, steps, warmup, world):
     try:
         n_warm = 0
         if CLOCK_WARM_MS > 0:
+            # the same number of steps on every rank (a step may hold a collective): from the slowest rank's step time
+            step_fn()
             torch.cuda.synchronize()
             t = time.perf_counter()
-            while time.perf_counter() - t < CLOCK_WARM_MS * 1e-3 and n_warm < 4000:
-                for _ in range(4):          # a synchronize between batches idles the GPU for microseconds: no clock step
-                    step_fn()
-                n_warm += 4
-                torch.cuda.synchronize()
+            step_fn()
+            step_fn()
+            torch.cuda.synchronize()
+            one = max_over_ranks((time.perf_counter() - t) / 2.0, world)
+            n_warm = int(min(max(CLOCK_WARM_MS * 1e-3 / max(one, 1e-6), 1.0), 4000.0))
+            for _ in range(n_warm):
+                step_fn()
+            n_warm += 3
         for _ in range(warmup):
             step_fn()
         barrier_sync(world)
