@@ -351,7 +351,16 @@ def test_loop_shapes_agree_and_the_model_picks_one(vc, fixture_model, which):
     issued, _, _, _ = g.convert_plan()
     tiles = -(-T // 16)
     assert g.prune_stats(False) == tiles * M
-    assert issued == 2 * 42 * M * 4 * (-(-T // 128))     # 42 MFMAs per (tile, mixture) at D = 40, two tiles per wave, four waves per workgroup
+    assert issued == 42 * M * 4 * (-(-T // 64))     # 42 MFMAs per (tile, mixture) at D = 40; T <= 32768: one tile per wave, four waves per workgroup
+    _lib.debug_force(_lib.DBG_CONVERT_WIDE_TILES)
+    try:
+        g.prune_stats(True)
+        Yw = vc.fvconvert(g, Xd.t()).t().clone()
+        assert g.convert_plan()[0] == 2 * 42 * M * 4 * (-(-T // 128))     # the throughput shape: two tiles per wave
+        g.prune_stats(False)
+    finally:
+        _lib.debug_force(0)
+    assert float((torch.linalg.norm(Yw - Yd, dim=1) / torch.linalg.norm(Yd, dim=1)).max()) < 1e-13
     g.set_prune(46.0)
     ref = co.GMMMap(w, mu, sig).fvconvert(X[:400])
     for force in (_lib.DBG_CONVERT_SHAPE_BROAD, _lib.DBG_CONVERT_SHAPE_PEAKED, 0):
@@ -368,3 +377,36 @@ def test_loop_shapes_agree_and_the_model_picks_one(vc, fixture_model, which):
         err = float((torch.linalg.norm(Y - Yd, dim=1) / torch.linalg.norm(Yd, dim=1)).max())
         assert err < 1e-13, (force, err)
         assert frame_relerr(Y[:400].cpu().numpy().T, ref.T) < TOL
+
+
+@pytest.mark.parametrize("T", [1, 17, 64, 65, 1000, 2000, 8191, 30000])
+def test_utterance_sized_calls_one_tile_per_wave(vc, T):
+    """Calls of up to 32768 frames run one frame tile per wave (64-frame workgroups: twice as many, each with half the
+    loop -- an utterance does not fill the chip either way); DBG_CONVERT_WIDE_TILES forces the 128-frame workgroups of the
+    throughput path.  Same y to rounding (the workgroups start their mixture loops at different mixtures), the oracle's to
+    TOL, in all three loop shapes, through device and host pointers (the host call hands the kernel its pinned slots)."""
+    import torch
+    from oracle import c_oracle as co, np_oracle as npo
+    from voiceconversion_jl_amd import _lib
+    w, mu, sig = npo.synth_model(1002, 80, 64)
+    X = npo.sample_frames(11, w, mu, sig, T, 0, 40)
+    Xd = torch.from_numpy(X).cuda()
+    g = vc.GMMMap(*julia_model(w, mu, sig))
+    ref = co.GMMMap(w, mu, sig).fvconvert(X[:300])
+    for prune in (46.0, float("inf")):
+        g.set_prune(prune)
+        for shape in (0, _lib.DBG_CONVERT_SHAPE_BROAD, _lib.DBG_CONVERT_SHAPE_PEAKED):
+            got = []
+            for wide in (0, _lib.DBG_CONVERT_WIDE_TILES):
+                _lib.debug_force(shape | wide)
+                try:
+                    got.append(vc.fvconvert(g, Xd.t()).t().clone())
+                finally:
+                    _lib.debug_force(0)
+            err = float((torch.linalg.norm(got[0] - got[1], dim=1) / torch.linalg.norm(got[1], dim=1)).max())
+            assert err < 1e-13, (prune, shape, err)
+            assert frame_relerr(got[0][:300].cpu().numpy().T, ref.T) < TOL
+    g.set_prune(46.0)
+    Yh = vc.fvconvert(g, np.asfortranarray(X.T))                # host pointers: (D,T) Julia image
+    assert frame_relerr(Yh[:, :300], ref.T) < TOL
+    assert np.array_equal(Yh, got[0].cpu().numpy().T) or frame_relerr(Yh, got[0].cpu().numpy().T) < 1e-13

@@ -173,6 +173,7 @@ DBG_CONVERT_SHAPE_BROAD, DBG_CONVERT_SHAPE_PEAKED = 4096, 8192
 DBG_DTW_NO_SEGMENTS, DBG_DTW_GRID_ORDER = 256, 512
 DBG_DTW_TWO_SEGMENTS, DBG_DTW_WHOLE_FIRST = 16384, 32768
 DBG_ESTEP_FULL_NO_LISTS = 65536
+DBG_CONVERT_WIDE_TILES = 131072
 
 
 def debug_force(flags):

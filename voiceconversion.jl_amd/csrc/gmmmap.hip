@@ -1355,6 +1355,13 @@ static int launch_mfma(const vcmi_gmmmap *g, const double *dX, int64_t ldx, int6
   return VCMI_OK;
 }
 
+// Calls of up to this many frames do not fill the chip with 128-frame workgroups (2000 frames: 16 of 256 CUs, each walking
+// all the mixtures for two frame tiles per wave): they run ONE frame tile per wave -- twice the workgroups, half the loop
+// each.  Device-resident call of 2000 frames, D = 40, M = 64: 224 -> 127 us (the reference's 32-mixture model: 118 -> 79;
+// one frame: 129 -> 83).  Grouping such calls (three more launches) does not pay: tools/small_T_sweep.py.
+static constexpr int64_t kSmallCallFrames = 32768;
+static constexpr int64_t kSortMinFrames = 8192;
+
 #ifndef VCMI_CONVERT_FT
 #define VCMI_CONVERT_FT 2          // frame tiles per wave and waves per workgroup of the D <= 48 convert kernels (A/B builds)
 #endif
@@ -1364,6 +1371,15 @@ static int launch_mfma(const vcmi_gmmmap *g, const double *dX, int64_t ldx, int6
 template <int MODE, int PRUNE = 2>
 static int dispatch_mfma(const vcmi_gmmmap *g, const double *dX, int64_t ldx, int64_t T, double *dY, int64_t ldy,
                          hipStream_t st, const int *perm = nullptr, const int *gkey = nullptr) {
+  if (MODE == 0 && g->DP <= 48 && T <= kSmallCallFrames && !debug_flag(kDbgConvertWideTiles)) {     // one frame tile per wave: twice the workgroups, half the loop each
+    switch (g->DP) {
+#define VCMI_CASE(DPV) \
+  case DPV: return launch_mfma<DPV, MODE, 1, 4, PRUNE>(g, dX, ldx, T, dY, ldy, st, perm, gkey);
+      VCMI_CASE(16) VCMI_CASE(20) VCMI_CASE(24) VCMI_CASE(28) VCMI_CASE(32) VCMI_CASE(36) VCMI_CASE(40) VCMI_CASE(44) VCMI_CASE(48)
+#undef VCMI_CASE
+      default: break;
+    }
+  }
   switch (g->DP) {
 #define VCMI_CASE(DPV) \
   case DPV: return launch_mfma<DPV, MODE, ((DPV) <= 48 ? VCMI_CONVERT_FT : 1), ((DPV) == 40 && MODE == 0 ? VCMI_CONVERT_WAVES : 4), PRUNE>(g, dX, ldx, T, dY, ldy, st, perm, gkey);
@@ -1426,7 +1442,7 @@ int gmmmap_convert_device(vcmi_gmmmap *g, const double *dX, int64_t ldx, int64_t
     // few thousand frames on; the prune = +inf (dense) setting has nothing to gain from it
     const int MT = (g->M + 15) / 16;
     const size_t gshmem = (size_t)MT * (std::min(g->DP / 4, kGroupKeyDims / 4) + 1) * 64 * sizeof(double) + (size_t)g->M * sizeof(int);
-    if (T >= 8192 && T < ((int64_t)1 << 31) && g->M >= 4 && g->gfrag.p && gshmem <= 64 * 1024 && g->prune < 1e300 &&
+    if (T >= kSortMinFrames && T < ((int64_t)1 << 31) && g->M >= 4 && g->gfrag.p && gshmem <= 64 * 1024 && g->prune < 1e300 &&
         !debug_flag(kDbgConvertNoGrouping)) {
       const int64_t nchunks = (T + kGroupChunk - 1) / kGroupChunk;
       VCMI_TRY(g->grp.reserve((size_t)2 * T + (size_t)(nchunks + 1) * g->M));
@@ -2246,7 +2262,8 @@ extern "C" int vcmi_vc_frames(vcmi_gmmmap *g, const double *fm, int64_t T, doubl
     return staged_pipeline(fm + lo * ld, row, row, out + lo * ld, row, row, hi - lo, kMinChunkFrames,
                            [&](const void *dIn, void *dOut, int64_t, int64_t n, hipStream_t st) -> int {
                              // the copy keeps row 1 (src/common.jl:23); the kernel then overwrites rows 2..D+1
-                             VCMI_HIP(hipMemcpyAsync(dOut, dIn, (size_t)n * row, hipMemcpyDeviceToDevice, st));
+                             // (hipMemcpyDefault: a small call hands the pinned slots themselves to this function)
+                             VCMI_HIP(hipMemcpyAsync(dOut, dIn, (size_t)n * row, hipMemcpyDefault, st));
                              return gmmmap_convert_device(r, (const double *)dIn + 1, ld, n, (double *)dOut + 1, ld, st);
                            });
   });

@@ -331,6 +331,7 @@ namespace {
 constexpr int K = 3;                                   // slots in flight
 constexpr size_t kXferChunk = (size_t)16 << 20;        // plain uploads / downloads
 constexpr size_t kPipeChunk = (size_t)32 << 20;        // pipeline chunks (bytes of the wider side)
+constexpr size_t kDirectBytes = (size_t)2 << 20;       // calls up to this many bytes (in + out): kernels on the pinned slots
 
 struct Ring {
   std::mutex mu;
@@ -554,6 +555,28 @@ int staged_pipeline(const void *hIn, size_t in_unit, size_t in_stride, void *hOu
   VCMI_TRY(current_ring(&r));
   std::lock_guard<std::mutex> lk(r->mu);
   VCMI_TRY(r->init());
+  // Small calls -- one frame, one utterance: what the reference's `vc` and a caller's own frame loop pass -- skip the
+  // ring: the three streams, their six event hand-overs and the two DMA transfers cost ~160 us before the first byte
+  // of a 1-frame call has moved.  The kernels read the pinned input slot and write the pinned output slot THEMSELVES
+  // (hipHostMalloc memory is mapped into the device's address space: loads and stores cross the link, once each, and x
+  // and y are touched exactly once by these kernels), on one stream with one synchronisation.  Up to kDirectBytes of
+  // input + output (VCMI_HOST_DIRECT_KB, read once; 0 = always the ring).
+  static const size_t direct_bytes = [] {
+    const char *e = getenv("VCMI_HOST_DIRECT_KB");
+    const long kb = e ? atol(e) : -1;
+    return kb >= 0 ? (size_t)kb << 10 : kDirectBytes;
+  }();
+  if ((size_t)units * (in_unit + out_unit) <= direct_bytes) {
+    VCMI_TRY(r->reserve(r->pin_in, r->pin_in_cap, (size_t)units * in_unit, true));
+    VCMI_TRY(r->reserve(r->pin_out, r->pin_out_cap, (size_t)units * out_unit, true));
+    host_copy_rows(r->pin_in[0], in_unit, hIn, in_stride, in_unit, units);
+    int rc = launch(r->pin_in[0], r->pin_out[0], 0, units, r->run);
+    const hipError_t e = hipStreamSynchronize(r->run);       // also on the error path: nothing stays in flight on the slots
+    if (rc != VCMI_OK) return rc;
+    if (e != hipSuccess) return fail(VCMI_ERR_HIP, "staged_pipeline (direct): %s", hipGetErrorString(e));
+    host_copy_rows(hOut, out_stride, r->pin_out[0], out_unit, out_unit, units);
+    return VCMI_OK;
+  }
   const size_t wide = std::max(in_unit, out_unit);
   static const size_t pipe_chunk = [] {          // A/B hook, read once: VCMI_HOST_CHUNK_MB (default: kPipeChunk)
     const char *e = getenv("VCMI_HOST_CHUNK_MB");
