@@ -100,11 +100,11 @@ estep_stats_kernel(const double *__restrict__ X, int64_t n0, int64_t nfr, int Dj
   }
 }
 
-// stats[e] += sum over the partial rows, in a FIXED order (deterministic): four threads per element each add up every
+// stats[e] (+)= sum over the partial rows (accumulate = 0: stats need no memset before), in a FIXED order (deterministic): four threads per element each add up every
 // fourth row in increasing order, then ((p0 + p1) + (p2 + p3)).  (One thread per element walking all rows one after the
 // other left two thirds of the CUs idle and took 64 us for the 256 rows of the benchmark E-step -- 4 % of the step.)
 __global__ void __launch_bounds__(256)
-estep_reduce_kernel(const double *__restrict__ part, int nrows, int64_t plen, double *__restrict__ stats) {
+estep_reduce_kernel(const double *__restrict__ part, int nrows, int64_t plen, double *__restrict__ stats, int accumulate) {
   __shared__ double psum[4][64];
   const int el = threadIdx.x & 63, q = threadIdx.x >> 6;
   const int64_t e = (int64_t)blockIdx.x * 64 + el;
@@ -121,10 +121,10 @@ estep_reduce_kernel(const double *__restrict__ part, int nrows, int64_t plen, do
   }
   psum[q][el] = s;
   __syncthreads();
-  if (q == 0 && e < plen) stats[e] += (psum[0][el] + psum[1][el]) + (psum[2][el] + psum[3][el]);
+  if (q == 0 && e < plen) stats[e] = (accumulate ? stats[e] : 0.0) + ((psum[0][el] + psum[1][el]) + (psum[2][el] + psum[3][el]));
 }
-static inline void estep_reduce_launch(const double *part, int nrows, int64_t plen, double *stats, hipStream_t st) {
-  hipLaunchKernelGGL(estep_reduce_kernel, dim3((unsigned)((plen + 63) / 64)), dim3(256), 0, st, part, nrows, plen, stats);
+static inline void estep_reduce_launch(const double *part, int nrows, int64_t plen, double *stats, hipStream_t st, int accumulate = 1) {
+  hipLaunchKernelGGL(estep_reduce_kernel, dim3((unsigned)((plen + 63) / 64)), dim3(256), 0, st, part, nrows, plen, stats, accumulate);
 }
 
 // More than 128 mixtures (groups of 128, one PHASE 3 launch each): the responsibilities G_g[f][.] are normalised within
@@ -723,7 +723,9 @@ static int estep_mfma_launch(EstepScratch &sc, const double *dX, int64_t N, int 
   memcpy(h + M, mu, sizeof(double) * M * dj);
   memcpy(h + M + (size_t)M * dj, var, sizeof(double) * M * dj);
   // (a copy kernel reading the pinned slot, not hipMemcpyAsync: the copy engine's hand-over to the compute queue costs
-  // ~20 us of idle GPU per call, a kernel on the same queue a few)
+  // ~20 us of idle GPU per call, a kernel on the same queue a few.  Round 4 let the prep kernel read the pinned slot itself
+  // and write the device copy -- one launch less -- and lost 7 us per call: its threads read every parameter three or four
+  // times, across the link.)
   hipLaunchKernelGGL(estep_param_copy_kernel, dim3((unsigned)((nraw + 255) / 256)), dim3(256), 0, st, h, draw, nraw);
   VCMI_HIP(hipEventRecord(sc.stage.copied[b], st));
   hipLaunchKernelGGL(estep_prep_kernel<DJ>, dim3((8 * C::KS * 64 + 255) / 256), dim3(256), 0, st, draw, M, dj, sc.Wpack.p,
@@ -737,7 +739,7 @@ static int estep_mfma_launch(EstepScratch &sc, const double *dX, int64_t N, int 
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), C::LDS_BYTES, st, dX, N, M, sc.Wpack.p, sc.cinit.p, sc.part.p, plen, dmu,
                        sc.refiv.p, sc.refc.p, (double *)nullptr, dj, mtp, sc.mfma_count.p);
     VCMI_HIP(hipGetLastError());
-    estep_reduce_launch(sc.part.p, grid * wpt, plen, dstats, st);
+    estep_reduce_launch(sc.part.p, grid * wpt, plen, dstats, st, /*accumulate=*/0);     // (dstats was not zeroed)
     VCMI_HIP(hipGetLastError());
   } else {
     // two kernels per chunk of frames, the responsibilities (frames x 128 doubles) through HBM in between
@@ -756,7 +758,7 @@ static int estep_mfma_launch(EstepScratch &sc, const double *dX, int64_t N, int 
       hipLaunchKernelGGL(ks, dim3(g2), dim3(512), C::LDS_BYTES, st, dX + n0 * dj, nfr, M, sc.Wpack.p, sc.cinit.p, sc.part.p, plen,
                          dmu, sc.refiv.p, sc.refc.p, sc.G.p, dj, mtp, sc.mfma_count.p);
       VCMI_HIP(hipGetLastError());
-      estep_reduce_launch(sc.part.p, g2 * wpt, plen, dstats, st);
+      estep_reduce_launch(sc.part.p, g2 * wpt, plen, dstats, st, /*accumulate=*/n0 > 0);
       VCMI_HIP(hipGetLastError());
     }
   }
@@ -863,7 +865,9 @@ static int estep_device_run(const double *dX, int64_t N, int Dj, int M, const do
     for (int d = 0; d < Dj; ++d)
       if (!(var[d + (size_t)Dj * m] > 0.0))
         return fail(VCMI_ERR_NOT_PD, "E-step: variance (%d,%d) is not positive", d + 1, m + 1);
-  VCMI_HIP(hipMemsetAsync(dstats, 0, plen * sizeof(double), st));
+  // (estep_mfma_launch's first reduction overwrites dstats: no memset -- two fill kernels -- in front of it)
+  const bool overwrites = N > 0 && M <= EstepCfg<80>::MMAX && Dj % 2 == 0 && Dj <= 160 && !debug_flag(kDbgEstepGeneric);
+  if (!overwrites) VCMI_HIP(hipMemsetAsync(dstats, 0, plen * sizeof(double), st));
   if (N == 0) return VCMI_OK;
 
   // MFMA instantiations for Dj = 32, 48, 64, 80 (one kernel) and 160 (two kernels); any even Dj up to 160 runs in the next

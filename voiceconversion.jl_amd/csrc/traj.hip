@@ -353,7 +353,7 @@ typedef double g_d4 __attribute__((ext_vector_type(4)));
 __global__ void __launch_bounds__(384)
 traj_g_mfma_kernel(const TrajUtt *__restrict__ utts, int n, int D2, int M, int KS, const double *__restrict__ Afrag,
                    const double *__restrict__ Qfrag, const double *__restrict__ bvec, const int64_t *__restrict__ mhat_all,
-                   int *__restrict__ perm_all, double *__restrict__ G_all) {
+                   int *__restrict__ perm_all, double *__restrict__ G_all, int split) {
   extern __shared__ double gsm2[];
   const int nthr = blockDim.x, NT = nthr >> 6;
   double *Xt = gsm2;                              // [4*KS][16] x of the tile's frames, k-major
@@ -364,7 +364,17 @@ traj_g_mfma_kernel(const TrajUtt *__restrict__ utts, int n, int D2, int M, int K
   __shared__ int ntiles_s;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lcol = lane & 15, lgrp = lane >> 4;
-  for (int u = blockIdx.x; u < n; u += gridDim.x) {
+  // `split` (a power of two) workgroups share an utterance: a tile takes ~6 us of dependent loads and barriers and an
+  // utterance has T / 16 and more of them -- with one workgroup per utterance and 256 utterances the kernel is a latency
+  // chain on every CU.  Member `part` takes the tiles part, part + split, ... of the utterance's grouped order; every member
+  // builds that order itself, so it has to be a function of the data: a STABLE counting sort (ranks by ballot / mbcnt per
+  // wave, waves and chunks of frames in order), not one by atomics.  (Splitting by MIXTURE instead -- whole groups per
+  // member, atomics allowed -- was measured first: a smooth trajectory stays in one or two mixtures, one member gets all the
+  // tiles.)  The member index is the HIGH part of blockIdx: the members of an utterance sit on different XCDs.
+  int *wcnt = start + M;                          // [NT][M] per-wave counts of the current chunk
+  const int nutt = (int)(gridDim.x / (unsigned)split);
+  const int part = (int)(blockIdx.x / (unsigned)nutt);
+  for (int u = (int)(blockIdx.x % (unsigned)nutt); u < n; u += nutt) {
     const TrajUtt U = utts[u];
     const int T = U.T;
     if (T == 0) continue;
@@ -372,7 +382,7 @@ traj_g_mfma_kernel(const TrajUtt *__restrict__ utts, int n, int D2, int M, int K
     double *G = G_all + U.frame0 * D2;
     // regions indexed by the utterance's position in the batch (frame0 grows with it): disjoint whatever the launch order
     int *perm = perm_all + U.frame0 + (int64_t)16 * M * U.idx;
-    // frames grouped by mixture; the order inside a group (atomics) is irrelevant, each frame is computed on its own
+    // frames grouped by mixture, in frame order inside a group
     for (int m = tid; m < M; m += nthr) cnt[m] = 0;
     __syncthreads();
     for (int t = tid; t < T; t += nthr) atomicAdd(&cnt[(int)mh[t] - 1], 1);
@@ -382,22 +392,47 @@ traj_g_mfma_kernel(const TrajUtt *__restrict__ utts, int n, int D2, int M, int K
       for (int m = 0; m < M; ++m) {
         start[m] = pos;
         pos += (cnt[m] + 15) / 16 * 16;
-        cnt[m] = 0;
+        cnt[m] = 0;                                     // from here on: frames of mixture m placed so far
       }
       ntiles_s = pos / 16;
     }
     __syncthreads();
     const int ntiles = ntiles_s;
-    for (int e = tid; e < ntiles * 16; e += nthr) perm[e] = -1;
-    __syncthreads();
-    for (int t = tid; t < T; t += nthr) {
-      const int m = (int)mh[t] - 1;
-      perm[start[m] + atomicAdd(&cnt[m], 1)] = t;
+    for (int e = tid; e < ntiles * 16; e += nthr)
+      if (((e >> 4) & (split - 1)) == part) perm[e] = -1;          // own tiles only
+    for (int c0 = 0; c0 < T; c0 += nthr) {
+      for (int e = tid; e < NT * M; e += nthr) wcnt[e] = 0;
+      __syncthreads();
+      const int t = c0 + tid;
+      const int m = t < T ? (int)mh[t] - 1 : -1;
+      int rank = 0;
+      unsigned long long rem = __builtin_amdgcn_ballot_w64(m >= 0);
+      while (rem) {                                     // one turn per distinct mixture among the wave's 64 frames
+        const int lead = __builtin_ctzll(rem);
+        const int k0 = __builtin_amdgcn_readlane(m, lead);
+        const unsigned long long mask = __builtin_amdgcn_ballot_w64(m == k0);
+        if (m == k0) rank = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
+        if (lane == lead) wcnt[wave * M + k0] = __builtin_popcountll(mask);
+        rem &= ~mask;
+      }
+      __syncthreads();
+      if (m >= 0) {
+        int off = cnt[m] + rank;
+        for (int w = 0; w < wave; ++w) off += wcnt[w * M + m];
+        const int slot = start[m] + off;
+        if (((slot >> 4) & (split - 1)) == part) perm[slot] = t;
+      }
+      __syncthreads();
+      for (int m2 = tid; m2 < M; m2 += nthr) {
+        int sum = 0;
+        for (int w = 0; w < NT; ++w) sum += wcnt[w * M + m2];
+        cnt[m2] += sum;
+      }
+      __syncthreads();
     }
-    __syncthreads();
     double afr[kGMaxKS], qfr[kGMaxKS];
     int mcur = -1;
-    for (int tile = 0; tile < ntiles; ++tile) {
+    for (int tile = part; tile < ntiles; tile += split) {
       if (tid < 16) tidx[tid] = perm[tile * 16 + tid];
       __syncthreads();
       for (int e = tid; e < 4 * KS * 16; e += nthr) {
@@ -1052,11 +1087,17 @@ static int traj_run(vcmi_traj *t, std::vector<TrajUtt> &utts, int64_t nframes, b
   if (g_mfma) {
     VCMI_TRY(t->gperm.reserve((size_t)nframes + (size_t)16 * t->M * n));
     const int nthr = 64 * t->NT;
-    const size_t shg = ((size_t)4 * t->KS * 16 + (size_t)4 * t->NT * 64) * sizeof(double) + 2 * (size_t)t->M * sizeof(int);
+    const size_t shg = ((size_t)4 * t->KS * 16 + (size_t)4 * t->NT * 64) * sizeof(double) + (2 + (size_t)t->NT) * (size_t)t->M * sizeof(int);
     VCMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(traj_g_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)shg));
-    hipLaunchKernelGGL(traj_g_mfma_kernel, dim3(std::min(n, 4 * cus)), dim3(nthr), shg, st, du, n, D2, t->M, t->KS, t->Afrag.p,
-                       t->Qfrag.p, t->bvec.p, t->mhat.p, t->gperm.p, t->gbuf.p);
+    // workgroups per utterance: only while the batch leaves CUs idle (one utterance, or the twenty 100-frame chunks of one:
+    // 328 -> ~70 us for 100 frames).  A batch that fills the chip gains nothing -- 256 x 2000 frames: 0.93 / 0.96 / 0.98 /
+    // 1.05 ms with 1 / 2 / 4 / 8 members: there the kernel is bound by the A / Q fragments every change of mixture reloads
+    // from L2 (102 KB each), not by the latency of a tile.
+    int split = 1;
+    while (split < 8 && (int64_t)n * 2 * split <= (int64_t)cus) split *= 2;
+    hipLaunchKernelGGL(traj_g_mfma_kernel, dim3((unsigned)std::min<int64_t>((int64_t)n * split, (int64_t)4 * cus / split * split)),
+                       dim3(nthr), shg, st, du, n, D2, t->M, t->KS, t->Afrag.p, t->Qfrag.p, t->bvec.p, t->mhat.p, t->gperm.p, t->gbuf.p, split);
     VCMI_HIP(hipGetLastError());
   }
   bool launched = false;
