@@ -305,7 +305,8 @@ def timed_steps(step_fn, steps, warmup, world):
     same launch takes 1.85 ms at the start of a burst and 1.52 ms from the 20th on; 1.55 -> 1.19 ms for the DTW fill), so
     `--warmup 5` of a 1.7 ms step ends inside the ramp and times the power state, not the kernel.  Untimed steps of the SAME
     workload are therefore enqueued for that many ms of GPU time ahead of the W warmup steps; how many is in the line
-    (`clock_warm`), and so are the first and last timed step (`step_ms_first_last`)."""
+    (`clock_warm`), and so are the first and last timed step (`step_ms_first_last`) and `cold_ms_per_step`: the same W + K
+    protocol run once BEFORE any of this, from the idle state (what a single cold call sequence costs)."""
     import gc
 
     import torch
@@ -316,7 +317,18 @@ def timed_steps(step_fn, steps, warmup, world):
     gc.disable()
     try:
         n_warm = 0
+        cold_ms = None
         if CLOCK_WARM_MS > 0:
+            # first the protocol to the letter, from the idle state the process is in: W warmups, K steps between
+            # barrier + synchronize -- reported beside the steady figure (`clock_warm.cold_ms_per_step`), never as `value`
+            for _ in range(warmup):
+                step_fn()
+            barrier_sync(world)
+            tc = time.perf_counter()
+            for _ in range(steps):
+                step_fn()
+            barrier_sync(world)
+            cold_ms = max_over_ranks(time.perf_counter() - tc, world) / max(steps, 1) * 1e3
             # the same number of steps on every rank (a step may hold a collective): from the slowest rank's step time
             step_fn()
             torch.cuda.synchronize()
@@ -346,6 +358,7 @@ def timed_steps(step_fn, steps, warmup, world):
     kernel_ms = float(np.mean(per_step))
     CLOCK_WARM.clear()
     CLOCK_WARM.update({"ms": CLOCK_WARM_MS, "untimed_steps_before_the_warmup": n_warm,
+                       "cold_ms_per_step": None if cold_ms is None else round(cold_ms, 4),
                        "step_ms_first_last": [round(per_step[0], 4), round(per_step[-1], 4)] if per_step else None})
     PER_RANK["wall_s"] = gather_over_ranks(t1 - t0, world)
     PER_RANK["kernel_ms"] = gather_over_ranks(kernel_ms, world)
@@ -1264,12 +1277,14 @@ def main():
         if par is None and "parity_bit_exact_vs_oracle" in d:
             par = "bit-exact" if d["parity_bit_exact_vs_oracle"] else "MISMATCH"
         r = d.get("roofline", {})
-        row = [round(d.get("ms_per_step", 0.0), 4), round(r.get("frac", 0.0), 4), par if isinstance(par, str) or par is None else float("%.2g" % par)]
+        row = [round(d.get("ms_per_step", 0.0), 4), round(r.get("frac", 0.0), 4), par if isinstance(par, str) or par is None else float("%.2g" % par),
+               (d.get("clock_warm") or {}).get("cold_ms_per_step")]
         if "dense" in r:
             row.append({"dense_ms": round(r["dense"]["kernel_ms"], 4), "dense_frac": round(r["dense"]["frac"], 4),
                         "regressions": round(r.get("regressions_evaluated_frac", 0.0), 4)})
         return row
-    out["summary"] = {"columns": ["ms_per_step", "roofline.frac (<= 1: issued or algorithmic work, whichever is less)", "parity vs oracle"],
+    out["summary"] = {"columns": ["ms_per_step", "roofline.frac (<= 1: issued or algorithmic work, whichever is less)", "parity vs oracle",
+                                  "ms_per_step from idle (W warmups + K steps to the letter, no clock warm-up)"],
                       **{name: _row(d) for name, d in table.items() if isinstance(d, dict) and "ms_per_step" in d}}
     if rank == 0:
         print(json.dumps(out), flush=True)
