@@ -1,8 +1,9 @@
 """tools/small_T_sweep.py -- device-resident fvconvert of utterance-sized inputs (D = 40, M = 64 and the fixture model):
-median time of one synchronised call per T.  Environment knobs of the library (read once per process) select the variant:
-VCMI_SMALL_CALL_FRAMES (one frame tile per wave up to that many frames), VCMI_GROUP_MIN_FRAMES (grouping from that many on).
+median time of one synchronised call per T, with the library's choice of launch shape (one frame tile per wave up to
+32768 frames) and with the throughput shape forced (DBG_CONVERT_WIDE_TILES).  The thresholds in csrc/gmmmap.hip
+(kSmallCallFrames, kSortMinFrames) come from this sweep, run with the two as environment knobs of a probe build.
 
-    gpurun -- 'for v in "0 8192" "16384 8192" "16384 512"; do set -- $v; python tools/small_T_sweep.py; done'
+    gpurun -- python tools/small_T_sweep.py
 """
 import json
 import os
@@ -34,14 +35,23 @@ def med(fn, n=200, warm=20):
 
 
 def main():
-    out = {"env": {k: os.environ.get(k) for k in ("VCMI_SMALL_CALL_FRAMES", "VCMI_GROUP_MIN_FRAMES")}}
+    from voiceconversion_jl_amd import _lib
+
+    out = {}
     for variant in ("synthetic", "fixture"):
         w, mu, sig = bench.convert_model(variant)
         g = vc.GMMMap(*bench.julia_model(w, mu, sig))
         for T in (1, 64, 256, 512, 1000, 2000, 4000, 8000, 16000, 32000):
             X = torch.from_numpy(sd.sample_frames(7, w, mu, sig, T, 0, 40)).cuda()
             Y = torch.empty_like(X)
-            out[f"{variant}_T{T}"] = med(lambda: vc.fvconvert(g, X.t(), out=Y.t()))
+            row = []
+            for force in (0, _lib.DBG_CONVERT_WIDE_TILES):
+                _lib.debug_force(force)
+                try:
+                    row.append(med(lambda: vc.fvconvert(g, X.t(), out=Y.t())))
+                finally:
+                    _lib.debug_force(0)
+            out[f"{variant}_T{T}"] = {"library_us": row[0], "wide_tiles_us": row[1]}
     print(json.dumps(out))
 
 
