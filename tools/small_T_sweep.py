@@ -12,6 +12,8 @@ import time
 
 import numpy as np
 
+os.environ.setdefault("VCMI_TEST_HOOKS", "1")       # vcmi_debug_force is inert without it
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 import torch  # noqa: E402
