@@ -174,3 +174,28 @@ def test_fixture_model_diagonal(vc, fixture_model):
     S0, S1, S2, ll = vc.estep_diag(X.T, w, mu.T, var.T)
     assert relerr(S0, r0) < TOL and relerr(S1, r1.T) < TOL and relerr(S2, r2.T) < TOL
     assert abs(ll - rl) < TOL * abs(rl)
+
+
+@pytest.mark.parametrize("Dj,M,N", [(80, 128, 5000), (160, 64, 3000), (48, 16, 700), (79, 20, 900), (80, 200, 1500), (80, 128, 0)])
+def test_output_buffer_is_overwritten_not_accumulated(vc, Dj, M, N):
+    """The packed statistics are an OUTPUT: whatever the buffer held before the call (here NaN) is gone afterwards, in every
+    dispatch (one kernel, two kernels at Dj = 160, odd Dj, groups of 128 mixtures, no frames).  The single-kernel path has
+    no memset in front of it any more -- its first reduction overwrites."""
+    import torch
+    from oracle import np_oracle as npo
+    w, mu, _ = npo.synth_model(900 + Dj + M, Dj, M)
+    rg = np.random.default_rng(Dj * M)
+    var = np.exp(rg.uniform(np.log(1e-3), 0.0, (M, Dj)))
+    comp = rg.choice(M, size=max(N, 1), p=w)
+    X = (mu[comp] + rg.standard_normal((max(N, 1), Dj)) * np.sqrt(var[comp]))[:N]
+    Xd = torch.from_numpy(np.ascontiguousarray(X)).cuda().reshape(N, Dj)
+    out = torch.full((vc.stats_len(Dj, M),), float("nan"), dtype=torch.float64, device="cuda")
+    got = vc.estep_diag_dev(Xd.t(), w, mu.T, var.T, out=out).clone()
+    fresh = vc.estep_diag_dev(Xd.t(), w, mu.T, var.T)
+    assert bool(torch.isfinite(got).all())
+    assert torch.equal(got, fresh)
+    out.fill_(1e300)
+    again = vc.estep_diag_dev(Xd.t(), w, mu.T, var.T, out=out)
+    assert torch.equal(again, fresh)
+    if N == 0:
+        assert float(got.abs().max()) == 0.0
