@@ -27,6 +27,14 @@ def fixture_model():
     return z["weights"], z["means"], z["covars"]
 
 
+@pytest.fixture(scope="session")
+def joint_model():
+    """The reference's other trained model, test/models/clb_and_slt_gmm32_order40.jld (the joint, non-differential model
+    test/vc.jl:40-51 converts with; M=32, Dj=80), extracted by oracle/gen_golden_joint.py.  Same array conventions."""
+    z = load_golden("model_clb_and_slt_gmm32_order40.npz")
+    return z["weights"], z["means"], z["covars"]
+
+
 def julia_model(w, mu, sig):
     """numpy [m][d] / [m][col][row] buffers -> Julia-shaped (Dj,M) / (Dj,Dj,M) Fortran arrays (no data change)."""
     M, Dj = mu.shape

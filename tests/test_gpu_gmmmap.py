@@ -40,6 +40,28 @@ def test_fixture_model_matches_golden(vc, fixture_model, kernel, swap):
     assert y0.shape == (40,) and relerr(y0, z[f"Y_{k}"][0]) < TOL
 
 
+@pytest.mark.parametrize("kernel", [1, 2])
+@pytest.mark.parametrize("swap", [False, True])
+def test_joint_model_matches_golden(vc, joint_model, kernel, swap):
+    """The reference's second trained model, clb_and_slt_gmm32_order40 (test/vc.jl:40-51): conversion, posteriors, arg-max
+    and the vc() frame loop against the committed vectors (oracle/gen_golden_joint.py)."""
+    w, mu, sig = julia_model(*joint_model)
+    z = load_golden("gmmmap_joint_model.npz")
+    k = "swap" if swap else "fwd"
+    g = vc.GMMMap(w, mu, sig, swap=swap)
+    g.set_kernel(kernel)
+    assert vc.dim(g) == 40 and vc.ncomponents(g) == 32
+    X = z[f"X_{k}"].T
+    Y = vc.fvconvert(g, X)
+    assert frame_relerr(Y, z[f"Y_{k}"].T) < TOL
+    assert np.max(np.abs(vc.predict_proba(g.px, X) - z[f"P_{k}"].T)) < 1e-9
+    assert np.array_equal(vc.predict(g.px, X), z[f"idx_{k}"])
+    if not swap:
+        out = vc.vc(g, z["vc_fm"].T)
+        assert np.array_equal(out[0], z["vc_fm"][:, 0])                  # src/common.jl:23
+        assert frame_relerr(out[1:], z["vc_out"][:, 1:].T) < TOL
+
+
 def test_vc_keeps_power_row(vc, fixture_model):
     w, mu, sig = julia_model(*fixture_model)
     z = load_golden("gmmmap_fixture_model.npz")

@@ -75,6 +75,22 @@ def test_gmmmap_fixture_model(fixture_model):
     assert relerr(gn.fvconvert(z["X_fwd"][:5]), z["Y_fwd"][:5]) < 1e-12
 
 
+def test_gmmmap_joint_model(joint_model):
+    """The reference's second trained model (test/vc.jl:40-51): both restatements against the committed vectors."""
+    w, mu, sig = joint_model
+    z = load_golden("gmmmap_joint_model.npz")
+    for swap, k in ((False, "fwd"), (True, "swap")):
+        g = co.GMMMap(w, mu, sig, swap=swap)
+        assert g.D == 40 and g.M == 32
+        assert relerr(g.fvconvert(z[f"X_{k}"]), z[f"Y_{k}"]) < 1e-9
+        assert np.max(np.abs(g.predict_proba(z[f"X_{k}"]) - z[f"P_{k}"])) < 1e-9
+        assert np.array_equal(g.predict(z[f"X_{k}"]), z[f"idx_{k}"])
+        gn = npo.GMMMap(w, mu, sig, swap=swap)
+        assert relerr(gn.fvconvert(z[f"X_{k}"][:5]), z[f"Y_{k}"][:5]) < 1e-12
+    out = co.GMMMap(w, mu, sig).vc(z["vc_fm"])
+    assert np.array_equal(out[:, 0], z["vc_fm"][:, 0]) and relerr(out[:, 1:], z["vc_out"][:, 1:]) < 1e-9
+
+
 def test_gmmmap_config1():
     z = load_golden("gmmmap_cfg1_D24_M8_T1000.npz")
     g = co.GMMMap(z["weights"], z["means"], z["covars"])

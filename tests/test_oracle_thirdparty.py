@@ -17,6 +17,15 @@ def test_fixture_model_conversion_vs_sklearn_scipy_lapack(fixture_model, k, swap
     assert out["fvconvert_vs_numpy_solve"] < 1e-9
 
 
+@pytest.mark.parametrize("k,swap", [("fwd", False), ("swap", True)])
+def test_joint_model_conversion_vs_sklearn_scipy_lapack(joint_model, k, swap):
+    """The reference's second trained model (test/vc.jl:40-51), same third-party pins."""
+    w, mu, sig = joint_model
+    z = load_golden("gmmmap_joint_model.npz")
+    out = cc.check_conversion(w, mu, sig, z[f"X_{k}"], z[f"Y_{k}"], z[f"P_{k}"], z[f"idx_{k}"], swap=swap, tol=1e-9)
+    assert out["fvconvert_vs_numpy_solve"] < 1e-9
+
+
 def test_config1_conversion_vs_third_party():
     z = load_golden("gmmmap_cfg1_D24_M8_T1000.npz")
     from oracle import np_oracle as npo
