@@ -378,6 +378,10 @@ CONVERT_VARIANTS = {
     # the reference's own trained model (test/models/clb_to_slt_gmm32_order40_diff.jld -> tests/golden/model_*.npz): M = 32
     "fixture": {"label": "GMMMap fvconvert, the reference's trained model clb_to_slt_gmm32_order40_diff (M = 32; not a BASELINE config)",
                 "M": 32, "seed": 1002},
+    # ... and its other one (test/models/clb_and_slt_gmm32_order40.jld, the joint model test/vc.jl:40-51 converts with); `--workload
+    # convert_joint` only, not part of the default run
+    "joint": {"label": "GMMMap fvconvert, the reference's trained model clb_and_slt_gmm32_order40 (M = 32; not a BASELINE config)",
+              "M": 32, "seed": 1002},
 }
 
 
@@ -385,8 +389,9 @@ def convert_model(variant):
     import synthdata as npo
 
     v = CONVERT_VARIANTS[variant]
-    if variant == "fixture":
-        z = np.load(os.path.join(ROOT, "tests", "golden", "model_clb_to_slt_gmm32_order40_diff.npz"))
+    if variant in ("fixture", "joint"):
+        z = np.load(os.path.join(ROOT, "tests", "golden", "model_clb_to_slt_gmm32_order40_diff.npz" if variant == "fixture" else
+                                 "model_clb_and_slt_gmm32_order40.npz"))
         return z["weights"], z["means"], z["covars"]
     return npo.synth_model(v["seed"], 80, v["M"], lam_lo=v["lam_lo"])
 
@@ -463,7 +468,7 @@ def bench_convert(args, world, rank, variant="synthetic"):
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": "f64",
-        "data": "synthetic" if variant != "fixture" else "synthetic frames drawn from the reference's trained model",
+        "data": "synthetic" if variant not in ("fixture", "joint") else "synthetic frames drawn from the reference's trained model",
         "config": {"workload": CONVERT_VARIANTS[variant]["label"], "D": D, "M": M, "frames_per_gpu": T,
                    "sharding": f"frames x{world}, no collective"},
         "roofline": {"bound": "mfma", "kernel": "gmmmap_mfma_kernel<40,2,4,0,2,%d>" % shape, "achieved": achieved,
@@ -1156,7 +1161,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="all",
-                    choices=["all", "convert", "convert_fixture", "convert_broad", "estep", "estep_full", "em_full", "dtw", "traj", "trajgv",
+                    choices=["all", "convert", "convert_fixture", "convert_joint", "convert_broad", "estep", "estep_full", "em_full", "dtw", "traj", "trajgv",
                              "selftest"],
                     help="all (default): the headline line of configs[1] plus a `workloads` table over configs[1..4]")
     ap.add_argument("--dim", type=int, default=40, help="dtw: feature dimension (40 = BASELINE; 41 = order-40 mel-cepstra with c0)")
@@ -1213,6 +1218,7 @@ def main():
            "dtw": bench_dtw, "traj": bench_traj, "trajgv": lambda a, w, r: bench_traj(a, w, r, gv=True),
            "convert_fixture": lambda a, w, r: bench_convert(a, w, r, variant="fixture"),
            "convert_broad": lambda a, w, r: bench_convert(a, w, r, variant="broad"),
+           "convert_joint": lambda a, w, r: bench_convert(a, w, r, variant="joint"),
            "selftest": bench_selftest}
     if args.workload == "all":
         import copy
