@@ -49,7 +49,7 @@ def estep_flops_per_frame(Dj, M):
     return 8 * Dj * M + 25 * M
 
 
-PMC_DIR = "r04_pmc"
+PMC_DIR = "r05_pmc"
 SOURCE_FILES = ("*.hip", "*.hpp", "*.inc", "*.cpp", "Makefile")
 
 
@@ -96,10 +96,23 @@ def traffic_from_table(tr, kernel_prefix, fetch_factor=VECTOR_FETCH_FACTOR):
     return total
 
 
+def table_problems(tr, kernel_prefixes):
+    """Why a PMC table must not be quoted: problems its collector recorded, or a kernel of interest whose launch count is not
+    a whole number of launches per bench step (round 4: ~60 clock-warm launches were divided by 3 steps)."""
+    why = list((tr.get("_meta") or {}).get("problems") or [])
+    for k, v in tr.items():
+        if k.startswith("_") or not any(p in k for p in kernel_prefixes):
+            continue
+        lps = v.get("launches_per_step")
+        if lps is not None and abs(lps - round(lps)) > 1e-9:
+            why.append("%s: %.3f launches per step" % (k[:60], lps))
+    return why
+
+
 def pmc_traffic(fname, kernel_prefixes, fetch_factor=VECTOR_FETCH_FACTOR, live=None):
     """`roofline.traffic` and where it came from.  `live`: a table measured by THIS run (measure_traffic_live); otherwise
-    the committed file profiles/r03_pmc/<fname> -- used only when its `_meta.source_hash` equals the hash of the sources
-    the loaded library was built from; a stale file yields traffic = None and says so."""
+    the committed file profiles/<PMC_DIR>/<fname> -- used only when its `_meta.source_hash` equals the hash of the sources
+    the loaded library was built from; a stale or inconsistent table yields traffic = None and says so."""
     if isinstance(kernel_prefixes, str):
         kernel_prefixes = (kernel_prefixes,)
     src = source_hash()
@@ -115,23 +128,36 @@ def pmc_traffic(fname, kernel_prefixes, fetch_factor=VECTOR_FETCH_FACTOR, live=N
             return None, {"source": f"profiles/{PMC_DIR}/{fname} REFUSED: collected at source hash {meta.get('source_hash')}, "
                                     f"the library sources are now {src}"}
         origin = {"source": f"profiles/{PMC_DIR}/{fname}", "source_hash": src, "collected": meta.get("collected")}
+    why = table_problems(tr, kernel_prefixes)
+    if why:
+        return None, {"source": origin["source"] + " REFUSED: " + "; ".join(why[:3])}
     vals = [traffic_from_table(tr, k, fetch_factor) for k in kernel_prefixes]
     vals = [v for v in vals if v is not None]
     return (sum(vals) if vals else None), origin
 
 
-def attach_traffic(out, fname, kernel_prefixes, fetch_factor=VECTOR_FETCH_FACTOR, standard=True, live=None):
-    """Fill roofline.traffic (+ traffic_source).  `standard`: the run has the sizes the PMC passes were collected at."""
+def attach_traffic(out, fname, kernel_prefixes, fetch_factor=VECTOR_FETCH_FACTOR, standard=True, live=None, algorithmic_bytes=None):
+    """Fill roofline.traffic (+ traffic_source, traffic_GBps, traffic_x_algorithmic): HBM bytes per step, rocprofv3 FETCH_SIZE +
+    WRITE_SIZE in separate passes, FETCH x `fetch_factor` (units and the gfx950 correction: profiles/README.md).  `standard`:
+    the run has the sizes the PMC passes were collected at.  A figure that implies more than the HBM peak over the kernel's
+    own time is not evidence and is refused."""
     roof = out["roofline"]
     if not standard and live is None:
         roof["traffic"], roof["traffic_source"] = None, {"source": "non-standard size: no PMC pass"}
         return
     roof["traffic"], roof["traffic_source"] = pmc_traffic(fname, kernel_prefixes, fetch_factor, live)
     roof["traffic_raw"], _ = pmc_traffic(fname, kernel_prefixes, 1.0, live)
-    roof["traffic_unit"] = ("HBM bytes per step, rocprofv3 FETCH_SIZE + WRITE_SIZE in separate passes; FETCH x %s: on gfx950 the "
-                            "counter reports half the bytes of vector-memory loads (MI355X_MICROARCH.md for 16-byte streams; every "
-                            "pattern of this library in profiles/r03_pmc/fetch_calibration.json) and all the bytes of scalar loads; "
-                            "`traffic_raw` = FETCH + WRITE as counted" % (json.dumps(fetch_factor),))
+    if roof["traffic"] is not None and roof.get("kernel_ms"):
+        gbps = roof["traffic"] / (roof["kernel_ms"] * 1e-3) / 1e9
+        if gbps > HBM_PEAK_GBS:
+            roof["traffic_source"] = {"source": roof["traffic_source"]["source"] + " REFUSED: %.0f GB/s over the kernel time exceeds "
+                                                "the %.0f GB/s HBM peak" % (gbps, HBM_PEAK_GBS)}
+            roof["traffic"] = roof["traffic_raw"] = None
+            return
+        roof["traffic_GBps"] = gbps
+        if algorithmic_bytes:
+            roof["algorithmic_bytes"] = algorithmic_bytes
+            roof["traffic_x_algorithmic"] = roof["traffic"] / algorithmic_bytes
 
 
 def measure_traffic_live(workload, extra=(), timeout=360):
@@ -288,81 +314,79 @@ PER_RANK = {}
 
 
 CLOCK_WARM_MS = 100.0     # --clock-warm-ms
-CLOCK_WARM = {}           # what the last timed_steps() did about it (goes into the line)
+CLOCK_WARM = {}           # the steady-clock pass of the last timed_steps() (reported BESIDE the protocol figure)
+_MID = {"ev": None}       # the event split_mark() records inside the step being timed
 
 
-def timed_steps(step_fn, steps, warmup, world):
-    """W untimed warmups, then exactly K steps between barrier+sync; also per-step HIP-event durations.
+def split_mark():
+    """Called by a step between its kernels and its collective: records the step's middle event when one is armed (the
+    E-step prices its kernels and its all-reduce from the SAME timed steps)."""
+    ev = _MID["ev"]
+    if ev is not None:
+        ev.record()
 
-    The Python garbage collector is off inside the timed region (as `timeit` does): with torch imported a full collection
-    pauses the interpreter for ~40 ms (measured on a busy host with tools/dtw_host_probe.py: the pause sat in the argument
-    marshalling of one call, outside the library), which is the whole timed region of a 20 x 1.7 ms workload -- the GPU
-    runs dry while the host stands still.  The collection and the event objects come BEFORE the warmup steps, so that
-    nothing but the contract's barrier + synchronize separates the warmup from the timed steps.
 
-    Clock warm-up (`--clock-warm-ms`, default 100; 0 = off): the MI355X raises its shader clock over the first ~30-40 ms of
-    back-to-back kernels and drops it again after a few tens of ms of idling (profiles/r04_convert_kernel_calls.csv: the
-    same launch takes 1.85 ms at the start of a burst and 1.52 ms from the 20th on; 1.55 -> 1.19 ms for the DTW fill), so
-    `--warmup 5` of a 1.7 ms step ends inside the ramp and times the power state, not the kernel.  Untimed steps of the SAME
-    workload are therefore enqueued for that many ms of GPU time ahead of the W warmup steps; how many is in the line
-    (`clock_warm`), and so are the first and last timed step (`step_ms_first_last`) and `cold_ms_per_step`: the same W + K
-    protocol run once BEFORE any of this, from the idle state (what a single cold call sequence costs)."""
-    import gc
-
+def _timed_pass(step_fn, steps, warmup, world, split):
     import torch
 
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True),
+            torch.cuda.Event(enable_timing=True) if split else None) for _ in range(steps)]
+    for _ in range(warmup):
+        step_fn()
+    barrier_sync(world)
+    t0 = time.perf_counter()
+    for a, b, m in evs:
+        a.record()
+        _MID["ev"] = m
+        step_fn()
+        b.record()
+    _MID["ev"] = None
+    barrier_sync(world)
+    t1 = time.perf_counter()
+    per_step = [a.elapsed_time(b) for a, b, _ in evs]
+    first = [a.elapsed_time(m) for a, _, m in evs] if split else None
+    return t1 - t0, per_step, first
+
+
+def timed_steps(step_fn, steps, warmup, world, steady=True, split=False):
+    """The contract's protocol to the letter: W untimed warmups, then exactly K steps between barrier + synchronize, with
+    per-step HIP events on the launch stream.  Returns (max-over-ranks wall seconds of the K steps, mean event ms per step) --
+    `value`, `ms_per_step` and `roofline.kernel_ms` of every line come from THIS pass.  With `split` the step calls
+    split_mark() once and PER_RANK["first_part_ms"] holds the mean duration up to the mark.
+
+    The Python garbage collector is off inside the timed region (as `timeit` does): with torch imported a full collection
+    pauses the interpreter for ~40 ms (tools/dtw_host_probe.py), which is the whole timed region of a 20 x 1.7 ms workload.
+
+    Steady-clock pass (`--clock-warm-ms`, default 100; 0 = off; `steady=False` = skip): the MI355X raises its shader clock
+    over the first ~30-40 ms of back-to-back kernels (profiles/r04_convert_kernel_calls.csv: 1.85 ms at the start of a burst,
+    1.52 ms from the 20th launch on), so W = 5 warmups of a 1.7 ms step end inside the ramp.  AFTER the protocol pass the same
+    K steps are therefore timed once more behind that many ms of untimed steps; the result goes into CLOCK_WARM
+    (`steady_ms_per_step`, `steady_kernel_ms`) and is reported beside the protocol figure, never as `value`."""
+    import gc
+
     gc.collect()
     gc_was_on = gc.isenabled()
     gc.disable()
     try:
-        n_warm = 0
-        cold_ms = None
-        if CLOCK_WARM_MS > 0:
-            # first the protocol to the letter, from the idle state the process is in: W warmups, K steps between
-            # barrier + synchronize -- reported beside the steady figure (`clock_warm.cold_ms_per_step`), never as `value`
-            for _ in range(warmup):
-                step_fn()
-            barrier_sync(world)
-            tc = time.perf_counter()
-            for _ in range(steps):
-                step_fn()
-            barrier_sync(world)
-            cold_ms = max_over_ranks(time.perf_counter() - tc, world) / max(steps, 1) * 1e3
-            # the same number of steps on every rank (a step may hold a collective): from the slowest rank's step time
-            step_fn()
-            torch.cuda.synchronize()
-            t = time.perf_counter()
-            step_fn()
-            step_fn()
-            torch.cuda.synchronize()
-            one = max_over_ranks((time.perf_counter() - t) / 2.0, world)
+        wall, per_step, first = _timed_pass(step_fn, steps, warmup, world, split)
+        wall = max_over_ranks(wall, world)
+        kernel_ms = float(np.mean(per_step))
+        PER_RANK["wall_s"] = gather_over_ranks(wall, world)
+        PER_RANK["kernel_ms"] = gather_over_ranks(kernel_ms, world)
+        if split:
+            PER_RANK["first_part_ms"] = float(np.mean(first))
+        CLOCK_WARM.clear()
+        if steady and CLOCK_WARM_MS > 0:
+            # the same number of untimed steps on every rank (a step may hold a collective): from the slowest rank's step time
+            one = max_over_ranks(kernel_ms * 1e-3, world)
             n_warm = int(min(max(CLOCK_WARM_MS * 1e-3 / max(one, 1e-6), 1.0), 4000.0))
-            for _ in range(n_warm):
-                step_fn()
-            n_warm += 3
-        for _ in range(warmup):
-            step_fn()
-        barrier_sync(world)
-        t0 = time.perf_counter()
-        for a, b in evs:
-            a.record()
-            step_fn()
-            b.record()
-        barrier_sync(world)
-        t1 = time.perf_counter()
+            swall, sper, _ = _timed_pass(step_fn, steps, n_warm, world, False)
+            CLOCK_WARM.update({"steady_ms_per_step": round(max_over_ranks(swall, world) / max(steps, 1) * 1e3, 4),
+                               "steady_kernel_ms": round(float(np.mean(sper)), 4), "untimed_steps": n_warm})
     finally:
         if gc_was_on:
             gc.enable()
-    per_step = [a.elapsed_time(b) for a, b in evs]
-    kernel_ms = float(np.mean(per_step))
-    CLOCK_WARM.clear()
-    CLOCK_WARM.update({"ms": CLOCK_WARM_MS, "untimed_steps_before_the_warmup": n_warm,
-                       "cold_ms_per_step": None if cold_ms is None else round(cold_ms, 4),
-                       "step_ms_first_last": [round(per_step[0], 4), round(per_step[-1], 4)] if per_step else None})
-    PER_RANK["wall_s"] = gather_over_ranks(t1 - t0, world)
-    PER_RANK["kernel_ms"] = gather_over_ranks(kernel_ms, world)
-    return max_over_ranks(t1 - t0, world), kernel_ms
+    return wall, kernel_ms
 
 
 # ------------------------------------------------------------------------------------------- convert
@@ -445,7 +469,7 @@ def bench_convert(args, world, rank, variant="synthetic"):
     # (profiling runs, --cpu-seconds 0, launch nothing but the warm-up and the timed steps: the PMC passes count there)
     _, shape, active_frac, undecided_frac = g.convert_plan()
     issued_mfma, nreg = None, None
-    if args.cpu_seconds > 0 or world > 1:            # (N > 1 lines run with --cpu-seconds 0 too, but are no profiling runs)
+    if not args.profile_run:
         g.prune_stats(True)
         step()
         torch.cuda.synchronize()
@@ -462,7 +486,7 @@ def bench_convert(args, world, rank, variant="synthetic"):
         "unit": "frames/s",
         "n_gpus": world,
         "steps": args.steps,
-        "warmup": args.warmup, "clock_warm": clock_warm,
+        "warmup": args.warmup, "steady": clock_warm,
         "ms_per_step": wall / args.steps * 1e3,
         "higher_is_better": True,
         "scaling": "weak",
@@ -474,17 +498,10 @@ def bench_convert(args, world, rank, variant="synthetic"):
         "roofline": {"bound": "mfma", "kernel": "gmmmap_mfma_kernel<40,2,4,0,2,%d>" % shape, "achieved": achieved,
                      "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS,
                      "traffic": None, "kernel_ms": kernel_ms,
-                     "frac_definition": "min(algorithmic flop, flop of the MFMAs the kernel issued) / kernel time / peak: work the kernel "
-                                        "skips is not credited (algorithmic_frac would exceed 1) and tile padding is not credited "
-                                        "either (the dense loop issues 344,064 flop per frame for 324,160 algorithmic)",
-                     "kernel_ms_definition": "HIP events around the whole vcmi_gmmmap_convert_dev call on its stream: the three grouping "
-                                             "kernels (~0.12 ms per 10^6 frames) and the MFMA kernel; profiles/r04_clock/ times the MFMA "
-                                             "kernel alone, so issued / that time is higher (0.68 against 0.62 for the headline)",
                      "flop_per_frame": convert_flops_per_frame(D, M),
                      "algorithmic_frac": alg_tflops / FP64_PEAK_TFLOPS,
                      "issued_mfma_frac": (iss_tflops / FP64_PEAK_TFLOPS) if iss_tflops else None,
                      "mfma_issued_per_launch": issued_mfma,
-                     "mfma_issued_source": "in-kernel count (vcmi_gmmmap_convert_plan); SQ_INSTS_MFMA of the same kernel: profiles/r04_clock/",
                      "work_skipped": (1.0 - issued_mfma / float(per_pair_dense * tiles * M)) if (per_pair_dense and issued_mfma) else None,
                      "regressions_evaluated_frac": (nreg / float(tiles * M)) if nreg is not None else None,
                      "loop_shape": {0: "dense", 1: "broad", 2: "peaked"}.get(shape, str(shape)),
@@ -494,7 +511,8 @@ def bench_convert(args, world, rank, variant="synthetic"):
     # HBM traffic of the kernel: PMC passes of this same command, run as child processes before the timed run (LIVE_PMC)
     # or, failing that, the committed passes if they were collected from the same library sources
     if headline:
-        attach_traffic(out, "convert_traffic.json", "gmmmap_mfma_kernel", standard=(T == 1_000_000), live=LIVE_PMC.get("convert"))
+        attach_traffic(out, "convert_traffic.json", "gmmmap_mfma_kernel", standard=(T == 1_000_000), live=LIVE_PMC.get("convert"),
+                       algorithmic_bytes=2.0 * D * 8 * T)
         if out["roofline"].get("traffic") is not None:
             # `traffic` is the dominant kernel's, as the roofline object is defined; the three grouping kernels in front of it read x
             # once more (the nearest-mean keys) and write the permutation
@@ -506,13 +524,13 @@ def bench_convert(args, world, rank, variant="synthetic"):
                 out["roofline"]["SQ_INSTS_MFMA_per_launch"] = v["SQ_INSTS_MFMA_per_launch"]
     # The same K steps with nothing skipped (vcmi_gmmmap_set_prune(inf): every mixture's whitening and regression for every
     # frame, the dense loop the flop count of SURVEY 8(d) assumes), and the pruned output against it.
-    if (args.prune is None or args.prune < 1e300) and args.cpu_seconds > 0:      # (not in profiling runs)
+    if (args.prune is None or args.prune < 1e300) and args.cpu_seconds > 0 and not args.profile_run:
         g.set_prune(float("inf"))
-        wall_d, kernel_ms_d = timed_steps(step, args.steps, 2, world)
+        wall_d, kernel_ms_d = timed_steps(step, args.steps, args.warmup, world)
         ach_d = flops / (kernel_ms_d * 1e-3) / 1e12
         out["roofline"]["dense"] = {"kernel_ms": kernel_ms_d, "frac": ach_d / FP64_PEAK_TFLOPS, "achieved": ach_d,
                                     "value": world * T * args.steps / wall_d, "unit": "frames/s",
-                                    "ms_per_step": wall_d / args.steps * 1e3,
+                                    "ms_per_step": wall_d / args.steps * 1e3, "steady": dict(CLOCK_WARM),
                                     "note": "vcmi_gmmmap_set_prune(inf): gmmmap_mfma_kernel<40,2,4,0,2,0>, every MFMA step of every "
                                             "mixture for every frame; frac = algorithmic flop / time / peak"}
         if rank == 0:
@@ -624,36 +642,25 @@ def bench_estep(args, world, rank):
 
     def step():
         vc.estep_diag_dev(Xd.t(), w, muT, varT, out=out_t)
+        split_mark()
         vc.dist.allreduce_sum_(out_t)
-
-    wall, step_ms = timed_steps(step, args.steps, args.warmup, world)
-
-    clock_warm = dict(CLOCK_WARM)
-    # the same K steps again without the collective (kernels only), and K collectives alone: `kernel_ms` prices the E-step
-    # kernels, `allreduce_ms` the RCCL all-reduce of the packed statistics (zero work with one rank and no process group)
-    per_rank_step = dict(PER_RANK)
 
     def step_kernels():
         vc.estep_diag_dev(Xd.t(), w, muT, varT, out=out_t)
 
-    def step_allreduce():
-        vc.dist.allreduce_sum_(out_t)
-
-    if args.cpu_seconds > 0 or world > 1:
-        _, kernel_ms = timed_steps(step_kernels, args.steps, 1, world)
-        _, allreduce_ms = timed_steps(step_allreduce, args.steps, 1, world)
-        vc.estep_diag_dev(Xd.t(), w, muT, varT, out=out_t)          # leave the statistics of ONE pass in out_t for the checks below
-        vc.dist.allreduce_sum_(out_t)
-    else:       # profiling run (--cpu-seconds 0, one rank): nothing but the warm-up and the timed steps may reach the trace
-        kernel_ms, allreduce_ms = step_ms, None
-    PER_RANK.update(per_rank_step)
+    # one set of timed steps prices both parts: `kernel_ms` = start of the step to the mark (the E-step kernels),
+    # `allreduce_ms` = the rest (the RCCL all-reduce of the packed statistics; no work with one rank and no process group)
+    wall, step_ms = timed_steps(step, args.steps, args.warmup, world, split=True)
+    clock_warm = dict(CLOCK_WARM)
+    kernel_ms = PER_RANK.pop("first_part_ms")
+    allreduce_ms = step_ms - kernel_ms
     fps = world * N * args.steps / wall
     mfma_path = Dj % 2 == 0 and Dj <= 160 and M <= 128           # estep.hip: estep_device
     # what the matrix pipe was given: the kernel counts its own MFMAs in one extra, untimed step (vcmi_debug_estep_mfma) --
     # step B skips k-steps whose responsibilities are all exactly zero, so the algorithmic flop count is not what is issued
     issued_mfma = None
     try:
-        if not (args.cpu_seconds > 0 or world > 1):
+        if args.profile_run:
             raise RuntimeError("profiling run: nothing but the warm-up and the timed steps is launched")
         import ctypes as C
 
@@ -675,7 +682,7 @@ def bench_estep(args, world, rank):
     iss_tflops = issued_mfma * MFMA_FLOP / (kernel_ms * 1e-3) / 1e12 if issued_mfma else None
     achieved = min(alg_tflops, iss_tflops) if iss_tflops else alg_tflops
     out = {"metric": "diag-GMM E-step frames/sec (Dj=%d, M=%d)" % (Dj, M), "value": fps, "unit": "frames/s", "n_gpus": world,
-           "steps": args.steps, "warmup": args.warmup, "clock_warm": clock_warm, "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True,
+           "steps": args.steps, "warmup": args.warmup, "steady": clock_warm, "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True,
            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
            "config": {"workload": "diag E-step (BASELINE configs[2])" if (Dj == 80 and M == 128) else
                       f"diag E-step, Dj={Dj}, M={M} ({'MFMA kernel' if mfma_path else 'generic kernels'}; not a BASELINE config)",
@@ -684,17 +691,15 @@ def bench_estep(args, world, rank):
            "roofline": {"bound": "mfma", "kernel": (f"estep_mfma_kernel<{min(d for d in (32, 48, 64, 80, 160) if d >= Dj)}>" if mfma_path else "estep_gamma_kernel + estep_stats_kernel (generic path)") + " (+ all-reduce)", "achieved": achieved,
                         "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS,
                         "traffic": None,
-                        "frac_definition": "min(algorithmic flop, flop of the MFMAs the kernels issued) / kernel time / peak",
                         "algorithmic_frac": alg_tflops / FP64_PEAK_TFLOPS,
                         "issued_mfma_frac": (iss_tflops / FP64_PEAK_TFLOPS) if iss_tflops else None,
                         "mfma_issued_per_step": issued_mfma,
-                        "mfma_issued_source": "in-kernel count (vcmi_debug_estep_mfma); SQ_INSTS_MFMA: profiles/r04_clock/estep_clock.json",
                         "flop_per_frame": estep_flops_per_frame(Dj, M), "kernel_ms": kernel_ms},
            "collective": {"op": "all-reduce(sum), %d doubles" % vc.stats_len(Dj, M), "allreduce_ms": allreduce_ms,
                           "step_ms_with_allreduce": step_ms, "ranks": world, "backend": BACKEND["name"]}}
     attach_traffic(out, "estep_traffic.json", "estep_mfma_kernel", standard=(N == 1_250_000 and Dj == 80 and M == 128),
-                   live=LIVE_PMC.get("estep"))
-    if rank == 0:
+                   live=LIVE_PMC.get("estep"), algorithmic_bytes=8.0 * Dj * N)
+    if rank == 0 and not args.profile_run:       # (the parity sample launches the kernel once more)
         from oracle import c_oracle as co
 
         n0 = 20000
@@ -774,11 +779,11 @@ def bench_estep_full(args, world, rank):
     clock_warm = dict(CLOCK_WARM)
     flop = 2 * M * Dj * (Dj + 1) + 2 * M * Dj
     alg_tflops = flop * N / (kernel_ms * 1e-3) / 1e12
-    issued = full_estep_issued_mfma(step, N, Dj, M) if (args.cpu_seconds > 0 or world > 1) else None
+    issued = full_estep_issued_mfma(step, N, Dj, M) if not args.profile_run else None
     iss_tflops = issued * MFMA_FLOP / (kernel_ms * 1e-3) / 1e12 if issued else None
     achieved = min(alg_tflops, iss_tflops) if iss_tflops else alg_tflops
     out = {"metric": "full-covariance GMM E-step frames/sec (Dj=%d, M=64)" % Dj, "value": world * N * args.steps / wall,
-           "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "clock_warm": clock_warm,
+           "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "steady": clock_warm,
            "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "f64", "data": "synthetic",
            "config": {"workload": "full-covariance E-step (SURVEY 8f rank 1; bin/train_gmm.jl:84-103)", "Dj": Dj, "M": M,
@@ -788,15 +793,13 @@ def bench_estep_full(args, world, rank):
                                   ("whole step: logdens_tiled_kernel + estep_full_stats_kernel<%d,4> (+ host Cholesky of the %d-dim blocks)" % (Dj, Dj)),
                         "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                         "frac": achieved / FP64_PEAK_TFLOPS,
-                        "frac_definition": "min(algorithmic flop, flop of the MFMAs issued) / step time / peak (the statistics of "
-                                           "responsibilities that are exactly zero are not multiplied)",
                         "algorithmic_frac": alg_tflops / FP64_PEAK_TFLOPS,
                         "issued_mfma_frac": (iss_tflops / FP64_PEAK_TFLOPS) if iss_tflops else None, "mfma_issued_per_step": issued,
                         "traffic": None,
                         "flop_per_frame": flop, "kernel_ms": kernel_ms}}
     attach_traffic(out, "estep_full_traffic.json", ("gmmmap_mfma_kernel", "estep_full_stats_kernel", "estep_full_softmax_kernel"),
                    standard=(N == 500_000 and Dj == 80))
-    if rank == 0:
+    if rank == 0 and not args.profile_run:       # (the parity sample launches the kernel once more)
         from oracle import c_oracle as co
 
         n = 40000 if Dj <= 80 else 10000
@@ -838,11 +841,11 @@ def bench_em_full(args, world, rank):
     clock_warm = dict(CLOCK_WARM)
     flop = 2 * M * Dj * (Dj + 1) + 2 * M * Dj
     alg_tflops = flop * N / (kernel_ms * 1e-3) / 1e12
-    issued = full_estep_issued_mfma(lambda: em.estep(Xd.t(), out=stats), N, Dj, M) if (args.cpu_seconds > 0 or world > 1) else None
+    issued = full_estep_issued_mfma(lambda: em.estep(Xd.t(), out=stats), N, Dj, M) if not args.profile_run else None
     iss_tflops = issued * MFMA_FLOP / (kernel_ms * 1e-3) / 1e12 if issued else None
     achieved = min(alg_tflops, iss_tflops) if iss_tflops else alg_tflops
     out = {"metric": "full-covariance GMM EM iteration frames/sec (Dj=%d, M=64)" % Dj, "value": world * N * args.steps / wall,
-           "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "clock_warm": clock_warm,
+           "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "steady": clock_warm,
            "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "f64", "data": "synthetic",
            "config": {"workload": "EM iteration, full covariance (SURVEY 8f rank 1; bin/train_gmm.jl:84-103)", "Dj": Dj, "M": M,
@@ -916,7 +919,7 @@ def bench_dtw(args, world, rank):
     flops = cells * (3 * D + 10)
     achieved = flops / (kernel_ms * 1e-3) / 1e12
     out = {"metric": "DTW aligned pairs/sec (~500x500 frames, D=%d)" % D, "value": world * n * args.steps / wall, "unit": "pairs/s",
-           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "clock_warm": clock_warm, "ms_per_step": wall / args.steps * 1e3,
+           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "steady": clock_warm, "ms_per_step": wall / args.steps * 1e3,
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
            "config": {"workload": "DTW fit!+backward, path-only (BASELINE configs[3])" if D == 40 else
                       f"DTW fit!+backward, path-only, D={D}" + (" (order-40 mel-cepstra with c0: bin/mcep.jl:12, src/align.jl:45)" if D == 41 else ""),
@@ -935,7 +938,7 @@ def bench_dtw(args, world, rank):
                         "cells_per_s": cells / (kernel_ms * 1e-3), "kernel_ms": kernel_ms}}
     attach_traffic(out, f"dtw{'' if D == 40 else '_d%d' % D}_traffic.json", "dtw_fused",
                    fetch_factor={"dtw_fused_persistent_kernel": DTW_FUSED_FETCH_FACTOR, "dtw_fused_kernel": DTW_FUSED_FETCH_FACTOR, "": VECTOR_FETCH_FACTOR},
-                   standard=(n == 1000), live=LIVE_PMC.get("dtw"))
+                   standard=(n == 1000), live=LIVE_PMC.get("dtw"), algorithmic_bytes=float(np.sum((S + T) * D * 8 + T * 8)))
     if rank == 0:
         from oracle import c_oracle as co
 
@@ -1017,7 +1020,7 @@ def bench_traj(args, world, rank, gv=False):
     achieved = flops_per_utt * n / (kernel_ms * 1e-3) / 1e12
     out = {"metric": ("trajectory+GV-converted" if gv else "trajectory-converted") + " frames/sec (static D=40, M=64, T=2000)",
            "value": world * n * T * args.steps / wall,
-           "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "clock_warm": clock_warm,
+           "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "steady": clock_warm,
            "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "f64", "data": "synthetic",
            "config": {"workload": ("TrajectoryGVGMMMap fvconvert, 100 epochs (SURVEY 8f rank 2)" if gv else
@@ -1035,7 +1038,8 @@ def bench_traj(args, world, rank, gv=False):
                                 "3.4); chunked conversion has the same number of block steps per CU, in shorter chains"}}
     attach_traffic(out, ("trajgv" if gv else "traj") + "_traffic.json",
                    ("gmmmap_mfma_kernel", "posterior_finish_kernel", "traj_g_mfma_kernel", "traj_solve_blk_kernel", "traj_gv_kernel",
-                    "traj_gv2_kernel"), standard=(n == 256 and L <= 0), live=LIVE_PMC.get("trajgv" if gv else "traj"))
+                    "traj_gv2_kernel"), standard=(n == 256 and L <= 0), live=LIVE_PMC.get("trajgv" if gv else "traj"),
+                   algorithmic_bytes=8.0 * n * T * 3 * D)
     if rank == 0:
         from oracle import c_oracle as co
 
@@ -1093,7 +1097,7 @@ def bench_selftest(args, world, rank):
 
 def summarize(out):
     """What the `workloads` table keeps of a workload's line."""
-    keep = ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "clock_warm", "config", "data", "roofline", "cpu_baseline", "collective",
+    keep = ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "steady", "config", "data", "roofline", "cpu_baseline", "collective",
             "parity_max_rel_err_vs_oracle", "parity_bit_exact_vs_oracle", "speedup_vs_cpu_baseline", "allreduce_check")
     d = {k: out[k] for k in keep if k in out}
     d["kernel_ms"] = out.get("roofline", {}).get("kernel_ms")
@@ -1101,6 +1105,125 @@ def summarize(out):
     if "cpu_baseline" in d and "value" in d["cpu_baseline"] and "speedup_vs_cpu_baseline" not in d:
         d["speedup_vs_cpu_baseline"] = out["value"] / d["cpu_baseline"]["value"]
     return d
+
+
+LINE_CAP = 7500           # characters of the ONE stdout line (the driver keeps an 8 KB tail; BENCH_r04 lost a 20.9 KB line)
+ROOF_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "kernel_ms", "algorithmic_frac", "issued_mfma_frac",
+             "traffic_whole_step", "traffic_x_algorithmic", "traffic_GBps")
+
+
+def _sig(x, n=6):
+    """Floats to n significant digits (the line is a record, not an archive: bench_detail has the full values)."""
+    if isinstance(x, bool) or not isinstance(x, float):
+        return x
+    if x != x or x in (float("inf"), float("-inf")):
+        return None
+    return float("%.*g" % (n, x))
+
+
+def compact_roofline(r, kernel_chars=80):
+    c = {k: _sig(r.get(k)) for k in ROOF_KEYS if k in r or k == "traffic"}
+    if isinstance(c.get("kernel"), str):
+        c["kernel"] = c["kernel"][:kernel_chars]
+    d = r.get("dense")
+    if isinstance(d, dict):
+        c["dense"] = {"kernel_ms": _sig(d.get("kernel_ms")), "frac": _sig(d.get("frac"))}
+    return c
+
+
+def compact_workload(d):
+    """One row of the line's `summary`: numbers only (definitions: profiles/README.md)."""
+    c = {k: _sig(d[k]) for k in ("value", "unit", "ms_per_step") if k in d}
+    st = d.get("steady") or {}
+    if st.get("steady_ms_per_step") is not None:
+        c["steady_ms_per_step"] = st["steady_ms_per_step"]
+    c["roofline"] = compact_roofline(d.get("roofline", {}), 48)
+    if "parity_max_rel_err_vs_oracle" in d:
+        c["parity"] = _sig(d["parity_max_rel_err_vs_oracle"], 3)
+    elif "parity_bit_exact_vs_oracle" in d:
+        c["parity"] = "bit-exact" if d["parity_bit_exact_vs_oracle"] else "MISMATCH"
+    b = d.get("cpu_baseline")
+    if isinstance(b, dict) and "value" in b:
+        c["cpu_baseline"] = {k: _sig(b[k]) for k in ("value", "unit", "cores", "kind") if k in b}
+        if "cached" in b:
+            c["cpu_baseline"]["cached"] = True
+    if d.get("speedup_vs_cpu_baseline") is not None:
+        c["speedup_vs_cpu_baseline"] = _sig(d["speedup_vs_cpu_baseline"], 4)
+    col = d.get("collective")
+    if isinstance(col, dict):
+        c["collective"] = {k: _sig(col.get(k)) for k in ("allreduce_ms", "ranks", "backend")}
+    return c
+
+
+def compact_line(out, table):
+    """The ONE JSON line the driver parses: the contract's keys first, `roofline` and `cpu_baseline` of the headline workload,
+    then one numeric row per workload (`summary`).  Everything else (definitions, notes, per-rank lists, PCIe probe, the full
+    `workloads` table) goes to the detail file named in `detail` -- never to stdout."""
+    head = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+            "data", "config")
+    c = {k: _sig(out.get(k)) for k in head if k in out}
+    c["roofline"] = compact_roofline(out.get("roofline", {}))
+    b = out.get("cpu_baseline")
+    if isinstance(b, dict):
+        c["cpu_baseline"] = {k: (_sig(v) if not isinstance(v, str) else v[:160]) for k, v in b.items()}
+    for k in ("parity_max_rel_err_vs_oracle", "parity_bit_exact_vs_oracle", "speedup_vs_cpu_baseline", "allreduce_exact", "allreduce_check", "debug_force",
+              "collective_backend", "library_source_hash", "loglik_monotone"):
+        if out.get(k) is not None:
+            c[k] = _sig(out[k])
+    st = out.get("steady") or {}
+    if st:
+        c["steady"] = st
+    col = out.get("collective")
+    if isinstance(col, dict):
+        c["collective"] = {k: _sig(col.get(k)) for k in ("allreduce_ms", "step_ms_with_allreduce", "ranks", "backend")}
+    h = out.get("host_inclusive")
+    if isinstance(h, dict):
+        hc = {"unit": "ms per 10^6-frame ccall-style call on host arrays (PCIe-inclusive; never `value`)"}
+        for name, key in (("fresh_output", None), ("reused_output", "reused_output"), ("registered", "registered")):
+            d = h if key is None else h.get(key)
+            if isinstance(d, dict) and d.get("ms_per_call") is not None:
+                hc[name] = {"ms": _sig(d["ms_per_call"], 4), "frac_of_pcie": _sig(d.get("frac_of_pcie"), 3)}
+        c["host_inclusive"] = hc
+    s1 = out.get("cpu_baseline_strong")
+    if isinstance(s1, dict) and "value" in s1:
+        c["cpu_baseline_strong"] = {k: _sig(s1[k]) for k in ("value", "unit", "cores", "kind")}
+    n1 = out.get("n1_consistency")
+    if isinstance(n1, dict):
+        c["n1_consistency"] = {k: ({"ratio": _sig(v.get("ratio"), 4), "within_5pct": v.get("within_5pct")} if isinstance(v, dict) else v)
+                               for k, v in n1.items()}
+    pr = out.get("per_rank")
+    if isinstance(pr, dict) and out.get("n_gpus", 1) > 1:
+        c["per_rank"] = {k: [_sig(x, 4) for x in v] if isinstance(v, list) else _sig(v, 4) for k, v in pr.items()}
+    if len(table) > 1 or (table and next(iter(table.values())) is not out):
+        c["summary"] = {name: compact_workload(d) for name, d in table.items() if isinstance(d, dict) and "ms_per_step" in d}
+    if out.get("detail"):
+        c["detail"] = out["detail"]
+    line = json.dumps(c)
+    for drop in ("n1_consistency", "per_rank", "host_inclusive", "cpu_baseline_strong", "steady"):   # never expected: the cap holds anyway
+        if len(line) <= LINE_CAP:
+            break
+        c.pop(drop, None)
+        line = json.dumps(c)
+    if len(line) > LINE_CAP:
+        c.pop("summary", None)
+        line = json.dumps(c)
+    return line
+
+
+def write_detail(out, name):
+    """The full record (every workload's complete object) -> gpurun_out/<name> under the repo, or the temp dir."""
+    import tempfile
+
+    for d in (os.path.join(ROOT, "gpurun_out"), tempfile.gettempdir()):
+        try:
+            os.makedirs(d, exist_ok=True)
+            path = os.path.join(d, name)
+            with open(path, "w") as f:
+                json.dump(out, f, indent=1)
+            return os.path.relpath(path, ROOT) if path.startswith(ROOT) else path
+        except OSError:
+            continue
+    return None
 
 
 CPU_CACHE = os.path.join(__import__("tempfile").gettempdir(), "vcmi_bench_cpu_baseline.json")
@@ -1186,11 +1309,17 @@ def main():
     ap.add_argument("--clock-warm-ms", type=float, default=100.0,
                     help="ms of untimed steps of the same workload enqueued ahead of the W warmup steps so that the timed steps run "
                          "at the steady shader clock (see timed_steps); 0 = only the W warmup steps")
+    ap.add_argument("--profile-run", action="store_true",
+                    help="for the rocprofv3 passes (tools/pmc_traffic.py, tools/clock_pmc.py, tools/round_profiles.sh): launch NOTHING but "
+                         "the W warm-up and the K timed steps (and the steady-clock pass unless --clock-warm-ms 0) -- no MFMA-count launch, "
+                         "no dense pass, no parity sample on the device, no host-pointer calls, no CPU baseline; implies --cpu-seconds 0 --pmc off")
     ap.add_argument("--verify-allreduce", action="store_true",
                     help="estep: rank 0 recomputes the statistics of every rank's frames in one process and compares")
     args = ap.parse_args()
     global CLOCK_WARM_MS
     CLOCK_WARM_MS = max(args.clock_warm_ms, 0.0)
+    if args.profile_run:
+        args.cpu_seconds, args.cpu_seconds_sub, args.pmc = 0.0, 0.0, "off"
 
     if args.gpus < 1:
         ap.error("--gpus must be >= 1")
@@ -1277,23 +1406,9 @@ def main():
     out["library_source_hash"] = source_hash()
     if args.debug_force:
         out["debug_force"] = args.debug_force      # not a product configuration
-    # last key of the line (the driver keeps the line's tail): per workload [ms_per_step, roofline.frac, parity]
-    def _row(d):
-        par = d.get("parity_max_rel_err_vs_oracle")
-        if par is None and "parity_bit_exact_vs_oracle" in d:
-            par = "bit-exact" if d["parity_bit_exact_vs_oracle"] else "MISMATCH"
-        r = d.get("roofline", {})
-        row = [round(d.get("ms_per_step", 0.0), 4), round(r.get("frac", 0.0), 4), par if isinstance(par, str) or par is None else float("%.2g" % par),
-               (d.get("clock_warm") or {}).get("cold_ms_per_step")]
-        if "dense" in r:
-            row.append({"dense_ms": round(r["dense"]["kernel_ms"], 4), "dense_frac": round(r["dense"]["frac"], 4),
-                        "regressions": round(r.get("regressions_evaluated_frac", 0.0), 4)})
-        return row
-    out["summary"] = {"columns": ["ms_per_step", "roofline.frac (<= 1: issued or algorithmic work, whichever is less)", "parity vs oracle",
-                                  "ms_per_step from idle (W warmups + K steps to the letter, no clock warm-up)"],
-                      **{name: _row(d) for name, d in table.items() if isinstance(d, dict) and "ms_per_step" in d}}
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        out["detail"] = write_detail(out, "bench_detail_%s_n%d.json" % (args.workload, world))
+        print(compact_line(out, table), flush=True)
     import torch.distributed as dist
 
     if dist.is_initialized():

@@ -73,3 +73,71 @@ def test_roofline_traffic_is_refused_when_collected_from_other_sources(tmp_path,
     # a table measured by this run is taken as it is
     v, src = bench.pmc_traffic("x_traffic.json", "some_kernel", 1.0, live=table)
     assert v == 1500.0 * 1024 and "measured in this run" in src["source"]
+
+
+def test_the_one_stdout_line_stays_under_the_cap():
+    """BENCH_r04 lost its record because the line had grown to 20.9 KB (the driver keeps an 8 KB tail): the line printed is
+    compact_line() of the full record -- contract keys, the headline's roofline and cpu_baseline, one numeric row per
+    workload -- and never exceeds LINE_CAP whatever the full record holds."""
+    sys.path.insert(0, ROOT)
+    import bench
+    full = json.loads(open(os.path.join(ROOT, "profiles", "r04_all_bench.json")).read().strip().splitlines()[-1])
+    assert len(json.dumps(full)) > 20000                     # the round-4 record, as it was printed then
+    full["detail"] = "gpurun_out/bench_detail_all_n1.json"
+    full["n1_consistency"] = {"available": True, "n1_measured": "x", **{k: {"n1_value": 1.0, "per_rank_value": 1.0, "ratio": 1.0,
+                                                                         "within_5pct": True} for k in full["workloads"]}}
+    full["per_rank"] = {"wall_s": [0.033] * 8, "kernel_ms": [1.6] * 8}
+    for n in (1, 8):
+        full["n_gpus"] = n
+        line = bench.compact_line(full, full["workloads"])
+        assert len(line) < bench.LINE_CAP <= 8000, len(line)
+        out = json.loads(line)
+        for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                  "dtype", "data", "config", "roofline", "cpu_baseline", "summary", "detail"):
+            assert k in out, k
+        assert list(out)[:3] == ["metric", "value", "unit"]
+        for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+            assert k in out["roofline"], k
+        assert {"value", "unit", "cores", "kind", "sample"} <= set(out["cpu_baseline"])
+        assert set(out["summary"]) == set(full["workloads"])
+        assert all("frac" in r["roofline"] and "traffic" in r["roofline"] for r in out["summary"].values())
+    # no prose anywhere in the line: every string value is short
+    def strings(o):
+        if isinstance(o, dict):
+            for v in o.values():
+                yield from strings(v)
+        elif isinstance(o, list):
+            for v in o:
+                yield from strings(v)
+        elif isinstance(o, str):
+            yield o
+    assert max(len(x) for x in strings(out)) <= 160
+
+
+def test_selftest_line_is_short_and_names_its_detail_file():
+    p = _run(["--gpus", "2", "--workload", "selftest", "--steps", "2"], {"VCMI_BENCH_BACKEND": "gloo"})
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = [l for l in p.stdout.splitlines() if l.startswith("{")][0]
+    assert len(line) < 2000
+    out = json.loads(line)
+    assert out["detail"] and os.path.exists(os.path.join(ROOT, out["detail"]) if not os.path.isabs(out["detail"]) else out["detail"])
+
+
+def test_traffic_tables_with_wrong_step_accounting_are_refused(tmp_path, monkeypatch):
+    """Round 4 divided the counters of ~60 launches by 3 steps; a table whose launch count is not whole per step, or whose
+    bytes over the kernel's time exceed the HBM peak, is refused with the reason (traffic = None)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    live = {"void vcmi::k<1>": {"FETCH_SIZE_KB_per_step": 1e6, "WRITE_SIZE_KB_per_step": 1e6, "launches_per_step": 19.0 / 3}, "_meta": {}}
+    v, src = bench.pmc_traffic("x", "vcmi::k", 1.0, live=live)
+    assert v is None and "REFUSED" in src["source"] and "launches per step" in src["source"]
+    live["void vcmi::k<1>"]["launches_per_step"] = 1.0
+    out = {"roofline": {"kernel_ms": 0.1}}
+    bench.attach_traffic(out, "x", "vcmi::k", 1.0, live=live)                # 2 GB in 0.1 ms = 20 TB/s
+    assert out["roofline"]["traffic"] is None and "exceeds" in out["roofline"]["traffic_source"]["source"]
+    out = {"roofline": {"kernel_ms": 1.0}}
+    bench.attach_traffic(out, "x", "vcmi::k", 1.0, live=live, algorithmic_bytes=1.024e9)
+    assert out["roofline"]["traffic"] == 2e6 * 1024 and abs(out["roofline"]["traffic_x_algorithmic"] - 2.0) < 1e-12
+    live["_meta"]["problems"] = ["k: 7 launches in the FETCH_SIZE pass are not a multiple of the 3 steps"]
+    v, src = bench.pmc_traffic("x", "vcmi::k", 1.0, live=live)
+    assert v is None and "not a multiple" in src["source"]

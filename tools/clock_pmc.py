@@ -31,7 +31,7 @@ def main():
         del argv[i:i + 2]
     os.makedirs(out, exist_ok=True)
     cmd = ["rocprofv3", "--kernel-trace", "--pmc"] + COUNTERS + ["--output-format", "csv", "-d", out, "--", sys.executable,
-           os.path.join(ROOT, "bench.py"), "--workload", w, "--steps", "20", "--warmup", "5", "--cpu-seconds", "0", "--pmc", "off"] + argv
+           os.path.join(ROOT, "bench.py"), "--workload", w, "--steps", "20", "--warmup", "5", "--profile-run", "--pmc", "off"] + argv     # (default --clock-warm-ms: the steady pass is in the averages)
     with open(os.path.join(out, "err.txt"), "w") as err:
         subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=err, timeout=400, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), check=True)
     cc = glob.glob(os.path.join(out, "*", "*counter_collection.csv"))[0]

@@ -2,8 +2,11 @@
 """HBM traffic of a bench workload's kernels: FETCH_SIZE and WRITE_SIZE in SEPARATE rocprofv3 passes (they do not fit one
 pass: MI355X_MICROARCH.md, HBM section), plus a third pass for SQ_INSTS_MFMA (the matrix instructions each kernel issued:
 what bench.py prices the MFMA pipe with), kernel-trace only, of `python3 bench.py --workload <w> --steps 2 --warmup 1
---cpu-seconds 0` (with --cpu-seconds 0 the bench launches nothing but the warm-up, the timed steps and a small parity
-sample).  Writes <out>/traffic.json: per kernel the KB counters per launch and per bench step, plus `_meta` with the hash
+--profile-run --clock-warm-ms 0` (with --cpu-seconds 0 the bench launches nothing but the W warm-up steps, the K timed
+steps and a small parity sample; --clock-warm-ms 0 switches the steady-clock pass off, so W + K = 3 steps reach the
+counters -- round 4 divided by 3 while ~60 clock-warm launches were counted too: every per-step figure was 4-23x high.
+Per-step figures are now per-launch averages x the launches of ONE step, and a launch count that is not a whole multiple
+of the 3 steps is recorded in `_meta.problems`, which makes bench.py refuse the table).  Writes <out>/traffic.json: per kernel the KB counters per launch and per bench step, plus `_meta` with the hash
 of the library sources the passes were collected from -- bench.py refuses a table whose hash is not the current one.
 
     python3 tools/pmc_traffic.py <workload> [--out DIR] [extra bench args]
@@ -35,7 +38,8 @@ def main():
 
     res = collections.defaultdict(dict)
     cmd_tail = ["--", sys.executable, os.path.join(ROOT, "bench.py"), "--workload", w, "--steps", "2", "--warmup", "1",
-                "--cpu-seconds", "0", "--pmc", "off"] + argv
+                "--profile-run", "--clock-warm-ms", "0", "--pmc", "off"] + argv
+    problems = []
     for c in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_MFMA"):
         d = os.path.join(out, c)
         os.makedirs(d, exist_ok=True)
@@ -54,16 +58,19 @@ def main():
             if c == "SQ_INSTS_MFMA":      # matrix instructions per launch (per wave: 2048 flop each for v_mfma_f64_16x16x4)
                 res[k]["SQ_INSTS_MFMA_per_launch"] = acc[k] / n[k]
                 continue
+            per_step = n[k] / NSTEPS
+            if n[k] % NSTEPS and n[k] > NSTEPS:      # (kernels launched once, e.g. by the parity sample, are not per-step work)
+                problems.append("%s: %d launches in the %s pass are not a multiple of the %d steps" % (k, n[k], c, NSTEPS))
             res[k][c + "_KB_per_launch"] = acc[k] / n[k]
-            res[k][c + "_KB_per_step"] = acc[k] / NSTEPS
-            res[k]["launches_per_step"] = n[k] / NSTEPS
+            res[k][c + "_KB_per_step"] = acc[k] / n[k] * per_step
+            res[k]["launches_per_step"] = per_step
     for k, d in res.items():
         d["hbm_bytes_per_launch_raw"] = (d.get("FETCH_SIZE_KB_per_launch", 0) + d.get("WRITE_SIZE_KB_per_launch", 0)) * 1024
         d["hbm_bytes_per_step_raw"] = (d.get("FETCH_SIZE_KB_per_step", 0) + d.get("WRITE_SIZE_KB_per_step", 0)) * 1024
     res = dict(res)
     res["_meta"] = {"source_hash": bench.source_hash(), "collected": time.strftime("%Y-%m-%dT%H:%M:%SZ", time.gmtime()),
-                    "command": "bench.py --workload %s --steps 2 --warmup 1 --cpu-seconds 0 %s" % (w, " ".join(argv)),
-                    "steps_per_pass": NSTEPS}
+                    "command": "bench.py --workload %s --steps 2 --warmup 1 --profile-run --clock-warm-ms 0 %s" % (w, " ".join(argv)),
+                    "steps_per_pass": NSTEPS, "problems": problems}
     json.dump(res, open(os.path.join(out, "traffic.json"), "w"), indent=1)
     print(json.dumps(res, indent=1))
 

@@ -23,7 +23,7 @@ for spec in ${@:-convert convert_fixture convert_joint convert_broad estep estep
   rm -rf $out/pmc_$name
   steps=20; warm=5; [ $w = trajgv ] && { steps=5; warm=2; }     # as the driver's default run: two warm-up steps leave the clock ramping
   timeout 400 python3 $R/bench.py --workload $w --steps $steps --warmup $warm --pmc off $extra 2>/dev/null | tail -1 > $out/${name}_bench.json
-  timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_$name -- python3 $R/bench.py --workload $w --steps $steps --warmup $warm --cpu-seconds 0 --pmc off $extra > /dev/null 2>&1
+  timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_$name -- python3 $R/bench.py --workload $w --steps $steps --warmup $warm --profile-run --clock-warm-ms 0 $extra > /dev/null 2>&1
   f=$(find $out/prof_$name -name "*kernel_stats.csv" | head -1)
   [ -n "$f" ] && cp $f $out/${name}_kernel_stats.csv
   t=$(find $out/prof_$name -name "*kernel_trace.csv" | head -1)
