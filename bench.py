@@ -582,6 +582,23 @@ def bench_convert(args, world, rank, variant="synthetic"):
         for _ in range(3):
             vc.fvconvert(g, Xh, out=Yh)
         dtr = (time.perf_counter() - t0) / 3
+        # a caller that keeps its arrays pins them once (vcmi_host_register): DMA straight from x into y, no staging copy
+        try:
+            t0 = time.perf_counter()
+            vc.pin(Xh), vc.pin(Yh)
+            dpin = time.perf_counter() - t0
+            Yh[:] = 0.0
+            vc.fvconvert(g, Xh, out=Yh)
+            reg_equal = bool(np.array_equal(Yh.T, Yd.cpu().numpy()))
+            t0 = time.perf_counter()
+            for _ in range(3):
+                vc.fvconvert(g, Xh, out=Yh)
+            dtp = (time.perf_counter() - t0) / 3
+            vc.unpin(Yh), vc.unpin(Xh)
+            registered = {"value": T / dtp, "ms_per_call": dtp * 1e3, "pinning_both_arrays_once_ms": dpin * 1e3,
+                          "parity_vs_device_path": reg_equal}
+        except Exception as e:  # noqa: BLE001  (informative; never fail the bench on it)
+            registered = {"error": repr(e)}
         try:
             pcie = pcie_roof(Xh.nbytes)
             floor_ms = pcie["duplex_ms_for_2x%dMB" % (Xh.nbytes // 1_000_000)]
@@ -591,6 +608,8 @@ def bench_convert(args, world, rank, variant="synthetic"):
                                  "reused_output": {"value": T / dtr, "ms_per_call": dtr * 1e3,
                                                    "frac_of_pcie": (floor_ms / (dtr * 1e3)) if floor_ms else None},
                                  "frac_of_pcie": (floor_ms / (dth * 1e3)) if floor_ms else None,
+                                 "registered": dict(registered, frac_of_pcie=(floor_ms / registered["ms_per_call"])
+                                                    if (floor_ms and "ms_per_call" in registered) else None),
                                  "pcie": pcie,
                                  "releasing_one_result_ms": dfree * 1e3,
                                  "note": "vcmi_gmmmap_convert on pageable host arrays (what a Julia ccall passes): chunked "

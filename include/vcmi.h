@@ -23,6 +23,7 @@
  */
 #ifndef VCMI_H
 #define VCMI_H
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -57,6 +58,19 @@ int vcmi_set_device(int device);
  * useful to test the sharding on a 1-GPU box) except for the E-step, whose RCCL communicator needs distinct devices. */
 int vcmi_set_devices(const int *devices, int n);
 int vcmi_get_devices(int *devices, int capacity, int *n);
+
+/* Caller-pinned arrays.  A Julia process keeps its feature matrices across calls (src/common.jl:7-26: `vc(c, fm)` reads fm
+ * and returns `converted`; bin/vc.jl:82 calls it once per file on arrays it owns).  vcmi_host_register(ptr, bytes) page-locks
+ * [ptr, ptr + bytes) ONCE (hipHostRegister); from then on every host-pointer entry point whose dense input and / or output
+ * lies inside a registered range moves it by DMA straight between that array and HBM -- no staging slot, no host memcpy --
+ * (vcmi_gmmmap_convert, vcmi_vc_frames' input, vcmi_gmmmap_posterior / _predict: each side independently; a side that is
+ * not registered, or strided, keeps the staged path).  Arrays pinned by the caller's own runtime (hipHostMalloc /
+ * hipHostRegister) are recognised as well.  Results are identical either way.  vcmi_host_unregister(ptr) takes the pointer
+ * that was registered; an array must be unregistered before it is freed.  Ranges must not overlap (VCMI_ERR_ARG).
+ * vcmi_host_is_registered: *flag = 1 when the whole range would take the direct path. */
+int vcmi_host_register(void *ptr, size_t bytes);
+int vcmi_host_unregister(void *ptr);
+int vcmi_host_is_registered(const void *ptr, size_t bytes, int *flag);
 
 /* ---------------------------------------------------------------------------------------------
  * GMMMap -- src/gmmmap.jl:57-118, posterior helpers src/gmm.jl:24-58

@@ -432,3 +432,55 @@ def test_utterance_sized_calls_one_tile_per_wave(vc, T):
     Yh = vc.fvconvert(g, np.asfortranarray(X.T))                # host pointers: (D,T) Julia image
     assert frame_relerr(Yh[:, :300], ref.T) < TOL
     assert np.array_equal(Yh, got[0].cpu().numpy().T) or frame_relerr(Yh, got[0].cpu().numpy().T) < 1e-13
+
+
+@pytest.mark.parametrize("T", [1, 3000, 700_000])
+def test_pinned_arrays_take_the_direct_path_and_change_nothing(vc, fixture_model, T):
+    """vcmi_host_register (include/vcmi.h): a caller that keeps its arrays pins them once; the host-pointer calls then DMA
+    straight from / into them.  Results are bit-identical to the staged path, for either side alone and for both; the
+    registration is visible through vcmi_host_is_registered, overlapping ranges and unknown pointers are refused."""
+    w, mu, sig = julia_model(*fixture_model)
+    g = vc.GMMMap(w, mu, sig)
+    rng = np.random.default_rng(T)
+    X = np.asfortranarray(rng.standard_normal((40, T)) * 0.3)
+    Y0 = vc.fvconvert(g, X)                                   # staged: nothing pinned
+    Xp, Yp = X.copy(order="F"), np.empty_like(X, order="F")
+    assert not vc.is_pinned(Xp)
+    vc.pin(Xp)
+    try:
+        assert vc.is_pinned(Xp) and not vc.is_pinned(Yp)
+        with pytest.raises(vc.VCMIError):
+            vc.pin(Xp)                                        # overlapping range
+        assert np.array_equal(vc.fvconvert(g, Xp), Y0)        # input direct, output staged
+        vc.pin(Yp)
+        try:
+            vc.fvconvert(g, Xp, out=Yp)                       # both direct
+            assert np.array_equal(Yp, Y0)
+            Yp[:] = 0.0
+            vc.fvconvert(g, X, out=Yp)                        # input staged, output direct
+            assert np.array_equal(Yp, Y0)
+            P0 = vc.predict_proba(g.px, X)
+            assert np.array_equal(vc.predict_proba(g.px, Xp), P0)
+            assert np.array_equal(vc.predict(g.px, Xp), vc.predict(g.px, X))
+        finally:
+            vc.unpin(Yp)
+    finally:
+        vc.unpin(Xp)
+    assert not vc.is_pinned(Xp)
+    with pytest.raises(vc.VCMIError):
+        vc.unpin(Xp)                                          # not registered (any more)
+    assert np.array_equal(vc.fvconvert(g, Xp), Y0)            # ... and the array still converts, staged again
+
+
+def test_torch_pinned_memory_is_recognised(vc, fixture_model):
+    """Host memory pinned by the caller's own runtime (here torch's pin_memory = hipHostMalloc) is found through the HIP
+    runtime's pointer attributes: no registration call needed."""
+    import torch
+    w, mu, sig = julia_model(*fixture_model)
+    g = vc.GMMMap(w, mu, sig)
+    T = 300_000
+    xt = (torch.randn(T, 40, dtype=torch.float64) * 0.3).pin_memory()
+    X = xt.numpy().T                                          # (40,T) Fortran view of the pinned storage
+    assert X.flags.f_contiguous and vc.is_pinned(X)
+    Y0 = vc.fvconvert(g, np.asfortranarray(X.copy()))
+    assert np.array_equal(vc.fvconvert(g, X), Y0)

@@ -24,7 +24,7 @@ def c_class(t):
     t = re.sub(r"\b[A-Za-z_][A-Za-z0-9_]*$", "", t).strip() if not t.endswith("*") and " " in t else t   # drop the name
     t = t.replace("const ", "").replace(" const", "").replace(" ", "")
     table = {"double*": "f64*", "int64_t*": "i64*", "double**": "f64**", "int64_t**": "i64**", "int": "i32", "int64_t": "i64",
-             "double": "f64", "void*": "void*", "int*": "i32*", "char*": "char*", "void": "void"}
+             "double": "f64", "void*": "void*", "int*": "i32*", "char*": "char*", "void": "void", "size_t": "u64"}
     if t in table:
         return table[t]
     m = re.fullmatch(r"(vcmi_[a-z_]+)(\*+)", t)
@@ -50,7 +50,7 @@ def header_prototypes():
 def ctypes_class(t):
     if t is None:
         return "void"
-    table = {C.c_int: "i32", C.c_int64: "i64", C.c_double: "f64", C.c_void_p: "void*", C.c_char_p: "char*",
+    table = {C.c_int: "i32", C.c_int64: "i64", C.c_double: "f64", C.c_void_p: "void*", C.c_char_p: "char*", C.c_size_t: "u64",
              C.POINTER(C.c_double): "f64*", C.POINTER(C.c_int64): "i64*", C.POINTER(C.c_int): "i32*",
              C.POINTER(C.POINTER(C.c_double)): "f64**", C.POINTER(C.POINTER(C.c_int64)): "i64**", C.POINTER(C.c_void_p): "void**"}
     return table[t]
@@ -114,7 +114,7 @@ def balanced(text, start):
 JL_TYPES = {"Cint": "i32", "Int64": "i64", "Cdouble": "f64", "Float64": "f64", "Cstring": "char*", "Ptr{Cvoid}": "void*",
             "Ptr{Float64}": "f64*", "Ref{Float64}": "f64*", "Ptr{Int64}": "i64*", "Ref{Int64}": "i64*", "Ptr{Cint}": "i32*",
             "Ref{Cint}": "i32*", "Ptr{Ptr{Float64}}": "f64**", "Ptr{Ptr{Int64}}": "i64**", "Ref{Ptr{Cvoid}}": "void**",
-            "Cvoid": "void"}
+            "Cvoid": "void", "Csize_t": "u64"}
 
 
 def julia_ccalls(text):

@@ -38,6 +38,18 @@ def main():
         X = sd.sample_frames(7, w, mu, sig, T, 0, 40)
         Xj = np.asfortranarray(X.T)               # Julia (D,T) image
         out[f"fvconvert_T{T}"] = med(lambda: vc.fvconvert(g, Xj))
+    # the other users of the direct small-call path: posterior (the finishing kernel re-reads and re-writes the
+    # pinned output), predict, vc (a pinned-to-pinned copy in front of the kernel), at the sizes around the direct limit
+    for T in (100, 500, 2000, 3000):
+        X = sd.sample_frames(7, w, mu, sig, T, 0, 40)
+        Xj = np.asfortranarray(X.T)
+        fm = np.asfortranarray(np.vstack([np.ones((1, T)), Xj]))
+        out[f"predict_proba_T{T}"] = med(lambda: vc.predict_proba(g.px, Xj))
+        out[f"predict_T{T}"] = med(lambda: vc.predict(g.px, Xj))
+        out[f"vc_T{T}"] = med(lambda: vc.vc(g, fm))
+    if os.environ.get("SMALL_CALLS_ONLY"):
+        print(json.dumps(out, indent=1))
+        return
     wt, mut, sigt = sd.synth_model(1005, 160, 64)
     gt = vc.GMMMap(*bench.julia_model(wt, mut, sigt))
     for T in (100, 500, 2000):

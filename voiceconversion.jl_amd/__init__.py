@@ -3,8 +3,8 @@
 Host-side mirror of the reference's exported API (src/VoiceConversion.jl:12-38) over the C-ABI of
 libvcmi.so (include/vcmi.h).  The directory name contains a dot, so the package is imported through the
 root-level shim `voiceconversion_jl_amd` (see voiceconversion_jl_amd.py)."""
-from ._lib import (DimensionMismatch, PosDefException, VCMIError, device_count, get_devices, set_device,  # noqa: F401
-                   set_devices)
+from ._lib import (DimensionMismatch, PosDefException, VCMIError, device_count, get_devices, is_pinned, pin,  # noqa: F401
+                   set_device, set_devices, unpin)
 from .common import (AbstractConverter, FrameByFrameConverter, TrajectoryConverter, dim, fvconvert,  # noqa: F401
                      ncomponents, size, vc)
 from .gmm import GMM, predict, predict_proba  # noqa: F401

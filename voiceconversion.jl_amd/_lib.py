@@ -54,6 +54,9 @@ SIGNATURES = {
     "vcmi_set_device": (_int, [_int]),
     "vcmi_set_devices": (_int, [C.POINTER(_int), _int]),
     "vcmi_get_devices": (_int, [C.POINTER(_int), _int, C.POINTER(_int)]),
+    "vcmi_host_register": (_int, [_vp, C.c_size_t]),
+    "vcmi_host_unregister": (_int, [_vp]),
+    "vcmi_host_is_registered": (_int, [_vp, C.c_size_t, C.POINTER(_int)]),
     "vcmi_gmmmap_create": (_int, [_dp, _dp, _dp, _int, _int, _int, C.POINTER(_vp)]),
     "vcmi_gmmmap_destroy": (_int, [_vp]),
     "vcmi_gmmmap_dim": (_int, [_vp]),
@@ -161,6 +164,23 @@ def get_devices():
     arr = (_int * 64)()
     check(lib.vcmi_get_devices(arr, 64, C.byref(n)))
     return [arr[i] for i in range(n.value)]
+
+
+def pin(a):
+    """Page-lock a host array once (vcmi_host_register): calls that pass it afterwards DMA straight from / into it.
+    The array must stay alive and must be unpinned before it is freed; returns the array."""
+    check(lib.vcmi_host_register(a.ctypes.data, a.nbytes))
+    return a
+
+
+def unpin(a):
+    check(lib.vcmi_host_unregister(a.ctypes.data))
+
+
+def is_pinned(a):
+    f = _int(0)
+    check(lib.vcmi_host_is_registered(a.ctypes.data, a.nbytes, C.byref(f)))
+    return bool(f.value)
 
 
 # Test hook (NOT part of include/vcmi.h; inert unless VCMI_TEST_HOOKS=1 is in the environment when the library first sees

@@ -157,7 +157,9 @@ class Pool {
 
  private:
   Pool() {
-    if (sched_getaffinity(0, sizeof(inherited_), &inherited_) != 0) {
+    // the PROCESS mask (the main thread's: its tid is the pid), not the mask of whichever thread happens to touch the pool
+    // first -- a pinned OpenMP / dataloader / Julia thread would confine every copy worker to its one or two CPUs
+    if (sched_getaffinity(getpid(), sizeof(inherited_), &inherited_) != 0) {
       CPU_ZERO(&inherited_);
       for (int k = 0; k < CPU_SETSIZE; ++k) CPU_SET(k, &inherited_);
     }
@@ -200,7 +202,7 @@ class Pool {
   std::condition_variable cv_;
   std::deque<Task> q_;
   int nworkers_ = 0;
-  cpu_set_t inherited_;      // affinity of the thread that created the pool: the workers stay inside it
+  cpu_set_t inherited_;      // affinity of the process (its main thread): the workers stay inside it
 };
 
 }  // namespace
@@ -516,6 +518,85 @@ size_t total_bytes(const std::vector<HostPiece> &pieces) {
 
 }  // namespace
 
+// ------------------------------------------------------------------------------------------------
+// caller-pinned memory (vcmi_host_register): ranges the DMA engines reach without a staging copy
+// ------------------------------------------------------------------------------------------------
+namespace {
+struct PinnedRange {
+  uintptr_t base;
+  size_t bytes;
+};
+std::mutex g_pinned_mu;
+std::vector<PinnedRange> g_pinned;      // ranges registered through vcmi_host_register (few: linear scan)
+
+// [p, p + bytes) lies in memory the DMA engines can address: a range registered here, or host memory another party pinned
+// (hipHostMalloc / hipHostRegister by the caller's runtime: torch's pin_memory, a Julia AMDGPU.jl pinned array) that the HIP
+// runtime knows.  VCMI_HOST_PINNED=0 (read once) switches the detection off (A/B: every call stages).
+bool range_is_pinned(const void *p, size_t bytes) {
+  static const bool enabled = [] {
+    const char *e = getenv("VCMI_HOST_PINNED");
+    return !(e && e[0] == '0');
+  }();
+  if (!enabled || !p || bytes == 0) return false;
+  const uintptr_t a = (uintptr_t)p;
+  {
+    std::lock_guard<std::mutex> lk(g_pinned_mu);
+    for (const PinnedRange &r : g_pinned)
+      if (a >= r.base && a + bytes <= r.base + r.bytes) return true;
+  }
+  hipPointerAttribute_t at;
+  if (hipPointerGetAttributes(&at, p) != hipSuccess) {
+    (void)hipGetLastError();            // an ordinary pageable pointer: not an error of this call
+    return false;
+  }
+  if (at.type != hipMemoryTypeHost) return false;
+  // the runtime reports the allocation the pointer lies in, not its extent: the last byte must be known to it as well
+  hipPointerAttribute_t at2;
+  if (hipPointerGetAttributes(&at2, (const char *)p + bytes - 1) != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  return at2.type == hipMemoryTypeHost;
+}
+}  // namespace
+
+int host_register(void *p, size_t bytes) {
+  if (!p || bytes == 0) return fail(VCMI_ERR_ARG, "vcmi_host_register: NULL pointer or zero length");
+  {
+    std::lock_guard<std::mutex> lk(g_pinned_mu);
+    for (const PinnedRange &r : g_pinned)
+      if ((uintptr_t)p < r.base + r.bytes && r.base < (uintptr_t)p + bytes)
+        return fail(VCMI_ERR_ARG, "vcmi_host_register: the range overlaps one that is already registered");
+  }
+  const hipError_t e = hipHostRegister(p, bytes, hipHostRegisterPortable);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    return fail(e == hipErrorOutOfMemory ? VCMI_ERR_OOM : VCMI_ERR_HIP, "hipHostRegister of %zu bytes failed: %s", bytes,
+                hipGetErrorString(e));
+  }
+  std::lock_guard<std::mutex> lk(g_pinned_mu);
+  g_pinned.push_back(PinnedRange{(uintptr_t)p, bytes});
+  return VCMI_OK;
+}
+
+int host_unregister(void *p) {
+  {
+    std::lock_guard<std::mutex> lk(g_pinned_mu);
+    auto it = std::find_if(g_pinned.begin(), g_pinned.end(), [p](const PinnedRange &r) { return r.base == (uintptr_t)p; });
+    if (it == g_pinned.end()) return fail(VCMI_ERR_ARG, "vcmi_host_unregister: %p was not registered with vcmi_host_register", p);
+    g_pinned.erase(it);
+  }
+  // transfers of earlier calls are complete (every host-pointer entry point returns with its data delivered)
+  const hipError_t e = hipHostUnregister(p);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    return fail(VCMI_ERR_HIP, "hipHostUnregister failed: %s", hipGetErrorString(e));
+  }
+  return VCMI_OK;
+}
+
+int host_is_registered(const void *p, size_t bytes) { return range_is_pinned(p, bytes) ? 1 : 0; }
+
 int staged_upload(void *dDst, const void *hSrc, size_t bytes, hipStream_t consumer) {
   Ring *r = nullptr;
   VCMI_TRY(current_ring(&r));
@@ -577,6 +658,10 @@ int staged_pipeline(const void *hIn, size_t in_unit, size_t in_stride, void *hOu
     host_copy_rows(hOut, out_stride, r->pin_out[0], out_unit, out_unit, units);
     return VCMI_OK;
   }
+  // A side whose array is PINNED (vcmi_host_register, or pinned by the caller's own runtime) and dense needs no staging copy:
+  // the DMA engines read the caller's x / write the caller's y themselves.  The two sides are independent.
+  const bool in_direct = in_stride == in_unit && range_is_pinned(hIn, (size_t)units * in_unit);
+  const bool out_direct = out_stride == out_unit && range_is_pinned(hOut, (size_t)units * out_unit);
   const size_t wide = std::max(in_unit, out_unit);
   static const size_t pipe_chunk = [] {          // A/B hook, read once: VCMI_HOST_CHUNK_MB (default: kPipeChunk)
     const char *e = getenv("VCMI_HOST_CHUNK_MB");
@@ -599,12 +684,17 @@ int staged_pipeline(const void *hIn, size_t in_unit, size_t in_stride, void *hOu
       return !(e && e[0] == '0');
     }();
     if (ramp && nch >= 6) {
-      const int64_t q = std::max<int64_t>(256, chunk / 4 / 256 * 256), h = std::max<int64_t>(256, chunk / 2 / 256 * 256);
-      int64_t pos = 0;
-      const int64_t tail = q + h;                          // units of the two short chunks at the end
-      for (int64_t step : {q, h}) {
+      // staged sides: 1/4, 1/2 (a host copy per chunk: shorter ones pay their hand-overs for nothing); both sides pinned:
+      // nothing but stream hand-overs per chunk, so the ramps start at 1/16 (7.5 -> 7.2 ms per 10^6 frames)
+      int64_t steps[4];
+      int ns = 0;
+      for (int64_t div : {16, 8, 4, 2})
+        if (div <= 4 || (in_direct && out_direct)) steps[ns++] = std::max<int64_t>(256, chunk / div / 256 * 256);
+      int64_t pos = 0, tail = 0;
+      for (int i = 0; i < ns; ++i) tail += steps[i];      // units of the short chunks at the end
+      for (int i = 0; i < ns; ++i) {
         start.push_back(pos);
-        pos += step;
+        pos += steps[i];
       }
       while (units - pos > tail + chunk) {
         start.push_back(pos);
@@ -620,9 +710,10 @@ int staged_pipeline(const void *hIn, size_t in_unit, size_t in_stride, void *hOu
         start.push_back(pos);
         pos = units - tail;
       }
-      start.push_back(pos);
-      pos += h;
-      start.push_back(pos);
+      for (int i = ns - 1; i >= 0; --i) {
+        start.push_back(pos);
+        pos += steps[i];
+      }
       start.push_back(units);
     } else {
       for (int64_t c = 0; c < nch; ++c) start.push_back(c * chunk);
@@ -630,8 +721,8 @@ int staged_pipeline(const void *hIn, size_t in_unit, size_t in_stride, void *hOu
     }
     nch = (int64_t)start.size() - 1;
   }
-  VCMI_TRY(r->reserve(r->pin_in, r->pin_in_cap, (size_t)chunk * in_unit, true));
-  VCMI_TRY(r->reserve(r->pin_out, r->pin_out_cap, (size_t)chunk * out_unit, true));
+  if (!in_direct) VCMI_TRY(r->reserve(r->pin_in, r->pin_in_cap, (size_t)chunk * in_unit, true));
+  if (!out_direct) VCMI_TRY(r->reserve(r->pin_out, r->pin_out_cap, (size_t)chunk * out_unit, true));
   VCMI_TRY(r->reserve(r->dev_in, r->dev_in_cap, (size_t)chunk * in_unit, false));
   VCMI_TRY(r->reserve(r->dev_out, r->dev_out_cap, (size_t)chunk * out_unit, false));
   VCMI_TRY(r->quiesce());
@@ -640,7 +731,7 @@ int staged_pipeline(const void *hIn, size_t in_unit, size_t in_stride, void *hOu
   std::shared_ptr<Latch> prefault;     // joined before this function returns, on the error path too
   {
     const size_t span = (size_t)(units - 1) * out_stride + out_unit, huge = (size_t)2 << 20;
-    if (span >= 16 * huge) {
+    if (!out_direct && span >= 16 * huge) {      // (a pinned output has its pages already)
       const uintptr_t a = ((uintptr_t)hOut + huge - 1) & ~(uintptr_t)(huge - 1), b = ((uintptr_t)hOut + span) & ~(uintptr_t)(huge - 1);
       if (b > a) (void)madvise(reinterpret_cast<void *>(a), b - a, MADV_HUGEPAGE);
     }
@@ -653,7 +744,7 @@ int staged_pipeline(const void *hIn, size_t in_unit, size_t in_stride, void *hOu
       const char *e = getenv("VCMI_HOST_POPULATE");      // read once; "0" switches the pre-faulting off
       return !(e && e[0] == '0');
     }();
-    if (populate && span >= 4 * huge) {
+    if (populate && !out_direct && span >= 4 * huge) {
       char *base = reinterpret_cast<char *>(hOut);
       constexpr size_t piece = (size_t)8 << 20;
       prefault = host_async_for((int64_t)((span + piece - 1) / piece), 1, [base, span](int64_t lo, int64_t hi) {
@@ -678,10 +769,14 @@ int staged_pipeline(const void *hIn, size_t in_unit, size_t in_stride, void *hOu
       if (c < nch) {
         const int s = (int)(c % K);
         const int64_t first = start[(size_t)c], n = start[(size_t)c + 1] - first;
-        if (c >= K) VCMI_HIP(hipEventSynchronize(r->ev_up[s]));                 // pinned slot: upload of chunk c-K done
-        host_copy_rows(r->pin_in[s], in_unit, (const char *)hIn + (size_t)first * in_stride, in_stride, in_unit, n);
+        const char *src = (const char *)hIn + (size_t)first * in_stride;
+        if (!in_direct) {
+          if (c >= K) VCMI_HIP(hipEventSynchronize(r->ev_up[s]));               // pinned slot: upload of chunk c-K done
+          host_copy_rows(r->pin_in[s], in_unit, src, in_stride, in_unit, n);
+          src = r->pin_in[s];
+        }
         if (c >= K) VCMI_HIP(hipStreamWaitEvent(r->up, r->ev_run[s], 0));        // device slot: kernels of chunk c-K done
-        VCMI_HIP(hipMemcpyAsync(r->dev_in[s], r->pin_in[s], (size_t)n * in_unit, hipMemcpyHostToDevice, r->up));
+        VCMI_HIP(hipMemcpyAsync(r->dev_in[s], src, (size_t)n * in_unit, hipMemcpyHostToDevice, r->up));
         VCMI_HIP(hipEventRecord(r->ev_up[s], r->up));
         VCMI_HIP(hipStreamWaitEvent(r->run, r->ev_up[s], 0));
         if (c >= K) VCMI_HIP(hipStreamWaitEvent(r->run, r->ev_down[s], 0));      // output slot: download of chunk c-K done
@@ -689,10 +784,15 @@ int staged_pipeline(const void *hIn, size_t in_unit, size_t in_stride, void *hOu
         VCMI_HIP(hipEventRecord(r->ev_run[s], r->run));
         VCMI_HIP(hipStreamWaitEvent(r->down, r->ev_run[s], 0));
         // pin_out[s] was drained by the host LAG < K iterations ago
-        VCMI_HIP(hipMemcpyAsync(r->pin_out[s], r->dev_out[s], (size_t)n * out_unit, hipMemcpyDeviceToHost, r->down));
+        VCMI_HIP(hipMemcpyAsync(out_direct ? (char *)hOut + (size_t)first * out_stride : r->pin_out[s], r->dev_out[s],
+                                (size_t)n * out_unit, hipMemcpyDeviceToHost, r->down));
         VCMI_HIP(hipEventRecord(r->ev_down[s], r->down));
       }
       const int64_t j = c - LAG;
+      if (out_direct) {
+        if (j == nch - 1) VCMI_HIP(hipStreamSynchronize(r->down));               // the caller's y is complete on return
+        continue;
+      }
       if (j >= 0 && j < nch) {
         const int s = (int)(j % K);
         const int64_t first = start[(size_t)j], n = start[(size_t)j + 1] - first;

@@ -41,4 +41,10 @@ using ChunkLaunch = std::function<int(const void *dIn, void *dOut, int64_t first
 int staged_pipeline(const void *hIn, size_t in_unit, size_t in_stride, void *hOut, size_t out_unit, size_t out_stride,
                     int64_t units, int64_t min_chunk_units, const ChunkLaunch &launch);
 
+// Caller-pinned arrays (include/vcmi.h: vcmi_host_register).  staged_pipeline moves a dense side that lies in pinned memory
+// straight between the caller's array and HBM: no staging slot, no host memcpy.
+int host_register(void *p, size_t bytes);
+int host_unregister(void *p);
+int host_is_registered(const void *p, size_t bytes);
+
 }  // namespace vcmi

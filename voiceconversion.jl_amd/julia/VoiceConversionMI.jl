@@ -24,7 +24,7 @@ export FrameByFrameConverter, TrajectoryConverter, GMMMapParam, GMMMap, Trajecto
        align, align_mcep, push_delta, GVDataset,
        DTW, fit!, update!, set_template!, backward,
        predict_proba, predict_proba!, predict, predict!, diffgmm,
-       estep_diag, estep_full, GMMEM, estep!, mstep!, params, set_devices, device_count, set_prune!, convert_plan
+       estep_diag, estep_full, GMMEM, estep!, mstep!, params, set_devices, device_count, set_prune!, convert_plan, pin!, unpin!, ispinned
 
 const libvcmi = get(ENV, "LIBVCMI", "libvcmi")
 
@@ -50,6 +50,29 @@ end
 function set_devices(devices)
     d = Cint[Cint(x) for x in devices]
     check(ccall((:vcmi_set_devices, libvcmi), Cint, (Ptr{Cint}, Cint), d, length(d)))
+end
+
+# Page-lock an array this process keeps across calls (vcmi_host_register): fvconvert / vc / predict_proba on it then DMA
+# straight from / into it -- no staging copy (include/vcmi.h).  pin!(X) returns X and unpins it when X is finalized;
+# unpin!(X) does it now.  Results are identical with and without.
+const PINNED = Set{UInt}()          # addresses, not the arrays: the table must not keep them alive
+function pin!(X::Array{Float64})
+    UInt(pointer(X)) in PINNED && return X
+    check(ccall((:vcmi_host_register, libvcmi), Cint, (Ptr{Cvoid}, Csize_t), X, sizeof(X)))
+    push!(PINNED, UInt(pointer(X)))
+    finalizer(unpin!, X)
+    X
+end
+function unpin!(X::Array{Float64})
+    UInt(pointer(X)) in PINNED || return X
+    delete!(PINNED, UInt(pointer(X)))
+    check(ccall((:vcmi_host_unregister, libvcmi), Cint, (Ptr{Cvoid},), X))
+    X
+end
+function ispinned(X::Array{Float64})
+    f = Ref{Cint}(0)
+    check(ccall((:vcmi_host_is_registered, libvcmi), Cint, (Ptr{Cvoid}, Csize_t, Ptr{Cint}), X, sizeof(X), f))
+    f[] != 0
 end
 
 abstract type AbstractConverter end                                    # src/common.jl:2-4
@@ -159,7 +182,8 @@ function convert_plan(g::GMMMap)
     issued = Ref{Int64}(0); shape = Ref{Cint}(0); active = Ref{Float64}(0.0); undecided = Ref{Float64}(0.0)
     check(ccall((:vcmi_gmmmap_convert_plan, libvcmi), Cint, (Ptr{Cvoid}, Ptr{Int64}, Ptr{Cint}, Ptr{Float64}, Ptr{Float64}),
                 g.h, issued, shape, active, undecided))
-    (Int(shape[]), active[], undecided[], issued[])
+    # the C argument order, which is also what Python's GMMMap.convert_plan returns; named, so that no caller indexes by position
+    (issued = issued[], shape = Int(shape[]), active = active[], undecided = undecided[])
 end
 
 # fvconvert(g, x) -- src/gmmmap.jl:101-118
