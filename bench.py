@@ -1185,7 +1185,7 @@ def compact_line(out, table):
     b = out.get("cpu_baseline")
     if isinstance(b, dict):
         c["cpu_baseline"] = {k: (_sig(v) if not isinstance(v, str) else v[:160]) for k, v in b.items()}
-    for k in ("parity_max_rel_err_vs_oracle", "parity_bit_exact_vs_oracle", "speedup_vs_cpu_baseline", "allreduce_exact", "allreduce_check", "debug_force",
+    for k in ("parity_max_rel_err_vs_oracle", "parity_bit_exact_vs_oracle", "speedup_vs_cpu_baseline", "allreduce_exact", "allreduce_check", "debug_force", "probe_library",
               "collective_backend", "library_source_hash", "loglik_monotone"):
         if out.get(k) is not None:
             c[k] = _sig(out[k])
@@ -1425,6 +1425,8 @@ def main():
     out["library_source_hash"] = source_hash()
     if args.debug_force:
         out["debug_force"] = args.debug_force      # not a product configuration
+    if os.environ.get("LIBVCMI_PROBE"):
+        out["probe_library"] = os.environ["LIBVCMI_PROBE"]      # an A/B or probe build, not the in-tree library
     if rank == 0:
         out["detail"] = write_detail(out, "bench_detail_%s_n%d.json" % (args.workload, world))
         print(compact_line(out, table), flush=True)

@@ -6,7 +6,6 @@
 # Box-to-box spread is ~3 %, run-to-run on one box ~0.2 %: differences of a per cent are only visible this way.
 names=$1; shift
 for v in $names; do
-  cp tools/_lib_$v.so voiceconversion.jl_amd/libvcmi.so
   echo -n "$v: "
-  python bench.py "$@" --cpu-seconds 1 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('%.4f ms' % d['ms_per_step'], 'frac %.4f' % d['roofline']['frac'], 'err', d.get('parity_max_rel_err_vs_oracle'))"
+  LIBVCMI_PROBE=tools/_lib_$v.so python bench.py "$@" --cpu-seconds 1 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('%.4f ms' % d['ms_per_step'], 'frac %.4f' % d['roofline']['frac'], 'err', d.get('parity_max_rel_err_vs_oracle'))"
 done

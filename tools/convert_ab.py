@@ -94,13 +94,9 @@ def main():
     ap.add_argument("--child", action="store_true")
     args = ap.parse_args()
     if args.libs and not args.child:
-        import shutil
-
-        target = os.path.join(ROOT, "voiceconversion.jl_amd", "libvcmi.so")
-        for lib in args.libs.split(","):
-            shutil.copy(os.path.join(ROOT, lib), target)
+        for lib in args.libs.split(","):             # selected through LIBVCMI_PROBE: the in-tree library is never overwritten
             p = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", "--frames", str(args.frames), "--steps", str(args.steps)],
-                               capture_output=True, text=True)
+                               capture_output=True, text=True, env=dict(os.environ, LIBVCMI_PROBE=os.path.join(ROOT, lib)))
             print("==", lib)
             try:
                 d = json.loads(p.stdout.strip().splitlines()[-1])

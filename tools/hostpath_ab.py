@@ -49,12 +49,7 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "--child":
         child()
     else:
-        target = os.path.join(ROOT, "voiceconversion.jl_amd", "libvcmi.so")
-        keep = target + ".keep"
-        shutil.copy(target, keep)
-        for lib in sys.argv[1].split(","):
-            shutil.copy(os.path.join(ROOT, lib), target)
-            p = subprocess.run([sys.executable, os.path.abspath(__file__), "--child"], capture_output=True, text=True)
+        for lib in sys.argv[1].split(","):           # selected through LIBVCMI_PROBE: the in-tree library is never overwritten
+            p = subprocess.run([sys.executable, os.path.abspath(__file__), "--child"], capture_output=True, text=True,
+                               env=dict(os.environ, LIBVCMI_PROBE=os.path.join(ROOT, lib)))
             print("==", lib, p.stdout.strip().splitlines()[-1] if p.stdout.strip() else p.stderr[-1500:])
-        shutil.copy(keep, target)
-        os.remove(keep)

@@ -8,6 +8,12 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libvcmi.so")
+# A/B and probe builds (tools/ab_swap.sh, tools/convert_ab.py, tools/*_prof.sh) are SELECTED through this variable, never
+# copied over the in-tree library (an interrupted tool left tests and bench running a probe build).  bench.py
+# marks a line produced with it (`probe_library`).
+PROBE = os.environ.get("LIBVCMI_PROBE")
+if PROBE:
+    LIB_PATH = os.path.abspath(PROBE)
 
 
 class DimensionMismatch(ValueError):
