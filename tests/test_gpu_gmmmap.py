@@ -346,10 +346,11 @@ def test_frame_grouping_changes_nothing_visible(vc, D, M, T, lam_lo):
 
 @pytest.mark.parametrize("which", ["synthetic", "broad", "fixture"])
 def test_loop_shapes_agree_and_the_model_picks_one(vc, fixture_model, which):
-    """gmmmap_mfma_kernel has three code shapes for fvconvert (include/vcmi.h: vcmi_gmmmap_convert_plan): 0 dense
-    (set_prune(inf)), 1 "broad" (every whitening tile, one branch around the regression), 2 "peaked" (last whitening tile
-    first).  Which of 1 / 2 runs is a property of the MODEL, estimated at creation from 256 frames drawn from it; the test
-    hook forces either.  All of them give the dense loop's y to rounding and the oracle's to TOL; the counters add up."""
+    """fvconvert has four code shapes (include/vcmi.h: vcmi_gmmmap_convert_plan): 0 dense (set_prune(inf)), 1 "broad" (every
+    whitening tile, one branch around the regression), 2 "peaked" (last whitening tile first), 3 "screened" (gmmmap_screen.hpp:
+    four mixtures screened per MFMA tile on their last four whitening rows, survivors evaluated in full; grouped calls).
+    Which of 1 / 2 / 3 runs is a property of the MODEL, estimated at creation from 256 frames drawn from it; the test
+    hook forces any.  All of them give the dense loop's y to rounding and the oracle's to TOL; the counters add up."""
     import torch
     from oracle import c_oracle as co, np_oracle as npo
     from voiceconversion_jl_amd import _lib
@@ -358,7 +359,7 @@ def test_loop_shapes_agree_and_the_model_picks_one(vc, fixture_model, which):
         expect = 1
     else:
         w, mu, sig = npo.synth_model(1002, 80, 64, lam_lo=1e-5 if which == "synthetic" else 1e-1)
-        expect = 2 if which == "synthetic" else 1
+        expect = 3 if which == "synthetic" else 1
     M, T, D = len(w), 20000, 40
     X = npo.sample_frames(9, w, mu, sig, T, 0, D)
     Xd = torch.from_numpy(X).cuda()
@@ -385,7 +386,7 @@ def test_loop_shapes_agree_and_the_model_picks_one(vc, fixture_model, which):
     assert float((torch.linalg.norm(Yw - Yd, dim=1) / torch.linalg.norm(Yd, dim=1)).max()) < 1e-13
     g.set_prune(46.0)
     ref = co.GMMMap(w, mu, sig).fvconvert(X[:400])
-    for force in (_lib.DBG_CONVERT_SHAPE_BROAD, _lib.DBG_CONVERT_SHAPE_PEAKED, 0):
+    for force in (_lib.DBG_CONVERT_SHAPE_BROAD, _lib.DBG_CONVERT_SHAPE_PEAKED, _lib.DBG_CONVERT_SHAPE_SCREENED, 0):
         _lib.debug_force(force)
         try:
             g.prune_stats(True)
@@ -394,8 +395,9 @@ def test_loop_shapes_agree_and_the_model_picks_one(vc, fixture_model, which):
             n_reg = g.prune_stats(False)
         finally:
             _lib.debug_force(0)
-        assert sh == (1 if force == _lib.DBG_CONVERT_SHAPE_BROAD else 2 if force == _lib.DBG_CONVERT_SHAPE_PEAKED else expect)
-        assert 0 < n_issued <= issued and 0 < n_reg <= tiles * M
+        assert sh == {_lib.DBG_CONVERT_SHAPE_BROAD: 1, _lib.DBG_CONVERT_SHAPE_PEAKED: 2, _lib.DBG_CONVERT_SHAPE_SCREENED: 3, 0: expect}[force]
+        # (shape 3 on a broad model: nearly every mixture survives the four-row screen, so the screen comes on top of the dense work)
+        assert 0 < n_issued <= issued * (1.1 if sh == 3 else 1.0) and 0 < n_reg <= tiles * M
         err = float((torch.linalg.norm(Y - Yd, dim=1) / torch.linalg.norm(Yd, dim=1)).max())
         assert err < 1e-13, (force, err)
         assert frame_relerr(Y[:400].cpu().numpy().T, ref.T) < TOL
@@ -437,13 +439,16 @@ def test_utterance_sized_calls_one_tile_per_wave(vc, T):
 @pytest.mark.parametrize("T", [1, 3000, 700_000])
 def test_pinned_arrays_take_the_direct_path_and_change_nothing(vc, fixture_model, T):
     """vcmi_host_register (include/vcmi.h): a caller that keeps its arrays pins them once; the host-pointer calls then DMA
-    straight from / into them.  Results are bit-identical to the staged path, for either side alone and for both; the
+    straight from / into them.  Results equal the staged path's, for either side alone and for both -- bit for bit where
+    the pipeline's chunks are the same, to rounding where they are not (with both sides pinned the first and last chunks are
+    shorter, and a chunk's frames are grouped among themselves: tile compositions differ on a broad model); the
     registration is visible through vcmi_host_is_registered, overlapping ranges and unknown pointers are refused."""
     w, mu, sig = julia_model(*fixture_model)
     g = vc.GMMMap(w, mu, sig)
     rng = np.random.default_rng(T)
     X = np.asfortranarray(rng.standard_normal((40, T)) * 0.3)
     Y0 = vc.fvconvert(g, X)                                   # staged: nothing pinned
+    same = lambda A, B: frame_relerr(A, B) < 1e-13            # noqa: E731
     Xp, Yp = X.copy(order="F"), np.empty_like(X, order="F")
     assert not vc.is_pinned(Xp)
     vc.pin(Xp)
@@ -455,7 +460,10 @@ def test_pinned_arrays_take_the_direct_path_and_change_nothing(vc, fixture_model
         vc.pin(Yp)
         try:
             vc.fvconvert(g, Xp, out=Yp)                       # both direct
-            assert np.array_equal(Yp, Y0)
+            assert same(Yp, Y0)
+            Yb = Yp.copy()
+            vc.fvconvert(g, Xp, out=Yp)
+            assert np.array_equal(Yp, Yb)                     # repeat runs of one path: bit-identical
             Yp[:] = 0.0
             vc.fvconvert(g, X, out=Yp)                        # input staged, output direct
             assert np.array_equal(Yp, Y0)
@@ -484,3 +492,55 @@ def test_torch_pinned_memory_is_recognised(vc, fixture_model):
     assert X.flags.f_contiguous and vc.is_pinned(X)
     Y0 = vc.fvconvert(g, np.asfortranarray(X.copy()))
     assert np.array_equal(vc.fvconvert(g, X), Y0)
+
+
+@pytest.mark.parametrize("D,M,T,lam_lo", [(40, 64, 200_000, 1e-5), (40, 64, 9000, 1e-5), (40, 67, 40_000, 1e-4), (24, 9, 33_000, 1e-5),
+                                          (16, 4, 8200, 1e-5), (47, 33, 50_000, 1e-5), (40, 130, 35_000, 1e-5), (40, 32, 70_000, 1e-1)])
+def test_screened_shape_against_dense_and_oracle(vc, D, M, T, lam_lo):
+    """Shape 3 (gmmmap_screen.hpp): on grouped frames the workgroup's own mixture is evaluated first, every other mixture is
+    screened on its last four whitening rows (four mixtures per MFMA tile, no cross-lane sum) and only survivors are evaluated.
+    A screened-out mixture is below e^-prune of the final maximum for every frame of the workgroup, so y is the dense loop's to
+    rounding: checked on both tile widths (T <= 32768: one tile per wave), M not a multiple of 4 / 16 / 64, M > 64, a zero-weight
+    mixture, D not a multiple of 4, the broad model (forced: nearly everything survives), against the oracle, repeat runs
+    bit-identical, and the counters show the saving on the peaked models."""
+    import torch
+    from oracle import c_oracle as co, np_oracle as npo
+    from voiceconversion_jl_amd import _lib
+    w, mu, sig = npo.synth_model(500 + D + M, 2 * D, M, lam_lo=lam_lo)
+    if M >= 9:
+        w = w.copy(); w[3] = 0.0; w /= w.sum()
+    X = npo.sample_frames(501, w, mu, sig, T, 0, D)
+    Xd = torch.from_numpy(X).cuda()
+    g = vc.GMMMap(*julia_model(w, mu, sig))
+    _lib.debug_force(_lib.DBG_CONVERT_SHAPE_SCREENED)
+    try:
+        assert g.convert_plan()[1] == 3
+        g.prune_stats(True)
+        Y = vc.fvconvert(g, Xd.t()).t().clone()
+        issued3 = g.convert_plan()[0]
+        nreg3 = g.prune_stats(False)
+        for _ in range(3):
+            assert torch.equal(vc.fvconvert(g, Xd.t()).t(), Y)
+    finally:
+        _lib.debug_force(0)
+    _lib.debug_force(_lib.DBG_CONVERT_SHAPE_PEAKED)
+    try:
+        g.prune_stats(True)
+        Y2 = vc.fvconvert(g, Xd.t()).t().clone()
+        issued2 = g.convert_plan()[0]
+        g.prune_stats(False)
+    finally:
+        _lib.debug_force(0)
+    g.set_prune(float("inf"))
+    Yd = vc.fvconvert(g, Xd.t()).t().clone()
+    g.set_prune(46.0)
+    rel = lambda a, b: float((torch.linalg.norm(a - b, dim=1) / torch.linalg.norm(b, dim=1)).max())  # noqa: E731
+    assert rel(Y, Yd) < 1e-13 and rel(Y, Y2) < 1e-13
+    ref = co.GMMMap(w, mu, sig).fvconvert(X[:300])
+    assert frame_relerr(Y[:300].cpu().numpy().T, ref.T) < TOL
+    tiles = -(-T // 16)
+    assert 0 < nreg3 <= tiles * M
+    if lam_lo <= 1e-4:
+        # the screen costs a quarter of the last-tile test; with few mixtures the group's own (42 MFMAs per tile) dominates both
+        assert issued3 < (0.6 if M >= 32 else 1.0) * issued2, (issued3, issued2)
+        assert nreg3 < max(0.2, 1.5 / M) * tiles * M             # about one regression per tile: the frame's own mixture

@@ -200,6 +200,7 @@ DBG_DTW_NO_SEGMENTS, DBG_DTW_GRID_ORDER = 256, 512
 DBG_DTW_TWO_SEGMENTS, DBG_DTW_WHOLE_FIRST = 16384, 32768
 DBG_ESTEP_FULL_NO_LISTS = 65536
 DBG_CONVERT_WIDE_TILES = 131072
+DBG_CONVERT_SHAPE_SCREENED = 262144
 
 
 def debug_force(flags):

@@ -835,6 +835,10 @@ gmmmap_mfma_kernel(const double *__restrict__ packed, int M, int D, const double
   }
 }
 
+}  // namespace vcmi
+#include "gmmmap_screen.hpp"
+namespace vcmi {
+
 // ------------------------------------------------------------------------------------------------
 // Generic VALU kernel (any D): one lane per frame, x and the y accumulator in LDS ([d][lane] layout,
 // conflict-free), parameters read through wave-uniform (scalar) loads.
@@ -1420,14 +1424,55 @@ static bool use_mfma(const vcmi_gmmmap *g) {
   return gmmmap_has_mfma(g->DP);
 }
 
+// shape 3 (gmmmap_screen.hpp): DP = 16..48, any M up to 1024 (the survivors' bitmap)
+static bool screen_has_kernel(int DP) { return DP >= 16 && DP <= 48 && DP % 4 == 0; }
+template <int DP, int FT>
+static int launch_screen(const vcmi_gmmmap *g, const double *dX, int64_t ldx, int64_t T, double *dY, int64_t ldy, hipStream_t st,
+                         const int *perm, const int *gkey) {
+  constexpr int WAVES = 4;
+  using TL = Tiling<DP, false>;
+  constexpr int BUF = (TL::BLK > screen_stage_doubles(DP)) ? TL::BLK : screen_stage_doubles(DP);
+  const size_t shmem = 2 * (size_t)BUF * sizeof(double);
+  auto kern = gmmmap_screen_kernel<DP, FT, WAVES>;
+  static std::atomic<bool> attr_done[64];
+  int dev = 0;
+  VCMI_HIP(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 64 || !attr_done[dev].load(std::memory_order_acquire)) {
+    VCMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    if (dev >= 0 && dev < 64) attr_done[dev].store(true, std::memory_order_release);
+  }
+  const int64_t per_wg = (int64_t)16 * FT * WAVES;
+  hipLaunchKernelGGL(kern, dim3((unsigned)((T + per_wg - 1) / per_wg)), dim3(WAVES * 64), shmem, st, g->packed.p, g->packedQ.p, g->M, g->D,
+                     dX, ldx, T, dY, ldy, g->prune, g->prune_count.p, perm, gkey);
+  VCMI_HIP(hipGetLastError());
+  return VCMI_OK;
+}
+static int dispatch_screen(const vcmi_gmmmap *g, const double *dX, int64_t ldx, int64_t T, double *dY, int64_t ldy, hipStream_t st,
+                           const int *perm, const int *gkey) {
+  const bool narrow = T <= kSmallCallFrames && !debug_flag(kDbgConvertWideTiles);     // one frame tile per wave, as dispatch_mfma
+  switch (g->DP) {
+#define VCMI_CASE(DPV) \
+  case DPV: return narrow ? launch_screen<DPV, 1>(g, dX, ldx, T, dY, ldy, st, perm, gkey) : launch_screen<DPV, 2>(g, dX, ldx, T, dY, ldy, st, perm, gkey);
+    VCMI_CASE(16) VCMI_CASE(20) VCMI_CASE(24) VCMI_CASE(28) VCMI_CASE(32) VCMI_CASE(36) VCMI_CASE(40) VCMI_CASE(44) VCMI_CASE(48)
+#undef VCMI_CASE
+    default: return fail(VCMI_ERR_ARG, "no screening kernel for padded dimension %d", g->DP);
+  }
+}
+
 static constexpr double kBroadModelFrac = 0.35;
+// shape 3 pays while the survivors of the four-row screen stay few: a survivor costs a whole mixture (42 MFMA steps at D = 40)
+// for every wave of its workgroup, a screened mixture 2.5 -- against the 10 of shape 2's last-tile test
+static constexpr double kScreenModelFrac = 0.05;
 // Which loop shape converts with this handle (gmmmap_mfma_kernel's PRUNE): 2 "peaked" when, for the model's own frames, the
 // last whitening tile's share of |z|^2 alone puts most mixtures e^-prune under the best one (model_undecided_frac, estimated
 // once by prepare(): 0.02 on the SURVEY 8d synthetic models) -- the loop that looks at that tile first then skips the other
 // whitening tiles; 1 "broad" otherwise (every whitening tile is needed anyway: the straight loop is faster).
 static int convert_shape(const vcmi_gmmmap *g) {
+  const bool can_screen = screen_has_kernel(g->DP) && g->M <= 1024 && g->packedQ.p != nullptr;
   if (debug_flag(kDbgConvertShapeBroad)) return 1;
   if (debug_flag(kDbgConvertShapePeaked)) return 2;
+  if (debug_flag(kDbgConvertShapeScreened) && can_screen) return 3;
+  if (can_screen && g->model_undecided4_frac <= kScreenModelFrac) return 3;     // (grouped calls only: see gmmmap_convert_device)
   return g->model_undecided_frac > kBroadModelFrac ? 1 : 2;
 }
 
@@ -1464,12 +1509,15 @@ int gmmmap_convert_device(vcmi_gmmmap *g, const double *dX, int64_t ldx, int64_t
       hipLaunchKernelGGL(gmmmap_group_scatter_kernel, dim3((unsigned)nchunks), dim3(256), (size_t)17 * g->M * sizeof(int), st,
                          key, T, g->M, chunkhist, total, perm);
       VCMI_HIP(hipGetLastError());
-      const int rc = convert_shape(g) == 1 ? dispatch_mfma<0, 1>(g, dX, ldx, T, dY, ldy, st, perm, key)
-                                           : dispatch_mfma<0, 2>(g, dX, ldx, T, dY, ldy, st, perm, key);
+      const int shape = convert_shape(g);
+      const int rc = shape == 3 ? dispatch_screen(g, dX, ldx, T, dY, ldy, st, perm, key)
+                   : shape == 1 ? dispatch_mfma<0, 1>(g, dX, ldx, T, dY, ldy, st, perm, key)
+                                : dispatch_mfma<0, 2>(g, dX, ldx, T, dY, ldy, st, perm, key);
       (void)g->grp_order.leave(st);
       return rc;
     }
     if (!(g->prune < 1e300) && !debug_flag(kDbgConvertShapePeaked)) return dispatch_mfma<0, 0>(g, dX, ldx, T, dY, ldy, st);
+    // (frames in the caller's order: the screen of shape 3 needs the tight running maximum of grouped frames -> shape 2)
     return convert_shape(g) == 1 ? dispatch_mfma<0, 1>(g, dX, ldx, T, dY, ldy, st) : dispatch_mfma<0, 2>(g, dX, ldx, T, dY, ldy, st);
   }
   if (g->kernel_choice != 1 && g->At.p && g->D > 16 && g->D <= 160) {
@@ -1547,15 +1595,16 @@ int gmmmap_predict_device(vcmi_gmmmap *g, const double *dX, int64_t ldx, int64_t
 // fvconvert (convert_shape), never a result.
 static double model_active_fraction(const std::vector<double> &hU, const std::vector<double> &hcz, const std::vector<double> &hlc,
                                     const std::vector<double> &hmux, const double *w, int D, int DP, int M,
-                                    double *undecided_frac) {
+                                    double *undecided_frac, double *undecided4_frac) {
   constexpr int S = 256;
   const size_t pp = (size_t)DP * DP;
   std::vector<double> cdf(M);
   double tot = 0.0;
   for (int m = 0; m < M; ++m) cdf[m] = (tot += (w[m] > 0.0 ? w[m] : 0.0));
   if (undecided_frac) *undecided_frac = 0.0;
+  if (undecided4_frac) *undecided4_frac = 1.0;
   if (!(tot > 0.0) || M < 2) return 0.0;
-  std::vector<int> counts(S, 0), undecided(S, 0);
+  std::vector<int> counts(S, 0), undecided(S, 0), undecided4(S, 0);
   const int r_last = 16 * ((DP + 15) / 16 - 1);                       // first row of the last whitening tile
   host_parallel_for(S, 8, [&](int64_t lo, int64_t hi) {
     std::vector<double> x(D), z(D);
@@ -1585,18 +1634,20 @@ static double model_active_fraction(const std::vector<double> &hU, const std::ve
       }
       for (int d = 0; d < D; ++d) x[d] += hmux[(size_t)D * m + d];
       double best = -INFINITY;
-      std::vector<double> l(M), qlast(M);
+      std::vector<double> l(M), qlast(M), qlast4(M);
       for (int n = 0; n < M; ++n) {
         const double *Un = &hU[pp * n];
-        double q = 0.0, ql = 0.0;
+        double q = 0.0, ql = 0.0, ql4 = 0.0;
         for (int r = 0; r < D; ++r) {
           double zz = -hcz[(size_t)DP * n + r];
           for (int c = 0; c <= r; ++c) zz += Un[(size_t)r * DP + c] * x[c];
           q += zz * zz;
           if (r >= r_last) ql += zz * zz;
+          if (r >= D - 4) ql4 += zz * zz;
         }
         l[n] = hlc[n] - 0.5 * q;
         qlast[n] = ql;
+        qlast4[n] = ql4;
         best = std::max(best, l[n]);
       }
       int cnt = 0;
@@ -1605,14 +1656,19 @@ static double model_active_fraction(const std::vector<double> &hU, const std::ve
       int und = 0;                                                     // ... and on the last 16-row whitening tile's share alone
       for (int n = 0; n < M; ++n) und += (hlc[n] - 0.5 * qlast[n] > best - 46.0);
       undecided[s] = und;
+      int und4 = 0;                                                    // ... and on the last FOUR whitening rows alone (the screen of shape 3)
+      for (int n = 0; n < M; ++n) und4 += (hlc[n] - 0.5 * qlast4[n] > best - 46.0);
+      undecided4[s] = und4;
     }
   });
-  double sum = 0.0, sumu = 0.0;
+  double sum = 0.0, sumu = 0.0, sumu4 = 0.0;
   for (int s = 0; s < S; ++s) {
     sum += counts[s];
     sumu += undecided[s];
+    sumu4 += undecided4[s];
   }
   if (undecided_frac) *undecided_frac = sumu / ((double)S * M);
+  if (undecided4_frac) *undecided4_frac = sumu4 / ((double)S * M);
   return sum / ((double)S * M);
 }
 
@@ -1703,7 +1759,7 @@ static int prepare(vcmi_gmmmap *g, const double *w, const double *mu, const doub
     if (bs < M && bs <= bp) return fail(VCMI_ERR_NOT_PD, "Sigma^xx of mixture %d is singular", bs + 1);
     if (bp < M) return fail(VCMI_ERR_NOT_PD, "Sigma^xx of mixture %d is not positive definite", bp + 1);
   }
-  if (!px_only) g->model_active_frac = model_active_fraction(hU, hcz, hlc, g->h_mux, w, D, DP, M, &g->model_undecided_frac);
+  if (!px_only) g->model_active_frac = model_active_fraction(hU, hcz, hlc, g->h_mux, w, D, DP, M, &g->model_undecided_frac, &g->model_undecided4_frac);
   // row-major blocks for the generic kernels; a p(x)-only handle that takes the MFMA path needs only its packed blocks
   // (device buffers are grow-only so that a handle re-prepared every EM iteration does not re-allocate)
   if (!(px_only && gmmmap_has_mfma(DP))) {
@@ -1772,6 +1828,27 @@ static int prepare(vcmi_gmmmap *g, const double *w, const double *mu, const doub
     DevBuf<double> &dst = uonly == 2 ? g->packedU2 : (uonly ? g->packedU : g->packed);
     VCMI_TRY(dst.reserve(pk.size()));
     VCMI_HIP(hipMemcpy(dst.p, pk.data(), pk.size() * 8, hipMemcpyHostToDevice));
+  }
+  // stages of the four-row screen (gmmmap_screen.hpp): row 4 r + j of a quad's tile = row D - 4 + r of mixture j's whitening
+  if (!px_only && screen_has_kernel(DP) && M <= 1024) {
+    const int KSQ = DP / 4, QFR = screen_frag_doubles(DP), STG = screen_stage_doubles(DP), nst = (M + 4 * kScreenQuads - 1) / (4 * kScreenQuads);
+    std::vector<double> pq((size_t)nst * STG, 0.0);
+    for (int st = 0; st < nst; ++st)
+      for (int q = 0; q < kScreenQuads; ++q) {
+        double *fr = &pq[(size_t)st * STG + (size_t)q * KSQ * 64], *cl = &pq[(size_t)st * STG + QFR + (size_t)q * 24];
+        for (int ks = 0; ks < KSQ; ++ks)
+          for (int l = 0; l < 64; ++l) {
+            const int i = l & 15, k = 4 * ks + (l >> 4), m = 16 * st + 4 * q + (i & 3), row = D - 4 + (i >> 2);
+            fr[(size_t)ks * 64 + l] = (m < M && k < DP) ? hU[pp * m + (size_t)row * DP + k] : 0.0;
+          }
+        for (int j = 0; j < 4; ++j) {
+          const int m = 16 * st + 4 * q + j;
+          for (int r = 0; r < 4; ++r) cl[j * 6 + r] = (m < M) ? -hcz[(size_t)DP * m + (D - 4 + r)] : 0.0;
+          cl[j * 6 + 4] = (m < M) ? hlc[m] : -std::numeric_limits<double>::infinity();
+        }
+      }
+    VCMI_TRY(g->packedQ.reserve(pq.size()));
+    VCMI_HIP(hipMemcpy(g->packedQ.p, pq.data(), pq.size() * 8, hipMemcpyHostToDevice));
   }
   if (!g->h_mux.empty()) {     // operand of the frame grouping (gmmmap_group_key_kernel): [-2 mu^x | |mu^x|^2] over its first dimensions, fragment order
     const int KSK = std::min(DP / 4, kGroupKeyDims / 4), KS1 = KSK + 1, MT = (M + 15) / 16, DK = std::min(D, 4 * KSK);

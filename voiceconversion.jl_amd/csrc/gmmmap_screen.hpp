@@ -1,0 +1,372 @@
+// gmmmap_screen.hpp -- fvconvert for PEAKED models on grouped frames: screen four mixtures per MFMA tile, evaluate the few that
+// survive (included by gmmmap.hip; shape 3 of vcmi_gmmmap_convert_plan).
+//
+// What the "peaked" loop of gmmmap_mfma_kernel (PRUNE = 2) spends its time on: of its ~10.5 MFMAs per (16-frame tile,
+// mixture) all but ~0.7 only PROVE that the mixture's posterior is below e^-prune -- the last 16-row whitening tile, whose
+// share of |z|^2 is a lower bound of |z|^2.  Any subset of the rows of z = U_m x - cz_m gives such a bound, and for a wrong
+// mixture the LAST rows of the Cholesky whitening (the small conditional variances) carry almost all of the distance.  So
+// the proof is made with the last FOUR rows, and the MFMA result layout does the rest: lane group g of a 16 x 16 result holds
+// rows {g, 4 + g, 8 + g, 12 + g}, so a tile whose row 4 r + j is row (D - 4 + r) of mixture j's whitening gives lane group j
+// the four rows of mixture j -- its share of |z_j|^2 is four multiply-adds in the lane, no cross-lane sum, and ONE tile of KS
+// MFMAs screens FOUR mixtures (2.5 MFMAs per pair instead of 10).  Per workgroup (WAVES waves x FT tiles of 16 frames):
+//   1. the mixtures of the workgroup's groups (gkey of its frames: one, or two or three where the workgroup straddles group
+//      boundaries) are evaluated in full -- whitening, regression, softmax -- which makes the running maximum tight for
+//      (almost) all of its frames;
+//   2. every quad of mixtures is screened against (running maximum - prune); a mixture that no frame of the workgroup lets
+//      through contributes less than e^-prune to every frame: exactly the terms the other shapes skip.  Survivors go into a
+//      bitmap in LDS (rare: one or two per workgroup on the SURVEY 8d model);
+//   3. the survivors are evaluated in full, in index order, with the "broad" loop's per-wave test in front of the regression.
+// The running maximum only grows, so a mixture screened out against the maximum of step 1 is below e^-prune of the final
+// maximum as well: the result is the dense loop's to rounding (the order of the sum differs: survivors in index order after
+// the group's mixture).  Stages of QS quads are staged by LDS-DMA, double-buffered, one barrier per stage (16 mixtures).
+#pragma once
+
+namespace vcmi {
+
+constexpr int kScreenQuads = 4;      // quads (of 4 mixtures) per stage: 16 mixtures per barrier
+
+// stage layout in doubles: [QS x KS x 64 operand fragments | QS x 4 lane groups x 6 {cinit r = 0..3, lc, pad}], whole KB
+__host__ __device__ constexpr int screen_frag_doubles(int DP) { return kScreenQuads * (DP / 4) * 64; }
+__host__ __device__ constexpr int screen_stage_doubles(int DP) { return (screen_frag_doubles(DP) + kScreenQuads * 24 + 127) / 128 * 128; }
+
+// one 1 KB wave instruction of LDS-DMA: uniform global address, uniform LDS byte address, the lane's 16-byte offset
+__device__ __forceinline__ void dma_1k(const char *ga, unsigned la, unsigned lane_off) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(lane_off), "s"(ga), "s"(la) : "memory", "m0");
+}
+
+template <int DP, int FT, int WAVES>
+__global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(DP <= 40 ? (FT == 2 ? 3 : 4) : 2)))
+gmmmap_screen_kernel(const double *__restrict__ packed, const double *__restrict__ packedQ, int M, int D,
+                     const double *__restrict__ X, int64_t ldx, int64_t T, double *__restrict__ Y, int64_t ldy, double prune,
+                     unsigned long long *__restrict__ nreg, const int *__restrict__ perm, const int *__restrict__ gkey) {
+  using TL = Tiling<DP, false>;
+  constexpr int KS = TL::KS, NT = TL::NT, NU = TL::NU, BLK = TL::BLK;
+  constexpr int QS = kScreenQuads, QFR = screen_frag_doubles(DP), STG = screen_stage_doubles(DP);
+  constexpr int BUF = (BLK > STG) ? BLK : STG;                  // doubles per buffer
+  constexpr int NI_BLK = BLK / 128, NI_STG = STG / 128;         // 1 KB wave instructions per block / stage
+  constexpr bool PAIRED = (FT == 2);
+  extern __shared__ double smem[];                              // 2 * BUF doubles
+  __shared__ double etab[64];
+  __shared__ unsigned survivors[32];                            // bit m: mixture m passed the screen on some frame of the workgroup (M <= 1024)
+  __shared__ unsigned keys[32];                                 // bit m: m is the group of some frame of the workgroup (evaluated in step 1)
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const unsigned lane_off = 16u * (unsigned)lane;
+  const int lcol = lane & 15, lgrp = lane >> 4;
+  const int64_t frame0 = ((int64_t)blockIdx.x * WAVES + wave) * (16 * FT);
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)(reinterpret_cast<char *>(smem));
+
+  if (tid < 64) etab[tid] = kExp2Tab[tid];
+  if (tid < 32) survivors[tid] = 0u;
+  else if (tid < 64) keys[tid - 32] = 0u;
+
+  // group of the workgroup's first frame: the mixture evaluated first
+  int mg = 0;
+  {
+    const int64_t f0 = (int64_t)blockIdx.x * WAVES * (16 * FT);
+    mg = (f0 < T) ? gkey[perm[f0]] : 0;
+    mg = (mg >= 0 && mg < M) ? mg : 0;
+  }
+  // block mg -> buffer 0, stage 0 -> buffer 1 (each wave issues every WAVES-th KB)
+  auto dma_block = [&](int m, int buf) {
+    const char *gb = reinterpret_cast<const char *>(packed + (size_t)m * BLK);
+    const unsigned lb = lds0 + (unsigned)buf * (BUF * 8u);
+#pragma unroll
+    for (int i = 0; i < (NI_BLK + WAVES - 1) / WAVES; ++i) {
+      const int k = wave_u + WAVES * i;
+      if (k < NI_BLK) dma_1k(gb + 1024 * k, lb + 1024u * k, lane_off);
+    }
+  };
+  auto dma_stage = [&](int s, int buf) {
+    const char *gb = reinterpret_cast<const char *>(packedQ + (size_t)s * STG);
+    const unsigned lb = lds0 + (unsigned)buf * (BUF * 8u);
+#pragma unroll
+    for (int i = 0; i < (NI_STG + WAVES - 1) / WAVES; ++i) {
+      const int k = wave_u + WAVES * i;
+      if (k < NI_STG) dma_1k(gb + 1024 * k, lb + 1024u * k, lane_off);
+    }
+  };
+  dma_block(mg, 0);
+  dma_stage(0, 1);
+  __builtin_amdgcn_sched_barrier(0);
+
+  // B operands: xb[f][ks] = X[k = 4 ks + lgrp][frame], zero outside (D, T)
+  double xb[FT][KS];
+  int64_t frow[FT];
+  unsigned tiles_in_range = 0;
+#pragma unroll
+  for (int f = 0; f < FT; ++f) {
+    const int64_t fr = frame0 + 16 * f + lcol;
+    frow[f] = (fr < T) ? (int64_t)perm[fr] : fr;
+    if (frame0 + 16 * f < T) tiles_in_range |= 1u << f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int k = 4 * ks + lgrp;
+      xb[f][ks] = (fr < T && k < D) ? X[frow[f] * ldx + k] : 0.0;
+    }
+  }
+  __syncthreads();                                               // the bitmaps are zeroed
+  if (lgrp == 0) {
+#pragma unroll
+    for (int f = 0; f < FT; ++f) {
+      const int64_t fr = frame0 + 16 * f + lcol;
+      if (fr < T) {
+        const int k = gkey[frow[f]];
+        if (k >= 0 && k < M) atomicOr(&keys[k >> 5], 1u << (k & 31));
+      }
+    }
+  }
+  double yacc[FT][KS];
+  double runmax[FT], den[FT];          // PAIRED: [0] holds tile 0's value in the even lane groups, tile 1's in the odd ones
+#pragma unroll
+  for (int f = 0; f < FT; ++f) {
+    runmax[f] = -INFINITY;
+    den[f] = 0.0;
+#pragma unroll
+    for (int j = 0; j < KS; ++j) yacc[f][j] = 0.0;
+  }
+  int nreg_wave = 0, nmfma_wave = 0;
+  const __attribute__((address_space(4))) double *packed_c = (const __attribute__((address_space(4))) double *)packed;
+
+  // ---- one mixture in full from the block in `cur`: whitening, (test,) regression, online softmax update -- the "broad" loop's body
+  auto full_mixture = [&](const double *cur, double lc, bool tested) {
+    if ((unsigned)((unsigned long long)__double_as_longlong(lc) >> 32) == 0xFFF00000u) return;      // zero weight: posterior exactly 0
+    d4 acc[FT][NT];
+#pragma unroll
+    for (int t = 0; t < NU; ++t) {
+      d4 c;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) c[r] = cur[TL::CINIT_OFF + 16 * t + 4 * r + lgrp];
+#pragma unroll
+      for (int f = 0; f < FT; ++f) acc[f][t] = c;
+    }
+    constexpr int NUS = TL::tile_off(NU);
+    int s = 0;
+    double a_cur = cur[lane];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+      for (int t = 0; t < NU; ++t) {
+        if (ks < TL::steps(t)) {
+          const double a = a_cur;
+          ++s;
+          if (s < NUS) a_cur = cur[s * 64 + lane];
+#pragma unroll
+          for (int f = 0; f < FT; ++f) acc[f][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, xb[f][ks], acc[f][t], 0, 0, 0);
+        }
+      }
+    }
+    nmfma_wave += FT * NUS;
+    double qv[FT];
+#pragma unroll
+    for (int f = 0; f < FT; ++f) {
+      double qq = 0.0;
+#pragma unroll
+      for (int t = 0; t < NU; ++t) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (16 * t + 4 * r < DP) qq = fma(acc[f][t][r], acc[f][t][r], qq);
+      }
+      qv[f] = qq;
+    }
+    double lsel;
+    if constexpr (PAIRED) lsel = lc - 0.5 * sum_lane_groups_pair(qv[0], qv[1]);
+    else lsel = lc - 0.5 * sum_lane_groups(qv[0]);
+    if (tested && __builtin_amdgcn_ballot_w64(lsel > runmax[0] - prune) == 0) return;
+    nreg_wave += __builtin_popcount(tiles_in_range);
+    nmfma_wave += FT * (TL::NSTEPS - NUS);
+    if (__builtin_amdgcn_ballot_w64(lsel > runmax[0]) != 0) {      // lazy rescale (wave-uniform; the factor is exactly 1 elsewhere)
+      const double nm = fmax(runmax[0], lsel);
+      const double scs = vc_exp(runmax[0] - nm);
+      den[0] *= scs;
+      runmax[0] = nm;
+      double sc[FT];
+      if constexpr (PAIRED) unpair_lane_groups(scs, sc[0], sc[1]);
+      else sc[0] = scs;
+#pragma unroll
+      for (int f = 0; f < FT; ++f) {
+#pragma unroll
+        for (int j = 0; j < KS; ++j) yacc[f][j] *= sc[f];
+      }
+    }
+    double wg[FT];
+    {
+      const double e = vc_exp_tab(lsel - runmax[0], etab);
+      den[0] += e;
+      if constexpr (PAIRED) unpair_lane_groups(e, wg[0], wg[1]);
+      else wg[0] = e;
+    }
+#pragma unroll
+    for (int t = NU; t < NT; ++t) {
+      d4 c;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) c[r] = cur[TL::CINIT_OFF + 16 * t + 4 * r + lgrp];
+#pragma unroll
+      for (int f = 0; f < FT; ++f) acc[f][t] = c;
+    }
+    int sa = NUS;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+      for (int t = NU; t < NT; ++t) {
+        const double a = cur[sa * 64 + lane];
+        ++sa;
+#pragma unroll
+        for (int f = 0; f < FT; ++f) acc[f][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, xb[f][ks], acc[f][t], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int f = 0; f < FT; ++f) {
+#pragma unroll
+      for (int t = NU - 1; t < NT; ++t) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int p0 = 16 * t + 4 * r;
+          if (p0 >= DP && p0 < 2 * DP) {
+            const int j = (p0 - DP) / 4;
+            yacc[f][j] = fma(wg[f], acc[f][t][r], yacc[f][j]);
+          }
+        }
+      }
+    }
+  };
+
+  // ---- every mixture of a bitmap (except `skip`) in full, in index order; blocks alternate between the buffers starting with
+  // `first_buf`, which every wave must have left (the caller's barrier); ends with everyone out of both buffers' readers... the
+  // bitmap must be complete and visible (a barrier since its last update)
+  auto eval_bitmap = [&](const unsigned *bm, int first_buf, int skip) -> int {
+    const int nwords = (M + 31) / 32;
+    int w = 0;
+    unsigned bits = __builtin_amdgcn_readfirstlane(bm[0]);
+    auto next = [&]() -> int {                                   // next mixture of the bitmap, -1 when there is none
+      for (;;) {
+        while (bits == 0u) {
+          if (++w >= nwords) return -1;
+          bits = __builtin_amdgcn_readfirstlane(bm[w]);
+        }
+        const int b = __builtin_ctz(bits);
+        bits &= bits - 1u;
+        if (32 * w + b != skip) return 32 * w + b;
+      }
+    };
+    int cur_m = next(), p = first_buf, n = 0;
+    if (cur_m < 0) return 0;
+    __syncthreads();                                             // everyone has left buffer p
+    dma_block(cur_m, p);
+    while (cur_m >= 0) {
+      ++n;
+      const int nxt_m = next();
+      const double lc = packed_c[(size_t)cur_m * BLK + TL::LC_OFF];
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();                                           // block cur_m is in buffer p; everyone has left buffer p ^ 1
+      if (nxt_m >= 0) dma_block(nxt_m, p ^ 1);
+      full_mixture(smem + p * BUF, lc, true);
+      cur_m = nxt_m;
+      p ^= 1;
+    }
+    return n;
+  };
+
+  // ---- 1. the group's own mixture
+  const double lc_g = packed_c[(size_t)mg * BLK + TL::LC_OFF];
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  full_mixture(smem, lc_g, false);
+  // the other groups present in the workgroup (it straddles a group boundary: rare on large calls, the rule on small ones)
+  // (blocks go to buffer 0, 1, 0, ...: from the second one on they overwrite stage 0, which is then fetched again)
+  const int nkeys = eval_bitmap(keys, 0, mg);
+  // the thresholds of the screen, per tile in every lane (a lane group of a screening tile is a MIXTURE, not a tile)
+  double thr[FT];
+  if constexpr (PAIRED) {
+    double r0, r1;
+    unpair_lane_groups(runmax[0], r0, r1);
+    thr[0] = r0 - prune;
+    thr[1] = r1 - prune;
+  } else {
+    thr[0] = runmax[0] - prune;
+  }
+  __syncthreads();                                               // everyone is done with the block buffers
+  if (nkeys >= 2) {
+    dma_stage(0, 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+
+  // ---- 2. screen every quad: stage s is in buffer (s + 1) & 1, stage s + 1 is fetched into the other one meanwhile
+  const int nstages = (M + 4 * QS - 1) / (4 * QS);
+  for (int s = 0; s < nstages; ++s) {
+    if (s + 1 < nstages) dma_stage(s + 1, s & 1);
+    __builtin_amdgcn_sched_barrier(0);
+    const double *stg = smem + ((s + 1) & 1) * BUF;
+#pragma unroll
+    for (int q = 0; q < QS; ++q) {
+      if (16 * s + 4 * q >= M) break;                            // (wave-uniform)
+      const double *fq = stg + q * (KS * 64) + lane;
+      const double *cl = stg + QFR + q * 24 + lgrp * 6;
+      double afr[KS];
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) afr[ks] = fq[ks * 64];
+      d4 c;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) c[r] = cl[r];
+      const double lcq = cl[4];
+      d4 a[FT];
+#pragma unroll
+      for (int f = 0; f < FT; ++f) a[f] = c;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+        for (int f = 0; f < FT; ++f) a[f] = __builtin_amdgcn_mfma_f64_16x16x4f64(afr[ks], xb[f][ks], a[f], 0, 0, 0);
+      }
+      nmfma_wave += FT * KS;
+      unsigned long long pass = 0;
+#pragma unroll
+      for (int f = 0; f < FT; ++f) {
+        double p = a[f][0] * a[f][0];
+        p = fma(a[f][1], a[f][1], p);
+        p = fma(a[f][2], a[f][2], p);
+        p = fma(a[f][3], a[f][3], p);
+        const unsigned long long b = __builtin_amdgcn_ballot_w64(fma(-0.5, p, lcq) > thr[f]);
+        if (tiles_in_range >> f & 1u) pass |= b;
+      }
+      if (pass) {                                                // rare: some mixture of the quad is not ruled out for some frame
+        if (lane == 0) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int m = 16 * s + 4 * q + j;
+            if ((pass >> (16 * j) & 0xffffull) && m < M && !(keys[m >> 5] >> (m & 31) & 1u)) atomicOr(&survivors[m >> 5], 1u << (m & 31));
+          }
+        }
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+
+  // ---- 3. the survivors in full, in index order (the bitmap is complete and visible: the loop above ended with a barrier)
+  eval_bitmap(survivors, 0, -1);
+
+  if (nreg && lane == 0) {
+    atomicAdd(nreg, (unsigned long long)nreg_wave);
+    atomicAdd(nreg + 1, (unsigned long long)nmfma_wave);
+  }
+  if constexpr (PAIRED) {
+    const double ds = den[0];
+    unpair_lane_groups(ds, den[0], den[1]);
+  }
+#pragma unroll
+  for (int f = 0; f < FT; ++f) {
+    const int64_t fr = frame0 + 16 * f + lcol;
+    const double inv = 1.0 / den[f];
+    if (fr < T) {
+#pragma unroll
+      for (int j = 0; j < KS; ++j) {
+        const int row = 4 * j + lgrp;
+        if (row < D) Y[frow[f] * ldy + row] = yacc[f][j] * inv;
+      }
+    }
+  }
+}
+
+}  // namespace vcmi

@@ -110,6 +110,7 @@ enum : unsigned {
   kDbgDtwWholeFirst = 32768u,     // fused DTW: whole-length jobs for the full rounds, segments for the rest (round 4 experiment: 3 % slower)
   kDbgEstepFullNoLists = 65536u,  // full-covariance statistics: every workgroup stages every frame of its segment (rounds 1-3) instead of its group's frame list
   kDbgDtwTwoSegments = 16384u,    // fused DTW: at most two column segments per strip (A/B of the traffic / balance trade)
+  kDbgConvertShapeScreened = 262144u, // fvconvert: the four-row screening kernel (shape 3) on grouped calls whatever the model
   kDbgConvertWideTiles = 131072u, // fvconvert: two frame tiles per wave (128-frame workgroups) also for calls of a few thousand frames
   kDbgPredictNoEarlyExit = 64u   // predict / trajectory argmax: every whitening tile of every mixture (MODE 2) instead of the early exit (MODE 3)
 };
