@@ -496,13 +496,15 @@ def test_torch_pinned_memory_is_recognised(vc, fixture_model):
 
 @pytest.mark.parametrize("D,M,T,lam_lo", [(40, 64, 200_000, 1e-5), (40, 64, 9000, 1e-5), (40, 67, 40_000, 1e-4), (24, 9, 33_000, 1e-5),
                                           (16, 4, 8200, 1e-5), (47, 33, 50_000, 1e-5), (40, 130, 35_000, 1e-5), (40, 32, 70_000, 1e-1)])
-def test_screened_shape_against_dense_and_oracle(vc, D, M, T, lam_lo):
+@pytest.mark.parametrize("rows", [4, 2, 1])
+def test_screened_shape_against_dense_and_oracle(vc, D, M, T, lam_lo, rows):
     """Shape 3 (gmmmap_screen.hpp): on grouped frames the workgroup's own mixture is evaluated first, every other mixture is
     screened on its last four whitening rows (four mixtures per MFMA tile, no cross-lane sum) and only survivors are evaluated.
     A screened-out mixture is below e^-prune of the final maximum for every frame of the workgroup, so y is the dense loop's to
     rounding: checked on both tile widths (T <= 32768: one tile per wave), M not a multiple of 4 / 16 / 64, M > 64, a zero-weight
-    mixture, D not a multiple of 4, the broad model (forced: nearly everything survives), against the oracle, repeat runs
-    bit-identical, and the counters show the saving on the peaked models."""
+    mixture, D not a multiple of 4, the broad model (forced: nearly everything survives), with 4 / 2 / 1 screening rows per
+    mixture (4 / 8 / 16 mixtures per tile; prepare() picks the cheapest for the model, the hook forces each), against the
+    oracle, repeat runs bit-identical, and the counters show the saving on the peaked models."""
     import torch
     from oracle import c_oracle as co, np_oracle as npo
     from voiceconversion_jl_amd import _lib
@@ -511,7 +513,11 @@ def test_screened_shape_against_dense_and_oracle(vc, D, M, T, lam_lo):
         w = w.copy(); w[3] = 0.0; w /= w.sum()
     X = npo.sample_frames(501, w, mu, sig, T, 0, D)
     Xd = torch.from_numpy(X).cuda()
-    g = vc.GMMMap(*julia_model(w, mu, sig))
+    _lib.debug_force({4: _lib.DBG_SCREEN_ROWS4, 2: _lib.DBG_SCREEN_ROWS2, 1: _lib.DBG_SCREEN_ROWS1}[rows])     # read at creation
+    try:
+        g = vc.GMMMap(*julia_model(w, mu, sig))
+    finally:
+        _lib.debug_force(0)
     _lib.debug_force(_lib.DBG_CONVERT_SHAPE_SCREENED)
     try:
         assert g.convert_plan()[1] == 3
@@ -542,5 +548,8 @@ def test_screened_shape_against_dense_and_oracle(vc, D, M, T, lam_lo):
     assert 0 < nreg3 <= tiles * M
     if lam_lo <= 1e-4:
         # the screen costs a quarter of the last-tile test; with few mixtures the group's own (42 MFMAs per tile) dominates both
-        assert issued3 < (0.6 if M >= 32 else 1.0) * issued2, (issued3, issued2)
-        assert nreg3 < max(0.2, 1.5 / M) * tiles * M             # about one regression per tile: the frame's own mixture
+        # (fewer rows per mixture screen more mixtures per tile but let more through: prepare() weighs the two; forced here)
+        if rows == 4:
+            assert issued3 < (0.6 if M >= 32 else 1.0) * issued2, (issued3, issued2)
+        if rows == 4:
+            assert nreg3 < max(0.2, 1.5 / M) * tiles * M         # about one regression per tile: the frame's own mixture

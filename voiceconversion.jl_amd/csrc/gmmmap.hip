@@ -1442,8 +1442,8 @@ static int launch_screen(const vcmi_gmmmap *g, const double *dX, int64_t ldx, in
     if (dev >= 0 && dev < 64) attr_done[dev].store(true, std::memory_order_release);
   }
   const int64_t per_wg = (int64_t)16 * FT * WAVES;
-  hipLaunchKernelGGL(kern, dim3((unsigned)((T + per_wg - 1) / per_wg)), dim3(WAVES * 64), shmem, st, g->packed.p, g->packedQ.p, g->M, g->D,
-                     dX, ldx, T, dY, ldy, g->prune, g->prune_count.p, perm, gkey);
+  hipLaunchKernelGGL(kern, dim3((unsigned)((T + per_wg - 1) / per_wg)), dim3(WAVES * 64), shmem, st, g->packed.p, g->packedQ.p, g->screen_rpm,
+                     g->M, g->D, dX, ldx, T, dY, ldy, g->prune, g->prune_count.p, perm, gkey);
   VCMI_HIP(hipGetLastError());
   return VCMI_OK;
 }
@@ -1594,17 +1594,18 @@ int gmmmap_predict_device(vcmi_gmmmap *g, const double *dX, int64_t ldx, int64_t
 // one are counted.  Returns the mean fraction of the M mixtures.  A property of the model only; it selects the loop SHAPE of
 // fvconvert (convert_shape), never a result.
 static double model_active_fraction(const std::vector<double> &hU, const std::vector<double> &hcz, const std::vector<double> &hlc,
+                                    const std::vector<double> &hP, const std::vector<double> &hcP,
                                     const std::vector<double> &hmux, const double *w, int D, int DP, int M,
-                                    double *undecided_frac, double *undecided4_frac) {
+                                    double *undecided_frac, double *undecided_rows) {
   constexpr int S = 256;
   const size_t pp = (size_t)DP * DP;
   std::vector<double> cdf(M);
   double tot = 0.0;
   for (int m = 0; m < M; ++m) cdf[m] = (tot += (w[m] > 0.0 ? w[m] : 0.0));
   if (undecided_frac) *undecided_frac = 0.0;
-  if (undecided4_frac) *undecided4_frac = 1.0;
+  if (undecided_rows) undecided_rows[0] = undecided_rows[1] = undecided_rows[2] = 1.0;   // on the 4 / 2 / 1 strongest screening rows
   if (!(tot > 0.0) || M < 2) return 0.0;
-  std::vector<int> counts(S, 0), undecided(S, 0), undecided4(S, 0);
+  std::vector<int> counts(S, 0), undecided(S, 0), undecided4(3 * S, 0);
   const int r_last = 16 * ((DP + 15) / 16 - 1);                       // first row of the last whitening tile
   host_parallel_for(S, 8, [&](int64_t lo, int64_t hi) {
     std::vector<double> x(D), z(D);
@@ -1634,20 +1635,26 @@ static double model_active_fraction(const std::vector<double> &hU, const std::ve
       }
       for (int d = 0; d < D; ++d) x[d] += hmux[(size_t)D * m + d];
       double best = -INFINITY;
-      std::vector<double> l(M), qlast(M), qlast4(M);
+      std::vector<double> l(M), qlast(M), qlast4(3 * (size_t)M);
       for (int n = 0; n < M; ++n) {
         const double *Un = &hU[pp * n];
-        double q = 0.0, ql = 0.0, ql4 = 0.0;
+        double q = 0.0, ql = 0.0, ql4[3] = {0.0, 0.0, 0.0};
         for (int r = 0; r < D; ++r) {
           double zz = -hcz[(size_t)DP * n + r];
           for (int c = 0; c <= r; ++c) zz += Un[(size_t)r * DP + c] * x[c];
           q += zz * zz;
           if (r >= r_last) ql += zz * zz;
-          if (r >= D - 4) ql4 += zz * zz;
         }
+        if (!hP.empty())
+          for (int i = 0; i < 4; ++i) {                                  // the screen's rows: strongest first
+            double pz = -hcP[(size_t)n * 4 + i];
+            for (int c = 0; c < D; ++c) pz += hP[((size_t)n * 4 + i) * DP + c] * x[c];
+            for (int c = 0; c < 3; ++c)
+              if (i < (4 >> c)) ql4[c] += pz * pz;
+          }
         l[n] = hlc[n] - 0.5 * q;
         qlast[n] = ql;
-        qlast4[n] = ql4;
+        for (int c = 0; c < 3; ++c) qlast4[3 * (size_t)n + c] = ql4[c];
         best = std::max(best, l[n]);
       }
       int cnt = 0;
@@ -1656,19 +1663,22 @@ static double model_active_fraction(const std::vector<double> &hU, const std::ve
       int und = 0;                                                     // ... and on the last 16-row whitening tile's share alone
       for (int n = 0; n < M; ++n) und += (hlc[n] - 0.5 * qlast[n] > best - 46.0);
       undecided[s] = und;
-      int und4 = 0;                                                    // ... and on the last FOUR whitening rows alone (the screen of shape 3)
-      for (int n = 0; n < M; ++n) und4 += (hlc[n] - 0.5 * qlast4[n] > best - 46.0);
-      undecided4[s] = und4;
+      for (int c = 0; c < 3; ++c) {                                    // ... and on the 4 / 2 / 1 strongest screening rows alone (shape 3)
+        int und4 = 0;
+        for (int n = 0; n < M; ++n) und4 += (hlc[n] - 0.5 * qlast4[3 * (size_t)n + c] > best - 46.0);
+        undecided4[3 * s + c] = und4;
+      }
     }
   });
-  double sum = 0.0, sumu = 0.0, sumu4 = 0.0;
+  double sum = 0.0, sumu = 0.0, sumu4[3] = {0.0, 0.0, 0.0};
   for (int s = 0; s < S; ++s) {
     sum += counts[s];
     sumu += undecided[s];
-    sumu4 += undecided4[s];
+    for (int c = 0; c < 3; ++c) sumu4[c] += undecided4[3 * s + c];
   }
   if (undecided_frac) *undecided_frac = sumu / ((double)S * M);
-  if (undecided4_frac) *undecided4_frac = sumu4 / ((double)S * M);
+  if (undecided_rows)
+    for (int c = 0; c < 3; ++c) undecided_rows[c] = sumu4[c] / ((double)S * M);
   return sum / ((double)S * M);
 }
 
@@ -1690,6 +1700,8 @@ static int prepare(vcmi_gmmmap *g, const double *w, const double *mu, const doub
   g->h_mux.assign((size_t)D * M, 0.0);
   g->h_muy.assign((size_t)D * M, 0.0);
   std::vector<double> hU(pp * M, 0.0), hA(reg * pp * M, 0.0), hcz((size_t)DP * M, 0.0), hb(reg * DP * M, 0.0), hlc(M);
+  const bool want_screen = !px_only && D >= 4 && DP >= 16 && DP <= 48 && M <= 1024;       // (screen_has_kernel, defined below)
+  std::vector<double> hP(want_screen ? (size_t)M * 4 * DP : 0, 0.0), hcP(want_screen ? (size_t)M * 4 : 0, 0.0);
   const int xo = (swap && !px_only) ? D : 0, yo = px_only ? 0 : (swap ? 0 : D);   // src/gmmmap.jl:74-78
   const double LOG2PI = 1.8378770664093454835606594728112;
   // The mixtures are independent (an inverse, a Cholesky factorisation and a triangular inverse each: 64 x 160^3 flop for
@@ -1752,6 +1764,39 @@ static int prepare(vcmi_gmmmap *g, const double *w, const double *mu, const doub
       hcz[(size_t)DP * m + r] = cz;
       if (!px_only) hb[(size_t)DP * m + r] = muy[r] - ba;
     }
+    // screening rows of shape 3 (gmmmap_screen.hpp): P_m = diag(sqrt(kappa_i)) v_i' over the FOUR LARGEST eigenpairs of
+    // inv(Sxx_m) = U'U -- the directions of smallest variance.  |P_m (x - mu_m)|^2 is a partial sum of the eigen-expansion of
+    // (x - mu_m)' inv(Sxx_m) (x - mu_m) = |z_m|^2: a lower bound of it, and per row the largest one any direction can give.
+    if (want_screen) {
+      std::vector<double> G(dd), V(dd);
+      for (int r = 0; r < D; ++r)
+        for (int c = 0; c < D; ++c) {
+          double sacc = 0.0;
+          for (int k = std::max(r, c); k < D; ++k) sacc += Ui[(size_t)k * D + r] * Ui[(size_t)k * D + c];
+          G[(size_t)r * D + c] = sacc;
+        }
+      la::sym_eigen_jacobi(G.data(), D, V.data());
+      int top[4] = {-1, -1, -1, -1};
+      for (int i = 0; i < 4; ++i) {
+        double bestv = -1.0;
+        for (int j = 0; j < D; ++j) {
+          bool used = false;
+          for (int u = 0; u < i; ++u) used = used || top[u] == j;
+          if (!used && G[(size_t)j * D + j] > bestv) {
+            bestv = G[(size_t)j * D + j];
+            top[i] = j;
+          }
+        }
+        const double sk = std::sqrt(std::max(bestv, 0.0));
+        double cp = 0.0;
+        for (int k = 0; k < D; ++k) {
+          const double v = sk * V[(size_t)k * D + top[i]];
+          hP[((size_t)m * 4 + i) * DP + k] = v;
+          cp += v * mux[k];
+        }
+        hcP[(size_t)m * 4 + i] = cp;
+      }
+    }
   }
   });
   {
@@ -1759,7 +1804,7 @@ static int prepare(vcmi_gmmmap *g, const double *w, const double *mu, const doub
     if (bs < M && bs <= bp) return fail(VCMI_ERR_NOT_PD, "Sigma^xx of mixture %d is singular", bs + 1);
     if (bp < M) return fail(VCMI_ERR_NOT_PD, "Sigma^xx of mixture %d is not positive definite", bp + 1);
   }
-  if (!px_only) g->model_active_frac = model_active_fraction(hU, hcz, hlc, g->h_mux, w, D, DP, M, &g->model_undecided_frac, &g->model_undecided4_frac);
+  if (!px_only) g->model_active_frac = model_active_fraction(hU, hcz, hlc, hP, hcP, g->h_mux, w, D, DP, M, &g->model_undecided_frac, g->model_undecided_rows);
   // row-major blocks for the generic kernels; a p(x)-only handle that takes the MFMA path needs only its packed blocks
   // (device buffers are grow-only so that a handle re-prepared every EM iteration does not re-allocate)
   if (!(px_only && gmmmap_has_mfma(DP))) {
@@ -1829,22 +1874,47 @@ static int prepare(vcmi_gmmmap *g, const double *w, const double *mu, const doub
     VCMI_TRY(dst.reserve(pk.size()));
     VCMI_HIP(hipMemcpy(dst.p, pk.data(), pk.size() * 8, hipMemcpyHostToDevice));
   }
-  // stages of the four-row screen (gmmmap_screen.hpp): row 4 r + j of a quad's tile = row D - 4 + r of mixture j's whitening
-  if (!px_only && screen_has_kernel(DP) && M <= 1024) {
-    const int KSQ = DP / 4, QFR = screen_frag_doubles(DP), STG = screen_stage_doubles(DP), nst = (M + 4 * kScreenQuads - 1) / (4 * kScreenQuads);
+  // stages of the screen of shape 3 (gmmmap_screen.hpp) on the first rpm rows of every mixture's P_m: rpm = the row count
+  // with the smallest estimated cost per 16-frame tile -- KS MFMAs screen 16 / rpm mixtures; a mixture the screen does not
+  // rule out costs its whole whitening (and usually its regression) for the four waves that share it
+  if (want_screen && screen_has_kernel(DP)) {
+    const int KSQ = DP / 4, QFR = screen_frag_doubles(DP), STG = screen_stage_doubles(DP);
+    int best = 4;
+    double best_cost = 1e300;
+    for (int c = 0; c < 3; ++c) {
+      const int rpm = 4 >> c;
+      const double extra = std::max(0.0, g->model_undecided_rows[c] - 1.0 / M);      // wrong mixtures let through, per frame
+      const double cost = (double)KSQ * M * rpm / 16.0 + 4.0 * extra * M * (2 * KSQ + 2);
+      if (cost < best_cost) {
+        best_cost = cost;
+        best = rpm;
+      }
+    }
+    if (debug_flag(kDbgScreenRows4)) best = 4;        // (test hooks, read when the converter is CREATED)
+    if (debug_flag(kDbgScreenRows2)) best = 2;
+    if (debug_flag(kDbgScreenRows1)) best = 1;
+    g->screen_rpm = best;
+    g->model_undecided4_frac = g->model_undecided_rows[best == 4 ? 0 : best == 2 ? 1 : 2];     // what the chosen screen lets through
+    const int rpm = best, mpt = 16 / rpm, nst = (M + mpt * kScreenQuads - 1) / (mpt * kScreenQuads);
     std::vector<double> pq((size_t)nst * STG, 0.0);
     for (int st = 0; st < nst; ++st)
       for (int q = 0; q < kScreenQuads; ++q) {
-        double *fr = &pq[(size_t)st * STG + (size_t)q * KSQ * 64], *cl = &pq[(size_t)st * STG + QFR + (size_t)q * 24];
+        const int m0 = (kScreenQuads * st + q) * mpt;
+        double *fr = &pq[(size_t)st * STG + (size_t)q * KSQ * 64], *cl = &pq[(size_t)st * STG + QFR + (size_t)q * 32];
         for (int ks = 0; ks < KSQ; ++ks)
           for (int l = 0; l < 64; ++l) {
-            const int i = l & 15, k = 4 * ks + (l >> 4), m = 16 * st + 4 * q + (i & 3), row = D - 4 + (i >> 2);
-            fr[(size_t)ks * 64 + l] = (m < M && k < DP) ? hU[pp * m + (size_t)row * DP + k] : 0.0;
+            const int i = l & 15, k = 4 * ks + (l >> 4), m = m0 + screen_row_mixture(i, rpm), row = screen_row_index(i, rpm);
+            fr[(size_t)ks * 64 + l] = (m < M && k < DP) ? hP[((size_t)m * 4 + row) * DP + k] : 0.0;
           }
         for (int j = 0; j < 4; ++j) {
-          const int m = 16 * st + 4 * q + j;
-          for (int r = 0; r < 4; ++r) cl[j * 6 + r] = (m < M) ? -hcz[(size_t)DP * m + (D - 4 + r)] : 0.0;
-          cl[j * 6 + 4] = (m < M) ? hlc[m] : -std::numeric_limits<double>::infinity();
+          for (int r = 0; r < 4; ++r) {                        // register r of lane group j holds tile row 4 r + j
+            const int i = 4 * r + j, m = m0 + screen_row_mixture(i, rpm), row = screen_row_index(i, rpm);
+            cl[j * 8 + r] = (m < M) ? -hcP[(size_t)m * 4 + row] : 0.0;
+          }
+          for (int u = 0; u < 4; ++u) {                        // sub-mixture u of lane group j (u < 4 / rpm)
+            const int m = m0 + (4 / rpm) * j + u;
+            cl[j * 8 + 4 + u] = (u < 4 / rpm && m < M) ? hlc[m] : -std::numeric_limits<double>::infinity();
+          }
         }
       }
     VCMI_TRY(g->packedQ.reserve(pq.size()));

@@ -19,9 +19,12 @@ struct vcmi_gmmmap {
   // ... and the mean fraction of the mixtures that the LAST 16-row whitening tile's share of |z|^2 alone does not put
   // e^-46 under the best one: what the "peaked" loop's first test leaves undecided.  Selects the loop shape (convert_shape).
   double model_undecided_frac = 0.0;
-  // ... and the fraction that the last FOUR whitening rows alone leave undecided: what the screen of shape 3
-  // (gmmmap_screen.hpp) lets through.  Small (<= kScreenModelFrac) -> grouped calls run the screening kernel.
+  // ... and the fractions that the 4 / 2 / 1 strongest screening rows (largest eigenpairs of inv(Sxx_m)) leave undecided: what the screen of shape 3
+  // (gmmmap_screen.hpp) lets through with that many rows per mixture.  prepare() picks screen_rpm (the cheapest) and keeps its
+  // fraction in model_undecided4_frac: small (<= kScreenModelFrac) -> grouped calls run the screening kernel.
+  double model_undecided_rows[3] = {1.0, 1.0, 1.0};
   double model_undecided4_frac = 1.0;
+  int screen_rpm = 4;
 
   // host copies kept for accessors and for TrajectoryGMMMap's constructor (row-major (D,D) per mixture)
   std::vector<double> h_A_julia;   // Julia memory image (D,D,M) of ΣʸˣΣˣˣ⁻¹
@@ -33,7 +36,7 @@ struct vcmi_gmmmap {
   // device parameters, MFMA fragment order: [M][Tiling::BLK]
   vcmi::DevBuf<double> packed;    // [U_m ; A_m] tiles (convert)
   vcmi::DevBuf<double> packedU;   // U_m tiles only (log-density / posterior / argmax)
-  vcmi::DevBuf<double> packedQ;   // stages of the four-row screen: 4 quads x (last 4 whitening rows of 4 mixtures) per stage (convert, shape 3)
+  vcmi::DevBuf<double> packedQ;   // stages of the screen: 4 tiles x (screen_rpm rows of 16 / screen_rpm mixtures) per stage (convert, shape 3)
   vcmi::DevBuf<double> packedU2;  // U_m tiles only, tile by tile, last tile first (predict with early exit; host-prepared handles)
   // fvconvert's frame grouping (gmmmap_group_key_kernel): nearest-source-mean operand [-2 mu | |mu|^2] in MFMA fragment order,
   // and the call's scratch: key (T), perm (T), counts (M), cursors (M)

@@ -3,11 +3,12 @@
 //
 // What the "peaked" loop of gmmmap_mfma_kernel (PRUNE = 2) spends its time on: of its ~10.5 MFMAs per (16-frame tile,
 // mixture) all but ~0.7 only PROVE that the mixture's posterior is below e^-prune -- the last 16-row whitening tile, whose
-// share of |z|^2 is a lower bound of |z|^2.  Any subset of the rows of z = U_m x - cz_m gives such a bound, and for a wrong
-// mixture the LAST rows of the Cholesky whitening (the small conditional variances) carry almost all of the distance.  So
-// the proof is made with the last FOUR rows, and the MFMA result layout does the rest: lane group g of a 16 x 16 result holds
-// rows {g, 4 + g, 8 + g, 12 + g}, so a tile whose row 4 r + j is row (D - 4 + r) of mixture j's whitening gives lane group j
-// the four rows of mixture j -- its share of |z_j|^2 is four multiply-adds in the lane, no cross-lane sum, and ONE tile of KS
+// share of |z|^2 is a lower bound of |z|^2.  |z_m|^2 = (x - mu_m)' inv(Sxx_m) (x - mu_m) = sum_i kappa_i (v_i' (x - mu_m))^2
+// over the eigenpairs of inv(Sxx_m): ANY partial sum is a lower bound, and the largest kappa (the directions of smallest
+// variance) give the largest one per row.  So the proof is made with the rows sqrt(kappa_i) v_i' of the FOUR largest
+// eigenpairs (prepare(), host: Jacobi), and the MFMA result layout does the rest: lane group g of a 16 x 16 result holds rows
+// {g, 4 + g, 8 + g, 12 + g}, so a tile whose row 4 r + j is screening row r of mixture j gives lane group j
+// the four rows of mixture j -- its bound is four multiply-adds in the lane, no cross-lane sum, and ONE tile of KS
 // MFMAs screens FOUR mixtures (2.5 MFMAs per pair instead of 10).  Per workgroup (WAVES waves x FT tiles of 16 frames):
 //   1. the mixtures of the workgroup's groups (gkey of its frames: one, or two or three where the workgroup straddles group
 //      boundaries) are evaluated in full -- whitening, regression, softmax -- which makes the running maximum tight for
@@ -23,11 +24,18 @@
 
 namespace vcmi {
 
-constexpr int kScreenQuads = 4;      // quads (of 4 mixtures) per stage: 16 mixtures per barrier
+// ROWS PER MIXTURE (rpm, chosen per model by prepare(): the fewest rows that still rule (almost) every wrong mixture out):
+//   4: lane group j of a screening tile = mixture j's four strongest rows               ->  4 mixtures per tile
+//   2: registers {0,1} of lane group j = mixture 2j's two strongest rows, {2,3} = mixture 2j+1's  ->  8 mixtures per tile
+//   1: register r of lane group j = the strongest row of mixture 4j + r                  -> 16 mixtures per tile (KS MFMAs screen 16)
+constexpr int kScreenQuads = 4;      // screening tiles per stage (one barrier per stage: 16 / 32 / 64 mixtures)
 
-// stage layout in doubles: [QS x KS x 64 operand fragments | QS x 4 lane groups x 6 {cinit r = 0..3, lc, pad}], whole KB
+// stage layout in doubles: [QS x KS x 64 operand fragments | QS x 4 lane groups x 8 {cinit r = 0..3, lc of sub-mixture 0..3}], whole KB
 __host__ __device__ constexpr int screen_frag_doubles(int DP) { return kScreenQuads * (DP / 4) * 64; }
-__host__ __device__ constexpr int screen_stage_doubles(int DP) { return (screen_frag_doubles(DP) + kScreenQuads * 24 + 127) / 128 * 128; }
+__host__ __device__ constexpr int screen_stage_doubles(int DP) { return (screen_frag_doubles(DP) + kScreenQuads * 32 + 127) / 128 * 128; }
+// which mixture (relative to the tile's first) and which of its screening rows (0 = the strongest) tile row i stands for
+__host__ __device__ constexpr int screen_row_mixture(int i, int rpm) { return (4 / rpm) * (i & 3) + (i >> 2) / rpm; }
+__host__ __device__ constexpr int screen_row_index(int i, int rpm) { return (i >> 2) % rpm; }
 
 // one 1 KB wave instruction of LDS-DMA: uniform global address, uniform LDS byte address, the lane's 16-byte offset
 __device__ __forceinline__ void dma_1k(const char *ga, unsigned la, unsigned lane_off) {
@@ -36,7 +44,7 @@ __device__ __forceinline__ void dma_1k(const char *ga, unsigned la, unsigned lan
 
 template <int DP, int FT, int WAVES>
 __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(DP <= 40 ? (FT == 2 ? 3 : 4) : 2)))
-gmmmap_screen_kernel(const double *__restrict__ packed, const double *__restrict__ packedQ, int M, int D,
+gmmmap_screen_kernel(const double *__restrict__ packed, const double *__restrict__ packedQ, int rpm, int M, int D,
                      const double *__restrict__ X, int64_t ldx, int64_t T, double *__restrict__ Y, int64_t ldy, double prune,
                      unsigned long long *__restrict__ nreg, const int *__restrict__ perm, const int *__restrict__ gkey) {
   using TL = Tiling<DP, false>;
@@ -294,23 +302,27 @@ gmmmap_screen_kernel(const double *__restrict__ packed, const double *__restrict
   }
 
   // ---- 2. screen every quad: stage s is in buffer (s + 1) & 1, stage s + 1 is fetched into the other one meanwhile
-  const int nstages = (M + 4 * QS - 1) / (4 * QS);
+  const int mpt = 16 / rpm;                                      // mixtures per screening tile
+  const int nstages = (M + mpt * QS - 1) / (mpt * QS);
   for (int s = 0; s < nstages; ++s) {
     if (s + 1 < nstages) dma_stage(s + 1, s & 1);
     __builtin_amdgcn_sched_barrier(0);
     const double *stg = smem + ((s + 1) & 1) * BUF;
 #pragma unroll
     for (int q = 0; q < QS; ++q) {
-      if (16 * s + 4 * q >= M) break;                            // (wave-uniform)
+      const int m0 = (QS * s + q) * mpt;                         // first mixture of the tile
+      if (m0 >= M) break;                                        // (wave-uniform)
       const double *fq = stg + q * (KS * 64) + lane;
-      const double *cl = stg + QFR + q * 24 + lgrp * 6;
+      const double *cl = stg + QFR + q * 32 + lgrp * 8;
       double afr[KS];
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) afr[ks] = fq[ks * 64];
       d4 c;
 #pragma unroll
       for (int r = 0; r < 4; ++r) c[r] = cl[r];
-      const double lcq = cl[4];
+      double lcq[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) lcq[u] = cl[4 + u];
       d4 a[FT];
 #pragma unroll
       for (int f = 0; f < FT; ++f) a[f] = c;
@@ -320,22 +332,35 @@ gmmmap_screen_kernel(const double *__restrict__ packed, const double *__restrict
         for (int f = 0; f < FT; ++f) a[f] = __builtin_amdgcn_mfma_f64_16x16x4f64(afr[ks], xb[f][ks], a[f], 0, 0, 0);
       }
       nmfma_wave += FT * KS;
-      unsigned long long pass = 0;
+      // pass[u]: lanes (lane group j, frame) that do not rule sub-mixture u of lane group j out (u < 4 / rpm)
+      unsigned long long pass[4] = {0, 0, 0, 0};
 #pragma unroll
       for (int f = 0; f < FT; ++f) {
-        double p = a[f][0] * a[f][0];
-        p = fma(a[f][1], a[f][1], p);
-        p = fma(a[f][2], a[f][2], p);
-        p = fma(a[f][3], a[f][3], p);
-        const unsigned long long b = __builtin_amdgcn_ballot_w64(fma(-0.5, p, lcq) > thr[f]);
-        if (tiles_in_range >> f & 1u) pass |= b;
+        if (!(tiles_in_range >> f & 1u)) continue;
+        const double s0 = a[f][0] * a[f][0], s1 = a[f][1] * a[f][1], s2 = a[f][2] * a[f][2], s3 = a[f][3] * a[f][3];
+        if (rpm == 4) {
+          pass[0] |= __builtin_amdgcn_ballot_w64(fma(-0.5, (s0 + s1) + (s2 + s3), lcq[0]) > thr[f]);
+        } else if (rpm == 2) {
+          pass[0] |= __builtin_amdgcn_ballot_w64(fma(-0.5, s0 + s1, lcq[0]) > thr[f]);
+          pass[1] |= __builtin_amdgcn_ballot_w64(fma(-0.5, s2 + s3, lcq[1]) > thr[f]);
+        } else {
+          pass[0] |= __builtin_amdgcn_ballot_w64(fma(-0.5, s0, lcq[0]) > thr[f]);
+          pass[1] |= __builtin_amdgcn_ballot_w64(fma(-0.5, s1, lcq[1]) > thr[f]);
+          pass[2] |= __builtin_amdgcn_ballot_w64(fma(-0.5, s2, lcq[2]) > thr[f]);
+          pass[3] |= __builtin_amdgcn_ballot_w64(fma(-0.5, s3, lcq[3]) > thr[f]);
+        }
       }
-      if (pass) {                                                // rare: some mixture of the quad is not ruled out for some frame
+      if (pass[0] | pass[1] | pass[2] | pass[3]) {               // rare: some mixture of the tile is not ruled out for some frame
         if (lane == 0) {
+          const int per = 4 / rpm;                               // sub-mixtures per lane group
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const int m = 16 * s + 4 * q + j;
-            if ((pass >> (16 * j) & 0xffffull) && m < M && !(keys[m >> 5] >> (m & 31) & 1u)) atomicOr(&survivors[m >> 5], 1u << (m & 31));
+          for (int u = 0; u < 4; ++u) {
+            if (u >= per) break;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const int m = m0 + per * j + u;
+              if ((pass[u] >> (16 * j) & 0xffffull) && m < M && !(keys[m >> 5] >> (m & 31) & 1u)) atomicOr(&survivors[m >> 5], 1u << (m & 31));
+            }
           }
         }
       }

@@ -82,5 +82,44 @@ inline void lower_inverse(const double *L, int n, double *U) {
   }
 }
 
+// Eigen-decomposition of a symmetric n x n matrix by cyclic Jacobi rotations (n is a few tens, once per mixture at handle
+// creation).  A (row-major) is destroyed: its diagonal ends as the eigenvalues; column j of V (row-major n x n) is the unit
+// eigenvector of eigenvalue A[j][j].
+inline void sym_eigen_jacobi(double *A, int n, double *V) {
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j < n; ++j) V[(size_t)i * n + j] = (i == j) ? 1.0 : 0.0;
+  for (int sweep = 0; sweep < 60; ++sweep) {
+    double off = 0.0, diag = 0.0;
+    for (int p = 0; p < n; ++p) {
+      diag += A[(size_t)p * n + p] * A[(size_t)p * n + p];
+      for (int q = p + 1; q < n; ++q) off += A[(size_t)p * n + q] * A[(size_t)p * n + q];
+    }
+    if (!(off > 1e-30 * diag)) break;
+    for (int p = 0; p < n - 1; ++p)
+      for (int q = p + 1; q < n; ++q) {
+        const double apq = A[(size_t)p * n + q];
+        if (apq == 0.0) continue;
+        const double theta = (A[(size_t)q * n + q] - A[(size_t)p * n + p]) / (2.0 * apq);
+        const double t = (theta >= 0.0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+        const double c = 1.0 / std::sqrt(t * t + 1.0), sn = t * c;
+        for (int k = 0; k < n; ++k) {                 // columns p, q
+          const double akp = A[(size_t)k * n + p], akq = A[(size_t)k * n + q];
+          A[(size_t)k * n + p] = c * akp - sn * akq;
+          A[(size_t)k * n + q] = sn * akp + c * akq;
+        }
+        for (int k = 0; k < n; ++k) {                 // rows p, q
+          const double apk = A[(size_t)p * n + k], aqk = A[(size_t)q * n + k];
+          A[(size_t)p * n + k] = c * apk - sn * aqk;
+          A[(size_t)q * n + k] = sn * apk + c * aqk;
+        }
+        for (int k = 0; k < n; ++k) {
+          const double vkp = V[(size_t)k * n + p], vkq = V[(size_t)k * n + q];
+          V[(size_t)k * n + p] = c * vkp - sn * vkq;
+          V[(size_t)k * n + q] = sn * vkp + c * vkq;
+        }
+      }
+  }
+}
+
 }  // namespace la
 }  // namespace vcmi

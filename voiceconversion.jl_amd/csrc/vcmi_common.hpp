@@ -111,6 +111,7 @@ enum : unsigned {
   kDbgEstepFullNoLists = 65536u,  // full-covariance statistics: every workgroup stages every frame of its segment (rounds 1-3) instead of its group's frame list
   kDbgDtwTwoSegments = 16384u,    // fused DTW: at most two column segments per strip (A/B of the traffic / balance trade)
   kDbgConvertShapeScreened = 262144u, // fvconvert: the four-row screening kernel (shape 3) on grouped calls whatever the model
+  kDbgScreenRows4 = 2097152u, kDbgScreenRows2 = 524288u, kDbgScreenRows1 = 1048576u,   // shape 3: rows per mixture of the screen, read when a converter is created
   kDbgConvertWideTiles = 131072u, // fvconvert: two frame tiles per wave (128-frame workgroups) also for calls of a few thousand frames
   kDbgPredictNoEarlyExit = 64u   // predict / trajectory argmax: every whitening tile of every mixture (MODE 2) instead of the early exit (MODE 3)
 };
