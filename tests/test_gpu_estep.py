@@ -199,3 +199,39 @@ def test_output_buffer_is_overwritten_not_accumulated(vc, Dj, M, N):
     assert torch.equal(again, fresh)
     if N == 0:
         assert float(got.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("N,Dj,M,hard", [(50_000, 80, 128, False), (4097, 80, 65, False), (31, 80, 128, False), (20_000, 64, 100, False),
+                                         (9000, 32, 128, False), (7000, 50, 96, False), (6000, 80, 128, True), (6000, 48, 70, True)])
+def test_one_barrier_experiment_against_the_three_barrier_kernel(vc, N, Dj, M, hard):
+    """More than 64 mixtures, Dj <= 80: estep_wave_kernel (csrc/estep_wave.hpp) -- every wave keeps the softmax of its own 16
+    mixtures to itself, one exchange + barrier per 32-frame block, the responsibilities never stored -- against
+    estep_mfma_kernel (three barriers per 64-frame block: the default -- the experiment is slower; DBG_ESTEP_WAVE_KERNEL selects it) and the oracle: statistics to 1e-12 of
+    each other (other summation orders), repeat runs bit-identical; `hard`: overlapping mixtures with tight variances, where
+    competing mixtures are re-evaluated term by term (the block's second exchange)."""
+    from oracle import c_oracle as co, np_oracle as npo
+    from voiceconversion_jl_amd import _lib
+    if hard:
+        w, mu, var, X = _hard_case(900 + Dj + M, Dj, M, N, 10.0, 1e-7, 1e-2, 3.0)
+    else:
+        w, mu, _ = npo.synth_model(4000 + N, Dj, M)
+        rg = np.random.default_rng(N)
+        var = np.exp(rg.uniform(np.log(1e-3), 0.0, (M, Dj)))
+        comp = rg.choice(M, size=N, p=w)
+        X = mu[comp] + rg.standard_normal((N, Dj)) * np.sqrt(var[comp])
+    o = vc.estep_diag(X.T, w, mu.T, var.T)
+    _lib.debug_force(_lib.DBG_ESTEP_WAVE_KERNEL)
+    try:
+        a = vc.estep_diag(X.T, w, mu.T, var.T)
+        for _ in range(2):
+            b = vc.estep_diag(X.T, w, mu.T, var.T)
+            assert all(np.array_equal(p, q) for p, q in zip(a[:3], b[:3])) and a[3] == b[3]
+        S0, S1, S2, ll = vc.estep_diag(X[:8000].T, w, mu.T, var.T)
+    finally:
+        _lib.debug_force(0)
+    for p, q in zip(a[:3], o[:3]):
+        assert relerr(p, q) < 1e-12, relerr(p, q)
+    assert abs(a[3] - o[3]) < 1e-12 * abs(o[3])
+    r0, r1, r2, rl = co.estep_diag(X[:8000], w, mu, var)
+    assert relerr(S0, r0) < TOL and relerr(S1, r1.T) < TOL and relerr(S2, r2.T) < TOL
+    assert abs(ll - rl) < TOL * abs(rl)

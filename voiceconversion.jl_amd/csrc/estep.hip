@@ -589,6 +589,10 @@ estep_mfma_kernel(const double *__restrict__ X, int64_t N, int M, const double *
   }
 }
 
+}  // namespace vcmi
+#include "estep_wave.hpp"
+namespace vcmi {
+
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
@@ -733,6 +737,20 @@ static int estep_mfma_launch(EstepScratch &sc, const double *dX, int64_t N, int 
   VCMI_HIP(hipGetLastError());
   const double *dmu = draw + M;      // (the means of the re-evaluation are the uploaded parameters themselves: raw = [w | mu (Dj,M) | var (Dj,M)])
   if constexpr (!C::SPLIT) {
+    if (mtp == 8 && debug_flag(kDbgEstepWaveKernel)) {      // (measured slower than the three-barrier kernel: 1.59 against 1.32 ms -- DESIGN 3.3 round 5)
+      // more than 64 mixtures: every wave owns a tile of 16 -- the one-barrier-per-block kernel (estep_wave.hpp)
+      using CW = EstepWaveCfg<DJ>;
+      const int gridw = (int)std::min<int64_t>((N + CW::FB - 1) / CW::FB, cus);
+      VCMI_TRY(sc.part.reserve((size_t)gridw * plen));
+      auto kw = estep_wave_kernel<DJ>;
+      VCMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kw), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CW::LDS_BYTES));
+      hipLaunchKernelGGL(kw, dim3(gridw), dim3(512), CW::LDS_BYTES, st, dX, N, M, sc.Wpack.p, sc.cinit.p, sc.part.p, plen, dmu, sc.refiv.p,
+                         sc.refc.p, dj, sc.mfma_count.p);
+      VCMI_HIP(hipGetLastError());
+      estep_reduce_launch(sc.part.p, gridw, plen, dstats, st, /*accumulate=*/0);
+      VCMI_HIP(hipGetLastError());
+      return VCMI_OK;
+    }
     auto kern = (mtp < 8) ? estep_mfma_kernel<DJ, 0, true> : estep_mfma_kernel<DJ, 0, false>;
     VCMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)C::LDS_BYTES));

@@ -112,6 +112,7 @@ enum : unsigned {
   kDbgDtwTwoSegments = 16384u,    // fused DTW: at most two column segments per strip (A/B of the traffic / balance trade)
   kDbgConvertShapeScreened = 262144u, // fvconvert: the four-row screening kernel (shape 3) on grouped calls whatever the model
   kDbgScreenRows4 = 2097152u, kDbgScreenRows2 = 524288u, kDbgScreenRows1 = 1048576u,   // shape 3: rows per mixture of the screen, read when a converter is created
+  kDbgEstepWaveKernel = 4194304u,    // diagonal E-step, M > 64: the one-barrier-per-block experiment (estep_wave.hpp) instead of estep_mfma_kernel
   kDbgConvertWideTiles = 131072u, // fvconvert: two frame tiles per wave (128-frame workgroups) also for calls of a few thousand frames
   kDbgPredictNoEarlyExit = 64u   // predict / trajectory argmax: every whitening tile of every mixture (MODE 2) instead of the early exit (MODE 3)
 };
