@@ -7,5 +7,5 @@
 names=$1; shift
 for v in $names; do
   echo -n "$v: "
-  LIBVCMI_PROBE=tools/_lib_$v.so python bench.py "$@" --cpu-seconds 1 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('%.4f ms' % d['ms_per_step'], 'frac %.4f' % d['roofline']['frac'], 'err', d.get('parity_max_rel_err_vs_oracle'))"
+  LIBVCMI_PROBE=tools/_lib_$v.so python bench.py "$@" --cpu-seconds 1 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('%.4f ms' % d['ms_per_step'], 'steady %s' % (d.get('steady') or {}).get('steady_ms_per_step'), 'frac %.4f' % d['roofline']['frac'], 'err', d.get('parity_max_rel_err_vs_oracle'))"
 done

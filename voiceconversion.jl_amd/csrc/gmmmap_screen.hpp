@@ -72,8 +72,12 @@ gmmmap_screen_kernel(const double *__restrict__ packed, const double *__restrict
   // group of the workgroup's first frame: the mixture evaluated first
   int mg = 0;
   {
+    // (uniform addresses through the constant address space: two dependent SCALAR loads -- the chain perm -> gkey -> DMA of the
+    // block does not queue behind, or hold up, the vector loads of the frames below; perm / gkey were written by earlier kernels)
     const int64_t f0 = (int64_t)blockIdx.x * WAVES * (16 * FT);
-    mg = (f0 < T) ? gkey[perm[f0]] : 0;
+    const __attribute__((address_space(4))) int *perm_c = (const __attribute__((address_space(4))) int *)perm;
+    const __attribute__((address_space(4))) int *gkey_c = (const __attribute__((address_space(4))) int *)gkey;
+    mg = (f0 < T) ? gkey_c[perm_c[f0]] : 0;
     mg = (mg >= 0 && mg < M) ? mg : 0;
   }
   // block mg -> buffer 0, stage 0 -> buffer 1 (each wave issues every WAVES-th KB)
