@@ -1,7 +1,6 @@
 // core.cpp -- error plumbing, device selection, version string of libvcmi.
 #include <cstdlib>
 #include "vcmi_common.hpp"
-#include "hostpipe.hpp"
 
 #include <atomic>
 
@@ -66,16 +65,5 @@ extern "C" int vcmi_device_count(int *count) {
 extern "C" int vcmi_set_device(int device) {
   VCMI_TRY(vcmi::check_device());
   VCMI_HIP(hipSetDevice(device));
-  return VCMI_OK;
-}
-
-extern "C" int vcmi_host_register(void *ptr, size_t bytes) {
-  VCMI_TRY(vcmi::check_device());
-  return vcmi::host_register(ptr, bytes);
-}
-extern "C" int vcmi_host_unregister(void *ptr) { return vcmi::host_unregister(ptr); }
-extern "C" int vcmi_host_is_registered(const void *ptr, size_t bytes, int *flag) {
-  if (!flag) return vcmi::fail(VCMI_ERR_ARG, "vcmi_host_is_registered: NULL argument");
-  *flag = vcmi::host_is_registered(ptr, bytes);
   return VCMI_OK;
 }

@@ -810,6 +810,18 @@ int staged_pipeline(const void *hIn, size_t in_unit, size_t in_stride, void *hOu
 
 }  // namespace vcmi
 
+// include/vcmi.h: caller-pinned arrays
+extern "C" int vcmi_host_register(void *ptr, size_t bytes) {
+  VCMI_TRY(vcmi::check_device());
+  return vcmi::host_register(ptr, bytes);
+}
+extern "C" int vcmi_host_unregister(void *ptr) { return vcmi::host_unregister(ptr); }
+extern "C" int vcmi_host_is_registered(const void *ptr, size_t bytes, int *flag) {
+  if (!flag) return vcmi::fail(VCMI_ERR_ARG, "vcmi_host_is_registered: NULL argument");
+  *flag = vcmi::host_is_registered(ptr, bytes);
+  return VCMI_OK;
+}
+
 // Measurement hook (not part of include/vcmi.h; bench.py's `host_inclusive.pcie`): what the link gives THIS library's own
 // staging path -- the ring's pinned slots and its upload / download streams, chunk by chunk as staged_pipeline moves them,
 // without any host memcpy or kernel: out[0] = H2D alone, out[1] = D2H alone, out[2] = both directions at once (GB/s per
