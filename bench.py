@@ -476,6 +476,7 @@ def bench_convert(args, world, rank, variant="synthetic"):
         issued_mfma = g.convert_plan()[0]
         nreg = g.prune_stats(False)
     per_pair_dense = 42 if D == 40 else None               # MFMA steps per (16-frame tile, mixture) with nothing skipped, D = 40
+    kname = "gmmmap_screen_kernel" if shape == 3 else "gmmmap_mfma_kernel"     # the dominant kernel of this model's loop shape
     alg_tflops = flops / (kernel_ms * 1e-3) / 1e12
     iss_tflops = (issued_mfma * MFMA_FLOP / (kernel_ms * 1e-3) / 1e12) if issued_mfma else None
     achieved = min(alg_tflops, iss_tflops) if iss_tflops else alg_tflops
@@ -495,7 +496,7 @@ def bench_convert(args, world, rank, variant="synthetic"):
         "data": "synthetic" if variant not in ("fixture", "joint") else "synthetic frames drawn from the reference's trained model",
         "config": {"workload": CONVERT_VARIANTS[variant]["label"], "D": D, "M": M, "frames_per_gpu": T,
                    "sharding": f"frames x{world}, no collective"},
-        "roofline": {"bound": "mfma", "kernel": "gmmmap_mfma_kernel<40,2,4,0,2,%d>" % shape, "achieved": achieved,
+        "roofline": {"bound": "mfma", "kernel": kname + ("<40,2,4>" if shape == 3 else "<40,2,4,0,2,%d>" % shape), "achieved": achieved,
                      "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS,
                      "traffic": None, "kernel_ms": kernel_ms,
                      "flop_per_frame": convert_flops_per_frame(D, M),
@@ -504,23 +505,23 @@ def bench_convert(args, world, rank, variant="synthetic"):
                      "mfma_issued_per_launch": issued_mfma,
                      "work_skipped": (1.0 - issued_mfma / float(per_pair_dense * tiles * M)) if (per_pair_dense and issued_mfma) else None,
                      "regressions_evaluated_frac": (nreg / float(tiles * M)) if nreg is not None else None,
-                     "loop_shape": {0: "dense", 1: "broad", 2: "peaked"}.get(shape, str(shape)),
+                     "loop_shape": {0: "dense", 1: "broad", 2: "peaked", 3: "screened"}.get(shape, str(shape)),
                      "model_active_frac": active_frac, "model_undecided_frac": undecided_frac,
                      "hbm_GBps_algorithmic": 2 * D * 8 * T / (kernel_ms * 1e-3) / 1e9},
     }
     # HBM traffic of the kernel: PMC passes of this same command, run as child processes before the timed run (LIVE_PMC)
     # or, failing that, the committed passes if they were collected from the same library sources
     if headline:
-        attach_traffic(out, "convert_traffic.json", "gmmmap_mfma_kernel", standard=(T == 1_000_000), live=LIVE_PMC.get("convert"),
+        attach_traffic(out, "convert_traffic.json", kname, standard=(T == 1_000_000), live=LIVE_PMC.get("convert"),
                        algorithmic_bytes=2.0 * D * 8 * T)
         if out["roofline"].get("traffic") is not None:
             # `traffic` is the dominant kernel's, as the roofline object is defined; the three grouping kernels in front of it read x
             # once more (the nearest-mean keys) and write the permutation
-            tot, _ = pmc_traffic("convert_traffic.json", ("gmmmap_mfma_kernel", "gmmmap_group_"), live=LIVE_PMC.get("convert"))
+            tot, _ = pmc_traffic("convert_traffic.json", (kname, "gmmmap_group_"), live=LIVE_PMC.get("convert"))
             out["roofline"]["traffic_whole_step"] = tot
         live = LIVE_PMC.get("convert") or {}
         for k, v in live.items():
-            if "gmmmap_mfma_kernel" in k and "SQ_INSTS_MFMA_per_launch" in v:
+            if kname in k and "SQ_INSTS_MFMA_per_launch" in v:
                 out["roofline"]["SQ_INSTS_MFMA_per_launch"] = v["SQ_INSTS_MFMA_per_launch"]
     # The same K steps with nothing skipped (vcmi_gmmmap_set_prune(inf): every mixture's whitening and regression for every
     # frame, the dense loop the flop count of SURVEY 8(d) assumes), and the pruned output against it.

@@ -123,11 +123,17 @@ int vcmi_gmmmap_prune_stats(vcmi_gmmmap *g, int enable, int64_t *evaluated);
  *                               vcmi_gmmmap_prune_stats last enabled the counters (0 while they are off); synchronises;
  *   *shape (may be NULL)        the loop the library chose for this model: 0 dense (prune = +inf), 1 "broad" (every
  *                               whitening tile, one branch around the regression), 2 "peaked" (a wrong mixture is decided
- *                               out on its last whitening tile), -1 no MFMA tile kernel for this dimension;
+ *                               out on its last whitening tile), 3 "screened" (calls of 8192 frames or more, D <= 48: the
+ *                               frames are grouped, the group's own mixture is evaluated, every other one is ruled out -- four
+ *                               at a time -- by a lower bound of its distance from the four largest eigenpairs of inv(Sxx),
+ *                               survivors are evaluated in full; smaller calls of such a model run shape 2),
+ *                               -1 no MFMA tile kernel for this dimension;
  *   *model_active_frac, *model_undecided_frac (may be NULL)  the model properties behind that choice, estimated once at
  *                               creation on 256 frames drawn from the model itself: the mean fraction of the mixtures within
  *                               e^-46 of the best one, and the fraction that the last 16-row whitening tile's share of |z|^2
- *                               alone does NOT put e^-46 under the best one ("peaked" is chosen below 0.35). */
+ *                               alone does NOT put e^-46 under the best one ("peaked" is chosen below 0.35; "screened" when
+ *                               the screen's own rows leave at most 0.05 undecided).  The shape selects code, never a result:
+ *                               every shape gives the dense loop's y to rounding. */
 int vcmi_gmmmap_convert_plan(vcmi_gmmmap *g, int64_t *mfma_issued, int *shape, double *model_active_frac,
                              double *model_undecided_frac);
 

@@ -139,7 +139,9 @@ def _hard_case(seed, Dj, M, N, spread, lo, hi, overlap):
 
 
 @pytest.mark.parametrize("generic", [False, True])
-@pytest.mark.parametrize("Dj,M", [(80, 128), (80, 37), (48, 16), (64, 40), (32, 128), (160, 64)])
+@pytest.mark.parametrize("Dj,M", [(80, 128), (80, 37), (48, 16), (64, 40), (32, 128), (160, 64),
+                                  # more than 128 mixtures: mixtures that compete ACROSS two groups of 128 (round 5: exact as well)
+                                  (80, 200), (48, 300), (160, 130)])
 def test_tight_variances_far_means_overlapping_mixtures(vc, generic, Dj, M):
     """sigma^2 log-uniform in [1e-7, 1e-2], |mu| up to 10, overlapping mixtures -- within 1e-9 of the
     oracle (which evaluates (x - mu)^2 / sigma^2 term by term) for both device paths."""

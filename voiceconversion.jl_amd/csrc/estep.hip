@@ -415,7 +415,11 @@ estep_mfma_kernel(const double *__restrict__ X, int64_t N, int M, const double *
 #pragma unroll
           for (int i = 0; i < C::MMAX / 16; ++i) nc += (v[i] > u - kRefine) ? 1 : 0;
           nc = row16_sum(nc);
-          if (nc > 1) {
+          // PHASE 3 (one group of 128 of a larger model): a mixture that is alone near the top of ITS group may still compete
+          // with one of another group, which this launch cannot see -- so every value within kRefine of the group's maximum is
+          // made exact, the maximum itself included (a mixture within 36 nats of the frame's maximum over all groups is within
+          // 36 nats of its own group's maximum): cross-group competition then sees exact log-densities too
+          if (nc > (PHASE == 3 ? 0 : 1)) {
             const double thr = u - kRefine;
             const double *xf = xs + f * RSX;
 #pragma unroll 1
@@ -786,8 +790,8 @@ static int estep_mfma_launch(EstepScratch &sc, const double *dX, int64_t N, int 
 // More than 128 mixtures: groups of 128, each with its own operand blocks.  Per chunk of frames: PHASE 3 per group
 // (responsibilities within the group -> G_g, the group's log-sum-exp per frame), estep_group_combine_kernel (frame-wise
 // log-sum-exp over the groups, rescaling of G, log-likelihood), PHASE 2 per group (statistics from G_g, partials reduced
-// in fixed order into the full layout).  Competing mixtures are re-evaluated exactly within a group (the kernel's
-// refinement); a pair that competes ACROSS two groups keeps the GEMM form's ~1e-7 absolute error in l.
+// in fixed order into the full layout).  Every log-density within 36 nats of its group's maximum is re-evaluated term by
+// term (the kernel's refinement, unconditional in PHASE 3), so mixtures that compete across two groups are exact as well.
 template <int DJ>
 static int estep_mfma_groups_launch(EstepScratch &sc, const double *dX, int64_t N, int dj, int M, const double *w, const double *mu,
                                     const double *var, double *dstats, int64_t plen, hipStream_t st) {
