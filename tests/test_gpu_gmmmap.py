@@ -439,10 +439,9 @@ def test_utterance_sized_calls_one_tile_per_wave(vc, T):
 @pytest.mark.parametrize("T", [1, 3000, 700_000])
 def test_pinned_arrays_take_the_direct_path_and_change_nothing(vc, fixture_model, T):
     """vcmi_host_register (include/vcmi.h): a caller that keeps its arrays pins them once; the host-pointer calls then DMA
-    straight from / into them.  Results equal the staged path's, for either side alone and for both -- bit for bit where
-    the pipeline's chunks are the same, to rounding where they are not (with both sides pinned the first and last chunks are
-    shorter, and a chunk's frames are grouped among themselves: tile compositions differ on a broad model); the
-    registration is visible through vcmi_host_is_registered, overlapping ranges and unknown pointers are refused."""
+    straight from / into them.  Results equal the staged path's, for either side alone and for both (compared to rounding:
+    a chunk's frames are grouped among themselves, so a path that chose other chunk boundaries would compose its tiles
+    differently on a broad model; repeat runs of one path are bit-identical); the registration is visible through vcmi_host_is_registered, overlapping ranges and unknown pointers are refused."""
     w, mu, sig = julia_model(*fixture_model)
     g = vc.GMMMap(w, mu, sig)
     rng = np.random.default_rng(T)

@@ -684,12 +684,12 @@ int staged_pipeline(const void *hIn, size_t in_unit, size_t in_stride, void *hOu
       return !(e && e[0] == '0');
     }();
     if (ramp && nch >= 6) {
-      // staged sides: 1/4, 1/2 (a host copy per chunk: shorter ones pay their hand-overs for nothing); both sides pinned:
-      // nothing but stream hand-overs per chunk, so the ramps start at 1/16 (7.5 -> 7.2 ms per 10^6 frames)
-      int64_t steps[4];
+      // 1/4, 1/2 of a chunk at either end.  (Both sides pinned -- nothing but stream hand-overs per chunk -- ramps from 1/16
+      // were measured: 9.3-9.6 ms per 10^6 frames against 7.4; so were uniformly smaller chunks, 12-25 ms: transfers of a few
+      // MB are not what the copy path is good at.  tools/pinned_probe.py, one box.)
+      int64_t steps[2];
       int ns = 0;
-      for (int64_t div : {16, 8, 4, 2})
-        if (div <= 4 || (in_direct && out_direct)) steps[ns++] = std::max<int64_t>(256, chunk / div / 256 * 256);
+      for (int64_t div : {4, 2}) steps[ns++] = std::max<int64_t>(256, chunk / div / 256 * 256);
       int64_t pos = 0, tail = 0;
       for (int i = 0; i < ns; ++i) tail += steps[i];      // units of the short chunks at the end
       for (int i = 0; i < ns; ++i) {
