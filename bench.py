@@ -1290,9 +1290,9 @@ def cpu_baseline_cached(workload):
     except (OSError, KeyError, ValueError):
         pass
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", f"r04_{workload}_bench.json")))
+        d = json.load(open(os.path.join(ROOT, "profiles", f"r05_{workload}_bench.json")))
         b = dict(d["cpu_baseline"])
-        b["cached"] = f"from the committed N=1 profile profiles/r04_{workload}_bench.json (another box); not re-timed at N>1"
+        b["cached"] = f"from the committed N=1 profile profiles/r05_{workload}_bench.json (another box); not re-timed at N>1"
         return b
     except (OSError, KeyError, ValueError):
         return None

@@ -23,6 +23,7 @@ for spec in ${@:-convert convert_fixture convert_joint convert_broad estep estep
   rm -rf $out/pmc_$name
   steps=20; warm=5; [ $w = trajgv ] && { steps=5; warm=2; }     # as the driver's default run: two warm-up steps leave the clock ramping
   timeout 400 python3 $R/bench.py --workload $w --steps $steps --warmup $warm --pmc off $extra 2>/dev/null | tail -1 > $out/${name}_bench.json
+  [ -f $R/gpurun_out/bench_detail_${w}_n1.json ] && cp $R/gpurun_out/bench_detail_${w}_n1.json $out/${name}_bench_detail.json      # the full record behind the line
   timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_$name -- python3 $R/bench.py --workload $w --steps $steps --warmup $warm --profile-run --clock-warm-ms 0 $extra > /dev/null 2>&1
   f=$(find $out/prof_$name -name "*kernel_stats.csv" | head -1)
   [ -n "$f" ] && cp $f $out/${name}_kernel_stats.csv
@@ -43,4 +44,5 @@ PY
   echo "$name: $(cut -c1-200 $out/${name}_bench.json | grep -o '"value": [0-9.e+]*\|ms_per_step": [0-9.]*' | tr '\n' ' ')"
 done
 ( time python3 $R/bench.py --steps 20 --warmup 5 > $out/all_bench.json 2> $out/all_bench.err ) 2> $out/all_bench.time
-echo "default command: $(cat $out/all_bench.time | tr '\n' ' ')"
+[ -f $R/gpurun_out/bench_detail_all_n1.json ] && cp $R/gpurun_out/bench_detail_all_n1.json $out/all_bench_detail.json
+echo "default command: $(cat $out/all_bench.time | tr '\n' ' '); line: $(wc -c < $out/all_bench.json) bytes"
