@@ -99,7 +99,11 @@ def traffic_from_table(tr, kernel_prefix, fetch_factor=VECTOR_FETCH_FACTOR):
 def table_problems(tr, kernel_prefixes):
     """Why a PMC table must not be quoted: problems its collector recorded, or a kernel of interest whose launch count is not
     a whole number of launches per bench step (round 4: ~60 clock-warm launches were divided by 3 steps)."""
-    why = list((tr.get("_meta") or {}).get("problems") or [])
+    rec = (tr.get("_meta") or {}).get("problems") or {}
+    if isinstance(rec, dict):        # per kernel: only the kernels of interest count (model uploads, set-up calls do not)
+        why = ["%s: %s" % (k[:60], v) for k, v in rec.items() if any(p in k for p in kernel_prefixes)]
+    else:
+        why = list(rec)
     for k, v in tr.items():
         if k.startswith("_") or not any(p in k for p in kernel_prefixes):
             continue

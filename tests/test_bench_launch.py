@@ -138,6 +138,9 @@ def test_traffic_tables_with_wrong_step_accounting_are_refused(tmp_path, monkeyp
     out = {"roofline": {"kernel_ms": 1.0}}
     bench.attach_traffic(out, "x", "vcmi::k", 1.0, live=live, algorithmic_bytes=1.024e9)
     assert out["roofline"]["traffic"] == 2e6 * 1024 and abs(out["roofline"]["traffic_x_algorithmic"] - 2.0) < 1e-12
-    live["_meta"]["problems"] = ["k: 7 launches in the FETCH_SIZE pass are not a multiple of the 3 steps"]
+    live["_meta"]["problems"] = {"__amd_rocclr_copyBuffer": "5 launches in the FETCH_SIZE pass are not a multiple of the 3 steps"}
+    v, src = bench.pmc_traffic("x", "vcmi::k", 1.0, live=live)                # another kernel's problem (a model upload): not ours
+    assert v == 2e6 * 1024
+    live["_meta"]["problems"]["void vcmi::k<1>"] = "7 launches in the FETCH_SIZE pass are not a multiple of the 3 steps"
     v, src = bench.pmc_traffic("x", "vcmi::k", 1.0, live=live)
     assert v is None and "not a multiple" in src["source"]

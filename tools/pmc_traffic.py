@@ -39,7 +39,7 @@ def main():
     res = collections.defaultdict(dict)
     cmd_tail = ["--", sys.executable, os.path.join(ROOT, "bench.py"), "--workload", w, "--steps", "2", "--warmup", "1",
                 "--profile-run", "--clock-warm-ms", "0", "--pmc", "off"] + argv
-    problems = []
+    problems = {}            # kernel -> why its per-step figures cannot be trusted (bench.py refuses a table for the kernels named here)
     for c in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_MFMA"):
         d = os.path.join(out, c)
         os.makedirs(d, exist_ok=True)
@@ -60,7 +60,7 @@ def main():
                 continue
             per_step = n[k] / NSTEPS
             if n[k] % NSTEPS and n[k] > NSTEPS:      # (kernels launched once, e.g. by the parity sample, are not per-step work)
-                problems.append("%s: %d launches in the %s pass are not a multiple of the %d steps" % (k, n[k], c, NSTEPS))
+                problems[k] = "%d launches in the %s pass are not a multiple of the %d steps" % (n[k], c, NSTEPS)
             res[k][c + "_KB_per_launch"] = acc[k] / n[k]
             res[k][c + "_KB_per_step"] = acc[k] / n[k] * per_step
             res[k]["launches_per_step"] = per_step

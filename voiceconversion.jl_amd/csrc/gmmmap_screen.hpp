@@ -298,6 +298,9 @@ gmmmap_screen_kernel(const double *__restrict__ packed, const double *__restrict
   } else {
     thr[0] = runmax[0] - prune;
   }
+#pragma unroll
+  for (int f = 0; f < FT; ++f)
+    if (!(tiles_in_range >> f & 1u)) thr[f] = INFINITY;            // a tile beyond T: no mixture passes on its account
   __syncthreads();                                               // everyone is done with the block buffers
   if (nkeys >= 2) {
     dma_stage(0, 1);
@@ -312,10 +315,11 @@ gmmmap_screen_kernel(const double *__restrict__ packed, const double *__restrict
     if (s + 1 < nstages) dma_stage(s + 1, s & 1);
     __builtin_amdgcn_sched_barrier(0);
     const double *stg = smem + ((s + 1) & 1) * BUF;
-#pragma unroll
-    for (int q = 0; q < QS; ++q) {
-      const int m0 = (QS * s + q) * mpt;                         // first mixture of the tile
-      if (m0 >= M) break;                                        // (wave-uniform)
+    // bit 4 q + u of a lane: sub-mixture u of the lane's group in tile q of the stage is NOT ruled out for the lane's frame on
+    // some tile of the wave.  Collected branch-free (a compare and an or per test) and looked at once per stage, so that the
+    // four tiles of a stage are one straight block: their operand reads, MFMAs and tests overlap
+    unsigned lanebits = 0;
+    auto screen_tile = [&](int q) {
       const double *fq = stg + q * (KS * 64) + lane;
       const double *cl = stg + QFR + q * 32 + lgrp * 8;
       double afr[KS];
@@ -336,37 +340,37 @@ gmmmap_screen_kernel(const double *__restrict__ packed, const double *__restrict
         for (int f = 0; f < FT; ++f) a[f] = __builtin_amdgcn_mfma_f64_16x16x4f64(afr[ks], xb[f][ks], a[f], 0, 0, 0);
       }
       nmfma_wave += FT * KS;
-      // pass[u]: lanes (lane group j, frame) that do not rule sub-mixture u of lane group j out (u < 4 / rpm)
-      unsigned long long pass[4] = {0, 0, 0, 0};
 #pragma unroll
       for (int f = 0; f < FT; ++f) {
-        if (!(tiles_in_range >> f & 1u)) continue;
         const double s0 = a[f][0] * a[f][0], s1 = a[f][1] * a[f][1], s2 = a[f][2] * a[f][2], s3 = a[f][3] * a[f][3];
+        const double th = thr[f];                                // (+inf for a tile beyond T: nothing passes)
         if (rpm == 4) {
-          pass[0] |= __builtin_amdgcn_ballot_w64(fma(-0.5, (s0 + s1) + (s2 + s3), lcq[0]) > thr[f]);
+          lanebits |= (fma(-0.5, (s0 + s1) + (s2 + s3), lcq[0]) > th) ? (1u << (4 * q)) : 0u;
         } else if (rpm == 2) {
-          pass[0] |= __builtin_amdgcn_ballot_w64(fma(-0.5, s0 + s1, lcq[0]) > thr[f]);
-          pass[1] |= __builtin_amdgcn_ballot_w64(fma(-0.5, s2 + s3, lcq[1]) > thr[f]);
+          lanebits |= (fma(-0.5, s0 + s1, lcq[0]) > th) ? (1u << (4 * q)) : 0u;
+          lanebits |= (fma(-0.5, s2 + s3, lcq[1]) > th) ? (2u << (4 * q)) : 0u;
         } else {
-          pass[0] |= __builtin_amdgcn_ballot_w64(fma(-0.5, s0, lcq[0]) > thr[f]);
-          pass[1] |= __builtin_amdgcn_ballot_w64(fma(-0.5, s1, lcq[1]) > thr[f]);
-          pass[2] |= __builtin_amdgcn_ballot_w64(fma(-0.5, s2, lcq[2]) > thr[f]);
-          pass[3] |= __builtin_amdgcn_ballot_w64(fma(-0.5, s3, lcq[3]) > thr[f]);
+          lanebits |= (fma(-0.5, s0, lcq[0]) > th) ? (1u << (4 * q)) : 0u;
+          lanebits |= (fma(-0.5, s1, lcq[1]) > th) ? (2u << (4 * q)) : 0u;
+          lanebits |= (fma(-0.5, s2, lcq[2]) > th) ? (4u << (4 * q)) : 0u;
+          lanebits |= (fma(-0.5, s3, lcq[3]) > th) ? (8u << (4 * q)) : 0u;
         }
       }
-      if (pass[0] | pass[1] | pass[2] | pass[3]) {               // rare: some mixture of the tile is not ruled out for some frame
-        if (lane == 0) {
-          const int per = 4 / rpm;                               // sub-mixtures per lane group
+    };
+    const int nq = (M - QS * s * mpt + mpt - 1) / mpt;           // tiles of this stage that hold a mixture (the last stage may have fewer)
+    if (nq >= QS) {
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            if (u >= per) break;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              const int m = m0 + per * j + u;
-              if ((pass[u] >> (16 * j) & 0xffffull) && m < M && !(keys[m >> 5] >> (m & 31) & 1u)) atomicOr(&survivors[m >> 5], 1u << (m & 31));
-            }
-          }
-        }
+      for (int q = 0; q < QS; ++q) screen_tile(q);
+    } else {
+      for (int q = 0; q < nq; ++q) screen_tile(q);
+    }
+    if (__builtin_amdgcn_ballot_w64(lanebits != 0u) != 0) {      // rare: some mixture of the stage is not ruled out for some frame
+      const int per = 4 / rpm;                                   // sub-mixtures per lane group
+      while (lanebits) {                                         // (divergent: a few lanes, a few bits)
+        const int bit = __builtin_ctz(lanebits);
+        lanebits &= lanebits - 1u;
+        const int m = (QS * s + (bit >> 2)) * mpt + per * lgrp + (bit & 3);
+        if (m < M && !(keys[m >> 5] >> (m & 31) & 1u)) atomicOr(&survivors[m >> 5], 1u << (m & 31));
       }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
