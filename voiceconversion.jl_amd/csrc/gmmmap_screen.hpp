@@ -319,7 +319,8 @@ gmmmap_screen_kernel(const double *__restrict__ packed, const double *__restrict
     // some tile of the wave.  Collected branch-free (a compare and an or per test) and looked at once per stage, so that the
     // four tiles of a stage are one straight block: their operand reads, MFMAs and tests overlap
     unsigned lanebits = 0;
-    auto screen_tile = [&](int q) {
+    auto screen_tile = [&](int q, auto rpm_c) {                  // (rows per mixture as a compile-time constant: no branch inside a tile)
+      constexpr int RPM = decltype(rpm_c)::value;
       const double *fq = stg + q * (KS * 64) + lane;
       const double *cl = stg + QFR + q * 32 + lgrp * 8;
       double afr[KS];
@@ -344,9 +345,9 @@ gmmmap_screen_kernel(const double *__restrict__ packed, const double *__restrict
       for (int f = 0; f < FT; ++f) {
         const double s0 = a[f][0] * a[f][0], s1 = a[f][1] * a[f][1], s2 = a[f][2] * a[f][2], s3 = a[f][3] * a[f][3];
         const double th = thr[f];                                // (+inf for a tile beyond T: nothing passes)
-        if (rpm == 4) {
+        if constexpr (RPM == 4) {
           lanebits |= (fma(-0.5, (s0 + s1) + (s2 + s3), lcq[0]) > th) ? (1u << (4 * q)) : 0u;
-        } else if (rpm == 2) {
+        } else if constexpr (RPM == 2) {
           lanebits |= (fma(-0.5, s0 + s1, lcq[0]) > th) ? (1u << (4 * q)) : 0u;
           lanebits |= (fma(-0.5, s2 + s3, lcq[1]) > th) ? (2u << (4 * q)) : 0u;
         } else {
@@ -358,12 +359,17 @@ gmmmap_screen_kernel(const double *__restrict__ packed, const double *__restrict
       }
     };
     const int nq = (M - QS * s * mpt + mpt - 1) / mpt;           // tiles of this stage that hold a mixture (the last stage may have fewer)
-    if (nq >= QS) {
+    auto screen_stage = [&](auto rpm_c) {
+      if (nq >= QS) {
 #pragma unroll
-      for (int q = 0; q < QS; ++q) screen_tile(q);
-    } else {
-      for (int q = 0; q < nq; ++q) screen_tile(q);
-    }
+        for (int q = 0; q < QS; ++q) screen_tile(q, rpm_c);
+      } else {
+        for (int q = 0; q < nq; ++q) screen_tile(q, rpm_c);
+      }
+    };
+    if (rpm == 4) screen_stage(std::integral_constant<int, 4>{});
+    else if (rpm == 2) screen_stage(std::integral_constant<int, 2>{});
+    else screen_stage(std::integral_constant<int, 1>{});
     if (__builtin_amdgcn_ballot_w64(lanebits != 0u) != 0) {      // rare: some mixture of the stage is not ruled out for some frame
       const int per = 4 / rpm;                                   // sub-mixtures per lane group
       while (lanebits) {                                         // (divergent: a few lanes, a few bits)
