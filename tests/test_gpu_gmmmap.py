@@ -552,3 +552,64 @@ def test_screened_shape_against_dense_and_oracle(vc, D, M, T, lam_lo, rows):
             assert issued3 < (0.6 if M >= 32 else 1.0) * issued2, (issued3, issued2)
         if rows == 4:
             assert nreg3 < max(0.2, 1.5 / M) * tiles * M         # about one regression per tile: the frame's own mixture
+
+
+@pytest.mark.parametrize("D,M,T,lam_lo", [(80, 64, 40_000, 1e-3), (40, 64, 20_000, 1e-5), (80, 32, 9000, 1e-1), (24, 9, 8200, 1e-2),
+                                          (47, 130, 12_000, 1e-3), (16, 4, 8192, 1e-5), (52, 17, 10_000, 1e-1)])
+def test_screened_predict_is_exact(vc, fixture_model, D, M, T, lam_lo):
+    """From 8192 frames on predict(px, X) groups the frames by nearest source mean and runs the screened arg-max
+    (gmmmap_screen_argmax_kernel): the group keys' mixtures in full, every other mixture ruled out -- four per MFMA tile -- as
+    soon as an upper bound of its log-density lies below the best one found, survivors in full.  Indices identical to the
+    early-exit kernel's (DBG_PREDICT_NO_SCREEN), the all-tiles kernel's and the oracle's: on peaked and broad models,
+    D = 80 (the trajectory conversion's static + delta vectors), D not a multiple of 4, M not a multiple of 4 / beyond 128,
+    exact ties (duplicated mixtures: the smaller index wins whatever the evaluation order), a mixture of weight zero;
+    repeat runs identical; device-resident and host arrays."""
+    import torch
+    from oracle import c_oracle as co, np_oracle as npo
+    from voiceconversion_jl_amd import _lib
+    w, mu, sig = npo.synth_model(1900 + D + M, 2 * D, M, lam_lo=lam_lo)
+    if M >= 4:
+        mu[M - 1], sig[M - 1] = mu[0], sig[0]
+        w = w.copy(); w[M - 1] = w[0]; w[1] = 0.0; w /= w.sum()
+    X = npo.sample_frames(1901, w, mu, sig, T, 0, D)
+    g = vc.GMMMap(*julia_model(w, mu, sig))
+    auto = vc.predict(g.px, X.T)                   # the library's own choice (screened where the model's frames leave few survivors)
+    _lib.debug_force(_lib.DBG_PREDICT_SCREEN)      # ... and the screen whatever the model: on a broad one nearly every mixture survives
+    try:
+        fast = vc.predict(g.px, X.T)
+        assert np.array_equal(vc.predict(g.px, X.T), fast)
+        dev = vc.predict(g.px, torch.from_numpy(X).cuda().t())
+        assert np.array_equal(np.asarray(dev.cpu()), fast)
+    finally:
+        _lib.debug_force(0)
+    assert np.array_equal(auto, fast)
+    _lib.debug_force(_lib.DBG_PREDICT_NO_SCREEN)
+    try:
+        early = vc.predict(g.px, X.T)
+    finally:
+        _lib.debug_force(0)
+    _lib.debug_force(_lib.DBG_PREDICT_NO_EARLY_EXIT)
+    try:
+        full = vc.predict(g.px, X.T)
+    finally:
+        _lib.debug_force(0)
+    assert np.array_equal(fast, early) and np.array_equal(fast, full)
+    ref = co.GMMMap(w, mu, sig).predict(X[:3000])
+    assert np.array_equal(fast[:3000], ref)
+    if M >= 4:
+        assert not np.any(fast == M) and not np.any(fast == 2)
+
+
+def test_screened_predict_on_the_reference_model(vc, fixture_model):
+    w, mu, sig = fixture_model
+    from oracle import c_oracle as co, np_oracle as npo
+    from voiceconversion_jl_amd import _lib
+    X = npo.sample_frames(77, w, mu, sig, 30_000, 0, 40)
+    g = vc.GMMMap(*julia_model(w, mu, sig))
+    early = vc.predict(g.px, X.T)                  # (a broad model: the library keeps the early-exit kernel)
+    _lib.debug_force(_lib.DBG_PREDICT_SCREEN)
+    try:
+        fast = vc.predict(g.px, X.T)
+    finally:
+        _lib.debug_force(0)
+    assert np.array_equal(fast, early) and np.array_equal(fast[:2000], co.GMMMap(w, mu, sig).predict(X[:2000]))

@@ -203,6 +203,8 @@ DBG_CONVERT_WIDE_TILES = 131072
 DBG_CONVERT_SHAPE_SCREENED = 262144
 DBG_SCREEN_ROWS4, DBG_SCREEN_ROWS2, DBG_SCREEN_ROWS1 = 2097152, 524288, 1048576
 DBG_ESTEP_WAVE_KERNEL = 4194304
+DBG_PREDICT_NO_SCREEN = 8388608
+DBG_PREDICT_SCREEN = 16777216
 
 
 def debug_force(flags):

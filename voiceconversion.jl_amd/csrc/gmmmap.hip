@@ -1459,6 +1459,42 @@ static int dispatch_screen(const vcmi_gmmmap *g, const double *dX, int64_t ldx, 
   }
 }
 
+// predict on grouped frames with the four-row screen (gmmmap_screen_argmax_kernel): every padded dimension of the tile kernel
+template <int DP>
+static int launch_screen_argmax(const vcmi_gmmmap *g, const double *dX, int64_t ldx, int64_t T, int64_t *didx, hipStream_t st,
+                                const int *perm, const int *gkey) {
+  constexpr int WAVES = 4;
+  using TL = Tiling<DP, true>;
+  constexpr int BUF = (TL::BLK > screen_stage_doubles(DP)) ? TL::BLK : screen_stage_doubles(DP);
+  const size_t shmem = 2 * (size_t)BUF * sizeof(double);
+  auto kern = gmmmap_screen_argmax_kernel<DP, WAVES>;
+  static std::atomic<bool> attr_done[64];
+  int dev = 0;
+  VCMI_HIP(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 64 || !attr_done[dev].load(std::memory_order_acquire)) {
+    VCMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    if (dev >= 0 && dev < 64) attr_done[dev].store(true, std::memory_order_release);
+  }
+  const int64_t per_wg = (int64_t)32 * WAVES;
+  hipLaunchKernelGGL(kern, dim3((unsigned)((T + per_wg - 1) / per_wg)), dim3(WAVES * 64), shmem, st, g->packedU.p, g->packedQA.p, g->M, g->D,
+                     dX, ldx, T, didx, perm, gkey);
+  VCMI_HIP(hipGetLastError());
+  return VCMI_OK;
+}
+static int dispatch_screen_argmax(const vcmi_gmmmap *g, const double *dX, int64_t ldx, int64_t T, int64_t *didx, hipStream_t st,
+                                  const int *perm, const int *gkey) {
+  switch (g->DP) {
+#define VCMI_CASE(DPV) \
+  case DPV: return launch_screen_argmax<DPV>(g, dX, ldx, T, didx, st, perm, gkey);
+    VCMI_CASE(16) VCMI_CASE(20) VCMI_CASE(24) VCMI_CASE(28) VCMI_CASE(32) VCMI_CASE(36) VCMI_CASE(40) VCMI_CASE(44)
+    VCMI_CASE(48) VCMI_CASE(52) VCMI_CASE(56) VCMI_CASE(60) VCMI_CASE(64) VCMI_CASE(68) VCMI_CASE(72) VCMI_CASE(76)
+    VCMI_CASE(80)
+#undef VCMI_CASE
+    default: return fail(VCMI_ERR_ARG, "no screening kernel for padded dimension %d", g->DP);
+  }
+}
+
+static constexpr double kScreenArgmaxFrac = 0.10;      // predict: screened arg-max when at most this fraction of the mixtures survives the screen
 static constexpr double kBroadModelFrac = 0.35;
 // shape 3 pays while the survivors of the four-row screen stay few: a survivor costs a whole mixture (42 MFMA steps at D = 40)
 // for every wave of its workgroup, a screened mixture 2.5 -- against the 10 of shape 2's last-tile test
@@ -1476,6 +1512,41 @@ static int convert_shape(const vcmi_gmmmap *g) {
   return g->model_undecided_frac > kBroadModelFrac ? 1 : 2;
 }
 
+// The three grouping kernels (keys + chunk histograms, prefix, stable scatter) on g's scratch: *key = group of every frame,
+// *perm = frames in group order.  The caller brackets its use of them with g->grp_order.enter / leave.
+static bool can_group(const vcmi_gmmmap *g, int64_t T) {
+  const int MT = (g->M + 15) / 16;
+  const size_t gshmem = (size_t)MT * (std::min(g->DP / 4, kGroupKeyDims / 4) + 1) * 64 * sizeof(double) + (size_t)g->M * sizeof(int);
+  return T >= kSortMinFrames && T < ((int64_t)1 << 31) && g->M >= 4 && g->gfrag.p && gshmem <= 64 * 1024;
+}
+static int launch_grouping(vcmi_gmmmap *g, const double *dX, int64_t ldx, int64_t T, hipStream_t st, int **key_out, int **perm_out) {
+  const int MT = (g->M + 15) / 16;
+  const size_t gshmem = (size_t)MT * (std::min(g->DP / 4, kGroupKeyDims / 4) + 1) * 64 * sizeof(double) + (size_t)g->M * sizeof(int);
+  const int64_t nchunks = (T + kGroupChunk - 1) / kGroupChunk;
+  VCMI_TRY(g->grp.reserve((size_t)2 * T + (size_t)(nchunks + 1) * g->M));
+  VCMI_TRY(g->grp_order.enter(st));
+  int *key = g->grp.p, *perm = key + T, *chunkhist = perm + T, *total = chunkhist + nchunks * g->M;
+  int cus = 256;
+  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, g->device);
+  const unsigned kgrid = (unsigned)std::min<int64_t>(nchunks, (int64_t)cus * 4);
+  switch (g->DP) {
+#define VCMI_CASE(DPV) \
+  case DPV: hipLaunchKernelGGL(gmmmap_group_key_kernel<DPV>, dim3(kgrid), dim3(256), gshmem, st, g->gfrag.p, g->M, g->D, dX, ldx, T, key, chunkhist); break;
+    VCMI_CASE(16) VCMI_CASE(20) VCMI_CASE(24) VCMI_CASE(28) VCMI_CASE(32) VCMI_CASE(36) VCMI_CASE(40) VCMI_CASE(44)
+    VCMI_CASE(48) VCMI_CASE(52) VCMI_CASE(56) VCMI_CASE(60) VCMI_CASE(64) VCMI_CASE(68) VCMI_CASE(72) VCMI_CASE(76)
+    VCMI_CASE(80)
+#undef VCMI_CASE
+    default: return fail(VCMI_ERR_ARG, "no MFMA instantiation for padded dimension %d", g->DP);
+  }
+  hipLaunchKernelGGL(gmmmap_group_scan_kernel, dim3((unsigned)g->M), dim3(256), 0, st, chunkhist, nchunks, g->M, total);
+  hipLaunchKernelGGL(gmmmap_group_scatter_kernel, dim3((unsigned)nchunks), dim3(256), (size_t)17 * g->M * sizeof(int), st,
+                     key, T, g->M, chunkhist, total, perm);
+  VCMI_HIP(hipGetLastError());
+  *key_out = key;
+  *perm_out = perm;
+  return VCMI_OK;
+}
+
 // convert on device pointers
 int gmmmap_convert_device(vcmi_gmmmap *g, const double *dX, int64_t ldx, int64_t T, double *dY, int64_t ldy,
                           hipStream_t st) {
@@ -1485,30 +1556,9 @@ int gmmmap_convert_device(vcmi_gmmmap *g, const double *dX, int64_t ldx, int64_t
   if (use_mfma(g)) {
     // frames grouped by their nearest source mean first (see gmmmap_group_key_kernel): worth its three small kernels from a
     // few thousand frames on; the prune = +inf (dense) setting has nothing to gain from it
-    const int MT = (g->M + 15) / 16;
-    const size_t gshmem = (size_t)MT * (std::min(g->DP / 4, kGroupKeyDims / 4) + 1) * 64 * sizeof(double) + (size_t)g->M * sizeof(int);
-    if (T >= kSortMinFrames && T < ((int64_t)1 << 31) && g->M >= 4 && g->gfrag.p && gshmem <= 64 * 1024 && g->prune < 1e300 &&
-        !debug_flag(kDbgConvertNoGrouping)) {
-      const int64_t nchunks = (T + kGroupChunk - 1) / kGroupChunk;
-      VCMI_TRY(g->grp.reserve((size_t)2 * T + (size_t)(nchunks + 1) * g->M));
-      VCMI_TRY(g->grp_order.enter(st));
-      int *key = g->grp.p, *perm = key + T, *chunkhist = perm + T, *total = chunkhist + nchunks * g->M;
-      int cus = 256;
-      (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, g->device);
-      const unsigned kgrid = (unsigned)std::min<int64_t>(nchunks, (int64_t)cus * 4);
-      switch (g->DP) {
-#define VCMI_CASE(DPV) \
-  case DPV: hipLaunchKernelGGL(gmmmap_group_key_kernel<DPV>, dim3(kgrid), dim3(256), gshmem, st, g->gfrag.p, g->M, g->D, dX, ldx, T, key, chunkhist); break;
-        VCMI_CASE(16) VCMI_CASE(20) VCMI_CASE(24) VCMI_CASE(28) VCMI_CASE(32) VCMI_CASE(36) VCMI_CASE(40) VCMI_CASE(44)
-        VCMI_CASE(48) VCMI_CASE(52) VCMI_CASE(56) VCMI_CASE(60) VCMI_CASE(64) VCMI_CASE(68) VCMI_CASE(72) VCMI_CASE(76)
-        VCMI_CASE(80)
-#undef VCMI_CASE
-        default: return fail(VCMI_ERR_ARG, "no MFMA instantiation for padded dimension %d", g->DP);
-      }
-      hipLaunchKernelGGL(gmmmap_group_scan_kernel, dim3((unsigned)g->M), dim3(256), 0, st, chunkhist, nchunks, g->M, total);
-      hipLaunchKernelGGL(gmmmap_group_scatter_kernel, dim3((unsigned)nchunks), dim3(256), (size_t)17 * g->M * sizeof(int), st,
-                         key, T, g->M, chunkhist, total, perm);
-      VCMI_HIP(hipGetLastError());
+    if (can_group(g, T) && g->prune < 1e300 && !debug_flag(kDbgConvertNoGrouping)) {
+      int *key = nullptr, *perm = nullptr;
+      VCMI_TRY(launch_grouping(g, dX, ldx, T, st, &key, &perm));
       const int shape = convert_shape(g);
       const int rc = shape == 3 ? dispatch_screen(g, dX, ldx, T, dY, ldy, st, perm, key)
                    : shape == 1 ? dispatch_mfma<0, 1>(g, dX, ldx, T, dY, ldy, st, perm, key)
@@ -1570,9 +1620,24 @@ int gmmmap_posterior_device(vcmi_gmmmap *g, const double *dX, int64_t ldx, int64
   return VCMI_OK;
 }
 
-int gmmmap_predict_device(vcmi_gmmmap *g, const double *dX, int64_t ldx, int64_t T, int64_t *didx, hipStream_t st) {
+int gmmmap_predict_device(vcmi_gmmmap *g, const double *dX, int64_t ldx, int64_t T, int64_t *didx, hipStream_t st, bool allow_screen) {
   if (T == 0) return VCMI_OK;
   if (use_mfma(g) && !debug_flag(kDbgPredictTwoPass)) {    // argmax inside the MFMA kernel: no (M,T) matrix, one launch
+    // long inputs: frames grouped by nearest source mean, then the screened arg-max (exact; gmmmap_screen.hpp)
+    // -- where the model's own frames leave it few survivors (model_argmax_survivors_frac, estimated by prepare(): 3.7 x on the
+    // SURVEY 8d model's frames; on a broad model the bound from four directions never reaches the 40 nats that the full
+    // 80-dimensional distance of the best mixture costs, every mixture survives and the early-exit kernel is as fast) and the
+    // caller allows it (the trajectory conversion does not: its static + delta vectors are not draws from p(x) -- measured
+    // 4.1 against 3.3 ms per 512,000 frames there, tools/predict_screen_ab.py)
+    const bool screen_pays = (g->model_argmax_survivors_frac <= kScreenArgmaxFrac || debug_flag(kDbgPredictScreen)) && allow_screen;
+    if (screen_pays && g->packedQA.p && g->packedU.p && g->M <= 1024 && can_group(g, T) && !debug_flag(kDbgPredictNoScreen) &&
+        !debug_flag(kDbgPredictNoEarlyExit)) {
+      int *key = nullptr, *perm = nullptr;
+      VCMI_TRY(launch_grouping(g, dX, ldx, T, st, &key, &perm));
+      const int rc = dispatch_screen_argmax(g, dX, ldx, T, didx, st, perm, key);
+      (void)g->grp_order.leave(st);
+      return rc;
+    }
     // host-prepared handles carry the reversed, tile-by-tile fragments: predict with the exact early exit (MODE 3)
     if (g->packedU2.p && !debug_flag(kDbgPredictNoEarlyExit))
       return dispatch_mfma<3>(g, dX, ldx, T, reinterpret_cast<double *>(didx), 0, st);
@@ -1596,7 +1661,7 @@ int gmmmap_predict_device(vcmi_gmmmap *g, const double *dX, int64_t ldx, int64_t
 static double model_active_fraction(const std::vector<double> &hU, const std::vector<double> &hcz, const std::vector<double> &hlc,
                                     const std::vector<double> &hP, const std::vector<double> &hcP,
                                     const std::vector<double> &hmux, const double *w, int D, int DP, int M,
-                                    double *undecided_frac, double *undecided_rows) {
+                                    double *undecided_frac, double *undecided_rows, double *argmax_survivors) {
   constexpr int S = 256;
   const size_t pp = (size_t)DP * DP;
   std::vector<double> cdf(M);
@@ -1605,7 +1670,8 @@ static double model_active_fraction(const std::vector<double> &hU, const std::ve
   if (undecided_frac) *undecided_frac = 0.0;
   if (undecided_rows) undecided_rows[0] = undecided_rows[1] = undecided_rows[2] = 1.0;   // on the 4 / 2 / 1 strongest screening rows
   if (!(tot > 0.0) || M < 2) return 0.0;
-  std::vector<int> counts(S, 0), undecided(S, 0), undecided4(3 * S, 0);
+  std::vector<int> counts(S, 0), undecided(S, 0), undecided4(3 * S, 0), asurv(S, 0);
+  if (argmax_survivors) *argmax_survivors = 1.0;
   const int r_last = 16 * ((DP + 15) / 16 - 1);                       // first row of the last whitening tile
   host_parallel_for(S, 8, [&](int64_t lo, int64_t hi) {
     std::vector<double> x(D), z(D);
@@ -1663,6 +1729,11 @@ static double model_active_fraction(const std::vector<double> &hU, const std::ve
       int und = 0;                                                     // ... and on the last 16-row whitening tile's share alone
       for (int n = 0; n < M; ++n) und += (hlc[n] - 0.5 * qlast[n] > best - 46.0);
       undecided[s] = und;
+      {                                                                // predict's screen: bound from four rows >= the best log-density
+        int sv = 0;
+        for (int n = 0; n < M; ++n) sv += (hlc[n] - 0.5 * qlast4[3 * (size_t)n] >= best);
+        asurv[s] = sv;
+      }
       for (int c = 0; c < 3; ++c) {                                    // ... and on the 4 / 2 / 1 strongest screening rows alone (shape 3)
         int und4 = 0;
         for (int n = 0; n < M; ++n) und4 += (hlc[n] - 0.5 * qlast4[3 * (size_t)n + c] > best - 46.0);
@@ -1679,6 +1750,11 @@ static double model_active_fraction(const std::vector<double> &hU, const std::ve
   if (undecided_frac) *undecided_frac = sumu / ((double)S * M);
   if (undecided_rows)
     for (int c = 0; c < 3; ++c) undecided_rows[c] = sumu4[c] / ((double)S * M);
+  if (argmax_survivors && !hP.empty()) {
+    double sa = 0.0;
+    for (int s = 0; s < S; ++s) sa += asurv[s];
+    *argmax_survivors = sa / ((double)S * M);
+  }
   return sum / ((double)S * M);
 }
 
@@ -1700,7 +1776,7 @@ static int prepare(vcmi_gmmmap *g, const double *w, const double *mu, const doub
   g->h_mux.assign((size_t)D * M, 0.0);
   g->h_muy.assign((size_t)D * M, 0.0);
   std::vector<double> hU(pp * M, 0.0), hA(reg * pp * M, 0.0), hcz((size_t)DP * M, 0.0), hb(reg * DP * M, 0.0), hlc(M);
-  const bool want_screen = !px_only && D >= 4 && DP >= 16 && DP <= 48 && M <= 1024;       // (screen_has_kernel, defined below)
+  const bool want_screen = !px_only && D >= 4 && gmmmap_has_mfma(DP) && M <= 1024;       // (fvconvert's screen: DP <= 48; predict's: every tile-kernel dimension)
   std::vector<double> hP(want_screen ? (size_t)M * 4 * DP : 0, 0.0), hcP(want_screen ? (size_t)M * 4 : 0, 0.0);
   const int xo = (swap && !px_only) ? D : 0, yo = px_only ? 0 : (swap ? 0 : D);   // src/gmmmap.jl:74-78
   const double LOG2PI = 1.8378770664093454835606594728112;
@@ -1804,7 +1880,7 @@ static int prepare(vcmi_gmmmap *g, const double *w, const double *mu, const doub
     if (bs < M && bs <= bp) return fail(VCMI_ERR_NOT_PD, "Sigma^xx of mixture %d is singular", bs + 1);
     if (bp < M) return fail(VCMI_ERR_NOT_PD, "Sigma^xx of mixture %d is not positive definite", bp + 1);
   }
-  if (!px_only) g->model_active_frac = model_active_fraction(hU, hcz, hlc, hP, hcP, g->h_mux, w, D, DP, M, &g->model_undecided_frac, g->model_undecided_rows);
+  if (!px_only) g->model_active_frac = model_active_fraction(hU, hcz, hlc, hP, hcP, g->h_mux, w, D, DP, M, &g->model_undecided_frac, g->model_undecided_rows, &g->model_argmax_survivors_frac);
   // row-major blocks for the generic kernels; a p(x)-only handle that takes the MFMA path needs only its packed blocks
   // (device buffers are grow-only so that a handle re-prepared every EM iteration does not re-allocate)
   if (!(px_only && gmmmap_has_mfma(DP))) {
@@ -1878,7 +1954,7 @@ static int prepare(vcmi_gmmmap *g, const double *w, const double *mu, const doub
   // with the smallest estimated cost per 16-frame tile -- KS MFMAs screen 16 / rpm mixtures; a mixture the screen does not
   // rule out costs its whole whitening (and usually its regression) for the four waves that share it
   if (want_screen && screen_has_kernel(DP)) {
-    const int KSQ = DP / 4, QFR = screen_frag_doubles(DP), STG = screen_stage_doubles(DP);
+    const int KSQ = DP / 4, QFR = screen_frag_doubles(DP), STG = screen_stage_doubles(DP), NQ = screen_quads(DP);
     int best = 4;
     double best_cost = 1e300;
     for (int c = 0; c < 3; ++c) {
@@ -1895,11 +1971,11 @@ static int prepare(vcmi_gmmmap *g, const double *w, const double *mu, const doub
     if (debug_flag(kDbgScreenRows1)) best = 1;
     g->screen_rpm = best;
     g->model_undecided4_frac = g->model_undecided_rows[best == 4 ? 0 : best == 2 ? 1 : 2];     // what the chosen screen lets through
-    const int rpm = best, mpt = 16 / rpm, nst = (M + mpt * kScreenQuads - 1) / (mpt * kScreenQuads);
+    const int rpm = best, mpt = 16 / rpm, nst = (M + mpt * NQ - 1) / (mpt * NQ);
     std::vector<double> pq((size_t)nst * STG, 0.0);
     for (int st = 0; st < nst; ++st)
-      for (int q = 0; q < kScreenQuads; ++q) {
-        const int m0 = (kScreenQuads * st + q) * mpt;
+      for (int q = 0; q < NQ; ++q) {
+        const int m0 = (NQ * st + q) * mpt;
         double *fr = &pq[(size_t)st * STG + (size_t)q * KSQ * 64], *cl = &pq[(size_t)st * STG + QFR + (size_t)q * 32];
         for (int ks = 0; ks < KSQ; ++ks)
           for (int l = 0; l < 64; ++l) {
@@ -1919,6 +1995,29 @@ static int prepare(vcmi_gmmmap *g, const double *w, const double *mu, const doub
       }
     VCMI_TRY(g->packedQ.reserve(pq.size()));
     VCMI_HIP(hipMemcpy(g->packedQ.p, pq.data(), pq.size() * 8, hipMemcpyHostToDevice));
+  }
+  // ... and of predict's screen (gmmmap_screen_argmax_kernel): always four rows per mixture, every tile-kernel dimension
+  if (want_screen) {
+    const int KSQ = DP / 4, QFR = screen_frag_doubles(DP), STG = screen_stage_doubles(DP), NQ = screen_quads(DP);
+    const int nst = (M + 4 * NQ - 1) / (4 * NQ);
+    std::vector<double> pq((size_t)nst * STG, 0.0);
+    for (int st = 0; st < nst; ++st)
+      for (int q = 0; q < NQ; ++q) {
+        const int m0 = (NQ * st + q) * 4;
+        double *fr = &pq[(size_t)st * STG + (size_t)q * KSQ * 64], *cl = &pq[(size_t)st * STG + QFR + (size_t)q * 32];
+        for (int ks = 0; ks < KSQ; ++ks)
+          for (int l = 0; l < 64; ++l) {
+            const int i = l & 15, k = 4 * ks + (l >> 4), m = m0 + (i & 3), row = i >> 2;
+            fr[(size_t)ks * 64 + l] = (m < M && k < DP) ? hP[((size_t)m * 4 + row) * DP + k] : 0.0;
+          }
+        for (int j = 0; j < 4; ++j) {
+          const int m = m0 + j;
+          for (int r = 0; r < 4; ++r) cl[j * 8 + r] = (m < M) ? -hcP[(size_t)m * 4 + r] : 0.0;
+          for (int u = 0; u < 4; ++u) cl[j * 8 + 4 + u] = (u == 0 && m < M) ? hlc[m] : -std::numeric_limits<double>::infinity();
+        }
+      }
+    VCMI_TRY(g->packedQA.reserve(pq.size()));
+    VCMI_HIP(hipMemcpy(g->packedQA.p, pq.data(), pq.size() * 8, hipMemcpyHostToDevice));
   }
   if (!g->h_mux.empty()) {     // operand of the frame grouping (gmmmap_group_key_kernel): [-2 mu^x | |mu^x|^2] over its first dimensions, fragment order
     const int KSK = std::min(DP / 4, kGroupKeyDims / 4), KS1 = KSK + 1, MT = (M + 15) / 16, DK = std::min(D, 4 * KSK);

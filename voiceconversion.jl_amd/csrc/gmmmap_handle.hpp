@@ -25,6 +25,9 @@ struct vcmi_gmmmap {
   double model_undecided_rows[3] = {1.0, 1.0, 1.0};
   double model_undecided4_frac = 1.0;
   int screen_rpm = 4;
+  // mean fraction of the mixtures whose four-row bound reaches a model-drawn frame's best log-density: what predict's screen
+  // (gmmmap_screen_argmax_kernel) would have to evaluate in full besides the frame's own mixture
+  double model_argmax_survivors_frac = 1.0;
 
   // host copies kept for accessors and for TrajectoryGMMMap's constructor (row-major (D,D) per mixture)
   std::vector<double> h_A_julia;   // Julia memory image (D,D,M) of ΣʸˣΣˣˣ⁻¹
@@ -37,6 +40,7 @@ struct vcmi_gmmmap {
   vcmi::DevBuf<double> packed;    // [U_m ; A_m] tiles (convert)
   vcmi::DevBuf<double> packedU;   // U_m tiles only (log-density / posterior / argmax)
   vcmi::DevBuf<double> packedQ;   // stages of the screen: 4 tiles x (screen_rpm rows of 16 / screen_rpm mixtures) per stage (convert, shape 3)
+  vcmi::DevBuf<double> packedQA;  // stages of predict's screen: four rows per mixture, every tile-kernel dimension (gmmmap_screen_argmax_kernel)
   vcmi::DevBuf<double> packedU2;  // U_m tiles only, tile by tile, last tile first (predict with early exit; host-prepared handles)
   // fvconvert's frame grouping (gmmmap_group_key_kernel): nearest-source-mean operand [-2 mu | |mu|^2] in MFMA fragment order,
   // and the call's scratch: key (T), perm (T), counts (M), cursors (M)
@@ -74,7 +78,8 @@ int gmm_px_prepare_device(vcmi_gmmmap **inout, const double *d_w, const double *
 int gmmmap_convert_device(vcmi_gmmmap *g, const double *dX, int64_t ldx, int64_t T, double *dY, int64_t ldy, hipStream_t st);
 int gmmmap_logdens_device(vcmi_gmmmap *g, const double *dX, int64_t ldx, int64_t T, double *dLP, hipStream_t st);
 int gmmmap_posterior_device(vcmi_gmmmap *g, const double *dX, int64_t ldx, int64_t T, double *dP, hipStream_t st);
-int gmmmap_predict_device(vcmi_gmmmap *g, const double *dX, int64_t ldx, int64_t T, int64_t *didx, hipStream_t st);
+// allow_screen: long inputs may be grouped and run the screened arg-max (exact; pays for draws from a peaked p(x))
+int gmmmap_predict_device(vcmi_gmmmap *g, const double *dX, int64_t ldx, int64_t T, int64_t *didx, hipStream_t st, bool allow_screen = true);
 // Device group support (devgroup.hpp): gmmmap_sync_replicas is called by the host thread before group_run; inside the
 // run member i obtains its converter (g itself on g's device, else a replica created on first use).
 void gmmmap_sync_replicas(vcmi_gmmmap *g);

@@ -28,11 +28,13 @@ namespace vcmi {
 //   4: lane group j of a screening tile = mixture j's four strongest rows               ->  4 mixtures per tile
 //   2: registers {0,1} of lane group j = mixture 2j's two strongest rows, {2,3} = mixture 2j+1's  ->  8 mixtures per tile
 //   1: register r of lane group j = the strongest row of mixture 4j + r                  -> 16 mixtures per tile (KS MFMAs screen 16)
-constexpr int kScreenQuads = 4;      // screening tiles per stage (one barrier per stage: 16 / 32 / 64 mixtures)
+// screening tiles per stage (one barrier per stage: 16 / 32 / 64 mixtures at four): two beyond DP = 48, where a stage of four
+// would no longer leave room for two workgroups per CU beside the 32 KB whitening block
+__host__ __device__ constexpr int screen_quads(int DP) { return DP <= 48 ? 4 : 2; }
 
 // stage layout in doubles: [QS x KS x 64 operand fragments | QS x 4 lane groups x 8 {cinit r = 0..3, lc of sub-mixture 0..3}], whole KB
-__host__ __device__ constexpr int screen_frag_doubles(int DP) { return kScreenQuads * (DP / 4) * 64; }
-__host__ __device__ constexpr int screen_stage_doubles(int DP) { return (screen_frag_doubles(DP) + kScreenQuads * 32 + 127) / 128 * 128; }
+__host__ __device__ constexpr int screen_frag_doubles(int DP) { return screen_quads(DP) * (DP / 4) * 64; }
+__host__ __device__ constexpr int screen_stage_doubles(int DP) { return (screen_frag_doubles(DP) + screen_quads(DP) * 32 + 127) / 128 * 128; }
 // which mixture (relative to the tile's first) and which of its screening rows (0 = the strongest) tile row i stands for
 __host__ __device__ constexpr int screen_row_mixture(int i, int rpm) { return (4 / rpm) * (i & 3) + (i >> 2) / rpm; }
 __host__ __device__ constexpr int screen_row_index(int i, int rpm) { return (i >> 2) % rpm; }
@@ -49,7 +51,7 @@ gmmmap_screen_kernel(const double *__restrict__ packed, const double *__restrict
                      unsigned long long *__restrict__ nreg, const int *__restrict__ perm, const int *__restrict__ gkey) {
   using TL = Tiling<DP, false>;
   constexpr int KS = TL::KS, NT = TL::NT, NU = TL::NU, BLK = TL::BLK;
-  constexpr int QS = kScreenQuads, QFR = screen_frag_doubles(DP), STG = screen_stage_doubles(DP);
+  constexpr int QS = screen_quads(DP), QFR = screen_frag_doubles(DP), STG = screen_stage_doubles(DP);
   constexpr int BUF = (BLK > STG) ? BLK : STG;                  // doubles per buffer
   constexpr int NI_BLK = BLK / 128, NI_STG = STG / 128;         // 1 KB wave instructions per block / stage
   constexpr bool PAIRED = (FT == 2);
@@ -405,6 +407,259 @@ gmmmap_screen_kernel(const double *__restrict__ packed, const double *__restrict
         if (row < D) Y[frow[f] * ldy + row] = yacc[f][j] * inv;
       }
     }
+  }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// predict (src/gmm.jl:44-47: the index of the first maximum of the log-weighted densities) on GROUPED frames with the same
+// screen.  An arg-max needs no margin: mixture m is out as soon as its bound lc_m - |P_m (x - mu_m)|^2 / 2 lies below the best
+// log-density found so far -- so the screen decides far more often than fvconvert's (which needs e^-prune of room), on broad
+// models too.  Per workgroup: the whitening of the group keys' mixtures in full (running maximum + index), the four-row screen
+// of every other mixture against the running maximum (>=: a tie must be looked at), survivors in full.  The result is EXACT:
+// a mixture is skipped only when an upper bound of its log-density is strictly below a log-density that was evaluated, and
+// ties go to the smaller index whatever the evaluation order.  U-only blocks (Tiling<DP, true>: packedU), DP up to 80 -- what
+// the trajectory conversion's m-hat needs (static + delta source vectors).
+// ------------------------------------------------------------------------------------------------
+template <int DP, int WAVES>
+__global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(DP <= 40 ? 3 : 2)))
+gmmmap_screen_argmax_kernel(const double *__restrict__ packedU, const double *__restrict__ packedQ, int M, int D,
+                            const double *__restrict__ X, int64_t ldx, int64_t T, int64_t *__restrict__ idx,
+                            const int *__restrict__ perm, const int *__restrict__ gkey) {
+  using TL = Tiling<DP, true>;
+  constexpr int FT = 2;
+  constexpr int KS = TL::KS, NU = TL::NT, BLK = TL::BLK;
+  constexpr int QS = screen_quads(DP), QFR = screen_frag_doubles(DP), STG = screen_stage_doubles(DP);
+  constexpr int BUF = (BLK > STG) ? BLK : STG;
+  constexpr int NI_BLK = BLK / 128, NI_STG = STG / 128;
+  extern __shared__ double smem[];
+  __shared__ unsigned survivors[32];
+  __shared__ unsigned keys[32];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const unsigned lane_off = 16u * (unsigned)lane;
+  const int lcol = lane & 15, lgrp = lane >> 4;
+  const int64_t frame0 = ((int64_t)blockIdx.x * WAVES + wave) * (16 * FT);
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)(reinterpret_cast<char *>(smem));
+  if (tid < 32) survivors[tid] = 0u;
+  else if (tid < 64) keys[tid - 32] = 0u;
+
+  int mg = 0;
+  {
+    const int64_t f0 = (int64_t)blockIdx.x * WAVES * (16 * FT);
+    const __attribute__((address_space(4))) int *perm_c = (const __attribute__((address_space(4))) int *)perm;
+    const __attribute__((address_space(4))) int *gkey_c = (const __attribute__((address_space(4))) int *)gkey;
+    mg = (f0 < T) ? gkey_c[perm_c[f0]] : 0;
+    mg = (mg >= 0 && mg < M) ? mg : 0;
+  }
+  auto dma_block = [&](int m, int buf) {
+    const char *gb = reinterpret_cast<const char *>(packedU + (size_t)m * BLK);
+    const unsigned lb = lds0 + (unsigned)buf * (BUF * 8u);
+#pragma unroll
+    for (int i = 0; i < (NI_BLK + WAVES - 1) / WAVES; ++i) {
+      const int k = wave_u + WAVES * i;
+      if (k < NI_BLK) dma_1k(gb + 1024 * k, lb + 1024u * k, lane_off);
+    }
+  };
+  auto dma_stage = [&](int s, int buf) {
+    const char *gb = reinterpret_cast<const char *>(packedQ + (size_t)s * STG);
+    const unsigned lb = lds0 + (unsigned)buf * (BUF * 8u);
+#pragma unroll
+    for (int i = 0; i < (NI_STG + WAVES - 1) / WAVES; ++i) {
+      const int k = wave_u + WAVES * i;
+      if (k < NI_STG) dma_1k(gb + 1024 * k, lb + 1024u * k, lane_off);
+    }
+  };
+  dma_block(mg, 0);
+  dma_stage(0, 1);
+  __builtin_amdgcn_sched_barrier(0);
+
+  double xb[FT][KS];
+  int64_t frow[FT];
+  unsigned tiles_in_range = 0;
+#pragma unroll
+  for (int f = 0; f < FT; ++f) {
+    const int64_t fr = frame0 + 16 * f + lcol;
+    frow[f] = (fr < T) ? (int64_t)perm[fr] : fr;
+    if (frame0 + 16 * f < T) tiles_in_range |= 1u << f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int k = 4 * ks + lgrp;
+      xb[f][ks] = (fr < T && k < D) ? X[frow[f] * ldx + k] : 0.0;
+    }
+  }
+  __syncthreads();                                               // the bitmaps are zeroed
+  if (lgrp == 0) {
+#pragma unroll
+    for (int f = 0; f < FT; ++f) {
+      const int64_t fr = frame0 + 16 * f + lcol;
+      if (fr < T) {
+        const int k = gkey[frow[f]];
+        if (k >= 0 && k < M) atomicOr(&keys[k >> 5], 1u << (k & 31));
+      }
+    }
+  }
+  // selected layout: the even lane groups carry tile 0's running maximum and index, the odd ones tile 1's
+  double runmax = -INFINITY;
+  int bestm = 0;
+  const __attribute__((address_space(4))) double *packed_c = (const __attribute__((address_space(4))) double *)packedU;
+
+  // ---- the log-weighted density of one mixture for the wave's frames (all whitening tiles), then the arg-max update ----
+  auto full_l = [&](const double *cur, double lc, int m) {
+    if ((unsigned)((unsigned long long)__double_as_longlong(lc) >> 32) == 0xFFF00000u) return;      // zero weight: l = -inf, never a maximum
+    d4 acc[FT][NU];
+#pragma unroll
+    for (int t = 0; t < NU; ++t) {
+      d4 c;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) c[r] = cur[TL::CINIT_OFF + 16 * t + 4 * r + lgrp];
+#pragma unroll
+      for (int f = 0; f < FT; ++f) acc[f][t] = c;
+    }
+    constexpr int NUS = TL::NSTEPS;
+    int s = 0;
+    double a_cur = cur[lane];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+      for (int t = 0; t < NU; ++t) {
+        if (ks < TL::steps(t)) {
+          const double a = a_cur;
+          ++s;
+          if (s < NUS) a_cur = cur[s * 64 + lane];
+#pragma unroll
+          for (int f = 0; f < FT; ++f) acc[f][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, xb[f][ks], acc[f][t], 0, 0, 0);
+        }
+      }
+    }
+    double qv[FT];
+#pragma unroll
+    for (int f = 0; f < FT; ++f) {
+      double qq = 0.0;
+#pragma unroll
+      for (int t = 0; t < NU; ++t) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (16 * t + 4 * r < DP) qq = fma(acc[f][t][r], acc[f][t][r], qq);
+      }
+      qv[f] = qq;
+    }
+    const double lsel = lc - 0.5 * sum_lane_groups_pair(qv[0], qv[1]);
+    // the first maximum in INDEX order, whatever the order of evaluation: a tie goes to the smaller index
+    const bool take = (lsel > runmax) || (lsel == runmax && m < bestm);
+    runmax = take ? lsel : runmax;
+    bestm = take ? m : bestm;
+  };
+  auto eval_bitmap = [&](const unsigned *bm, int first_buf, int skip) -> int {
+    const int nwords = (M + 31) / 32;
+    int w = 0;
+    unsigned bits = __builtin_amdgcn_readfirstlane(bm[0]);
+    auto next = [&]() -> int {
+      for (;;) {
+        while (bits == 0u) {
+          if (++w >= nwords) return -1;
+          bits = __builtin_amdgcn_readfirstlane(bm[w]);
+        }
+        const int b = __builtin_ctz(bits);
+        bits &= bits - 1u;
+        if (32 * w + b != skip) return 32 * w + b;
+      }
+    };
+    int cur_m = next(), p = first_buf, n = 0;
+    if (cur_m < 0) return 0;
+    __syncthreads();
+    dma_block(cur_m, p);
+    while (cur_m >= 0) {
+      ++n;
+      const int nxt_m = next();
+      const double lc = packed_c[(size_t)cur_m * BLK + TL::LC_OFF];
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (nxt_m >= 0) dma_block(nxt_m, p ^ 1);
+      full_l(smem + p * BUF, lc, cur_m);
+      cur_m = nxt_m;
+      p ^= 1;
+    }
+    return n;
+  };
+
+  // ---- 1. the mixtures of the workgroup's group keys
+  const double lc_g = packed_c[(size_t)mg * BLK + TL::LC_OFF];
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  full_l(smem, lc_g, mg);
+  const int nkeys = eval_bitmap(keys, 0, mg);
+  double thr[FT];
+  {
+    double r0, r1;
+    unpair_lane_groups(runmax, r0, r1);
+    // (a hair of slack: the bound and the log-density it is compared with are rounded differently -- a mixture whose bound
+    // misses the running maximum by less than that is simply evaluated)
+    thr[0] = (tiles_in_range & 1u) ? r0 - (1e-7 + 1e-12 * fabs(r0)) : INFINITY;
+    thr[1] = (tiles_in_range & 2u) ? r1 - (1e-7 + 1e-12 * fabs(r1)) : INFINITY;
+  }
+  __syncthreads();
+  if (nkeys >= 2) {
+    dma_stage(0, 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+
+  // ---- 2. the screen: four mixtures per tile, against the best log-density so far (>=: a tie has to be evaluated)
+  const int nstages = (M + 4 * QS - 1) / (4 * QS);
+  for (int s = 0; s < nstages; ++s) {
+    if (s + 1 < nstages) dma_stage(s + 1, s & 1);
+    __builtin_amdgcn_sched_barrier(0);
+    const double *stg = smem + ((s + 1) & 1) * BUF;
+    unsigned lanebits = 0;
+    auto screen_tile = [&](int q) {
+      const double *fq = stg + q * (KS * 64) + lane;
+      const double *cl = stg + QFR + q * 32 + lgrp * 8;
+      d4 c;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) c[r] = cl[r];
+      const double lcq = cl[4];
+      d4 a[FT];
+#pragma unroll
+      for (int f = 0; f < FT; ++f) a[f] = c;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const double afr = fq[ks * 64];
+#pragma unroll
+        for (int f = 0; f < FT; ++f) a[f] = __builtin_amdgcn_mfma_f64_16x16x4f64(afr, xb[f][ks], a[f], 0, 0, 0);
+      }
+#pragma unroll
+      for (int f = 0; f < FT; ++f) {
+        const double s0 = a[f][0] * a[f][0], s1 = a[f][1] * a[f][1], s2 = a[f][2] * a[f][2], s3 = a[f][3] * a[f][3];
+        lanebits |= (fma(-0.5, (s0 + s1) + (s2 + s3), lcq) >= thr[f]) ? (1u << q) : 0u;
+      }
+    };
+    const int nq = (M - QS * s * 4 + 3) / 4;
+    if (nq >= QS) {
+#pragma unroll
+      for (int q = 0; q < QS; ++q) screen_tile(q);
+    } else {
+      for (int q = 0; q < nq; ++q) screen_tile(q);
+    }
+    if (__builtin_amdgcn_ballot_w64(lanebits != 0u) != 0) {
+      while (lanebits) {
+        const int bit = __builtin_ctz(lanebits);
+        lanebits &= lanebits - 1u;
+        const int m = (QS * s + bit) * 4 + lgrp;
+        if (m < M && !(keys[m >> 5] >> (m & 31) & 1u)) atomicOr(&survivors[m >> 5], 1u << (m & 31));
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+
+  // ---- 3. the survivors in full
+  eval_bitmap(survivors, 0, -1);
+
+  if (lgrp < FT) {                                               // lane group 0 holds tile 0's result, lane group 1 tile 1's
+    const int64_t fr = frame0 + 16 * lgrp + lcol;
+    if (fr < T) idx[lgrp == 0 ? frow[0] : frow[1]] = (int64_t)bestm + 1;
   }
 }
 

@@ -1052,14 +1052,14 @@ static int traj_run(vcmi_traj *t, std::vector<TrajUtt> &utts, int64_t nframes, b
   // (1) mhat = predict(g.px, X), src/trajectory_gmmmap.jl:82
   const bool g_mfma = t->NT <= 6 && !debug_flag(kDbgTrajGScalar);   // g_t on MFMA tiles (one workgroup per utterance)
   if (contiguous) {
-    VCMI_TRY(gmmmap_predict_device(t->g, dX0, D2, nframes, t->mhat.p, st));
+    VCMI_TRY(gmmmap_predict_device(t->g, dX0, D2, nframes, t->mhat.p, st, /*allow_screen=*/false));
     if (!g_mfma)
       hipLaunchKernelGGL(traj_g_kernel, dim3((unsigned)nframes), dim3(128), 2 * D2 * sizeof(double), st, dX0, nframes, D2,
                          t->mhat.p, t->AT.p, t->QT.p, t->bvec.p, t->gbuf.p);
   } else {
     for (auto &u : utts) {
       if (u.T == 0) continue;
-      VCMI_TRY(gmmmap_predict_device(t->g, u.X, D2, u.T, t->mhat.p + u.frame0, st));
+      VCMI_TRY(gmmmap_predict_device(t->g, u.X, D2, u.T, t->mhat.p + u.frame0, st, /*allow_screen=*/false));
       if (!g_mfma)
         hipLaunchKernelGGL(traj_g_kernel, dim3((unsigned)u.T), dim3(128), 2 * D2 * sizeof(double), st, u.X, (int64_t)u.T, D2,
                            t->mhat.p + u.frame0, t->AT.p, t->QT.p, t->bvec.p, t->gbuf.p + (size_t)u.frame0 * D2);

@@ -113,6 +113,8 @@ enum : unsigned {
   kDbgConvertShapeScreened = 262144u, // fvconvert: the four-row screening kernel (shape 3) on grouped calls whatever the model
   kDbgScreenRows4 = 2097152u, kDbgScreenRows2 = 524288u, kDbgScreenRows1 = 1048576u,   // shape 3: rows per mixture of the screen, read when a converter is created
   kDbgEstepWaveKernel = 4194304u,    // diagonal E-step, M > 64: the one-barrier-per-block experiment (estep_wave.hpp) instead of estep_mfma_kernel
+  kDbgPredictNoScreen = 8388608u,    // predict / trajectory argmax: the early-exit kernel (MODE 3) also for long inputs, instead of grouping + screen
+  kDbgPredictScreen = 16777216u,     // predict: grouping + screened arg-max on long inputs whatever the model
   kDbgConvertWideTiles = 131072u, // fvconvert: two frame tiles per wave (128-frame workgroups) also for calls of a few thousand frames
   kDbgPredictNoEarlyExit = 64u   // predict / trajectory argmax: every whitening tile of every mixture (MODE 2) instead of the early exit (MODE 3)
 };
