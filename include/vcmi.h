@@ -98,7 +98,9 @@ int vcmi_vc_frames(vcmi_gmmmap *g, const double *fm, int64_t T, double *out);
 /* predict_proba(g.px, X) -> P (M,T), src/gmm.jl:24-41 */
 int vcmi_gmmmap_posterior(vcmi_gmmmap *g, const double *X, int64_t ldx, int64_t T, double *P);
 int vcmi_gmmmap_posterior_dev(vcmi_gmmmap *g, const double *dX, int64_t ldx, int64_t T, double *dP, void *stream);
-/* predict(g.px, X) -> idx (T), 1-based, first maximum wins; src/gmm.jl:44-58 */
+/* predict(g.px, X) -> idx (T), 1-based, first maximum wins; src/gmm.jl:44-58.  The index is exact on every path: a
+ * mixture's evaluation is cut short (or, on inputs of 8192 frames or more of a peaked model, skipped after a four-row
+ * screen on grouped frames) only when an upper bound of its log-density lies below a log-density that was evaluated. */
 int vcmi_gmmmap_predict(vcmi_gmmmap *g, const double *X, int64_t ldx, int64_t T, int64_t *idx);
 int vcmi_gmmmap_predict_dev(vcmi_gmmmap *g, const double *dX, int64_t ldx, int64_t T, int64_t *didx, void *stream);
 /* Kernel selection: 0 = auto (MFMA tile kernel when dim(g), rounded up to a multiple of 4, is one of 16..80 in steps of

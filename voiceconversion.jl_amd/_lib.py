@@ -205,6 +205,7 @@ DBG_SCREEN_ROWS4, DBG_SCREEN_ROWS2, DBG_SCREEN_ROWS1 = 2097152, 524288, 1048576
 DBG_ESTEP_WAVE_KERNEL = 4194304
 DBG_PREDICT_NO_SCREEN = 8388608
 DBG_PREDICT_SCREEN = 16777216
+DBG_SCREEN_FP64 = 33554432
 
 
 def debug_force(flags):

@@ -1426,14 +1426,15 @@ static bool use_mfma(const vcmi_gmmmap *g) {
 
 // shape 3 (gmmmap_screen.hpp): DP = 16..48, any M up to 1024 (the survivors' bitmap)
 static bool screen_has_kernel(int DP) { return DP >= 16 && DP <= 48 && DP % 4 == 0; }
-template <int DP, int FT>
+template <int DP, int FT, bool B16 = false>
 static int launch_screen(const vcmi_gmmmap *g, const double *dX, int64_t ldx, int64_t T, double *dY, int64_t ldy, hipStream_t st,
                          const int *perm, const int *gkey) {
   constexpr int WAVES = 4;
   using TL = Tiling<DP, false>;
-  constexpr int BUF = (TL::BLK > screen_stage_doubles(DP)) ? TL::BLK : screen_stage_doubles(DP);
+  constexpr int STG = B16 ? screen16_stage_doubles(DP) : screen_stage_doubles(DP);
+  constexpr int BUF = (TL::BLK > STG) ? TL::BLK : STG;
   const size_t shmem = 2 * (size_t)BUF * sizeof(double);
-  auto kern = gmmmap_screen_kernel<DP, FT, WAVES>;
+  auto kern = gmmmap_screen_kernel<DP, FT, WAVES, B16>;
   static std::atomic<bool> attr_done[64];
   int dev = 0;
   VCMI_HIP(hipGetDevice(&dev));
@@ -1442,7 +1443,7 @@ static int launch_screen(const vcmi_gmmmap *g, const double *dX, int64_t ldx, in
     if (dev >= 0 && dev < 64) attr_done[dev].store(true, std::memory_order_release);
   }
   const int64_t per_wg = (int64_t)16 * FT * WAVES;
-  hipLaunchKernelGGL(kern, dim3((unsigned)((T + per_wg - 1) / per_wg)), dim3(WAVES * 64), shmem, st, g->packed.p, g->packedQ.p, g->screen_rpm,
+  hipLaunchKernelGGL(kern, dim3((unsigned)((T + per_wg - 1) / per_wg)), dim3(WAVES * 64), shmem, st, g->packed.p, B16 ? g->packedQ16.p : g->packedQ.p, g->screen_rpm,
                      g->M, g->D, dX, ldx, T, dY, ldy, g->prune, g->prune_count.p, perm, gkey);
   VCMI_HIP(hipGetLastError());
   return VCMI_OK;
@@ -1450,6 +1451,16 @@ static int launch_screen(const vcmi_gmmmap *g, const double *dX, int64_t ldx, in
 static int dispatch_screen(const vcmi_gmmmap *g, const double *dX, int64_t ldx, int64_t T, double *dY, int64_t ldy, hipStream_t st,
                            const int *perm, const int *gkey) {
   const bool narrow = T <= kSmallCallFrames && !debug_flag(kDbgConvertWideTiles);     // one frame tile per wave, as dispatch_mfma
+  // the screen on the BF16 matrix pipe (certified bound from split operands) where it exists: four rows per mixture, DP <= 40
+  if (g->packedQ16.p && g->screen_rpm == 4 && screen16_has(g->DP) && !debug_flag(kDbgScreenFp64)) {
+    switch (g->DP) {
+#define VCMI_CASE(DPV) \
+  case DPV: return narrow ? launch_screen<DPV, 1, true>(g, dX, ldx, T, dY, ldy, st, perm, gkey) : launch_screen<DPV, 2, true>(g, dX, ldx, T, dY, ldy, st, perm, gkey);
+      VCMI_CASE(16) VCMI_CASE(20) VCMI_CASE(24) VCMI_CASE(28) VCMI_CASE(32) VCMI_CASE(36) VCMI_CASE(40)
+#undef VCMI_CASE
+      default: break;
+    }
+  }
   switch (g->DP) {
 #define VCMI_CASE(DPV) \
   case DPV: return narrow ? launch_screen<DPV, 1>(g, dX, ldx, T, dY, ldy, st, perm, gkey) : launch_screen<DPV, 2>(g, dX, ldx, T, dY, ldy, st, perm, gkey);
@@ -1995,6 +2006,50 @@ static int prepare(vcmi_gmmmap *g, const double *w, const double *mu, const doub
       }
     VCMI_TRY(g->packedQ.reserve(pq.size()));
     VCMI_HIP(hipMemcpy(g->packedQ.p, pq.data(), pq.size() * 8, hipMemcpyHostToDevice));
+    // the same four rows split into bf16 hi + lo for the screen on the BF16 matrix pipe (gmmmap_screen.hpp, B16)
+    if (rpm == 4 && screen16_has(DP)) {
+      const int KS8 = std::min(KSQ, 8), NTL = KSQ - KS8, STG16 = screen16_stage_doubles(DP), nst16 = (M + 4 * NQ - 1) / (4 * NQ);
+      std::vector<double> p16((size_t)nst16 * STG16, 0.0);
+      const double kEps = 1.0 / 4096.0;                            // 2^-12: see the error bound in gmmmap_screen.hpp
+      for (int st = 0; st < nst16; ++st)
+        for (int q = 0; q < NQ; ++q) {
+          const int m0 = (NQ * st + q) * 4;
+          unsigned short *fr = reinterpret_cast<unsigned short *>(&p16[(size_t)st * STG16 + (size_t)q * screen16_tile_doubles()]);
+          double *cl = &p16[(size_t)st * STG16 + (size_t)NQ * screen16_tile_doubles() + (size_t)q * 64];
+          for (int l = 0; l < 64; ++l) {
+            const int r = l & 15, gq = l >> 4, m = m0 + (r >> 2), row = r & 3;     // tile row r <-> mixture r >> 2, screening row r & 3
+            auto pv = [&](int ks) -> double {                      // P[row][feature 4 ks + lane group]
+              const int k = 4 * ks + gq;
+              return (m < M && ks < KSQ && k < DP) ? hP[((size_t)m * 4 + row) * DP + k] : 0.0;
+            };
+            unsigned short ph[10] = {0}, pl[10] = {0};
+            for (int ks = 0; ks < KSQ; ++ks) split_bf16(pv(ks), ph[ks], pl[ks]);
+            for (int j = 0; j < 8; ++j) {
+              fr[(size_t)l * 8 + j] = j < KS8 ? ph[j] : 0;                       // Ph, k-steps 0..7
+              fr[512 + (size_t)l * 8 + j] = j < KS8 ? pl[j] : 0;                 // Pl, k-steps 0..7
+            }
+            const unsigned short t0h = NTL > 0 ? ph[KS8] : 0, t1h = NTL > 1 ? ph[KS8 + 1] : 0;
+            const unsigned short t0l = NTL > 0 ? pl[KS8] : 0, t1l = NTL > 1 ? pl[KS8 + 1] : 0;
+            const unsigned short tail[8] = {t0h, t1h, t0h, t1h, t0l, t1l, 0, 0};  // against {xh8, xh9, xl8, xl9, xh8, xh9, 0, 0}
+            for (int j = 0; j < 8; ++j) fr[1024 + (size_t)l * 8 + j] = tail[j];
+          }
+          for (int j = 0; j < 4; ++j) {
+            const int m = m0 + j;
+            for (int r = 0; r < 4; ++r) {
+              double nrm = 0.0;
+              if (m < M)
+                for (int k = 0; k < D; ++k) nrm += hP[((size_t)m * 4 + r) * DP + k] * hP[((size_t)m * 4 + r) * DP + k];
+              const double c = (m < M) ? hcP[(size_t)m * 4 + r] : 0.0;
+              cl[j * 16 + r] = c;
+              cl[j * 16 + 4 + r] = kEps * std::sqrt(nrm) * (1.0 + 1e-12);
+              cl[j * 16 + 8 + r] = kEps * std::fabs(c);
+            }
+            cl[j * 16 + 12] = (m < M) ? hlc[m] : -std::numeric_limits<double>::infinity();
+          }
+        }
+      VCMI_TRY(g->packedQ16.reserve(p16.size()));
+      VCMI_HIP(hipMemcpy(g->packedQ16.p, p16.data(), p16.size() * 8, hipMemcpyHostToDevice));
+    }
   }
   // ... and of predict's screen (gmmmap_screen_argmax_kernel): always four rows per mixture, every tile-kernel dimension
   if (want_screen) {
@@ -2436,8 +2491,8 @@ extern "C" int vcmi_gmmmap_prune_stats(vcmi_gmmmap *g, int enable, int64_t *eval
     }
   }
   if (enable) {
-    if (!g->prune_count.p) VCMI_TRY(g->prune_count.alloc(2));
-    VCMI_HIP(hipMemset(g->prune_count.p, 0, 2 * sizeof(unsigned long long)));
+    if (!g->prune_count.p) VCMI_TRY(g->prune_count.alloc(3));
+    VCMI_HIP(hipMemset(g->prune_count.p, 0, 3 * sizeof(unsigned long long)));
   } else {
     g->prune_count.release();
   }

@@ -11,7 +11,7 @@ struct vcmi_gmmmap {
   // fvconvert skips the regression of mixture m for a 16-frame tile when l_m < max_l - prune (nats) for all its frames:
   // the posterior there is below e^-prune (1e-20 at 46: under the rounding error of the sum).  +inf: dense loop.
   double prune = 46.0;
-  vcmi::DevBuf<unsigned long long> prune_count;   // optional diagnostic counters (vcmi_gmmmap_prune_stats): [0] (tile, mixture) regressions, [1] MFMAs issued
+  vcmi::DevBuf<unsigned long long> prune_count;   // optional diagnostic counters (vcmi_gmmmap_prune_stats): [0] (tile, mixture) regressions, [1] FP64 MFMAs issued, [2] BF16 MFMAs of the screen
   // Mean fraction of the mixtures that lie within e^-46 of the best one for a frame drawn from the model itself (256 frames
   // sampled on the host by prepare(), fixed seed).  Reported by vcmi_gmmmap_convert_plan (synthetic SURVEY 8d models: 1/M;
   // the reference's trained 32-mixture model: 0.37).
@@ -40,6 +40,7 @@ struct vcmi_gmmmap {
   vcmi::DevBuf<double> packed;    // [U_m ; A_m] tiles (convert)
   vcmi::DevBuf<double> packedU;   // U_m tiles only (log-density / posterior / argmax)
   vcmi::DevBuf<double> packedQ;   // stages of the screen: 4 tiles x (screen_rpm rows of 16 / screen_rpm mixtures) per stage (convert, shape 3)
+  vcmi::DevBuf<double> packedQ16;  // the four-row screen split into bf16 hi + lo (screen on the BF16 matrix pipe; DP <= 40)
   vcmi::DevBuf<double> packedQA;  // stages of predict's screen: four rows per mixture, every tile-kernel dimension (gmmmap_screen_argmax_kernel)
   vcmi::DevBuf<double> packedU2;  // U_m tiles only, tile by tile, last tile first (predict with early exit; host-prepared handles)
   // fvconvert's frame grouping (gmmmap_group_key_kernel): nearest-source-mean operand [-2 mu | |mu|^2] in MFMA fragment order,

@@ -39,22 +39,56 @@ __host__ __device__ constexpr int screen_stage_doubles(int DP) { return (screen_
 __host__ __device__ constexpr int screen_row_mixture(int i, int rpm) { return (4 / rpm) * (i & 3) + (i >> 2) / rpm; }
 __host__ __device__ constexpr int screen_row_index(int i, int rpm) { return (i >> 2) % rpm; }
 
+// ---- the screen on the BF16 matrix pipe (B16 = true; rpm = 4, DP <= 40) --------------------------------------------------
+// The screen only has to produce a CERTIFIED lower bound of sum_i a_i^2, a_i = P_i x - c_i.  v_mfma_f32_16x16x32_bf16 runs
+// at 16x the FP64 MFMA rate, so P and x are split into two bf16 pieces each (hi + lo: 16 of their 53 bits) and
+//   a^ = Ph xh + Ph xl + Pl xh - c      (three K = 32 instructions over the first eight k-steps of the FP64 operand layout -- lane
+//                                        group g, slot j <-> feature 4 j + g, exactly what the lane's xb[.][j] holds -- and one
+//                                        more whose slots carry the three terms of k-steps 8, 9), accumulated in FP32.
+// |a^ - a| <= (dropped Pl xl and the two split residuals: 3 x 2^-16; FP32 accumulation of <= 130 exact products: 2^-15)
+//             x sum_k |P_ik||x_k|  +  2^-24 |c_i|   <=   eps_i := 2^-12 (|P_i| |x| + |c_i|)       (Cauchy-Schwarz; ~2 x the sum above),
+// so  a_i^2 >= max(|a^_i| - eps_i, 0)^2  and  lc - sum_i max(|a^_i| - eps_i, 0)^2 / 2  is still an upper bound of the mixture's
+// log-density: a mixture it rules out is ruled out.  eps is ~0.3 where the test needs |a| of 10 and more: what the screen
+// decides hardly changes, its matrix work drops from 10 FP64 MFMAs (640 cycles) to 4 BF16 ones (64 cycles) per tile.
+// The FP32 result layout gives lane group j rows 4 j .. 4 j + 3: tile row i <-> mixture i >> 2, screening row i & 3.
+// Stage layout in doubles: per tile [Ph main | Pl main | tail] as 3 x 1 KB of bf16x8 per lane, then per tile and lane group
+// 16 doubles {c_0..3, 2^-12 |P_0..3|, 2^-12 |c_0..3|, lc, pad}.
+__host__ __device__ constexpr int screen16_tile_doubles() { return 3 * 128; }
+__host__ __device__ constexpr int screen16_stage_doubles(int DP) { return screen_quads(DP) * (screen16_tile_doubles() + 64); }
+__host__ __device__ constexpr bool screen16_has(int DP) { return DP >= 16 && DP <= 40 && DP % 4 == 0; }
+// x -> bf16 hi (round to nearest even) and bf16 lo of the FP32 remainder (x_f32 - hi is exact in FP32)
+__host__ __device__ inline void split_bf16(double x, unsigned short &h, unsigned short &l) {
+  union {
+    float f;
+    unsigned u;
+  } a, b, d;
+  a.f = (float)x;
+  h = (unsigned short)((a.u + 0x7FFFu + ((a.u >> 16) & 1u)) >> 16);
+  b.u = (unsigned)h << 16;
+  d.f = a.f - b.f;
+  l = (unsigned short)((d.u + 0x7FFFu + ((d.u >> 16) & 1u)) >> 16);
+}
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+
 // one 1 KB wave instruction of LDS-DMA: uniform global address, uniform LDS byte address, the lane's 16-byte offset
 __device__ __forceinline__ void dma_1k(const char *ga, unsigned la, unsigned lane_off) {
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(lane_off), "s"(ga), "s"(la) : "memory", "m0");
 }
 
-template <int DP, int FT, int WAVES>
+template <int DP, int FT, int WAVES, bool B16 = false>
 __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(DP <= 40 ? (FT == 2 ? 3 : 4) : 2)))
 gmmmap_screen_kernel(const double *__restrict__ packed, const double *__restrict__ packedQ, int rpm, int M, int D,
                      const double *__restrict__ X, int64_t ldx, int64_t T, double *__restrict__ Y, int64_t ldy, double prune,
                      unsigned long long *__restrict__ nreg, const int *__restrict__ perm, const int *__restrict__ gkey) {
   using TL = Tiling<DP, false>;
   constexpr int KS = TL::KS, NT = TL::NT, NU = TL::NU, BLK = TL::BLK;
-  constexpr int QS = screen_quads(DP), QFR = screen_frag_doubles(DP), STG = screen_stage_doubles(DP);
+  constexpr int QS = screen_quads(DP), QFR = screen_frag_doubles(DP), STG = B16 ? screen16_stage_doubles(DP) : screen_stage_doubles(DP);
   constexpr int BUF = (BLK > STG) ? BLK : STG;                  // doubles per buffer
   constexpr int NI_BLK = BLK / 128, NI_STG = STG / 128;         // 1 KB wave instructions per block / stage
   constexpr bool PAIRED = (FT == 2);
+  static_assert(!B16 || (screen16_has(DP) && STG % 128 == 0), "the bf16 screen covers up to ten k-steps");
   extern __shared__ double smem[];                              // 2 * BUF doubles
   __shared__ double etab[64];
   __shared__ unsigned survivors[32];                            // bit m: mixture m passed the screen on some frame of the workgroup (M <= 1024)
@@ -114,12 +148,19 @@ gmmmap_screen_kernel(const double *__restrict__ packed, const double *__restrict
     const int64_t fr = frame0 + 16 * f + lcol;
     frow[f] = (fr < T) ? (int64_t)perm[fr] : fr;
     if (frame0 + 16 * f < T) tiles_in_range |= 1u << f;
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      const int k = 4 * ks + lgrp;
-      xb[f][ks] = (fr < T && k < D) ? X[frow[f] * ldx + k] : 0.0;
-    }
   }
+  auto load_x = [&]() {
+#pragma unroll
+    for (int f = 0; f < FT; ++f) {
+      const int64_t fr = frame0 + 16 * f + lcol;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const int k = 4 * ks + lgrp;
+        xb[f][ks] = (fr < T && k < D) ? X[frow[f] * ldx + k] : 0.0;
+      }
+    }
+  };
+  load_x();
   __syncthreads();                                               // the bitmaps are zeroed
   if (lgrp == 0) {
 #pragma unroll
@@ -140,7 +181,7 @@ gmmmap_screen_kernel(const double *__restrict__ packed, const double *__restrict
 #pragma unroll
     for (int j = 0; j < KS; ++j) yacc[f][j] = 0.0;
   }
-  int nreg_wave = 0, nmfma_wave = 0;
+  int nreg_wave = 0, nmfma_wave = 0, nmfma16_wave = 0;           // (v_mfma_f64_16x16x4 / v_mfma_f32_16x16x32_bf16 instructions issued)
   const __attribute__((address_space(4))) double *packed_c = (const __attribute__((address_space(4))) double *)packed;
 
   // ---- one mixture in full from the block in `cur`: whitening, (test,) regression, online softmax update -- the "broad" loop's body
@@ -249,7 +290,7 @@ gmmmap_screen_kernel(const double *__restrict__ packed, const double *__restrict
   // ---- every mixture of a bitmap (except `skip`) in full, in index order; blocks alternate between the buffers starting with
   // `first_buf`, which every wave must have left (the caller's barrier); ends with everyone out of both buffers' readers... the
   // bitmap must be complete and visible (a barrier since its last update)
-  auto eval_bitmap = [&](const unsigned *bm, int first_buf, int skip) -> int {
+  auto eval_bitmap = [&](const unsigned *bm, int first_buf, int skip, bool reload_x) -> int {
     const int nwords = (M + 31) / 32;
     int w = 0;
     unsigned bits = __builtin_amdgcn_readfirstlane(bm[0]);
@@ -268,6 +309,8 @@ gmmmap_screen_kernel(const double *__restrict__ packed, const double *__restrict
     if (cur_m < 0) return 0;
     __syncthreads();                                             // everyone has left buffer p
     dma_block(cur_m, p);
+    // (B16: the FP64 operands of x were given up for the screen -- the survivors are rare -- and come back from L2 here)
+    if (reload_x) load_x();
     while (cur_m >= 0) {
       ++n;
       const int nxt_m = next();
@@ -289,7 +332,7 @@ gmmmap_screen_kernel(const double *__restrict__ packed, const double *__restrict
   full_mixture(smem, lc_g, false);
   // the other groups present in the workgroup (it straddles a group boundary: rare on large calls, the rule on small ones)
   // (blocks go to buffer 0, 1, 0, ...: from the second one on they overwrite stage 0, which is then fetched again)
-  const int nkeys = eval_bitmap(keys, 0, mg);
+  const int nkeys = eval_bitmap(keys, 0, mg, false);
   // the thresholds of the screen, per tile in every lane (a lane group of a screening tile is a MIXTURE, not a tile)
   double thr[FT];
   if constexpr (PAIRED) {
@@ -303,6 +346,45 @@ gmmmap_screen_kernel(const double *__restrict__ packed, const double *__restrict
 #pragma unroll
   for (int f = 0; f < FT; ++f)
     if (!(tiles_in_range >> f & 1u)) thr[f] = INFINITY;            // a tile beyond T: no mixture passes on its account
+  // B16: the B operands of the screen from the lane's own FP64 operands (slot j of the K = 32 instructions <-> k-step j), and
+  // |x| per frame for the error bound; xb itself is not needed again unless something survives
+  constexpr int NMAIN = KS < 8 ? KS : 8, NTAIL = KS - NMAIN;     // k-steps in the three main instructions / in the tail one
+  u32x4_t bh[B16 ? FT : 1], bl[B16 ? FT : 1], bt[B16 ? FT : 1];
+  double nx[B16 ? FT : 1];
+  if constexpr (B16) {
+#pragma unroll
+    for (int f = 0; f < FT; ++f) {
+      unsigned short h[KS], l[KS];
+      double q = 0.0;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        split_bf16(xb[f][ks], h[ks], l[ks]);
+        q = fma(xb[f][ks], xb[f][ks], q);
+      }
+      nx[f] = sqrt(sum_lane_groups(q)) * (1.0 + 1e-12);
+#pragma unroll
+      for (int w2 = 0; w2 < 4; ++w2) {
+        const int j0 = 2 * w2, j1 = 2 * w2 + 1;
+        bh[f][w2] = (unsigned)(j0 < NMAIN ? h[j0] : 0) | ((unsigned)(j1 < NMAIN ? h[j1] : 0) << 16);
+        bl[f][w2] = (unsigned)(j0 < NMAIN ? l[j0] : 0) | ((unsigned)(j1 < NMAIN ? l[j1] : 0) << 16);
+      }
+      // tail slots: {xh8, xh9, xl8, xl9, xh8, xh9, 0, 0}  against  {Ph8, Ph9, Ph8, Ph9, Pl8, Pl9, 0, 0}
+      unsigned short t0h = 0, t1h = 0, t0l = 0, t1l = 0;
+      if constexpr (NTAIL > 0) {
+        t0h = h[NMAIN];
+        t0l = l[NMAIN];
+      }
+      if constexpr (NTAIL > 1) {
+        t1h = h[NMAIN + 1];
+        t1l = l[NMAIN + 1];
+      }
+      const unsigned th = (unsigned)t0h | ((unsigned)t1h << 16), tl = (unsigned)t0l | ((unsigned)t1l << 16);
+      bt[f][0] = th;
+      bt[f][1] = tl;
+      bt[f][2] = th;
+      bt[f][3] = 0u;
+    }
+  }
   __syncthreads();                                               // everyone is done with the block buffers
   if (nkeys >= 2) {
     dma_stage(0, 1);
@@ -321,6 +403,41 @@ gmmmap_screen_kernel(const double *__restrict__ packed, const double *__restrict
     // some tile of the wave.  Collected branch-free (a compare and an or per test) and looked at once per stage, so that the
     // four tiles of a stage are one straight block: their operand reads, MFMAs and tests overlap
     unsigned lanebits = 0;
+    auto screen_tile16 = [&](int q) {                            // B16: lane group j <-> mixture j of the tile, its four rows in the lane
+      const char *tb = reinterpret_cast<const char *>(stg + q * screen16_tile_doubles());
+      const double *cl = stg + QS * screen16_tile_doubles() + q * 64 + lgrp * 16;
+      const u32x4_t aph = *reinterpret_cast<const u32x4_t *>(tb + 16 * lane);
+      const u32x4_t apl = *reinterpret_cast<const u32x4_t *>(tb + 1024 + 16 * lane);
+      const u32x4_t apt = *reinterpret_cast<const u32x4_t *>(tb + 2048 + 16 * lane);
+      double cc[4], np[4], nc[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        cc[i] = cl[i];
+        np[i] = cl[4 + i];
+        nc[i] = cl[8 + i];
+      }
+      const double lcq = cl[12];
+      f32x4_t a[FT];
+#pragma unroll
+      for (int f = 0; f < FT; ++f) {
+        a[f] = f32x4_t{(float)-cc[0], (float)-cc[1], (float)-cc[2], (float)-cc[3]};
+        a[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, aph), __builtin_bit_cast(bf16x8_t, bh[f]), a[f], 0, 0, 0);
+        a[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, aph), __builtin_bit_cast(bf16x8_t, bl[f]), a[f], 0, 0, 0);
+        a[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, apl), __builtin_bit_cast(bf16x8_t, bh[f]), a[f], 0, 0, 0);
+        if constexpr (NTAIL > 0)
+          a[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, apt), __builtin_bit_cast(bf16x8_t, bt[f]), a[f], 0, 0, 0);
+      }
+#pragma unroll
+      for (int f = 0; f < FT; ++f) {
+        double lb = 0.0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const double t = fmax(fabs((double)a[f][i]) - fma(np[i], nx[f], nc[i]), 0.0);      // certified |a_i| from below
+          lb = fma(t, t, lb);
+        }
+        lanebits |= (fma(-0.5, lb, lcq) > thr[f]) ? (1u << (4 * q)) : 0u;
+      }
+    };
     auto screen_tile = [&](int q, auto rpm_c) {                  // (rows per mixture as a compile-time constant: no branch inside a tile)
       constexpr int RPM = decltype(rpm_c)::value;
       const double *fq = stg + q * (KS * 64) + lane;
@@ -369,9 +486,19 @@ gmmmap_screen_kernel(const double *__restrict__ packed, const double *__restrict
         for (int q = 0; q < nq; ++q) screen_tile(q, rpm_c);
       }
     };
-    if (rpm == 4) screen_stage(std::integral_constant<int, 4>{});
-    else if (rpm == 2) screen_stage(std::integral_constant<int, 2>{});
-    else screen_stage(std::integral_constant<int, 1>{});
+    if constexpr (B16) {
+      if (nq >= QS) {
+#pragma unroll
+        for (int q = 0; q < QS; ++q) screen_tile16(q);
+      } else {
+        for (int q = 0; q < nq; ++q) screen_tile16(q);
+      }
+      nmfma16_wave += (nq < QS ? nq : QS) * FT * (3 + (NTAIL > 0 ? 1 : 0));
+    } else {
+      if (rpm == 4) screen_stage(std::integral_constant<int, 4>{});
+      else if (rpm == 2) screen_stage(std::integral_constant<int, 2>{});
+      else screen_stage(std::integral_constant<int, 1>{});
+    }
     if (__builtin_amdgcn_ballot_w64(lanebits != 0u) != 0) {      // rare: some mixture of the stage is not ruled out for some frame
       const int per = 4 / rpm;                                   // sub-mixtures per lane group
       while (lanebits) {                                         // (divergent: a few lanes, a few bits)
@@ -386,11 +513,12 @@ gmmmap_screen_kernel(const double *__restrict__ packed, const double *__restrict
   }
 
   // ---- 3. the survivors in full, in index order (the bitmap is complete and visible: the loop above ended with a barrier)
-  eval_bitmap(survivors, 0, -1);
+  eval_bitmap(survivors, 0, -1, B16);
 
   if (nreg && lane == 0) {
     atomicAdd(nreg, (unsigned long long)nreg_wave);
     atomicAdd(nreg + 1, (unsigned long long)nmfma_wave);
+    if (B16) atomicAdd(nreg + 2, (unsigned long long)nmfma16_wave);
   }
   if constexpr (PAIRED) {
     const double ds = den[0];
