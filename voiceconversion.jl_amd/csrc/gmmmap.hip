@@ -2015,7 +2015,7 @@ static int prepare(vcmi_gmmmap *g, const double *w, const double *mu, const doub
         for (int q = 0; q < NQ; ++q) {
           const int m0 = (NQ * st + q) * 4;
           unsigned short *fr = reinterpret_cast<unsigned short *>(&p16[(size_t)st * STG16 + (size_t)q * screen16_tile_doubles()]);
-          double *cl = &p16[(size_t)st * STG16 + (size_t)NQ * screen16_tile_doubles() + (size_t)q * 64];
+          double *cl = &p16[(size_t)st * STG16 + (size_t)NQ * screen16_tile_doubles() + (size_t)q * 32];
           for (int l = 0; l < 64; ++l) {
             const int r = l & 15, gq = l >> 4, m = m0 + (r >> 2), row = r & 3;     // tile row r <-> mixture r >> 2, screening row r & 3
             auto pv = [&](int ks) -> double {                      // P[row][feature 4 ks + lane group]
@@ -2040,11 +2040,13 @@ static int prepare(vcmi_gmmmap *g, const double *w, const double *mu, const doub
               if (m < M)
                 for (int k = 0; k < D; ++k) nrm += hP[((size_t)m * 4 + r) * DP + k] * hP[((size_t)m * 4 + r) * DP + k];
               const double c = (m < M) ? hcP[(size_t)m * 4 + r] : 0.0;
-              cl[j * 16 + r] = c;
-              cl[j * 16 + 4 + r] = kEps * std::sqrt(nrm) * (1.0 + 1e-12);
-              cl[j * 16 + 8 + r] = kEps * std::fabs(c);
+              float *cf = reinterpret_cast<float *>(cl + j * 8);          // {c (4 floats) | 2^-12 |P| (4) | 2^-12 |c| (4)}, margins rounded UP
+              auto up = [](double v) { return std::nextafterf((float)(v * (1.0 + 0x1p-20)), INFINITY); };
+              cf[r] = (float)c;                                           // (its FP32 rounding is inside the 2^-12 |c| margin)
+              cf[4 + r] = up(kEps * std::sqrt(nrm));
+              cf[8 + r] = up(kEps * std::fabs(c));
             }
-            cl[j * 16 + 12] = (m < M) ? hlc[m] : -std::numeric_limits<double>::infinity();
+            cl[j * 8 + 6] = (m < M) ? hlc[m] : -std::numeric_limits<double>::infinity();
           }
         }
       VCMI_TRY(g->packedQ16.reserve(p16.size()));

@@ -51,10 +51,13 @@ __host__ __device__ constexpr int screen_row_index(int i, int rpm) { return (i >
 // log-density: a mixture it rules out is ruled out.  eps is ~0.3 where the test needs |a| of 10 and more: what the screen
 // decides hardly changes, its matrix work drops from 10 FP64 MFMAs (640 cycles) to 4 BF16 ones (64 cycles) per tile.
 // The FP32 result layout gives lane group j rows 4 j .. 4 j + 3: tile row i <-> mixture i >> 2, screening row i & 3.
+// The margins and the sum of squares are formed in FP32 (the FP64 vector pipe is the one the conversion itself needs): the
+// constants are rounded UP on the host (and carry a factor 1 + 2^-20 for the FP32 roundings of eps), the sum is taken down by
+// 1 - 2^-20 before it is used.
 // Stage layout in doubles: per tile [Ph main | Pl main | tail] as 3 x 1 KB of bf16x8 per lane, then per tile and lane group
-// 16 doubles {c_0..3, 2^-12 |P_0..3|, 2^-12 |c_0..3|, lc, pad}.
+// 8 doubles {c_0..3 (4 floats), 2^-12 |P_0..3| (4 floats), 2^-12 |c_0..3| (4 floats), lc (double), pad}.
 __host__ __device__ constexpr int screen16_tile_doubles() { return 3 * 128; }
-__host__ __device__ constexpr int screen16_stage_doubles(int DP) { return screen_quads(DP) * (screen16_tile_doubles() + 64); }
+__host__ __device__ constexpr int screen16_stage_doubles(int DP) { return screen_quads(DP) * (screen16_tile_doubles() + 32); }
 __host__ __device__ constexpr bool screen16_has(int DP) { return DP >= 16 && DP <= 40 && DP % 4 == 0; }
 // x -> bf16 hi (round to nearest even) and bf16 lo of the FP32 remainder (x_f32 - hi is exact in FP32)
 __host__ __device__ inline void split_bf16(double x, unsigned short &h, unsigned short &l) {
@@ -350,7 +353,7 @@ gmmmap_screen_kernel(const double *__restrict__ packed, const double *__restrict
   // |x| per frame for the error bound; xb itself is not needed again unless something survives
   constexpr int NMAIN = KS < 8 ? KS : 8, NTAIL = KS - NMAIN;     // k-steps in the three main instructions / in the tail one
   u32x4_t bh[B16 ? FT : 1], bl[B16 ? FT : 1], bt[B16 ? FT : 1];
-  double nx[B16 ? FT : 1];
+  float nxf[B16 ? FT : 1];                                       // |x| of the lane's frame, rounded up
   if constexpr (B16) {
 #pragma unroll
     for (int f = 0; f < FT; ++f) {
@@ -361,7 +364,7 @@ gmmmap_screen_kernel(const double *__restrict__ packed, const double *__restrict
         split_bf16(xb[f][ks], h[ks], l[ks]);
         q = fma(xb[f][ks], xb[f][ks], q);
       }
-      nx[f] = sqrt(sum_lane_groups(q)) * (1.0 + 1e-12);
+      nxf[f] = (float)(sqrt(sum_lane_groups(q)) * (1.0 + 0x1p-20));
 #pragma unroll
       for (int w2 = 0; w2 < 4; ++w2) {
         const int j0 = 2 * w2, j1 = 2 * w2 + 1;
@@ -405,22 +408,17 @@ gmmmap_screen_kernel(const double *__restrict__ packed, const double *__restrict
     unsigned lanebits = 0;
     auto screen_tile16 = [&](int q) {                            // B16: lane group j <-> mixture j of the tile, its four rows in the lane
       const char *tb = reinterpret_cast<const char *>(stg + q * screen16_tile_doubles());
-      const double *cl = stg + QS * screen16_tile_doubles() + q * 64 + lgrp * 16;
+      const double *cl = stg + QS * screen16_tile_doubles() + q * 32 + lgrp * 8;
       const u32x4_t aph = *reinterpret_cast<const u32x4_t *>(tb + 16 * lane);
       const u32x4_t apl = *reinterpret_cast<const u32x4_t *>(tb + 1024 + 16 * lane);
       const u32x4_t apt = *reinterpret_cast<const u32x4_t *>(tb + 2048 + 16 * lane);
-      double cc[4], np[4], nc[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        cc[i] = cl[i];
-        np[i] = cl[4 + i];
-        nc[i] = cl[8 + i];
-      }
-      const double lcq = cl[12];
+      const f32x4_t cc = *reinterpret_cast<const f32x4_t *>(cl), np = *reinterpret_cast<const f32x4_t *>(cl + 2),
+                    nc = *reinterpret_cast<const f32x4_t *>(cl + 4);
+      const double lcq = cl[6];
       f32x4_t a[FT];
 #pragma unroll
       for (int f = 0; f < FT; ++f) {
-        a[f] = f32x4_t{(float)-cc[0], (float)-cc[1], (float)-cc[2], (float)-cc[3]};
+        a[f] = -cc;
         a[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, aph), __builtin_bit_cast(bf16x8_t, bh[f]), a[f], 0, 0, 0);
         a[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, aph), __builtin_bit_cast(bf16x8_t, bl[f]), a[f], 0, 0, 0);
         a[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, apl), __builtin_bit_cast(bf16x8_t, bh[f]), a[f], 0, 0, 0);
@@ -429,13 +427,13 @@ gmmmap_screen_kernel(const double *__restrict__ packed, const double *__restrict
       }
 #pragma unroll
       for (int f = 0; f < FT; ++f) {
-        double lb = 0.0;
+        float lb = 0.0f;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          const double t = fmax(fabs((double)a[f][i]) - fma(np[i], nx[f], nc[i]), 0.0);      // certified |a_i| from below
-          lb = fma(t, t, lb);
+          const float t = fmaxf(fabsf(a[f][i]) - fmaf(np[i], nxf[f], nc[i]), 0.0f);          // certified |a_i| from below
+          lb = fmaf(t, t, lb);
         }
-        lanebits |= (fma(-0.5, lb, lcq) > thr[f]) ? (1u << (4 * q)) : 0u;
+        lanebits |= (fma(-0.5 * (1.0 - 0x1p-20), (double)lb, lcq) > thr[f]) ? (1u << (4 * q)) : 0u;
       }
     };
     auto screen_tile = [&](int q, auto rpm_c) {                  // (rows per mixture as a compile-time constant: no branch inside a tile)
