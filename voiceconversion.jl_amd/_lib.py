@@ -206,6 +206,7 @@ DBG_ESTEP_WAVE_KERNEL = 4194304
 DBG_PREDICT_NO_SCREEN = 8388608
 DBG_PREDICT_SCREEN = 16777216
 DBG_SCREEN_FP64 = 33554432
+DBG_GROUP_KEY_FP64 = 67108864
 
 
 def debug_force(flags):

@@ -1245,6 +1245,84 @@ gmmmap_group_key_kernel(const double *__restrict__ gfrag, int M, int D, const do
   }
 }
 
+// The same keys on the BF16 matrix pipe (round 5).  The key only has to be mostly right, and the FP64 products were half of the
+// kernel's time (28 MFMAs of 64 cycles per tile beside a read of x that is bound by HBM): -2 mu and x are split into bf16
+// hi + lo (gmmmap_screen.hpp: split_bf16; products to ~2^-16 relative) and the distances over the first 24 dimensions are three
+// v_mfma_f32_16x16x32_bf16 per 16 mixtures (slot j of lane group g <-> feature 4 j + g: the lane's own FP64 operand), |mu|^2
+// in the accumulator's initial value.  gfrag16[mt]: 64 x 16 bytes of hi, 64 x 16 bytes of lo, 4 x 4 floats of |mu|^2 (lane
+// group g of the result holds rows 4 g .. 4 g + 3; rows >= M: 1e30).  Deterministic like the FP64 kernel; a frame between
+// two means may get the other key, which costs a regression, never a result.
+constexpr int kKey16TileBytes = 2 * 1024 + 64;
+template <int DP>
+__global__ void __launch_bounds__(256)
+gmmmap_group_key16_kernel(const double *__restrict__ gfrag16, int M, int D, const double *__restrict__ X, int64_t ldx, int64_t T,
+                          int *__restrict__ key, int *__restrict__ chunkhist) {
+  constexpr int KS = (DP / 4 < kGroupKeyDims / 4) ? DP / 4 : kGroupKeyDims / 4;
+  static_assert(KS <= 8, "one K = 32 instruction per term");
+  extern __shared__ double gsm[];
+  const int MT = (M + 15) / 16, nd = MT * (kKey16TileBytes / 8);
+  int *hist = reinterpret_cast<int *>(gsm + nd);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lcol = lane & 15, lgrp = lane >> 4;
+  for (int e = tid; e < nd; e += 256) gsm[e] = gfrag16[e];
+  const int64_t nchunks = (T + kGroupChunk - 1) / kGroupChunk;
+  for (int64_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
+    for (int m = tid; m < M; m += 256) hist[m] = 0;
+    __syncthreads();
+    for (int i = 0; i < kGroupChunk / 64; ++i) {
+      const int64_t fr = c * kGroupChunk + 16 * (4 * i + wave) + lcol;
+      if (fr - lcol >= T) break;                                    // (wave-uniform)
+      u32x4_t bh = {0u, 0u, 0u, 0u}, bl = {0u, 0u, 0u, 0u};
+      {
+        unsigned short h[8] = {0, 0, 0, 0, 0, 0, 0, 0}, l[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const int k = 4 * ks + lgrp;
+          const double x = (fr < T && k < D) ? X[fr * ldx + k] : 0.0;
+          split_bf16(x, h[ks], l[ks]);
+        }
+#pragma unroll
+        for (int w2 = 0; w2 < 4; ++w2) {
+          bh[w2] = (unsigned)h[2 * w2] | ((unsigned)h[2 * w2 + 1] << 16);
+          bl[w2] = (unsigned)l[2 * w2] | ((unsigned)l[2 * w2 + 1] << 16);
+        }
+      }
+      float best = INFINITY;
+      int bm = 0;
+      for (int mt = 0; mt < MT; ++mt) {
+        const char *tb = reinterpret_cast<const char *>(gsm) + (size_t)mt * kKey16TileBytes;
+        const u32x4_t aph = *reinterpret_cast<const u32x4_t *>(tb + 16 * lane), apl = *reinterpret_cast<const u32x4_t *>(tb + 1024 + 16 * lane);
+        f32x4_t acc = *reinterpret_cast<const f32x4_t *>(tb + 2048 + 16 * lgrp);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, aph), __builtin_bit_cast(bf16x8_t, bh), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, aph), __builtin_bit_cast(bf16x8_t, bl), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, apl), __builtin_bit_cast(bf16x8_t, bh), acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (acc[r] < best) {
+            best = acc[r];
+            bm = 16 * mt + 4 * lgrp + r;
+          }
+      }
+#pragma unroll
+      for (int sh = 16; sh < 64; sh <<= 1) {
+        const float ov = __shfl_xor(best, sh);
+        const int om = __shfl_xor(bm, sh);
+        if (ov < best || (ov == best && om < bm)) {
+          best = ov;
+          bm = om;
+        }
+      }
+      if (lgrp == 0 && fr < T) {
+        bm = bm < M ? bm : 0;
+        key[fr] = bm;
+        atomicAdd(&hist[bm], 1);
+      }
+    }
+    __syncthreads();
+    for (int m = tid; m < M; m += 256) chunkhist[c * M + m] = hist[m];
+    __syncthreads();
+  }
+}
+
 // One workgroup per group m: chunkhist[c][m] -> its exclusive prefix over the chunks (in place) and total[m].
 __global__ void __launch_bounds__(256)
 gmmmap_group_scan_kernel(int *__restrict__ chunkhist, int64_t nchunks, int M, int *__restrict__ total) {
@@ -1525,14 +1603,18 @@ static int convert_shape(const vcmi_gmmmap *g) {
 
 // The three grouping kernels (keys + chunk histograms, prefix, stable scatter) on g's scratch: *key = group of every frame,
 // *perm = frames in group order.  The caller brackets its use of them with g->grp_order.enter / leave.
-static bool can_group(const vcmi_gmmmap *g, int64_t T) {
+static size_t group_key_shmem(const vcmi_gmmmap *g, bool fp64) {
   const int MT = (g->M + 15) / 16;
-  const size_t gshmem = (size_t)MT * (std::min(g->DP / 4, kGroupKeyDims / 4) + 1) * 64 * sizeof(double) + (size_t)g->M * sizeof(int);
-  return T >= kSortMinFrames && T < ((int64_t)1 << 31) && g->M >= 4 && g->gfrag.p && gshmem <= 64 * 1024;
+  return (fp64 ? (size_t)MT * (std::min(g->DP / 4, kGroupKeyDims / 4) + 1) * 64 * sizeof(double) : (size_t)MT * kKey16TileBytes) +
+         (size_t)g->M * sizeof(int);
+}
+static bool group_key_fp64(const vcmi_gmmmap *g) { return debug_flag(kDbgGroupKeyFp64) || !g->gfrag16.p; }
+static bool can_group(const vcmi_gmmmap *g, int64_t T) {
+  return T >= kSortMinFrames && T < ((int64_t)1 << 31) && g->M >= 4 && g->gfrag.p && group_key_shmem(g, group_key_fp64(g)) <= 64 * 1024;
 }
 static int launch_grouping(vcmi_gmmmap *g, const double *dX, int64_t ldx, int64_t T, hipStream_t st, int **key_out, int **perm_out) {
-  const int MT = (g->M + 15) / 16;
-  const size_t gshmem = (size_t)MT * (std::min(g->DP / 4, kGroupKeyDims / 4) + 1) * 64 * sizeof(double) + (size_t)g->M * sizeof(int);
+  const bool fp64 = group_key_fp64(g);
+  const size_t gshmem = group_key_shmem(g, fp64);
   const int64_t nchunks = (T + kGroupChunk - 1) / kGroupChunk;
   VCMI_TRY(g->grp.reserve((size_t)2 * T + (size_t)(nchunks + 1) * g->M));
   VCMI_TRY(g->grp_order.enter(st));
@@ -1542,7 +1624,10 @@ static int launch_grouping(vcmi_gmmmap *g, const double *dX, int64_t ldx, int64_
   const unsigned kgrid = (unsigned)std::min<int64_t>(nchunks, (int64_t)cus * 4);
   switch (g->DP) {
 #define VCMI_CASE(DPV) \
-  case DPV: hipLaunchKernelGGL(gmmmap_group_key_kernel<DPV>, dim3(kgrid), dim3(256), gshmem, st, g->gfrag.p, g->M, g->D, dX, ldx, T, key, chunkhist); break;
+  case DPV: \
+    if (fp64) hipLaunchKernelGGL(gmmmap_group_key_kernel<DPV>, dim3(kgrid), dim3(256), gshmem, st, g->gfrag.p, g->M, g->D, dX, ldx, T, key, chunkhist); \
+    else hipLaunchKernelGGL(gmmmap_group_key16_kernel<DPV>, dim3(kgrid), dim3(256), gshmem, st, g->gfrag16.p, g->M, g->D, dX, ldx, T, key, chunkhist); \
+    break;
     VCMI_CASE(16) VCMI_CASE(20) VCMI_CASE(24) VCMI_CASE(28) VCMI_CASE(32) VCMI_CASE(36) VCMI_CASE(40) VCMI_CASE(44)
     VCMI_CASE(48) VCMI_CASE(52) VCMI_CASE(56) VCMI_CASE(60) VCMI_CASE(64) VCMI_CASE(68) VCMI_CASE(72) VCMI_CASE(76)
     VCMI_CASE(80)
@@ -2097,6 +2182,33 @@ static int prepare(vcmi_gmmmap *g, const double *w, const double *mu, const doub
         }
     VCMI_TRY(g->gfrag.reserve(gf.size()));
     VCMI_HIP(hipMemcpy(g->gfrag.p, gf.data(), gf.size() * 8, hipMemcpyHostToDevice));
+    // ... and for the BF16 matrix pipe (gmmmap_group_key16_kernel): -2 mu split into bf16 hi + lo, |mu|^2 as floats
+    {
+      std::vector<double> g16((size_t)MT * (kKey16TileBytes / 8), 0.0);
+      for (int mt = 0; mt < MT; ++mt) {
+        unsigned short *hi = reinterpret_cast<unsigned short *>(&g16[(size_t)mt * (kKey16TileBytes / 8)]), *lo = hi + 512;
+        float *msq = reinterpret_cast<float *>(hi + 1024);
+        for (int l = 0; l < 64; ++l) {
+          const int m = 16 * mt + (l & 15), gq = l >> 4;
+          for (int j = 0; j < 8; ++j) {
+            const int k = 4 * j + gq;
+            const double v = (m < M && j < KSK && k < DK) ? -2.0 * g->h_mux[(size_t)D * m + k] : 0.0;
+            split_bf16(v, hi[(size_t)l * 8 + j], lo[(size_t)l * 8 + j]);
+          }
+        }
+        for (int r = 0; r < 16; ++r) {
+          const int m = 16 * mt + r;
+          double v = 1e30;
+          if (m < M) {
+            v = 0.0;
+            for (int d = 0; d < DK; ++d) v += g->h_mux[(size_t)D * m + d] * g->h_mux[(size_t)D * m + d];
+          }
+          msq[r] = (float)v;                                  // lane group r >> 2 reads floats 4 (r >> 2) .. + 3
+        }
+      }
+      VCMI_TRY(g->gfrag16.reserve(g16.size()));
+      VCMI_HIP(hipMemcpy(g->gfrag16.p, g16.data(), g16.size() * 8, hipMemcpyHostToDevice));
+    }
   }
   return VCMI_OK;
 }

@@ -46,6 +46,7 @@ struct vcmi_gmmmap {
   // fvconvert's frame grouping (gmmmap_group_key_kernel): nearest-source-mean operand [-2 mu | |mu|^2] in MFMA fragment order,
   // and the call's scratch: key (T), perm (T), counts (M), cursors (M)
   vcmi::DevBuf<double> gfrag;
+  vcmi::DevBuf<double> gfrag16;   // the same operand split into bf16 hi + lo for gmmmap_group_key16_kernel
   vcmi::DevBuf<int> grp;
   vcmi::StreamOrder grp_order;
 

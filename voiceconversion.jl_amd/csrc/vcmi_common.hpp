@@ -116,6 +116,7 @@ enum : unsigned {
   kDbgPredictNoScreen = 8388608u,    // predict / trajectory argmax: the early-exit kernel (MODE 3) also for long inputs, instead of grouping + screen
   kDbgPredictScreen = 16777216u,     // predict: grouping + screened arg-max on long inputs whatever the model
   kDbgScreenFp64 = 33554432u,        // fvconvert shape 3: the screen on FP64 MFMAs instead of the certified bf16-split one
+  kDbgGroupKeyFp64 = 67108864u,      // grouping keys from FP64 MFMAs (gmmmap_group_key_kernel) instead of the bf16-split ones
   kDbgConvertWideTiles = 131072u, // fvconvert: two frame tiles per wave (128-frame workgroups) also for calls of a few thousand frames
   kDbgPredictNoEarlyExit = 64u   // predict / trajectory argmax: every whitening tile of every mixture (MODE 2) instead of the early exit (MODE 3)
 };
