@@ -159,6 +159,7 @@ def attach_traffic(out, fname, kernel_prefixes, fetch_factor=VECTOR_FETCH_FACTOR
             roof["traffic"] = roof["traffic_raw"] = None
             return
         roof["traffic_GBps"] = gbps
+        roof["hbm_frac"] = gbps / HBM_PEAK_GBS            # the other roof: measured HBM bytes over the kernel's time / 8 TB/s
         if algorithmic_bytes:
             roof["algorithmic_bytes"] = algorithmic_bytes
             roof["traffic_x_algorithmic"] = roof["traffic"] / algorithmic_bytes
@@ -1133,7 +1134,7 @@ def summarize(out):
 
 LINE_CAP = 7500           # characters of the ONE stdout line (the driver keeps an 8 KB tail; BENCH_r04 lost a 20.9 KB line)
 ROOF_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "kernel_ms", "algorithmic_frac", "issued_mfma_frac",
-             "traffic_whole_step", "traffic_x_algorithmic", "traffic_GBps")
+             "traffic_whole_step", "traffic_x_algorithmic", "traffic_GBps", "hbm_frac")
 
 
 def _sig(x, n=6):
