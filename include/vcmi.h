@@ -64,7 +64,9 @@ int vcmi_get_devices(int *devices, int capacity, int *n);
  * [ptr, ptr + bytes) ONCE (hipHostRegister); from then on every host-pointer entry point whose dense input and / or output
  * lies inside a registered range moves it by DMA straight between that array and HBM -- no staging slot, no host memcpy --
  * (vcmi_gmmmap_convert, vcmi_vc_frames' input, vcmi_gmmmap_posterior / _predict: each side independently; a side that is
- * not registered, or strided, keeps the staged path).  Arrays pinned by the caller's own runtime (hipHostMalloc /
+ * not registered, or strided, keeps the staged path); the plain uploads / downloads of the other entry points (the frame
+ * matrix of vcmi_estep_diag / _full, result buffers) go straight from / to a registered array as well.  Arrays pinned by
+ * the caller's own runtime (hipHostMalloc /
  * hipHostRegister) are recognised as well.  Results are identical either way.  vcmi_host_unregister(ptr) takes the pointer
  * that was registered; an array must be unregistered before it is freed.  Ranges must not overlap (VCMI_ERR_ARG).
  * vcmi_host_is_registered: *flag = 1 when the whole range would take the direct path. */

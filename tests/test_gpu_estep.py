@@ -237,3 +237,23 @@ def test_one_barrier_experiment_against_the_three_barrier_kernel(vc, N, Dj, M, h
     r0, r1, r2, rl = co.estep_diag(X[:8000], w, mu, var)
     assert relerr(S0, r0) < TOL and relerr(S1, r1.T) < TOL and relerr(S2, r2.T) < TOL
     assert abs(ll - rl) < TOL * abs(rl)
+
+
+def test_pinned_frames_are_uploaded_directly(vc):
+    """vcmi_host_register: a training matrix the caller keeps (bin/train_gmm.jl holds X for all EM iterations) is DMA'd
+    straight out of its pages by the plain uploads too -- same statistics, bit for bit."""
+    from oracle import np_oracle as npo
+    N, Dj, M = 300_000, 80, 128
+    w, mu, _ = npo.synth_model(77, Dj, M)
+    rg = np.random.default_rng(5)
+    var = np.exp(rg.uniform(np.log(1e-3), 0.0, (M, Dj)))
+    comp = rg.choice(M, size=N, p=w)
+    X = np.asfortranarray((mu[comp] + rg.standard_normal((N, Dj)) * np.sqrt(var[comp])).T)
+    a = vc.estep_diag(X, w, mu.T, var.T)
+    vc.pin(X)
+    try:
+        assert vc.is_pinned(X)
+        b = vc.estep_diag(X, w, mu.T, var.T)
+    finally:
+        vc.unpin(X)
+    assert all(np.array_equal(p, q) for p, q in zip(a[:3], b[:3])) and a[3] == b[3]

@@ -434,8 +434,20 @@ void window_segments(const std::vector<HostPiece> &pieces, const std::vector<siz
   }
 }
 
+bool range_is_pinned(const void *p, size_t bytes);      // (below: caller-pinned memory)
+
 int do_upload(Ring *r, char *dDst, const std::vector<HostPiece> *pieces, const char *hSrc, size_t bytes, hipStream_t consumer) {
   if (bytes == 0) return VCMI_OK;
+  if (!pieces && range_is_pinned(hSrc, bytes)) {
+    // the caller pinned this array (vcmi_host_register): one DMA straight out of it.  The upload is complete on return -- the
+    // staged path has copied the caller's data out of the array by then, and an entry point that only uploads (a resident
+    // training matrix) must leave the same freedom to free or overwrite it.
+    VCMI_HIP(hipEventRecord(r->ev_tmp, consumer));       // dDst may still be read by work the consumer enqueued earlier
+    VCMI_HIP(hipStreamWaitEvent(r->up, r->ev_tmp, 0));
+    VCMI_HIP(hipMemcpyAsync(dDst, hSrc, bytes, hipMemcpyHostToDevice, r->up));
+    VCMI_HIP(hipStreamSynchronize(r->up));
+    return VCMI_OK;
+  }
   const size_t chunk = std::min(bytes, kXferChunk);
   VCMI_TRY(r->reserve(r->pin_in, r->pin_in_cap, chunk, true));
   // dDst may still be read by work the consumer enqueued earlier
@@ -471,6 +483,13 @@ int do_upload(Ring *r, char *dDst, const std::vector<HostPiece> *pieces, const c
 
 int do_download(Ring *r, const std::vector<HostPiece> *pieces, char *hDst, const char *dSrc, size_t bytes, hipStream_t producer) {
   if (bytes == 0) return VCMI_OK;
+  if (!pieces && range_is_pinned(hDst, bytes)) {        // a pinned destination: one DMA straight into it
+    VCMI_HIP(hipEventRecord(r->ev_tmp, producer));
+    VCMI_HIP(hipStreamWaitEvent(r->down, r->ev_tmp, 0));
+    VCMI_HIP(hipMemcpyAsync(hDst, dSrc, bytes, hipMemcpyDeviceToHost, r->down));
+    VCMI_HIP(hipStreamSynchronize(r->down));
+    return VCMI_OK;
+  }
   const size_t chunk = std::min(bytes, kXferChunk);
   VCMI_TRY(r->reserve(r->pin_out, r->pin_out_cap, chunk, true));
   VCMI_HIP(hipEventRecord(r->ev_tmp, producer));
