@@ -257,3 +257,129 @@ def test_pinned_frames_are_uploaded_directly(vc):
     finally:
         vc.unpin(X)
     assert all(np.array_equal(p, q) for p, q in zip(a[:3], b[:3])) and a[3] == b[3]
+
+
+# ---- the hard-assignment path (csrc/estep_hard.hpp): N >= 65536 frames, M <= 128, Dj <= 80 ----
+
+def _separated_case(seed, N, Dj, M, sep, zero_weight=None):
+    """Mixtures `sep` standard deviations apart per dimension (BASELINE-like: every frame has one owner), unit-ish variances."""
+    rg = np.random.default_rng(seed)
+    w = rg.dirichlet(2.0 * np.ones(M))
+    if zero_weight is not None:
+        w[zero_weight] = 0.0
+        w /= w.sum()
+    var = np.exp(rg.uniform(np.log(0.05), 0.0, (M, Dj)))
+    mu = sep * rg.standard_normal((M, Dj))
+    comp = rg.choice(M, size=N, p=w)
+    X = mu[comp] + rg.standard_normal((N, Dj)) * np.sqrt(var[comp])
+    return w, mu, var, X
+
+
+def _forget_feedback(vc):
+    """The path watches the soft fraction of the previous call (of any model): start every test from a clean slate."""
+    from voiceconversion_jl_amd import _lib
+    _lib.debug_force(_lib.DBG_ESTEP_NO_HARD)
+    try:
+        vc.estep_diag(np.zeros((2, 1)), np.ones(1), np.zeros((2, 1)), np.ones((2, 1)))
+    finally:
+        _lib.debug_force(0)
+
+
+def _both_paths(vc, X, w, mu, var):
+    from voiceconversion_jl_amd import _lib
+    _forget_feedback(vc)
+    a = vc.estep_diag(X.T, w, mu.T, var.T)
+    soft = _lib.estep_last_soft()
+    _lib.debug_force(_lib.DBG_ESTEP_NO_HARD)
+    try:
+        o = vc.estep_diag(X.T, w, mu.T, var.T)
+        assert _lib.estep_last_soft() == -1
+    finally:
+        _lib.debug_force(0)
+    return a, o, soft
+
+
+@pytest.mark.parametrize("N,Dj,M,sep,zw", [(70_000, 80, 128, 3.0, None), (66_000, 80, 40, 3.0, None), (100_001, 48, 128, 4.0, None),
+                                           (65_536, 50, 17, 4.0, 3), (80_000, 32, 16, 6.0, None), (70_000, 64, 100, 3.0, 99),
+                                           (90_000, 10, 4, 12.0, None), (70_000, 79, 128, 3.0, None), (70_000, 80, 1, 3.0, None)])
+def test_hard_assignment_path_all_frames_owned(vc, N, Dj, M, sep, zw):
+    """Far-apart mixtures: every frame is certified to have exactly one non-zero responsibility (no frame reaches the FP64
+    kernel), the statistics are segmented sums -- against the one-kernel path (DBG_ESTEP_NO_HARD) to 1e-12 and the oracle to
+    1e-9; repeat runs bit-identical; dj below the instantiated width, M not a multiple of 16, a mixture without weight."""
+    from oracle import c_oracle as co
+    w, mu, var, X = _separated_case(N + Dj + M, N, Dj, M, sep, zw)
+    a, o, soft = _both_paths(vc, X, w, mu, var)
+    assert soft == 0, soft
+    for p, q in zip(a[:3], o[:3]):
+        assert relerr(p, q) < 1e-12, relerr(p, q)
+    assert abs(a[3] - o[3]) < 1e-12 * abs(o[3])
+    b = vc.estep_diag(X.T, w, mu.T, var.T)
+    assert all(np.array_equal(p, q) for p, q in zip(a[:3], b[:3])) and a[3] == b[3]
+    r0, r1, r2, rl = co.estep_diag(X, w, mu, var)
+    assert relerr(a[0], r0) < TOL and relerr(a[1], r1.T) < TOL and relerr(a[2], r2.T) < TOL
+    assert abs(a[3] - rl) < TOL * abs(rl)
+    assert abs(a[0].sum() - N) < 1e-6
+    if zw is not None:
+        assert a[0][zw] == 0.0 and not a[1][:, zw].any()
+
+
+@pytest.mark.parametrize("N,Dj,M", [(70_000, 80, 128), (66_000, 48, 24), (80_000, 64, 100)])
+def test_hard_assignment_path_mixed_frames(vc, N, Dj, M):
+    """Half of the mixtures far apart, the other half overlapping: the owned frames are settled by the screen, the others
+    (thousands) are gathered and go through the FP64 kernel -- sum of the two equals the one-kernel path and the oracle."""
+    from oracle import c_oracle as co
+    rg = np.random.default_rng(N + M)
+    w, mu, var, _ = _separated_case(N + 1, 16, Dj, M, 3.0)
+    mu[M // 2:] = mu[M // 2] + 0.3 * rg.standard_normal((M - M // 2, Dj)) * np.sqrt(var[M // 2:])       # a cluster of overlapping mixtures
+    comp = rg.choice(M, size=N, p=w)
+    X = mu[comp] + rg.standard_normal((N, Dj)) * np.sqrt(var[comp])
+    a, o, soft = _both_paths(vc, X, w, mu, var)
+    assert 0.05 * N < soft < 0.95 * N, soft
+    for p, q in zip(a[:3], o[:3]):
+        assert relerr(p, q) < 1e-12, relerr(p, q)
+    assert abs(a[3] - o[3]) < 1e-12 * abs(o[3])
+    b = vc.estep_diag(X.T, w, mu.T, var.T)
+    assert all(np.array_equal(p, q) for p, q in zip(a[:3], b[:3])) and a[3] == b[3]
+    r0, r1, r2, rl = co.estep_diag(X, w, mu, var)
+    assert relerr(a[0], r0) < TOL and relerr(a[1], r1.T) < TOL and relerr(a[2], r2.T) < TOL
+    assert abs(a[3] - rl) < TOL * abs(rl)
+    _forget_feedback(vc)
+
+
+def test_hard_assignment_path_steps_aside_when_frames_are_shared(vc):
+    """Overlapping mixtures everywhere: the first call finds (nearly) all frames soft -- still the right statistics, through
+    the gathered FP64 pass -- and the following calls stay on the one-kernel path (the soft fraction of the previous call is
+    the feedback); the path is tried again later."""
+    from oracle import c_oracle as co
+    from voiceconversion_jl_amd import _lib
+    N, Dj, M = 70_000, 80, 64
+    w, mu, var, X = _hard_case(4242, Dj, M, N, 10.0, 1e-3, 1e-1, 3.0)       # (a quarter of its mixtures are far away: those frames are owned)
+    r0, r1, r2, rl = co.estep_diag(X, w, mu, var)
+    _forget_feedback(vc)
+    seen = []
+    for _ in range(20):
+        a = vc.estep_diag(X.T, w, mu.T, var.T)
+        seen.append(_lib.estep_last_soft())
+        assert relerr(a[0], r0) < TOL and relerr(a[1], r1.T) < TOL and relerr(a[2], r2.T) < TOL
+        assert abs(a[3] - rl) < TOL * abs(rl)
+    assert seen[0] > 0.5 * N, seen                 # the first call took the path and found most frames shared
+    assert seen[1:16] == [-1] * 15, seen           # fifteen calls on the one-kernel path
+    assert seen[16] > 0.5 * N, seen                # then another look
+    _forget_feedback(vc)
+
+
+def test_hard_assignment_path_device_resident_and_small_calls(vc):
+    """estep_diag_dev on device-resident frames takes the same path; below 65536 frames the one-kernel path runs."""
+    import torch
+    from voiceconversion_jl_amd import _lib
+    w, mu, var, X = _separated_case(9, 131_072, 80, 128, 3.0)
+    _forget_feedback(vc)
+    Xd = torch.from_numpy(np.ascontiguousarray(X)).cuda()
+    got = vc.estep_diag_dev(Xd.t(), w, mu.T, var.T)
+    assert _lib.estep_last_soft() == 0
+    S0, S1, S2, ll = vc.estep_diag(X.T, w, mu.T, var.T)
+    plen = got.numel()
+    g = got.cpu().numpy()
+    assert np.array_equal(g[:128], S0) and g[plen - 1] == ll
+    vc.estep_diag(X[:60_000].T, w, mu.T, var.T)
+    assert _lib.estep_last_soft() == -1

@@ -207,6 +207,18 @@ DBG_PREDICT_NO_SCREEN = 8388608
 DBG_PREDICT_SCREEN = 16777216
 DBG_SCREEN_FP64 = 33554432
 DBG_GROUP_KEY_FP64 = 67108864
+DBG_ESTEP_NO_HARD = 134217728
+
+
+def estep_last_soft():
+    """Measurement hook: frames of this thread's last diagonal E-step that went through the FP64 kernel after the
+    hard-assignment screen (csrc/estep_hard.hpp); -1 when the call took the one-kernel path."""
+    fn = lib.vcmi_debug_estep_last_soft
+    fn.argtypes = [C.POINTER(C.c_int64)]
+    fn.restype = _int
+    v = C.c_int64(0)
+    check(fn(C.byref(v)))
+    return int(v.value)
 
 
 def debug_force(flags):

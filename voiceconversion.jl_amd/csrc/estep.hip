@@ -104,7 +104,9 @@ estep_stats_kernel(const double *__restrict__ X, int64_t n0, int64_t nfr, int Dj
 // fourth row in increasing order, then ((p0 + p1) + (p2 + p3)).  (One thread per element walking all rows one after the
 // other left two thirds of the CUs idle and took 64 us for the 256 rows of the benchmark E-step -- 4 % of the step.)
 __global__ void __launch_bounds__(256)
-estep_reduce_kernel(const double *__restrict__ part, int nrows, int64_t plen, double *__restrict__ stats, int accumulate) {
+estep_reduce_kernel(const double *__restrict__ part, int nrows, int64_t plen, double *__restrict__ stats, int accumulate,
+                    const int64_t *__restrict__ only_if) {
+  if (only_if && *only_if == 0) return;      // (the soft frames of estep_hard.hpp: without any, the partials were not written)
   __shared__ double psum[4][64];
   const int el = threadIdx.x & 63, q = threadIdx.x >> 6;
   const int64_t e = (int64_t)blockIdx.x * 64 + el;
@@ -123,8 +125,9 @@ estep_reduce_kernel(const double *__restrict__ part, int nrows, int64_t plen, do
   __syncthreads();
   if (q == 0 && e < plen) stats[e] = (accumulate ? stats[e] : 0.0) + ((psum[0][el] + psum[1][el]) + (psum[2][el] + psum[3][el]));
 }
-static inline void estep_reduce_launch(const double *part, int nrows, int64_t plen, double *stats, hipStream_t st, int accumulate = 1) {
-  hipLaunchKernelGGL(estep_reduce_kernel, dim3((unsigned)((plen + 63) / 64)), dim3(256), 0, st, part, nrows, plen, stats, accumulate);
+static inline void estep_reduce_launch(const double *part, int nrows, int64_t plen, double *stats, hipStream_t st, int accumulate = 1,
+                                       const int64_t *only_if = nullptr) {
+  hipLaunchKernelGGL(estep_reduce_kernel, dim3((unsigned)((plen + 63) / 64)), dim3(256), 0, st, part, nrows, plen, stats, accumulate, only_if);
 }
 
 // More than 128 mixtures (groups of 128, one PHASE 3 launch each): the responsibilities G_g[f][.] are normalised within
@@ -245,7 +248,12 @@ __global__ void __launch_bounds__(512)
 estep_mfma_kernel(const double *__restrict__ X, int64_t N, int M, const double *__restrict__ Wpack,
                   const double *__restrict__ cinit, double *__restrict__ part, int64_t plen,
                   const double *__restrict__ refmu, const double *__restrict__ refiv, const double *__restrict__ refc,
-                  double *__restrict__ G, int dj, int mtp_arg, unsigned long long *__restrict__ mfma_count) {
+                  double *__restrict__ G, int dj, int mtp_arg, unsigned long long *__restrict__ mfma_count,
+                  const int64_t *__restrict__ Ndev) {
+  if (Ndev) {                                // (the soft frames of estep_hard.hpp: their number exists on the device only)
+    N = *Ndev;
+    if (N == 0) return;                      // none: no partials either -- estep_reduce_kernel is told the same way and leaves the statistics alone
+  }
   // mfma_count (optional, measurement): v_mfma_f64_16x16x4 instructions issued, counted by wave-uniform scalar adds
   // mtp = 1, 2, 4 or 8 mixture tiles of 16 (>= M / 16): with fewer than eight (SHARE), 8 / mtp waves share a tile -- wave
   // w takes tile w % mtp and every (8 / mtp)-th frame tile of step A / k-step of step B, and writes its own row of
@@ -595,6 +603,7 @@ estep_mfma_kernel(const double *__restrict__ X, int64_t N, int M, const double *
 
 }  // namespace vcmi
 #include "estep_wave.hpp"
+#include "estep_hard.hpp"
 namespace vcmi {
 
 // ------------------------------------------------------------------------------------------------
@@ -637,6 +646,22 @@ struct EstepStaging {
 struct EstepScratch {
   DevBuf<double> mu, iv, cst, G, LSE, part, Wpack, cinit, X, stats, raw, refiv, refc, Xpad, statsp;
   DevBuf<unsigned long long> mfma_count;      // optional measurement counter (vcmi_debug_estep_mfma); null: the kernels count nothing
+  // the hard-assignment path (estep_hard.hpp): operands, sort scratch, pieces, the soft frames' matrix, and the feedback that
+  // keeps it off while the data leaves it little (the previous call's soft count, read back without waiting)
+  DevBuf<unsigned char> W16;
+  DevBuf<int> hkeys;                           // key (N) | perm (N) | chunkhist (nchunks x (M + 1)) | total (M + 1)
+  DevBuf<double> hpart, hllm, Xsoft;
+  DevBuf<int64_t> nsoft;
+  int *h_soft = nullptr;                       // pinned
+  hipEvent_t soft_ev = nullptr;
+  bool soft_pending = false;
+  int64_t soft_N = 0;
+  int hard_skip = 0;                           // calls left on the one-kernel path
+  bool last_hard = false;                      // the last diagonal E-step of this thread took the hard-assignment path
+  ~EstepScratch() {
+    if (h_soft) (void)hipHostFree(h_soft);
+    if (soft_ev) (void)hipEventDestroy(soft_ev);
+  }
   EstepStaging stage;
   StreamOrder order;   // calls of one thread on different streams share the buffers above
 };
@@ -741,6 +766,67 @@ static int estep_mfma_launch(EstepScratch &sc, const double *dX, int64_t N, int 
   VCMI_HIP(hipGetLastError());
   const double *dmu = draw + M;      // (the means of the re-evaluation are the uploaded parameters themselves: raw = [w | mu (Dj,M) | var (Dj,M)])
   if constexpr (!C::SPLIT) {
+    // ---- frames that one mixture owns never see an FP64 MFMA (estep_hard.hpp); the rest goes on below, gathered ----
+    static constexpr int64_t kHardMinFrames = 65536;
+    if (sc.soft_pending && hipEventQuery(sc.soft_ev) == hipSuccess) {          // what the previous call found
+      sc.soft_pending = false;
+      if (sc.h_soft && (double)*sc.h_soft > 0.25 * (double)sc.soft_N) sc.hard_skip = 15;      // mostly soft: not worth its two passes
+    }
+    if (debug_flag(kDbgEstepNoHard)) {                                         // (tests: the flag also forgets the feedback)
+      sc.soft_pending = false;
+      sc.hard_skip = 0;
+    }
+    const bool hard_on = N >= kHardMinFrames && N < ((int64_t)1 << 31) && !debug_flag(kDbgEstepNoHard);
+    sc.last_hard = false;
+    if (hard_on && sc.hard_skip > 0) --sc.hard_skip;
+    else if (hard_on) {
+      using CH = EstepHardCfg<DJ>;
+      const int MT = (M + 15) / 16, MK = M + 1;
+      const int64_t nchunks = (N + kGroupChunk - 1) / kGroupChunk, npmax = (N + kHardPiece - 1) / kHardPiece + M, prow = 2 * (int64_t)dj + 2;
+      VCMI_TRY(sc.W16.reserve((size_t)MT * CH::TILE_BYTES));
+      VCMI_TRY(sc.hkeys.reserve((size_t)2 * N + (size_t)(nchunks + 1) * MK));
+      VCMI_TRY(sc.hpart.reserve((size_t)npmax * prow));
+      VCMI_TRY(sc.hllm.reserve((size_t)M));
+      VCMI_TRY(sc.Xsoft.reserve((size_t)N * dj));
+      VCMI_TRY(sc.nsoft.reserve(1));
+      if (!sc.h_soft) {
+        VCMI_HIP(hipHostMalloc(reinterpret_cast<void **>(&sc.h_soft), sizeof(int), hipHostMallocDefault));
+        VCMI_HIP(hipEventCreateWithFlags(&sc.soft_ev, hipEventDisableTiming));
+      }
+      int *key = sc.hkeys.p, *perm = key + N, *chunkhist = perm + N, *total = chunkhist + nchunks * MK;
+      hipLaunchKernelGGL(estep_hard_prep_kernel<DJ>, dim3((unsigned)((MT * CH::NI * 64 + 255) / 256 + 4 * MT)), dim3(256), 0, st, draw, sc.cinit.p, M,
+                         dj, sc.W16.p);
+      const size_t kshmem = CH::lds_bytes(MT) + (size_t)MK * sizeof(int);
+      auto kk = estep_hard_key_kernel<DJ>;
+      VCMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kshmem));
+      hipLaunchKernelGGL(kk, dim3((unsigned)std::min<int64_t>(nchunks, (int64_t)cus)), dim3(kHardKeyThreads), kshmem, st, sc.W16.p, M, dj, dX, N, key,
+                         chunkhist);
+      hipLaunchKernelGGL(gmmmap_group_scan_kernel, dim3((unsigned)MK), dim3(256), 0, st, chunkhist, nchunks, MK, total);
+      hipLaunchKernelGGL(gmmmap_group_scatter_kernel, dim3((unsigned)nchunks), dim3(256), (size_t)17 * MK * sizeof(int), st, key, N, MK,
+                         chunkhist, total, perm);
+      hipLaunchKernelGGL(estep_hard_stats_kernel<DJ>, dim3((unsigned)npmax), dim3(256), 0, st, dX, dj, M, perm, total, dmu, sc.refiv.p,
+                         sc.hpart.p, prow);
+      hipLaunchKernelGGL(estep_hard_reduce_kernel, dim3((unsigned)M), dim3(256), 0, st, sc.hpart.p, prow, total, M, dj, sc.refc.p, dstats,
+                         sc.hllm.p);
+      hipLaunchKernelGGL(estep_hard_ll_kernel, dim3(1), dim3(64), 0, st, sc.hllm.p, M, dstats, plen);
+      hipLaunchKernelGGL(estep_hard_gather_kernel, dim3((unsigned)(cus * 4)), dim3(256), 0, st, dX, dj, M, perm, total, sc.Xsoft.p, sc.nsoft.p, N);
+      VCMI_HIP(hipGetLastError());
+      VCMI_HIP(hipMemcpyAsync(sc.h_soft, total + M, sizeof(int), hipMemcpyDeviceToHost, st));
+      VCMI_HIP(hipEventRecord(sc.soft_ev, st));
+      sc.soft_pending = true;
+      sc.soft_N = N;
+      sc.last_hard = true;
+      // the soft frames through the one-kernel path, their number read on the device; its partials are added on top
+      VCMI_TRY(sc.part.reserve((size_t)cus * wpt * plen));
+      auto kern = (mtp < 8) ? estep_mfma_kernel<DJ, 0, true> : estep_mfma_kernel<DJ, 0, false>;
+      VCMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES));
+      hipLaunchKernelGGL(kern, dim3(cus), dim3(512), C::LDS_BYTES, st, sc.Xsoft.p, N, M, sc.Wpack.p, sc.cinit.p, sc.part.p, plen, dmu,
+                         sc.refiv.p, sc.refc.p, (double *)nullptr, dj, mtp, sc.mfma_count.p, (const int64_t *)sc.nsoft.p);
+      VCMI_HIP(hipGetLastError());
+      estep_reduce_launch(sc.part.p, cus * wpt, plen, dstats, st, /*accumulate=*/1, (const int64_t *)sc.nsoft.p);
+      VCMI_HIP(hipGetLastError());
+      return VCMI_OK;
+    }
     if (mtp == 8 && debug_flag(kDbgEstepWaveKernel)) {      // (measured slower than the three-barrier kernel: 1.59 against 1.32 ms -- DESIGN 3.3 round 5)
       // more than 64 mixtures: every wave owns a tile of 16 -- the one-barrier-per-block kernel (estep_wave.hpp)
       using CW = EstepWaveCfg<DJ>;
@@ -759,7 +845,7 @@ static int estep_mfma_launch(EstepScratch &sc, const double *dX, int64_t N, int 
     VCMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)C::LDS_BYTES));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), C::LDS_BYTES, st, dX, N, M, sc.Wpack.p, sc.cinit.p, sc.part.p, plen, dmu,
-                       sc.refiv.p, sc.refc.p, (double *)nullptr, dj, mtp, sc.mfma_count.p);
+                       sc.refiv.p, sc.refc.p, (double *)nullptr, dj, mtp, sc.mfma_count.p, (const int64_t *)nullptr);
     VCMI_HIP(hipGetLastError());
     estep_reduce_launch(sc.part.p, grid * wpt, plen, dstats, st, /*accumulate=*/0);     // (dstats was not zeroed)
     VCMI_HIP(hipGetLastError());
@@ -776,9 +862,9 @@ static int estep_mfma_launch(EstepScratch &sc, const double *dX, int64_t N, int 
       const int64_t nfr = std::min<int64_t>(kSplitChunk, N - n0);
       const int g2 = (int)std::min<int64_t>((nfr + C::FB - 1) / C::FB, cus);
       hipLaunchKernelGGL(kg, dim3(g2), dim3(512), C::LDS_BYTES, st, dX + n0 * dj, nfr, M, sc.Wpack.p, sc.cinit.p, sc.part.p, plen,
-                         dmu, sc.refiv.p, sc.refc.p, sc.G.p, dj, mtp, sc.mfma_count.p);
+                         dmu, sc.refiv.p, sc.refc.p, sc.G.p, dj, mtp, sc.mfma_count.p, (const int64_t *)nullptr);
       hipLaunchKernelGGL(ks, dim3(g2), dim3(512), C::LDS_BYTES, st, dX + n0 * dj, nfr, M, sc.Wpack.p, sc.cinit.p, sc.part.p, plen,
-                         dmu, sc.refiv.p, sc.refc.p, sc.G.p, dj, mtp, sc.mfma_count.p);
+                         dmu, sc.refiv.p, sc.refc.p, sc.G.p, dj, mtp, sc.mfma_count.p, (const int64_t *)nullptr);
       VCMI_HIP(hipGetLastError());
       estep_reduce_launch(sc.part.p, g2 * wpt, plen, dstats, st, /*accumulate=*/n0 > 0);
       VCMI_HIP(hipGetLastError());
@@ -847,7 +933,7 @@ static int estep_mfma_groups_launch(EstepScratch &sc, const double *dX, int64_t 
       const int m0 = g * C::MMAX, Mg = std::min(C::MMAX, M - m0);
       hipLaunchKernelGGL(k3, dim3(g2), dim3(512), C::LDS_BYTES, st, dX + n0 * dj, nfr, Mg, sc.Wpack.p + wlen * g,
                          sc.cinit.p + (size_t)C::MMAX * g, sc.LSE.p + (size_t)g * nfr, (int64_t)0, draw + goff[(size_t)g] + Mg,
-                         sc.refiv.p + (size_t)m0 * dj, sc.refc.p + m0, sc.G.p + (size_t)g * chunk * C::MMAX, dj, 8, sc.mfma_count.p);
+                         sc.refiv.p + (size_t)m0 * dj, sc.refc.p + m0, sc.G.p + (size_t)g * chunk * C::MMAX, dj, 8, sc.mfma_count.p, (const int64_t *)nullptr);
     }
     hipLaunchKernelGGL(estep_group_combine_kernel, dim3(kCombineGrid), dim3(256), 0, st, sc.G.p, sc.LSE.p, ng, nfr,
                        (int64_t)chunk * C::MMAX, llpart);
@@ -856,7 +942,7 @@ static int estep_mfma_groups_launch(EstepScratch &sc, const double *dX, int64_t 
       const int m0 = g * C::MMAX, Mg = std::min(C::MMAX, M - m0);
       const int64_t plen_g = (int64_t)Mg * (1 + 2 * dj) + 1;
       hipLaunchKernelGGL(k2, dim3(g2), dim3(512), C::LDS_BYTES, st, dX + n0 * dj, nfr, Mg, sc.Wpack.p, sc.cinit.p, sc.part.p, plen_g,
-                         draw, sc.refiv.p, sc.refc.p, sc.G.p + (size_t)g * chunk * C::MMAX, dj, 8, sc.mfma_count.p);
+                         draw, sc.refiv.p, sc.refc.p, sc.G.p + (size_t)g * chunk * C::MMAX, dj, 8, sc.mfma_count.p, (const int64_t *)nullptr);
       hipLaunchKernelGGL(estep_group_reduce_kernel, dim3((unsigned)((plen_g + 255) / 256)), dim3(256), 0, st, sc.part.p, g2, plen_g, Mg,
                          dj, m0, M, dstats);
     }
@@ -1758,6 +1844,21 @@ extern "C" int vcmi_debug_estep_mfma(int enable, int64_t *issued) {
     VCMI_HIP(hipMemset(sc.mfma_count.p, 0, sizeof(unsigned long long)));
   } else {
     sc.mfma_count.release();
+  }
+  return VCMI_OK;
+}
+
+// Measurement hook (not part of include/vcmi.h): did the last diagonal E-step of this host thread take the hard-assignment
+// path (estep_hard.hpp), and how many of its frames were soft (went through estep_mfma_kernel)?  *soft = -1: the one-kernel
+// path.  Synchronises with the device.
+extern "C" int vcmi_debug_estep_last_soft(int64_t *soft) {
+  using namespace vcmi;
+  if (!soft) return fail(VCMI_ERR_ARG, "vcmi_debug_estep_last_soft: NULL argument");
+  EstepScratch &sc = scratch();
+  *soft = -1;
+  if (sc.last_hard && sc.nsoft.p) {
+    VCMI_HIP(hipDeviceSynchronize());
+    VCMI_HIP(hipMemcpy(soft, sc.nsoft.p, sizeof(int64_t), hipMemcpyDeviceToHost));
   }
   return VCMI_OK;
 }

@@ -26,6 +26,7 @@
 #include "devgroup.hpp"
 #include "hostpipe.hpp"
 #include "fp64_exp.hpp"
+#include "grouping.hpp"
 #ifndef VCMI_CONVERT_PRIO
 #define VCMI_CONVERT_PRIO 1        // s_setprio: 1 = a wave's stretches WITHOUT MFMAs (|z|^2, the test, the y update, the barrier) at high
                                    // priority, so that it is back in an MFMA stream sooner (+1..2 % on one box); 2 = the reverse; 0 = none
@@ -1175,7 +1176,6 @@ convert_from_logdens_kernel(const double *__restrict__ LP, int M, int D, int DP,
 // gfrag[mt][ks][lane]: A-operand fragments, rows = mixtures 16 mt + (lane & 15), k = 4 ks + (lane >> 4); the last k-step
 // carries |mu|^2 (rows >= M: 1e300, never the minimum).
 // ------------------------------------------------------------------------------------------------
-constexpr int kGroupChunk = 1024;     // frames per chunk of the grouping sort (64 tiles of 16; 16 wave rows of 64)
 constexpr int kGroupKeyDims = 24;     // dimensions the nearest-mean key is taken over (a multiple of 4)
 
 // keys + one histogram per CHUNK of 1024 consecutive frames (chunkhist[c][m]); a workgroup walks chunks blockIdx.x,

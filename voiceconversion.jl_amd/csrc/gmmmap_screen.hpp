@@ -21,6 +21,8 @@
 // maximum as well: the result is the dense loop's to rounding (the order of the sum differs: survivors in index order after
 // the group's mixture).  Stages of QS quads are staged by LDS-DMA, double-buffered, one barrier per stage (16 mixtures).
 #pragma once
+#include <type_traits>
+#include "bf16_split.hpp"
 
 namespace vcmi {
 
@@ -59,22 +61,6 @@ __host__ __device__ constexpr int screen_row_index(int i, int rpm) { return (i >
 __host__ __device__ constexpr int screen16_tile_doubles() { return 3 * 128; }
 __host__ __device__ constexpr int screen16_stage_doubles(int DP) { return screen_quads(DP) * (screen16_tile_doubles() + 32); }
 __host__ __device__ constexpr bool screen16_has(int DP) { return DP >= 16 && DP <= 40 && DP % 4 == 0; }
-// x -> bf16 hi (round to nearest even) and bf16 lo of the FP32 remainder (x_f32 - hi is exact in FP32)
-__host__ __device__ inline void split_bf16(double x, unsigned short &h, unsigned short &l) {
-  union {
-    float f;
-    unsigned u;
-  } a, b, d;
-  a.f = (float)x;
-  h = (unsigned short)((a.u + 0x7FFFu + ((a.u >> 16) & 1u)) >> 16);
-  b.u = (unsigned)h << 16;
-  d.f = a.f - b.f;
-  l = (unsigned short)((d.u + 0x7FFFu + ((d.u >> 16) & 1u)) >> 16);
-}
-typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
-typedef float f32x4_t __attribute__((ext_vector_type(4)));
-typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
-
 // one 1 KB wave instruction of LDS-DMA: uniform global address, uniform LDS byte address, the lane's 16-byte offset
 __device__ __forceinline__ void dma_1k(const char *ga, unsigned la, unsigned lane_off) {
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(lane_off), "s"(ga), "s"(la) : "memory", "m0");
