@@ -703,6 +703,14 @@ def bench_estep(args, world, rank):
         vc.dist.allreduce_sum_(out_t)
     except Exception:  # noqa: BLE001  (an older library: the line keeps its algorithmic figure, labelled)
         issued_mfma = None
+    # the hard-assignment path (csrc/estep_hard.hpp): how many frames of the last step still went through the FP64 kernel
+    # (-1: the one-kernel path ran) -- asked once, after the timed steps
+    try:
+        from voiceconversion_jl_amd import _lib as _l
+
+        soft = _l.estep_last_soft()
+    except Exception:  # noqa: BLE001  (an older library)
+        soft = -1
     alg_tflops = estep_flops_per_frame(Dj, M) * N / (kernel_ms * 1e-3) / 1e12
     iss_tflops = issued_mfma * MFMA_FLOP / (kernel_ms * 1e-3) / 1e12 if issued_mfma else None
     achieved = min(alg_tflops, iss_tflops) if iss_tflops else alg_tflops
@@ -722,7 +730,22 @@ def bench_estep(args, world, rank):
                         "flop_per_frame": estep_flops_per_frame(Dj, M), "kernel_ms": kernel_ms},
            "collective": {"op": "all-reduce(sum), %d doubles" % vc.stats_len(Dj, M), "allreduce_ms": allreduce_ms,
                           "step_ms_with_allreduce": step_ms, "ranks": world, "backend": BACKEND["name"]}}
-    attach_traffic(out, "estep_traffic.json", "estep_mfma_kernel", standard=(N == 1_250_000 and Dj == 80 and M == 128),
+    prefixes = "estep_mfma_kernel"
+    if soft >= 0:
+        # Frames one mixture owns never reach the FP64 pipe: what is left is reading X (once algorithmically; this path reads
+        # it twice -- the screen, then the sums over the sorted rows) -- an HBM-bound job.  achieved = 8 Dj N bytes over the
+        # E-step kernels' time; the FP64-formulation figure (flops of the one-kernel formulation / this time) is kept beside
+        # it, labelled: those flops are not performed.
+        gbs = 8.0 * Dj * N / (kernel_ms * 1e-3) / 1e9
+        dj_inst = min(d for d in (32, 48, 64, 80) if d >= Dj)
+        out["roofline"] = {"bound": "hbm", "kernel": f"estep_hard_key_kernel<{dj_inst}> + sort + estep_hard_stats_kernel<{dj_inst}> (+ all-reduce)",
+                           "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
+                           "kernel_ms": kernel_ms, "soft_frames": soft, "soft_frac": soft / N,
+                           "fp64_formulation_tflops": alg_tflops,
+                           "fp64_formulation_note": "flops of the one-kernel formulation over this step's time; owned frames never reach the FP64 pipe",
+                           "mfma_issued_per_step": issued_mfma, "algorithmic_bytes_per_frame": 8 * Dj}
+        prefixes = ("estep_hard", "gmmmap_group_sc", "estep_mfma_kernel")
+    attach_traffic(out, "estep_traffic.json", prefixes, standard=(N == 1_250_000 and Dj == 80 and M == 128),
                    live=LIVE_PMC.get("estep"), algorithmic_bytes=8.0 * Dj * N)
     if rank == 0 and not args.profile_run:       # (the parity sample launches the kernel once more)
         from oracle import c_oracle as co
@@ -1134,7 +1157,7 @@ def summarize(out):
 
 LINE_CAP = 7500           # characters of the ONE stdout line (the driver keeps an 8 KB tail; BENCH_r04 lost a 20.9 KB line)
 ROOF_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "kernel_ms", "algorithmic_frac", "issued_mfma_frac",
-             "traffic_whole_step", "traffic_x_algorithmic", "traffic_GBps", "hbm_frac")
+             "traffic_whole_step", "traffic_x_algorithmic", "traffic_GBps", "hbm_frac", "soft_frac", "fp64_formulation_tflops")
 
 
 def _sig(x, n=6):

@@ -1134,12 +1134,26 @@ static int traj_run(vcmi_traj *t, std::vector<TrajUtt> &utts, int64_t nframes, b
     /* as many workgroups as the device holds at once: two per CU where LDS and registers allow (static D <= 30) */ \
     int occ = 1;                                                                                                    \
     if (debug_flag(kDbgTrajOneWgPerCu) ||                                                                           \
-        hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, kBlkThreads, shb) != hipSuccess || occ < 1)        \
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, blk_threads<DV>(), shb) != hipSuccess || occ < 1)        \
       occ = 1;                                                                                                      \
     const int grid_blk = (int)std::min<int64_t>(n, (int64_t)cus * occ);                                             \
     VCMI_TRY(t->ws.reserve((size_t)grid_blk * std::max(ws_stride, ws_stride_s)));                                   \
-    hipLaunchKernelGGL(kern, dim3(grid_blk), dim3(kBlkThreads), shb, st, dus, n, Qs, t->mhat.p, gs, t->ws.p,         \
-                       ws_stride_s, t->status.p);                                                                   \
+    if (blk_deferred_waves<DV>() <= 2) {                                                                            \
+      hipLaunchKernelGGL(kern, dim3(grid_blk), dim3(blk_threads<DV>()), shb, st, dus, n, Qs, t->mhat.p, gs, t->ws.p,  \
+                         ws_stride_s, t->status.p);                                                                 \
+    } else {                                                                                                        \
+      /* eight waves: factorisation and back substitution are two kernels, per batch of grid_blk utterances */       \
+      auto kb = traj_backsub_blk_kernel<DV>;                                                                        \
+      const size_t shs = blk_backsub_lds_bytes<DV>();                                                               \
+      VCMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kb), hipFuncAttributeMaxDynamicSharedMemorySize,  \
+                                   (int)shs));                                                                      \
+      for (int b0 = 0; b0 < n; b0 += grid_blk) {                                                                    \
+        const int nb = std::min(grid_blk, n - b0);                                                                  \
+        hipLaunchKernelGGL(kern, dim3(nb), dim3(blk_threads<DV>()), shb, st, dus + b0, nb, Qs, t->mhat.p, gs,        \
+                           t->ws.p, ws_stride_s, t->status.p);                                                      \
+        hipLaunchKernelGGL(kb, dim3(nb), dim3(256), shs, st, dus + b0, nb, t->ws.p, ws_stride_s);                    \
+      }                                                                                                             \
+    }                                                                                                               \
     launched = true;                                                                                                \
   } break;
       VCMI_TRAJ_BLK_CASE(12) VCMI_TRAJ_BLK_CASE(16) VCMI_TRAJ_BLK_CASE(20) VCMI_TRAJ_BLK_CASE(24) VCMI_TRAJ_BLK_CASE(25)
@@ -1187,7 +1201,7 @@ static int traj_run(vcmi_traj *t, std::vector<TrajUtt> &utts, int64_t nframes, b
 static int traj_check_status(vcmi_traj *t, hipStream_t st) {
 #ifdef TRAJ_BLK_PROF
   {
-    long long h[16], z[16] = {0};
+    long long h[32], z[32] = {0};
     (void)hipStreamSynchronize(st);
     (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(blk_prof), sizeof(h));
     (void)hipMemcpyToSymbol(HIP_SYMBOL(blk_prof), z, sizeof(z));
@@ -1196,6 +1210,8 @@ static int traj_check_status(vcmi_traj *t, hipStream_t st) {
     fprintf(stderr, "   gv kernel: product phase %lld, update %lld, moments %lld\n", h[13], h[14], h[15]);
     fprintf(stderr, "   deferred wave 2: L20 done %lld, S21/S22 done %lld, loads issued %lld, panel stored %lld, combined %lld | wave 0 jobs done %lld, wave 1 jobs done %lld | wave 3: S21/S22 done %lld, combined %lld\n", h[8],
             h[6], h[10], h[11], h[7], h[9], h[12], h[14], h[13]);
+    fprintf(stderr, "   deferred waves 2..7: S21/S22 jobs done %lld %lld %lld %lld %lld %lld | at the barrier %lld %lld %lld %lld %lld %lld\n", h[26], h[27], h[28],
+            h[29], h[30], h[31], h[18], h[19], h[20], h[21], h[22], h[23]);
   }
 #endif
   int h = 0;

@@ -40,7 +40,7 @@ struct BlkCfg {
 typedef double blk_d4 __attribute__((ext_vector_type(4)));
 
 #ifdef TRAJ_BLK_PROF
-__device__ long long blk_prof[16];   // cycles of workgroup 0 per phase (printed by traj_check_status)
+__device__ long long blk_prof[32];   // cycles of workgroup 0 per phase (printed by traj_check_status)
 #define BLK_PROF_T0() long long pt_ = (long long)__builtin_readcyclecounter()
 #define BLK_PROF(k)                                                     \
   do {                                                                  \
@@ -188,6 +188,12 @@ __device__ void pv2_wave0(double *B00, int *flags, int fbase, int lane, int *bad
 #pragma unroll
     for (int q = 0; q < 4; ++q) e[q] = (i == 4 * q + g) ? 1.0 : 0.0;
     double pvi = 1.0;                                       // the pivot of row i
+#ifdef TRAJ_BLK_FREE_CHAIN
+    // Experiment (wrong results, timing only): the scalar chain costs nothing -- U_kk = diag(S_kk)^-1/2, hand-overs kept.
+    // The step time of this build is the bound of what ANY faster pivot scheme could reach.
+#pragma unroll
+    for (int j = 0; j < 16; ++j) pvi = (i == j) ? fabs(a[j]) + 1.0 : pvi;
+#else
 #pragma unroll
     for (int c = 0; c < 16; ++c) {
       if (c < nb) {                                        // wave-uniform
@@ -209,6 +215,7 @@ __device__ void pv2_wave0(double *B00, int *flags, int fbase, int lane, int *bad
           asm volatile("v_fmac_f64_dpp %0, %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "+v"(e[q]) : "v"(m), "n"(c));
       }
     }
+#endif
     // U_kk = D^-1/2 (unit-lower inverse): row i scaled by 1/sqrt(p_i); zeros above the diagonal
     notpd |= !(pvi > 0.0);
     if (i < nb) {
@@ -460,7 +467,9 @@ __device__ void blk_backsub(const double *__restrict__ ws, int T, double *buf, d
   constexpr int YB = 8;                    // steps per result flush
   const int tid = threadIdx.x, j = tid & 63, p = tid >> 6;
   double *ybuf = part + 320;               // [YB][D]
+  const bool act = tid < 256;              // (eight-wave workgroups: the other waves only keep the barriers' count)
   auto fetch = [&](int t, double (&regs)[NPRE]) {
+    if (!act) return;
     const double *pan = ws + (size_t)t * PAN;
 #pragma unroll
     for (int k = 0; k < NPRE; ++k) {
@@ -469,6 +478,7 @@ __device__ void blk_backsub(const double *__restrict__ ws, int T, double *buf, d
     }
   };
   auto stage = [&](int t, const double (&regs)[NPRE]) {
+    if (!act) return;
     double *dst = buf + (size_t)(t % 3) * PAN;
 #pragma unroll
     for (int k = 0; k < NPRE; ++k) {
@@ -489,7 +499,7 @@ __device__ void blk_backsub(const double *__restrict__ ws, int T, double *buf, d
     const double *pb = buf + (size_t)(t % 3) * PAN;
     double *y1 = yring + ((t + 1) & 1) * D, *y2 = yring + (t & 1) * D;   // y_{t+1}, y_{t+2}
     const int jc = j < D ? j : D - 1;
-    {   // partial sums of h - [M1; M2]' [y_{t+1}; y_{t+2}]: compile-time trip count, all LDS reads issued up front
+    if (act) {   // partial sums of h - [M1; M2]' [y_{t+1}; y_{t+2}]: compile-time trip count, all LDS reads issued up front
       double s0 = (p == 0) ? pb[OH + jc] : 0.0, s1 = 0.0;
       const int r_lo = p * R1;
 #pragma unroll
@@ -512,7 +522,8 @@ __device__ void blk_backsub(const double *__restrict__ ws, int T, double *buf, d
     __syncthreads();
     if ((t & (YB - 1)) == 0) {            // rows t .. t+YB-1 of reshape(y, D, T), src/trajectory_gmmmap.jl:109
       const int nrow = (T - t < YB) ? T - t : YB;
-      for (int e = tid; e < nrow * D; e += 256) Y[(size_t)t * D + e] = ybuf[e];
+      if (act)
+        for (int e = tid; e < nrow * D; e += 256) Y[(size_t)t * D + e] = ybuf[e];
       __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): no store is pending when the loop goes on
     }
   };
@@ -534,6 +545,13 @@ __device__ void blk_backsub(const double *__restrict__ ws, int T, double *buf, d
 #endif
 #define TRAJ_DEFERRED_WAVES 2     // waves of the deferred team (beside the two pivot waves); 4 was measured: the kernel
                                   // then has two waves per SIMD, spills 68 VGPRs and the scalar chain shares its FP64 pipe: 40.6 ms
+#ifndef TRAJ_DEFERRED_WAVES_NT3
+#define TRAJ_DEFERRED_WAVES_NT3 6 // the same at three tiles per dimension (D = 32..46): 6 = eight waves, two per SIMD, see blk_job_owner (2: round 4's kernel)
+#endif
+template <int D>
+__host__ __device__ constexpr int blk_deferred_waves() { return BlkCfg<D>::NT == 3 ? TRAJ_DEFERRED_WAVES_NT3 : TRAJ_DEFERRED_WAVES; }
+template <int D>
+__host__ __device__ constexpr int blk_threads() { return 64 * (2 + blk_deferred_waves<D>()); }
 // Which wave runs job j of the deferred list (see the kernel).  At three tiles per dimension (D = 32..46) by measured
 // job lengths (tools/microbench_blkops.hip, counts of s_memtime: S21 row group 2.9k, S22 row groups 2.9k / 2.0k / 1.4k,
 // panel row tile 2.2k alone, ~3k beside the other waves' stores) and by when a wave becomes free: the deferred waves
@@ -547,17 +565,27 @@ __device__ constexpr int blk_job_owner(int j) {
     constexpr int own[12] = {2, 3, 2, 3, 2, 3, 1, 1, 2, 3, 0, 0};
     return own[j];
   }
+  if (NT == 3 && NDW == 6) {
+    // Eight waves, two per SIMD (wave w on SIMD w % 4): wave 4 shares the scalar chain's SIMD and gets no products (a
+    // dependent FP64 chain advances one instruction per MFMA slot beside a wave that streams MFMAs); wave 5 shares the
+    // SIMD of pivot wave 1 and gets the two lightest jobs.
+    //               S21 r0 r1 r2 | S22 r2 r1 r0 | M1 t0 t1 t2 | M2 t0 t1 t2
+#ifndef TRAJ_W8_OWNERS
+#define TRAJ_W8_OWNERS {2, 3, 6, 7, 6, 7, 6, 7, 5, 0, 3, 5}
+#endif
+    constexpr int own[12] = TRAJ_W8_OWNERS;
+    return own[j];
+  }
   return NPW + j % NDW;
 }
 
-static constexpr int kBlkThreads = 64 * (2 + TRAJ_DEFERRED_WAVES);
 
 // Two workgroups per CU where they fit (static D <= 25: 16-row tiles up to 32 rows -> <= 70 KB of LDS; the second launch
 // bound caps the registers at 256): two independent scalar chains then share a CU's SIMDs, and a batch of more utterances
 // (or vc() chunks) than CUs runs 1.5-1.6x faster (tools/traj_occupancy_probe.py).  At D = 30..40 the window alone is
 // 115 KB: one workgroup per CU.
 template <int D>
-__global__ void __launch_bounds__(kBlkThreads, (BlkCfg<D>::lds_doubles * 8 <= 80 * 1024) ? 2 : 1)
+__global__ void __launch_bounds__(blk_threads<D>(), (BlkCfg<D>::lds_doubles * 8 <= 80 * 1024) ? 2 : 1)
 traj_solve_blk_kernel(const TrajUtt *__restrict__ utts, int n, const double *__restrict__ Qall,
                       const int64_t *__restrict__ mhat_all, const double *__restrict__ g_all, double *__restrict__ ws_all,
                       int64_t ws_stride, int *__restrict__ status) {
@@ -565,7 +593,7 @@ traj_solve_blk_kernel(const TrajUtt *__restrict__ utts, int n, const double *__r
   constexpr int D2 = 2 * D, DP = C::DP, LS = C::LS, NT = C::NT, BUF = C::BUF;
   constexpr size_t PAN = C::PAN;
   constexpr int NLOW = NT * (NT + 1) / 2;
-  constexpr int NPW = 2, NDW = TRAJ_DEFERRED_WAVES, NDT = 64 * NDW;      // pivot pair, deferred team
+  constexpr int NPW = 2, NDW = blk_deferred_waves<D>(), NDT = 64 * NDW;      // pivot pair, deferred team
   constexpr int W1L = BlkCfg<D>::NT >= 3 ? TRAJ_W1_L20 : 0;
   static_assert(W1L == 0 || D / 16 >= W1L, "pivot wave 1 does not form the L20 row tile that holds the rhs row");
   constexpr int NW = NPW + NDW, NTHR = 64 * NW;
@@ -679,6 +707,8 @@ traj_solve_blk_kernel(const TrajUtt *__restrict__ utts, int n, const double *__r
           for (int j = 0; j < 4 * NT; ++j)
             if (blk_job_owner<NT, NPW, NDW>(j) < NPW && blk_job_owner<NT, NPW, NDW>(j) == wave) run_job(j);
         }
+        BLK_PROF_AT(9, 0);
+        BLK_PROF_AT(12, 64);
       } else {
         const int dw = wave - NPW;
         // mixtures of block rows t+1, t+2, t+3 (clamped), loaded before the products so that the stencil loads below
@@ -697,6 +727,26 @@ traj_solve_blk_kernel(const TrajUtt *__restrict__ utts, int n, const double *__r
             if (blk_job_owner<NT, NPW, NDW>(j) >= NPW && blk_job_owner<NT, NPW, NDW>(j) == wave) run_job(j);
         }
         BLK_PROF_AT(6, 64 * NPW);
+        BLK_PROF_AT(14, 64 * NPW + 64);
+        BLK_PROF_AT(24 + wave, 64 * wave);      // ... and the end of its S21 / S22 jobs
+        // (two waves per SIMD: the stencil values are fetched after the panel jobs -- the SIMD's other wave covers the wait,
+        // and 5 x NIT values in flight beside a job's 52 operand doubles do not fit 256 registers)
+#ifndef TRAJ_W8_STENCIL_MID
+#define TRAJ_W8_STENCIL_MID 0
+#endif
+        constexpr bool kLateStencil = NDW > 2 && !TRAJ_W8_STENCIL_MID;
+        // (measured and dropped: M1 tiles -- which need nothing of this step -- run by the waves without an L20 tile while the
+        // others form L20: 23.9 against 23.45 ms, the products beside them delay L20, which everything else waits for)
+        auto late_panel_jobs = [&]() {
+#pragma unroll
+          for (int j = 2 * NT; j < 4 * NT; ++j)
+            if (blk_job_owner<NT, NPW, NDW>(j) >= NPW && blk_job_owner<NT, NPW, NDW>(j) == wave) run_job(j);
+        };
+        // Wave 4 of eight shares the scalar chain's SIMD and gets no job at all.  (Measured: a panel job for it after wave 0's
+        // last diagonal block -- even the polling for that moment alone, one LDS read per s_sleep -- costs the chain 1.4 ms
+        // per 2000 steps: 24.8 against 23.3 ms.)
+        constexpr bool chainmate = false;
+        if (kLateStencil && defer && !chainmate) late_panel_jobs();
         // Block row a = t+2 of the stencil.  Every load is unconditional on a clamped address (a select on a loaded
         // value would make the wave wait for each load in turn); masks are applied when the operands are combined.
         // Issued between the row-group jobs and the panel jobs: early enough to be back in time, late enough that the
@@ -717,11 +767,7 @@ traj_solve_blk_kernel(const TrajUtt *__restrict__ utts, int n, const double *__r
         const int jr = dt < D ? dt : D - 1;
         const double g0 = g[(size_t)ac * D2 + jr], g1 = g[(size_t)am * D2 + D + jr], g2 = g[(size_t)ap * D2 + D + jr];
         BLK_PROF_AT(10, 64 * NPW);
-        if (defer) {
-#pragma unroll
-          for (int j = 2 * NT; j < 4 * NT; ++j)
-            if (blk_job_owner<NT, NPW, NDW>(j) >= NPW && blk_job_owner<NT, NPW, NDW>(j) == wave) run_job(j);
-        }
+        if (!kLateStencil && defer && !chainmate) late_panel_jobs();
         BLK_PROF_AT(11, 64 * NPW);
         const double w4 = hasp ? 0.25 : 0.0, w2 = hasp ? 0.5 : 0.0, lv = live ? 1.0 : 0.0;
 #pragma unroll
@@ -732,6 +778,8 @@ traj_solve_blk_kernel(const TrajUtt *__restrict__ utts, int n, const double *__r
         }
         rv = lv * ((g0 + 0.5 * g1) - w2 * g2);
         BLK_PROF_AT(7, 64 * NPW);
+        BLK_PROF_AT(13, 64 * NPW + 64);
+        BLK_PROF_AT(16 + wave, 64 * wave);      // every deferred wave's arrival at the barrier (its own clock since the S11 update)
       }
       __syncthreads();                    // end of phase 1: every read of p0, p1, p2 is done
       BLK_PROF(0);
@@ -772,7 +820,9 @@ traj_solve_blk_kernel(const TrajUtt *__restrict__ utts, int n, const double *__r
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       } else {
-        for (int job = wave; job < NLOW; job += NW - 1) {
+        // (eight waves: wave 4 sits on the chain's SIMD, where wave 0 has just gone on to the next chain -- no tile for it)
+        const int first = (NW == 8) ? (wave == 4 ? NLOW : (wave < 4 ? wave : wave - 1)) : wave;
+        for (int job = first; job < NLOW; job += (NW == 8 ? NW - 2 : NW - 1)) {
           int q = job, it = 0;
           while (q > it) { q -= it + 1; ++it; }
           blk_update_tile<D>(b11, b10, b10, it, q, lane);
@@ -790,9 +840,29 @@ traj_solve_blk_kernel(const TrajUtt *__restrict__ utts, int n, const double *__r
         b00 = b11; b10 = f1; b11 = f0;    // S11 -> S00, block (t+2,t+1) -> S10, block (t+2,t+2) -> S11
       }
     }
-    blk_backsub<D>(ws, T, wk, yring, part, U.Y);
+    // (eight waves: the back substitution is a kernel of its own, traj_backsub_blk_kernel -- inside this one it would be
+    // compiled for 256 registers beside everything else and spill in its loop: 5.0k instead of 2.8k counts per step)
+    if constexpr (NW <= 4) blk_backsub<D>(ws, T, wk, yring, part, U.Y);
     BLK_PROF(5);
     if (tid == 0 && bad) status[0] = 1;
     __syncthreads();
   }
 }
+
+// The back substitution alone (launched behind traj_solve_blk_kernel where that kernel has eight waves): workgroup b reads
+// the panels workgroup b of the factorisation left in its workspace -- the host launches the pair per batch of at most
+// gridDim.x utterances, so that a workspace holds one utterance's panels.
+template <int D>
+__global__ void __launch_bounds__(256)
+traj_backsub_blk_kernel(const TrajUtt *__restrict__ utts, int n, const double *__restrict__ ws_all, int64_t ws_stride) {
+  using C = BlkCfg<D>;
+  extern __shared__ __attribute__((aligned(16))) double blk_sm[];
+  double *yring = blk_sm, *part = yring + 2 * D, *wk = part + 770;
+  const int u = blockIdx.x;
+  if (u >= n) return;
+  const TrajUtt U = utts[u];
+  if (U.T == 0) return;
+  blk_backsub<D>(ws_all + (size_t)blockIdx.x * ws_stride, U.T, wk, yring, part, U.Y);
+}
+template <int D>
+constexpr size_t blk_backsub_lds_bytes() { return (2 * D + 770 + 3 * BlkCfg<D>::PAN) * sizeof(double); }
