@@ -1076,17 +1076,17 @@ def bench_traj(args, world, rank, gv=False):
                                    f"vc(TrajectoryGMMMap) in chunks of {L} frames (bin/vc.jl:18, src/common.jl:42-57)"),
                       "static_D": D, "M": M, "T": T, "utterances_per_gpu": n, "solves_per_step": nsolve,
                       "frames_per_solve": int(Ts.max())},
-           "roofline": {"bound": "mfma", "kernel": "predict + traj_g_mfma_kernel + traj_solve_blk_kernel<40>" + (" + traj_gv2_kernel" if gv else ""),
+           "roofline": {"bound": "mfma", "kernel": "predict + traj_g_mfma_kernel + traj_solve_blk_kernel<40> + traj_backsub_blk_kernel<40>" + (" + traj_gv2_kernel" if gv else ""),
                         "achieved": achieved,
                         "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS,
                         "traffic": None,
                         "flop_per_utterance": flops_per_utt, "kernel_ms": kernel_ms,
-                        "note": "whole pipeline (3 kernels); the banded solve is a sequential block recurrence along each "
-                                "(sub-)sequence whose pivot block is factorised column by column (latency-bound, see DESIGN "
-                                "3.4); chunked conversion has the same number of block steps per CU, in shorter chains"}}
+                        "note": "whole pipeline (4 kernels); the banded solve is a sequential block recurrence along each "
+                                "(sub-)sequence (latency-bound, see DESIGN 3.4: factorisation, then the back substitution as its "
+                                "own kernel); chunked conversion has the same number of block steps per CU, in shorter chains"}}
     attach_traffic(out, ("trajgv" if gv else "traj") + "_traffic.json",
-                   ("gmmmap_mfma_kernel", "posterior_finish_kernel", "traj_g_mfma_kernel", "traj_solve_blk_kernel", "traj_gv_kernel",
-                    "traj_gv2_kernel"), standard=(n == 256 and L <= 0), live=LIVE_PMC.get("trajgv" if gv else "traj"),
+                   ("gmmmap_mfma_kernel", "posterior_finish_kernel", "traj_g_mfma_kernel", "traj_solve_blk_kernel", "traj_backsub_blk_kernel",
+                    "traj_gv_kernel", "traj_gv2_kernel"), standard=(n == 256 and L <= 0), live=LIVE_PMC.get("trajgv" if gv else "traj"),
                    algorithmic_bytes=8.0 * n * T * 3 * D)
     if rank == 0:
         from oracle import c_oracle as co
