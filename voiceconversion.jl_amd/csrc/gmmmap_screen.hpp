@@ -23,6 +23,7 @@
 #pragma once
 #include <type_traits>
 #include "bf16_split.hpp"
+#include "lds_dma.hpp"
 
 namespace vcmi {
 
@@ -61,10 +62,6 @@ __host__ __device__ constexpr int screen_row_index(int i, int rpm) { return (i >
 __host__ __device__ constexpr int screen16_tile_doubles() { return 3 * 128; }
 __host__ __device__ constexpr int screen16_stage_doubles(int DP) { return screen_quads(DP) * (screen16_tile_doubles() + 32); }
 __host__ __device__ constexpr bool screen16_has(int DP) { return DP >= 16 && DP <= 40 && DP % 4 == 0; }
-// one 1 KB wave instruction of LDS-DMA: uniform global address, uniform LDS byte address, the lane's 16-byte offset
-__device__ __forceinline__ void dma_1k(const char *ga, unsigned la, unsigned lane_off) {
-  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(lane_off), "s"(ga), "s"(la) : "memory", "m0");
-}
 
 template <int DP, int FT, int WAVES, bool B16 = false>
 __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(DP <= 40 ? (FT == 2 ? 3 : 4) : 2)))

@@ -20,6 +20,7 @@
 #include "gmmmap_handle.hpp"
 #include "devgroup.hpp"
 #include "hostpipe.hpp"
+#include "lds_dma.hpp"
 
 #include <algorithm>
 #include <cstdlib>
@@ -1137,7 +1138,7 @@ static int traj_run(vcmi_traj *t, std::vector<TrajUtt> &utts, int64_t nframes, b
         hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, blk_threads<DV>(), shb) != hipSuccess || occ < 1)        \
       occ = 1;                                                                                                      \
     const int grid_blk = (int)std::min<int64_t>(n, (int64_t)cus * occ);                                             \
-    VCMI_TRY(t->ws.reserve((size_t)grid_blk * std::max(ws_stride, ws_stride_s)));                                   \
+    VCMI_TRY(t->ws.reserve((size_t)grid_blk * std::max(ws_stride, ws_stride_s) + 256)); /* + slack: whole-KB reads */ \
     if (blk_deferred_waves<DV>() <= 2) {                                                                            \
       hipLaunchKernelGGL(kern, dim3(grid_blk), dim3(blk_threads<DV>()), shb, st, dus, n, Qs, t->mhat.p, gs, t->ws.p,  \
                          ws_stride_s, t->status.p);                                                                 \
@@ -1151,7 +1152,7 @@ static int traj_run(vcmi_traj *t, std::vector<TrajUtt> &utts, int64_t nframes, b
         const int nb = std::min(grid_blk, n - b0);                                                                  \
         hipLaunchKernelGGL(kern, dim3(nb), dim3(blk_threads<DV>()), shb, st, dus + b0, nb, Qs, t->mhat.p, gs,        \
                            t->ws.p, ws_stride_s, t->status.p);                                                      \
-        hipLaunchKernelGGL(kb, dim3(nb), dim3(256), shs, st, dus + b0, nb, t->ws.p, ws_stride_s);                    \
+        hipLaunchKernelGGL(kb, dim3(nb), dim3(BacksubCfg<DV>::THREADS), shs, st, dus + b0, nb, t->ws.p, ws_stride_s);                    \
       }                                                                                                             \
     }                                                                                                               \
     launched = true;                                                                                                \

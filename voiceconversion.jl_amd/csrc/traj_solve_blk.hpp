@@ -849,20 +849,136 @@ traj_solve_blk_kernel(const TrajUtt *__restrict__ utts, int n, const double *__r
   }
 }
 
-// The back substitution alone (launched behind traj_solve_blk_kernel where that kernel has eight waves): workgroup b reads
-// the panels workgroup b of the factorisation left in its workspace -- the host launches the pair per batch of at most
-// gridDim.x utterances, so that a workspace holds one utterance's panels.
+// ------------------------------------------------------------------------------------------------
+// The back substitution alone, as a STREAM (launched behind traj_solve_blk_kernel where that kernel has eight waves): workgroup
+// b reads the panels workgroup b of the factorisation left in its workspace -- the host launches the pair per batch of at
+// most gridDim.x utterances, so that a workspace holds one utterance's panels.
+//   y_t = h_t - M1_t' y_{t+1} - M2_t' y_{t+2}:  3240 multiply-adds per step at D = 40, but 25.9 KB of panel -- 13.3 GB per 256
+// utterances of 2000 frames: the loop is bound by HBM, so it is built around the read:
+//   loader waves (NLOAD of them, panel i = l, l + NLOAD, ...; i counts from the LAST block step): LDS-DMA of whole panels
+//     (global_load_lds_dwordx4, 1 KB per wave instruction, no registers) into a ring of RING slots, PF panels in flight
+//     per wave (vmcnt is a 6-bit counter: PF x NI <= 60); a slot is reused once the compute wave has gone past it (`done`),
+//     a panel is published (`ready[slot]`) when the wave's vmcnt says its last kilobyte has landed;
+//   ONE compute wave: lane j < D owns column j -- 2 D + 1 conflict-free LDS reads of the panel, the 2 D values of y_{t+1},
+//     y_{t+2} as broadcast reads (16 bytes each) from a three-deep LDS ring it writes itself, four accumulators; no barrier
+//     in the loop, no other wave on its critical path.
+// Panels are read in whole kilobytes: the last read of a panel runs up to 1008 bytes into the next one (the workspace has that
+// much slack behind its last panel).
+// ------------------------------------------------------------------------------------------------
 template <int D>
-__global__ void __launch_bounds__(256)
+struct BacksubCfg {
+  static constexpr int PAN = (int)BlkCfg<D>::PAN;
+  static constexpr int NI = (PAN * 8 + 1023) / 1024;                 // 1 KB wave instructions per panel
+  static constexpr int SLOT = NI * 128;                              // doubles per ring slot
+  static constexpr int PF = (60 / NI) < 3 ? (60 / NI) : 3;           // panels in flight per loader wave
+  static constexpr int RING_MAX = (150 * 1024) / (NI * 1024);
+  static constexpr int NLOAD = ((RING_MAX - 1) / PF) < 3 ? ((RING_MAX - 1) / PF) : 3;
+  static constexpr int RING = NLOAD * PF + 1;
+  static constexpr int THREADS = 64 * (1 + NLOAD);
+  static constexpr size_t lds_bytes = (size_t)RING * SLOT * 8 + 3 * 64 * 8 + 64 * 4;      // ring | y ring (3 x 64) | flags
+  static_assert(PF >= 1 && NLOAD >= 1 && RING >= NLOAD + 1, "ring too small");
+};
+
+template <int D>
+__global__ void __launch_bounds__(BacksubCfg<D>::THREADS)
 traj_backsub_blk_kernel(const TrajUtt *__restrict__ utts, int n, const double *__restrict__ ws_all, int64_t ws_stride) {
-  using C = BlkCfg<D>;
+  using B = BacksubCfg<D>;
+  constexpr int PAN = B::PAN, NI = B::NI, SLOT = B::SLOT, PF = B::PF, NLOAD = B::NLOAD, RING = B::RING;
+  constexpr int OH = D * D, OM2 = (D + 1) * D;
   extern __shared__ __attribute__((aligned(16))) double blk_sm[];
-  double *yring = blk_sm, *part = yring + 2 * D, *wk = part + 770;
+  double *ring = blk_sm;                              // [RING][SLOT]
+  double *ysh = ring + (size_t)RING * SLOT;           // [3][64]: y_t ring (slot t % 3)
+  int *ready = reinterpret_cast<int *>(ysh + 3 * 64); // [RING] = index + 1 of the panel the slot holds; [RING] = done
+  int *done = ready + RING;
   const int u = blockIdx.x;
   if (u >= n) return;
   const TrajUtt U = utts[u];
-  if (U.T == 0) return;
-  blk_backsub<D>(ws_all + (size_t)blockIdx.x * ws_stride, U.T, wk, yring, part, U.Y);
+  const int T = U.T;
+  if (T == 0) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const double *ws = ws_all + (size_t)blockIdx.x * ws_stride;
+  if (tid <= RING) ready[tid] = 0;                    // (ready[RING] is `done`)
+  for (int e = tid; e < 3 * 64; e += B::THREADS) ysh[e] = 0.0;
+  __syncthreads();
+  if (wave > 0) {
+    // ---- loader wave l: panels l, l + NLOAD, ... (counted from the last block step)
+    const int l = wave - 1;
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)(reinterpret_cast<char *>(ring));
+    const unsigned lane_off = 16u * (unsigned)lane;
+    int issued = l, signalled = l, inflight = 0;
+    while (signalled < T) {
+      while (inflight < PF && issued < T) {
+        pv2_wait(done, issued - RING + 1);            // the slot's previous panel has been consumed
+        const char *gp = reinterpret_cast<const char *>(ws + (size_t)(T - 1 - issued) * PAN);
+        const unsigned la = lds0 + (unsigned)(issued % RING) * (unsigned)(SLOT * 8);
+#pragma unroll
+        for (int k = 0; k < NI; ++k) dma_1k(gp + 1024 * k, la + 1024u * k, lane_off);
+        issued += NLOAD;
+        ++inflight;
+      }
+      // the oldest panel in flight has landed when at most (inflight - 1) x NI of this wave's loads are outstanding
+      if (inflight >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NI < 63 ? 2 * NI : 63) : "memory");
+      else if (inflight == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI < 63 ? NI : 63) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      pv2_signal(ready + signalled % RING, signalled + 1, lane);
+      signalled += NLOAD;
+      --inflight;
+    }
+    return;
+  }
+  // ---- the compute wave
+  const int j = lane < D ? lane : D - 1;
+  double *Y = U.Y;
+  for (int i = 0; i < T; ++i) {
+    const int t = T - 1 - i;
+    pv2_wait(ready + i % RING, i + 1);
+    const double *pb = ring + (size_t)(i % RING) * SLOT;
+    const double *y1 = ysh + ((t + 1) % 3) * 64, *y2 = ysh + ((t + 2) % 3) * 64;      // y_{t+1}, y_{t+2} (zeros beyond the end)
+    // the lane's column of the panel into registers, then the slot is handed back at once: the loaders run ahead while the
+    // sums are formed (a slot held for the whole step left the read 10 % below what the loaders reach alone)
+    double mh = pb[OH + j], m1v[D], m2v[D];
+#pragma unroll
+    for (int r = 0; r < D; ++r) m1v[r] = pb[r * D + j];
+#pragma unroll
+    for (int r = 0; r < D; ++r) m2v[r] = pb[OM2 + r * D + j];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    pv2_signal(done, i + 1, lane);
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    double a0 = mh, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+#ifdef TRAJ_BACKSUB_NO_COMPUTE
+    if (false)
+#endif
+    {
+#pragma unroll
+      for (int r = 0; r < D; r += 2) {
+        const d2 yy = *reinterpret_cast<const d2 *>(y1 + r);                            // (uniform address: a broadcast read)
+        const d2 zz = *reinterpret_cast<const d2 *>(y2 + r);
+        if (r & 2) {
+          a2 = fma(-m1v[r], yy.x, a2);
+          a3 = fma(-m2v[r], zz.x, a3);
+          if (r + 1 < D) {
+            a2 = fma(-m1v[r + 1], yy.y, a2);
+            a3 = fma(-m2v[r + 1], zz.y, a3);
+          }
+        } else {
+          a0 = fma(-m1v[r], yy.x, a0);
+          a1 = fma(-m2v[r], zz.x, a1);
+          if (r + 1 < D) {
+            a0 = fma(-m1v[r + 1], yy.y, a0);
+            a1 = fma(-m2v[r + 1], zz.y, a1);
+          }
+        }
+      }
+    }
+    const double yv = (a0 + a1) + (a2 + a3);
+    if (lane < D) {
+      ysh[(t % 3) * 64 + lane] = yv;                  // the slot of y_{t+3}, read for the last time one step ago
+      Y[(size_t)t * D + lane] = yv;                   // row t of reshape(y, D, T), src/trajectory_gmmmap.jl:109
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
 }
 template <int D>
-constexpr size_t blk_backsub_lds_bytes() { return (2 * D + 770 + 3 * BlkCfg<D>::PAN) * sizeof(double); }
+constexpr size_t blk_backsub_lds_bytes() { return BacksubCfg<D>::lds_bytes; }
