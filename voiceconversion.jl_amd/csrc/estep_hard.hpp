@@ -129,11 +129,17 @@ estep_hard_key_kernel(const unsigned char *__restrict__ W16, int M, int dj, cons
       const double *xr = X + (fr < N ? fr : N - 1) * dj;
 #pragma unroll
       for (int i = 0; i < NI; ++i) {
+        // two 16-byte loads on clamped addresses (dj is even and the rows are 16-byte aligned on this path: a pair is inside
+        // the row or outside it as a whole), masked afterwards -- no branch around a load
         double x[4];
+        typedef double kd2 __attribute__((ext_vector_type(2)));
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < 4; j += 2) {
           const int d = 16 * i + 4 * lgrp + j;
-          x[j] = (d < dj) ? xr[d] : 0.0;
+          const bool in = d < dj;
+          const kd2 v = *reinterpret_cast<const kd2 *>(xr + (in ? d : 0));
+          x[j] = in ? v.x : 0.0;
+          x[j + 1] = in ? v.y : 0.0;
         }
         double x2[4];
 #pragma unroll
@@ -168,7 +174,9 @@ estep_hard_key_kernel(const unsigned char *__restrict__ W16, int M, int dj, cons
           const u32x4_t ah = *reinterpret_cast<const u32x4_t *>(tb + i * 2048 + 16 * lane), al = *reinterpret_cast<const u32x4_t *>(tb + i * 2048 + 1024 + 16 * lane);
           acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, ah), __builtin_bit_cast(bf16x8_t, bh[i]), acc, 0, 0, 0);
           acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, ah), __builtin_bit_cast(bf16x8_t, bl[i]), acc, 0, 0, 0);
+#ifndef ESTEP_KEY_TWO_TERMS      // (timing experiment: without the W-lo term -- and its LDS read -- the margins would not hold)
           acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, al), __builtin_bit_cast(bf16x8_t, bh[i]), acc, 0, 0, 0);
+#endif
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
