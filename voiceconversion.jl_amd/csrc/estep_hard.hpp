@@ -311,10 +311,22 @@ estep_hard_reduce_kernel(const double *__restrict__ part, int64_t prow, const in
   const int np = (tot[m] + kHardPiece - 1) / kHardPiece;
   const int e = threadIdx.x;                                    // element of the row: 0 count, 1 .. dj S1, dj+1 .. 2dj S2, 2dj+1 T
   if (e > 2 * dj + 1) return;
-  // four partial sums over every fourth piece (independent loads in flight), combined in a fixed order
+  // four partial sums over every fourth piece, combined in a fixed order; sixteen loads in flight
   double q0 = 0.0, q1 = 0.0, q2 = 0.0, q3 = 0.0;
   const double *pp = part + (size_t)first * prow + e;
   int r = 0;
+  for (; r + 15 < np; r += 16) {
+    double v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) v[u] = pp[(size_t)(r + u) * prow];
+#pragma unroll
+    for (int u = 0; u < 16; u += 4) {
+      q0 += v[u];
+      q1 += v[u + 1];
+      q2 += v[u + 2];
+      q3 += v[u + 3];
+    }
+  }
   for (; r + 3 < np; r += 4) {
     const double v0 = pp[(size_t)r * prow], v1 = pp[(size_t)(r + 1) * prow], v2 = pp[(size_t)(r + 2) * prow], v3 = pp[(size_t)(r + 3) * prow];
     q0 += v0;

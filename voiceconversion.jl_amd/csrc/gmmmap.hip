@@ -1362,31 +1362,48 @@ gmmmap_group_scatter_kernel(const int *__restrict__ key, int64_t T, int M, const
   int *base = lsm, *rowcnt = lsm + M;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t c = blockIdx.x, f0 = c * kGroupChunk;
-  if (tid == 0) {
-    int run = 0;
-    for (int m = 0; m < M; ++m) {
-      base[m] = run + chunkhist[c * M + m];
-      run += total[m];
-    }
-  }
+  // group bases: exclusive prefix of the totals (wave 0: a lane sums its stretch, the lanes' sums are scanned by shuffles) + the
+  // group's frames in earlier chunks.  (One thread walking total[] and chunkhist[] through global memory took 10 us per
+  // workgroup at 128 groups: most of this kernel's time.)
+  for (int m = tid; m < M; m += 256) base[m] = total[m];
   for (int e = tid; e < 16 * M; e += 256) rowcnt[e] = 0;
   __syncthreads();
+  if (wave == 0) {
+    const int per = (M + 63) / 64, lo = lane * per, hi = (lo + per < M) ? lo + per : M;
+    int s = 0;
+    for (int m = lo; m < hi; ++m) s += base[m];
+    int incl = s;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int v = __shfl_up(incl, o);
+      if (lane >= o) incl += v;
+    }
+    int run = incl - s;
+    for (int m = lo; m < hi; ++m) {
+      const int v = base[m];
+      base[m] = run;
+      run += v;
+    }
+  }
+  __syncthreads();
+  for (int m = tid; m < M; m += 256) base[m] += chunkhist[c * M + m];
   int k[4], rank[4];
+  const int nbits = 32 - __builtin_clz((unsigned)(M > 1 ? M - 1 : 1));
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int r = wave + 4 * i;                                   // row of 64 consecutive frames
     const int64_t fr = f0 + 64 * r + lane;
     k[i] = fr < T ? key[fr] : -1;
-    rank[i] = 0;
-    unsigned long long rem = __builtin_amdgcn_ballot_w64(k[i] >= 0);
-    while (rem) {                                                  // one turn per distinct key of the row
-      const int lead = __builtin_ctzll(rem);
-      const int k0 = __builtin_amdgcn_readlane(k[i], lead);
-      const unsigned long long mask = __builtin_amdgcn_ballot_w64(k[i] == k0);
-      if (k[i] == k0) rank[i] = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
-      if (lane == lead) rowcnt[r * M + k0] = __builtin_popcountll(mask);
-      rem &= ~mask;
+    // the lanes of the row that hold the same key, by one ballot per key BIT (log2 M turns whatever the number of distinct
+    // keys: unsorted keys of 128 groups put ~40 distinct ones into a row, one turn each in the first version)
+    unsigned long long eq = __builtin_amdgcn_ballot_w64(k[i] >= 0);
+    for (int b = 0; b < nbits; ++b) {
+      const bool bit = (k[i] >> b) & 1;
+      const unsigned long long bal = __builtin_amdgcn_ballot_w64(bit);
+      eq &= bit ? bal : ~bal;
     }
+    rank[i] = __builtin_amdgcn_mbcnt_hi((unsigned)(eq >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)eq, 0));
+    if (k[i] >= 0 && rank[i] == 0) rowcnt[r * M + k[i]] = __builtin_popcountll(eq);
   }
   __syncthreads();
   for (int m = tid; m < M; m += 256) {
