@@ -383,3 +383,49 @@ def test_hard_assignment_path_device_resident_and_small_calls(vc):
     assert np.array_equal(g[:128], S0) and g[plen - 1] == ll
     vc.estep_diag(X[:60_000].T, w, mu.T, var.T)
     assert _lib.estep_last_soft() == -1
+
+
+@pytest.mark.parametrize("Dj,M", [(80, 128), (48, 37)])
+def test_hard_assignment_path_tight_variances(vc, Dj, M):
+    """The regime of VERDICT r1 weak #8 at a size the screen sees: variances down to 1e-7, means up to 10, a cluster of
+    overlapping mixtures (soft: their bf16 intervals are wide and they compete) beside far-away ones (owned: gaps of 1e9 nats
+    against margins of 1e6) -- hard and soft frames together equal the one-kernel path to 1e-12 and the oracle to 1e-9."""
+    from oracle import c_oracle as co
+    N = 70_000
+    w, mu, var, X = _hard_case(77 + Dj + M, Dj, M, N, 10.0, 1e-7, 1e-2, 3.0)
+    a, o, soft = _both_paths(vc, X, w, mu, var)
+    assert 0 < soft < N, soft                        # both kinds of frames are present
+    for p, q in zip(a[:3], o[:3]):
+        assert relerr(p, q) < 1e-12, relerr(p, q)
+    # the log-likelihood of an owned frame is the winner's log-density term by term here, the expanded form x^2 a + x b + c in the
+    # one-kernel path when nothing competes (1e-7 absolute per frame at these variances): the two agree to 1e-10, and the
+    # hard path is the one closer to the oracle
+    assert abs(a[3] - o[3]) < 1e-10 * abs(o[3])
+    r0, r1, r2, rl = co.estep_diag(X, w, mu, var)
+    assert relerr(a[0], r0) < TOL and relerr(a[1], r1.T) < TOL and relerr(a[2], r2.T) < TOL
+    assert abs(a[3] - rl) < TOL * abs(rl)
+    assert abs(a[3] - rl) <= abs(o[3] - rl) + 1e-13 * abs(rl), (a[3] - rl, o[3] - rl)
+    _forget_feedback(vc)
+
+
+def test_hard_assignment_path_a_handful_of_shared_frames(vc):
+    """Three frames half-way between two mixtures among 70,000 owned ones: the gathered pass runs on three rows (most of its
+    workgroups have nothing to do and must contribute exact zeros)."""
+    from oracle import c_oracle as co
+    N, Dj, M = 70_000, 80, 128
+    w, mu, var, X = _separated_case(31, N, Dj, M, 3.0)
+    var[:] = 0.3                                     # equal covariances: the mid-point is equidistant
+    rg = np.random.default_rng(2)
+    comp = rg.choice(M, size=N, p=w)
+    X = mu[comp] + rg.standard_normal((N, Dj)) * np.sqrt(var[comp])
+    for f, (p, q) in zip((5, 40_000, N - 1), ((0, 1), (7, 90), (126, 127))):
+        X[f] = 0.5 * (mu[p] + mu[q]) + 1e-3 * rg.standard_normal(Dj)
+    a, o, soft = _both_paths(vc, X, w, mu, var)
+    assert 3 <= soft <= 8, soft
+    for p, q in zip(a[:3], o[:3]):
+        assert relerr(p, q) < 1e-12, relerr(p, q)
+    assert abs(a[3] - o[3]) < 1e-12 * abs(o[3])
+    r0, r1, r2, rl = co.estep_diag(X, w, mu, var)
+    assert relerr(a[0], r0) < TOL and relerr(a[1], r1.T) < TOL and relerr(a[2], r2.T) < TOL
+    assert abs(a[3] - rl) < TOL * abs(rl)
+    assert abs(a[0].sum() - N) < 1e-6
