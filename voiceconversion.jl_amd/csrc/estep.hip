@@ -657,6 +657,7 @@ struct EstepScratch {
   bool soft_pending = false;
   int64_t soft_N = 0;
   int hard_skip = 0;                           // calls left on the one-kernel path
+  int hard_backoff = 15;                       // ... the next pause, should the next look find mostly shared frames again
   bool last_hard = false;                      // the last diagonal E-step of this thread took the hard-assignment path
   ~EstepScratch() {
     if (h_soft) (void)hipHostFree(h_soft);
@@ -770,11 +771,19 @@ static int estep_mfma_launch(EstepScratch &sc, const double *dX, int64_t N, int 
     static constexpr int64_t kHardMinFrames = 65536;
     if (sc.soft_pending && hipEventQuery(sc.soft_ev) == hipSuccess) {          // what the previous call found
       sc.soft_pending = false;
-      if (sc.h_soft && (double)*sc.h_soft > 0.25 * (double)sc.soft_N) sc.hard_skip = 15;      // mostly soft: not worth its two passes
+      // mostly soft: not worth its two passes -- 15 calls on the one-kernel path, then another look; every look in a row that
+      // finds the same doubles the pause (31, 63, ... 255: an EM run on a model that shares its frames pays < 1 % for looking)
+      if (sc.h_soft && (double)*sc.h_soft > 0.25 * (double)sc.soft_N) {
+        sc.hard_skip = sc.hard_backoff;
+        sc.hard_backoff = std::min(2 * sc.hard_backoff + 1, 255);
+      } else {
+        sc.hard_backoff = 15;
+      }
     }
     if (debug_flag(kDbgEstepNoHard)) {                                         // (tests: the flag also forgets the feedback)
       sc.soft_pending = false;
       sc.hard_skip = 0;
+      sc.hard_backoff = 15;
     }
     const bool hard_on = N >= kHardMinFrames && N < ((int64_t)1 << 31) && !debug_flag(kDbgEstepNoHard);
     sc.last_hard = false;
