@@ -643,22 +643,43 @@ def bench_convert(args, world, rank, variant="synthetic"):
 
 
 # --------------------------------------------------------------------------------------------- E-step
-def bench_estep(args, world, rank):
+def bench_estep(args, world, rank, variant="synthetic"):
     """BASELINE configs[2]: diagonal E-step, Dj=80, M=128, N=10^7 frames over 8 GPUs -> 1.25e6 frames per GPU
-    (weak scaling), followed by ONE all-reduce of the packed statistics over RCCL."""
+    (weak scaling), followed by ONE all-reduce of the packed statistics over RCCL.
+    variant "fixture": the same call on frames that SHARE their mixtures -- drawn from the reference's trained joint model
+    (test/models/clb_and_slt_gmm32_order40.jld, full covariances), E-step of the diagonal model with its means and variances
+    (M = 32): what a train_gmm run on real joint mel-cepstra looks like to the kernel."""
     import torch
 
     import voiceconversion_jl_amd as vc
     import synthdata as npo
 
     Dj, M, N = args.dj, args.mixtures, args.frames if args.frames != 1_000_000 else 1_250_000
-    w, mu, _ = npo.synth_model(1003, Dj, M)
-    var = np.exp(np.random.default_rng(1003).uniform(np.log(1e-3), 0.0, (M, Dj)))   # the model: same on every rank
+    if variant == "fixture":
+        z = np.load(os.path.join(ROOT, "tests", "golden", "model_clb_and_slt_gmm32_order40.npz"))
+        w, mu, sig = z["weights"] / z["weights"].sum(), np.ascontiguousarray(z["means"]), z["covars"]
+        M, Dj = mu.shape
+        var = np.ascontiguousarray(np.stack([np.diag(sig[m]) for m in range(M)]))
+        chol = np.linalg.cholesky(sig)
 
-    def shard_frames(r):                             # rank r's frames, drawn from the model
-        rg = np.random.default_rng(2003 + r)
-        comp = rg.choice(M, size=N, p=w)
-        return mu[comp] + rg.standard_normal((N, Dj)) * np.sqrt(var[comp])
+        def shard_frames(r):                         # rank r's frames, drawn from the FULL-covariance model
+            rg = np.random.default_rng(2003 + r)
+            comp = np.sort(rg.choice(M, size=N, p=w))
+            X = np.empty((N, Dj))
+            lo = 0
+            for m in range(M):
+                n = int(np.searchsorted(comp, m, side="right")) - lo
+                X[lo:lo + n] = mu[m] + rg.standard_normal((n, Dj)) @ chol[m].T
+                lo += n
+            return X[rg.permutation(N)]
+    else:
+        w, mu, _ = npo.synth_model(1003, Dj, M)
+        var = np.exp(np.random.default_rng(1003).uniform(np.log(1e-3), 0.0, (M, Dj)))   # the model: same on every rank
+
+        def shard_frames(r):                         # rank r's frames, drawn from the model
+            rg = np.random.default_rng(2003 + r)
+            comp = rg.choice(M, size=N, p=w)
+            return mu[comp] + rg.standard_normal((N, Dj)) * np.sqrt(var[comp])
 
     X = shard_frames(rank)
     Xd = torch.from_numpy(X).cuda()
@@ -717,7 +738,8 @@ def bench_estep(args, world, rank):
     out = {"metric": "diag-GMM E-step frames/sec (Dj=%d, M=%d)" % (Dj, M), "value": fps, "unit": "frames/s", "n_gpus": world,
            "steps": args.steps, "warmup": args.warmup, "steady": clock_warm, "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True,
            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-           "config": {"workload": "diag E-step (BASELINE configs[2])" if (Dj == 80 and M == 128) else
+           "config": {"workload": "diag E-step on frames drawn from the reference's trained model clb_and_slt_gmm32_order40 (M = 32; not a BASELINE config)"
+                      if variant == "fixture" else "diag E-step (BASELINE configs[2])" if (Dj == 80 and M == 128) else
                       f"diag E-step, Dj={Dj}, M={M} ({'MFMA kernel' if mfma_path else 'generic kernels'}; not a BASELINE config)",
                       "Dj": Dj, "M": M, "frames_per_gpu": N,
                       "collective": "all-reduce(sum) of %d doubles per step" % vc.stats_len(Dj, M)},
@@ -745,8 +767,10 @@ def bench_estep(args, world, rank):
                            "fp64_formulation_note": "flops of the one-kernel formulation over this step's time; owned frames never reach the FP64 pipe",
                            "mfma_issued_per_step": issued_mfma, "algorithmic_bytes_per_frame": 8 * Dj}
         prefixes = ("estep_hard", "gmmmap_group_sc", "estep_mfma_kernel")
-    attach_traffic(out, "estep_traffic.json", prefixes, standard=(N == 1_250_000 and Dj == 80 and M == 128),
-                   live=LIVE_PMC.get("estep"), algorithmic_bytes=8.0 * Dj * N)
+    out["config"]["soft_frames_of_last_step"] = soft          # -1: the one-kernel path ran (the hard-assignment path looked and stepped aside)
+    attach_traffic(out, "estep_fixture_traffic.json" if variant == "fixture" else "estep_traffic.json", prefixes,
+                   standard=(N == 1_250_000 and Dj == 80 and M == (32 if variant == "fixture" else 128)),
+                   live=LIVE_PMC.get("estep_fixture" if variant == "fixture" else "estep"), algorithmic_bytes=8.0 * Dj * N)
     if rank == 0 and not args.profile_run:       # (the parity sample launches the kernel once more)
         from oracle import c_oracle as co
 
@@ -1332,7 +1356,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="all",
-                    choices=["all", "convert", "convert_fixture", "convert_joint", "convert_broad", "estep", "estep_full", "em_full", "dtw", "traj", "trajgv",
+                    choices=["all", "convert", "convert_fixture", "convert_joint", "convert_broad", "estep", "estep_fixture", "estep_full", "em_full", "dtw", "traj", "trajgv",
                              "selftest"],
                     help="all (default): the headline line of configs[1] plus a `workloads` table over configs[1..4]")
     ap.add_argument("--dim", type=int, default=40, help="dtw: feature dimension (40 = BASELINE; 41 = order-40 mel-cepstra with c0)")
@@ -1396,6 +1420,7 @@ def main():
            "convert_fixture": lambda a, w, r: bench_convert(a, w, r, variant="fixture"),
            "convert_broad": lambda a, w, r: bench_convert(a, w, r, variant="broad"),
            "convert_joint": lambda a, w, r: bench_convert(a, w, r, variant="joint"),
+           "estep_fixture": lambda a, w, r: bench_estep(a, w, r, variant="fixture"),
            "selftest": bench_selftest}
     if args.workload == "all":
         import copy
@@ -1407,7 +1432,7 @@ def main():
         table = {"convert": summarize(out)}
         sub = copy.copy(args)
         sub.cpu_seconds = args.cpu_seconds_sub
-        for name in ("convert_fixture", "convert_broad", "estep", "dtw", "traj"):
+        for name in ("convert_fixture", "convert_broad", "estep", "estep_fixture", "dtw", "traj"):
             gc.collect()
             torch.cuda.empty_cache()
             PER_RANK.clear()

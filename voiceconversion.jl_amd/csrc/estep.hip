@@ -232,7 +232,8 @@ struct EstepCfg {
   // the epilogue aliases the l/gamma area
   // + the 2^(j/64) table of vc_exp_tab (64 doubles) + step B's frame order: winning tile per frame (FB ints) and one
   // permutation per wave (8 x FB ints)
-  static constexpr size_t LDS_BYTES = ((size_t)2 * XBUF + (size_t)FB * RSG + 64) * sizeof(double) + (size_t)9 * FB * sizeof(int);
+  // + the refinement thresholds of the 128 mixture slots (see estep_prep_kernel)
+  static constexpr size_t LDS_BYTES = ((size_t)2 * XBUF + (size_t)FB * RSG + 64 + MMAX) * sizeof(double) + (size_t)9 * FB * sizeof(int);
   static_assert(RSX >= DJ + 2 && RSX % 2 == 0, "row stride");
   static_assert(LDS_BYTES <= 160 * 1024, "LDS");
 };
@@ -281,7 +282,9 @@ estep_mfma_kernel(const double *__restrict__ X, int64_t N, int M, const double *
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lcol = lane & 15, lgrp = lane >> 4;
-  int *fkey = reinterpret_cast<int *>(etab + 64);   // [FB] winning tile of each frame (softmax phase)
+  double *tthr = etab + 64;                         // [MMAX] refinement thresholds (refc[2 m + 1]; -inf: the expanded form is always good enough)
+  if (kGamma && threadIdx.x < C::MMAX) tthr[threadIdx.x] = ((int)threadIdx.x < M) ? refc[2 * threadIdx.x + 1] : -INFINITY;
+  int *fkey = reinterpret_cast<int *>(tthr + C::MMAX);   // [FB] winning tile of each frame (softmax phase)
   int *fperm = fkey + FB + wave * FB;               // [FB] this wave's copy of the grouped order
   constexpr bool kSortB = (PHASE == 0);
   const int tile = SHARE ? (wave & (mtp - 1)) : wave, sub = SHARE ? wave / mtp : 0, wpt = SHARE ? 8 / mtp : 1;      // mixture tile, position among the tile's waves
@@ -433,7 +436,11 @@ estep_mfma_kernel(const double *__restrict__ X, int64_t N, int M, const double *
 #pragma unroll 1
             for (int i = 0; i < mtp; ++i) {
               const double li = row[16 * i];
-              if (li > thr) {
+              // ... unless the expanded form is provably good enough for this (frame, mixture): li >= the mixture's threshold
+              // (estep_prep_kernel: an error bound of 1e-10 from the value itself -- models with ordinary variances, the
+              // reference's trained ones among them, never take the loop below; the first version did for every competing
+              // pair: 3.8 ms instead of 1.3 per 1.25e6 frames that share their mixtures)
+              if (li > thr && li < tthr[lcol + 16 * i]) {
                 const int m = lcol + 16 * i;
                 const double *mp = refmu + (size_t)dj * m, *ip = refiv + (size_t)dj * m;
                 double q = 0.0;
@@ -442,7 +449,7 @@ estep_mfma_kernel(const double *__restrict__ X, int64_t N, int M, const double *
                   const double df = xf[d] - mp[d];
                   q = fma(df * df, ip[d], q);
                 }
-                row[16 * i] = refc[m] - 0.5 * q;
+                row[16 * i] = refc[2 * m] - 0.5 * q;
               }
             }
             u = -INFINITY;
@@ -656,12 +663,18 @@ struct EstepScratch {
   hipEvent_t soft_ev = nullptr;
   bool soft_pending = false;
   int64_t soft_N = 0;
-  int hard_skip = 0;                           // calls left on the one-kernel path
-  int hard_backoff = 15;                       // ... the next pause, should the next look find mostly shared frames again
+  int hard_mode = 1;                           // 1: the hard-assignment path (optimistic start), 0: the one-kernel path + sampled looks
+  int probe_tick = 0;                          // calls in mode 0 (a sampled look every fourth)
+  int *h_probe = nullptr;                      // pinned [2]: frames of the sample without an owner, frames of the sample
+  hipEvent_t probe_ev = nullptr;
+  bool probe_pending = false;
+  DevBuf<int> probe;                           // sample histograms + the two sums
   bool last_hard = false;                      // the last diagonal E-step of this thread took the hard-assignment path
   ~EstepScratch() {
     if (h_soft) (void)hipHostFree(h_soft);
     if (soft_ev) (void)hipEventDestroy(soft_ev);
+    if (h_probe) (void)hipHostFree(h_probe);
+    if (probe_ev) (void)hipEventDestroy(probe_ev);
   }
   EstepStaging stage;
   StreamOrder order;   // calls of one thread on different streams share the buffers above
@@ -720,7 +733,18 @@ estep_prep_kernel(const double *__restrict__ raw, int M, int dj, double *__restr
     }
     if (l == 0) {
       const double base = (m < M) ? (w[m] > 0.0 ? log(w[m]) : -INFINITY) - 0.5 * (dj * kLog2Pi + sl) : -INFINITY;
-      if (m < M) refc[m] = base;            // the constant WITHOUT the -mu^2/(2 var) term (exact re-evaluation)
+      if (m < M) {
+        refc[2 * m] = base;                 // the constant WITHOUT the -mu^2/(2 var) term (exact re-evaluation)
+        // When is the expanded form  l^ = sum_d (a_d x_d^2 + b_d x_d) + cinit  good enough?  Its rounding error is at most
+        // (2 dj + 6) u T,  T = sum_d |a_d x_d^2| + |b_d x_d| + |cinit|  (u = 2^-53; the accumulation, the rounded operands, x^2).
+        // With A = sum x^2/var, C = sum mu^2/var (`t` above) and q = sum (x - mu)^2/var = 2 (base - l):  sum |a x^2| = A / 2,
+        // sum |b x| <= sqrt(A C), sqrt(A) <= sqrt(q) + sqrt(C)  =>  T <= (sqrt(q) + 2 sqrt(C))^2 / 2 + |base| <= q + 4 C + |base|.
+        // The error stays below 1e-10 (tests: statistics to 1e-9) when q + 4 C + |base| <= Tmax = 1e-10 / ((2 dj + 6) u), i.e. when
+        //   l >= base - (Tmax - 4 C - |base|) / 2   =: the threshold -- above `base` (never reached) for the tight-variance models
+        // the re-evaluation exists for, far below any competing value for ordinary ones.
+        const double tmax = 1e-10 / ((2.0 * dj + 6.0) * 0x1p-53);
+        refc[2 * m + 1] = base > -INFINITY ? base - 0.5 * (tmax - 4.0 * t - fabs(base)) : -INFINITY;
+      }
       cinit[m] = (m < M) ? base - 0.5 * t : -INFINITY;
     }
   }
@@ -742,7 +766,7 @@ static int estep_mfma_launch(EstepScratch &sc, const double *dX, int64_t N, int 
   VCMI_TRY(sc.Wpack.reserve((size_t)8 * C::KS * 64));
   VCMI_TRY(sc.cinit.reserve((size_t)C::MMAX));
   VCMI_TRY(sc.refiv.reserve((size_t)M * dj));
-  VCMI_TRY(sc.refc.reserve((size_t)M));
+  VCMI_TRY(sc.refc.reserve((size_t)2 * M));
   // mixture tiles of 16, rounded up to a power of two: 8 / mtp waves share a tile and each writes its own partial row
   int mtp = 1;
   while (16 * mtp < M) mtp *= 2;
@@ -769,26 +793,53 @@ static int estep_mfma_launch(EstepScratch &sc, const double *dX, int64_t N, int 
   if constexpr (!C::SPLIT) {
     // ---- frames that one mixture owns never see an FP64 MFMA (estep_hard.hpp); the rest goes on below, gathered ----
     static constexpr int64_t kHardMinFrames = 65536;
-    if (sc.soft_pending && hipEventQuery(sc.soft_ev) == hipSuccess) {          // what the previous call found
+    // Which path?  The hard-assignment path pays where most frames have an owner and costs an E-step and a half where they
+    // do not (real joint mel-cepstra: DESIGN 3.3).  It starts optimistic; its own count of shared frames (a 4-byte download
+    // behind an event, never waited for) sends the thread to the one-kernel path when more than a quarter were shared; there,
+    // every fourth call first runs the screen on a SAMPLE of 16 chunks spread over the frames (~20 us) and a later call
+    // switches back when the sample found owners for three quarters of its frames.
+    if (sc.soft_pending && hipEventQuery(sc.soft_ev) == hipSuccess) {          // what the previous hard-path call found
       sc.soft_pending = false;
-      // mostly soft: not worth its two passes -- 15 calls on the one-kernel path, then another look; every look in a row that
-      // finds the same doubles the pause (31, 63, ... 255: an EM run on a model that shares its frames pays < 1 % for looking)
-      if (sc.h_soft && (double)*sc.h_soft > 0.25 * (double)sc.soft_N) {
-        sc.hard_skip = sc.hard_backoff;
-        sc.hard_backoff = std::min(2 * sc.hard_backoff + 1, 255);
-      } else {
-        sc.hard_backoff = 15;
-      }
+      sc.hard_mode = (sc.h_soft && (double)*sc.h_soft > 0.25 * (double)sc.soft_N) ? 0 : 1;
     }
-    if (debug_flag(kDbgEstepNoHard)) {                                         // (tests: the flag also forgets the feedback)
+    if (sc.probe_pending && hipEventQuery(sc.probe_ev) == hipSuccess) {        // what the last sampled look found
+      sc.probe_pending = false;
+      if (sc.h_probe[1] > 0 && (double)sc.h_probe[0] <= 0.25 * (double)sc.h_probe[1]) sc.hard_mode = 1;
+    }
+    if (debug_flag(kDbgEstepNoHard)) {                                         // (tests: the flag also forgets what was learnt)
       sc.soft_pending = false;
-      sc.hard_skip = 0;
-      sc.hard_backoff = 15;
+      sc.probe_pending = false;
+      sc.hard_mode = 1;
+      sc.probe_tick = 0;
     }
     const bool hard_on = N >= kHardMinFrames && N < ((int64_t)1 << 31) && !debug_flag(kDbgEstepNoHard);
     sc.last_hard = false;
-    if (hard_on && sc.hard_skip > 0) --sc.hard_skip;
-    else if (hard_on) {
+    if (hard_on && sc.hard_mode == 0) {
+      if (!sc.probe_pending && (sc.probe_tick++ & 3) == 0) {
+        using CH = EstepHardCfg<DJ>;
+        const int MT = (M + 15) / 16, MK = M + 1;
+        const int64_t nchunks = (N + kGroupChunk - 1) / kGroupChunk, nsample = std::min<int64_t>(16, nchunks), cstride = nchunks / nsample;
+        VCMI_TRY(sc.W16.reserve((size_t)MT * CH::TILE_BYTES));
+        VCMI_TRY(sc.probe.reserve((size_t)nsample * MK + 2));
+        if (!sc.h_probe) {
+          VCMI_HIP(hipHostMalloc(reinterpret_cast<void **>(&sc.h_probe), 2 * sizeof(int), hipHostMallocDefault));
+          VCMI_HIP(hipEventCreateWithFlags(&sc.probe_ev, hipEventDisableTiming));
+        }
+        hipLaunchKernelGGL(estep_hard_prep_kernel<DJ>, dim3((unsigned)((MT * CH::NI * 64 + 255) / 256 + 4 * MT)), dim3(256), 0, st, draw, sc.cinit.p,
+                           M, dj, sc.W16.p);
+        const size_t kshmem = CH::lds_bytes(MT) + (size_t)MK * sizeof(int);
+        auto kk = estep_hard_key_kernel<DJ>;
+        VCMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kshmem));
+        hipLaunchKernelGGL(kk, dim3((unsigned)nsample), dim3(kHardKeyThreads), kshmem, st, sc.W16.p, M, dj, dX, N, (int *)nullptr, sc.probe.p, nsample,
+                           cstride);
+        hipLaunchKernelGGL(estep_hard_probe_sum_kernel, dim3(1), dim3(64), 0, st, sc.probe.p, (int)nsample, MK, sc.probe.p + nsample * MK);
+        VCMI_HIP(hipGetLastError());
+        VCMI_HIP(hipMemcpyAsync(sc.h_probe, sc.probe.p + nsample * MK, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
+        VCMI_HIP(hipEventRecord(sc.probe_ev, st));
+        sc.probe_pending = true;
+      }
+    }
+    else if (hard_on) {      // (hard_mode == 1)
       using CH = EstepHardCfg<DJ>;
       const int MT = (M + 15) / 16, MK = M + 1;
       const int64_t nchunks = (N + kGroupChunk - 1) / kGroupChunk, npmax = (N + kHardPiece - 1) / kHardPiece + M, prow = 2 * (int64_t)dj + 2;
@@ -809,7 +860,7 @@ static int estep_mfma_launch(EstepScratch &sc, const double *dX, int64_t N, int 
       auto kk = estep_hard_key_kernel<DJ>;
       VCMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kshmem));
       hipLaunchKernelGGL(kk, dim3((unsigned)std::min<int64_t>(nchunks, (int64_t)cus)), dim3(kHardKeyThreads), kshmem, st, sc.W16.p, M, dj, dX, N, key,
-                         chunkhist);
+                         chunkhist, nchunks, (int64_t)1);
       hipLaunchKernelGGL(gmmmap_group_scan_kernel, dim3((unsigned)MK), dim3(256), 0, st, chunkhist, nchunks, MK, total);
       hipLaunchKernelGGL(gmmmap_group_scatter_kernel, dim3((unsigned)nchunks), dim3(256), (size_t)17 * MK * sizeof(int), st, key, N, MK,
                          chunkhist, total, perm);
@@ -902,7 +953,7 @@ static int estep_mfma_groups_launch(EstepScratch &sc, const double *dX, int64_t 
   VCMI_TRY(sc.Wpack.reserve(wlen * ng));
   VCMI_TRY(sc.cinit.reserve((size_t)C::MMAX * ng));
   VCMI_TRY(sc.refiv.reserve((size_t)M * dj));
-  VCMI_TRY(sc.refc.reserve((size_t)M));
+  VCMI_TRY(sc.refc.reserve((size_t)2 * M));
   VCMI_TRY(sc.G.reserve((size_t)ng * chunk * C::MMAX));
   VCMI_TRY(sc.LSE.reserve((size_t)ng * chunk + kCombineGrid));
   VCMI_TRY(sc.part.reserve((size_t)cus * ((size_t)C::MMAX * (1 + 2 * dj) + 1)));
@@ -927,7 +978,7 @@ static int estep_mfma_groups_launch(EstepScratch &sc, const double *dX, int64_t 
   for (int g = 0; g < ng; ++g) {
     const int m0 = g * C::MMAX, Mg = std::min(C::MMAX, M - m0);
     hipLaunchKernelGGL(estep_prep_kernel<DJ>, dim3((unsigned)((wlen + 255) / 256)), dim3(256), 0, st, draw + goff[(size_t)g], Mg, dj,
-                       sc.Wpack.p + wlen * g, sc.cinit.p + (size_t)C::MMAX * g, sc.refiv.p + (size_t)m0 * dj, sc.refc.p + m0);
+                       sc.Wpack.p + wlen * g, sc.cinit.p + (size_t)C::MMAX * g, sc.refiv.p + (size_t)m0 * dj, sc.refc.p + 2 * m0);
   }
   VCMI_HIP(hipGetLastError());
   auto k3 = estep_mfma_kernel<DJ, 3, false>;
@@ -942,7 +993,7 @@ static int estep_mfma_groups_launch(EstepScratch &sc, const double *dX, int64_t 
       const int m0 = g * C::MMAX, Mg = std::min(C::MMAX, M - m0);
       hipLaunchKernelGGL(k3, dim3(g2), dim3(512), C::LDS_BYTES, st, dX + n0 * dj, nfr, Mg, sc.Wpack.p + wlen * g,
                          sc.cinit.p + (size_t)C::MMAX * g, sc.LSE.p + (size_t)g * nfr, (int64_t)0, draw + goff[(size_t)g] + Mg,
-                         sc.refiv.p + (size_t)m0 * dj, sc.refc.p + m0, sc.G.p + (size_t)g * chunk * C::MMAX, dj, 8, sc.mfma_count.p, (const int64_t *)nullptr);
+                         sc.refiv.p + (size_t)m0 * dj, sc.refc.p + 2 * m0, sc.G.p + (size_t)g * chunk * C::MMAX, dj, 8, sc.mfma_count.p, (const int64_t *)nullptr);
     }
     hipLaunchKernelGGL(estep_group_combine_kernel, dim3(kCombineGrid), dim3(256), 0, st, sc.G.p, sc.LSE.p, ng, nfr,
                        (int64_t)chunk * C::MMAX, llpart);

@@ -94,7 +94,9 @@ constexpr int kHardKeyThreads = 1024;     // one workgroup per CU (the operands 
 template <int DJ>
 __global__ void __launch_bounds__(kHardKeyThreads)
 estep_hard_key_kernel(const unsigned char *__restrict__ W16, int M, int dj, const double *__restrict__ X, int64_t N,
-                      int *__restrict__ key, int *__restrict__ chunkhist) {
+                      int *__restrict__ key, int *__restrict__ chunkhist, int64_t nrun, int64_t cstride) {
+  // nrun chunks are looked at, chunk c of the run = chunk c * cstride of the frames: all of them (cstride = 1), or a SAMPLE
+  // spread over the frames (key = nullptr: only the histograms are wanted -- estep_hard_probe_sum_kernel)
   using C = EstepHardCfg<DJ>;
   constexpr int NI = C::NI;
   extern __shared__ double hsm[];
@@ -116,12 +118,11 @@ estep_hard_key_kernel(const unsigned char *__restrict__ W16, int M, int dj, cons
     nwmax = fmaxf(nwmax, __shfl_xor(nwmax, sh));
     ncmax = fmaxf(ncmax, __shfl_xor(ncmax, sh));
   }
-  const int64_t nchunks = (N + kGroupChunk - 1) / kGroupChunk;
-  for (int64_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
+  for (int64_t c = blockIdx.x; c < nrun; c += gridDim.x) {
     for (int m = tid; m < MK; m += kHardKeyThreads) hist[m] = 0;
     __syncthreads();
     for (int it = 0; it < kGroupChunk / (16 * (kHardKeyThreads / 64)); ++it) {
-      const int64_t fr = c * kGroupChunk + 16 * ((kHardKeyThreads / 64) * it + wave) + lcol;
+      const int64_t fr = c * cstride * kGroupChunk + 16 * ((kHardKeyThreads / 64) * it + wave) + lcol;
       if (fr - lcol >= N) break;                                    // (wave-uniform)
       // B operands: slot j < 4: x^2, j >= 4: x, of dimensions 16 i + 4 g + (j & 3); and |[x^2 ; x]|^2
       u32x4_t bh[NI], bl[NI];
@@ -204,13 +205,32 @@ estep_hard_key_kernel(const unsigned char *__restrict__ W16, int M, int dj, cons
         // -745.2; the margin also covers the 1e-7 the one-kernel path's own log-densities may be off), and the best is finite
         const bool hard = bm < M && blo > -1e29f && hi2 < blo - 746.0f;
         const int k = hard ? bm : M;
-        key[fr] = k;
+        if (key) key[fr] = k;
         atomicAdd(&hist[k], 1);
       }
     }
     __syncthreads();
     for (int m = tid; m < MK; m += kHardKeyThreads) chunkhist[c * MK + m] = hist[m];
     __syncthreads();
+  }
+}
+
+// the sampled look: out[0] = frames of the sample without an owner, out[1] = frames of the sample
+__global__ void estep_hard_probe_sum_kernel(const int *__restrict__ chunkhist, int nsample, int MK, int *__restrict__ out) {
+  int soft = 0, all = 0;
+  for (int e = threadIdx.x; e < nsample * MK; e += 64) {
+    const int v = chunkhist[e];
+    all += v;
+    soft += (e % MK == MK - 1) ? v : 0;
+  }
+#pragma unroll
+  for (int sh = 1; sh < 64; sh <<= 1) {
+    soft += __shfl_xor(soft, sh);
+    all += __shfl_xor(all, sh);
+  }
+  if (threadIdx.x == 0) {
+    out[0] = soft;
+    out[1] = all;
   }
 }
 
@@ -339,7 +359,7 @@ estep_hard_reduce_kernel(const double *__restrict__ part, int64_t prow, const in
   if (e == 0) stats[m] = s;
   else if (e <= dj) stats[M + (size_t)m * dj + (e - 1)] = s;
   else if (e <= 2 * dj) stats[M + (size_t)M * dj + (size_t)m * dj + (e - 1 - dj)] = s;
-  else llm[m] = np > 0 ? (double)tot[m] * refc[m] - 0.5 * s : 0.0;
+  else llm[m] = np > 0 ? (double)tot[m] * refc[2 * m] - 0.5 * s : 0.0;
 }
 // the hard frames' log-likelihood (mixtures in order) into the statistics' last element; the soft frames' is added by the
 // one-kernel path's reduction afterwards

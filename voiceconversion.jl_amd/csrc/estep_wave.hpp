@@ -198,7 +198,7 @@ estep_wave_kernel(const double *__restrict__ X, int64_t N, int M, const double *
                 const double df = xf[d] - mp[d];
                 q = fma(df * df, ip[d], q);
               }
-              lr[i * PROW] = refc[m] - 0.5 * q;
+              lr[i * PROW] = refc[2 * m] - 0.5 * q;
             }
           }
         }
