@@ -826,17 +826,24 @@ def full_estep_issued_mfma(step_fn, N, Dj, M):
     return logdens + int(cnt.value)
 
 
-def bench_estep_full(args, world, rank):
+def bench_estep_full(args, world, rank, variant="synthetic"):
     """full-covariance E-step (what bin/train_gmm.jl:84-103 runs), Dj=80, M=64, 5e5 frames per
     GPU (weak scaling) + ONE all-reduce of the packed statistics.  Algorithmic flops per frame: triangular
-    whitening M*Dj*(Dj+1) + symmetric-half second moments M*Dj*(Dj+1) + first moments 2*M*Dj."""
+    whitening M*Dj*(Dj+1) + symmetric-half second moments M*Dj*(Dj+1) + first moments 2*M*Dj.
+    variant "fixture": the reference's trained joint model (M = 32) and frames drawn from it -- frames that share their
+    mixtures, as in a train_gmm run on real joint mel-cepstra."""
     import torch
 
     import voiceconversion_jl_amd as vc
     import synthdata as npo
 
     Dj, M, N = args.dj, 64, args.frames if args.frames != 1_000_000 else 500_000
-    w, mu, sig = npo.synth_model(1005, Dj, M, lam_lo=1e-3)
+    if variant == "fixture":
+        z = np.load(os.path.join(ROOT, "tests", "golden", "model_clb_and_slt_gmm32_order40.npz"))
+        w, mu, sig = z["weights"] / z["weights"].sum(), np.ascontiguousarray(z["means"]), np.ascontiguousarray(z["covars"])
+        M, Dj = mu.shape
+    else:
+        w, mu, sig = npo.synth_model(1005, Dj, M, lam_lo=1e-3)
     X = npo.sample_frames(1005 + rank, w, mu, sig, N, 0, Dj)
     Xd = torch.from_numpy(X).cuda()
     out_t = torch.empty(vc.full_stats_len(Dj, M), dtype=torch.float64, device="cuda")
@@ -854,11 +861,12 @@ def bench_estep_full(args, world, rank):
     issued = full_estep_issued_mfma(step, N, Dj, M) if not args.profile_run else None
     iss_tflops = issued * MFMA_FLOP / (kernel_ms * 1e-3) / 1e12 if issued else None
     achieved = min(alg_tflops, iss_tflops) if iss_tflops else alg_tflops
-    out = {"metric": "full-covariance GMM E-step frames/sec (Dj=%d, M=64)" % Dj, "value": world * N * args.steps / wall,
+    out = {"metric": "full-covariance GMM E-step frames/sec (Dj=%d, M=%d)" % (Dj, M), "value": world * N * args.steps / wall,
            "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "steady": clock_warm,
            "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "f64", "data": "synthetic",
-           "config": {"workload": "full-covariance E-step (SURVEY 8f rank 1; bin/train_gmm.jl:84-103)", "Dj": Dj, "M": M,
+           "config": {"workload": "full-covariance E-step, the reference's trained model clb_and_slt_gmm32_order40 and frames drawn from it (M = 32)"
+                      if variant == "fixture" else "full-covariance E-step (SURVEY 8f rank 1; bin/train_gmm.jl:84-103)", "Dj": Dj, "M": M,
                       "frames_per_gpu": N,
                       "collective": "all-reduce(sum) of %d doubles per step" % vc.full_stats_len(Dj, M)},
            "roofline": {"bound": "mfma", "kernel": ("whole step: gmmmap_mfma_kernel<MODE 1> + estep_full_stats_kernel<%d,1>" % Dj) if Dj <= 80 else
@@ -869,8 +877,8 @@ def bench_estep_full(args, world, rank):
                         "issued_mfma_frac": (iss_tflops / FP64_PEAK_TFLOPS) if iss_tflops else None, "mfma_issued_per_step": issued,
                         "traffic": None,
                         "flop_per_frame": flop, "kernel_ms": kernel_ms}}
-    attach_traffic(out, "estep_full_traffic.json", ("gmmmap_mfma_kernel", "estep_full_stats_kernel", "estep_full_softmax_kernel"),
-                   standard=(N == 500_000 and Dj == 80))
+    attach_traffic(out, "estep_full_fixture_traffic.json" if variant == "fixture" else "estep_full_traffic.json",
+                   ("gmmmap_mfma_kernel", "estep_full_stats_kernel", "estep_full_softmax_kernel"), standard=(N == 500_000 and Dj == 80))
     if rank == 0 and not args.profile_run:       # (the parity sample launches the kernel once more)
         from oracle import c_oracle as co
 
@@ -1356,7 +1364,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="all",
-                    choices=["all", "convert", "convert_fixture", "convert_joint", "convert_broad", "estep", "estep_fixture", "estep_full", "em_full", "dtw", "traj", "trajgv",
+                    choices=["all", "convert", "convert_fixture", "convert_joint", "convert_broad", "estep", "estep_fixture", "estep_full", "estep_full_fixture", "em_full", "dtw", "traj", "trajgv",
                              "selftest"],
                     help="all (default): the headline line of configs[1] plus a `workloads` table over configs[1..4]")
     ap.add_argument("--dim", type=int, default=40, help="dtw: feature dimension (40 = BASELINE; 41 = order-40 mel-cepstra with c0)")
@@ -1421,6 +1429,7 @@ def main():
            "convert_broad": lambda a, w, r: bench_convert(a, w, r, variant="broad"),
            "convert_joint": lambda a, w, r: bench_convert(a, w, r, variant="joint"),
            "estep_fixture": lambda a, w, r: bench_estep(a, w, r, variant="fixture"),
+           "estep_full_fixture": lambda a, w, r: bench_estep_full(a, w, r, variant="fixture"),
            "selftest": bench_selftest}
     if args.workload == "all":
         import copy

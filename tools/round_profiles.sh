@@ -11,7 +11,7 @@ R=$GRAFT_REPO_ROOT
 out=$R/gpurun_out/$tag
 mkdir -p $out $out/pmc $out/clock
 cd /tmp && export TMPDIR=/tmp
-for spec in ${@:-convert convert_fixture convert_joint convert_broad estep estep_fixture estep_full em_full dtw dtw:d41 traj traj:chunk100 trajgv}; do
+for spec in ${@:-convert convert_fixture convert_joint convert_broad estep estep_fixture estep_full estep_full_fixture em_full dtw dtw:d41 traj traj:chunk100 trajgv}; do
   w=${spec%%:*}; var=${spec#*:}; [ "$var" = "$spec" ] && var=""
   name=$w; extra=""
   [ "$var" = d41 ] && { name=dtw_d41; extra="--dim 41"; }
