@@ -101,6 +101,18 @@ def test_the_one_stdout_line_stays_under_the_cap():
         assert {"value", "unit", "cores", "kind", "sample"} <= set(out["cpu_baseline"])
         assert set(out["summary"]) == set(full["workloads"])
         assert all("frac" in r["roofline"] and "traffic" in r["roofline"] for r in out["summary"].values())
+    # this round's record (seven workloads in the default run) at N = 1 and N = 8 as well
+    full5 = json.load(open(os.path.join(ROOT, "profiles", "r05_all_bench_detail.json")))
+    assert len(full5["workloads"]) >= 7
+    full5["detail"] = "gpurun_out/bench_detail_all_n8.json"
+    full5["n1_consistency"] = {"available": True, "n1_measured": "x", **{k: {"n1_value": 1.0, "per_rank_value": 1.0, "ratio": 1.0,
+                                                                          "within_5pct": True} for k in full5["workloads"]}}
+    full5["per_rank"] = {"wall_s": [0.033] * 8, "kernel_ms": [1.6] * 8, "first_part_ms": [0.5] * 8}
+    for n in (1, 8):
+        full5["n_gpus"] = n
+        line5 = bench.compact_line(full5, full5["workloads"])
+        assert len(line5) < bench.LINE_CAP, len(line5)
+        assert set(json.loads(line5)["summary"]) == set(full5["workloads"])
     # no prose anywhere in the line: every string value is short
     def strings(o):
         if isinstance(o, dict):
