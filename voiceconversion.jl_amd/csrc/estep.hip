@@ -1149,6 +1149,38 @@ estep_full_softmax_kernel(double *__restrict__ LP, int M, int64_t n, double *__r
   __shared__ double wsum[4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   double acc = 0.0;
+  if (M <= 32) {
+    // Small models (the reference's own: 16 mixtures by default, 32 in its trained ones): 8, 16 or 32 lanes per frame, so a
+    // wave takes 8, 4 or 2 frames per turn instead of leaving most of its lanes idle.  The butterflies over lpf lanes give
+    // the bits of the 64-lane ones (those only add the zeros of the idle lanes first).
+    const int lpf = M <= 8 ? 8 : (M <= 16 ? 16 : 32), fpw = 64 / lpf, sub = lane / lpf, sl = lane % lpf;
+    for (int64_t f0 = ((int64_t)blockIdx.x * 4 + wave) * fpw; f0 < n; f0 += (int64_t)gridDim.x * 4 * fpw) {
+      const int64_t fr = f0 + sub;
+      const bool on = fr < n && sl < M;
+      double *l = LP + (fr < n ? fr : n - 1) * M;
+      const double lv = on ? l[sl] : -INFINITY;
+      double u = lv;
+      for (int o = lpf / 2; o >= 1; o >>= 1) u = fmax(u, __shfl_xor(u, o));
+      double sm = on ? exp(lv - u) : 0.0;
+      for (int o = lpf / 2; o >= 1; o >>= 1) sm += __shfl_xor(sm, o);
+      const double ls = u + log(sm);
+      unsigned bits = 0;
+      if (on) {
+        const double gm = exp(lv - ls);
+        l[sl] = gm;
+        if (gm != 0.0) bits = 1u << ((sl / nm) & 31);
+      }
+      if (fmask) {
+        for (int o = lpf / 2; o >= 1; o >>= 1) bits |= (unsigned)__shfl_xor((int)bits, o);
+        if (sl == 0 && fr < n) fmask[fr] = bits;
+      }
+      if (fr < n) acc += ls;
+    }
+    // the sub-groups' sums in sub-group order (lanes 0, lpf, 2 lpf, ...)
+    double t = 0.0;
+    for (int sg = 0; sg < fpw; ++sg) t += __shfl(acc, sg * lpf);
+    acc = t;
+  } else
   for (int64_t fr = (int64_t)blockIdx.x * 4 + wave; fr < n; fr += (int64_t)gridDim.x * 4) {
     double *l = LP + fr * M;
     double u = -INFINITY;

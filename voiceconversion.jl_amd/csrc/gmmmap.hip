@@ -2276,42 +2276,34 @@ px_prep_kernel(const double *__restrict__ w, const double *__restrict__ mu, cons
   for (int e = tid; e < D * D; e += 256) {
     const int r = e / D, c = e - r * D;
     S[r * LD + c] = (r <= c) ? Sg[r + (size_t)D * c] : Sg[c + (size_t)D * r];
-    V[r * LD + c] = 0.0;
+    V[r * LD + c] = (r == c) ? 1.0 : 0.0;
   }
   if (tid == 0) bad = 0;
   __syncthreads();
+  // Cholesky and U = L^-1 in ONE loop over the columns: the row operations that eliminate column j of L (row j scaled by
+  // 1 / l_jj, row i -= l_ij row j) are applied to the identity beside it -- row j of V is final when its step comes, and the
+  // updates of a step are independent of each other (threads as a 16 x 16 grid over (row, column)).  Round 5: the inverse used
+  // to be a forward substitution AFTER the loop, one thread per column walking 3200 dependent multiply-adds through LDS:
+  // two thirds of this kernel's 181 us.
   for (int j = 0; j < D; ++j) {
     const double d = S[j * LD + j];
     if (!(d > 0.0) && tid == 0) bad = 1;
-    const double sd = sqrt(d);
+    const double sd = sqrt(d), isd = 1.0 / sd;
+    __syncthreads();                      // every thread has read the pivot
     for (int i = j + tid; i < D; i += 256) S[i * LD + j] = (i == j) ? sd : S[i * LD + j] / sd;
+    for (int c = tid; c <= j; c += 256) V[j * LD + c] *= isd;
     __syncthreads();
-    // trailing update of the lower triangle, threads as a 16 x 16 grid over (row, column): no division per element
     for (int i = j + 1 + (tid >> 4); i < D; i += 16) {
       const double lij = S[i * LD + j];
+      // trailing update of the lower triangle: no division per element
       for (int k = j + 1 + (tid & 15); k <= i; k += 16) S[i * LD + k] = fma(-lij, S[k * LD + j], S[i * LD + k]);
+      // the same row operation on the identity's rows: columns 0 .. j of row i
+      for (int c = (tid & 15); c <= j; c += 16) V[i * LD + c] = fma(-lij, V[j * LD + c], V[i * LD + c]);
     }
+    // (all operands first, then the products, then the stores -- 7 x 7 guarded elements per thread, unrolled -- was tried
+    // against the dependent read-modify-writes of these loops: 435 us instead of 145, most of its slots are empty at D = 80)
     __syncthreads();
   }
-  if (tid < D) {                          // column tid of U
-    const int c = tid;
-    V[c * LD + c] = 1.0 / S[c * LD + c];
-    for (int i = c + 1; i < D; ++i) {
-      // four partial sums: the LDS reads of a run of k are independent of each other and stay in flight together (one sum:
-      // every multiply-add waited for its own two reads, ~130 cycles each, 3200 of them per column)
-      double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-      int k = c;
-      for (; k + 3 < i; k += 4) {
-        s0 = fma(S[i * LD + k], V[k * LD + c], s0);
-        s1 = fma(S[i * LD + k + 1], V[(k + 1) * LD + c], s1);
-        s2 = fma(S[i * LD + k + 2], V[(k + 2) * LD + c], s2);
-        s3 = fma(S[i * LD + k + 3], V[(k + 3) * LD + c], s3);
-      }
-      for (; k < i; ++k) s0 = fma(S[i * LD + k], V[k * LD + c], s0);
-      V[i * LD + c] = -((s0 + s1) + (s2 + s3)) / S[i * LD + i];
-    }
-  }
-  __syncthreads();
   if (tid < D) {
     double s = 0.0;
     for (int c = 0; c <= tid; ++c) s = fma(V[tid * LD + c], mu[c + (size_t)D * m], s);
