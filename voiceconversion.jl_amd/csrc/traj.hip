@@ -1139,7 +1139,7 @@ static int traj_run(vcmi_traj *t, std::vector<TrajUtt> &utts, int64_t nframes, b
       occ = 1;                                                                                                      \
     const int grid_blk = (int)std::min<int64_t>(n, (int64_t)cus * occ);                                             \
     VCMI_TRY(t->ws.reserve((size_t)grid_blk * std::max(ws_stride, ws_stride_s) + 256)); /* + slack: whole-KB reads */ \
-    if (blk_deferred_waves<DV>() <= 2) {                                                                            \
+    if (blk_fused_backsub<DV>()) {                                                                                  \
       hipLaunchKernelGGL(kern, dim3(grid_blk), dim3(blk_threads<DV>()), shb, st, dus, n, Qs, t->mhat.p, gs, t->ws.p,  \
                          ws_stride_s, t->status.p);                                                                 \
     } else {                                                                                                        \

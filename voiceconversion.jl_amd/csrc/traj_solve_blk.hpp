@@ -550,6 +550,15 @@ __device__ void blk_backsub(const double *__restrict__ ws, int T, double *buf, d
 #endif
 template <int D>
 __host__ __device__ constexpr int blk_deferred_waves() { return BlkCfg<D>::NT == 3 ? TRAJ_DEFERRED_WAVES_NT3 : TRAJ_DEFERRED_WAVES; }
+#ifndef TRAJ_SEPARATE_BACKSUB_ALL
+#define TRAJ_SEPARATE_BACKSUB_ALL 0
+#endif
+// The back substitution inside the factorisation kernel or as traj_backsub_blk_kernel behind it (eight-wave kernels, and D = 30:
+// its four-wave kernel runs two workgroups per CU under a 256-register cap and spilled 55 registers with the back substitution
+// inside -- 256 / 1024 utterances of 2000 frames 17.1 / 45.8 -> 13.3 / 39.3 ms; D = 16 the same either way, D = 24 7 % slower at
+// 1024 utterances with the separate kernel, which runs one workgroup per CU: TRAJ_SEPARATE_BACKSUB_ALL=1 for the A/B).
+template <int D>
+__host__ __device__ constexpr bool blk_fused_backsub() { return !TRAJ_SEPARATE_BACKSUB_ALL && blk_deferred_waves<D>() <= 2 && D < 30; }
 template <int D>
 __host__ __device__ constexpr int blk_threads() { return 64 * (2 + blk_deferred_waves<D>()); }
 // Which wave runs job j of the deferred list (see the kernel).  At three tiles per dimension (D = 32..46) by measured
@@ -842,7 +851,7 @@ traj_solve_blk_kernel(const TrajUtt *__restrict__ utts, int n, const double *__r
     }
     // (eight waves: the back substitution is a kernel of its own, traj_backsub_blk_kernel -- inside this one it would be
     // compiled for 256 registers beside everything else and spill in its loop: 5.0k instead of 2.8k counts per step)
-    if constexpr (NW <= 4) blk_backsub<D>(ws, T, wk, yring, part, U.Y);
+    if constexpr (blk_fused_backsub<D>()) blk_backsub<D>(ws, T, wk, yring, part, U.Y);
     BLK_PROF(5);
     if (tid == 0 && bad) status[0] = 1;
     __syncthreads();
