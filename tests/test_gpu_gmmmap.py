@@ -83,7 +83,9 @@ def test_config1_plumbing(vc, kernel):
 
 
 @pytest.mark.parametrize("D,M,T", [(40, 64, 4099), (16, 3, 130), (20, 5, 1), (25, 4, 77), (7, 2, 65), (80, 8, 300),
-                                   (33, 6, 200), (42, 4, 100), (50, 5, 333), (55, 3, 64), (57, 3, 70), (70, 4, 129), (66, 3, 90), (75, 2, 40)])
+                                   (33, 6, 200), (42, 4, 100), (50, 5, 333), (55, 3, 64), (57, 3, 70), (70, 4, 129), (66, 3, 90), (75, 2, 40),
+                                   # beyond D = 48: eight waves per workgroup (128 frames), two block buffers up to D = 72
+                                   (56, 6, 1000), (64, 5, 777), (72, 4, 600), (80, 3, 515)])
 def test_random_models_vs_oracle(vc, D, M, T):
     """Seeded synthetic models (SURVEY 8d generator) at sizes the C oracle finishes in seconds.  The MFMA kernel exists
     for the padded dimensions 16..80 in steps of 4 (D = 50 is the static + delta vector of 25-dimensional

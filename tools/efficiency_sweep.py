@@ -1,0 +1,53 @@
+"""Looking for cliffs (tools, GPU box): fvconvert and the diagonal E-step over dimensions and mixture counts on models whose
+frames are SHARED between mixtures (what trained models look like), device-resident; per shape ms per call and the fraction of
+the FP64 MFMA roof by algorithmic flops -- an outlier in a row or column is a shape that fell off its fast path."""
+import sys, time
+import numpy as np, torch
+sys.path.insert(0, ".")
+import voiceconversion_jl_amd as vc, synthdata as sd
+
+PEAK = 78.6e12
+
+
+def timeit(fn, n=5):
+    fn(); fn(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n
+
+
+what = sys.argv[1] if len(sys.argv) > 1 else "both"
+if what in ("convert", "both"):
+    T = 500_000
+    print("fvconvert, broad synthetic models (eigenvalues in [0.1, 1]), %d frames: ms (fraction of the roof, dense flops)" % T)
+    for D in ((16, 24, 25, 32, 40, 48, 64, 80) if len(sys.argv) < 3 else tuple(int(a) for a in sys.argv[2].split(","))):
+        row = []
+        for M in (8, 32, 64):
+            w, mu, sig = sd.synth_model(7, 2 * D, M, lam_lo=1e-1)
+            g = vc.GMMMap(w, np.asfortranarray(mu.T), np.asfortranarray(np.transpose(sig, (2, 1, 0))))
+            X = torch.from_numpy(sd.sample_frames(8, w, mu, sig, T, 0, D)).cuda()
+            Y = torch.empty_like(X)
+            dt = timeit(lambda: vc.fvconvert(g, X.t(), out=Y.t()))
+            flop = T * M * (D * (D + 1) + 2 * D * D + 2 * D)
+            row.append("%7.3f (%.2f)" % (dt * 1e3, flop / dt / PEAK))
+        print("  D %3d: M 8 / 32 / 64: %s" % (D, "  ".join(row)))
+if what in ("estep", "both"):
+    N = 500_000
+    print("diagonal E-step, shared frames (means 3 sigma / sqrt(Dj) apart), %d frames: ms (fraction of the roof)" % N)
+    for Dj in (24, 32, 48, 50, 64, 80, 81, 100, 160):
+        row = []
+        for M in (16, 64, 128, 256):
+            rg = np.random.default_rng(M + Dj)
+            w = rg.dirichlet(2.0 * np.ones(M))
+            var = np.exp(rg.uniform(np.log(0.05), 0.0, (M, Dj)))
+            mu = 3.0 * rg.standard_normal((M, Dj)) / np.sqrt(Dj)
+            comp = rg.choice(M, size=N, p=w)
+            X = torch.from_numpy(mu[comp] + rg.standard_normal((N, Dj)) * np.sqrt(var[comp])).cuda()
+            muT, varT = np.asfortranarray(mu.T), np.asfortranarray(var.T)
+            out = torch.empty(vc.stats_len(Dj, M), dtype=torch.float64, device="cuda")
+            dt = timeit(lambda: vc.estep_diag_dev(X.t(), w, muT, varT, out=out))
+            flop = N * (2 * M * 2 * Dj + 2 * M * 2 * Dj + 2 * M)
+            row.append("%7.3f (%.2f)" % (dt * 1e3, flop / dt / PEAK))
+        print("  Dj %3d: M 16 / 64 / 128 / 256: %s" % (Dj, "  ".join(row)))

@@ -1433,7 +1433,8 @@ static int launch_mfma(const vcmi_gmmmap *g, const double *dX, int64_t ldx, int6
   constexpr int WAVES = WV;
   using TL = Tiling<DP, MODE >= 1>;
   // double-buffer the per-mixture block when two copies fit in half of the CU's 160 KiB LDS
-  constexpr int NBUF = (2 * (size_t)TL::BLK * sizeof(double) <= 80 * 1024) ? 2 : 1;
+  // (eight-wave workgroups -- one per CU -- take two buffers whenever they fit the CU's LDS at all)
+  constexpr int NBUF = (2 * (size_t)TL::BLK * sizeof(double) <= (WAVES == 8 ? 156 : 80) * 1024) ? 2 : 1;
   const size_t shmem = NBUF * (size_t)TL::BLK * sizeof(double);
   auto kern = gmmmap_mfma_kernel<DP, FT, WAVES, MODE, NBUF, PRUNE>;
   // the attribute is per DEVICE: one flag per device, so a host that drives several GPUs sets it on each of them
@@ -1467,6 +1468,14 @@ static constexpr int64_t kSortMinFrames = 8192;
 #ifndef VCMI_CONVERT_WAVES
 #define VCMI_CONVERT_WAVES 4
 #endif
+#ifndef VCMI_CONVERT_WAVES_WIDE
+// Waves per workgroup of the fvconvert kernels beyond D = 48 (one frame tile per wave).  A mixture's block is 46 KB (DP = 52) to
+// 102 KB (DP = 80) there, so a CU holds ONE or two workgroups: with four waves that was four to eight waves per CU, each
+// workgroup streaming the whole model through LDS for its 64 frames.  Eight waves share a block (and two buffers where they
+// fit: DP <= 72): 5e5 frames, M = 64: D = 56 8.06 -> 3.16 ms, D = 64 8.50 -> 3.34, D = 72 15.1 -> 4.54, D = 80 20.7 -> 10.1
+// (tools/efficiency_sweep.py; A/B: -DVCMI_CONVERT_WAVES_WIDE=4).
+#define VCMI_CONVERT_WAVES_WIDE 8
+#endif
 template <int MODE, int PRUNE = 2>
 static int dispatch_mfma(const vcmi_gmmmap *g, const double *dX, int64_t ldx, int64_t T, double *dY, int64_t ldy,
                          hipStream_t st, const int *perm = nullptr, const int *gkey = nullptr) {
@@ -1481,7 +1490,7 @@ static int dispatch_mfma(const vcmi_gmmmap *g, const double *dX, int64_t ldx, in
   }
   switch (g->DP) {
 #define VCMI_CASE(DPV) \
-  case DPV: return launch_mfma<DPV, MODE, ((DPV) <= 48 ? VCMI_CONVERT_FT : 1), ((DPV) == 40 && MODE == 0 ? VCMI_CONVERT_WAVES : 4), PRUNE>(g, dX, ldx, T, dY, ldy, st, perm, gkey);
+  case DPV: return launch_mfma<DPV, MODE, ((DPV) <= 48 ? VCMI_CONVERT_FT : 1), ((DPV) == 40 && MODE == 0 ? VCMI_CONVERT_WAVES : ((DPV) > 48 && MODE == 0 ? VCMI_CONVERT_WAVES_WIDE : 4)), PRUNE>(g, dX, ldx, T, dY, ldy, st, perm, gkey);
     VCMI_CASE(16) VCMI_CASE(20) VCMI_CASE(24) VCMI_CASE(28) VCMI_CASE(32) VCMI_CASE(36) VCMI_CASE(40) VCMI_CASE(44)
     VCMI_CASE(48) VCMI_CASE(52) VCMI_CASE(56) VCMI_CASE(60) VCMI_CASE(64) VCMI_CASE(68) VCMI_CASE(72) VCMI_CASE(76)
     VCMI_CASE(80)
