@@ -51,3 +51,29 @@ if what in ("estep", "both"):
             flop = N * (2 * M * 2 * Dj + 2 * M * 2 * Dj + 2 * M)
             row.append("%7.3f (%.2f)" % (dt * 1e3, flop / dt / PEAK))
         print("  Dj %3d: M 16 / 64 / 128 / 256: %s" % (Dj, "  ".join(row)))
+if what in ("estep_full",):
+    N = 200_000
+    print("full-covariance E-step, broad synthetic models, %d frames: ms (fraction of the roof)" % N)
+    for Dj in (32, 48, 50, 64, 80, 82, 96, 128, 160):
+        row = []
+        for M in (8, 32, 64):
+            w, mu, sig = sd.synth_model(9, Dj, M, lam_lo=1e-1)
+            X = torch.from_numpy(sd.sample_frames(10, w, mu, sig, N, 0, Dj)).cuda()
+            muT, sgT = np.asfortranarray(mu.T), np.asfortranarray(np.transpose(sig, (2, 1, 0)))
+            out = torch.empty(vc.full_stats_len(Dj, M), dtype=torch.float64, device="cuda")
+            dt = timeit(lambda: vc.estep_full_dev(X.t(), w, muT, sgT, out=out), n=3)
+            flop = N * (2 * M * Dj * (Dj + 1) + 2 * M * Dj)
+            row.append("%7.3f (%.2f)" % (dt * 1e3, flop / dt / PEAK))
+        print("  Dj %3d: M 8 / 32 / 64: %s" % (Dj, "  ".join(row)))
+if what in ("dtw",):
+    n, S = 1000, 500
+    print("DTW fit + backward, %d pairs of ~%d x %d frames: ms (fraction of the FMA-free FP64 vector roof, 39.3 TFLOP/s)" % (n, S, S))
+    rg = np.random.default_rng(3)
+    for D in (12, 24, 25, 32, 40, 41, 48, 60, 80):
+        tm = [rg.standard_normal((D, S)) for _ in range(8)]
+        sq = [rg.standard_normal((D, S + 17)) for _ in range(8)]
+        d = vc.DTW()
+        ts, ss = [tm[i % 8] for i in range(n)], [sq[i % 8] for i in range(n)]
+        t0 = time.perf_counter(); vc.fit_batch(d, ts, ss); t1 = time.perf_counter() - t0
+        t0 = time.perf_counter(); vc.fit_batch(d, ts, ss); t1 = time.perf_counter() - t0
+        print("  D %3d: host-pointer batch %.2f ms" % (D, t1 * 1e3))
