@@ -77,3 +77,17 @@ if what in ("dtw",):
         t0 = time.perf_counter(); vc.fit_batch(d, ts, ss); t1 = time.perf_counter() - t0
         t0 = time.perf_counter(); vc.fit_batch(d, ts, ss); t1 = time.perf_counter() - t0
         print("  D %3d: host-pointer batch %.2f ms" % (D, t1 * 1e3))
+if what in ("posterior",):
+    T = 500_000
+    print("predict_proba / predict, broad synthetic models, %d frames: ms (fraction of the roof, M D (D + 1) flops per frame)" % T)
+    for D in (16, 24, 32, 40, 48, 56, 64, 72, 80):
+        row = []
+        for M in (8, 32, 64):
+            w, mu, sig = sd.synth_model(11, 2 * D, M, lam_lo=1e-1)
+            px = vc.GMMMap(w, np.asfortranarray(mu.T), np.asfortranarray(np.transpose(sig, (2, 1, 0)))).px
+            X = torch.from_numpy(sd.sample_frames(12, w, mu, sig, T, 0, D)).cuda()
+            d1 = timeit(lambda: vc.predict_proba(px, X.t()), n=3)
+            d2 = timeit(lambda: vc.predict(px, X.t()), n=3)
+            flop = T * M * D * (D + 1)
+            row.append("%6.3f (%.2f) / %6.3f (%.2f)" % (d1 * 1e3, flop / d1 / PEAK, d2 * 1e3, flop / d2 / PEAK))
+        print("  D %3d: M 8 / 32 / 64: %s" % (D, "   ".join(row)))

@@ -1082,26 +1082,56 @@ logdens_tiled_kernel(const double *__restrict__ U, const double *__restrict__ cz
 
 // ------------------------------------------------------------------------------------------------
 // (M,T) log-weighted densities -> posterior in place (MODE 0) or 1-based argmax (MODE 1).
-// One lane per frame.  Follows src/gmm.jl:28-29 (max-shifted log-sum-exp, exp(l - lse)) and :46 (first max).
+// Lanes ACROSS the mixtures of a frame (8, 16, 32 or 64 of them: several frames per wave where M is small), so that a wave
+// reads whole rows of the (T,M) matrix.  (Round 5: one lane per frame walked its row three times with a stride of M doubles
+// between the lanes -- 1.47 ms for 5e5 x 64, fifteen times what the bytes take; tools/efficiency_sweep.py posterior.)
+// Follows src/gmm.jl:28-29 (max-shifted log-sum-exp, exp(l - lse)) and :46 (the FIRST maximum: ties go to the smaller index).
 // ------------------------------------------------------------------------------------------------
 template <int MODE>
 __global__ void __launch_bounds__(256)
 posterior_finish_kernel(double *__restrict__ LP, int M, int64_t T, int64_t *__restrict__ idx) {
-  const int64_t fr = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (fr >= T) return;
-  double *l = LP + fr * M;
-  double u = l[0];
-  int best = 0;
-  for (int m = 1; m < M; ++m)
-    if (l[m] > u) { u = l[m]; best = m; }
-  if (MODE == 1) {
-    idx[fr] = best + 1;
-    return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lpf = M <= 8 ? 8 : (M <= 16 ? 16 : (M <= 32 ? 32 : 64)), fpw = 64 / lpf, sub = lane / lpf, sl = lane % lpf;
+  for (int64_t f0 = ((int64_t)blockIdx.x * 4 + wave) * fpw; f0 < T; f0 += (int64_t)gridDim.x * 4 * fpw) {
+    const int64_t fr = f0 + sub;
+    const bool live = fr < T;
+    double *l = LP + (live ? fr : T - 1) * M;
+    // the lane's first maximum among m = sl, sl + lpf, ... (increasing m, strict >), then across the lanes
+    double u = -INFINITY;
+    int best = 0x7fffffff;
+    if (sl < M) {
+      u = l[sl];
+      best = sl;
+      for (int m = sl + lpf; m < M; m += lpf) {
+        const double v = l[m];
+        if (v > u) {
+          u = v;
+          best = m;
+        }
+      }
+    }
+    for (int o = lpf / 2; o >= 1; o >>= 1) {
+      const double ou = __shfl_xor(u, o);
+      const int ob = __shfl_xor(best, o);
+      const bool take = ou > u || (ou == u && ob < best);
+      u = take ? ou : u;
+      best = take ? ob : best;
+    }
+    if (MODE == 1) {
+      if (live && sl == 0) idx[fr] = best + 1;
+      continue;
+    }
+    double s = 0.0;
+    for (int m = sl; m < M; m += lpf) s += vc_exp(l[m] - u);
+    for (int o = lpf / 2; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+    const double lse = u + log(s);
+    if (live)
+      for (int m = sl; m < M; m += lpf) l[m] = vc_exp(l[m] - lse);
   }
-  double s = 0.0;
-  for (int m = 0; m < M; ++m) s += vc_exp(l[m] - u);
-  const double lse = u + log(s);
-  for (int m = 0; m < M; ++m) l[m] = vc_exp(l[m] - lse);
+}
+static inline unsigned posterior_finish_grid(int M, int64_t T) {
+  const int lpf = M <= 8 ? 8 : (M <= 16 ? 16 : (M <= 32 ? 32 : 64)), fpw = 64 / lpf;
+  return (unsigned)std::min<int64_t>((T + 4 * fpw - 1) / (4 * fpw), 8192);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1736,7 +1766,7 @@ int gmmmap_logdens_device(vcmi_gmmmap *g, const double *dX, int64_t ldx, int64_t
 int gmmmap_posterior_device(vcmi_gmmmap *g, const double *dX, int64_t ldx, int64_t T, double *dP, hipStream_t st) {
   if (T == 0) return VCMI_OK;
   VCMI_TRY(gmmmap_logdens_device(g, dX, ldx, T, dP, st));
-  hipLaunchKernelGGL(posterior_finish_kernel<0>, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, st, dP, g->M, T,
+  hipLaunchKernelGGL(posterior_finish_kernel<0>, dim3(posterior_finish_grid(g->M, T)), dim3(256), 0, st, dP, g->M, T,
                      (int64_t *)nullptr);
   VCMI_HIP(hipGetLastError());
   return VCMI_OK;
@@ -1767,7 +1797,7 @@ int gmmmap_predict_device(vcmi_gmmmap *g, const double *dX, int64_t ldx, int64_t
   }
   VCMI_TRY(g->scratch_lp.reserve((size_t)T * g->M));
   VCMI_TRY(gmmmap_logdens_device(g, dX, ldx, T, g->scratch_lp.p, st));
-  hipLaunchKernelGGL(posterior_finish_kernel<1>, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, st, g->scratch_lp.p,
+  hipLaunchKernelGGL(posterior_finish_kernel<1>, dim3(posterior_finish_grid(g->M, T)), dim3(256), 0, st, g->scratch_lp.p,
                      g->M, T, didx);
   VCMI_HIP(hipGetLastError());
   return VCMI_OK;
