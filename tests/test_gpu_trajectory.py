@@ -243,3 +243,38 @@ def test_batch_of_empty_utterances_on_a_fresh_handle(vc):
                                                 C.c_void_p(dY.data_ptr()), _lib.iptr(off), None)
     assert rc == 0
     assert t.fvconvert_batch([np.zeros((2 * D, 0), order="F")])[0].shape == (D, 0)
+
+
+@pytest.mark.parametrize("D,M,Ts", [(47, 3, [40, 1]), (48, 4, [75, 2, 3]), (64, 3, [50]), (57, 2, [33, 4]), (72, 2, [20, 5]), (90, 2, [12])])
+def test_static_dimensions_beyond_the_blocked_solver(vc, D, M, Ts):
+    """The reference has no limit on the static dimension (src/trajectory_gmmmap.jl:65-110); the blocked solver ends at 46.
+    Beyond it `traj_solve_big_kernel` runs: the same banded Cholesky with the window's lower triangle packed in LDS up to
+    D = 64 and in HBM above -- a fallback (19 x the blocked solver's time at D = 48), but the same answers: against the oracle,
+    batch == single bit for bit, and the not-PD report."""
+    from oracle import c_oracle as co, np_oracle as npo
+    w, mu, sig = npo.synth_model(500 + D, 4 * D, M, lam_lo=1e-3)
+    ref = co.TrajectoryGMMMap(co.GMMMap(w, mu, sig))
+    g = vc.GMMMap(*julia_model(w, mu, sig))
+    t = vc.TrajectoryGMMMap(g, max(Ts))
+    rng = np.random.default_rng(D)
+    Xs = []
+    for T in Ts:
+        static = npo.sample_frames(int(rng.integers(1 << 30)), w, mu, sig, T, 0, D)
+        static = np.cumsum(static, axis=0) / np.sqrt(np.arange(1, T + 1))[:, None]
+        Xs.append(npo.push_delta(static))
+    Ys = t.fvconvert_batch([x.T for x in Xs])
+    for x, y in zip(Xs, Ys):
+        yref, _, _ = ref.fvconvert(x)
+        assert relerr(y, yref.T) < TOL
+    assert np.array_equal(vc.fvconvert(t, Xs[0].T), Ys[0])
+
+
+def test_not_positive_definite_beyond_the_blocked_solver(vc):
+    D, M, T = 50, 2, 7
+    rng = np.random.default_rng(3)
+    I = np.eye(2 * D)
+    sig = np.stack([np.block([[I, 2.0 * I], [2.0 * I, I]])] * M)
+    g = vc.GMMMap(*julia_model(np.array([0.5, 0.5]), rng.standard_normal((M, 4 * D)), sig))
+    t = vc.TrajectoryGMMMap(g, T)
+    with pytest.raises(vc.PosDefException):
+        vc.fvconvert(t, rng.standard_normal((2 * D, T)))

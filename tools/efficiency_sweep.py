@@ -91,3 +91,29 @@ if what in ("posterior",):
             flop = T * M * D * (D + 1)
             row.append("%6.3f (%.2f) / %6.3f (%.2f)" % (d1 * 1e3, flop / d1 / PEAK, d2 * 1e3, flop / d2 / PEAK))
         print("  D %3d: M 8 / 32 / 64: %s" % (D, "   ".join(row)))
+if what in ("traj",):
+    M = 16
+    print("TrajectoryGMMMap fvconvert, 256 utterances: ms per call (ns per frame and static dimension cubed x 1e3)")
+    for D in (12, 16, 20, 24, 25, 28, 30, 32, 36, 40, 44, 46, 48):
+        w, mu, sig = sd.synth_model(5, 4 * D, M, lam_lo=1e-3)
+        g = vc.GMMMap(w, np.asfortranarray(mu.T), np.asfortranarray(np.transpose(sig, (2, 1, 0))))
+        row = []
+        for T in (100, 500, 2000):
+            tj = vc.TrajectoryGMMMap(g, T)
+            st = sd.sample_frames(6, w, mu, sig, T, 0, D)
+            st = np.cumsum(st, axis=0) / np.sqrt(np.arange(1, T + 1))[:, None]
+            X1 = np.ascontiguousarray(vc.push_delta(np.asfortranarray(st.T)).T)
+            n = 256
+            X = torch.from_numpy(np.tile(X1, (n, 1))).cuda()
+            Y = torch.empty((n * T, D), dtype=torch.float64, device="cuda")
+            xoff = np.arange(n, dtype=np.int64) * T * 2 * D
+            yoff = np.arange(n, dtype=np.int64) * T * D
+            Ts = np.full(n, T, dtype=np.int64)
+            from voiceconversion_jl_amd import _lib
+
+            def step():
+                _lib.check(_lib.lib.vcmi_traj_convert_batch_dev(tj._h, n, X.data_ptr(), _lib.iptr(xoff), _lib.iptr(Ts), Y.data_ptr(), _lib.iptr(yoff),
+                                                                torch.cuda.current_stream().cuda_stream))
+            dt = timeit(step, n=3)
+            row.append("%8.3f (%.2f)" % (dt * 1e3, dt * 1e9 / (n * T) / D ** 3 * 1e3))
+        print("  D %3d: T 100 / 500 / 2000: %s" % (D, "  ".join(row)))

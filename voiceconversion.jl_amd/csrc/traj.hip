@@ -42,6 +42,8 @@ struct vcmi_traj {
   // sides and solutions of a call
   int Dpad = 0;
   vcmi::DevBuf<double> Qpad, gpad, ypad;
+  bool big = false;                       // static D beyond the LDS-window solvers (D >= 47): traj_solve_big_kernel, window in HBM
+  vcmi::DevBuf<double> gwin;
   vcmi::DevBuf<unsigned char> uttpad;
   vcmi::DevBuf<int64_t> mhat;
   vcmi::DevBuf<int> status;
@@ -1037,6 +1039,160 @@ static int traj_blk_padded_dim(int D) {
   return 0;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Any static dimension (D >= 47: the reference has no limit, src/trajectory_gmmmap.jl:65-110): the algorithm of
+// traj_solve_kernel with its 3D x 3D window, right-hand side, pivot column and the vectors of the back substitution in HBM
+// (a per-workgroup scratch, L2-resident) instead of LDS -- a fallback for completeness, not a fast path: every
+// __syncthreads also orders the workgroup's global accesses.  Window shift through a second buffer; the triangular solve of
+// the back substitution column by column across the workgroup.
+// ------------------------------------------------------------------------------------------------
+static size_t traj_big_win_doubles(int D) {
+  const size_t W3 = 3 * (size_t)D, D2 = 2 * (size_t)D;
+  return W3 * (W3 + 1) + 2 * W3 + 2 * D + 2 * D + D2 * D2 + D2 + 64;
+}
+
+// PK = true (47 <= D <= 64): the window's LOWER TRIANGLE in packed storage, (i, j <= i) at i (i + 1) / 2 + j, fits LDS
+// (148 KB at D = 64) together with the small vectors; only the shift buffer and the panels stay in HBM.  PK = false: everything
+// in the per-workgroup HBM scratch.
+static size_t traj_big_lds_bytes(int D) {
+  const size_t W3 = 3 * (size_t)D;
+  return (W3 * (W3 + 1) / 2 + 2 * W3 + 2 * D + 2 * D + 8) * sizeof(double);
+}
+
+template <bool PK>
+__global__ void __launch_bounds__(256)
+traj_solve_big_kernel(const TrajUtt *__restrict__ utts, int n, int D, const double *__restrict__ Qall,
+                      const int64_t *__restrict__ mhat_all, const double *__restrict__ g_all, double *__restrict__ ws_all,
+                      int64_t ws_stride, int *__restrict__ status, double *__restrict__ gwin_all, int64_t gwin_stride) {
+  const int D2 = 2 * D, W3 = 3 * D, LD = W3 + 1;
+  extern __shared__ double sm_big[];
+  double *gw = gwin_all + (size_t)blockIdx.x * gwin_stride;
+  double *Wd = PK ? sm_big : gw;                                   // the window: packed lower triangle (LDS) or [W3][LD] (HBM)
+  double *vec = PK ? sm_big + (size_t)W3 * (W3 + 1) / 2 : gw + (size_t)W3 * LD;
+  double *rr = vec;                      // [W3]
+  double *lcol = rr + W3;                // [W3]
+  double *yring = lcol + W3;             // [2][D]
+  double *wv = yring + 2 * D;            // [D]
+  double *rdiag = wv + D;                // [D]
+  double *tmp = PK ? gw : rdiag + D;     // [D2][D2] + [D2] in HBM: the shifted part of the window on its way up-left
+  auto W = [&](int i, int j) -> double & { return PK ? Wd[(size_t)i * (i + 1) / 2 + j] : Wd[(size_t)i * LD + j]; };
+  __shared__ int bad;
+  __shared__ double zc_s;
+  const int tid = threadIdx.x;
+  const int ti = tid >> 4, tj = tid & 15;
+  const size_t PAN = (size_t)(W3 + 1) * D;
+
+  for (int u = blockIdx.x; u < n; u += gridDim.x) {
+    const TrajUtt U = utts[u];
+    const int T = U.T;
+    if (T == 0) continue;
+    const int64_t *mh = mhat_all + U.frame0;
+    const double *g = g_all + U.frame0 * D2;
+    double *ws = ws_all + (size_t)blockIdx.x * ws_stride;
+    if (tid == 0) bad = 0;
+    // block row a of P (blocks (a,a-2), (a,a-1), (a,a): traj_add_block_row's terms) into window block row la; lower triangle only
+    auto add_block_row = [&](int a, int la) {
+      const double *Qa = Qall + (size_t)(mh[a] - 1) * D2 * D2;
+      const double *Qm = (a >= 1) ? Qall + (size_t)(mh[a - 1] - 1) * D2 * D2 : nullptr;
+      const double *Qp = (a + 1 < T) ? Qall + (size_t)(mh[a + 1] - 1) * D2 * D2 : nullptr;
+      for (int e = tid; e < D * D; e += 256) {
+        const int i = e / D, j = e - i * D;
+        if (j <= i) {
+          double v = Qa[(size_t)i * D2 + j];
+          if (Qm) v += 0.25 * Qm[(size_t)(D + i) * D2 + (D + j)];
+          if (Qp) v += 0.25 * Qp[(size_t)(D + i) * D2 + (D + j)];
+          W(la * D + i, la * D + j) = v;
+        }
+        if (la >= 1 && a >= 1) W(la * D + i, (la - 1) * D + j) = 0.5 * Qm[(size_t)(D + i) * D2 + j] - 0.5 * Qa[(size_t)i * D2 + (D + j)];
+        if (la >= 2 && a >= 2) W(la * D + i, (la - 2) * D + j) = -0.25 * Qm[(size_t)(D + i) * D2 + (D + j)];
+      }
+      for (int k = tid; k < D; k += 256) {
+        double v = g[(size_t)a * D2 + k];
+        if (a >= 1) v += 0.5 * g[(size_t)(a - 1) * D2 + D + k];
+        if (a + 1 < T) v -= 0.5 * g[(size_t)(a + 1) * D2 + D + k];
+        rr[la * D + k] = v;
+      }
+    };
+    for (int a = 0; a < 3 && a < T; ++a) add_block_row(a, a);
+    __syncthreads();
+    for (int t = 0; t < T; ++t) {
+      const int nb = (T - t < 3) ? T - t : 3;
+      const int nrows = nb * D;
+      for (int c = 0; c < D; ++c) {
+        const double piv = W(c, c);
+        if (!(piv > 0.0) && tid == 0) bad = 1;
+        const double dinv = traj_rsqrt(piv);
+        for (int lr = c + tid; lr < nrows; lr += 256) lcol[lr] = (lr == c) ? piv * dinv : W(lr, c) * dinv;
+        if (tid == 255) zc_s = rr[c] * dinv;
+        __syncthreads();
+        const int rem = nrows - c - 1;
+        for (int a = ti; a < rem; a += 16) {
+          const int ri = c + 1 + a;
+          const double lic = lcol[ri];
+          double *row = &W(ri, c + 1);
+          for (int b = tj; b <= a; b += 16) row[b] = fma(-lic, lcol[c + 1 + b], row[b]);
+        }
+        const double zc = zc_s;
+        for (int lr = c + tid; lr < nrows; lr += 256) {
+          W(lr, c) = lcol[lr];
+          if (lr > c) rr[lr] = fma(-zc, lcol[lr], rr[lr]);
+          else rr[lr] = zc;
+        }
+        __syncthreads();
+      }
+      double *pan = ws + (size_t)t * PAN;
+      for (int e = tid; e < W3 * D; e += 256) {
+        const int lr = e / D, cc = e - lr * D;
+        pan[e] = (lr < nrows && cc <= lr) ? W(lr, cc) : 0.0;
+      }
+      for (int cc = tid; cc < D; cc += 256) pan[(size_t)W3 * D + cc] = rr[cc];
+      // the lower-right 2D x 2D part (its lower triangle) moves up-left by D
+      for (int e = tid; e < D2 * D2; e += 256) {
+        const int i = e / D2, j = e - i * D2;
+        if (j <= i) tmp[e] = W(i + D, j + D);
+      }
+      for (int k = tid; k < D2; k += 256) tmp[(size_t)D2 * D2 + k] = rr[k + D];
+      __syncthreads();
+      for (int e = tid; e < D2 * D2; e += 256) {
+        const int i = e / D2, j = e - i * D2;
+        if (j <= i) W(i, j) = tmp[e];
+      }
+      for (int k = tid; k < D2; k += 256) rr[k] = tmp[(size_t)D2 * D2 + k];
+      __syncthreads();
+      if (t + 3 < T) add_block_row(t + 3, 2);
+      __syncthreads();
+    }
+    // ---------------- back substitution: y_t = Dg'^-1 (z - E' y_{t+1} - F' y_{t+2}) from the panels ----------------
+    for (int i = tid; i < 2 * D; i += 256) yring[i] = 0.0;
+    __syncthreads();
+    for (int t = T - 1; t >= 0; --t) {
+      const double *pb = ws + (size_t)t * PAN;
+      double *y1 = yring + ((t + 1) & 1) * D, *y2 = yring + (t & 1) * D;
+      for (int j = tid; j < D; j += 256) {
+        double sacc = pb[(size_t)W3 * D + j];
+        for (int i = 0; i < D; ++i) sacc = fma(-pb[(size_t)(D + i) * D + j], y1[i], sacc);
+        for (int i = 0; i < D; ++i) sacc = fma(-pb[(size_t)(2 * D + i) * D + j], y2[i], sacc);
+        wv[j] = sacc;
+        rdiag[j] = 1.0 / pb[(size_t)j * D + j];
+      }
+      for (int k = D - 1; k >= 0; --k) {
+        __syncthreads();
+        const double yk = wv[k] * rdiag[k];
+        for (int j = tid; j < k; j += 256) wv[j] = fma(-pb[(size_t)k * D + j], yk, wv[j]);
+        if (tid == 0) {
+          lcol[k] = yk;                      // (lcol is free during the back substitution)
+          U.Y[(size_t)t * D + k] = yk;
+        }
+      }
+      __syncthreads();
+      for (int j = tid; j < D; j += 256) y2[j] = lcol[j];
+      __syncthreads();
+    }
+    if (tid == 0 && bad) status[0] = 1;
+    __syncthreads();
+  }
+}
+
 static size_t solve_lds_bytes(int D) {
   const size_t W3 = 3 * (size_t)D;
   const size_t NK = (W3 + 15) / 16;
@@ -1167,7 +1323,20 @@ static int traj_run(vcmi_traj *t, std::vector<TrajUtt> &utts, int64_t nframes, b
     hipLaunchKernelGGL(traj_unpad_y_kernel, dim3(n, 8), dim3(256), 0, st, du, t->ypad.p, D, t->Dpad);
     VCMI_HIP(hipGetLastError());
   }
-  if (!launched) {
+  if (!launched && t->big) {
+    const int64_t gstride = (int64_t)traj_big_win_doubles(D);
+    VCMI_TRY(t->gwin.reserve((size_t)grid * gstride));
+    const size_t lds_pk = traj_big_lds_bytes(D);
+    if (lds_pk <= 160 * 1024 - 256) {       // D <= 64: the window's lower triangle in LDS
+      VCMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(traj_solve_big_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)lds_pk));
+      hipLaunchKernelGGL(traj_solve_big_kernel<true>, dim3(grid), dim3(256), lds_pk, st, du, n, D, t->Q.p, t->mhat.p, t->gbuf.p, t->ws.p,
+                         ws_stride, t->status.p, t->gwin.p, gstride);
+    } else {
+      hipLaunchKernelGGL(traj_solve_big_kernel<false>, dim3(grid), dim3(256), 0, st, du, n, D, t->Q.p, t->mhat.p, t->gbuf.p, t->ws.p,
+                         ws_stride, t->status.p, t->gwin.p, gstride);
+    }
+  } else if (!launched) {
     VCMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(traj_solve_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)shmem));
     hipLaunchKernelGGL(traj_solve_kernel, dim3(grid), dim3(256), shmem, st, du, n, D, t->Q.p, t->mhat.p, t->gbuf.p, t->ws.p,
@@ -1343,10 +1512,9 @@ extern "C" int vcmi_traj_create(vcmi_gmmmap *g, int64_t T, vcmi_traj **out) {
   if (g->D & 1) return fail(VCMI_ERR_DIM, "TrajectoryGMMMap: dim(g) = %d must be even (static + delta)", g->D);
   if (T < 0) return fail(VCMI_ERR_ARG, "TrajectoryGMMMap: negative length");
   const int D2 = g->D, D = D2 / 2, M = g->M;
-  if (solve_lds_bytes(D) > 160 * 1024 - 64)
-    return fail(VCMI_ERR_ARG, "TrajectoryGMMMap: static dimension %d exceeds the LDS-window solver's limit (46)", D);
   vcmi_traj *t = new (std::nothrow) vcmi_traj();
   if (!t) return fail(VCMI_ERR_OOM, "out of host memory");
+  t->big = solve_lds_bytes(D) > 160 * 1024 - 64;      // D >= 47: the window of the solve does not fit LDS -> traj_solve_big_kernel
   t->g = g;
   t->D2 = D2;
   t->D = D;
