@@ -203,6 +203,25 @@ def test_long_sequence_falls_back_to_two_kernels(vc, S, T):
     assert np.array_equal(newtgt, co.align(t, s)[0].T)
 
 
+@pytest.mark.parametrize("S,T,bs", [(7000, 600, 2), (6100, 6400, 1)])
+def test_long_template_runs_on_an_hbm_scratch(vc, S, T, bs):
+    """A TEMPLATE of more than ~5800 frames (half a minute at a 5 ms shift) no longer fits two cost columns, the path and the
+    align() lists in LDS: the call used to fail ("exceeds the supported length"; the reference has no limit,
+    src/dtw.jl:11-59).  The generic kernel now keeps those arrays in a per-pair HBM scratch: the same bit-exact path and
+    newtgt, in a batch with a short pair too."""
+    from oracle import c_oracle as co
+    rng = np.random.default_rng(S + T)
+    t, s = _warped_pair(rng, S, T, 6)
+    d = vc.DTW(fstep=0, bstep=bs)
+    ref = co.dtw_fit(t, s, 0, bs, tables=False)
+    assert np.array_equal(vc.fit_(d, t.T, s.T, tables=False), ref)
+    both = vc.fit_batch(d, [t.T, t[:40].T], [s.T, s[:100].T])
+    assert np.array_equal(both[0], ref) and np.array_equal(both[1], co.dtw_fit(t[:40], s[:100], 0, bs, tables=False))
+    if bs == 2:
+        src, newtgt = vc.align(t.T, s.T)
+        assert np.array_equal(newtgt, co.align(t, s)[0].T)
+
+
 @pytest.mark.parametrize("D", [16, 41])
 def test_column_segments_and_persistent_workgroups(vc, D):
     """More jobs than the device has slots and sequences long enough: every strip's columns are cut into segments (a segment

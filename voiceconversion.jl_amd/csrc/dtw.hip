@@ -757,10 +757,15 @@ dtw_fused_align_kernel(const double *__restrict__ feats, const DtwPair *__restri
 // template read from HBM/L2, step codes as bytes in HBM.
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(1024)
-dtw_generic_kernel(const double *__restrict__ feats, const DtwPair *__restrict__ pairs, int D, int fstep, int bstep, int Smax, int Tmax) {
+dtw_generic_kernel(const double *__restrict__ feats, const DtwPair *__restrict__ pairs, int D, int fstep, int bstep, int Smax, int Tmax,
+                   unsigned char *__restrict__ gscr, size_t gscr_stride) {
+  // gscr (templates beyond ~5800 frames: two cost columns, the path and the align() lists no longer fit LDS): the same
+  // arrays in a per-pair HBM scratch -- the reference has no length limit (src/dtw.jl:11-59); __syncthreads orders the
+  // workgroup's global accesses as it orders its LDS accesses
   const DtwPair P = pairs[blockIdx.x];
   const int S = P.S, T = P.T, tid = threadIdx.x, nthr = blockDim.x;
-  extern __shared__ unsigned char smem_raw[];
+  extern __shared__ unsigned char smem_lds[];
+  unsigned char *smem_raw = gscr ? gscr + (size_t)blockIdx.x * gscr_stride : smem_lds;
   double *cbuf = reinterpret_cast<double *>(smem_raw);
   int32_t *path32 = reinterpret_cast<int32_t *>(cbuf + 2 * Smax);
   int32_t *owner = path32 + Tmax;
@@ -900,7 +905,7 @@ static int launch_obs(const double *feats, const double *spad, const DtwPair *dp
 
 // per-thread scratch shared by the DTW entry points
 struct DtwScratch {
-  DevBuf<unsigned char> codes;
+  DevBuf<unsigned char> codes, longscr;      // longscr: cost columns / path / lists of the generic kernel beyond the LDS lengths
   DevBuf<DtwPair> dpairs;
   DevBuf<double> feats, cost, newtgt, obs, spad;
   DevBuf<int64_t> paths, bp;
@@ -1344,7 +1349,7 @@ static int dtw_run(const double *feats, std::vector<DtwPair> &pairs, int D, int 
   const size_t base_generic = base;
   const size_t codes_lds = (size_t)((Tmax + (32 / bits) - 1) / (32 / bits)) * Smax * 4;
   const bool ldscodes = fast && (base + codes_lds <= kLdsLimit);
-  if (base > kLdsLimit) return fail(VCMI_ERR_ARG, "DTW: template of %d frames exceeds the supported length", Smax);
+  const bool longseq = base > kLdsLimit;       // two cost columns + path + lists beyond LDS: the generic kernel on an HBM scratch
   if (!ldscodes) {
     size_t total = 0;
     for (auto &p : pairs) total += (size_t)p.S * p.T;
@@ -1421,9 +1426,18 @@ static int dtw_run(const double *feats, std::vector<DtwPair> &pairs, int D, int 
     return VCMI_OK;
   }
   VCMI_TRY(sc.upload(dpairs.p, pairs.data(), (size_t)n, st));
+  if (longseq) {
+    const size_t stride = (base_generic + 255) / 256 * 256;
+    VCMI_TRY(sc.longscr.reserve((size_t)n * stride));
+    hipLaunchKernelGGL(dtw_generic_kernel, dim3(n), dim3(1024), 0, st, feats, dpairs.p, D, fstep, bstep, Smax, Tmax, sc.longscr.p, stride);
+    VCMI_HIP(hipGetLastError());
+    VCMI_HIP(hipEventRecord(sc.last_use, st));
+    return VCMI_OK;
+  }
   VCMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(dtw_generic_kernel),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)base_generic));
-  hipLaunchKernelGGL(dtw_generic_kernel, dim3(n), dim3(1024), base_generic, st, feats, dpairs.p, D, fstep, bstep, Smax, Tmax);
+  hipLaunchKernelGGL(dtw_generic_kernel, dim3(n), dim3(1024), base_generic, st, feats, dpairs.p, D, fstep, bstep, Smax, Tmax,
+                     (unsigned char *)nullptr, (size_t)0);
   VCMI_HIP(hipGetLastError());
   VCMI_HIP(hipEventRecord(sc.last_use, st));
   return VCMI_OK;
