@@ -249,7 +249,7 @@ def test_batch_of_empty_utterances_on_a_fresh_handle(vc):
 def test_static_dimensions_beyond_the_blocked_solver(vc, D, M, Ts):
     """The reference has no limit on the static dimension (src/trajectory_gmmmap.jl:65-110); the blocked solver ends at 46.
     Beyond it `traj_solve_big_kernel` runs: the same banded Cholesky with the window's lower triangle packed in LDS up to
-    D = 64 and in HBM above -- a fallback (19 x the blocked solver's time at D = 48), but the same answers: against the oracle,
+    D = 64 and in HBM above -- a fallback (17 x the blocked solver's time at D = 48), but the same answers: against the oracle,
     batch == single bit for bit, and the not-PD report."""
     from oracle import c_oracle as co, np_oracle as npo
     w, mu, sig = npo.synth_model(500 + D, 4 * D, M, lam_lo=1e-3)

@@ -1167,6 +1167,13 @@ traj_solve_big_kernel(const TrajUtt *__restrict__ utts, int n, int D, const doub
     __syncthreads();
     for (int t = T - 1; t >= 0; --t) {
       const double *pb = ws + (size_t)t * PAN;
+      if (PK) {
+        // the panel into the (now free) window area first, by all threads: the sums and the column-by-column solve below then
+        // read LDS instead of walking HBM with one dependent load after the other (PAN <= W3 (W3 + 1) / 2 for every D)
+        for (size_t e = tid; e < PAN; e += 256) sm_big[e] = pb[e];
+        __syncthreads();
+        pb = sm_big;
+      }
       double *y1 = yring + ((t + 1) & 1) * D, *y2 = yring + (t & 1) * D;
       for (int j = tid; j < D; j += 256) {
         double sacc = pb[(size_t)W3 * D + j];
