@@ -1498,6 +1498,11 @@ static constexpr int64_t kSortMinFrames = 8192;
 #ifndef VCMI_CONVERT_WAVES
 #define VCMI_CONVERT_WAVES 4
 #endif
+// (the arg-max kernel, MODE 3, takes the eight waves as well: 3.48 -> 3.25 ms per 512k frames at D = 80; the log-density kernel,
+// MODE 1, gains nothing from them -- its two four-wave workgroups per CU already fill the register file: 3.87 / 3.85 ms)
+#ifndef VCMI_WIDE_ALL_MODES
+#define VCMI_WIDE_ALL_MODES 0
+#endif
 #ifndef VCMI_CONVERT_WAVES_WIDE
 // Waves per workgroup of the fvconvert kernels beyond D = 48 (one frame tile per wave).  A mixture's block is 46 KB (DP = 52) to
 // 102 KB (DP = 80) there, so a CU holds ONE or two workgroups: with four waves that was four to eight waves per CU, each
@@ -1520,7 +1525,7 @@ static int dispatch_mfma(const vcmi_gmmmap *g, const double *dX, int64_t ldx, in
   }
   switch (g->DP) {
 #define VCMI_CASE(DPV) \
-  case DPV: return launch_mfma<DPV, MODE, ((DPV) <= 48 ? VCMI_CONVERT_FT : 1), ((DPV) == 40 && MODE == 0 ? VCMI_CONVERT_WAVES : ((DPV) > 48 && MODE == 0 ? VCMI_CONVERT_WAVES_WIDE : 4)), PRUNE>(g, dX, ldx, T, dY, ldy, st, perm, gkey);
+  case DPV: return launch_mfma<DPV, MODE, ((DPV) <= 48 ? VCMI_CONVERT_FT : 1), ((DPV) == 40 && MODE == 0 ? VCMI_CONVERT_WAVES : ((DPV) > 48 && (MODE == 0 || MODE == 3 || VCMI_WIDE_ALL_MODES) ? VCMI_CONVERT_WAVES_WIDE : 4)), PRUNE>(g, dX, ldx, T, dY, ldy, st, perm, gkey);
     VCMI_CASE(16) VCMI_CASE(20) VCMI_CASE(24) VCMI_CASE(28) VCMI_CASE(32) VCMI_CASE(36) VCMI_CASE(40) VCMI_CASE(44)
     VCMI_CASE(48) VCMI_CASE(52) VCMI_CASE(56) VCMI_CASE(60) VCMI_CASE(64) VCMI_CASE(68) VCMI_CASE(72) VCMI_CASE(76)
     VCMI_CASE(80)
