@@ -44,7 +44,9 @@ def test_golden(vc, generic):
                                     # more than 128 mixtures: groups of 128 (responsibilities per group, combined per frame)
                                     (3000, 80, 129), (4000, 80, 256), (2500, 32, 200), (1200, 160, 130), (900, 50, 300), (65, 48, 257),
                                     # odd joint dimensions: one zero dimension more, then the even kernels (161: generic kernels)
-                                    (3000, 79, 128), (1000, 81, 200), (50, 159, 3), (700, 1, 2), (300, 161, 4)])
+                                    (3000, 79, 128), (1000, 81, 200), (50, 159, 3), (700, 1, 2), (300, 161, 4),
+                                    # the 112-wide two-kernel instantiation (Dj = 82 ... 112), also in groups of 128 mixtures
+                                    (2000, 82, 128), (900, 96, 40), (700, 112, 130), (500, 111, 9)])
 def test_vs_oracle(vc, N, Dj, M, generic):
     """Every Dj <= 160 runs the MFMA kernel: in the next larger of its instantiations 32, 48, 64, 80 and -- as two kernels,
     the responsibilities through HBM -- 160, with zero weights in the padding dimensions; more than 128 mixtures in

@@ -36,7 +36,7 @@ if what in ("convert", "both"):
 if what in ("estep", "both"):
     N = 500_000
     print("diagonal E-step, shared frames (means 3 sigma / sqrt(Dj) apart), %d frames: ms (fraction of the roof)" % N)
-    for Dj in (24, 32, 48, 50, 64, 80, 81, 100, 160):
+    for Dj in ((24, 32, 48, 50, 64, 80, 81, 100, 160) if len(sys.argv) < 3 else tuple(int(a) for a in sys.argv[2].split(","))):
         row = []
         for M in (16, 64, 128, 256):
             rg = np.random.default_rng(M + Dj)

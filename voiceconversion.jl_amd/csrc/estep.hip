@@ -1069,6 +1069,7 @@ static int estep_device_run(const double *dX, int64_t N, int Dj, int M, const do
     if (Dj <= 48) return estep_mfma_groups_launch<48>(sc, dX, N, Dj, M, w, mu, var, dstats, plen, st);
     if (Dj <= 64) return estep_mfma_groups_launch<64>(sc, dX, N, Dj, M, w, mu, var, dstats, plen, st);
     if (Dj <= 80) return estep_mfma_groups_launch<80>(sc, dX, N, Dj, M, w, mu, var, dstats, plen, st);
+    if (Dj <= 112) return estep_mfma_groups_launch<112>(sc, dX, N, Dj, M, w, mu, var, dstats, plen, st);
     return estep_mfma_groups_launch<160>(sc, dX, N, Dj, M, w, mu, var, dstats, plen, st);
   }
   if (M <= EstepCfg<80>::MMAX && Dj % 2 == 0 && Dj <= 160 && !debug_flag(kDbgEstepGeneric)) {
@@ -1077,6 +1078,8 @@ static int estep_device_run(const double *dX, int64_t N, int Dj, int M, const do
     if (Dj <= 48) return estep_mfma_launch<48>(sc, dX, N, Dj, M, w, mu, var, dstats, plen, st);
     if (Dj <= 64) return estep_mfma_launch<64>(sc, dX, N, Dj, M, w, mu, var, dstats, plen, st);
     if (Dj <= 80) return estep_mfma_launch<80>(sc, dX, N, Dj, M, w, mu, var, dstats, plen, st);
+    // (the two-kernel form beyond 80; 112 for the dimensions between -- Dj = 82 ... 112 ran in the 160-wide one: 1.5 x the work)
+    if (Dj <= 112) return estep_mfma_launch<112>(sc, dX, N, Dj, M, w, mu, var, dstats, plen, st);
     return estep_mfma_launch<160>(sc, dX, N, Dj, M, w, mu, var, dstats, plen, st);
   }
 
