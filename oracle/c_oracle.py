@@ -19,7 +19,7 @@ _ip = C.POINTER(C.c_int64)
 
 
 def build(force=False):
-    src = [os.path.join(_HERE, f) for f in ("vc_oracle.c", "vc_oracle.h", "Makefile")]
+    src = [os.path.join(_HERE, f) for f in ("vc_oracle.c", "vc_oracle_gemm.c", "vc_oracle.h", "vc_oracle_internal.h", "Makefile")]
     if os.environ.get("VCORACLE_LIB"):
         return _SO
     if force or not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in src):
@@ -31,6 +31,9 @@ def lib():
     global _lib
     if _lib is None:
         build()
+        # idle OpenMP workers sleep instead of spinning: the multi-threaded helpers are called from Python loops, with long
+        # gaps between parallel regions, on hosts whose cores are shared (must be set before libgomp initialises)
+        os.environ.setdefault("OMP_WAIT_POLICY", "passive")
         L = C.CDLL(_SO)
         L.vco_gmmmap_new.restype = C.c_void_p
         L.vco_gmmmap_new.argtypes = [_dp, _dp, _dp, C.c_int, C.c_int, C.c_int]
@@ -41,6 +44,8 @@ def lib():
         L.vco_fvconvert.argtypes = [C.c_void_p, _dp, _dp, _dp]
         L.vco_fvconvert_batch.argtypes = [C.c_void_p, _dp, C.c_int64, _dp]
         L.vco_fvconvert_batch_mt.argtypes = [C.c_void_p, _dp, C.c_int64, _dp]
+        L.vco_fvconvert_batch_gemm.argtypes = [C.c_void_p, _dp, C.c_int64, _dp]
+        L.vco_logdens.argtypes = [C.c_void_p, _dp, C.c_int64, _dp]
         L.vco_predict_proba.argtypes = [C.c_void_p, _dp, C.c_int64, _dp]
         L.vco_predict.argtypes = [C.c_void_p, _dp, C.c_int64, _ip]
         L.vco_vc_frames.argtypes = [C.c_void_p, _dp, C.c_int64, _dp]
@@ -111,6 +116,22 @@ class GMMMap:
         Y = np.empty_like(X)
         n = lib().vco_fvconvert_batch_mt(self._h, _d(X), X.shape[0], _d(Y))
         return Y, int(n)
+
+    def fvconvert_gemm(self, X):
+        """GEMM-structured, all host cores (oracle/vc_oracle_gemm.c); returns (Y, threads)"""
+        X = _f64(X)
+        Y = np.empty_like(X)
+        n = lib().vco_fvconvert_batch_gemm(self._h, _d(X), X.shape[0], _d(Y))
+        if n <= 0:
+            raise MemoryError("vco_fvconvert_batch_gemm")
+        return Y, int(n)
+
+    def logdens(self, X):
+        """lpr of src/gmm.jl:25-27: (T, M) log w_m + logpdf_m(x)"""
+        X = _f64(X)
+        L = np.empty((X.shape[0], self.M))
+        lib().vco_logdens(self._h, _d(X), X.shape[0], _d(L))
+        return L
 
     def predict_proba(self, X):
         X = _f64(X)

@@ -17,6 +17,7 @@
  * gvgrad and one step in 50-digit mpmath) and mc2e (frequency-domain evaluation with numpy.fft, no SPTK recursion).
  */
 #include "vc_oracle.h"
+#include "vc_oracle_internal.h"
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -98,15 +99,7 @@ static void matmul(const double *A, const double *B, int n, double *C) {
 /* ------------------------------------------------------------------------------------------------
  * GMMMap -- src/gmmmap.jl, src/gmm.jl
  * ---------------------------------------------------------------------------------------------- */
-struct vco_gmmmap {
-  int D, M;
-  double *w;                       /* (M) */
-  double *mux, *muy;               /* (D,M) */
-  double *Sxx, *Sxy, *Syx, *Syy;   /* (D,D,M) */
-  double *A;                       /* Sigma^yx Sigma^xx^-1, (D,D,M)  src/gmmmap.jl:33-36 */
-  double *L;                       /* Cholesky factor of Hermitian(Sigma^xx) (upper triangle mirrored), (D,D,M) */
-  double *logdet;                  /* (M) */
-};
+/* struct vco_gmmmap: vc_oracle_internal.h */
 
 vco_gmmmap *vco_gmmmap_new(const double *w, const double *mu, const double *sigma, int Dj, int M, int swap) {
   int D = Dj >> 1;                                          /* src/gmmmap.jl:70 */
@@ -271,6 +264,29 @@ void vco_predict_proba(const vco_gmmmap *g, const double *X, int64_t T, double *
   double *z = (double *)malloc(sizeof(double) * g->D);
   for (int64_t t = 0; t < T; ++t) posterior(g, X + (size_t)g->D * t, P + (size_t)g->M * t, z);
   free(z);
+}
+
+/* the log-weighted densities themselves, lpr of src/gmm.jl:25-27 before the logsumexp: L is (M,T).  What the adversarial
+ * test generator (oracle/adversarial.py) bisects on to place frames on decision boundaries. */
+void vco_logdens(const vco_gmmmap *g, const double *X, int64_t T, double *L) {
+  /* (frames are independent: OpenMP over them only shortens the generator's bisections; the arithmetic per frame is unchanged) */
+  /* at most 16 threads, one per 64 frames: the generator calls this thousands of times on a few thousand frames, and a
+   * parallel region over every core of a big (and shared) host costs more in barriers than the frames do */
+#ifdef _OPENMP
+  int nt = omp_get_max_threads();
+  if (nt > 16) nt = 16;
+  if ((int64_t)nt > (T + 63) / 64) nt = (int)((T + 63) / 64);
+  if (nt < 1) nt = 1;
+#pragma omp parallel num_threads(nt)
+#endif
+  {
+    double *z = (double *)malloc(sizeof(double) * g->D);
+#ifdef _OPENMP
+#pragma omp for schedule(static)
+#endif
+    for (int64_t t = 0; t < T; ++t) log_weighted_densities(g, X + (size_t)g->D * t, L + (size_t)g->M * t, z);
+    free(z);
+  }
 }
 
 void vco_predict(const vco_gmmmap *g, const double *X, int64_t T, int64_t *idx) {

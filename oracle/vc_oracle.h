@@ -44,6 +44,12 @@ void vco_fvconvert_batch(const vco_gmmmap *g, const double *X, int64_t T, double
 int vco_fvconvert_batch_mt(const vco_gmmmap *g, const double *X, int64_t T, double *Y);
 /* predict_proba(gmm, X) -- src/gmm.jl:24-41 ; P is (M,T) */
 void vco_predict_proba(const vco_gmmmap *g, const double *X, int64_t T, double *P);
+/* lpr of src/gmm.jl:25-27 (log w_m + logpdf_m(x), -inf for a zero weight) before the softmax; L is (M,T) */
+void vco_logdens(const vco_gmmmap *g, const double *X, int64_t T, double *L);
+/* SURVEY 8d(ii), the strong CPU baseline as specified: the same math restructured as blocked FP64 GEMMs over frame blocks
+ * (whitening with inv(L_m), regression with A_m, register-blocked micro-kernel, FMA) with OpenMP over the blocks;
+ * vc_oracle_gemm.c.  Returns the thread count.  Not a parity reference: it is checked AGAINST vco_fvconvert_batch. */
+int vco_fvconvert_batch_gemm(const vco_gmmmap *g, const double *X, int64_t T, double *Y);
 /* predict(gmm, X) -- src/gmm.jl:44-58 ; 1-based argmax, first maximum wins */
 void vco_predict(const vco_gmmmap *g, const double *X, int64_t T, int64_t *idx);
 /* vc(c::FrameByFrameConverter, fm) -- src/common.jl:7-26 ; fm and out are (D+1,T) */

@@ -203,6 +203,24 @@ def test_long_sequence_falls_back_to_two_kernels(vc, S, T):
     assert np.array_equal(newtgt, co.align(t, s)[0].T)
 
 
+@pytest.mark.parametrize("S,T,fs,bs,tables", [(500, 40_000, 0, 2, True), (320, 41_000, 0, 3, False), (200, 45_000, 1, 1, False)])
+def test_long_sequence_short_template_beyond_the_lds_path(vc, S, T, fs, bs, tables):
+    """a SEQUENCE of more than ~34k frames with a template the two-kernel fast path would take (S <= 1024, D <= 96)
+    needs 4 T bytes of path in LDS on top of the cost columns -- beyond 160 KB the launch failed (VCMI_ERR_HIP) whenever the
+    fused kernel did not apply: tables requested, bstep not in {1, 2}, fstep != 0.  These pairs now go to the generic kernel on
+    its HBM scratch.  Bit-exact path and tables (src/dtw.jl:93-145: no length limit)."""
+    from oracle import c_oracle as co
+    rng = np.random.default_rng(S + T)
+    t, s = _warped_pair(rng, S, T, 5)
+    d = vc.DTW(fstep=fs, bstep=bs)
+    if tables:
+        pref, cref, bref = co.dtw_fit(t, s, fs, bs)
+        assert np.array_equal(vc.fit_(d, t.T, s.T), pref)
+        assert np.array_equal(d.costtable, cref.T) and np.array_equal(d.backpointer, bref.T)
+    else:
+        assert np.array_equal(vc.fit_(d, t.T, s.T, tables=False), co.dtw_fit(t, s, fs, bs, tables=False))
+
+
 @pytest.mark.parametrize("S,T,bs", [(7000, 600, 2), (6100, 6400, 1)])
 def test_long_template_runs_on_an_hbm_scratch(vc, S, T, bs):
     """A TEMPLATE of more than ~5800 frames (half a minute at a 5 ms shift) no longer fits two cost columns, the path and the

@@ -98,6 +98,43 @@ def test_gmmmap_config1():
     assert np.array_equal(g.predict(z["X"]), z["idx"])
 
 
+@pytest.mark.parametrize("D,M,T,lam_lo", [(40, 64, 3001, 1e-5), (24, 8, 1000, 1e-5), (25, 5, 77, 1e-2), (7, 3, 31, 1e-1), (40, 32, 1, 1e-3)])
+def test_gemm_structured_baseline_matches_the_per_frame_oracle(D, M, T, lam_lo):
+    """bench.py's cpu_baseline_strong (the same math as blocked GEMMs + OpenMP, oracle/vc_oracle_gemm.c) is a
+    BASELINE, not a reference: it must reproduce the per-frame restatement of src/gmmmap.jl:101-118 to 1e-12 -- ragged block
+    tails, D not a multiple of the 4-row register tile, a zero-weight mixture (posterior exactly 0), fewer frames than a block."""
+    import synthdata as sd
+    w, mu, sig = sd.synth_model(900 + D + M, 2 * D, M, lam_lo=lam_lo)
+    if M >= 5:
+        w = w.copy(); w[2] = 0.0; w /= w.sum()
+    X = sd.sample_frames(901, w, mu, sig, T, 0, D)
+    g = co.GMMMap(w, mu, sig)
+    Y, nthr = g.fvconvert_gemm(X)
+    Yref = g.fvconvert(X)
+    assert nthr >= 1 and Y.shape == Yref.shape
+    assert float(np.max(np.linalg.norm(Y - Yref, axis=1) / np.linalg.norm(Yref, axis=1))) < 1e-12
+
+
+def test_gemm_baseline_on_the_reference_model(fixture_model):
+    w, mu, sig = fixture_model
+    z = load_golden("gmmmap_fixture_model.npz")
+    Y, _ = co.GMMMap(w, mu, sig).fvconvert_gemm(z["X_fwd"])
+    assert float(np.max(np.linalg.norm(Y - z["Y_fwd"], axis=1) / np.linalg.norm(z["Y_fwd"], axis=1))) < 1e-11
+
+
+def test_logdens_is_the_posterior_before_the_softmax(fixture_model):
+    """vco_logdens (lpr of src/gmm.jl:25-27) -- the quantity oracle/adversarial.py bisects on -- against the golden posteriors
+    and against numpy's independent restatement."""
+    from scipy.special import logsumexp
+    w, mu, sig = fixture_model
+    z = load_golden("gmmmap_fixture_model.npz")
+    L = co.GMMMap(w, mu, sig).logdens(z["X_fwd"])
+    P = np.exp(L - logsumexp(L, axis=1, keepdims=True))
+    assert np.max(np.abs(P - z["P_fwd"])) < 1e-10                       # (the golden posteriors come from the numpy restatement)
+    assert np.max(np.abs(P - co.GMMMap(w, mu, sig).predict_proba(z["X_fwd"]))) < 1e-13
+    assert np.array_equal(np.argmax(L, axis=1) + 1, z["idx_fwd"])
+
+
 def test_not_positive_definite_is_reported(fixture_model):
     w, mu, sig = fixture_model
     bad = sig.copy()

@@ -1344,12 +1344,14 @@ static int dtw_run(const double *feats, std::vector<DtwPair> &pairs, int D, int 
     return (int64_t)a.S * a.T > (int64_t)b.S * b.T;
   });
   const int bits = (fstep + bstep + 1 <= 4) ? 2 : 8;
-  const bool fast = (Smax <= 1024 && D <= 96);
   const size_t base = (size_t)2 * Smax * 8 + (size_t)Tmax * 4 + (size_t)2 * Smax * 4;
   const size_t base_generic = base;
+  // two cost columns + path + lists beyond LDS (a template of > ~5800 frames, or a SEQUENCE of > ~34k frames whatever the
+  // template: the path alone is 4 T bytes): the generic kernel on an HBM scratch -- the two-kernel fast path keeps them in LDS
+  const bool longseq = base > kLdsLimit;
+  const bool fast = (Smax <= 1024 && D <= 96 && !longseq);
   const size_t codes_lds = (size_t)((Tmax + (32 / bits) - 1) / (32 / bits)) * Smax * 4;
   const bool ldscodes = fast && (base + codes_lds <= kLdsLimit);
-  const bool longseq = base > kLdsLimit;       // two cost columns + path + lists beyond LDS: the generic kernel on an HBM scratch
   if (!ldscodes) {
     size_t total = 0;
     for (auto &p : pairs) total += (size_t)p.S * p.T;
