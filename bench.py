@@ -514,6 +514,17 @@ def bench_convert(args, world, rank, variant="synthetic"):
                      "model_active_frac": active_frac, "model_undecided_frac": undecided_frac,
                      "hbm_GBps_algorithmic": 2 * D * 8 * T / (kernel_ms * 1e-3) / 1e9},
     }
+    if shape == 3:
+        # The screened shape proves 63 of the 64 mixtures irrelevant for (nearly) every frame and never evaluates them: the
+        # SURVEY 8(d) flop count is not performed (fp64_formulation_frac > 1 says exactly that), and the FP64 roof does not bind a
+        # pass that reads x and writes y once.  Priced like the E-step's hard-assignment path: against HBM, with the ALGORITHMIC
+        # bytes (2 D 8 per frame: x in, y out) over the step's kernel time.  The FP64 credit of this configuration is `dense`.
+        gbs = 2.0 * D * 8 * T / (kernel_ms * 1e-3) / 1e9
+        out["roofline"].update({"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                                "algorithmic_bytes_per_frame": 2 * D * 8,
+                                "fp64_formulation_frac": out["roofline"].pop("algorithmic_frac"),
+                                "fp64_formulation_note": "flops of the every-mixture formulation over this step's time; the screen rules "
+                                                         "them out without performing them (see `dense` for the FP64 figure)"})
     # HBM traffic of the kernel: PMC passes of this same command, run as child processes before the timed run (LIVE_PMC)
     # or, failing that, the committed passes if they were collected from the same library sources
     if headline:
@@ -1187,7 +1198,9 @@ def bench_selftest(args, world, rank):
     PER_RANK["wall_s"] = gather_over_ranks(wall, world)
     return {"metric": "launch self-test (no kernels)", "value": 0.0, "unit": "n/a", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": wall / max(args.steps, 1) * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f64", "data": "synthetic", "config": {"workload": "selftest"},
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "selftest", "sharding": f"one rank per GPU x{world}; frames / pairs / utterances split by rank, E-step statistics all-reduced"},
+            "collective": {"op": "all-reduce(sum), %d doubles" % n, "ranks": world, "backend": BACKEND["name"]},
             "allreduce_exact": ok}
 
 
@@ -1205,7 +1218,8 @@ def summarize(out):
 
 LINE_CAP = 7500           # characters of the ONE stdout line (the driver keeps an 8 KB tail; BENCH_r04 lost a 20.9 KB line)
 ROOF_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "kernel_ms", "algorithmic_frac", "issued_mfma_frac",
-             "traffic_whole_step", "traffic_x_algorithmic", "traffic_GBps", "hbm_frac", "soft_frac", "fp64_formulation_tflops")
+             "traffic_whole_step", "traffic_x_algorithmic", "traffic_GBps", "hbm_frac", "soft_frac", "fp64_formulation_tflops",
+             "fp64_formulation_frac")
 
 
 def _sig(x, n=6):

@@ -97,6 +97,10 @@ int vcmi_gmmmap_convert_dev(vcmi_gmmmap *g, const double *dX, int64_t ldx, int64
                             void *stream);
 /* vc(c::FrameByFrameConverter, fm), src/common.jl:7-26: fm, out are (D+1,T); row 1 (power) is copied. */
 int vcmi_vc_frames(vcmi_gmmmap *g, const double *fm, int64_t T, double *out);
+/* ... with the VarianceScaling post-filter (src/gv.jl:10-15) as a fused post step: out[2:end,:] = fvpostf(VarianceScaling(sigma2),
+ * vc(g, fm)[2:end,:]); sigma2 (D) host vector, NULL = plain vcmi_vc_frames.  The converted matrix never leaves HBM between the
+ * conversion and the filter: one upload, one download. */
+int vcmi_vc_frames_postf(vcmi_gmmmap *g, const double *fm, int64_t T, const double *sigma2, double *out);
 /* predict_proba(g.px, X) -> P (M,T), src/gmm.jl:24-41 */
 int vcmi_gmmmap_posterior(vcmi_gmmmap *g, const double *X, int64_t ldx, int64_t T, double *P);
 int vcmi_gmmmap_posterior_dev(vcmi_gmmmap *g, const double *dX, int64_t ldx, int64_t T, double *dP, void *stream);
@@ -236,8 +240,15 @@ int vcmi_traj_convert_batch_dev(vcmi_traj *t, int64_t n, const double *dX, const
                                 double *dY, const int64_t *y_off, void *stream);
 /* vc(c::TrajectoryConverter, fm (2D+1,T)) -> out (D+1,T) in chunks of length(t) frames; src/common.jl:31-63 */
 int vcmi_vc_traj(vcmi_traj *t, const double *fm, int64_t T, double *out);
-/* push_delta(src (D,T)) -> out (2D,T); src/datasets.jl:6-13 (host-side helper, O(DT)) */
+/* push_delta(src (D,T)) -> out (2D,T); src/datasets.jl:6-13.  Host matrices, host arithmetic (O(DT), no device needed). */
 int vcmi_push_delta(const double *src, int D, int64_t T, double *out);
+/* ... and on DEVICE-RESIDENT matrices with leading dimensions (lds >= D, ldo >= 2D), asynchronous on `stream`: the input of
+ * the trajectory conversion is built where the features already are (bin/vc.jl:75-78 builds it in front of vc). */
+int vcmi_push_delta_dev(const double *dsrc, int64_t lds, int D, int64_t T, double *dout, int64_t ldo, void *stream);
+/* vc(c::TrajectoryConverter, fm) with the VarianceScaling post-filter (src/gv.jl:10-15) applied to the converted rows
+ * 2..D+1 BEFORE the download: out[2:end,:] = fvpostf(VarianceScaling(sigma2), vc(t, fm)[2:end,:]); sigma2 (D) host vector,
+ * NULL = plain vcmi_vc_traj.  One upload, one download; everything in between stays in HBM. */
+int vcmi_vc_traj_postf(vcmi_traj *t, const double *fm, int64_t T, const double *sigma2, double *out);
 
 /* ---------------------------------------------------------------------------------------------
  * TrajectoryGVGMMMap -- src/trajectory_gmmmap.jl:114-189
@@ -257,6 +268,10 @@ int vcmi_trajgv_convert_batch_dev(vcmi_trajgv *h, int64_t n, const double *dX, c
 
 /* fvpostf(vs::VarianceScaling, src) -- src/gv.jl:10-21.  src, out (D,T), sigma2 (D); out may alias src. */
 int vcmi_variance_scaling(const double *src, int D, int64_t T, const double *sigma2, double *out);
+/* fvpostf! on a DEVICE-RESIDENT matrix (leading dimensions lds, ldo >= D; dout may be dsrc: in place), asynchronous on
+ * `stream`; sigma2 (D) is a host vector.  Deterministic: every sum has a fixed order. */
+int vcmi_variance_scaling_dev(const double *dsrc, int64_t lds, int D, int64_t T, const double *sigma2, double *dout,
+                              int64_t ldo, void *stream);
 /* diffgmm(params) -- src/diffgmm.jl:9-25 on joint parameters mu (2D,M), sigma (2D,2D,M); host arithmetic. */
 int vcmi_diffgmm(const double *mu, const double *sigma, int Dj, int M, double *mu_out, double *sigma_out);
 

@@ -28,6 +28,21 @@ def test_self_launch_two_ranks_gloo():
     assert len(out["per_rank"]["wall_s"]) == 2
 
 
+def test_self_launch_eight_ranks_gloo():
+    """the launch path of `bench.py --gpus 8` -- eight child ranks over gloo, the barrier-bracketed region,
+    the max over ranks, the statistics-sized all-reduce -- emits exactly ONE line whose collective names eight ranks and whose
+    config names the split, so that on the first 8-GPU node the only unknown left is RCCL itself (nothing in this tree has run
+    on two physical GPUs: README)."""
+    p = _run(["--gpus", "8", "--workload", "selftest", "--steps", "2"], {"VCMI_BENCH_BACKEND": "gloo"}, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["collective"]["ranks"] == 8 and out["collective"]["backend"] == "gloo"
+    assert "x8" in out["config"]["sharding"] and out["allreduce_exact"] is True
+    assert len(out["per_rank"]["wall_s"]) == 8 and out["scaling"] == "weak"
+
+
 def test_rank_count_mismatch_is_refused():
     p = _run(["--gpus", "2", "--workload", "selftest"], {"WORLD_SIZE": "1", "RANK": "0", "VCMI_BENCH_BACKEND": "gloo"})
     assert p.returncode == 2 and "refusing to run" in p.stderr

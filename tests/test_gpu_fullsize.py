@@ -66,18 +66,56 @@ def test_config4_dtw_1000_pairs(vc):
         assert np.array_equal(paths[k], co.dtw_fit(t, s, 0, 2, tables=False)), k
 
 
-def test_config5_trajectory_T2000(vc):
-    """configs[4]: static D=40 (X dim 80), M=64, T=2000.  One utterance against the oracle, a batch of identical
-    utterances gives identical outputs, and the result is finite."""
+def test_config2_convert_1M_distinct_frames_sampled_at_random_offsets(vc):
+    """configs[1] at full size with 10^6 DISTINCT frames (not a tile repeated): 512 frames at seeded random positions -- the
+    last, partial workgroup's included -- against the oracle, on the device path and through host pointers (chunked pipeline),
+    in the caller's order although the kernel works on grouped frames; a second run is bit-identical; and the same 512 frames
+    converted on their own (an utterance-sized call: ungrouped, other tiles) agree to rounding."""
+    import torch
     from oracle import c_oracle as co, np_oracle as npo
-    D, M, T = 40, 64, 2000
+    D, M, T = 40, 64, 1_000_000
+    w, mu, sig = npo.synth_model(1002, 2 * D, M)
+    X = npo.sample_frames(20_002, w, mu, sig, T, 0, D)
+    g = vc.GMMMap(*julia_model(w, mu, sig))
+    Xd = torch.from_numpy(X).cuda()
+    Y = vc.fvconvert(g, Xd.t()).t()
+    assert bool(torch.isfinite(Y).all()) and torch.equal(Y, vc.fvconvert(g, Xd.t()).t())
+    rng = np.random.default_rng(77)
+    pos = np.unique(np.concatenate([rng.choice(T - 64, size=448, replace=False), np.arange(T - 64, T)]))     # 1e6 % 128 = 64
+    ref = co.GMMMap(w, mu, sig).fvconvert(X[pos])
+    got = Y[torch.from_numpy(pos).cuda()].cpu().numpy()
+    err = np.linalg.norm(got - ref, axis=1) / np.linalg.norm(ref, axis=1)
+    assert err.max() < 1e-9, (float(err.max()), int(pos[np.argmax(err)]))
+    small = vc.fvconvert(g, np.asfortranarray(X[pos].T)).T
+    assert (np.linalg.norm(small - got, axis=1) / np.linalg.norm(got, axis=1)).max() < 1e-13
+    Yh = vc.fvconvert(g, np.asfortranarray(X.T))               # host pointers: 320 MB up, 320 MB down, chunks grouped one by one
+    errh = np.linalg.norm(Yh.T[pos] - ref, axis=1) / np.linalg.norm(ref, axis=1)
+    assert errh.max() < 1e-9
+    assert (np.linalg.norm(Yh.T - Y.cpu().numpy(), axis=1) / np.linalg.norm(Yh.T, axis=1)).max() < 1e-13
+
+
+def test_config5_trajectory_T2000(vc):
+    """configs[4]: static D=40 (X dim 80), M=64, T about 2000.  SIXTEEN DIFFERENT utterances of unequal length (1900..2100
+    frames) in one batch, each against the oracle; a batch of identical utterances gives identical outputs; one utterance
+    alone equals its result in the batch bit for bit."""
+    from oracle import c_oracle as co, np_oracle as npo
+    D, M = 40, 64
     w, mu, sig = npo.synth_model(1005, 4 * D, M, lam_lo=1e-3)
     g = vc.GMMMap(*julia_model(w, mu, sig))
-    tj = vc.TrajectoryGMMMap(g, T)
-    st = npo.sample_frames(7, w, mu, sig, T, 0, D)
-    st = np.cumsum(st, axis=0) / np.sqrt(np.arange(1, T + 1))[:, None]
-    X = npo.push_delta(st)
-    Ys = tj.fvconvert_batch([X.T] * 6)
-    assert all(np.array_equal(Ys[0], y) for y in Ys[1:]) and np.all(np.isfinite(Ys[0]))
-    Yref, _, _ = co.TrajectoryGMMMap(co.GMMMap(w, mu, sig)).fvconvert(X)
-    assert relerr(Ys[0], Yref.T) < 1e-6
+    tj = vc.TrajectoryGMMMap(g, 2000)
+    rng = np.random.default_rng(1005)
+    Ts = [2000] + [int(v) for v in rng.integers(1900, 2101, size=15)]
+    Xs = []
+    for k, T in enumerate(Ts):
+        st = npo.sample_frames(7 + k, w, mu, sig, T, 0, D)
+        st = np.cumsum(st, axis=0) / np.sqrt(np.arange(1, T + 1))[:, None]
+        Xs.append(npo.push_delta(st))
+    Ys = tj.fvconvert_batch([X.T for X in Xs])
+    ref = co.TrajectoryGMMMap(co.GMMMap(w, mu, sig))
+    for X, Y in zip(Xs, Ys):
+        assert Y.shape == (D, X.shape[0]) and np.all(np.isfinite(Y))
+        Yref, _, _ = ref.fvconvert(X)
+        assert relerr(Y, Yref.T) < 1e-6
+    same = tj.fvconvert_batch([Xs[0].T] * 6)
+    assert all(np.array_equal(same[0], y) for y in same[1:]) and np.array_equal(same[0], Ys[0])
+    assert np.array_equal(tj.fvconvert_batch([Xs[5].T])[0], Ys[5])

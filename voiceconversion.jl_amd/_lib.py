@@ -71,6 +71,7 @@ SIGNATURES = {
     "vcmi_gmmmap_convert": (_int, [_vp, _dp, _i64, _i64, _dp, _i64]),
     "vcmi_gmmmap_convert_dev": (_int, [_vp, _vp, _i64, _i64, _vp, _i64, _vp]),
     "vcmi_vc_frames": (_int, [_vp, _dp, _i64, _dp]),
+    "vcmi_vc_frames_postf": (_int, [_vp, _dp, _i64, _dp, _dp]),
     "vcmi_gmmmap_posterior": (_int, [_vp, _dp, _i64, _i64, _dp]),
     "vcmi_gmmmap_posterior_dev": (_int, [_vp, _vp, _i64, _i64, _vp, _vp]),
     "vcmi_gmmmap_predict": (_int, [_vp, _dp, _i64, _i64, _ip]),
@@ -103,12 +104,15 @@ SIGNATURES = {
     "vcmi_traj_convert_batch_dev": (_int, [_vp, _i64, _vp, _ip, _ip, _vp, _ip, _vp]),
     "vcmi_vc_traj": (_int, [_vp, _dp, _i64, _dp]),
     "vcmi_push_delta": (_int, [_dp, _int, _i64, _dp]),
+    "vcmi_push_delta_dev": (_int, [_vp, _i64, _int, _i64, _vp, _i64, _vp]),
+    "vcmi_vc_traj_postf": (_int, [_vp, _dp, _i64, _dp, _dp]),
     "vcmi_trajgv_create": (_int, [_vp, _dp, _dp, C.POINTER(_vp)]),
     "vcmi_trajgv_destroy": (_int, [_vp]),
     "vcmi_trajgv_convert": (_int, [_vp, _dp, _i64, _int, C.c_double, _dp]),
     "vcmi_trajgv_convert_batch": (_int, [_vp, _i64, _dpp, _ip, _int, C.c_double, _dpp]),
     "vcmi_trajgv_convert_batch_dev": (_int, [_vp, _i64, _vp, _ip, _ip, _int, C.c_double, _vp, _ip, _vp]),
     "vcmi_variance_scaling": (_int, [_dp, _int, _i64, _dp, _dp]),
+    "vcmi_variance_scaling_dev": (_int, [_vp, _i64, _int, _i64, _dp, _vp, _i64, _vp]),
     "vcmi_diffgmm": (_int, [_dp, _dp, _int, _int, _dp, _dp]),
     "vcmi_mc2e": (_int, [_dp, _int, _i64, C.c_double, _int, _dp]),
     "vcmi_align_mcep": (_int, [_dp, _i64, _dp, _i64, _int, C.c_double, _int, C.c_double, _int, _dp, _dp, _ip]),
@@ -175,6 +179,8 @@ def get_devices():
 def pin(a):
     """Page-lock a host array once (vcmi_host_register): calls that pass it afterwards DMA straight from / into it.
     The array must stay alive and must be unpinned before it is freed; returns the array."""
+    if not (a.flags.c_contiguous or a.flags.f_contiguous):
+        raise ValueError("pin: the array must be contiguous (a.nbytes would not describe the memory of a strided view)")
     check(lib.vcmi_host_register(a.ctypes.data, a.nbytes))
     return a
 

@@ -21,6 +21,7 @@
 #include "devgroup.hpp"
 #include "hostpipe.hpp"
 #include "lds_dma.hpp"
+#include "postf.hpp"
 
 #include <algorithm>
 #include <cstdlib>
@@ -954,52 +955,6 @@ traj_gv2_kernel(const TrajUtt *__restrict__ utts, int n, int D, int M, int KS, i
   }
 }
 
-// fvpostf!(vs::VarianceScaling, src), src/gv.jl:10-15, for a matrix of any length: three streaming passes (sums,
-// centred squares, scale) over frame chunks, every reduction in a fixed order (deterministic).
-//   vs_partial_kernel: part[chunk][d] = sum over the chunk's frames of x (MODE 0) or (x - mean[d])^2 (MODE 1)
-//   vs_final_kernel:   stat[d] = sum_chunk part[chunk][d] / denom
-static constexpr int kVsChunk = 2048;   // frames per workgroup
-template <int MODE>
-__global__ void __launch_bounds__(256)
-vs_partial_kernel(const double *__restrict__ src, int D, int64_t T, const double *__restrict__ mean, double *__restrict__ part) {
-  extern __shared__ double vred[];       // [NG][D]
-  const int tid = threadIdx.x, NG = 256 / D, d = tid % D, g = tid / D;
-  const int64_t f0 = (int64_t)blockIdx.x * kVsChunk, f1 = (f0 + kVsChunk < T) ? f0 + kVsChunk : T;
-  double s = 0.0;
-  if (g < NG) {
-    const double m = MODE ? mean[d] : 0.0;
-    for (int64_t t = f0 + g; t < f1; t += NG) {
-      const double e = src[(size_t)t * D + d] - m;
-      s = MODE ? fma(e, e, s) : s + e;
-    }
-    vred[g * D + d] = s;
-  }
-  __syncthreads();
-  if (tid < D) {
-    double a = 0.0;
-    for (int k = 0; k < NG; ++k) a += vred[k * D + tid];
-    part[(size_t)blockIdx.x * D + tid] = a;
-  }
-}
-
-__global__ void __launch_bounds__(256)
-vs_final_kernel(const double *__restrict__ part, int nchunks, int D, double denom, double *__restrict__ stat) {
-  const int d = threadIdx.x;
-  if (d >= D) return;
-  double a = 0.0;
-  for (int c = 0; c < nchunks; ++c) a += part[(size_t)c * D + d];
-  stat[d] = a / denom;
-}
-
-__global__ void __launch_bounds__(256)
-vs_scale_kernel(const double *__restrict__ src, int D, int64_t n, const double *__restrict__ sigma2,
-                const double *__restrict__ mean, const double *__restrict__ var, double *__restrict__ out) {
-  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
-    const int d = (int)(e % D);
-    out[e] = sqrt(sigma2[d] / var[d]) * (src[e] - mean[d]) + mean[d];
-  }
-}
-
 // g (frames x [gs (D); gd (D)]) -> gpad (frames x [gs (Dp); gd (Dp)]), zeros in the padding
 __global__ void __launch_bounds__(256)
 traj_pad_g_kernel(const double *__restrict__ g, int64_t nframes, int D, int Dp, double *__restrict__ gpad) {
@@ -1667,16 +1622,39 @@ extern "C" int vcmi_vc_traj(vcmi_traj *t, const double *fm, int64_t T, double *o
   return VCMI_OK;
 }
 
-extern "C" int vcmi_push_delta(const double *src, int D, int64_t T, double *out) {
-  if (!src || !out || D < 1 || T < 0) return fail(VCMI_ERR_ARG, "vcmi_push_delta: bad argument");
-  for (int64_t t = 0; t < T; ++t)
-    for (int d = 0; d < D; ++d) {   // repmat(src, 2), src/datasets.jl:8
-      out[d + (size_t)2 * D * t] = src[d + (size_t)D * t];
-      out[D + d + (size_t)2 * D * t] = src[d + (size_t)D * t];
-    }
-  for (int64_t t = 1; t + 1 < T; ++t)   // t = 2:T-1, src/datasets.jl:9-11
-    for (int d = 0; d < D; ++d)
-      out[D + d + (size_t)2 * D * t] = -0.5 * src[d + (size_t)D * (t - 1)] + 0.5 * src[d + (size_t)D * (t + 1)];
+// vc(c::TrajectoryConverter, fm) followed by fvpostf!(VarianceScaling(sigma2), converted[2:end, :]) -- src/common.jl:31-63,
+// src/gv.jl:10-15 -- with the matrix resident in HBM from the upload of fm to the download of the filtered result: the power
+// row and the (2D,T) feature rows are split on the device, the chunks are converted by the device-resident batch path, the
+// post-filter runs on the (D,T) result and the output matrix is assembled on the device.
+extern "C" int vcmi_vc_traj_postf(vcmi_traj *t, const double *fm, int64_t T, const double *sigma2, double *out) {
+  if (!sigma2) return vcmi_vc_traj(t, fm, T, out);
+  if (!t) return fail(VCMI_ERR_ARG, "vcmi_vc_traj_postf: NULL handle");
+  if (T < 0 || (T > 0 && (!fm || !out))) return fail(VCMI_ERR_ARG, "vcmi_vc_traj_postf: bad argument");
+  if (T == 0) return VCMI_OK;
+  if (T < 2) return fail(VCMI_ERR_DIM, "vcmi_vc_traj_postf: the variance of a one-frame matrix is undefined");
+  if (t->length < 1) return fail(VCMI_ERR_ARG, "vcmi_vc_traj_postf: length(t) must be positive");
+  VCMI_TRY(check_device());
+  const int D = t->D, D2 = t->D2;
+  const int64_t L = t->length, nch = (T + L - 1) / L;   // chunks [kL+1, min((k+1)L, T)], src/common.jl:42-57
+  static thread_local DevBuf<double> dfm, dx, dy, dout;
+  VCMI_TRY(dfm.reserve((size_t)(D2 + 1) * T));
+  VCMI_TRY(dx.reserve((size_t)D2 * T));
+  VCMI_TRY(dy.reserve((size_t)D * T));
+  VCMI_TRY(dout.reserve((size_t)(D + 1) * T));
+  VCMI_TRY(staged_upload(dfm.p, fm, sizeof(double) * (size_t)(D2 + 1) * T, nullptr));
+  VCMI_TRY(copy_rows_device(dfm.p, D2 + 1, 1, D2, T, dx.p, D2, 0, nullptr));
+  VCMI_TRY(copy_rows_device(dfm.p, D2 + 1, 0, 1, T, dout.p, D + 1, 0, nullptr));         // power row kept, src/common.jl:60
+  std::vector<int64_t> xo(nch), yo(nch), Ts(nch);
+  for (int64_t k = 0; k < nch; ++k) {
+    xo[k] = k * L * D2;
+    yo[k] = k * L * D;
+    Ts[k] = std::min<int64_t>(L, T - k * L);
+  }
+  VCMI_TRY(vcmi_traj_convert_batch_dev(t, nch, dx.p, xo.data(), Ts.data(), dy.p, yo.data(), nullptr));
+  VCMI_TRY(variance_scaling_device(dy.p, D, D, T, sigma2, dy.p, D, nullptr));
+  VCMI_TRY(copy_rows_device(dy.p, D, 0, D, T, dout.p, D + 1, 1, nullptr));
+  VCMI_TRY(staged_download(out, dout.p, sizeof(double) * (size_t)(D + 1) * T, nullptr));
+  t->length = Ts[nch - 1];   // as vcmi_vc_traj: the last fvconvert of the loop left W at the last chunk's length
   return VCMI_OK;
 }
 
@@ -1768,33 +1746,6 @@ extern "C" int vcmi_trajgv_convert_batch_dev(vcmi_trajgv *h, int64_t n, const do
   if (f0 == 0) return VCMI_OK;
   VCMI_TRY(traj_run(t, utts, f0, contiguous, dX + x_off[0], as_stream(stream), &gv));
   return traj_check_status(t, as_stream(stream));
-}
-
-// fvpostf(vs::VarianceScaling, src) -- src/gv.jl:10-21.  src, out (D,T) host matrices (may alias), sigma2 (D).
-extern "C" int vcmi_variance_scaling(const double *src, int D, int64_t T, const double *sigma2, double *out) {
-  if (!src || !sigma2 || !out) return fail(VCMI_ERR_ARG, "vcmi_variance_scaling: NULL argument");
-  if (D < 1 || D > 256 || T < 2)
-    return fail(VCMI_ERR_DIM, "vcmi_variance_scaling: D=%d T=%lld unsupported (needs 1 <= D <= 256, T >= 2)", D, (long long)T);
-  VCMI_TRY(check_device());
-  DevBuf<double> dsrc, dout, dsig, dpart, dstat;
-  const int nchunks = (int)((T + kVsChunk - 1) / kVsChunk);
-  VCMI_TRY(dsrc.alloc((size_t)D * T));
-  VCMI_TRY(dout.alloc((size_t)D * T));
-  VCMI_TRY(dsig.alloc(D));
-  VCMI_TRY(dpart.alloc((size_t)nchunks * D));
-  VCMI_TRY(dstat.alloc((size_t)2 * D));
-  VCMI_HIP(hipMemcpy(dsrc.p, src, sizeof(double) * D * T, hipMemcpyHostToDevice));
-  VCMI_HIP(hipMemcpy(dsig.p, sigma2, sizeof(double) * D, hipMemcpyHostToDevice));
-  const size_t shm = (size_t)(256 / D) * D * sizeof(double);
-  double *mean = dstat.p, *var = dstat.p + D;
-  hipLaunchKernelGGL(vs_partial_kernel<0>, dim3(nchunks), dim3(256), shm, nullptr, dsrc.p, D, T, mean, dpart.p);
-  hipLaunchKernelGGL(vs_final_kernel, dim3(1), dim3(256), 0, nullptr, dpart.p, nchunks, D, (double)T, mean);
-  hipLaunchKernelGGL(vs_partial_kernel<1>, dim3(nchunks), dim3(256), shm, nullptr, dsrc.p, D, T, mean, dpart.p);
-  hipLaunchKernelGGL(vs_final_kernel, dim3(1), dim3(256), 0, nullptr, dpart.p, nchunks, D, (double)(T - 1), var);   // Julia's var
-  hipLaunchKernelGGL(vs_scale_kernel, dim3(2048), dim3(256), 0, nullptr, dsrc.p, D, (int64_t)D * T, dsig.p, mean, var, dout.p);
-  VCMI_HIP(hipGetLastError());
-  VCMI_HIP(hipMemcpy(out, dout.p, sizeof(double) * D * T, hipMemcpyDeviceToHost));
-  return VCMI_OK;
 }
 
 // diffgmm(params) -- src/diffgmm.jl:9-25, on the joint parameters mu (2D,M), sigma (2D,2D,M) (host arithmetic: a

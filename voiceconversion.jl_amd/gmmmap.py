@@ -109,10 +109,15 @@ class GMMMap(FrameByFrameConverter):
         _lib.check(_lib.lib.vcmi_gmmmap_convert(self._h, _lib.dptr(X), D, T, _lib.dptr(Y), D))
         return Y
 
-    def _vc(self, fm):                           # src/common.jl:7-26
+    def _vc(self, fm, postfilter=None):          # src/common.jl:7-26 (+ fvpostf! of src/gv.jl:10-15 before the download)
         fm = jl_matrix(fm, "fm")
         if fm.shape[0] != self._D + 1:
             raise _lib.DimensionMismatch("Inconsistent dimentions.")
         out = np.empty_like(fm, order="F")
-        _lib.check(_lib.lib.vcmi_vc_frames(self._h, _lib.dptr(fm), fm.shape[1], _lib.dptr(out)))
+        if postfilter is None:
+            _lib.check(_lib.lib.vcmi_vc_frames(self._h, _lib.dptr(fm), fm.shape[1], _lib.dptr(out)))
+        else:
+            if postfilter.sigma2.shape != (self._D,):
+                raise _lib.DimensionMismatch("sigma2 must have one entry per converted feature row")
+            _lib.check(_lib.lib.vcmi_vc_frames_postf(self._h, _lib.dptr(fm), fm.shape[1], _lib.dptr(postfilter.sigma2), _lib.dptr(out)))
         return out

@@ -2,7 +2,7 @@
 import numpy as np
 
 from . import _lib
-from ._arrays import jl_matrix
+from ._arrays import current_stream_ptr, dev_matrix, is_torch, jl_matrix
 
 
 class VarianceScaling:
@@ -14,7 +14,10 @@ class VarianceScaling:
 
 def fvpostf(vs, src):
     """fvpostf(vs, src (D,T)): per row sqrt(sigma2 / var) * (x - mean) + mean with Julia's corrected variance;
-    src/gv.jl:10-21"""
+    src/gv.jl:10-21.  A torch tensor on the device is filtered where it is (a new device tensor is returned)."""
+    if is_torch(src):
+        out = src.clone(memory_format=__import__("torch").preserve_format)
+        return fvpostf_(vs, out)
     src = jl_matrix(src, "src")
     D, T = src.shape
     if vs.sigma2.shape != (D,):
@@ -25,7 +28,15 @@ def fvpostf(vs, src):
 
 
 def fvpostf_(vs, src):
-    """fvpostf!(vs, src): in place (src must be a Fortran-ordered float64 array); src/gv.jl:10-15"""
+    """fvpostf!(vs, src): in place; src/gv.jl:10-15.  Device tensors ((D,T), unit stride along D: e.g. the rows 2..D+1 of a
+    converted (D+1,T) matrix, `out[1:]`) are filtered in HBM on the current stream (vcmi_variance_scaling_dev); host arrays
+    must be Fortran-ordered float64."""
+    if is_torch(src):
+        ptr, D, T, ld = dev_matrix(src, "src")
+        if vs.sigma2.shape != (D,):
+            raise _lib.DimensionMismatch("sigma2 must have one entry per feature row")
+        _lib.check(_lib.lib.vcmi_variance_scaling_dev(ptr, ld, D, T, _lib.dptr(vs.sigma2), ptr, ld, current_stream_ptr()))
+        return src
     src[...] = fvpostf(vs, src)
     return src
 

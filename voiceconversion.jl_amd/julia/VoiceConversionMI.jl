@@ -18,7 +18,7 @@ module VoiceConversionMI
 
 import LinearAlgebra
 
-export FrameByFrameConverter, TrajectoryConverter, GMMMapParam, GMMMap, TrajectoryGMMMap, TrajectoryGVGMMMap,
+export DeviceMatrix, FrameByFrameConverter, TrajectoryConverter, GMMMapParam, GMMMap, TrajectoryGMMMap, TrajectoryGVGMMMap,
        fvconvert, vc, ncomponents, dim,
        VarianceScaling, fvpostf!, fvpostf,
        align, align_mcep, push_delta, GVDataset,
@@ -499,6 +499,48 @@ end
 function fvpostf!(vs::VarianceScaling, src::Matrix{Float64})          # in place: the library allows out == src
     check(ccall((:vcmi_variance_scaling, libvcmi), Cint, (Ptr{Float64}, Cint, Int64, Ptr{Float64}, Ptr{Float64}),
                 src, size(src, 1), size(src, 2), vs.σ², src))
+    src
+end
+
+# ---- the steps either side of vc without leaving HBM (SURVEY 8(f) rank 4) -------------------------------------------
+# vc(c, fm, vs): out[2:end, :] = fvpostf(vs, vc(c, fm)[2:end, :]) -- src/common.jl:7-63 followed by src/gv.jl:10-15, the
+# converted matrix filtered on the device before it is downloaded (one upload, one download)
+function vc(g::GMMMap, fm::Matrix{Float64}, vs::VarianceScaling)
+    size(fm, 1) == dim(g) + 1 || throw(DimensionMismatch("Inconsistent dimentions."))
+    length(vs.σ²) == dim(g) || throw(DimensionMismatch("σ² must have one entry per converted feature row"))
+    out = similar(fm)
+    check(ccall((:vcmi_vc_frames_postf, libvcmi), Cint, (Ptr{Cvoid}, Ptr{Float64}, Int64, Ptr{Float64}, Ptr{Float64}),
+                g.h, fm, size(fm, 2), vs.σ², out))
+    out
+end
+function vc(t::TrajectoryGMMMap, fm::Matrix{Float64}, vs::VarianceScaling)
+    size(fm, 1) == dim(t) + 1 || throw(DimensionMismatch("Inconsistent dimentions."))
+    length(vs.σ²) == dim(t) >> 1 || throw(DimensionMismatch("σ² must have one entry per converted feature row"))
+    out = Matrix{Float64}(undef, (size(fm, 1) - 1) >> 1 + 1, size(fm, 2))
+    check(ccall((:vcmi_vc_traj_postf, libvcmi), Cint, (Ptr{Cvoid}, Ptr{Float64}, Int64, Ptr{Float64}, Ptr{Float64}),
+                t.h, fm, size(fm, 2), vs.σ², out))
+    out
+end
+
+# A Float64 matrix that lives in HBM: device address, shape and leading dimension (what a GPU array package, or the
+# library's own `_dev` entry points, hand around).  push_delta and fvpostf! on it run where the data is, on `stream`.
+struct DeviceMatrix
+    ptr::Ptr{Float64}
+    rows::Int
+    cols::Int
+    ld::Int
+end
+function push_delta(src::DeviceMatrix, out::DeviceMatrix; stream::Ptr{Cvoid}=C_NULL)      # src/datasets.jl:6-13
+    (out.rows == 2src.rows && out.cols == src.cols) || throw(DimensionMismatch("out must be (2D,T)"))
+    check(ccall((:vcmi_push_delta_dev, libvcmi), Cint, (Ptr{Float64}, Int64, Cint, Int64, Ptr{Float64}, Int64, Ptr{Cvoid}),
+                src.ptr, src.ld, src.rows, src.cols, out.ptr, out.ld, stream))
+    out
+end
+function fvpostf!(vs::VarianceScaling, src::DeviceMatrix; stream::Ptr{Cvoid}=C_NULL)      # src/gv.jl:10-15, in place
+    length(vs.σ²) == src.rows || throw(DimensionMismatch("σ² must have one entry per feature row"))
+    check(ccall((:vcmi_variance_scaling_dev, libvcmi), Cint,
+                (Ptr{Float64}, Int64, Cint, Int64, Ptr{Float64}, Ptr{Float64}, Int64, Ptr{Cvoid}),
+                src.ptr, src.ld, src.rows, src.cols, vs.σ², src.ptr, src.ld, stream))
     src
 end
 

@@ -4,7 +4,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._arrays import jl_matrix
+from ._arrays import current_stream_ptr, dev_matrix, is_torch, jl_matrix
 from .common import TrajectoryConverter
 
 
@@ -34,7 +34,16 @@ def constructW(D, T):
 
 def push_delta(src):
     """push_delta(src (D,T)) -> (2D,T), src/datasets.jl:6-13: delta_t = (x_{t+1} - x_{t-1})/2 for 2 <= t <= T-1;
-    the first and last frame keep a copy of the static features in the delta rows (repmat artefact)."""
+    the first and last frame keep a copy of the static features in the delta rows (repmat artefact).
+    A torch tensor on the device gives a device tensor (vcmi_push_delta_dev on the current stream): the trajectory
+    converter's input is built where the features are."""
+    if is_torch(src):
+        import torch
+
+        ptr, D, T, ld = dev_matrix(src, "src")
+        buf = torch.empty((T, 2 * D), dtype=torch.float64, device=src.device)
+        _lib.check(_lib.lib.vcmi_push_delta_dev(ptr, ld, D, T, buf.data_ptr(), 2 * D, current_stream_ptr()))
+        return buf.t()
     src = jl_matrix(src, "src")
     D, T = src.shape
     out = np.empty((2 * D, T), order="F")
@@ -94,7 +103,7 @@ class TrajectoryGMMMap(TrajectoryConverter):
                                                     dpp(*[_lib.dptr(y) for y in Ys])))
         return Ys
 
-    def _vc(self, fm):
+    def _vc(self, fm, postfilter=None):
         """vc(c::TrajectoryConverter, fm (2D+1,T)) -> (D+1,T) in chunks of length(c) frames; src/common.jl:31-63"""
         fm = jl_matrix(fm, "fm")
         D2 = self._dim()
@@ -102,7 +111,12 @@ class TrajectoryGMMMap(TrajectoryConverter):
             raise _lib.DimensionMismatch("Inconsistent dimentions.")
         T = fm.shape[1]
         out = np.empty((D2 // 2 + 1, T), order="F")
-        _lib.check(_lib.lib.vcmi_vc_traj(self._h, _lib.dptr(fm), T, _lib.dptr(out)))
+        if postfilter is None:
+            _lib.check(_lib.lib.vcmi_vc_traj(self._h, _lib.dptr(fm), T, _lib.dptr(out)))
+        else:       # fvpostf! (src/gv.jl:10-15) on the converted rows before the download
+            if postfilter.sigma2.shape != (D2 // 2,):
+                raise _lib.DimensionMismatch("sigma2 must have one entry per converted feature row")
+            _lib.check(_lib.lib.vcmi_vc_traj_postf(self._h, _lib.dptr(fm), T, _lib.dptr(postfilter.sigma2), _lib.dptr(out)))
         return out
 
 
