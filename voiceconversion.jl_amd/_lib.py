@@ -214,7 +214,6 @@ DBG_PREDICT_SCREEN = 16777216
 DBG_SCREEN_FP64 = 33554432
 DBG_GROUP_KEY_FP64 = 67108864
 DBG_ESTEP_NO_HARD = 134217728
-DBG_SCREEN_NO_PERSIST = 268435456
 
 
 def estep_last_soft():

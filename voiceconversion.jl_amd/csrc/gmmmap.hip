@@ -838,7 +838,6 @@ gmmmap_mfma_kernel(const double *__restrict__ packed, int M, int D, const double
 
 }  // namespace vcmi
 #include "gmmmap_screen.hpp"
-#include "gmmmap_screen_pers.hpp"
 namespace vcmi {
 
 // ------------------------------------------------------------------------------------------------
@@ -1490,10 +1489,7 @@ static int launch_mfma(const vcmi_gmmmap *g, const double *dX, int64_t ldx, int6
 // all the mixtures for two frame tiles per wave): they run ONE frame tile per wave -- twice the workgroups, half the loop
 // each.  Device-resident call of 2000 frames, D = 40, M = 64: 224 -> 127 us (the reference's 32-mixture model: 118 -> 79;
 // one frame: 129 -> 83).  Grouping such calls (three more launches) does not pay: tools/small_T_sweep.py.
-#ifndef VCMI_SMALL_CALL_FRAMES
-#define VCMI_SMALL_CALL_FRAMES 32768
-#endif
-static constexpr int64_t kSmallCallFrames = VCMI_SMALL_CALL_FRAMES;
+static constexpr int64_t kSmallCallFrames = 32768;
 static constexpr int64_t kSortMinFrames = 8192;
 
 #ifndef VCMI_CONVERT_FT
@@ -1591,56 +1587,9 @@ static int launch_screen(const vcmi_gmmmap *g, const double *dX, int64_t ldx, in
   VCMI_HIP(hipGetLastError());
   return VCMI_OK;
 }
-// the persistent form of the bf16-screened kernel (gmmmap_screen_pers.hpp): long calls, four rows per mixture, every screening
-// stage resident in LDS, two workgroups of four independent waves per CU
-template <int DP>
-static int launch_screen_pers(const vcmi_gmmmap *g, const double *dX, int64_t ldx, int64_t T, double *dY, int64_t ldy, hipStream_t st,
-                              const int *perm, const int *gkey) {
-  constexpr int WAVES = screen_pers_waves();
-  const size_t shmem = screen_pers_lds_bytes<DP>(g->M);
-  auto kern = gmmmap_screen_pers_kernel<DP, WAVES>;
-  static std::atomic<bool> attr_done[64];
-  int dev = 0, cus = 256;
-  VCMI_HIP(hipGetDevice(&dev));
-  if (dev < 0 || dev >= 64 || !attr_done[dev].load(std::memory_order_acquire)) {
-    VCMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)screen_pers_lds_budget()));
-    if (dev >= 0 && dev < 64) attr_done[dev].store(true, std::memory_order_release);
-  }
-  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-  const int64_t njobs = (T + 31) / 32, nwg = (njobs + WAVES - 1) / WAVES;
-  hipLaunchKernelGGL(kern, dim3((unsigned)std::min<int64_t>(nwg, (int64_t)2 * cus)), dim3(WAVES * 64), shmem, st, g->packed.p, g->packedQ16.p, g->M, g->D,
-                     dX, ldx, T, dY, ldy, g->prune, g->prune_count.p, perm, gkey);
-  VCMI_HIP(hipGetLastError());
-#if VCMI_PERS_EXP & 32
-  {
-    unsigned long long h[8], z[8] = {0};
-    (void)hipStreamSynchronize(st);
-    (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(pers_prof), sizeof(h));
-    (void)hipMemcpyToSymbol(HIP_SYMBOL(pers_prof), z, sizeof(z));
-    if (h[5])
-      fprintf(stderr, "pers_prof: %llu wave-jobs; cycles per wave-job: keys' mixtures %.0f, operand prep %.0f, screen %.0f, survivors %.0f, stores %.0f, rotate %.0f, next rows %.0f\n",
-              h[5], (double)h[0] / h[5], (double)h[1] / h[5], (double)h[2] / h[5], (double)h[3] / h[5], (double)h[4] / h[5], (double)h[6] / h[5], (double)h[7] / h[5]);
-  }
-#endif
-  return VCMI_OK;
-}
-template <int DP>
-static bool screen_pers_fits(const vcmi_gmmmap *g) {
-  return g->M <= 64 && screen_pers_lds_bytes<DP>(g->M) <= screen_pers_lds_budget();
-}
-
 static int dispatch_screen(const vcmi_gmmmap *g, const double *dX, int64_t ldx, int64_t T, double *dY, int64_t ldy, hipStream_t st,
                            const int *perm, const int *gkey) {
   const bool narrow = T <= kSmallCallFrames && !debug_flag(kDbgConvertWideTiles);     // one frame tile per wave, as dispatch_mfma
-  if (!narrow && g->packedQ16.p && g->screen_rpm == 4 && screen16_has(g->DP) && !debug_flag(kDbgScreenFp64) && !debug_flag(kDbgScreenNoPersist)) {
-    switch (g->DP) {
-#define VCMI_CASE(DPV) \
-  case DPV: if (screen_pers_fits<DPV>(g)) return launch_screen_pers<DPV>(g, dX, ldx, T, dY, ldy, st, perm, gkey); break;
-      VCMI_CASE(16) VCMI_CASE(20) VCMI_CASE(24) VCMI_CASE(28) VCMI_CASE(32) VCMI_CASE(36) VCMI_CASE(40)
-#undef VCMI_CASE
-      default: break;
-    }
-  }
   // the screen on the BF16 matrix pipe (certified bound from split operands) where it exists: four rows per mixture, DP <= 40
   if (g->packedQ16.p && g->screen_rpm == 4 && screen16_has(g->DP) && !debug_flag(kDbgScreenFp64)) {
     switch (g->DP) {
