@@ -179,13 +179,18 @@ int vcmi_estep_diag(const double *X, int64_t N, int Dj, int M, const double *w, 
                     double *S0, double *S1, double *S2, double *loglik);
 /* Device X; parameters are HOST arrays (tiny).  dstats is a DEVICE buffer of vcmi_estep_stats_len(Dj,M)
  * doubles laid out [S0 (M) | S1 (Dj,M) | S2 (Dj,M) | loglik] -- one contiguous buffer so that the
- * multi-GPU path is a single all-reduce(sum).  Every sum has a fixed order: a call is deterministic -- the same bits run to run --
- * for the path it takes.  From 65536 frames on (M <= 128, Dj <= 80) there are two: frames that ONE mixture owns (every other
- * responsibility exactly 0 in double precision) can be settled by a certified low-precision screen and summed per mixture, the
- * rest goes through the FP64 kernel (csrc/estep_hard.hpp; statistics within 1e-12 of each other).  Which one a call takes
- * follows from what the calling thread's earlier calls found on their frames, so the first calls on a new kind of data may
- * differ from later ones in the last bits.  Log-densities of competing mixtures are evaluated term by term, (x - mu)^2 / var,
- * wherever the expanded form's rounding-error bound exceeds 1e-10 (variances near min_covar). */
+ * multi-GPU path is a single all-reduce(sum).  Every sum has a fixed order and nothing depends on earlier calls: identical inputs
+ * give identical bits, run to run, thread to thread.  From 65536 frames on (M <= 128, Dj <= 80) there are two paths: frames that
+ * ONE mixture owns (every other responsibility exactly 0 in double precision) can be settled by a certified low-precision screen
+ * and summed per mixture in one pass over X, the rest goes through the FP64 kernel (csrc/estep_hard.hpp, estep_onepass.hpp;
+ * statistics within 1e-12 of each other).  VCMI_ESTEP_AUTO (default) decides per call, on the device, from a sample of the call's
+ * own frames (16 chunks of 1024: at most a quarter without an owner -> the hard-assignment path); vcmi_estep_set_path pins
+ * VCMI_ESTEP_HARD or VCMI_ESTEP_SOFT for the calling thread (training loops that must take the same path on every rank).
+ * Log-densities of competing mixtures are evaluated term by term, (x - mu)^2 / var, wherever the expanded form's
+ * rounding-error bound exceeds 1e-10 (variances near min_covar). */
+enum { VCMI_ESTEP_AUTO = 0, VCMI_ESTEP_HARD = 1, VCMI_ESTEP_SOFT = 2 };
+int vcmi_estep_set_path(int path);
+int vcmi_estep_get_path(int *path);
 int64_t vcmi_estep_stats_len(int Dj, int M);
 int vcmi_estep_diag_dev(const double *dX, int64_t N, int Dj, int M, const double *w, const double *mu,
                         const double *var, double *dstats, void *stream);

@@ -70,3 +70,69 @@ def test_two_rank_train_gmm_and_convert_match_single_process():
     g = vc.GMMMap(w, np.asfortranarray((mu * 3.0).T), np.asfortranarray(np.transpose(sig, (2, 1, 0))))
     full = vc.fvconvert(g, np.asfortranarray(X[:, :Dj // 2].T))
     assert np.array_equal(np.concatenate([res[0]["y"], res[1]["y"]], axis=1), full)
+
+
+def _estep_case():
+    """first half: frames with owners (far-apart mixtures); second half: frames of a cluster of overlapping mixtures -- contiguous
+    shards of two ranks then take DIFFERENT paths of the diagonal E-step"""
+    Dj, M, Nh = 80, 64, 70_000
+    rg = np.random.default_rng(77)
+    w = rg.dirichlet(2.0 * np.ones(M))
+    var = np.exp(rg.uniform(np.log(0.05), 0.0, (M, Dj)))
+    mu = 3.0 * rg.standard_normal((M, Dj))
+    mu[M // 2:] = mu[M // 2] + 0.3 * rg.standard_normal((M - M // 2, Dj)) * np.sqrt(var[M // 2:])
+    p_far = w[:M // 2] / w[:M // 2].sum()
+    p_near = w[M // 2:] / w[M // 2:].sum()
+    c0 = rg.choice(M // 2, size=Nh, p=p_far)
+    c1 = M // 2 + rg.choice(M - M // 2, size=Nh, p=p_near)
+    comp = np.concatenate([c0, c1])
+    X = mu[comp] + rg.standard_normal((2 * Nh, Dj)) * np.sqrt(var[comp])
+    return w, mu, var, X
+
+
+def _estep_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), VCMI_TEST_HOOKS="1")
+    import torch.distributed as dist
+    import voiceconversion_jl_amd as vc
+    from voiceconversion_jl_amd import _lib, dist as vd
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    w, mu, var, X = _estep_case()
+    lo, hi = vd.shard_range(len(X), rank, world)
+    Xd = torch.from_numpy(X[lo:hi]).cuda().t()
+    local = vc.estep_diag_dev(Xd, w, mu.T, var.T)
+    soft = _lib.estep_last_soft()
+    red = vc.unpack_stats(vc.estep_diag_allreduce(Xd, w, mu.T, var.T).cpu().numpy(), mu.shape[1], len(w))
+    q.put((rank, {"soft": soft, "stats": [np.array(t) for t in red[:3]] + [float(red[3])]}))
+    dist.destroy_process_group()
+
+
+def test_two_ranks_on_different_estep_paths_match_single_process():
+    """the path of the diagonal E-step follows from each rank's OWN frames -- rank 0's shard is all owned (the
+    hard-assignment path), rank 1's is shared between overlapping mixtures (the one-kernel path): the all-reduced statistics
+    are within 1e-12 of one process on all frames, and both ranks hold the same bits."""
+    import voiceconversion_jl_amd as vc
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29700 + (os.getpid() % 90)
+    procs = [ctx.Process(target=_estep_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0]["soft"] == 0 and res[1]["soft"] == -1, (res[0]["soft"], res[1]["soft"])
+    w, mu, var, X = _estep_case()
+    vc.estep_set_path(vc.ESTEP_SOFT)
+    try:
+        S0, S1, S2, ll = vc.estep_diag(X.T, w, mu.T, var.T)
+    finally:
+        vc.estep_set_path(vc.ESTEP_AUTO)
+    for rank in (0, 1):
+        g0, g1, g2, gl = res[rank]["stats"]
+        assert np.max(np.abs(g0 - S0)) <= 1e-12 * np.max(np.abs(S0)) and np.max(np.abs(g1 - S1)) <= 1e-12 * np.max(np.abs(S1))
+        assert np.max(np.abs(g2 - S2)) <= 1e-12 * np.max(np.abs(S2)) and abs(gl - ll) <= 1e-12 * abs(ll)
+    assert all(np.array_equal(a, b) for a, b in zip(res[0]["stats"][:3], res[1]["stats"][:3])) and res[0]["stats"][3] == res[1]["stats"][3]

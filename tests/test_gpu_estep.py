@@ -251,7 +251,6 @@ def test_pinned_frames_are_uploaded_directly(vc):
     var = np.exp(rg.uniform(np.log(1e-3), 0.0, (M, Dj)))
     comp = rg.choice(M, size=N, p=w)
     X = np.asfortranarray((mu[comp] + rg.standard_normal((N, Dj)) * np.sqrt(var[comp])).T)
-    _forget_feedback(vc)             # (both calls on the same path: which one a call takes depends on what earlier calls found)
     a = vc.estep_diag(X, w, mu.T, var.T)
     vc.pin(X)
     try:
@@ -278,27 +277,28 @@ def _separated_case(seed, N, Dj, M, sep, zero_weight=None):
     return w, mu, var, X
 
 
-def _forget_feedback(vc):
-    """The path watches the soft fraction of the previous call (of any model): start every test from a clean slate."""
+def _both_paths(vc, X, w, mu, var, path=None):
+    """(statistics of the library's own choice (or of the pinned `path`), statistics of the one-kernel path, soft frames of the
+    first call: -1 = it took the one-kernel path).  The choice is made from the call's own frames (vcmi_estep_set_path: AUTO), so
+    nothing has to be forgotten between tests; with the hard-assignment path pinned, AUTO must give the same bits when it
+    chooses that path."""
     from voiceconversion_jl_amd import _lib
-    _lib.debug_force(_lib.DBG_ESTEP_NO_HARD)
+    assert vc.estep_get_path() == vc.ESTEP_AUTO
     try:
-        vc.estep_diag(np.zeros((2, 1)), np.ones(1), np.zeros((2, 1)), np.ones((2, 1)))
-    finally:
-        _lib.debug_force(0)
-
-
-def _both_paths(vc, X, w, mu, var):
-    from voiceconversion_jl_amd import _lib
-    _forget_feedback(vc)
-    a = vc.estep_diag(X.T, w, mu.T, var.T)
-    soft = _lib.estep_last_soft()
-    _lib.debug_force(_lib.DBG_ESTEP_NO_HARD)
-    try:
+        if path is not None:
+            vc.estep_set_path(path)
+        a = vc.estep_diag(X.T, w, mu.T, var.T)
+        soft = _lib.estep_last_soft()
+        vc.estep_set_path(vc.ESTEP_SOFT)
         o = vc.estep_diag(X.T, w, mu.T, var.T)
         assert _lib.estep_last_soft() == -1
+        vc.estep_set_path(vc.ESTEP_AUTO)
+        if soft >= 0:
+            b = vc.estep_diag(X.T, w, mu.T, var.T)
+            if _lib.estep_last_soft() >= 0:
+                assert all(np.array_equal(p, q) for p, q in zip(a[:3], b[:3])) and a[3] == b[3]
     finally:
-        _lib.debug_force(0)
+        vc.estep_set_path(vc.ESTEP_AUTO)
     return a, o, soft
 
 
@@ -336,49 +336,72 @@ def test_hard_assignment_path_mixed_frames(vc, N, Dj, M):
     mu[M // 2:] = mu[M // 2] + 0.3 * rg.standard_normal((M - M // 2, Dj)) * np.sqrt(var[M // 2:])       # a cluster of overlapping mixtures
     comp = rg.choice(M, size=N, p=w)
     X = mu[comp] + rg.standard_normal((N, Dj)) * np.sqrt(var[comp])
-    a, o, soft = _both_paths(vc, X, w, mu, var)
+    a, o, soft = _both_paths(vc, X, w, mu, var, vc.ESTEP_HARD)       # (pinned: the library itself would step aside here)
     assert 0.05 * N < soft < 0.95 * N, soft
     for p, q in zip(a[:3], o[:3]):
         assert relerr(p, q) < 1e-12, relerr(p, q)
     assert abs(a[3] - o[3]) < 1e-12 * abs(o[3])
-    b = vc.estep_diag(X.T, w, mu.T, var.T)
+    vc.estep_set_path(vc.ESTEP_HARD)
+    try:
+        b = vc.estep_diag(X.T, w, mu.T, var.T)
+    finally:
+        vc.estep_set_path(vc.ESTEP_AUTO)
     assert all(np.array_equal(p, q) for p, q in zip(a[:3], b[:3])) and a[3] == b[3]
     r0, r1, r2, rl = co.estep_diag(X, w, mu, var)
     assert relerr(a[0], r0) < TOL and relerr(a[1], r1.T) < TOL and relerr(a[2], r2.T) < TOL
     assert abs(a[3] - rl) < TOL * abs(rl)
-    _forget_feedback(vc)
 
 
 def test_hard_assignment_path_steps_aside_when_frames_are_shared(vc):
-    """Overlapping mixtures: the first call (optimistic) finds most frames shared -- still the right statistics, through the
-    gathered FP64 pass -- and the thread moves to the one-kernel path; there every fourth call screens a SAMPLE of the frames
-    first (16 chunks, ~20 us) and nothing else changes while the sample keeps finding shared frames.  When the data (or the
-    model) change so that frames have owners again, a sampled look notices and the path comes back within a few calls."""
+    """The path is chosen from the call's OWN frames (a screen on a sample of 16 chunks, decided on the device: VERDICT r5 item
+    5), not from what earlier calls found: overlapping mixtures -> the one-kernel path on the FIRST call and on every one; frames
+    with owners -> the hard-assignment path on the first call; the two kinds of data interleaved on one thread -> every call
+    bit-identical to the same call made alone, in another thread, in any order."""
+    import threading
     from oracle import c_oracle as co
     from voiceconversion_jl_amd import _lib
     N, Dj, M = 70_000, 80, 64
-    w, mu, var, X = _hard_case(4242, Dj, M, N, 10.0, 1e-3, 1e-1, 3.0)       # (a quarter of its mixtures are far away: those frames are owned)
-    r0, r1, r2, rl = co.estep_diag(X, w, mu, var)
-    _forget_feedback(vc)
-    seen = []
-    for _ in range(24):
+    w, mu, var, X = _hard_case(4242, Dj, M, N, 10.0, 1e-3, 1e-1, 3.0)       # (three quarters of its frames are shared between mixtures)
+    w2, mu2, var2, X2 = _separated_case(5, N, Dj, M, 3.0)                   # (every frame has an owner)
+    r = co.estep_diag(X, w, mu, var)
+    r2 = co.estep_diag(X2, w2, mu2, var2)
+
+    def close(a, ref):
+        return relerr(a[0], ref[0]) < TOL and relerr(a[1], ref[1].T) < TOL and relerr(a[2], ref[2].T) < TOL and abs(a[3] - ref[3]) < TOL * abs(ref[3])
+
+    alone = {}
+
+    def in_a_fresh_thread(name, Xk, wk, muk, vark):
+        alone[name] = (vc.estep_diag(Xk.T, wk, muk.T, vark.T), _lib.estep_last_soft())
+
+    for args in (("shared", X, w, mu, var), ("owned", X2, w2, mu2, var2)):
+        t = threading.Thread(target=in_a_fresh_thread, args=args)
+        t.start()
+        t.join()
+    assert alone["shared"][1] == -1 and alone["owned"][1] == 0
+    assert close(alone["shared"][0], r) and close(alone["owned"][0], r2)
+    same = lambda a, b: all(np.array_equal(p, q) for p, q in zip(a[:3], b[:3])) and a[3] == b[3]      # noqa: E731
+    for order in ("shared", "owned", "owned", "shared", "shared", "owned", "shared"):
+        if order == "shared":
+            a = vc.estep_diag(X.T, w, mu.T, var.T)
+        else:
+            a = vc.estep_diag(X2.T, w2, mu2.T, var2.T)
+        assert _lib.estep_last_soft() == alone[order][1]
+        assert same(a, alone[order][0]), order
+    # pinned paths: still the right statistics on the "wrong" kind of data, and the setting is per thread
+    vc.estep_set_path(vc.ESTEP_HARD)
+    try:
         a = vc.estep_diag(X.T, w, mu.T, var.T)
-        seen.append(_lib.estep_last_soft())
-        assert relerr(a[0], r0) < TOL and relerr(a[1], r1.T) < TOL and relerr(a[2], r2.T) < TOL
-        assert abs(a[3] - rl) < TOL * abs(rl)
-    assert seen[0] > 0.5 * N, seen                 # the first call took the path and found most frames shared
-    assert seen[1:] == [-1] * 23, seen             # from then on the one-kernel path (with sampled looks that change nothing)
-    # frames with owners: the path is back after at most two sampled looks
-    w2, mu2, var2, X2 = _separated_case(5, N, Dj, M, 3.0)
-    s0 = co.estep_diag(X2, w2, mu2, var2)
-    seen2 = []
-    for _ in range(12):
-        a = vc.estep_diag(X2.T, w2, mu2.T, var2.T)
-        seen2.append(_lib.estep_last_soft())
-        assert relerr(a[0], s0[0]) < TOL and relerr(a[1], s0[1].T) < TOL and relerr(a[2], s0[2].T) < TOL
-    k = seen2.index(0)
-    assert k <= 9 and seen2[k:] == [0] * (12 - k), seen2
-    _forget_feedback(vc)
+        assert _lib.estep_last_soft() > 0.5 * N and close(a, r)
+        seen = []
+        t = threading.Thread(target=lambda: seen.append(vc.estep_get_path()))
+        t.start()
+        t.join()
+        assert seen == [vc.ESTEP_AUTO] and vc.estep_get_path() == vc.ESTEP_HARD
+    finally:
+        vc.estep_set_path(vc.ESTEP_AUTO)
+    with pytest.raises(vc.VCMIError):
+        vc.estep_set_path(7)
 
 
 def test_hard_assignment_path_device_resident_and_small_calls(vc):
@@ -386,7 +409,6 @@ def test_hard_assignment_path_device_resident_and_small_calls(vc):
     import torch
     from voiceconversion_jl_amd import _lib
     w, mu, var, X = _separated_case(9, 131_072, 80, 128, 3.0)
-    _forget_feedback(vc)
     Xd = torch.from_numpy(np.ascontiguousarray(X)).cuda()
     got = vc.estep_diag_dev(Xd.t(), w, mu.T, var.T)
     assert _lib.estep_last_soft() == 0
@@ -406,7 +428,7 @@ def test_hard_assignment_path_tight_variances(vc, Dj, M):
     from oracle import c_oracle as co
     N = 70_000
     w, mu, var, X = _hard_case(77 + Dj + M, Dj, M, N, 10.0, 1e-7, 1e-2, 3.0)
-    a, o, soft = _both_paths(vc, X, w, mu, var)
+    a, o, soft = _both_paths(vc, X, w, mu, var, vc.ESTEP_HARD)
     assert 0 < soft < N, soft                        # both kinds of frames are present
     for p, q in zip(a[:3], o[:3]):
         assert relerr(p, q) < 1e-12, relerr(p, q)
@@ -418,7 +440,6 @@ def test_hard_assignment_path_tight_variances(vc, Dj, M):
     assert relerr(a[0], r0) < TOL and relerr(a[1], r1.T) < TOL and relerr(a[2], r2.T) < TOL
     assert abs(a[3] - rl) < TOL * abs(rl)
     assert abs(a[3] - rl) <= abs(o[3] - rl) + 1e-13 * abs(rl), (a[3] - rl, o[3] - rl)
-    _forget_feedback(vc)
 
 
 def test_hard_assignment_path_a_handful_of_shared_frames(vc):

@@ -11,7 +11,8 @@ from .gmm import GMM, predict, predict_proba  # noqa: F401
 from .gmmmap import GMMMap  # noqa: F401
 from .dtw import DTW, backward, fit_, fit_batch, set_template_, update_  # noqa: F401,E402
 from .align import align, align_batch  # noqa: F401,E402
-from .estep import (estep_diag, estep_diag_allreduce, estep_diag_dev, mstep_diag, stats_len, unpack_stats,  # noqa: F401,E402
+from .estep import (ESTEP_AUTO, ESTEP_HARD, ESTEP_SOFT, estep_diag, estep_diag_allreduce, estep_diag_dev, estep_get_path,  # noqa: F401,E402
+                    estep_set_path, mstep_diag, stats_len, unpack_stats,
                     estep_full, estep_full_allreduce, estep_full_dev, fit_full, full_stats_len, mstep_full,
                     unpack_full_stats)
 from .trajectory_gmmmap import TrajectoryGVGMMMap, TrajectoryGMMMap, constructW, push_delta  # noqa: F401,E402

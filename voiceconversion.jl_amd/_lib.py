@@ -87,6 +87,8 @@ SIGNATURES = {
     "vcmi_align_batch": (_int, [_i64, _dpp, _ip, _dpp, _ip, _int, _dpp]),
     "vcmi_estep_diag": (_int, [_dp, _i64, _int, _int, _dp, _dp, _dp, _dp, _dp, _dp, _dp]),
     "vcmi_estep_stats_len": (_i64, [_int, _int]),
+    "vcmi_estep_set_path": (_int, [_int]),
+    "vcmi_estep_get_path": (_int, [C.POINTER(_int)]),
     "vcmi_estep_diag_dev": (_int, [_vp, _i64, _int, _int, _dp, _dp, _dp, _vp, _vp]),
     "vcmi_estep_full_stats_len": (_i64, [_int, _int]),
     "vcmi_estep_full": (_int, [_dp, _i64, _int, _int, _dp, _dp, _dp, _dp, _dp, _dp, _dp]),

@@ -611,6 +611,7 @@ estep_mfma_kernel(const double *__restrict__ X, int64_t N, int M, const double *
 }  // namespace vcmi
 #include "estep_wave.hpp"
 #include "estep_hard.hpp"
+#include "estep_onepass.hpp"
 namespace vcmi {
 
 // ------------------------------------------------------------------------------------------------
@@ -653,29 +654,14 @@ struct EstepStaging {
 struct EstepScratch {
   DevBuf<double> mu, iv, cst, G, LSE, part, Wpack, cinit, X, stats, raw, refiv, refc, Xpad, statsp;
   DevBuf<unsigned long long> mfma_count;      // optional measurement counter (vcmi_debug_estep_mfma); null: the kernels count nothing
-  // the hard-assignment path (estep_hard.hpp): operands, sort scratch, pieces, the soft frames' matrix, and the feedback that
-  // keeps it off while the data leaves it little (the previous call's soft count, read back without waiting)
+  // the hard-assignment path (estep_hard.hpp, estep_onepass.hpp): operands, the sample's histograms, the path control words, the
+  // workgroups' partial sums, the chunks' soft lists and the soft frames' matrix
   DevBuf<unsigned char> W16;
-  DevBuf<int> hkeys;                           // key (N) | perm (N) | chunkhist (nchunks x (M + 1)) | total (M + 1)
+  DevBuf<int> probe;                           // sample histograms (16 x (M + 1))
+  DevBuf<int64_t> ctl;                         // kCtlLen control words (estep_onepass.hpp) | softoffs (nchunks)
+  DevBuf<int> softlist;                        // softidx (nchunks x 1024) | softcount (nchunks)
   DevBuf<double> hpart, hllm, Xsoft;
-  DevBuf<int64_t> nsoft;
-  int *h_soft = nullptr;                       // pinned
-  hipEvent_t soft_ev = nullptr;
-  bool soft_pending = false;
-  int64_t soft_N = 0;
-  int hard_mode = 1;                           // 1: the hard-assignment path (optimistic start), 0: the one-kernel path + sampled looks
-  int probe_tick = 0;                          // calls in mode 0 (a sampled look every fourth)
-  int *h_probe = nullptr;                      // pinned [2]: frames of the sample without an owner, frames of the sample
-  hipEvent_t probe_ev = nullptr;
-  bool probe_pending = false;
-  DevBuf<int> probe;                           // sample histograms + the two sums
-  bool last_hard = false;                      // the last diagonal E-step of this thread took the hard-assignment path
-  ~EstepScratch() {
-    if (h_soft) (void)hipHostFree(h_soft);
-    if (soft_ev) (void)hipEventDestroy(soft_ev);
-    if (h_probe) (void)hipHostFree(h_probe);
-    if (probe_ev) (void)hipEventDestroy(probe_ev);
-  }
+  bool last_hard = false;                      // the last diagonal E-step of this thread launched the hard-assignment path's kernels
   EstepStaging stage;
   StreamOrder order;   // calls of one thread on different streams share the buffers above
 };
@@ -683,6 +669,13 @@ static EstepScratch &scratch() {
   static thread_local EstepScratch s;
   return s;
 }
+// vcmi_estep_set_path: which of the two paths the diagonal E-step of this host thread takes (default: decided per call, from
+// the call's own data)
+static int &estep_path_choice_ref() {
+  static thread_local int p = VCMI_ESTEP_AUTO;
+  return p;
+}
+static int estep_path_choice() { return estep_path_choice_ref(); }
 
 
 // model parameters: pinned host slot -> device
@@ -791,99 +784,75 @@ static int estep_mfma_launch(EstepScratch &sc, const double *dX, int64_t N, int 
   VCMI_HIP(hipGetLastError());
   const double *dmu = draw + M;      // (the means of the re-evaluation are the uploaded parameters themselves: raw = [w | mu (Dj,M) | var (Dj,M)])
   if constexpr (!C::SPLIT) {
-    // ---- frames that one mixture owns never see an FP64 MFMA (estep_hard.hpp); the rest goes on below, gathered ----
+    // ---- frames that one mixture owns never see an FP64 MFMA (estep_hard.hpp, estep_onepass.hpp); the rest goes on below, gathered ----
     static constexpr int64_t kHardMinFrames = 65536;
-    // Which path?  The hard-assignment path pays where most frames have an owner and costs an E-step and a half where they
-    // do not (real joint mel-cepstra: DESIGN 3.3).  It starts optimistic; its own count of shared frames (a 4-byte download
-    // behind an event, never waited for) sends the thread to the one-kernel path when more than a quarter were shared; there,
-    // every fourth call first runs the screen on a SAMPLE of 16 chunks spread over the frames (~20 us) and a later call
-    // switches back when the sample found owners for three quarters of its frames.
-    if (sc.soft_pending && hipEventQuery(sc.soft_ev) == hipSuccess) {          // what the previous hard-path call found
-      sc.soft_pending = false;
-      sc.hard_mode = (sc.h_soft && (double)*sc.h_soft > 0.25 * (double)sc.soft_N) ? 0 : 1;
-    }
-    if (sc.probe_pending && hipEventQuery(sc.probe_ev) == hipSuccess) {        // what the last sampled look found
-      sc.probe_pending = false;
-      if (sc.h_probe[1] > 0 && (double)sc.h_probe[0] <= 0.25 * (double)sc.h_probe[1]) sc.hard_mode = 1;
-    }
-    if (debug_flag(kDbgEstepNoHard)) {                                         // (tests: the flag also forgets what was learnt)
-      sc.soft_pending = false;
-      sc.probe_pending = false;
-      sc.hard_mode = 1;
-      sc.probe_tick = 0;
-    }
-    const bool hard_on = N >= kHardMinFrames && N < ((int64_t)1 << 31) && !debug_flag(kDbgEstepNoHard);
+    // Which path?  The hard-assignment path pays where most frames have an owner and costs its pass over X on top of the whole
+    // one-kernel E-step where they do not (real joint mel-cepstra: DESIGN 3.3).  Decided from THIS call's data, on the device:
+    // the screen on a SAMPLE of 16 chunks spread over the frames (~20 us), estep_path_decide_kernel writes the control words,
+    // every kernel of either path starts with a look at them -- the launch sequence is fixed, nothing waits for the GPU, and
+    // identical inputs give identical bits whatever this thread (or any other) ran before.  vcmi_estep_set_path pins one.
+    const int path = debug_flag(kDbgEstepNoHard) ? VCMI_ESTEP_SOFT : estep_path_choice();
+    bool hard_on = N >= kHardMinFrames && N < ((int64_t)1 << 31) && M <= kHardMaxM && path != VCMI_ESTEP_SOFT;
     sc.last_hard = false;
-    if (hard_on && sc.hard_mode == 0) {
-      if (!sc.probe_pending && (sc.probe_tick++ & 3) == 0) {
-        using CH = EstepHardCfg<DJ>;
-        const int MT = (M + 15) / 16, MK = M + 1;
-        const int64_t nchunks = (N + kGroupChunk - 1) / kGroupChunk, nsample = std::min<int64_t>(16, nchunks), cstride = nchunks / nsample;
-        VCMI_TRY(sc.W16.reserve((size_t)MT * CH::TILE_BYTES));
-        VCMI_TRY(sc.probe.reserve((size_t)nsample * MK + 2));
-        if (!sc.h_probe) {
-          VCMI_HIP(hipHostMalloc(reinterpret_cast<void **>(&sc.h_probe), 2 * sizeof(int), hipHostMallocDefault));
-          VCMI_HIP(hipEventCreateWithFlags(&sc.probe_ev, hipEventDisableTiming));
-        }
-        hipLaunchKernelGGL(estep_hard_prep_kernel<DJ>, dim3((unsigned)((MT * CH::NI * 64 + 255) / 256 + 4 * MT)), dim3(256), 0, st, draw, sc.cinit.p,
-                           M, dj, sc.W16.p);
+    using CH = EstepHardCfg<DJ>;
+    const int MT = (M + 15) / 16, MK = M + 1;
+    const int64_t nchunks = (N + kGroupChunk - 1) / kGroupChunk;
+    const int ngrid = (int)std::min<int64_t>(nchunks, (int64_t)cus);
+    if (hard_on) {
+      // the soft frames' dense matrix is as large as X in the worst case: a device without room for it takes the one-kernel path
+      // (the reservation used to fail the whole E-step)
+      if (sc.Xsoft.reserve((size_t)N * dj) != VCMI_OK) {
+        (void)hipGetLastError();
+        hard_on = false;
+      }
+    }
+    if (hard_on) {
+      const int64_t prow = 2 * (int64_t)dj + 1;
+      const int64_t nsample = std::min<int64_t>(16, nchunks), cstride = nchunks / nsample;
+      VCMI_TRY(sc.W16.reserve((size_t)MT * CH::TILE_BYTES));
+      VCMI_TRY(sc.probe.reserve((size_t)nsample * MK));
+      VCMI_TRY(sc.ctl.reserve((size_t)kCtlLen + (size_t)nchunks));
+      VCMI_TRY(sc.softlist.reserve((size_t)nchunks * kGroupChunk + (size_t)nchunks));
+      VCMI_TRY(sc.hpart.reserve((size_t)ngrid * M * prow));
+      VCMI_TRY(sc.hllm.reserve((size_t)M));
+      int64_t *ctl = sc.ctl.p, *softoffs = ctl + kCtlLen;
+      int *softidx = sc.softlist.p, *softcount = softidx + nchunks * kGroupChunk;
+      hipLaunchKernelGGL(estep_hard_prep_kernel<DJ>, dim3((unsigned)((MT * CH::NI * 64 + 255) / 256 + 4 * MT)), dim3(256), 0, st, draw, sc.cinit.p, M,
+                         dj, sc.W16.p);
+      if (path == VCMI_ESTEP_AUTO) {
         const size_t kshmem = CH::lds_bytes(MT) + (size_t)MK * sizeof(int);
         auto kk = estep_hard_key_kernel<DJ>;
         VCMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kshmem));
         hipLaunchKernelGGL(kk, dim3((unsigned)nsample), dim3(kHardKeyThreads), kshmem, st, sc.W16.p, M, dj, dX, N, (int *)nullptr, sc.probe.p, nsample,
                            cstride);
-        hipLaunchKernelGGL(estep_hard_probe_sum_kernel, dim3(1), dim3(64), 0, st, sc.probe.p, (int)nsample, MK, sc.probe.p + nsample * MK);
-        VCMI_HIP(hipGetLastError());
-        VCMI_HIP(hipMemcpyAsync(sc.h_probe, sc.probe.p + nsample * MK, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
-        VCMI_HIP(hipEventRecord(sc.probe_ev, st));
-        sc.probe_pending = true;
       }
-    }
-    else if (hard_on) {      // (hard_mode == 1)
-      using CH = EstepHardCfg<DJ>;
-      const int MT = (M + 15) / 16, MK = M + 1;
-      const int64_t nchunks = (N + kGroupChunk - 1) / kGroupChunk, npmax = (N + kHardPiece - 1) / kHardPiece + M, prow = 2 * (int64_t)dj + 2;
-      VCMI_TRY(sc.W16.reserve((size_t)MT * CH::TILE_BYTES));
-      VCMI_TRY(sc.hkeys.reserve((size_t)2 * N + (size_t)(nchunks + 1) * MK));
-      VCMI_TRY(sc.hpart.reserve((size_t)npmax * prow));
-      VCMI_TRY(sc.hllm.reserve((size_t)M));
-      VCMI_TRY(sc.Xsoft.reserve((size_t)N * dj));
-      VCMI_TRY(sc.nsoft.reserve(1));
-      if (!sc.h_soft) {
-        VCMI_HIP(hipHostMalloc(reinterpret_cast<void **>(&sc.h_soft), sizeof(int), hipHostMallocDefault));
-        VCMI_HIP(hipEventCreateWithFlags(&sc.soft_ev, hipEventDisableTiming));
-      }
-      int *key = sc.hkeys.p, *perm = key + N, *chunkhist = perm + N, *total = chunkhist + nchunks * MK;
-      hipLaunchKernelGGL(estep_hard_prep_kernel<DJ>, dim3((unsigned)((MT * CH::NI * 64 + 255) / 256 + 4 * MT)), dim3(256), 0, st, draw, sc.cinit.p, M,
-                         dj, sc.W16.p);
-      const size_t kshmem = CH::lds_bytes(MT) + (size_t)MK * sizeof(int);
-      auto kk = estep_hard_key_kernel<DJ>;
-      VCMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kshmem));
-      hipLaunchKernelGGL(kk, dim3((unsigned)std::min<int64_t>(nchunks, (int64_t)cus)), dim3(kHardKeyThreads), kshmem, st, sc.W16.p, M, dj, dX, N, key,
-                         chunkhist, nchunks, (int64_t)1);
-      hipLaunchKernelGGL(gmmmap_group_scan_kernel, dim3((unsigned)MK), dim3(256), 0, st, chunkhist, nchunks, MK, total);
-      hipLaunchKernelGGL(gmmmap_group_scatter_kernel, dim3((unsigned)nchunks), dim3(256), (size_t)17 * MK * sizeof(int), st, key, N, MK,
-                         chunkhist, total, perm);
-      hipLaunchKernelGGL(estep_hard_stats_kernel<DJ>, dim3((unsigned)npmax), dim3(256), 0, st, dX, dj, M, perm, total, dmu, sc.refiv.p,
-                         sc.hpart.p, prow);
-      hipLaunchKernelGGL(estep_hard_reduce_kernel, dim3((unsigned)M), dim3(256), 0, st, sc.hpart.p, prow, total, M, dj, sc.refc.p, dstats,
-                         sc.hllm.p);
-      hipLaunchKernelGGL(estep_hard_ll_kernel, dim3(1), dim3(64), 0, st, sc.hllm.p, M, dstats, plen);
-      hipLaunchKernelGGL(estep_hard_gather_kernel, dim3((unsigned)(cus * 4)), dim3(256), 0, st, dX, dj, M, perm, total, sc.Xsoft.p, sc.nsoft.p, N);
+      hipLaunchKernelGGL(estep_path_decide_kernel, dim3(1), dim3(64), 0, st, sc.probe.p, (int)nsample, MK, path == VCMI_ESTEP_AUTO ? -1 : 1, N, ctl);
+      const size_t oshmem = CH::lds_bytes(MT) + (size_t)2 * kOnePassRound * sizeof(int);
+      auto ko = estep_onepass_kernel<DJ>;
+      VCMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ko), hipFuncAttributeMaxDynamicSharedMemorySize, (int)oshmem));
+      hipLaunchKernelGGL(ko, dim3((unsigned)ngrid), dim3(kOnePassThreads), oshmem, st, sc.W16.p, M, dj, dX, N, dmu, (const int64_t *)ctl, sc.hpart.p,
+                         softidx, softcount, nchunks);
+      hipLaunchKernelGGL(estep_onepass_finish_kernel, dim3((unsigned)(M + 1)), dim3(256), 0, st, sc.hpart.p, ngrid, M, dj, dmu, sc.refiv.p, sc.refc.p,
+                         softcount, nchunks, softoffs, ctl, dstats, sc.hllm.p);
+      hipLaunchKernelGGL(estep_onepass_ll_kernel, dim3(1), dim3(64), 0, st, sc.hllm.p, M, (const int64_t *)ctl, dstats, plen);
+      hipLaunchKernelGGL(estep_onepass_gather_kernel, dim3((unsigned)std::min<int64_t>(nchunks, (int64_t)cus * 4)), dim3(256), 0, st, dX, dj, softidx,
+                         softcount, softoffs, nchunks, (const int64_t *)ctl, sc.Xsoft.p);
       VCMI_HIP(hipGetLastError());
-      VCMI_HIP(hipMemcpyAsync(sc.h_soft, total + M, sizeof(int), hipMemcpyDeviceToHost, st));
-      VCMI_HIP(hipEventRecord(sc.soft_ev, st));
-      sc.soft_pending = true;
-      sc.soft_N = N;
       sc.last_hard = true;
-      // the soft frames through the one-kernel path, their number read on the device; its partials are added on top
+      // the soft frames through the one-kernel path, their number read on the device; its partials are added on top ...
       VCMI_TRY(sc.part.reserve((size_t)cus * wpt * plen));
       auto kern = (mtp < 8) ? estep_mfma_kernel<DJ, 0, true> : estep_mfma_kernel<DJ, 0, false>;
       VCMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES));
       hipLaunchKernelGGL(kern, dim3(cus), dim3(512), C::LDS_BYTES, st, sc.Xsoft.p, N, M, sc.Wpack.p, sc.cinit.p, sc.part.p, plen, dmu,
-                         sc.refiv.p, sc.refc.p, (double *)nullptr, dj, mtp, sc.mfma_count.p, (const int64_t *)sc.nsoft.p);
+                         sc.refiv.p, sc.refc.p, (double *)nullptr, dj, mtp, sc.mfma_count.p, (const int64_t *)(ctl + kCtlNSoft));
       VCMI_HIP(hipGetLastError());
-      estep_reduce_launch(sc.part.p, cus * wpt, plen, dstats, st, /*accumulate=*/1, (const int64_t *)sc.nsoft.p);
+      estep_reduce_launch(sc.part.p, cus * wpt, plen, dstats, st, /*accumulate=*/1, (const int64_t *)(ctl + kCtlNSoft));
+      // ... or, where the sample found few owners, every frame (ctl[kCtlAllSoft] = N; 0 otherwise: both launches return at once)
+      if (path == VCMI_ESTEP_AUTO) {
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), C::LDS_BYTES, st, dX, N, M, sc.Wpack.p, sc.cinit.p, sc.part.p, plen, dmu,
+                           sc.refiv.p, sc.refc.p, (double *)nullptr, dj, mtp, sc.mfma_count.p, (const int64_t *)(ctl + kCtlAllSoft));
+        estep_reduce_launch(sc.part.p, grid * wpt, plen, dstats, st, /*accumulate=*/0, (const int64_t *)(ctl + kCtlAllSoft));
+      }
       VCMI_HIP(hipGetLastError());
       return VCMI_OK;
     }
@@ -1951,10 +1920,26 @@ extern "C" int vcmi_debug_estep_last_soft(int64_t *soft) {
   if (!soft) return fail(VCMI_ERR_ARG, "vcmi_debug_estep_last_soft: NULL argument");
   EstepScratch &sc = scratch();
   *soft = -1;
-  if (sc.last_hard && sc.nsoft.p) {
+  if (sc.last_hard && sc.ctl.p) {
+    int64_t h[kCtlLen];
     VCMI_HIP(hipDeviceSynchronize());
-    VCMI_HIP(hipMemcpy(soft, sc.nsoft.p, sizeof(int64_t), hipMemcpyDeviceToHost));
+    VCMI_HIP(hipMemcpy(h, sc.ctl.p, sizeof(h), hipMemcpyDeviceToHost));
+    if (h[kCtlHard]) *soft = h[kCtlNSoft];
   }
+  return VCMI_OK;
+}
+
+extern "C" int vcmi_estep_set_path(int path) {
+  using namespace vcmi;
+  if (path != VCMI_ESTEP_AUTO && path != VCMI_ESTEP_HARD && path != VCMI_ESTEP_SOFT)
+    return fail(VCMI_ERR_ARG, "vcmi_estep_set_path: %d is not VCMI_ESTEP_AUTO / _HARD / _SOFT", path);
+  estep_path_choice_ref() = path;
+  return VCMI_OK;
+}
+extern "C" int vcmi_estep_get_path(int *path) {
+  using namespace vcmi;
+  if (!path) return fail(VCMI_ERR_ARG, "vcmi_estep_get_path: NULL argument");
+  *path = estep_path_choice_ref();
   return VCMI_OK;
 }
 

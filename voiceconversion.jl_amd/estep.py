@@ -16,6 +16,22 @@ def stats_len(Dj, M):
     return int(_lib.lib.vcmi_estep_stats_len(int(Dj), int(M)))
 
 
+ESTEP_AUTO, ESTEP_HARD, ESTEP_SOFT = 0, 1, 2
+
+
+def estep_set_path(path):
+    """Which path the diagonal E-step of the calling thread takes from 65536 frames on (include/vcmi.h): ESTEP_AUTO decides per
+    call from a sample of the call's own frames, ESTEP_HARD / ESTEP_SOFT pin the hard-assignment / the one-kernel path."""
+    _lib.check(_lib.lib.vcmi_estep_set_path(int(path)))
+
+
+def estep_get_path():
+    import ctypes as C
+    v = C.c_int(0)
+    _lib.check(_lib.lib.vcmi_estep_get_path(C.byref(v)))
+    return int(v.value)
+
+
 def _params(w, mu, var):
     w = jl_vector(w)
     mu = jl_matrix(mu, "mu")
