@@ -832,6 +832,17 @@ static int estep_mfma_launch(EstepScratch &sc, const double *dX, int64_t N, int 
       VCMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ko), hipFuncAttributeMaxDynamicSharedMemorySize, (int)oshmem));
       hipLaunchKernelGGL(ko, dim3((unsigned)ngrid), dim3(kOnePassThreads), oshmem, st, sc.W16.p, M, dj, dX, N, dmu, (const int64_t *)ctl, sc.hpart.p,
                          softidx, softcount, nchunks);
+#ifdef VCMI_ONEPASS_PROF
+      {
+        unsigned long long h[8], z[8] = {0};
+        (void)hipStreamSynchronize(st);
+        (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(onepass_prof), sizeof(h));
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(onepass_prof), z, sizeof(z));
+        if (h[4])
+          fprintf(stderr, "onepass_prof: %llu wave-rounds; cycles per wave-round: screen %.0f, barrier %.0f, sums %.0f, soft list %.0f\n", h[4],
+                  (double)h[0] / h[4], (double)h[1] / h[4], (double)h[2] / h[4], (double)h[3] / h[4]);
+      }
+#endif
       hipLaunchKernelGGL(estep_onepass_finish_kernel, dim3((unsigned)(M + 1)), dim3(256), 0, st, sc.hpart.p, ngrid, M, dj, dmu, sc.refiv.p, sc.refc.p,
                          softcount, nchunks, softoffs, ctl, dstats, sc.hllm.p);
       hipLaunchKernelGGL(estep_onepass_ll_kernel, dim3(1), dim3(64), 0, st, sc.hllm.p, M, (const int64_t *)ctl, dstats, plen);

@@ -6,13 +6,13 @@
 // log-likelihood -> gather of the frames without an owner -> the FP64 kernel on those -> reduce.  The sort existed to turn
 // "sum the rows of mixture m" into contiguous pieces.  It is not needed: the accumulators can stay where they are and the
 // FRAMES come to them --
-//   * a persistent workgroup of 512 threads per CU owns the 2 x 80 x 128 running sums of ITS frames in registers: thread
-//     (m, p) = (tid / 4, tid % 4) holds sum (x - mu_m) and sum (x - mu_m)^2 over the DJ / 4 dimensions of part p of mixture m
-//     (40 doubles at DJ = 80) and mu_m's 20 values (centred sums: the owner's log-density then needs no cancelling terms);
-//   * per round of 128 frames: each of the eight waves screens 16 frames (the arithmetic of estep_hard_key_kernel, operands of
-//     all mixtures resident in LDS), writes their owners (or "none") to LDS; one barrier; every thread scans the round's 128
+//   * a persistent workgroup of 1024 threads per CU owns the 2 x 80 x 128 running sums of ITS frames in registers: thread
+//     (m, p) = (tid / 8, tid % 8) holds sum (x - mu_m) and sum (x - mu_m)^2 over the DJ / 8 dimensions of part p of mixture m
+//     (20 doubles at DJ = 80; centred sums: the owner's log-density then needs no cancelling terms; mu_m comes with the rows);
+//   * per round of 256 frames: each of the sixteen waves screens 16 frames (the arithmetic of estep_hard_key_kernel, operands of
+//     all mixtures resident in LDS), writes their owners (or "none") to LDS; one barrier; every thread scans the round's 256
 //     owners IN FRAME ORDER and adds the frames its mixture owns -- their rows come back from L2 (this CU read them a moment
-//     ago), 160 contiguous bytes per thread; the owners are double-buffered, so a round costs one barrier;
+//     ago), 80 contiguous bytes per thread; the owners are double-buffered, so a round costs one barrier;
 //   * frames without an owner go, in frame order, into the chunk's list of indices (1024 frames per chunk, chunks handed to the
 //     workgroups with a fixed stride: every sum is a function of the data alone);
 //   * estep_onepass_finish_kernel adds the workgroups' sums in order, uncentres them (S1 = S1' + n mu, S2 = S2' + 2 mu S1' + n
@@ -26,8 +26,15 @@
 
 namespace vcmi {
 
-constexpr int kOnePassThreads = 512;
-constexpr int kOnePassRound = 128;            // frames per round: 8 waves x 16
+#ifdef VCMI_ONEPASS_PROF
+__device__ unsigned long long onepass_prof[8];      // wave cycles: A (screen), barrier, B (sums), soft list; rounds
+#define OP_T(k) { const unsigned long long t_ = __builtin_readcyclecounter(); pp[k] += t_ - tlast; tlast = t_; }
+#else
+#define OP_T(k)
+#endif
+
+constexpr int kOnePassThreads = 1024;
+constexpr int kOnePassRound = 256;            // frames per round: 16 waves x 16
 // ctl (int64, device): [0] 1: the hard-assignment path runs / 0: every frame through estep_mfma_kernel; [1] frames of the
 // "everything soft" launch (N or 0); [2] soft frames found by the one-pass kernel (set by the finish kernel)
 enum { kCtlHard = 0, kCtlAllSoft = 1, kCtlNSoft = 2, kCtlLen = 4 };
@@ -58,28 +65,28 @@ __global__ void estep_path_decide_kernel(const int *__restrict__ hist, int nsamp
 
 // part (per workgroup): [M][1 + 2 dj] doubles: count | S1' (dj) | S2' (dj)
 template <int DJ>
-__global__ void __launch_bounds__(kOnePassThreads) __attribute__((amdgpu_waves_per_eu(2, 2)))
+__global__ void __launch_bounds__(kOnePassThreads)
 estep_onepass_kernel(const unsigned char *__restrict__ W16, int M, int dj, const double *__restrict__ X, int64_t N,
                      const double *__restrict__ mu, const int64_t *__restrict__ ctl, double *__restrict__ part, int *__restrict__ softidx,
                      int *__restrict__ softcount, int64_t nchunks) {
   if (ctl[kCtlHard] == 0) return;
   using C = EstepHardCfg<DJ>;
-  constexpr int NI = C::NI, DP4 = DJ / 4;                    // dimensions per accumulator thread
-  static_assert(DJ % 8 == 0, "an accumulator thread's slice must be a whole number of 16-byte pairs");
+  constexpr int NI = C::NI, DP8 = DJ / 8;                    // dimensions per accumulator thread (eight threads per mixture)
+  static_assert(DJ % 16 == 0, "an accumulator thread's slice must be a whole number of 16-byte pairs");
   extern __shared__ double hsm[];
   const int MT = (M + 15) / 16;
   const int nd = (int)(C::lds_bytes(MT) / 8);
   int *keys = reinterpret_cast<int *>(hsm + nd);             // [2][kOnePassRound]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lcol = lane & 15, lgrp = lane >> 4;
   for (int e = tid; e < nd; e += kOnePassThreads) hsm[e] = reinterpret_cast<const double *>(W16)[e];
-  // this thread's accumulators: mixture am, dimensions d0 .. d0 + DP4 - 1
-  const int am = tid >> 2, d0 = (tid & 3) * DP4;
+  // this thread's accumulators: mixture am, dimensions d0 .. d0 + DP8 - 1 (centred on mu_m, which is fetched with the rows: 1024
+  // threads leave 128 registers each, and the running sums are 4 DP8 of them)
+  const int am = tid >> 3, d0 = (tid & 7) * DP8;
   const bool acc_on = am < M;
-  double mud[DP4], s1[DP4], s2[DP4];
+  double s1[DP8], s2[DP8];
   double cnt = 0.0;
 #pragma unroll
-  for (int i = 0; i < DP4; ++i) {
-    mud[i] = (acc_on && d0 + i < dj) ? mu[(d0 + i) + (size_t)dj * am] : 0.0;
+  for (int i = 0; i < DP8; ++i) {
     s1[i] = 0.0;
     s2[i] = 0.0;
   }
@@ -97,6 +104,9 @@ estep_onepass_kernel(const unsigned char *__restrict__ W16, int M, int dj, const
     ncmax = fmaxf(ncmax, __shfl_xor(ncmax, sh));
   }
   int round = 0;
+#ifdef VCMI_ONEPASS_PROF
+  unsigned long long pp[5] = {0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
+#endif
   for (int64_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
     int nsoft_chunk = 0;                                      // (kept by wave 0)
     const int64_t cf0 = c * kGroupChunk;
@@ -180,24 +190,69 @@ estep_onepass_kernel(const unsigned char *__restrict__ W16, int M, int dj, const
           kr[16 * wave + lcol] = fr < N ? (hard ? bm : M) : -1;
         }
       }
+      OP_T(0)
       __syncthreads();                                          // the round's owners are in LDS (the other buffer is the previous round's)
-      // ---- B: every accumulator thread takes the frames of the round that its mixture owns, in frame order
-      if (acc_on) {
-#pragma unroll 1
-        for (int f4 = 0; f4 < kOnePassRound; f4 += 4) {
-          const int4 k4 = *reinterpret_cast<const int4 *>(kr + f4);
-          const int kk[4] = {k4.x, k4.y, k4.z, k4.w};
+      OP_T(1)
+      // ---- B: every accumulator thread takes the frames of the round that its mixture owns, in frame order.  The eight threads
+      // of a mixture each compare an eighth of the round's owners and exchange the 32-bit masks inside their group; the rows then
+      // come back from L2 two frames at a time together with the mixture's means: one exposed load latency per pair of frames
+      // (the first version took the frames one by one: 16 serialised L2 round trips per wave and round, 1.16 ms per 1.25e6 frames)
+      {
+        unsigned mask[8];
+        {
+          const int part = tid & 7;
+          unsigned mm = 0u;
+          if (acc_on) {
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            if (kk[u] == am) {
-              const double *xr = X + (r0 + f4 + u) * dj + d0;
-              typedef double kd2 __attribute__((ext_vector_type(2)));
-              kd2 v[DP4 / 2];
+            for (int f4 = 0; f4 < 32; f4 += 4) {
+              const int4 k4 = *reinterpret_cast<const int4 *>(kr + 32 * part + f4);
+              mm |= (k4.x == am ? 1u : 0u) << f4 | (k4.y == am ? 2u : 0u) << f4 | (k4.z == am ? 4u : 0u) << f4 | (k4.w == am ? 8u : 0u) << f4;
+            }
+          }
 #pragma unroll
-              for (int i = 0; i < DP4 / 2; ++i) v[i] = (d0 + 2 * i < dj) ? *reinterpret_cast<const kd2 *>(xr + 2 * i) : kd2{0.0, 0.0};
+          for (int q = 0; q < 8; ++q) mask[q] = (unsigned)__shfl((int)mm, (lane & ~7) | q);
+        }
+        typedef double kd2 __attribute__((ext_vector_type(2)));
+        constexpr int HP = DP8 / 2;                               // 16-byte pairs per slice
+        constexpr int KB = 2;                                     // frames per batch
+        int w = 0;                                                // first mask word that may still hold a frame
+        for (;;) {
+          while (w < 7 && mask[w] == 0u) ++w;                     // (per-thread; eight words at most over the whole round)
+          const bool more = mask[w] != 0u;
+          if (__builtin_amdgcn_ballot_w64(more) == 0) break;
+          int pos[KB];
+          bool on[KB];
 #pragma unroll
-              for (int i = 0; i < DP4 / 2; ++i) {
-                const double a = v[i].x - mud[2 * i], b = v[i].y - mud[2 * i + 1];
+          for (int k = 0; k < KB; ++k) {                          // the next KB owned frames of this thread, in order
+            unsigned mw = 0u;
+            int ww = 0;
+#pragma unroll
+            for (int q = 7; q >= 0; --q) {
+              const bool take = mask[q] != 0u;
+              mw = take ? mask[q] : mw;
+              ww = take ? q : ww;
+            }
+            on[k] = mw != 0u;
+            pos[k] = 32 * ww + (on[k] ? __builtin_ctz(mw) : 0);
+            const unsigned clr = mw & (mw - 1u);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) mask[q] = (on[k] && q == ww) ? clr : mask[q];
+          }
+          kd2 v[KB][HP], mv[HP];
+#pragma unroll
+          for (int i = 0; i < HP; ++i) mv[i] = (acc_on && d0 + 2 * i < dj) ? *reinterpret_cast<const kd2 *>(mu + (size_t)dj * am + d0 + 2 * i) : kd2{0.0, 0.0};
+#pragma unroll
+          for (int k = 0; k < KB; ++k) {
+            const double *xr = X + (r0 + (on[k] ? pos[k] : 0)) * dj + d0;
+#pragma unroll
+            for (int i = 0; i < HP; ++i) v[k][i] = (d0 + 2 * i < dj) ? *reinterpret_cast<const kd2 *>(xr + 2 * i) : kd2{0.0, 0.0};
+          }
+#pragma unroll
+          for (int k = 0; k < KB; ++k) {
+            if (on[k]) {
+#pragma unroll
+              for (int i = 0; i < HP; ++i) {
+                const double a = v[k][i].x - mv[i].x, b = v[k][i].y - mv[i].y;
                 s1[2 * i] += a;
                 s1[2 * i + 1] += b;
                 s2[2 * i] = fma(a, a, s2[2 * i]);
@@ -208,24 +263,34 @@ estep_onepass_kernel(const unsigned char *__restrict__ W16, int M, int dj, const
           }
         }
       }
+      OP_T(2)
       // the frames without an owner, in frame order, into the chunk's list (wave 0: two ballots per round)
       if (wave == 0) {
-        const int k0 = kr[lane], k1 = kr[64 + lane];
-        const unsigned long long b0 = __builtin_amdgcn_ballot_w64(k0 == M), b1 = __builtin_amdgcn_ballot_w64(k1 == M);
         const unsigned long long below = (1ull << lane) - 1ull;
-        const int n0 = __builtin_popcountll(b0);
-        if (k0 == M) softidx[cf0 + nsoft_chunk + __builtin_popcountll(b0 & below)] = (int)(r0 + lane);
-        if (k1 == M) softidx[cf0 + nsoft_chunk + n0 + __builtin_popcountll(b1 & below)] = (int)(r0 + 64 + lane);
-        nsoft_chunk += n0 + __builtin_popcountll(b1);
+#pragma unroll
+        for (int h = 0; h < kOnePassRound / 64; ++h) {
+          const int kk = kr[64 * h + lane];
+          const unsigned long long bb = __builtin_amdgcn_ballot_w64(kk == M);
+          if (kk == M) softidx[cf0 + nsoft_chunk + __builtin_popcountll(bb & below)] = (int)(r0 + 64 * h + lane);
+          nsoft_chunk += __builtin_popcountll(bb);
+        }
       }
+      OP_T(3)
+#ifdef VCMI_ONEPASS_PROF
+      pp[4] += 1;
+#endif
     }
     if (wave == 0 && lane == 0) softcount[c] = nsoft_chunk;
   }
+#ifdef VCMI_ONEPASS_PROF
+  if (lane == 0)
+    for (int k = 0; k < 5; ++k) atomicAdd(&onepass_prof[k], pp[k]);
+#endif
   if (acc_on) {
     double *P = part + ((size_t)blockIdx.x * M + am) * (1 + 2 * dj);
-    if ((tid & 3) == 0) P[0] = cnt;
+    if ((tid & 7) == 0) P[0] = cnt;
 #pragma unroll
-    for (int i = 0; i < DP4; ++i) {
+    for (int i = 0; i < DP8; ++i) {
       if (d0 + i < dj) {
         P[1 + d0 + i] = s1[i];
         P[1 + dj + d0 + i] = s2[i];
