@@ -722,7 +722,7 @@ def bench_estep(args, world, rank, variant="synthetic"):
         vc.estep_diag_dev(Xd.t(), w, muT, varT, out=out_t)
 
     # The very first E-step of this process on these frames: model upload, scratch allocation, the path decision from the call's
-    # own frames (csrc/estep_onepass.hpp) -- what a caller pays before anything is warm (nothing is learnt from
+    # own frames (csrc/estep_path.hpp) -- what a caller pays before anything is warm (nothing is learnt from
     # earlier calls any more, so the warm-up steps below can no longer hide a path that mis-fires on its first calls)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -793,19 +793,19 @@ def bench_estep(args, world, rank, variant="synthetic"):
                           "step_ms_with_allreduce": step_ms, "ranks": world, "backend": BACKEND["name"]}}
     prefixes = "estep_mfma_kernel"
     if soft >= 0:
-        # Frames one mixture owns never reach the FP64 pipe: what is left is reading X once (round 6: the screen and the per-mixture
-        # sums in one pass, csrc/estep_onepass.hpp) -- an HBM-bound job.  achieved = 8 Dj N bytes over the
+        # Frames one mixture owns never reach the FP64 pipe: what is left is reading X (once algorithmically; this path reads
+        # it twice -- the screen, then the sums over the sorted rows) -- an HBM-bound job.  achieved = 8 Dj N bytes over the
         # E-step kernels' time; the FP64-formulation figure (flops of the one-kernel formulation / this time) is kept beside
         # it, labelled: those flops are not performed.
         gbs = 8.0 * Dj * N / (kernel_ms * 1e-3) / 1e9
         dj_inst = min(d for d in (32, 48, 64, 80) if d >= Dj)
-        out["roofline"] = {"bound": "hbm", "kernel": f"estep_onepass_kernel<{dj_inst}> (+ prep, path decision, finish; + all-reduce)",
+        out["roofline"] = {"bound": "hbm", "kernel": f"estep_hard_key_kernel<{dj_inst}> + sort + estep_hard_stats_kernel<{dj_inst}> (+ path decision; + all-reduce)",
                            "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
                            "kernel_ms": kernel_ms, "soft_frames": soft, "soft_frac": soft / N,
                            "fp64_formulation_tflops": alg_tflops,
                            "fp64_formulation_note": "flops of the one-kernel formulation over this step's time; owned frames never reach the FP64 pipe",
                            "mfma_issued_per_step": issued_mfma, "algorithmic_bytes_per_frame": 8 * Dj}
-        prefixes = ("estep_hard", "estep_onepass", "estep_path", "estep_mfma_kernel")
+        prefixes = ("estep_hard", "estep_path", "gmmmap_group_sc", "estep_mfma_kernel")
     out["config"]["soft_frames_of_last_step"] = soft          # -1: the one-kernel path ran (the sample of the call's frames found few owners)
     out["cold_first_call_ms"] = cold_first_call_ms
     out["second_call_ms"] = second_call_ms

@@ -182,7 +182,7 @@ int vcmi_estep_diag(const double *X, int64_t N, int Dj, int M, const double *w, 
  * multi-GPU path is a single all-reduce(sum).  Every sum has a fixed order and nothing depends on earlier calls: identical inputs
  * give identical bits, run to run, thread to thread.  From 65536 frames on (M <= 128, Dj <= 80) there are two paths: frames that
  * ONE mixture owns (every other responsibility exactly 0 in double precision) can be settled by a certified low-precision screen
- * and summed per mixture in one pass over X, the rest goes through the FP64 kernel (csrc/estep_hard.hpp, estep_onepass.hpp;
+ * and summed per mixture in one pass over X, the rest goes through the FP64 kernel (csrc/estep_hard.hpp, estep_path.hpp;
  * statistics within 1e-12 of each other).  VCMI_ESTEP_AUTO (default) decides per call, on the device, from a sample of the call's
  * own frames (16 chunks of 1024: at most a quarter without an owner -> the hard-assignment path); vcmi_estep_set_path pins
  * VCMI_ESTEP_HARD or VCMI_ESTEP_SOFT for the calling thread (training loops that must take the same path on every rank).

@@ -611,7 +611,7 @@ estep_mfma_kernel(const double *__restrict__ X, int64_t N, int M, const double *
 }  // namespace vcmi
 #include "estep_wave.hpp"
 #include "estep_hard.hpp"
-#include "estep_onepass.hpp"
+#include "estep_path.hpp"
 namespace vcmi {
 
 // ------------------------------------------------------------------------------------------------
@@ -654,12 +654,12 @@ struct EstepStaging {
 struct EstepScratch {
   DevBuf<double> mu, iv, cst, G, LSE, part, Wpack, cinit, X, stats, raw, refiv, refc, Xpad, statsp;
   DevBuf<unsigned long long> mfma_count;      // optional measurement counter (vcmi_debug_estep_mfma); null: the kernels count nothing
-  // the hard-assignment path (estep_hard.hpp, estep_onepass.hpp): operands, the sample's histograms, the path control words, the
-  // workgroups' partial sums, the chunks' soft lists and the soft frames' matrix
+  // the hard-assignment path (estep_hard.hpp, estep_path.hpp): operands, the sample's histograms, the path control words, sort
+  // scratch, pieces and the soft frames' matrix
   DevBuf<unsigned char> W16;
   DevBuf<int> probe;                           // sample histograms (16 x (M + 1))
-  DevBuf<int64_t> ctl;                         // kCtlLen control words (estep_onepass.hpp) | softoffs (nchunks)
-  DevBuf<int> softlist;                        // softidx (nchunks x 1024) | softcount (nchunks)
+  DevBuf<int64_t> ctl;                         // kCtlLen control words (estep_path.hpp)
+  DevBuf<int> hkeys;                           // key (N) | perm (N) | chunkhist (nchunks x (M + 1)) | total (M + 1)
   DevBuf<double> hpart, hllm, Xsoft;
   bool last_hard = false;                      // the last diagonal E-step of this thread launched the hard-assignment path's kernels
   EstepStaging stage;
@@ -784,7 +784,7 @@ static int estep_mfma_launch(EstepScratch &sc, const double *dX, int64_t N, int 
   VCMI_HIP(hipGetLastError());
   const double *dmu = draw + M;      // (the means of the re-evaluation are the uploaded parameters themselves: raw = [w | mu (Dj,M) | var (Dj,M)])
   if constexpr (!C::SPLIT) {
-    // ---- frames that one mixture owns never see an FP64 MFMA (estep_hard.hpp, estep_onepass.hpp); the rest goes on below, gathered ----
+    // ---- frames that one mixture owns never see an FP64 MFMA (estep_hard.hpp, estep_path.hpp); the rest goes on below, gathered ----
     static constexpr int64_t kHardMinFrames = 65536;
     // Which path?  The hard-assignment path pays where most frames have an owner and costs its pass over X on top of the whole
     // one-kernel E-step where they do not (real joint mel-cepstra: DESIGN 3.3).  Decided from THIS call's data, on the device:
@@ -797,7 +797,6 @@ static int estep_mfma_launch(EstepScratch &sc, const double *dX, int64_t N, int 
     using CH = EstepHardCfg<DJ>;
     const int MT = (M + 15) / 16, MK = M + 1;
     const int64_t nchunks = (N + kGroupChunk - 1) / kGroupChunk;
-    const int ngrid = (int)std::min<int64_t>(nchunks, (int64_t)cus);
     if (hard_on) {
       // the soft frames' dense matrix is as large as X in the worst case: a device without room for it takes the one-kernel path
       // (the reservation used to fail the whole E-step)
@@ -807,47 +806,38 @@ static int estep_mfma_launch(EstepScratch &sc, const double *dX, int64_t N, int 
       }
     }
     if (hard_on) {
-      const int64_t prow = 2 * (int64_t)dj + 1;
+      const int64_t npmax = (N + kHardPiece - 1) / kHardPiece + M, prow = 2 * (int64_t)dj + 2;
       const int64_t nsample = std::min<int64_t>(16, nchunks), cstride = nchunks / nsample;
       VCMI_TRY(sc.W16.reserve((size_t)MT * CH::TILE_BYTES));
       VCMI_TRY(sc.probe.reserve((size_t)nsample * MK));
-      VCMI_TRY(sc.ctl.reserve((size_t)kCtlLen + (size_t)nchunks));
-      VCMI_TRY(sc.softlist.reserve((size_t)nchunks * kGroupChunk + (size_t)nchunks));
-      VCMI_TRY(sc.hpart.reserve((size_t)ngrid * M * prow));
+      VCMI_TRY(sc.ctl.reserve((size_t)kCtlLen));
+      VCMI_TRY(sc.hkeys.reserve((size_t)2 * N + (size_t)(nchunks + 1) * MK));
+      VCMI_TRY(sc.hpart.reserve((size_t)npmax * prow));
       VCMI_TRY(sc.hllm.reserve((size_t)M));
-      int64_t *ctl = sc.ctl.p, *softoffs = ctl + kCtlLen;
-      int *softidx = sc.softlist.p, *softcount = softidx + nchunks * kGroupChunk;
+      int64_t *ctl = sc.ctl.p;
+      const int64_t *gate = ctl + kCtlHard;
+      int *key = sc.hkeys.p, *perm = key + N, *chunkhist = perm + N, *total = chunkhist + nchunks * MK;
       hipLaunchKernelGGL(estep_hard_prep_kernel<DJ>, dim3((unsigned)((MT * CH::NI * 64 + 255) / 256 + 4 * MT)), dim3(256), 0, st, draw, sc.cinit.p, M,
                          dj, sc.W16.p);
-      if (path == VCMI_ESTEP_AUTO) {
-        const size_t kshmem = CH::lds_bytes(MT) + (size_t)MK * sizeof(int);
-        auto kk = estep_hard_key_kernel<DJ>;
-        VCMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kshmem));
+      const size_t kshmem = CH::lds_bytes(MT) + (size_t)MK * sizeof(int);
+      auto kk = estep_hard_key_kernel<DJ>;
+      VCMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kshmem));
+      if (path == VCMI_ESTEP_AUTO)       // the screen on a sample of the call's frames -> the control words
         hipLaunchKernelGGL(kk, dim3((unsigned)nsample), dim3(kHardKeyThreads), kshmem, st, sc.W16.p, M, dj, dX, N, (int *)nullptr, sc.probe.p, nsample,
-                           cstride);
-      }
+                           cstride, (const int64_t *)nullptr);
       hipLaunchKernelGGL(estep_path_decide_kernel, dim3(1), dim3(64), 0, st, sc.probe.p, (int)nsample, MK, path == VCMI_ESTEP_AUTO ? -1 : 1, N, ctl);
-      const size_t oshmem = CH::lds_bytes(MT) + (size_t)2 * kOnePassRound * sizeof(int);
-      auto ko = estep_onepass_kernel<DJ>;
-      VCMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ko), hipFuncAttributeMaxDynamicSharedMemorySize, (int)oshmem));
-      hipLaunchKernelGGL(ko, dim3((unsigned)ngrid), dim3(kOnePassThreads), oshmem, st, sc.W16.p, M, dj, dX, N, dmu, (const int64_t *)ctl, sc.hpart.p,
-                         softidx, softcount, nchunks);
-#ifdef VCMI_ONEPASS_PROF
-      {
-        unsigned long long h[8], z[8] = {0};
-        (void)hipStreamSynchronize(st);
-        (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(onepass_prof), sizeof(h));
-        (void)hipMemcpyToSymbol(HIP_SYMBOL(onepass_prof), z, sizeof(z));
-        if (h[4])
-          fprintf(stderr, "onepass_prof: %llu wave-rounds; cycles per wave-round: screen %.0f, barrier %.0f, sums %.0f, soft list %.0f\n", h[4],
-                  (double)h[0] / h[4], (double)h[1] / h[4], (double)h[2] / h[4], (double)h[3] / h[4]);
-      }
-#endif
-      hipLaunchKernelGGL(estep_onepass_finish_kernel, dim3((unsigned)(M + 1)), dim3(256), 0, st, sc.hpart.p, ngrid, M, dj, dmu, sc.refiv.p, sc.refc.p,
-                         softcount, nchunks, softoffs, ctl, dstats, sc.hllm.p);
-      hipLaunchKernelGGL(estep_onepass_ll_kernel, dim3(1), dim3(64), 0, st, sc.hllm.p, M, (const int64_t *)ctl, dstats, plen);
-      hipLaunchKernelGGL(estep_onepass_gather_kernel, dim3((unsigned)std::min<int64_t>(nchunks, (int64_t)cus * 4)), dim3(256), 0, st, dX, dj, softidx,
-                         softcount, softoffs, nchunks, (const int64_t *)ctl, sc.Xsoft.p);
+      // the hard-assignment path proper: every kernel looks at ctl[kCtlHard] first
+      hipLaunchKernelGGL(kk, dim3((unsigned)std::min<int64_t>(nchunks, (int64_t)cus)), dim3(kHardKeyThreads), kshmem, st, sc.W16.p, M, dj, dX, N, key,
+                         chunkhist, nchunks, (int64_t)1, gate);
+      hipLaunchKernelGGL(gmmmap_group_scan_kernel, dim3((unsigned)MK), dim3(256), 0, st, chunkhist, nchunks, MK, total, gate);
+      hipLaunchKernelGGL(gmmmap_group_scatter_kernel, dim3((unsigned)nchunks), dim3(256), (size_t)17 * MK * sizeof(int), st, key, N, MK,
+                         chunkhist, total, perm, gate);
+      hipLaunchKernelGGL(estep_hard_stats_kernel<DJ>, dim3((unsigned)npmax), dim3(256), 0, st, dX, dj, M, perm, total, dmu, sc.refiv.p,
+                         sc.hpart.p, prow, gate);
+      hipLaunchKernelGGL(estep_hard_reduce_kernel, dim3((unsigned)M), dim3(256), 0, st, sc.hpart.p, prow, total, M, dj, sc.refc.p, dstats,
+                         sc.hllm.p, gate);
+      hipLaunchKernelGGL(estep_hard_ll_kernel, dim3(1), dim3(64), 0, st, sc.hllm.p, M, dstats, plen, gate);
+      hipLaunchKernelGGL(estep_hard_gather_kernel, dim3((unsigned)(cus * 4)), dim3(256), 0, st, dX, dj, M, perm, total, sc.Xsoft.p, ctl + kCtlNSoft, N, gate);
       VCMI_HIP(hipGetLastError());
       sc.last_hard = true;
       // the soft frames through the one-kernel path, their number read on the device; its partials are added on top ...

@@ -94,7 +94,8 @@ constexpr int kHardKeyThreads = 1024;     // one workgroup per CU (the operands 
 template <int DJ>
 __global__ void __launch_bounds__(kHardKeyThreads)
 estep_hard_key_kernel(const unsigned char *__restrict__ W16, int M, int dj, const double *__restrict__ X, int64_t N,
-                      int *__restrict__ key, int *__restrict__ chunkhist, int64_t nrun, int64_t cstride) {
+                      int *__restrict__ key, int *__restrict__ chunkhist, int64_t nrun, int64_t cstride, const int64_t *__restrict__ gate) {
+  if (gate && *gate == 0) return;                             // (estep_path.hpp: the call takes the other path)
   // nrun chunks are looked at, chunk c of the run = chunk c * cstride of the frames: all of them (cstride = 1), or a SAMPLE
   // spread over the frames (key = nullptr: only the histograms are wanted -- estep_hard_probe_sum_kernel)
   using C = EstepHardCfg<DJ>;
@@ -241,7 +242,9 @@ __global__ void estep_hard_probe_sum_kernel(const int *__restrict__ chunkhist, i
 template <int DJ>
 __global__ void __launch_bounds__(256)
 estep_hard_stats_kernel(const double *__restrict__ X, int dj, int M, const int *__restrict__ perm, const int *__restrict__ total,
-                        const double *__restrict__ mu, const double *__restrict__ iv, double *__restrict__ part, int64_t prow) {
+                        const double *__restrict__ mu, const double *__restrict__ iv, double *__restrict__ part, int64_t prow,
+                        const int64_t *__restrict__ gate) {
+  if (gate && *gate == 0) return;
   constexpr int RPP = 256 / DJ;                                 // rows in flight per pass
   __shared__ int piece[3], tot[kHardMaxM];
   __shared__ double red[3][RPP > 1 ? RPP : 1][DJ];
@@ -321,7 +324,8 @@ estep_hard_stats_kernel(const double *__restrict__ X, int dj, int M, const int *
 // share of the log-likelihood, count * c'_m - sum T / 2 with c'_m = log w - (dj log 2 pi + sum log var) / 2 (refc)
 __global__ void __launch_bounds__(256)
 estep_hard_reduce_kernel(const double *__restrict__ part, int64_t prow, const int *__restrict__ total, int M, int dj,
-                         const double *__restrict__ refc, double *__restrict__ stats, double *__restrict__ llm) {
+                         const double *__restrict__ refc, double *__restrict__ stats, double *__restrict__ llm, const int64_t *__restrict__ gate) {
+  if (gate && *gate == 0) return;
   const int m = blockIdx.x;
   __shared__ int tot[kHardMaxM];
   if ((int)threadIdx.x < M) tot[threadIdx.x] = total[threadIdx.x];
@@ -363,7 +367,8 @@ estep_hard_reduce_kernel(const double *__restrict__ part, int64_t prow, const in
 }
 // the hard frames' log-likelihood (mixtures in order) into the statistics' last element; the soft frames' is added by the
 // one-kernel path's reduction afterwards
-__global__ void estep_hard_ll_kernel(const double *__restrict__ llm, int M, double *__restrict__ stats, int64_t plen) {
+__global__ void estep_hard_ll_kernel(const double *__restrict__ llm, int M, double *__restrict__ stats, int64_t plen, const int64_t *__restrict__ gate) {
+  if (gate && *gate == 0) return;
   __shared__ double v[kHardMaxM];
   for (int m = threadIdx.x; m < M; m += blockDim.x) v[m] = llm[m];
   __syncthreads();
@@ -378,7 +383,8 @@ __global__ void estep_hard_ll_kernel(const double *__restrict__ llm, int M, doub
 // their number (read by that kernel from device memory)
 __global__ void __launch_bounds__(256)
 estep_hard_gather_kernel(const double *__restrict__ X, int dj, int M, const int *__restrict__ perm, const int *__restrict__ total,
-                         double *__restrict__ Xs, int64_t *__restrict__ nsoft, int64_t N) {
+                         double *__restrict__ Xs, int64_t *__restrict__ nsoft, int64_t N, const int64_t *__restrict__ gate) {
+  if (gate && *gate == 0) return;                             // (nsoft stays 0: estep_path_decide_kernel)
   const int64_t n = total[M], base = N - n;                     // (every frame has a key: the hard ones come first)
   if (blockIdx.x == 0 && threadIdx.x == 0) nsoft[0] = n;
   const int64_t ne = n * dj;

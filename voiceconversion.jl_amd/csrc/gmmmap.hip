@@ -1355,7 +1355,8 @@ gmmmap_group_key16_kernel(const double *__restrict__ gfrag16, int M, int D, cons
 
 // One workgroup per group m: chunkhist[c][m] -> its exclusive prefix over the chunks (in place) and total[m].
 __global__ void __launch_bounds__(256)
-gmmmap_group_scan_kernel(int *__restrict__ chunkhist, int64_t nchunks, int M, int *__restrict__ total) {
+gmmmap_group_scan_kernel(int *__restrict__ chunkhist, int64_t nchunks, int M, int *__restrict__ total, const int64_t *__restrict__ gate) {
+  if (gate && *gate == 0) return;
   __shared__ int part[256];
   const int m = blockIdx.x, tid = threadIdx.x;
   const int64_t per = (nchunks + 255) / 256, lo = std::min<int64_t>(nchunks, tid * per), hi = std::min<int64_t>(nchunks, lo + per);
@@ -1387,7 +1388,8 @@ gmmmap_group_scan_kernel(int *__restrict__ chunkhist, int64_t nchunks, int M, in
 // the scan) + those in earlier 64-frame rows of this chunk + those on lower lanes of the row.
 __global__ void __launch_bounds__(256)
 gmmmap_group_scatter_kernel(const int *__restrict__ key, int64_t T, int M, const int *__restrict__ chunkhist,
-                            const int *__restrict__ total, int *__restrict__ perm) {
+                            const int *__restrict__ total, int *__restrict__ perm, const int64_t *__restrict__ gate) {
+  if (gate && *gate == 0) return;
   extern __shared__ int lsm[];             // [M] group bases, then [16][M] row counts -> row bases
   int *base = lsm, *rowcnt = lsm + M;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1695,9 +1697,9 @@ static int launch_grouping(vcmi_gmmmap *g, const double *dX, int64_t ldx, int64_
 #undef VCMI_CASE
     default: return fail(VCMI_ERR_ARG, "no MFMA instantiation for padded dimension %d", g->DP);
   }
-  hipLaunchKernelGGL(gmmmap_group_scan_kernel, dim3((unsigned)g->M), dim3(256), 0, st, chunkhist, nchunks, g->M, total);
+  hipLaunchKernelGGL(gmmmap_group_scan_kernel, dim3((unsigned)g->M), dim3(256), 0, st, chunkhist, nchunks, g->M, total, (const int64_t *)nullptr);
   hipLaunchKernelGGL(gmmmap_group_scatter_kernel, dim3((unsigned)nchunks), dim3(256), (size_t)17 * g->M * sizeof(int), st,
-                     key, T, g->M, chunkhist, total, perm);
+                     key, T, g->M, chunkhist, total, perm, (const int64_t *)nullptr);
   VCMI_HIP(hipGetLastError());
   *key_out = key;
   *perm_out = perm;
