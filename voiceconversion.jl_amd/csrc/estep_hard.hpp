@@ -90,7 +90,7 @@ estep_hard_prep_kernel(const double *__restrict__ raw, const double *__restrict_
 }
 
 // keys + one histogram per chunk of kGroupChunk frames (keys 0 .. M: M = soft), as gmmmap_group_key_kernel
-constexpr int kHardKeyThreads = 1024;     // one workgroup per CU (the operands of all mixtures fill half its LDS): sixteen waves
+constexpr int kHardKeyThreads = 512;      // one workgroup per CU (the operands of all mixtures fill half its LDS): eight waves of two frame tiles each (256 registers: sixteen waves of two tiles spill at Dj = 80)
 template <int DJ>
 __global__ void __launch_bounds__(kHardKeyThreads)
 estep_hard_key_kernel(const unsigned char *__restrict__ W16, int M, int dj, const double *__restrict__ X, int64_t N,
@@ -122,92 +122,118 @@ estep_hard_key_kernel(const unsigned char *__restrict__ W16, int M, int dj, cons
   for (int64_t c = blockIdx.x; c < nrun; c += gridDim.x) {
     for (int m = tid; m < MK; m += kHardKeyThreads) hist[m] = 0;
     __syncthreads();
-    for (int it = 0; it < kGroupChunk / (16 * (kHardKeyThreads / 64)); ++it) {
-      const int64_t fr = c * cstride * kGroupChunk + 16 * ((kHardKeyThreads / 64) * it + wave) + lcol;
-      if (fr - lcol >= N) break;                                    // (wave-uniform)
+    // TWO frame tiles (32 frames) per wave and pass: every operand fragment read from LDS feeds six MFMAs instead of three -- the
+    // kernel is bound by those reads (80 ds_read_b128 of 1 KB per 16 frames at Dj = 80, M = 128: round 6, profiles/r06_ab)
+    constexpr int FT = 2;
+    for (int it = 0; it < kGroupChunk / (16 * FT * (kHardKeyThreads / 64)); ++it) {
+      const int64_t fr0 = c * cstride * kGroupChunk + 16 * FT * ((kHardKeyThreads / 64) * it + wave) + lcol;
+      if (fr0 - lcol >= N) break;                                   // (wave-uniform)
       // B operands: slot j < 4: x^2, j >= 4: x, of dimensions 16 i + 4 g + (j & 3); and |[x^2 ; x]|^2
-      u32x4_t bh[NI], bl[NI];
-      double q = 0.0;
-      const double *xr = X + (fr < N ? fr : N - 1) * dj;
+      u32x4_t bh[FT][NI], bl[FT][NI];
+      float nxe[FT];
 #pragma unroll
-      for (int i = 0; i < NI; ++i) {
-        // two 16-byte loads on clamped addresses (dj is even and the rows are 16-byte aligned on this path: a pair is inside
-        // the row or outside it as a whole), masked afterwards -- no branch around a load
-        double x[4];
-        typedef double kd2 __attribute__((ext_vector_type(2)));
+      for (int f = 0; f < FT; ++f) {
+        const int64_t fr = fr0 + 16 * f;
+        double q = 0.0;
+        const double *xr = X + (fr < N ? fr : N - 1) * dj;
 #pragma unroll
-        for (int j = 0; j < 4; j += 2) {
-          const int d = 16 * i + 4 * lgrp + j;
-          const bool in = d < dj;
-          const kd2 v = *reinterpret_cast<const kd2 *>(xr + (in ? d : 0));
-          x[j] = in ? v.x : 0.0;
-          x[j + 1] = in ? v.y : 0.0;
+        for (int i = 0; i < NI; ++i) {
+          // two 16-byte loads on clamped addresses (dj is even and the rows are 16-byte aligned on this path: a pair is inside
+          // the row or outside it as a whole), masked afterwards -- no branch around a load
+          double x[4];
+          typedef double kd2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+          for (int j = 0; j < 4; j += 2) {
+            const int d = 16 * i + 4 * lgrp + j;
+            const bool in = d < dj;
+            const kd2 v = *reinterpret_cast<const kd2 *>(xr + (in ? d : 0));
+            x[j] = in ? v.x : 0.0;
+            x[j + 1] = in ? v.y : 0.0;
+          }
+          double x2[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            x2[j] = x[j] * x[j];
+            q = fma(x2[j], x2[j], fma(x[j], x[j], q));
+          }
+          unsigned ph[4], pl[4];
+          split_bf16_pair(x2[0], x2[1], ph[0], pl[0]);               // slots 0 .. 3: x^2, 4 .. 7: x
+          split_bf16_pair(x2[2], x2[3], ph[1], pl[1]);
+          split_bf16_pair(x[0], x[1], ph[2], pl[2]);
+          split_bf16_pair(x[2], x[3], ph[3], pl[3]);
+#pragma unroll
+          for (int w2 = 0; w2 < 4; ++w2) {
+            bh[f][i][w2] = ph[w2];
+            bl[f][i][w2] = pl[w2];
+          }
         }
-        double x2[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          x2[j] = x[j] * x[j];
-          q = fma(x2[j], x2[j], fma(x[j], x[j], q));
-        }
-        unsigned ph[4], pl[4];
-        split_bf16_pair(x2[0], x2[1], ph[0], pl[0]);               // slots 0 .. 3: x^2, 4 .. 7: x
-        split_bf16_pair(x2[2], x2[3], ph[1], pl[1]);
-        split_bf16_pair(x[0], x[1], ph[2], pl[2]);
-        split_bf16_pair(x[2], x[3], ph[3], pl[3]);
-#pragma unroll
-        for (int w2 = 0; w2 < 4; ++w2) {
-          bh[i][w2] = ph[w2];
-          bl[i][w2] = pl[w2];
-        }
+        q += __shfl_xor(q, 16);
+        q += __shfl_xor(q, 32);
+        nxe[f] = (float)(sqrt(q) * (1.0 + 0x1p-20));
       }
-      q += __shfl_xor(q, 16);
-      q += __shfl_xor(q, 32);
-      const float nxe = (float)(sqrt(q) * (1.0 + 0x1p-20));
       // The margin of every mixture is at most E = NWmax |[x^2 ; x]| + NCmax (the largest 2^-12 |W_m| and 2^-12 |c_m| of the model,
       // floats 0 and 1 behind the operands), so it suffices to know the two largest l^ of the frame: hard iff
       // second + E < (best - E) - 746.  This lane sees rows 4 lgrp .. 4 lgrp + 3 of every mixture tile.
-      float b1 = -INFINITY, b2 = -INFINITY;                         // the largest and second largest l^ among the lane's mixtures
-      int bm = 0;
+      float b1[FT], b2[FT];                                         // the largest and second largest l^ among the lane's mixtures
+      int bm[FT];
+#pragma unroll
+      for (int f = 0; f < FT; ++f) {
+        b1[f] = -INFINITY;
+        b2[f] = -INFINITY;
+        bm[f] = 0;
+      }
       for (int mt = 0; mt < MT; ++mt) {
         const char *tb = reinterpret_cast<const char *>(hsm) + (size_t)mt * C::TILE_BYTES;
-        f32x4_t acc = *reinterpret_cast<const f32x4_t *>(tb + NI * 2048 + 16 * lgrp);
+        f32x4_t acc[FT];
+#pragma unroll
+        for (int f = 0; f < FT; ++f) acc[f] = *reinterpret_cast<const f32x4_t *>(tb + NI * 2048 + 16 * lgrp);
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
           const u32x4_t ah = *reinterpret_cast<const u32x4_t *>(tb + i * 2048 + 16 * lane), al = *reinterpret_cast<const u32x4_t *>(tb + i * 2048 + 1024 + 16 * lane);
-          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, ah), __builtin_bit_cast(bf16x8_t, bh[i]), acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, ah), __builtin_bit_cast(bf16x8_t, bl[i]), acc, 0, 0, 0);
+#pragma unroll
+          for (int f = 0; f < FT; ++f) {
+            acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, ah), __builtin_bit_cast(bf16x8_t, bh[f][i]), acc[f], 0, 0, 0);
+            acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, ah), __builtin_bit_cast(bf16x8_t, bl[f][i]), acc[f], 0, 0, 0);
 #ifndef ESTEP_KEY_TWO_TERMS      // (timing experiment: without the W-lo term -- and its LDS read -- the margins would not hold)
-          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, al), __builtin_bit_cast(bf16x8_t, bh[i]), acc, 0, 0, 0);
+            acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, al), __builtin_bit_cast(bf16x8_t, bh[f][i]), acc[f], 0, 0, 0);
 #endif
+          }
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float v = acc[r];
-          const bool nb = v > b1;
-          b2 = nb ? b1 : fmaxf(b2, v);
-          bm = nb ? 16 * mt + 4 * lgrp + r : bm;
-          b1 = nb ? v : b1;
+        for (int f = 0; f < FT; ++f) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float v = acc[f][r];
+            const bool nb = v > b1[f];
+            b2[f] = nb ? b1[f] : fmaxf(b2[f], v);
+            bm[f] = nb ? 16 * mt + 4 * lgrp + r : bm[f];
+            b1[f] = nb ? v : b1[f];
+          }
         }
       }
-      // across the four lane groups of the frame (ties: the smaller index -- any choice is certified or none is)
 #pragma unroll
-      for (int sh = 16; sh < 64; sh <<= 1) {
-        const float o1 = __shfl_xor(b1, sh), o2 = __shfl_xor(b2, sh);
-        const int om = __shfl_xor(bm, sh);
-        const bool take = o1 > b1 || (o1 == b1 && om < bm);
-        b2 = fmaxf(fmaxf(b2, o2), take ? b1 : o1);
-        bm = take ? om : bm;
-        b1 = take ? o1 : b1;
-      }
-      const float E = fmaf(nwmax, nxe, ncmax) * 1.000001f;
-      const float blo = b1 - E, hi2 = b2 + E;
-      if (lgrp == 0 && fr < N) {
-        // hard: every other mixture is certified more than 746 nats below the best one (exp underflows to exactly 0 below
-        // -745.2; the margin also covers the 1e-7 the one-kernel path's own log-densities may be off), and the best is finite
-        const bool hard = bm < M && blo > -1e29f && hi2 < blo - 746.0f;
-        const int k = hard ? bm : M;
-        if (key) key[fr] = k;
-        atomicAdd(&hist[k], 1);
+      for (int f = 0; f < FT; ++f) {
+        const int64_t fr = fr0 + 16 * f;
+        // across the four lane groups of the frame (ties: the smaller index -- any choice is certified or none is)
+#pragma unroll
+        for (int sh = 16; sh < 64; sh <<= 1) {
+          const float o1 = __shfl_xor(b1[f], sh), o2 = __shfl_xor(b2[f], sh);
+          const int om = __shfl_xor(bm[f], sh);
+          const bool take = o1 > b1[f] || (o1 == b1[f] && om < bm[f]);
+          b2[f] = fmaxf(fmaxf(b2[f], o2), take ? b1[f] : o1);
+          bm[f] = take ? om : bm[f];
+          b1[f] = take ? o1 : b1[f];
+        }
+        const float E = fmaf(nwmax, nxe[f], ncmax) * 1.000001f;
+        const float blo = b1[f] - E, hi2 = b2[f] + E;
+        if (lgrp == 0 && fr < N) {
+          // hard: every other mixture is certified more than 746 nats below the best one (exp underflows to exactly 0 below
+          // -745.2; the margin also covers the 1e-7 the one-kernel path's own log-densities may be off), and the best is finite
+          const bool hard = bm[f] < M && blo > -1e29f && hi2 < blo - 746.0f;
+          const int k = hard ? bm[f] : M;
+          if (key) key[fr] = k;
+          atomicAdd(&hist[k], 1);
+        }
       }
     }
     __syncthreads();
