@@ -563,54 +563,57 @@ bool range_is_pinned(const void *p, size_t bytes) {
     for (const PinnedRange &r : g_pinned)
       if (a >= r.base && a + bytes <= r.base + r.bytes) return true;
   }
+  // memory pinned by another party: worth two runtime look-ups only for transfers that are not small anyway (they stage)
+  if (bytes < ((size_t)64 << 10)) return false;
   hipPointerAttribute_t at;
   if (hipPointerGetAttributes(&at, p) != hipSuccess) {
     (void)hipGetLastError();            // an ordinary pageable pointer: not an error of this call
     return false;
   }
-  if (at.type != hipMemoryTypeHost) return false;
-  // the runtime reports the allocation the pointer lies in, not its extent: the last byte must be known to it as well
-  hipPointerAttribute_t at2;
-  if (hipPointerGetAttributes(&at2, (const char *)p + bytes - 1) != hipSuccess) {
+  if (at.type != hipMemoryTypeHost || !at.devicePointer) return false;
+  // The attributes name the allocation the FIRST byte lies in, not its extent; two pinned allocations with a pageable gap
+  // between them would pass a first-byte / last-byte test.  The extent of the allocation comes from its device
+  // mapping: the whole range must lie inside ONE pinned allocation, else the call stages.
+  hipDeviceptr_t base = nullptr;
+  size_t size = 0;
+  if (hipMemGetAddressRange(&base, &size, (hipDeviceptr_t)at.devicePointer) != hipSuccess) {
     (void)hipGetLastError();
     return false;
   }
-  return at2.type == hipMemoryTypeHost;
+  const uintptr_t off = (uintptr_t)at.devicePointer - (uintptr_t)base;
+  return off <= size && bytes <= size - off;
 }
 }  // namespace
 
 int host_register(void *p, size_t bytes) {
   if (!p || bytes == 0) return fail(VCMI_ERR_ARG, "vcmi_host_register: NULL pointer or zero length");
-  {
-    std::lock_guard<std::mutex> lk(g_pinned_mu);
-    for (const PinnedRange &r : g_pinned)
-      if ((uintptr_t)p < r.base + r.bytes && r.base < (uintptr_t)p + bytes)
-        return fail(VCMI_ERR_ARG, "vcmi_host_register: the range overlaps one that is already registered");
-  }
+  // (one critical section over the overlap test, the registration and the table entry: two threads registering overlapping
+  // ranges at once could both pass the test -- ADVICE r5)
+  std::lock_guard<std::mutex> lk(g_pinned_mu);
+  for (const PinnedRange &r : g_pinned)
+    if ((uintptr_t)p < r.base + r.bytes && r.base < (uintptr_t)p + bytes)
+      return fail(VCMI_ERR_ARG, "vcmi_host_register: the range overlaps one that is already registered");
   const hipError_t e = hipHostRegister(p, bytes, hipHostRegisterPortable);
   if (e != hipSuccess) {
     (void)hipGetLastError();
     return fail(e == hipErrorOutOfMemory ? VCMI_ERR_OOM : VCMI_ERR_HIP, "hipHostRegister of %zu bytes failed: %s", bytes,
                 hipGetErrorString(e));
   }
-  std::lock_guard<std::mutex> lk(g_pinned_mu);
   g_pinned.push_back(PinnedRange{(uintptr_t)p, bytes});
   return VCMI_OK;
 }
 
 int host_unregister(void *p) {
-  {
-    std::lock_guard<std::mutex> lk(g_pinned_mu);
-    auto it = std::find_if(g_pinned.begin(), g_pinned.end(), [p](const PinnedRange &r) { return r.base == (uintptr_t)p; });
-    if (it == g_pinned.end()) return fail(VCMI_ERR_ARG, "vcmi_host_unregister: %p was not registered with vcmi_host_register", p);
-    g_pinned.erase(it);
-  }
+  std::lock_guard<std::mutex> lk(g_pinned_mu);
+  auto it = std::find_if(g_pinned.begin(), g_pinned.end(), [p](const PinnedRange &r) { return r.base == (uintptr_t)p; });
+  if (it == g_pinned.end()) return fail(VCMI_ERR_ARG, "vcmi_host_unregister: %p was not registered with vcmi_host_register", p);
   // transfers of earlier calls are complete (every host-pointer entry point returns with its data delivered)
   const hipError_t e = hipHostUnregister(p);
-  if (e != hipSuccess) {
+  if (e != hipSuccess) {                // the pages are still locked: the entry stays, so that the range is still known as pinned
     (void)hipGetLastError();
     return fail(VCMI_ERR_HIP, "hipHostUnregister failed: %s", hipGetErrorString(e));
   }
+  g_pinned.erase(it);
   return VCMI_OK;
 }
 

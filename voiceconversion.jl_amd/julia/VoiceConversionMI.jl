@@ -55,18 +55,32 @@ end
 # Page-lock an array this process keeps across calls (vcmi_host_register): fvconvert / vc / predict_proba on it then DMA
 # straight from / into it -- no staging copy (include/vcmi.h).  pin!(X) returns X and unpins it when X is finalized;
 # unpin!(X) does it now.  Results are identical with and without.
-const PINNED = Set{UInt}()          # addresses, not the arrays: the table must not keep them alive
+# The table keeps the REGISTERED address and length (not the arrays: it must not keep them alive) behind a lock -- finalizers
+# run at arbitrary points, possibly on another thread.  A pinned array must not be resized (resize! / append! move its data:
+# the old range would stay page-locked; unpin! it first).
+const PINNED = Dict{UInt,Tuple{Ptr{Cvoid},Csize_t}}()     # objectid(X) -> (registered pointer, bytes)
+const PINNED_LOCK = ReentrantLock()
 function pin!(X::Array{Float64})
-    UInt(pointer(X)) in PINNED && return X
-    check(ccall((:vcmi_host_register, libvcmi), Cint, (Ptr{Cvoid}, Csize_t), X, sizeof(X)))
-    push!(PINNED, UInt(pointer(X)))
-    finalizer(unpin!, X)
-    X
+    lock(PINNED_LOCK) do
+        haskey(PINNED, objectid(X)) && return X
+        p = Ptr{Cvoid}(pointer(X))
+        check(ccall((:vcmi_host_register, libvcmi), Cint, (Ptr{Cvoid}, Csize_t), p, sizeof(X)))
+        PINNED[objectid(X)] = (p, Csize_t(sizeof(X)))
+        finalizer(unpin_quietly, X)
+        X
+    end
 end
+# unregisters the pointer that WAS registered (pointer(X) may have moved); returns the library's status
+function unpin_status(X::Array{Float64})
+    lock(PINNED_LOCK) do
+        e = pop!(PINNED, objectid(X), nothing)
+        e === nothing && return Cint(0)
+        ccall((:vcmi_host_unregister, libvcmi), Cint, (Ptr{Cvoid},), e[1])
+    end
+end
+unpin_quietly(X::Array{Float64}) = (unpin_status(X); nothing)        # finalizer: never throws
 function unpin!(X::Array{Float64})
-    UInt(pointer(X)) in PINNED || return X
-    delete!(PINNED, UInt(pointer(X)))
-    check(ccall((:vcmi_host_unregister, libvcmi), Cint, (Ptr{Cvoid},), X))
+    check(unpin_status(X))
     X
 end
 function ispinned(X::Array{Float64})
