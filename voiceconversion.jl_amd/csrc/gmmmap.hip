@@ -1298,53 +1298,71 @@ gmmmap_group_key16_kernel(const double *__restrict__ gfrag16, int M, int D, cons
   for (int64_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
     for (int m = tid; m < M; m += 256) hist[m] = 0;
     __syncthreads();
-    for (int i = 0; i < kGroupChunk / 64; ++i) {
-      const int64_t fr = c * kGroupChunk + 16 * (4 * i + wave) + lcol;
-      if (fr - lcol >= T) break;                                    // (wave-uniform)
-      u32x4_t bh = {0u, 0u, 0u, 0u}, bl = {0u, 0u, 0u, 0u};
-      {
-        unsigned short h[8] = {0, 0, 0, 0, 0, 0, 0, 0}, l[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    // two frame tiles per pass: both tiles' rows are requested before either is used (the kernel is a chain of exposed load
+    // latencies: 16 passes per wave and chunk, each waiting for its rows -- round 6)
+    for (int i = 0; i < kGroupChunk / 64; i += 2) {
+      const int64_t fr0 = c * kGroupChunk + 16 * (4 * i + wave) + lcol;
+      if (fr0 - lcol >= T) break;                                   // (wave-uniform)
+      double xv[2][KS];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int64_t fr = fr0 + 64 * u;
+        const double *xr = X + (fr < T ? fr : T - 1) * ldx;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
           const int k = 4 * ks + lgrp;
-          const double x = (fr < T && k < D) ? X[fr * ldx + k] : 0.0;
-          split_bf16(x, h[ks], l[ks]);
-        }
-#pragma unroll
-        for (int w2 = 0; w2 < 4; ++w2) {
-          bh[w2] = (unsigned)h[2 * w2] | ((unsigned)h[2 * w2 + 1] << 16);
-          bl[w2] = (unsigned)l[2 * w2] | ((unsigned)l[2 * w2 + 1] << 16);
+          xv[u][ks] = xr[k < D ? k : 0];
         }
       }
-      float best = INFINITY;
-      int bm = 0;
-      for (int mt = 0; mt < MT; ++mt) {
-        const char *tb = reinterpret_cast<const char *>(gsm) + (size_t)mt * kKey16TileBytes;
-        const u32x4_t aph = *reinterpret_cast<const u32x4_t *>(tb + 16 * lane), apl = *reinterpret_cast<const u32x4_t *>(tb + 1024 + 16 * lane);
-        f32x4_t acc = *reinterpret_cast<const f32x4_t *>(tb + 2048 + 16 * lgrp);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, aph), __builtin_bit_cast(bf16x8_t, bh), acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, aph), __builtin_bit_cast(bf16x8_t, bl), acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, apl), __builtin_bit_cast(bf16x8_t, bh), acc, 0, 0, 0);
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (acc[r] < best) {
-            best = acc[r];
-            bm = 16 * mt + 4 * lgrp + r;
+      for (int u = 0; u < 2; ++u) {
+        const int64_t fr = fr0 + 64 * u;
+        if (fr - lcol >= T) break;                                  // (wave-uniform: the second tile of the pass lies beyond T)
+        u32x4_t bh = {0u, 0u, 0u, 0u}, bl = {0u, 0u, 0u, 0u};
+        {
+          unsigned short h[8] = {0, 0, 0, 0, 0, 0, 0, 0}, l[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) {
+            const int k = 4 * ks + lgrp;
+            const double x = (fr < T && k < D) ? xv[u][ks] : 0.0;
+            split_bf16(x, h[ks], l[ks]);
           }
-      }
 #pragma unroll
-      for (int sh = 16; sh < 64; sh <<= 1) {
-        const float ov = __shfl_xor(best, sh);
-        const int om = __shfl_xor(bm, sh);
-        if (ov < best || (ov == best && om < bm)) {
-          best = ov;
-          bm = om;
+          for (int w2 = 0; w2 < 4; ++w2) {
+            bh[w2] = (unsigned)h[2 * w2] | ((unsigned)h[2 * w2 + 1] << 16);
+            bl[w2] = (unsigned)l[2 * w2] | ((unsigned)l[2 * w2 + 1] << 16);
+          }
         }
-      }
-      if (lgrp == 0 && fr < T) {
-        bm = bm < M ? bm : 0;
-        key[fr] = bm;
-        atomicAdd(&hist[bm], 1);
+        float best = INFINITY;
+        int bm = 0;
+        for (int mt = 0; mt < MT; ++mt) {
+          const char *tb = reinterpret_cast<const char *>(gsm) + (size_t)mt * kKey16TileBytes;
+          const u32x4_t aph = *reinterpret_cast<const u32x4_t *>(tb + 16 * lane), apl = *reinterpret_cast<const u32x4_t *>(tb + 1024 + 16 * lane);
+          f32x4_t acc = *reinterpret_cast<const f32x4_t *>(tb + 2048 + 16 * lgrp);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, aph), __builtin_bit_cast(bf16x8_t, bh), acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, aph), __builtin_bit_cast(bf16x8_t, bl), acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, apl), __builtin_bit_cast(bf16x8_t, bh), acc, 0, 0, 0);
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (acc[r] < best) {
+              best = acc[r];
+              bm = 16 * mt + 4 * lgrp + r;
+            }
+        }
+#pragma unroll
+        for (int sh = 16; sh < 64; sh <<= 1) {
+          const float ov = __shfl_xor(best, sh);
+          const int om = __shfl_xor(bm, sh);
+          if (ov < best || (ov == best && om < bm)) {
+            best = ov;
+            bm = om;
+          }
+        }
+        if (lgrp == 0 && fr < T) {
+          bm = bm < M ? bm : 0;
+          key[fr] = bm;
+          atomicAdd(&hist[bm], 1);
+        }
       }
     }
     __syncthreads();
