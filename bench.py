@@ -49,7 +49,7 @@ def estep_flops_per_frame(Dj, M):
     return 8 * Dj * M + 25 * M
 
 
-PMC_DIR = "r05_pmc"
+PMC_DIR = "r06_pmc"
 SOURCE_FILES = ("*.hip", "*.hpp", "*.inc", "*.cpp", "Makefile")
 
 
@@ -724,15 +724,18 @@ def bench_estep(args, world, rank, variant="synthetic"):
     # The very first E-step of this process on these frames: model upload, scratch allocation, the path decision from the call's
     # own frames (csrc/estep_path.hpp) -- what a caller pays before anything is warm (nothing is learnt from
     # earlier calls any more, so the warm-up steps below can no longer hide a path that mis-fires on its first calls)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    step_kernels()
-    torch.cuda.synchronize()
-    cold_first_call_ms = (time.perf_counter() - t0) * 1e3
-    t0 = time.perf_counter()
-    step_kernels()
-    torch.cuda.synchronize()
-    second_call_ms = (time.perf_counter() - t0) * 1e3
+    # (profiling runs launch nothing but the warm-up and the timed steps: the PMC passes count launches per step)
+    cold_first_call_ms = second_call_ms = None
+    if not args.profile_run:
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        step_kernels()
+        torch.cuda.synchronize()
+        cold_first_call_ms = (time.perf_counter() - t0) * 1e3
+        t0 = time.perf_counter()
+        step_kernels()
+        torch.cuda.synchronize()
+        second_call_ms = (time.perf_counter() - t0) * 1e3
     # one set of timed steps prices both parts: `kernel_ms` = start of the step to the mark (the E-step kernels),
     # `allreduce_ms` = the rest (the RCCL all-reduce of the packed statistics; no work with one rank and no process group)
     wall, step_ms = timed_steps(step, args.steps, args.warmup, world, split=True)
@@ -1396,9 +1399,9 @@ def cpu_baseline_cached(workload):
     except (OSError, KeyError, ValueError):
         pass
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", f"r05_{workload}_bench.json")))
+        d = json.load(open(os.path.join(ROOT, "profiles", f"r06_{workload}_bench.json")))
         b = dict(d["cpu_baseline"])
-        b["cached"] = f"from the committed N=1 profile profiles/r05_{workload}_bench.json (another box); not re-timed at N>1"
+        b["cached"] = f"from the committed N=1 profile profiles/r06_{workload}_bench.json (another box); not re-timed at N>1"
         return b
     except (OSError, KeyError, ValueError):
         return None

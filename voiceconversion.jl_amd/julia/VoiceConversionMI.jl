@@ -24,7 +24,7 @@ export DeviceMatrix, FrameByFrameConverter, TrajectoryConverter, GMMMapParam, GM
        align, align_mcep, push_delta, GVDataset,
        DTW, fit!, update!, set_template!, backward,
        predict_proba, predict_proba!, predict, predict!, diffgmm,
-       estep_diag, estep_full, GMMEM, estep!, mstep!, params, set_devices, device_count, set_prune!, convert_plan, pin!, unpin!, ispinned
+       estep_diag, estep_full, estep_set_path, estep_get_path, ESTEP_AUTO, ESTEP_HARD, ESTEP_SOFT, GMMEM, estep!, mstep!, params, set_devices, device_count, set_prune!, convert_plan, pin!, unpin!, ispinned
 
 const libvcmi = get(ENV, "LIBVCMI", "libvcmi")
 
@@ -436,6 +436,16 @@ end
 
 # full-covariance statistics: Σ is (Dj,Dj,M) as in the model file; S2 is (Dj,Dj,M) = Σₙ γₙₘ xₙxₙᵀ.  This is the
 # E-step of the sklearn.mixture.GMM(covariance_type="full") that bin/train_gmm.jl:84-89 constructs.
+# Which of the diagonal E-step's two paths the calling thread takes from 65536 frames on (include/vcmi.h): ESTEP_AUTO decides per
+# call, on the device, from a sample of the call's own frames; ESTEP_HARD / ESTEP_SOFT pin one (e.g. on every rank of a training run)
+const ESTEP_AUTO, ESTEP_HARD, ESTEP_SOFT = Cint(0), Cint(1), Cint(2)
+estep_set_path(path::Integer) = check(ccall((:vcmi_estep_set_path, libvcmi), Cint, (Cint,), path))
+function estep_get_path()
+    p = Ref{Cint}(0)
+    check(ccall((:vcmi_estep_get_path, libvcmi), Cint, (Ptr{Cint},), p))
+    p[]
+end
+
 function estep_full(X::Matrix{Float64}, w::Vector{Float64}, μ::Matrix{Float64}, Σ::Array{Float64,3})
     Dj, M = size(μ)
     size(Σ) == (Dj, Dj, M) || throw(DimensionMismatch("Σ must be (Dj,Dj,M)"))
