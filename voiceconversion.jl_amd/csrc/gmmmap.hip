@@ -145,6 +145,100 @@ __device__ __forceinline__ void unpair_lane_groups(double v, double &v0, double 
 }
 
 // ------------------------------------------------------------------------------------------------
+// Rows of x and y as whole 128-byte lines (round 6).  The MFMA operand / result layout gives lane group g of a frame's column the
+// features 4 j + g (slot j = k-step j): a load or store instruction then touches 32 bytes of each of its 16 frames, and the
+// pieces cost ~8 % of the screened conversion's step (profiles/r06_ab).  Where the rows are 16-byte aligned and unpadded, lane
+// group g moves features 16 b + 4 g .. + 3 instead -- 32 contiguous bytes per lane, a line per frame and block of four slots --
+// and a 4 x 4 transpose across the lane groups (two exchange stages: wave halves with v_permlane32_swap, then 16-lane rows with
+// v_permlane16_swap; an involution) converts between the two: (slot j, group g) <-> (slot g, group j).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void transpose_lane_groups4(double &e0, double &e1, double &e2, double &e3) {
+  unsigned lo[4] = {(unsigned)__double2loint(e0), (unsigned)__double2loint(e1), (unsigned)__double2loint(e2), (unsigned)__double2loint(e3)};
+  unsigned hi[4] = {(unsigned)__double2hiint(e0), (unsigned)__double2hiint(e1), (unsigned)__double2hiint(e2), (unsigned)__double2hiint(e3)};
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {                              // lane groups {2, 3} of slot j <-> lane groups {0, 1} of slot j + 2
+    auto a = __builtin_amdgcn_permlane32_swap(lo[j], lo[j + 2], false, false);
+    auto c = __builtin_amdgcn_permlane32_swap(hi[j], hi[j + 2], false, false);
+    lo[j] = a[0];
+    lo[j + 2] = a[1];
+    hi[j] = c[0];
+    hi[j + 2] = c[1];
+  }
+#pragma unroll
+  for (int j = 0; j < 4; j += 2) {                           // odd lane groups of slot j <-> even lane groups of slot j + 1
+    auto a = __builtin_amdgcn_permlane16_swap(lo[j], lo[j + 1], false, false);
+    auto c = __builtin_amdgcn_permlane16_swap(hi[j], hi[j + 1], false, false);
+    lo[j] = a[0];
+    lo[j + 1] = a[1];
+    hi[j] = c[0];
+    hi[j + 1] = c[1];
+  }
+  e0 = __hiloint2double(hi[0], lo[0]);
+  e1 = __hiloint2double(hi[1], lo[1]);
+  e2 = __hiloint2double(hi[2], lo[2]);
+  e3 = __hiloint2double(hi[3], lo[3]);
+}
+__device__ __forceinline__ bool rows_as_lines(const void *base, int64_t ld, int D, int DP) {
+  return D == DP && DP >= 16 && (ld & 1) == 0 && (reinterpret_cast<uintptr_t>(base) & 15u) == 0;
+}
+// xo[ks] = row[4 ks + lgrp] for the lane's frame (`row` = its first feature; zero when !live or beyond D).  ALL lanes of the
+// wave must call it (the transpose exchanges registers across lanes); a frame that is not live passes any valid row.
+template <int KS>
+__device__ __forceinline__ void load_frame_row(const double *row, bool live, bool lines, int D, int lgrp, double (&xo)[KS]) {
+  constexpr int NB = KS / 4;
+  if (lines) {
+    typedef double xd2 __attribute__((ext_vector_type(2)));
+    xd2 v[NB > 0 ? NB : 1][2];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      v[b][0] = *reinterpret_cast<const xd2 *>(row + 16 * b + 4 * lgrp);
+      v[b][1] = *reinterpret_cast<const xd2 *>(row + 16 * b + 4 * lgrp + 2);
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      double e0 = v[b][0].x, e1 = v[b][0].y, e2 = v[b][1].x, e3 = v[b][1].y;
+      transpose_lane_groups4(e0, e1, e2, e3);
+      xo[4 * b] = live ? e0 : 0.0;
+      xo[4 * b + 1] = live ? e1 : 0.0;
+      xo[4 * b + 2] = live ? e2 : 0.0;
+      xo[4 * b + 3] = live ? e3 : 0.0;
+    }
+#pragma unroll
+    for (int ks = 4 * NB; ks < KS; ++ks) xo[ks] = live ? row[4 * ks + lgrp] : 0.0;
+  } else {
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int k = 4 * ks + lgrp;
+      xo[ks] = (live && k < D) ? row[k] : 0.0;
+    }
+  }
+}
+// row[4 j + lgrp] = yo[j] for the lane's frame; ALL lanes of the wave must call it
+template <int KS>
+__device__ __forceinline__ void store_frame_row(double *row, bool live, bool lines, int D, int lgrp, const double (&yo)[KS]) {
+  constexpr int NB = KS / 4;
+  if (lines) {
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      double e0 = yo[4 * b], e1 = yo[4 * b + 1], e2 = yo[4 * b + 2], e3 = yo[4 * b + 3];
+      transpose_lane_groups4(e0, e1, e2, e3);
+      if (live) {
+        typedef double yd2 __attribute__((ext_vector_type(2)));
+        *reinterpret_cast<yd2 *>(row + 16 * b + 4 * lgrp) = yd2{e0, e1};
+        *reinterpret_cast<yd2 *>(row + 16 * b + 4 * lgrp + 2) = yd2{e2, e3};
+      }
+    }
+  }
+  if (live) {
+#pragma unroll
+    for (int j = 0; j < KS; ++j) {
+      const int r = 4 * j + lgrp;
+      if ((!lines || j >= 4 * NB) && r < D) row[r] = yo[j];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // MFMA tile kernel.  One wave owns FT tiles of 16 frames; a workgroup of WAVES waves shares the
 // per-mixture operand block, double-buffered in LDS.
 // MODE 0: convert (writes Y).  MODE 1: log-weighted densities l_m (writes LP (M,T)), no A tiles used.
@@ -203,11 +297,7 @@ gmmmap_mfma_kernel(const double *__restrict__ packed, int M, int D, const double
   for (int f = 0; f < FT; ++f) {
     const int64_t fr = frame0 + 16 * f + lcol;
     frow[f] = (MODE == 0 && perm != nullptr && fr < T) ? (int64_t)perm[fr] : fr;
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      const int k = 4 * ks + lgrp;
-      xb[f][ks] = (fr < T && k < D) ? X[frow[f] * ldx + k] : 0.0;
-    }
+    load_frame_row<KS>(X + (fr < T ? frow[f] : (int64_t)0) * ldx, fr < T, rows_as_lines(X, ldx, D, DP), D, lgrp, xb[f]);
   }
   // first mixture of the loop: the group of the workgroup's first frame (grouped launch), else 0
   int mfirst = 0;
@@ -825,13 +915,10 @@ gmmmap_mfma_kernel(const double *__restrict__ packed, int M, int D, const double
     for (int f = 0; f < FT; ++f) {
       const int64_t fr = frame0 + 16 * f + lcol;
       const double inv = 1.0 / den[f];
-      if (fr < T) {
+      double yo[KS];
 #pragma unroll
-        for (int j = 0; j < KS; ++j) {
-          const int row = 4 * j + lgrp;
-          if (row < D) Y[frow[f] * ldy + row] = yacc[f][j] * inv;
-        }
-      }
+      for (int j = 0; j < KS; ++j) yo[j] = yacc[f][j] * inv;
+      store_frame_row<KS>(Y + (fr < T ? frow[f] : (int64_t)0) * ldy, fr < T, rows_as_lines(Y, ldy, D, DP), D, lgrp, yo);
     }
   }
 }

@@ -135,63 +135,13 @@ gmmmap_screen_kernel(const double *__restrict__ packed, const double *__restrict
     frow[f] = (fr < T) ? (int64_t)perm[fr] : fr;
     if (frame0 + 16 * f < T) tiles_in_range |= 1u << f;
   }
-  // (round 6) where the rows are 16-byte aligned and unpadded, lane group g fetches features 16 b + 4 g .. + 3 of its frame -- 32
-  // contiguous bytes per lane, a whole 128-byte line per frame and block -- and the 4 x 4 transpose across the lane groups (see
-  // the stores at the end) puts feature 4 j + g into slot j; otherwise 8 bytes per lane as before
-  constexpr int NBLKX = KS / 4;
-  const bool xlines = (D == DP) && NBLKX > 0 && (ldx & 1) == 0 && (reinterpret_cast<uintptr_t>(X) & 15u) == 0;
+  // (round 6: rows as whole 128-byte lines where they are 16-byte aligned and unpadded -- load_frame_row, gmmmap.hip)
+  const bool xlines = rows_as_lines(X, ldx, D, DP);
   auto load_x = [&]() {
 #pragma unroll
     for (int f = 0; f < FT; ++f) {
       const int64_t fr = frame0 + 16 * f + lcol;
-      if (xlines) {
-        typedef double xd2 __attribute__((ext_vector_type(2)));
-        const double *xr = X + (fr < T ? frow[f] : (int64_t)0) * ldx;        // (a position beyond T reads row 0 and is zeroed below)
-        xd2 v[NBLKX > 0 ? NBLKX : 1][2];
-#pragma unroll
-        for (int b = 0; b < NBLKX; ++b) {
-          v[b][0] = *reinterpret_cast<const xd2 *>(xr + 16 * b + 4 * lgrp);
-          v[b][1] = *reinterpret_cast<const xd2 *>(xr + 16 * b + 4 * lgrp + 2);
-        }
-#pragma unroll
-        for (int b = 0; b < NBLKX; ++b) {
-          unsigned lo[4], hi[4];
-          const double e[4] = {v[b][0].x, v[b][0].y, v[b][1].x, v[b][1].y};
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            lo[j] = __double2loint(e[j]);
-            hi[j] = __double2hiint(e[j]);
-          }
-#pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            auto a = __builtin_amdgcn_permlane32_swap(lo[j], lo[j + 2], false, false);
-            auto c = __builtin_amdgcn_permlane32_swap(hi[j], hi[j + 2], false, false);
-            lo[j] = a[0];
-            lo[j + 2] = a[1];
-            hi[j] = c[0];
-            hi[j + 2] = c[1];
-          }
-#pragma unroll
-          for (int j = 0; j < 4; j += 2) {
-            auto a = __builtin_amdgcn_permlane16_swap(lo[j], lo[j + 1], false, false);
-            auto c = __builtin_amdgcn_permlane16_swap(hi[j], hi[j + 1], false, false);
-            lo[j] = a[0];
-            lo[j + 1] = a[1];
-            hi[j] = c[0];
-            hi[j + 1] = c[1];
-          }
-#pragma unroll
-          for (int j = 0; j < 4; ++j) xb[f][4 * b + j] = (fr < T) ? __hiloint2double(hi[j], lo[j]) : 0.0;
-        }
-#pragma unroll
-        for (int ks = 4 * NBLKX; ks < KS; ++ks) xb[f][ks] = (fr < T) ? xr[4 * ks + lgrp] : 0.0;
-      } else {
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-          const int k = 4 * ks + lgrp;
-          xb[f][ks] = (fr < T && k < D) ? X[frow[f] * ldx + k] : 0.0;
-        }
-      }
+      load_frame_row<KS>(X + (fr < T ? frow[f] : (int64_t)0) * ldx, fr < T, xlines, D, lgrp, xb[f]);
     }
   };
   load_x();
@@ -557,58 +507,11 @@ gmmmap_screen_kernel(const double *__restrict__ packed, const double *__restrict
   for (int f = 0; f < FT; ++f) {
     const int64_t fr = frame0 + 16 * f + lcol;
     const double inv = 1.0 / den[f];
-    // Rows of y as whole 128-byte lines where they can be (round 6: the 32-byte pieces -- lane group g holds rows 4 j + g -- cost
-    // ~6 % of the step: profiles/r06_ab/convert_persistent_experiments.txt).  Per block of four slots the 4 x 4 matrix
-    // (slot j, lane group g) -> row 16 b + 4 j + g is transposed across the lane groups (two exchange stages: wave halves, then
-    // 16-lane rows), after which lane group g holds rows 16 b + 4 g .. + 3: 32 contiguous bytes per lane, 128 per frame.
+    // rows of y as whole 128-byte lines where they can be (round 6: store_frame_row, gmmmap.hip)
     double yo[KS];
 #pragma unroll
     for (int j = 0; j < KS; ++j) yo[j] = yacc[f][j] * inv;
-    constexpr int NBLK = KS / 4;
-    // (wave-uniform; padded dimensions, and rows that are not 16-byte aligned -- vc's (D+1,T) matrix --, keep the per-row stores)
-    const bool lines = (D == DP) && NBLK > 0 && (ldy & 1) == 0 && (reinterpret_cast<uintptr_t>(Y) & 15u) == 0;
-    if (lines) {
-#pragma unroll
-      for (int b = 0; b < NBLK; ++b) {
-        unsigned lo[4], hi[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          lo[j] = __double2loint(yo[4 * b + j]);
-          hi[j] = __double2hiint(yo[4 * b + j]);
-        }
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {                              // stage 1: lane groups {2, 3} of slot j <-> lane groups {0, 1} of slot j + 2
-          auto a = __builtin_amdgcn_permlane32_swap(lo[j], lo[j + 2], false, false);
-          auto c = __builtin_amdgcn_permlane32_swap(hi[j], hi[j + 2], false, false);
-          lo[j] = a[0];
-          lo[j + 2] = a[1];
-          hi[j] = c[0];
-          hi[j + 2] = c[1];
-        }
-#pragma unroll
-        for (int j = 0; j < 4; j += 2) {                           // stage 2: odd lane groups of slot j <-> even lane groups of slot j + 1
-          auto a = __builtin_amdgcn_permlane16_swap(lo[j], lo[j + 1], false, false);
-          auto c = __builtin_amdgcn_permlane16_swap(hi[j], hi[j + 1], false, false);
-          lo[j] = a[0];
-          lo[j + 1] = a[1];
-          hi[j] = c[0];
-          hi[j + 1] = c[1];
-        }
-        if (fr < T) {
-          typedef double yd2 __attribute__((ext_vector_type(2)));
-          double *yr = Y + frow[f] * ldy + 16 * b + 4 * lgrp;
-          *reinterpret_cast<yd2 *>(yr) = yd2{__hiloint2double(hi[0], lo[0]), __hiloint2double(hi[1], lo[1])};
-          *reinterpret_cast<yd2 *>(yr + 2) = yd2{__hiloint2double(hi[2], lo[2]), __hiloint2double(hi[3], lo[3])};
-        }
-      }
-    }
-    if (fr < T) {
-#pragma unroll
-      for (int j = 0; j < KS; ++j) {
-        const int row = 4 * j + lgrp;
-        if ((!lines || j >= 4 * NBLK) && row < D) Y[frow[f] * ldy + row] = yo[j];
-      }
-    }
+    store_frame_row<KS>(Y + (fr < T ? frow[f] : (int64_t)0) * ldy, fr < T, rows_as_lines(Y, ldy, D, DP), D, lgrp, yo);
   }
 }
 
