@@ -1391,15 +1391,11 @@ gmmmap_group_key16_kernel(const double *__restrict__ gfrag16, int M, int D, cons
       const int64_t fr0 = c * kGroupChunk + 16 * (4 * i + wave) + lcol;
       if (fr0 - lcol >= T) break;                                   // (wave-uniform)
       double xv[2][KS];
+      const bool klines = rows_as_lines(X, ldx, D, DP);             // (whole lines for the first 16 features: load_frame_row)
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         const int64_t fr = fr0 + 64 * u;
-        const double *xr = X + (fr < T ? fr : T - 1) * ldx;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-          const int k = 4 * ks + lgrp;
-          xv[u][ks] = xr[k < D ? k : 0];
-        }
+        load_frame_row<KS>(X + (fr < T ? fr : T - 1) * ldx, true, klines, D, lgrp, xv[u]);
       }
 #pragma unroll
       for (int u = 0; u < 2; ++u) {

@@ -588,11 +588,7 @@ gmmmap_screen_argmax_kernel(const double *__restrict__ packedU, const double *__
     const int64_t fr = frame0 + 16 * f + lcol;
     frow[f] = (fr < T) ? (int64_t)perm[fr] : fr;
     if (frame0 + 16 * f < T) tiles_in_range |= 1u << f;
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      const int k = 4 * ks + lgrp;
-      xb[f][ks] = (fr < T && k < D) ? X[frow[f] * ldx + k] : 0.0;
-    }
+    load_frame_row<KS>(X + (fr < T ? frow[f] : (int64_t)0) * ldx, fr < T, rows_as_lines(X, ldx, D, DP), D, lgrp, xb[f]);
   }
   __syncthreads();                                               // the bitmaps are zeroed
   if (lgrp == 0) {
