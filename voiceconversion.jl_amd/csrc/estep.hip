@@ -809,7 +809,8 @@ static int estep_mfma_launch(EstepScratch &sc, const double *dX, int64_t N, int 
       const int64_t npmax = (N + kHardPiece - 1) / kHardPiece + M, prow = 2 * (int64_t)dj + 2;
       const int64_t nsample = std::min<int64_t>(16, nchunks), cstride = nchunks / nsample;
       VCMI_TRY(sc.W16.reserve((size_t)MT * CH::TILE_BYTES));
-      VCMI_TRY(sc.probe.reserve((size_t)nsample * MK));
+      constexpr int kSamplePasses = kGroupChunk / (32 * (kHardKeyThreads / 64));      // run units per sampled chunk (one pass each)
+      VCMI_TRY(sc.probe.reserve((size_t)nsample * kSamplePasses * MK));
       VCMI_TRY(sc.ctl.reserve((size_t)kCtlLen));
       VCMI_TRY(sc.hkeys.reserve((size_t)2 * N + (size_t)(nchunks + 1) * MK));
       VCMI_TRY(sc.hpart.reserve((size_t)npmax * prow));
@@ -823,12 +824,13 @@ static int estep_mfma_launch(EstepScratch &sc, const double *dX, int64_t N, int 
       auto kk = estep_hard_key_kernel<DJ>;
       VCMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kshmem));
       if (path == VCMI_ESTEP_AUTO)       // the screen on a sample of the call's frames -> the control words
-        hipLaunchKernelGGL(kk, dim3((unsigned)nsample), dim3(kHardKeyThreads), kshmem, st, sc.W16.p, M, dj, dX, N, (int *)nullptr, sc.probe.p, nsample,
-                           cstride, (const int64_t *)nullptr);
-      hipLaunchKernelGGL(estep_path_decide_kernel, dim3(1), dim3(64), 0, st, sc.probe.p, (int)nsample, MK, path == VCMI_ESTEP_AUTO ? -1 : 1, N, ctl);
+        hipLaunchKernelGGL(kk, dim3((unsigned)(nsample * kSamplePasses)), dim3(kHardKeyThreads), kshmem, st, sc.W16.p, M, dj, dX, N, (int *)nullptr,
+                           sc.probe.p, nsample * kSamplePasses, cstride, (const int64_t *)nullptr, 1);
+      hipLaunchKernelGGL(estep_path_decide_kernel, dim3(1), dim3(64), 0, st, sc.probe.p, (int)(nsample * kSamplePasses), MK,
+                         path == VCMI_ESTEP_AUTO ? -1 : 1, N, ctl);
       // the hard-assignment path proper: every kernel looks at ctl[kCtlHard] first
       hipLaunchKernelGGL(kk, dim3((unsigned)std::min<int64_t>(nchunks, (int64_t)cus)), dim3(kHardKeyThreads), kshmem, st, sc.W16.p, M, dj, dX, N, key,
-                         chunkhist, nchunks, (int64_t)1, gate);
+                         chunkhist, nchunks, (int64_t)1, gate, 0);
       hipLaunchKernelGGL(gmmmap_group_scan_kernel, dim3((unsigned)MK), dim3(256), 0, st, chunkhist, nchunks, MK, total, gate);
       hipLaunchKernelGGL(gmmmap_group_scatter_kernel, dim3((unsigned)nchunks), dim3(256), (size_t)17 * MK * sizeof(int), st, key, N, MK,
                          chunkhist, total, perm, gate);

@@ -94,10 +94,12 @@ constexpr int kHardKeyThreads = 512;      // one workgroup per CU (the operands 
 template <int DJ>
 __global__ void __launch_bounds__(kHardKeyThreads)
 estep_hard_key_kernel(const unsigned char *__restrict__ W16, int M, int dj, const double *__restrict__ X, int64_t N,
-                      int *__restrict__ key, int *__restrict__ chunkhist, int64_t nrun, int64_t cstride, const int64_t *__restrict__ gate) {
+                      int *__restrict__ key, int *__restrict__ chunkhist, int64_t nrun, int64_t cstride, const int64_t *__restrict__ gate,
+                      int split) {
   if (gate && *gate == 0) return;                             // (estep_path.hpp: the call takes the other path)
   // nrun chunks are looked at, chunk c of the run = chunk c * cstride of the frames: all of them (cstride = 1), or a SAMPLE
-  // spread over the frames (key = nullptr: only the histograms are wanted -- estep_hard_probe_sum_kernel)
+  // spread over the frames (key = nullptr: only the histograms are wanted -- estep_path_decide_kernel).  split = 1: a run unit is
+  // ONE pass (a quarter of a chunk: unit u = pass u % 4 of chunk u / 4) -- the sample then spreads over four times as many CUs
   using C = EstepHardCfg<DJ>;
   constexpr int NI = C::NI;
   extern __shared__ double hsm[];
@@ -119,13 +121,16 @@ estep_hard_key_kernel(const unsigned char *__restrict__ W16, int M, int dj, cons
     nwmax = fmaxf(nwmax, __shfl_xor(nwmax, sh));
     ncmax = fmaxf(ncmax, __shfl_xor(ncmax, sh));
   }
-  for (int64_t c = blockIdx.x; c < nrun; c += gridDim.x) {
+  constexpr int kPasses = kGroupChunk / (16 * 2 * (kHardKeyThreads / 64));
+  for (int64_t cu = blockIdx.x; cu < nrun; cu += gridDim.x) {
+    const int64_t c = split ? cu / kPasses : cu;
     for (int m = tid; m < MK; m += kHardKeyThreads) hist[m] = 0;
     __syncthreads();
     // TWO frame tiles (32 frames) per wave and pass: every operand fragment read from LDS feeds six MFMAs instead of three -- the
     // kernel is bound by those reads (80 ds_read_b128 of 1 KB per 16 frames at Dj = 80, M = 128: round 6, profiles/r06_ab)
     constexpr int FT = 2;
-    for (int it = 0; it < kGroupChunk / (16 * FT * (kHardKeyThreads / 64)); ++it) {
+    static_assert(kPasses == kGroupChunk / (16 * FT * (kHardKeyThreads / 64)), "passes per chunk");
+    for (int it = split ? (int)(cu % kPasses) : 0; it < (split ? (int)(cu % kPasses) + 1 : kPasses); ++it) {
       const int64_t fr0 = c * cstride * kGroupChunk + 16 * FT * ((kHardKeyThreads / 64) * it + wave) + lcol;
       if (fr0 - lcol >= N) break;                                   // (wave-uniform)
       // B operands: slot j < 4: x^2, j >= 4: x, of dimensions 16 i + 4 g + (j & 3); and |[x^2 ; x]|^2
@@ -237,7 +242,7 @@ estep_hard_key_kernel(const unsigned char *__restrict__ W16, int M, int dj, cons
       }
     }
     __syncthreads();
-    for (int m = tid; m < MK; m += kHardKeyThreads) chunkhist[c * MK + m] = hist[m];
+    for (int m = tid; m < MK; m += kHardKeyThreads) chunkhist[cu * MK + m] = hist[m];
     __syncthreads();
   }
 }
