@@ -130,7 +130,31 @@ estep_hard_key_kernel(const unsigned char *__restrict__ W16, int M, int dj, cons
     // kernel is bound by those reads (80 ds_read_b128 of 1 KB per 16 frames at Dj = 80, M = 128: round 6, profiles/r06_ab)
     constexpr int FT = 2;
     static_assert(kPasses == kGroupChunk / (16 * FT * (kHardKeyThreads / 64)), "passes per chunk");
-    for (int it = split ? (int)(cu % kPasses) : 0; it < (split ? (int)(cu % kPasses) + 1 : kPasses); ++it) {
+    // the rows of a pass are requested one pass ahead (into the registers the previous pass's rows have just left: they are
+    // converted to bf16 operands first), so that their latency runs under the MFMAs of the pass before
+    typedef double kd2 __attribute__((ext_vector_type(2)));
+    kd2 xraw[FT][NI][2];
+    const int it_first = split ? (int)(cu % kPasses) : 0, it_end = split ? it_first + 1 : kPasses;
+    auto request = [&](int it) {
+      const int64_t fr0 = c * cstride * kGroupChunk + 16 * FT * ((kHardKeyThreads / 64) * it + wave) + lcol;
+#pragma unroll
+      for (int f = 0; f < FT; ++f) {
+        const int64_t fr = fr0 + 16 * f;
+        // 16-byte loads on clamped addresses (dj is even and the rows are 16-byte aligned on this path: a pair is inside the row
+        // or outside it as a whole), masked when they are used -- no branch around a load
+        const double *xr = X + (fr < N ? fr : N - 1) * dj;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const int d = 16 * i + 4 * lgrp + 2 * j;
+            xraw[f][i][j] = *reinterpret_cast<const kd2 *>(xr + (d < dj ? d : 0));
+          }
+        }
+      }
+    };
+    request(it_first);
+    for (int it = it_first; it < it_end; ++it) {
       const int64_t fr0 = c * cstride * kGroupChunk + 16 * FT * ((kHardKeyThreads / 64) * it + wave) + lcol;
       if (fr0 - lcol >= N) break;                                   // (wave-uniform)
       // B operands: slot j < 4: x^2, j >= 4: x, of dimensions 16 i + 4 g + (j & 3); and |[x^2 ; x]|^2
@@ -138,20 +162,15 @@ estep_hard_key_kernel(const unsigned char *__restrict__ W16, int M, int dj, cons
       float nxe[FT];
 #pragma unroll
       for (int f = 0; f < FT; ++f) {
-        const int64_t fr = fr0 + 16 * f;
         double q = 0.0;
-        const double *xr = X + (fr < N ? fr : N - 1) * dj;
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
-          // two 16-byte loads on clamped addresses (dj is even and the rows are 16-byte aligned on this path: a pair is inside
-          // the row or outside it as a whole), masked afterwards -- no branch around a load
           double x[4];
-          typedef double kd2 __attribute__((ext_vector_type(2)));
 #pragma unroll
           for (int j = 0; j < 4; j += 2) {
             const int d = 16 * i + 4 * lgrp + j;
             const bool in = d < dj;
-            const kd2 v = *reinterpret_cast<const kd2 *>(xr + (in ? d : 0));
+            const kd2 v = xraw[f][i][j >> 1];
             x[j] = in ? v.x : 0.0;
             x[j + 1] = in ? v.y : 0.0;
           }
@@ -176,6 +195,7 @@ estep_hard_key_kernel(const unsigned char *__restrict__ W16, int M, int dj, cons
         q += __shfl_xor(q, 32);
         nxe[f] = (float)(sqrt(q) * (1.0 + 0x1p-20));
       }
+      if (it + 1 < it_end) request(it + 1);                        // (beyond N: clamped to the last row, never used)
       // The margin of every mixture is at most E = NWmax |[x^2 ; x]| + NCmax (the largest 2^-12 |W_m| and 2^-12 |c_m| of the model,
       // floats 0 and 1 behind the operands), so it suffices to know the two largest l^ of the frame: hard iff
       // second + E < (best - E) - 746.  This lane sees rows 4 lgrp .. 4 lgrp + 3 of every mixture tile.
