@@ -463,3 +463,58 @@ def test_hard_assignment_path_a_handful_of_shared_frames(vc):
     assert relerr(a[0], r0) < TOL and relerr(a[1], r1.T) < TOL and relerr(a[2], r2.T) < TOL
     assert abs(a[3] - rl) < TOL * abs(rl)
     assert abs(a[0].sum() - N) < 1e-6
+
+
+@pytest.mark.parametrize("Dj,M,N", [(80, 1, 700), (80, 16, 4000), (80, 17, 4001), (80, 32, 12_345), (80, 33, 3000), (48, 32, 31), (30, 9, 32),
+                                    (79, 32, 33), (64, 20, 2500), (32, 32, 100_000), (80, 32, 70_001), (80, 12, 66_000)])
+def test_small_models_take_the_small_workgroups(vc, Dj, M, N):
+    """M <= 32 (bin/train_gmm.jl:84-89 trains 32 mixtures): estep_small_kernel -- workgroups of two waves per
+    mixture tile, 32-frame blocks, a softmax as wide as the model -- against the oracle and against estep_mfma_kernel's
+    shared-tile form of the same model (forced); M = 33 is the first model of the other side.  Shared responsibilities
+    (clustered means) so that the softmax matters; the calls of >= 65536 frames come through the path decision and its gated
+    launches."""
+    from oracle import c_oracle as co
+    from voiceconversion_jl_amd import _lib
+    w, mu, var, X = _hard_case(77 + Dj + M, Dj, M, N, 5.0, 1e-3, 1.0, 2.0)
+    r = co.estep_diag(X, w, mu, var)
+
+    def run(force):
+        _lib.debug_force(force)
+        try:
+            return vc.estep_diag(X.T, w, mu.T, var.T)
+        finally:
+            _lib.debug_force(0)
+
+    new, again, old = run(0), run(0), run(_lib.DBG_ESTEP_NO_SMALL)
+    for got in (new, old):
+        assert relerr(got[0], r[0]) < TOL and relerr(got[1], r[1].T) < TOL and relerr(got[2], r[2].T) < TOL
+        assert abs(got[3] - r[3]) < TOL * abs(r[3])
+    assert abs(new[0].sum() - N) < 1e-9 * N
+    assert all(np.array_equal(a, b) for a, b in zip(new[:3], again[:3])) and new[3] == again[3]      # a function of the data alone
+    assert relerr(new[1], old[1]) < 1e-12 and relerr(new[2], old[2]) < 1e-12
+
+
+def test_small_model_on_the_reference_model_and_its_paths(vc, joint_model):
+    """the reference's trained 32-mixture model (test/models/clb_and_slt_gmm32_order40.jld), its diagonal: frames of its own that
+    share their mixtures (every frame through estep_small_kernel, decided on the device) and, with the variances shrunk, frames
+    that one mixture owns (hard-assignment path; the few soft ones through estep_small_kernel with the device's count)"""
+    from oracle import c_oracle as co
+    w, mu, sig = joint_model
+    var0 = np.stack([np.diag(s.T).copy() for s in sig])
+    rg = np.random.default_rng(9)
+    N = 90_000
+    comp = rg.choice(len(w), size=N, p=w)
+    from voiceconversion_jl_amd import _lib
+    for shrink, path in ((1.0, vc.ESTEP_AUTO), (1e-3, vc.ESTEP_HARD), (1e-3, vc.ESTEP_AUTO)):
+        var = var0 * shrink
+        X = mu[comp] + rg.standard_normal((N, mu.shape[1])) * np.sqrt(var[comp])
+        r0, r1, r2, rl = co.estep_diag(X, w, mu, var)
+        vc.estep_set_path(path)
+        try:
+            S0, S1, S2, ll = vc.estep_diag(X.T, w, mu.T, var.T)
+        finally:
+            vc.estep_set_path(vc.ESTEP_AUTO)
+        assert relerr(S0, r0) < TOL and relerr(S1, r1.T) < TOL and relerr(S2, r2.T) < TOL
+        assert abs(ll - rl) < TOL * abs(rl)
+        if path == vc.ESTEP_HARD:                # (-1: the one-kernel path; otherwise the number of soft frames)
+            assert 0 <= _lib.estep_last_soft() <= N

@@ -4,10 +4,15 @@ the bench.  Prints ms per 1.25e6 frames and the issued-MFMA fraction is left to 
 import sys, time
 import numpy as np, torch
 sys.path.insert(0, ".")
+import os
 import voiceconversion_jl_amd as vc
+from voiceconversion_jl_amd import _lib
+
+_lib.debug_force(int(os.environ.get("FORCE", "0")))        # e.g. FORCE=1024: M <= 32 through estep_mfma_kernel's shared tiles
+MS = [int(m) for m in os.environ.get("MS", "8,16,32,64,128").split(",")]
 
 Dj, N = 80, 1_250_000
-for M in (8, 16, 32, 64, 128):
+for M in MS:
     for sep in (3.0, 40.0):
         rg = np.random.default_rng(M)
         w = rg.dirichlet(2.0 * np.ones(M))

@@ -216,6 +216,7 @@ DBG_PREDICT_SCREEN = 16777216
 DBG_SCREEN_FP64 = 33554432
 DBG_GROUP_KEY_FP64 = 67108864
 DBG_ESTEP_NO_HARD = 134217728
+DBG_ESTEP_NO_SMALL = 1024
 
 
 def estep_last_soft():

@@ -610,6 +610,7 @@ estep_mfma_kernel(const double *__restrict__ X, int64_t N, int M, const double *
 
 }  // namespace vcmi
 #include "estep_wave.hpp"
+#include "estep_small.hpp"
 #include "estep_hard.hpp"
 #include "estep_path.hpp"
 namespace vcmi {
@@ -784,6 +785,35 @@ static int estep_mfma_launch(EstepScratch &sc, const double *dX, int64_t N, int 
   VCMI_HIP(hipGetLastError());
   const double *dmu = draw + M;      // (the means of the re-evaluation are the uploaded parameters themselves: raw = [w | mu (Dj,M) | var (Dj,M)])
   if constexpr (!C::SPLIT) {
+    // The one-kernel E-step of `nfr` frames at Xp (their number read from *ndev on the device where that is given: the grid
+    // then covers the CUs) + the fixed-order reduction of its partial statistics into dstats.  M <= 32: estep_small.hpp.
+    auto soft = [&](const double *Xp, int64_t nfr, const int64_t *ndev, int accumulate) -> int {
+      if (M <= 32 && !debug_flag(kDbgEstepNoSmall)) {
+        auto go = [&](auto cfg, auto kern) -> int {
+          using CS = decltype(cfg);
+          const int g = (int)std::min<int64_t>((nfr + CS::FB - 1) / CS::FB, (int64_t)cus * CS::WG_PER_CU);
+          VCMI_TRY(sc.part.reserve((size_t)g * 2 * plen));
+          VCMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CS::LDS_BYTES));
+          hipLaunchKernelGGL(kern, dim3(g), dim3(64 * CS::NW), CS::LDS_BYTES, st, Xp, nfr, M, sc.Wpack.p, sc.cinit.p, sc.part.p, plen, dmu,
+                             sc.refiv.p, sc.refc.p, dj, sc.mfma_count.p, ndev);
+          VCMI_HIP(hipGetLastError());
+          estep_reduce_launch(sc.part.p, g * 2, plen, dstats, st, accumulate, ndev);
+          VCMI_HIP(hipGetLastError());
+          return VCMI_OK;
+        };
+        return M <= 16 ? go(EstepSmallCfg<DJ, 1>{}, estep_small_kernel<DJ, 1>) : go(EstepSmallCfg<DJ, 2>{}, estep_small_kernel<DJ, 2>);
+      }
+      const int g = (int)std::min<int64_t>((nfr + C::FB - 1) / C::FB, cus);
+      VCMI_TRY(sc.part.reserve((size_t)g * wpt * plen));
+      auto kern = (mtp < 8) ? estep_mfma_kernel<DJ, 0, true> : estep_mfma_kernel<DJ, 0, false>;
+      VCMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES));
+      hipLaunchKernelGGL(kern, dim3(g), dim3(512), C::LDS_BYTES, st, Xp, nfr, M, sc.Wpack.p, sc.cinit.p, sc.part.p, plen, dmu,
+                         sc.refiv.p, sc.refc.p, (double *)nullptr, dj, mtp, sc.mfma_count.p, ndev);
+      VCMI_HIP(hipGetLastError());
+      estep_reduce_launch(sc.part.p, g * wpt, plen, dstats, st, accumulate, ndev);
+      VCMI_HIP(hipGetLastError());
+      return VCMI_OK;
+    };
     // ---- frames that one mixture owns never see an FP64 MFMA (estep_hard.hpp, estep_path.hpp); the rest goes on below, gathered ----
     static constexpr int64_t kHardMinFrames = 65536;
     // Which path?  The hard-assignment path pays where most frames have an owner and costs its pass over X on top of the whole
@@ -843,20 +873,9 @@ static int estep_mfma_launch(EstepScratch &sc, const double *dX, int64_t N, int 
       VCMI_HIP(hipGetLastError());
       sc.last_hard = true;
       // the soft frames through the one-kernel path, their number read on the device; its partials are added on top ...
-      VCMI_TRY(sc.part.reserve((size_t)cus * wpt * plen));
-      auto kern = (mtp < 8) ? estep_mfma_kernel<DJ, 0, true> : estep_mfma_kernel<DJ, 0, false>;
-      VCMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES));
-      hipLaunchKernelGGL(kern, dim3(cus), dim3(512), C::LDS_BYTES, st, sc.Xsoft.p, N, M, sc.Wpack.p, sc.cinit.p, sc.part.p, plen, dmu,
-                         sc.refiv.p, sc.refc.p, (double *)nullptr, dj, mtp, sc.mfma_count.p, (const int64_t *)(ctl + kCtlNSoft));
-      VCMI_HIP(hipGetLastError());
-      estep_reduce_launch(sc.part.p, cus * wpt, plen, dstats, st, /*accumulate=*/1, (const int64_t *)(ctl + kCtlNSoft));
+      VCMI_TRY(soft(sc.Xsoft.p, /*every CU: the count is the device's*/ (int64_t)1 << 40, (const int64_t *)(ctl + kCtlNSoft), /*accumulate=*/1));
       // ... or, where the sample found few owners, every frame (ctl[kCtlAllSoft] = N; 0 otherwise: both launches return at once)
-      if (path == VCMI_ESTEP_AUTO) {
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), C::LDS_BYTES, st, dX, N, M, sc.Wpack.p, sc.cinit.p, sc.part.p, plen, dmu,
-                           sc.refiv.p, sc.refc.p, (double *)nullptr, dj, mtp, sc.mfma_count.p, (const int64_t *)(ctl + kCtlAllSoft));
-        estep_reduce_launch(sc.part.p, grid * wpt, plen, dstats, st, /*accumulate=*/0, (const int64_t *)(ctl + kCtlAllSoft));
-      }
-      VCMI_HIP(hipGetLastError());
+      if (path == VCMI_ESTEP_AUTO) VCMI_TRY(soft(dX, N, (const int64_t *)(ctl + kCtlAllSoft), /*accumulate=*/0));
       return VCMI_OK;
     }
     if (mtp == 8 && debug_flag(kDbgEstepWaveKernel)) {      // (measured slower than the three-barrier kernel: 1.59 against 1.32 ms -- DESIGN 3.3 round 5)
@@ -873,14 +892,7 @@ static int estep_mfma_launch(EstepScratch &sc, const double *dX, int64_t N, int 
       VCMI_HIP(hipGetLastError());
       return VCMI_OK;
     }
-    auto kern = (mtp < 8) ? estep_mfma_kernel<DJ, 0, true> : estep_mfma_kernel<DJ, 0, false>;
-    VCMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 (int)C::LDS_BYTES));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), C::LDS_BYTES, st, dX, N, M, sc.Wpack.p, sc.cinit.p, sc.part.p, plen, dmu,
-                       sc.refiv.p, sc.refc.p, (double *)nullptr, dj, mtp, sc.mfma_count.p, (const int64_t *)nullptr);
-    VCMI_HIP(hipGetLastError());
-    estep_reduce_launch(sc.part.p, grid * wpt, plen, dstats, st, /*accumulate=*/0);     // (dstats was not zeroed)
-    VCMI_HIP(hipGetLastError());
+    VCMI_TRY(soft(dX, N, (const int64_t *)nullptr, /*accumulate=*/0));     // (dstats was not zeroed)
   } else {
     // two kernels per chunk of frames, the responsibilities (frames x 128 doubles) through HBM in between
     constexpr int64_t kSplitChunk = 1 << 20;

@@ -117,6 +117,7 @@ enum : unsigned {
   kDbgPredictScreen = 16777216u,     // predict: grouping + screened arg-max on long inputs whatever the model
   kDbgScreenFp64 = 33554432u,        // fvconvert shape 3: the screen on FP64 MFMAs instead of the certified bf16-split one
   kDbgGroupKeyFp64 = 67108864u,      // grouping keys from FP64 MFMAs (gmmmap_group_key_kernel) instead of the bf16-split ones
+  kDbgEstepNoSmall = 1024u,          // diagonal E-step, M <= 32: estep_mfma_kernel with shared tiles instead of estep_small_kernel (estep_small.hpp)
   kDbgEstepNoHard = 134217728u,      // diagonal E-step: every frame through estep_mfma_kernel (no hard-assignment path, estep_hard.hpp)
   kDbgConvertWideTiles = 131072u, // fvconvert: two frame tiles per wave (128-frame workgroups) also for calls of a few thousand frames
   kDbgPredictNoEarlyExit = 64u   // predict / trajectory argmax: every whitening tile of every mixture (MODE 2) instead of the early exit (MODE 3)
