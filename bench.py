@@ -775,6 +775,10 @@ def bench_estep(args, world, rank, variant="synthetic"):
     except Exception:  # noqa: BLE001  (an older library)
         soft = -1
     alg_tflops = estep_flops_per_frame(Dj, M) * N / (kernel_ms * 1e-3) / 1e12
+    # the FP64 kernel of the one-kernel path: M <= 32 (Dj <= 80) runs in workgroups as small as the model (csrc/estep_small.hpp)
+    dj_soft = min(d for d in (32, 48, 64, 80, 112, 160) if d >= Dj) if Dj <= 160 else Dj
+    small = mfma_path and M <= 32 and dj_soft <= 80 and not (args.debug_force & 1024)
+    soft_kernel = f"estep_small_kernel<{dj_soft}, {1 if M <= 16 else 2}>" if small else f"estep_mfma_kernel<{dj_soft}>"
     iss_tflops = issued_mfma * MFMA_FLOP / (kernel_ms * 1e-3) / 1e12 if issued_mfma else None
     achieved = min(alg_tflops, iss_tflops) if iss_tflops else alg_tflops
     out = {"metric": "diag-GMM E-step frames/sec (Dj=%d, M=%d)" % (Dj, M), "value": fps, "unit": "frames/s", "n_gpus": world,
@@ -785,7 +789,7 @@ def bench_estep(args, world, rank, variant="synthetic"):
                       f"diag E-step, Dj={Dj}, M={M} ({'MFMA kernel' if mfma_path else 'generic kernels'}; not a BASELINE config)",
                       "Dj": Dj, "M": M, "frames_per_gpu": N,
                       "collective": "all-reduce(sum) of %d doubles per step" % vc.stats_len(Dj, M)},
-           "roofline": {"bound": "mfma", "kernel": (f"estep_mfma_kernel<{min(d for d in (32, 48, 64, 80, 160) if d >= Dj)}>" if mfma_path else "estep_gamma_kernel + estep_stats_kernel (generic path)") + " (+ all-reduce)", "achieved": achieved,
+           "roofline": {"bound": "mfma", "kernel": (soft_kernel if mfma_path else "estep_gamma_kernel + estep_stats_kernel (generic path)") + " (+ all-reduce)", "achieved": achieved,
                         "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS,
                         "traffic": None,
                         "algorithmic_frac": alg_tflops / FP64_PEAK_TFLOPS,
@@ -794,7 +798,7 @@ def bench_estep(args, world, rank, variant="synthetic"):
                         "flop_per_frame": estep_flops_per_frame(Dj, M), "kernel_ms": kernel_ms},
            "collective": {"op": "all-reduce(sum), %d doubles" % vc.stats_len(Dj, M), "allreduce_ms": allreduce_ms,
                           "step_ms_with_allreduce": step_ms, "ranks": world, "backend": BACKEND["name"]}}
-    prefixes = "estep_mfma_kernel"
+    prefixes = ("estep_small_kernel", "estep_mfma_kernel")
     if soft >= 0:
         # Frames one mixture owns never reach the FP64 pipe: what is left is reading X (once algorithmically; this path reads
         # it twice -- the screen, then the sums over the sorted rows) -- an HBM-bound job.  achieved = 8 Dj N bytes over the
@@ -808,7 +812,7 @@ def bench_estep(args, world, rank, variant="synthetic"):
                            "fp64_formulation_tflops": alg_tflops,
                            "fp64_formulation_note": "flops of the one-kernel formulation over this step's time; owned frames never reach the FP64 pipe",
                            "mfma_issued_per_step": issued_mfma, "algorithmic_bytes_per_frame": 8 * Dj}
-        prefixes = ("estep_hard", "estep_path", "gmmmap_group_sc", "estep_mfma_kernel")
+        prefixes = ("estep_hard", "estep_path", "gmmmap_group_sc", "estep_mfma_kernel", "estep_small_kernel")
     out["config"]["soft_frames_of_last_step"] = soft          # -1: the one-kernel path ran (the sample of the call's frames found few owners)
     out["cold_first_call_ms"] = cold_first_call_ms
     out["second_call_ms"] = second_call_ms

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Where a kernel's wave cycles go: several rocprofv3 PMC passes (<= 8 SQ counters each) over tools/convert_once.py, per-launch
-averages per kernel.   python3 tools/sq_pmc.py [--force FLAGS] [--out DIR]        (run on the GPU box)"""
+"""Where a kernel's wave cycles go: several rocprofv3 PMC passes (<= 8 SQ counters each) over tools/convert_once.py (or --prog), per-launch
+averages per kernel.   python3 tools/sq_pmc.py [--prog tools/estep_once.py] [--force FLAGS] [--out DIR]        (run on the GPU box)"""
 import collections, csv, glob, json, os, subprocess, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -14,7 +14,9 @@ PASSES = [
 
 def main():
     argv = sys.argv[1:]
-    force, out = "0", os.path.join(ROOT, "gpurun_out", "sq_pmc")
+    force, out, prog = "0", os.path.join(ROOT, "gpurun_out", "sq_pmc"), os.path.join("tools", "convert_once.py")
+    if "--prog" in argv:                       # e.g. tools/estep_once.py
+        prog = argv[argv.index("--prog") + 1]
     if "--force" in argv:
         force = argv[argv.index("--force") + 1]
     if "--out" in argv:
@@ -25,7 +27,7 @@ def main():
     for i, counters in enumerate(PASSES):
         d = os.path.join(out, f"pass{i}")
         cmd = ["rocprofv3", "--kernel-trace", "--pmc"] + counters + ["--output-format", "csv", "-d", d, "--", sys.executable,
-               os.path.join(ROOT, "tools", "convert_once.py"), "8", force]
+               os.path.join(ROOT, prog), "8", force]
         with open(os.path.join(out, f"err{i}.txt"), "w") as err:
             r = subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=err, timeout=400, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"))
         if r.returncode != 0:

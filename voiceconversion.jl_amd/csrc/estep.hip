@@ -787,7 +787,7 @@ static int estep_mfma_launch(EstepScratch &sc, const double *dX, int64_t N, int 
   if constexpr (!C::SPLIT) {
     // The one-kernel E-step of `nfr` frames at Xp (their number read from *ndev on the device where that is given: the grid
     // then covers the CUs) + the fixed-order reduction of its partial statistics into dstats.  M <= 32: estep_small.hpp.
-    auto soft = [&](const double *Xp, int64_t nfr, const int64_t *ndev, int accumulate) -> int {
+    auto soft = [&](const double *Xp, int64_t nfr, const int64_t *ndev, int accumulate, hipStream_t st) -> int {
       if (M <= 32 && !debug_flag(kDbgEstepNoSmall)) {
         auto go = [&](auto cfg, auto kern) -> int {
           using CS = decltype(cfg);
@@ -858,24 +858,29 @@ static int estep_mfma_launch(EstepScratch &sc, const double *dX, int64_t N, int 
                            sc.probe.p, nsample * kSamplePasses, cstride, (const int64_t *)nullptr, 1);
       hipLaunchKernelGGL(estep_path_decide_kernel, dim3(1), dim3(64), 0, st, sc.probe.p, (int)(nsample * kSamplePasses), MK,
                          path == VCMI_ESTEP_AUTO ? -1 : 1, N, ctl);
-      // the hard-assignment path proper: every kernel looks at ctl[kCtlHard] first
-      hipLaunchKernelGGL(kk, dim3((unsigned)std::min<int64_t>(nchunks, (int64_t)cus)), dim3(kHardKeyThreads), kshmem, st, sc.W16.p, M, dj, dX, N, key,
+      // The hard-assignment path proper: every kernel looks at ctl[kCtlHard] first.  (With the decision left to the device one of
+      // the two chains -- these launches, or the one-kernel E-step of every frame -- returns at once, launch by launch, ~4.4 us
+      // each.  Running the two chains on two streams, forked behind the decision and joined at the end, was measured in round 6:
+      // the fork / join events cost more than the idle launches -- estep_fixture 0.619 against 0.608 ms, estep 0.556 against 0.526.)
+      hipStream_t hs = st;
+      hipLaunchKernelGGL(kk, dim3((unsigned)std::min<int64_t>(nchunks, (int64_t)cus)), dim3(kHardKeyThreads), kshmem, hs, sc.W16.p, M, dj, dX, N, key,
                          chunkhist, nchunks, (int64_t)1, gate, 0);
-      hipLaunchKernelGGL(gmmmap_group_scan_kernel, dim3((unsigned)MK), dim3(256), 0, st, chunkhist, nchunks, MK, total, gate);
-      hipLaunchKernelGGL(gmmmap_group_scatter_kernel, dim3((unsigned)nchunks), dim3(256), (size_t)17 * MK * sizeof(int), st, key, N, MK,
+      hipLaunchKernelGGL(gmmmap_group_scan_kernel, dim3((unsigned)MK), dim3(256), 0, hs, chunkhist, nchunks, MK, total, gate);
+      hipLaunchKernelGGL(gmmmap_group_scatter_kernel, dim3((unsigned)nchunks), dim3(256), (size_t)17 * MK * sizeof(int), hs, key, N, MK,
                          chunkhist, total, perm, gate);
-      hipLaunchKernelGGL(estep_hard_stats_kernel<DJ>, dim3((unsigned)npmax), dim3(256), 0, st, dX, dj, M, perm, total, dmu, sc.refiv.p,
+      hipLaunchKernelGGL(estep_hard_stats_kernel<DJ>, dim3((unsigned)npmax), dim3(256), 0, hs, dX, dj, M, perm, total, dmu, sc.refiv.p,
                          sc.hpart.p, prow, gate);
-      hipLaunchKernelGGL(estep_hard_reduce_kernel, dim3((unsigned)M), dim3(256), 0, st, sc.hpart.p, prow, total, M, dj, sc.refc.p, dstats,
+      hipLaunchKernelGGL(estep_hard_reduce_kernel, dim3((unsigned)M), dim3(256), 0, hs, sc.hpart.p, prow, total, M, dj, sc.refc.p, dstats,
                          sc.hllm.p, gate);
-      hipLaunchKernelGGL(estep_hard_ll_kernel, dim3(1), dim3(64), 0, st, sc.hllm.p, M, dstats, plen, gate);
-      hipLaunchKernelGGL(estep_hard_gather_kernel, dim3((unsigned)(cus * 4)), dim3(256), 0, st, dX, dj, M, perm, total, sc.Xsoft.p, ctl + kCtlNSoft, N, gate);
+      hipLaunchKernelGGL(estep_hard_ll_kernel, dim3(1), dim3(64), 0, hs, sc.hllm.p, M, dstats, plen, gate);
+      hipLaunchKernelGGL(estep_hard_gather_kernel, dim3((unsigned)(cus * 4)), dim3(256), 0, hs, dX, dj, M, perm, total, sc.Xsoft.p, ctl + kCtlNSoft, N, gate);
       VCMI_HIP(hipGetLastError());
       sc.last_hard = true;
       // the soft frames through the one-kernel path, their number read on the device; its partials are added on top ...
-      VCMI_TRY(soft(sc.Xsoft.p, /*every CU: the count is the device's*/ (int64_t)1 << 40, (const int64_t *)(ctl + kCtlNSoft), /*accumulate=*/1));
+      // (both one-kernel launches share the partial rows: only one of them has frames; reserved for the larger grid first)
+      VCMI_TRY(soft(sc.Xsoft.p, /*every CU: the count is the device's*/ (int64_t)1 << 40, (const int64_t *)(ctl + kCtlNSoft), /*accumulate=*/1, hs));
       // ... or, where the sample found few owners, every frame (ctl[kCtlAllSoft] = N; 0 otherwise: both launches return at once)
-      if (path == VCMI_ESTEP_AUTO) VCMI_TRY(soft(dX, N, (const int64_t *)(ctl + kCtlAllSoft), /*accumulate=*/0));
+      if (path == VCMI_ESTEP_AUTO) VCMI_TRY(soft(dX, N, (const int64_t *)(ctl + kCtlAllSoft), /*accumulate=*/0, st));
       return VCMI_OK;
     }
     if (mtp == 8 && debug_flag(kDbgEstepWaveKernel)) {      // (measured slower than the three-barrier kernel: 1.59 against 1.32 ms -- DESIGN 3.3 round 5)
@@ -892,7 +897,7 @@ static int estep_mfma_launch(EstepScratch &sc, const double *dX, int64_t N, int 
       VCMI_HIP(hipGetLastError());
       return VCMI_OK;
     }
-    VCMI_TRY(soft(dX, N, (const int64_t *)nullptr, /*accumulate=*/0));     // (dstats was not zeroed)
+    VCMI_TRY(soft(dX, N, (const int64_t *)nullptr, /*accumulate=*/0, st));     // (dstats was not zeroed)
   } else {
     // two kernels per chunk of frames, the responsibilities (frames x 128 doubles) through HBM in between
     constexpr int64_t kSplitChunk = 1 << 20;

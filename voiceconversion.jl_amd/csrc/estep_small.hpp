@@ -5,19 +5,37 @@
 // estep_mfma_kernel<DJ, 0, SHARE = true> runs such a model with four (M <= 32) or eight (M <= 16) of its eight waves on one
 // tile, which balances the MFMAs -- but everything around them is laid out for 128 slots: the softmax walks eight slot groups
 // per lane with sixteen lanes on a frame (two slots of the eight exist), takes two passes per wave and block, and the one
-// workgroup of a CU moves through step A | barrier | softmax | barrier | step B | barrier in lock step, so the FP64 matrix pipe
-// idles through every softmax (phase timers at M = 32: 39 % of the workgroup's time in the softmax, 26 % / 34 % in the steps
-// that hold all the MFMAs; 0.37 of the FP64 MFMA peak -- DESIGN 3.3 round 6).
+// workgroup of a CU moves through step A | barrier | softmax | barrier | step B | barrier in lock step (phase timers at M = 32:
+// 39 % of the workgroup's time in the softmax, 26 % / 34 % in the steps that hold all the MFMAs; 0.37 of the FP64 MFMA peak).
 //
 // Here the workgroup is as small as the model: 2 MT waves (MT = mixture tiles), 32 frames per block, two waves to a tile
-// (wave = (tile, half): step A on frame tile `half`, every other k-step of step B).  Then
-//   * the softmax is ONE pass per wave and block with four values per lane and 4 MT lanes on a frame (16 / MT frames per wave),
-//     all loops as long as the model is wide;
-//   * a CU holds two (MT = 2: 256 threads, 55 KB of LDS each) or three (MT = 1) workgroups that run at their own pace: one
-//     is in its softmax (vector pipe, LDS) while the other issues MFMAs -- the overlap the barriers deny a single workgroup.
+// (wave = (tile, half): step A on frame tile `half`, every other k-step of step B); a CU holds two of them, which run at their
+// own pace.  What the measurements of round 6 say about this kernel (profiles/r06_ab/estep_small_kernel.txt):
+//   * The FP64 vector instructions and the FP64 MFMAs share ONE pipe, and so does everything else a wave issues to the VALU:
+//     over all variants the time of a SIMD is  64 cycles x MFMAs + ~8 cycles x other VALU instructions, whatever the order
+//     and whichever of the two resident waves issues them.  Overlapping "the softmax of one workgroup with the MFMAs of the
+//     other" buys the latencies (LDS round trips, dependent chains), not the instructions.  So the kernel counts VALU
+//     instructions: one softmax pass per wave and block with four values per lane and 4 MT lanes on a frame, loops as long
+//     as the model is wide; the refinement test folded into the exps' own operands, its re-evaluation out of line; 1/s by
+//     v_rcp_f64 and two Newton steps; lane permutations without the copy of the old value; the LDS-DMA's source offsets
+//     from a table in LDS instead of a dozen integer instructions per chunk (470 -> 220 per wave and block).
+//   * A wave is alone on its SIMD with its workgroup.  Step A of the NEXT block (MFMAs, operands from LDS) is interleaved
+//     piece by piece with the softmax of the current one, so the wave has an MFMA to issue while an exp's chain or an LDS
+//     read is under way; three x buffers make the next block's frames available one iteration early.
+//   * The older of a SIMD's two waves wins every arbitration: left alone, the first workgroup of a CU finished its blocks in
+//     0.82 M cycles and the second in 1.16 M.  s_setprio by phase (high in the softmax + step A phase, low in step B's MFMA
+//     stream) evens them out (1.02 M / 1.06 M).
+// estep_fixture (M = 32, Dj = 80, 1.25e6 frames): 0.815 ms in estep_mfma_kernel -> 0.51 ms here (step: 0.89 -> 0.61 ms).
 // The arithmetic of a frame is that of estep_mfma_kernel (same expanded form, same refinement rule, same table exp); the
 // partial statistics have the same row layout (row = workgroup x half) and go through estep_reduce_kernel.
 #pragma once
+
+#ifndef VCMI_SMALL_PRIO
+#define VCMI_SMALL_PRIO 1
+#endif
+#ifndef VCMI_SMALL_B_BATCH
+#define VCMI_SMALL_B_BATCH 1
+#endif
 
 namespace vcmi {
 
@@ -33,11 +51,20 @@ struct EstepSmallCfg {
   // LDS row stride of l / gamma: 20 MT doubles -- the softmax's half-wave (32 / LPF frames x LPF consecutive doubles) lands on
   // 64 distinct banks (MT = 2: rows 80 dwords apart -> 0, 16, 32, 48 mod 64; MT = 1: 40 dwords -> 0, 40, 16, 56, 32, 8, 48, 24)
   static constexpr int RSG = 20 * MT;
-  static constexpr int WG_PER_CU = MT == 2 ? 2 : 3;
-  // [x 2][l / gamma FB x RSG][etab 64][thresholds 16 MT] doubles
-  static constexpr size_t LDS_BYTES = ((size_t)2 * XBUF + (size_t)FB * RSG + 64 + 16 * MT) * sizeof(double);
+  static constexpr int WG_PER_CU = 2;
+  // [x 3][l / gamma FB x RSG][etab 64][thresholds 16 MT] doubles + [DMA source offsets: XBUF / 128 chunks x 64 lanes] ints
+  static constexpr size_t LDS_BYTES = ((size_t)3 * XBUF + (size_t)FB * RSG + 64 + 16 * MT) * sizeof(double) + (size_t)(XBUF / 128) * 64 * sizeof(unsigned);
   static_assert(LDS_BYTES * WG_PER_CU <= 160 * 1024, "LDS");
 };
+
+// a lane permutation within DPP rows (quad_perm / row_half_mirror: every lane has a source) without the copy of the destination's
+// old value that update_dpp's tied operand costs -- two VALU instructions per double and step
+template <int CTRL>
+__device__ __forceinline__ double dpp_perm_f64(double x) {
+  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(x), CTRL, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(x), CTRL, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
 
 // all-reduce over aligned groups of N = 4 or 8 lanes: the first two / three steps of row16_* (fp64_exp.hpp)
 template <int N>
@@ -87,12 +114,14 @@ estep_small_kernel(const double *__restrict__ X, int64_t N, int M, const double 
 #endif
   constexpr int KS = C::KS, NDT = C::NDT, FB = C::FB, RSX = C::RSX, RSG = C::RSG, XBUF = C::XBUF, NW = C::NW, LPF = C::LPF;
   extern __shared__ double smem[];
-  double *xbuf = smem;                     // [2][XBUF]: [FB][RSX] images
-  double *lg = smem + 2 * XBUF;            // [FB][RSG]   l, then gamma
+  double *xbuf = smem;                     // [3][XBUF]: [FB][RSX] images
+  double *lg = smem + 3 * XBUF;            // [FB][RSG]   l, then gamma
   double *red = lg;                        // [NW] scratch of the log-likelihood reduction (epilogue only)
   double *etab = lg + FB * RSG;            // [64] 2^(j/64) for vc_exp_tab
   double *tthr = etab + 64;                // [16 MT] refinement thresholds
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  unsigned *otab = reinterpret_cast<unsigned *>(tthr + 16 * MT);   // [NCHUNK][64] source offsets of the LDS-DMA (full blocks)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // in a scalar register: per-wave addresses and branches are uniform
   const int lcol = lane & 15, lgrp = lane >> 4;
   if (tid < 64) etab[tid] = kExp2Tab[tid];
   if (tid < 16 * MT) tthr[tid] = (tid < M) ? refc[2 * tid + 1] : -INFINITY;
@@ -111,123 +140,241 @@ estep_small_kernel(const double *__restrict__ X, int64_t N, int M, const double 
 
   const int64_t nblocks = (N + FB - 1) / FB;
   constexpr int ROWB = RSX * 8, NCHUNK = XBUF / 128;
-  auto stage = [&](int64_t f0, double *dst) {          // LDS-DMA of one block, 1 KB per wave-instruction (see estep_mfma_kernel)
+  // LDS-DMA of one block, 1 KB per wave-instruction (see estep_mfma_kernel).  The per-lane source offset of every chunk is the
+  // same for all full blocks: it comes from a table in LDS (one ds_read per chunk instead of a dozen integer instructions --
+  // every VALU instruction of this kernel is paid for in matrix-pipe time); only the call's last, partial block computes it.
+  auto chunk_off = [&](int q, int lane_, int last) -> unsigned {
+    const int o = 1024 * q + 16 * lane_, row = o / ROWB, col = o - row * ROWB;
+    const int rowc = row < last ? row : last;                    // (also the rows >= FB of the padding)
+    return (col < dj * 8) ? (unsigned)(rowc * (dj * 8) + col) : 0u;
+  };
+  for (int e = tid; e < NCHUNK * 64; e += 64 * NW) otab[e] = chunk_off(e >> 6, e & 63, FB - 1);
+  auto stage = [&](int64_t f0, double *dst) {
     const char *base = reinterpret_cast<const char *>(X + f0 * dj);
-    const int last = (int)((N - 1 - f0 < FB - 1) ? N - 1 - f0 : FB - 1);
-    int lane_v = lane;
-    asm volatile("" : "+v"(lane_v));
+    auto dma = [&](int q, unsigned off) {
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(base + off),
+                                       (__attribute__((address_space(3))) void *)(reinterpret_cast<char *>(dst) + 1024 * q), 16, 0, 0);
+    };
+    if (N - f0 >= FB) {                                          // workgroup-uniform
+      // (the table address is formed here, per block, from the opaque lane id: hoisted out of the loop the six addresses are
+      // spilled, and a scratch reload's s_waitcnt vmcnt(0) also waits for the DMA issued just before it -- 950 cycles a chunk)
+      int lane_t = lane;
+      asm volatile("" : "+v"(lane_t));
+      const unsigned *ot = otab + lane_t;
+      unsigned off[(NCHUNK + NW - 1) / NW];
 #pragma unroll
-    for (int i = 0; i < (NCHUNK + NW - 1) / NW; ++i) {
-      const int q = wave + NW * i;
-      if (q < NCHUNK) {                                          // wave-uniform
-        const int o = 1024 * q + 16 * lane_v, row = o / ROWB, col = o - row * ROWB;
-        const int rowc = row < last ? row : last;
-        const unsigned off = (col < dj * 8) ? (unsigned)(rowc * (dj * 8) + col) : 0u;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(base + off),
-                                         (__attribute__((address_space(3))) void *)(reinterpret_cast<char *>(dst) + 1024 * q), 16, 0, 0);
+      for (int i = 0; i < (NCHUNK + NW - 1) / NW; ++i) {
+        const int q = wave + NW * i;
+        off[i] = ot[64 * (q < NCHUNK ? q : 0)];
       }
+#pragma unroll
+      for (int i = 0; i < (NCHUNK + NW - 1) / NW; ++i) {
+        const int q = wave + NW * i;
+        if (q < NCHUNK) dma(q, off[i]);                          // wave-uniform
+      }
+    } else {
+      int lane_v = lane;
+      asm volatile("" : "+v"(lane_v));                           // (nothing of this branch is to be computed ahead of the loop)
+#pragma unroll 1
+      for (int q = wave; q < NCHUNK; q += NW) dma(q, chunk_off(q, lane_v, (int)(N - 1 - f0)));
     }
   };
-  if (blockIdx.x < nblocks) stage((int64_t)blockIdx.x * FB, xbuf);
+  // ---- the pipeline.  Block i of this workgroup lives in x buffer i % 3.  Iteration i:
+  //        [DMA of block i+2 issued]
+  //        S1: softmax(i) on l_i in LDS  INTERLEAVED, instruction by instruction, with step A(i+1) (-> registers)
+  //        barrier;  S2: step B(i);  barrier;  S3: l_{i+1} -> LDS, DMA landed;  barrier
+  //      A wave is alone on its SIMD with its workgroup: whatever its softmax waits for (LDS round trips, the dependent FP64
+  //      chains of the exps) is time the matrix pipe idles unless the same wave has MFMAs to issue in between.
+  const int64_t blk0 = blockIdx.x, bstride = gridDim.x;
+  __syncthreads();                                               // (the offset table)
+  if (blk0 < nblocks) stage(blk0 * FB, xbuf);
+  if (blk0 + bstride < nblocks) stage((blk0 + bstride) * FB, xbuf + XBUF);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  const int arow = (16 * half + lcol) * RSX + lgrp;            // step A: this lane's operand row / k offset in an x image
+  if (blk0 < nblocks) {                                        // step A(0), on its own
+    d4 acc = cin, acc2 = {0, 0, 0, 0};
+    nmfma += KS;
+    const double *xr = xbuf + arow;
+#pragma unroll
+    for (int ks = 0; ks < KS / 2; ++ks) {
+      const double x = xr[4 * ks];
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x * x, wfrag[ks], acc, 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(x, wfrag[KS / 2 + ks], acc2, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) lg[(16 * half + 4 * r + lgrp) * RSG + 16 * tile + lcol] = acc[r] + acc2[r];
+  }
   __syncthreads();
   int cur = 0;
 #ifdef VCMI_ESTEP_PROF
-  unsigned long long pt_[6] = {0, 0, 0, 0, 0, 0};     // probe build: cycle counts in A | barrier | softmax | barrier | B | barrier
+  int nslow_ = 0;
+  unsigned long long pt_[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};     // probe build: cycle counts in S1 | barrier | B | barrier | S3 | barrier
   const unsigned long long tk1_ = __builtin_readcyclecounter();
 #define VCMI_PT(i) { const unsigned long long t_ = __builtin_readcyclecounter(); pt_[i] += t_ - tl_; tl_ = t_; }
 #else
 #define VCMI_PT(i)
 #endif
-  for (int64_t blk = blockIdx.x; blk < nblocks; blk += gridDim.x, cur ^= 1) {
+  constexpr int NS = KS / 2;                            // MFMA slots of a step A: one k-step of x^2 and one of x each
+  for (int64_t blk = blk0; blk < nblocks; blk += bstride) {
 #ifdef VCMI_ESTEP_PROF
     unsigned long long tl_ = __builtin_readcyclecounter();
 #endif
     const int64_t f0 = blk * FB;
+    const int nxt = cur == 2 ? 0 : cur + 1, nn = nxt == 2 ? 0 : nxt + 1;
     const double *xs = xbuf + cur * XBUF;
-    // ---- step A: l[f][m] = c_m + sum_k Xe[f][k] W[m][k],  Xe = [x^2 | x]: this wave's frame tile and mixture tile.  The two
-    //      halves of the contraction run as two accumulator chains (a chain's MFMAs wait for one another) ----
+    const bool has_next = blk + bstride < nblocks;
+    if (blk + 2 * bstride < nblocks) stage((blk + 2 * bstride) * FB, xbuf + nn * XBUF);
+    VCMI_PT(6)                                 // (probe: the DMA issue)
+    // ---- S1 ----
+#if VCMI_SMALL_PRIO
+    __builtin_amdgcn_s_setprio(2);             // the phase with the dependent chains goes first where both workgroups of the CU want to issue
+#endif
+    d4 acc = cin, acc2 = {0, 0, 0, 0};        // step A(i+1): l[f][m] = c_m + sum_k Xe[f][k] W[m][k], Xe = [x^2 | x], two chains
     {
-      d4 acc = cin, acc2 = {0, 0, 0, 0};
-      nmfma += KS;
-      const double *xr = xs + (16 * half + lcol) * RSX + lgrp;
-#pragma unroll
-      for (int ks = 0; ks < KS / 2; ++ks) {
-        const double x = xr[4 * ks];
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x * x, wfrag[ks], acc, 0, 0, 0);
-        acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(x, wfrag[KS / 2 + ks], acc2, 0, 0, 0);
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) lg[(16 * half + 4 * r + lgrp) * RSG + 16 * tile + lcol] = acc[r] + acc2[r];
-    }
-    VCMI_PT(0)
-    __syncthreads();
-    VCMI_PT(1)
-    if (blk + gridDim.x < nblocks) stage((blk + gridDim.x) * FB, xbuf + (cur ^ 1) * XBUF);
-    // ---- softmax over the 16 MT slots of each frame: LPF lanes per frame, lane l owns the slots l + LPF i.  Straight-line
-    //      code but for the (rare) exact re-evaluation: the wave is alone on its SIMD with its workgroup in this phase, every
-    //      dependent LDS round trip is exposed ----
-    {
+      // (without a next block the products run on whatever the buffer holds and are dropped)
+      const double *xr = xbuf + nxt * XBUF + arow;
+      double xq[3];
+      xq[0] = xr[0];
+      xq[1] = xr[4];
+      auto mfma_slot = [&](int k) {           // k-step k of both chains; the operand of slot k + 2 is requested
+        if (k + 2 < NS) xq[(k + 2) % 3] = xr[4 * (k + 2)];
+        const double x = xq[k % 3];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x * x, wfrag[k], acc, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(x, wfrag[NS + k], acc2, 0, 0, 0);
+      };
+      // softmax over the 16 MT slots of each frame: LPF lanes per frame, lane l owns the slots l + LPF i.  e^(v - u) by
+      // vc_exp_tab's steps (fp64_exp.hpp), the four values of a lane side by side, one piece per MFMA slot.
       const int l = lane & (LPF - 1), f = (64 / LPF) * wave + lane / LPF;
       double *row = lg + f * RSG + l;
-      double v[4];
-      double u = -INFINITY;
-      bool below[4];                           // value under its mixture's refinement threshold (tthr; -inf: never)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        v[i] = row[LPF * i];
-        below[i] = v[i] < tthr[l + LPF * i];
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i) u = fmax(u, v[i]);
-      u = rowN_max<LPF>(u);
-      {
-        // refinement: when several mixtures are within kRefine of the frame's maximum, exactly those whose expanded form is
-        // not provably good enough (value below the mixture's threshold: estep_prep_kernel) are re-evaluated term by term
-        constexpr double kRefine = 36.0;
-        const double thr = u - kRefine;
-        int nc = 0;
-        bool need = false;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          nc += (v[i] > thr) ? 1 : 0;
-          need = need || (v[i] > thr && below[i]);
-        }
-        nc = rowN_sum<LPF>(nc);
-        need = need && nc > 1;
-        if (__builtin_amdgcn_ballot_w64(need) != 0) {      // models with ordinary variances never get here
-          const double *xf = xs + f * RSX;
+      constexpr double kRefine = 36.0;        // e^-36 = 2e-16: a mixture further below the maximum cannot change a sum
+      double v[4], tt[4], t[4], kf[4], r[4], pl[4], u = -INFINITY, s = 0.0, inv = 0.0;
+      int ki[4];
+      bool below[4], needl = false;
+      const bool livef = (f0 + f < N);
+      auto piece = [&](int p) {
+        if (p == 0) {
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
-            if (need && v[i] > thr && v[i] < tthr[l + LPF * i]) {
-              const int m = l + LPF * i;
-              const double *mp = refmu + (size_t)dj * m, *ip = refiv + (size_t)dj * m;
-              double q = 0.0;
-#pragma unroll 2
-              for (int d = 0; d < dj; ++d) {
-                const double df = xf[d] - mp[d];
-                q = fma(df * df, ip[d], q);
-              }
-              v[i] = refc[2 * m] - 0.5 * q;
-            }
+            v[i] = row[LPF * i];
+            tt[i] = tthr[l + LPF * i];
           }
-          u = -INFINITY;
+        } else if (p == 1) {
+          u = fmax(fmax(v[0], v[1]), fmax(v[2], v[3]));
 #pragma unroll
-          for (int i = 0; i < 4; ++i) u = fmax(u, v[i]);
-          u = rowN_max<LPF>(u);
+          for (int i = 0; i < 4; ++i) below[i] = v[i] < tt[i];       // under the mixture's refinement threshold (-inf: never)
+        } else if (p == 2) {
+          u = fmax(u, dpp_perm_f64<0xB1>(u));
+        } else if (p == 3) {
+          u = fmax(u, dpp_perm_f64<0x4E>(u));
+        } else if (p == 4) {
+          if constexpr (LPF == 8) u = fmax(u, dpp_perm_f64<0x141>(u));
+        } else if (p == 5) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            t[i] = fmax(v[i] - u, -1000.0);       // (also maps -inf: slots beyond M, zero weights)
+            needl = needl || (below[i] && t[i] > -kRefine);
+          }
+        } else if (p == 6) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) kf[i] = rint(t[i] * 92.332482616893656877);
+        } else if (p == 7) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) r[i] = fma(kf[i], -1.083042469326756e-02, t[i]);
+        } else if (p == 8) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            r[i] = fma(kf[i], -2.9815858269852933e-12, r[i]);
+            ki[i] = (int)kf[i];
+            t[i] = etab[ki[i] & 63];
+          }
+        } else if (p == 9) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) pl[i] = vc_fma_sconst(8.333333333333333e-03, r[i], 4.1666666666666664e-02);
+        } else if (p == 10) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) pl[i] = vc_fma_sconst(pl[i], r[i], 1.6666666666666666e-01);
+        } else if (p == 11) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) pl[i] = fma(pl[i], r[i], 0.5);
+        } else if (p == 12) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) pl[i] = fma(pl[i], r[i], 1.0);
+        } else if (p == 13) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) pl[i] = fma(pl[i], r[i], 1.0);
+        } else if (p == 14) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[i] = ldexp(t[i] * pl[i], ki[i] >> 6);      // exactly 0 below -745
+        } else if (p == 15) {
+          s = (v[0] + v[1]) + (v[2] + v[3]);
+          s += dpp_perm_f64<0xB1>(s);
+        } else if (p == 16) {
+          s += dpp_perm_f64<0x4E>(s);
+          if constexpr (LPF == 8) s += dpp_perm_f64<0x141>(s);
+        } else {
+          // 1 / s, s in [1, 32]: the hardware's estimate and two Newton steps (the division's scaling and fix-up cases cannot occur)
+          const double sc = s > 0.0 ? s : 1.0;
+          double q = __builtin_amdgcn_rcp(sc);
+          q = fma(fma(-sc, q, 1.0), q, q);
+          q = fma(fma(-sc, q, 1.0), q, q);
+          inv = (livef && s > 0.0) ? q : 0.0;              // frames beyond N, models without any weight: gamma = 0
         }
-      }
-      double s = 0.0;
+      };
+      constexpr int NP = 18;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        v[i] = vc_exp_tab(v[i] - u, etab);    // -inf (slots beyond M, zero weights) and < -745 give exactly 0
-        s += v[i];
+      for (int sl = 0; sl < NS; ++sl) {
+#pragma unroll
+        for (int p = sl * NP / NS; p < (sl + 1) * NP / NS; ++p) piece(p);
+        mfma_slot(sl);
+        __builtin_amdgcn_sched_barrier(0);
       }
-      s = rowN_sum<LPF>(s);
-      const bool livef = (f0 + f < N);
-      const double inv = (livef && s > 0.0) ? 1.0 / s : 0.0;      // frames beyond N, models without any weight: gamma = 0
+      VCMI_PT(7)                               // (probe: the slots)
+      // Refinement (rare: models with ordinary variances never get here).  Several mixtures share the frame (s > 1: another one
+      // within ~36 nats of the maximum) and one of those within kRefine has an expanded-form value that is not provably good
+      // enough (below its mixture's threshold, estep_prep_kernel): exactly those are re-evaluated term by term, (x - mu)^2 / var
+      // summed over d as the reference formula reads, and the frame's softmax is taken again.
+      if (__builtin_amdgcn_ballot_w64(needl && s > 1.0) != 0) {
+#ifdef VCMI_ESTEP_PROF
+        ++nslow_;
+#endif
+        const double *xf = xs + f * RSX;
+        double vv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) vv[i] = row[LPF * i];
+        double uu = rowN_max<LPF>(fmax(fmax(vv[0], vv[1]), fmax(vv[2], vv[3])));
+        const double thr = uu - kRefine;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int m = l + LPF * i;
+          if (needl && s > 1.0 && vv[i] > thr && vv[i] < tthr[m]) {
+            const double *mp = refmu + (size_t)dj * m, *ip = refiv + (size_t)dj * m;
+            double q = 0.0;
+#pragma unroll 2
+            for (int d = 0; d < dj; ++d) {
+              const double df = xf[d] - mp[d];
+              q = fma(df * df, ip[d], q);
+            }
+            vv[i] = refc[2 * m] - 0.5 * q;
+          }
+        }
+        uu = rowN_max<LPF>(fmax(fmax(vv[0], vv[1]), fmax(vv[2], vv[3])));
+        double ss = 0.0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          vv[i] = vc_exp_tab(vv[i] - uu, etab);
+          ss += vv[i];
+        }
+        ss = rowN_sum<LPF>(ss);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = vv[i];
+        u = uu;
+        s = ss;
+        inv = (livef && ss > 0.0) ? 1.0 / ss : 0.0;
+      }
 #pragma unroll
       for (int i = 0; i < 4; ++i) row[LPF * i] = v[i] * inv;
+      if (has_next) nmfma += KS;
       // log-likelihood: sum of u + log s; the s of a lane's frames (in [1, 32]) are multiplied up, one log per sixteen blocks
       if (l == 0 && livef) {
         llacc += u;
@@ -239,10 +386,13 @@ estep_small_kernel(const double *__restrict__ X, int64_t N, int M, const double 
         nprod = 0;
       }
     }
-    VCMI_PT(2)
+#if VCMI_SMALL_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
+    VCMI_PT(0)
     __syncthreads();
-    VCMI_PT(3)
-    // ---- step B: S[m][c] += sum_f gamma[f][m] Xe[f][c],  Xe = [x | x^2]; this wave takes every other k-step of 4 frames.
+    VCMI_PT(1)
+    // ---- S2, step B: S[m][c] += sum_f gamma[f][m] Xe[f][c],  Xe = [x | x^2]; this wave takes every other k-step of 4 frames.
     //      No test for responsibilities that are all zero (estep_mfma_kernel's skip, and the grouping of the frames that makes
     //      it bite): with at most 32 mixtures a frame that one mixture owns went down the hard-assignment path, and without
     //      the branch the next k-step's operands are on their way while this one's products run ----
@@ -264,24 +414,41 @@ estep_small_kernel(const double *__restrict__ X, int64_t N, int M, const double 
 #pragma unroll
           for (int j = 0; j < NDT / 2; ++j) xn[j] = xs[(4 * (2 * kk + 2 + half) + lgrp) * RSX + lcol + 16 * j];
         }
+        double x2[NDT / 2];
+#pragma unroll
+        for (int j = 0; j < NDT / 2; ++j) x2[j] = xc[j] * xc[j];
 #pragma unroll
         for (int j = 0; j < NDT / 2; ++j) {
           sacc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(gm, xc[j], sacc[j], 0, 0, 0);
-          sacc[NDT / 2 + j] = __builtin_amdgcn_mfma_f64_16x16x4f64(gm, xc[j] * xc[j], sacc[NDT / 2 + j], 0, 0, 0);
+          sacc[NDT / 2 + j] = __builtin_amdgcn_mfma_f64_16x16x4f64(gm, x2[j], sacc[NDT / 2 + j], 0, 0, 0);
         }
         s0l += gm;
+#if VCMI_SMALL_B_BATCH
+        __builtin_amdgcn_sched_group_barrier(0x100, NDT / 2, 0);      // the next k-step's reads
+        __builtin_amdgcn_sched_group_barrier(0x002, NDT / 2 + 1, 0);  // the squares (and s0l), back to back
+        __builtin_amdgcn_sched_group_barrier(0x008, NDT, 0);          // the products, back to back
+#endif
         __builtin_amdgcn_sched_barrier(0);
       }
     }
+    VCMI_PT(2)
+    __syncthreads();
+    VCMI_PT(3)
+    // ---- S3: l of the next block into LDS (its responsibilities-to-be), the DMA of the block after it has landed ----
+    if (has_next) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) lg[(16 * half + 4 * r + lgrp) * RSG + 16 * tile + lcol] = acc[r] + acc2[r];
+    }
     VCMI_PT(4)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next block's LDS-DMA has landed
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     VCMI_PT(5)
+    cur = nxt;
   }
 #ifdef VCMI_ESTEP_PROF
   const unsigned long long tk2_ = __builtin_readcyclecounter();
   if (blockIdx.x == 3 && lane == 0)
-    printf("estep small prof wave %d: A %llu | bar %llu | softmax %llu | bar %llu | B %llu | bar %llu\n", wave, pt_[0], pt_[1], pt_[2], pt_[3], pt_[4], pt_[5]);
+    printf("estep small prof wave %d: S1 %llu | bar %llu | B %llu | bar %llu | S3 %llu | bar %llu; refinement branch taken %d times; stage %llu slots %llu\n", wave, pt_[0], pt_[1], pt_[2], pt_[3], pt_[4], pt_[5], nslow_, pt_[6], pt_[7]);
 #endif
 #undef VCMI_PT
 
