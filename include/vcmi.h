@@ -69,7 +69,12 @@ int vcmi_get_devices(int *devices, int capacity, int *n);
  * the caller's own runtime (hipHostMalloc /
  * hipHostRegister) are recognised as well.  Results are identical either way.  vcmi_host_unregister(ptr) takes the pointer
  * that was registered; an array must be unregistered before it is freed.  Ranges must not overlap (VCMI_ERR_ARG).
- * vcmi_host_is_registered: *flag = 1 when the whole range would take the direct path. */
+ * What is locked are the WHOLE PAGES inside the array -- its partial first and last page, which it shares with its neighbours on
+ * the heap, travel as ordinary copies (unmapping such a shared page at unregistration broke later transfers of the HIP runtime
+ * from pageable memory nearby: DESIGN 4b, round 6) -- and an array with less than 1 MB of whole pages is recorded, not locked:
+ * its calls stage as before.
+ * vcmi_host_is_registered: *flag = 1 when the whole range lies in an array registered here (locked or recorded) or in memory
+ * another runtime pinned. */
 int vcmi_host_register(void *ptr, size_t bytes);
 int vcmi_host_unregister(void *ptr);
 int vcmi_host_is_registered(const void *ptr, size_t bytes, int *flag);

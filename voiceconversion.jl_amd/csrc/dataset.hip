@@ -106,7 +106,7 @@ static int ensure_freqt(DatasetScratch &sc, int D, int len, double alpha) {
   std::vector<double> Ft;
   build_freqt_matrix(D, len, alpha, Ft);
   VCMI_TRY(sc.Ft.reserve(Ft.size()));
-  VCMI_HIP(hipMemcpy(sc.Ft.p, Ft.data(), Ft.size() * 8, hipMemcpyHostToDevice));
+  VCMI_TRY(upload_now(sc.Ft.p, Ft.data(), Ft.size() * 8));
   sc.ft_D = D;
   sc.ft_len = len;
   sc.ft_alpha = alpha;
@@ -202,7 +202,7 @@ extern "C" int vcmi_mc2e(const double *mc, int D, int64_t T, double alpha, int f
   DatasetScratch &sc = dscratch();
   VCMI_TRY(sc.mc.reserve((size_t)D * T));
   VCMI_TRY(sc.e.reserve((size_t)T));
-  VCMI_HIP(hipMemcpy(sc.mc.p, mc, sizeof(double) * D * T, hipMemcpyHostToDevice));
+  VCMI_TRY(upload_now(sc.mc.p, mc, sizeof(double) * D * T));
   VCMI_TRY(mc2e_device(sc, sc.mc.p, D, T, alpha, fftlen, sc.e.p, nullptr));
   VCMI_HIP(hipMemcpy(e, sc.e.p, sizeof(double) * T, hipMemcpyDeviceToHost));
   return VCMI_OK;
@@ -251,8 +251,8 @@ extern "C" int vcmi_parallel_dataset_dev(int64_t n, const double *const *src, co
       o += (int64_t)D * S[p];
     }
     VCMI_TRY(sc.mc.reserve(2 * hs.size()));
-    VCMI_HIP(hipMemcpy(sc.mc.p, hs.data(), hs.size() * 8, hipMemcpyHostToDevice));
-    VCMI_HIP(hipMemcpy(sc.mc.p + hs.size(), ht.data(), ht.size() * 8, hipMemcpyHostToDevice));
+    VCMI_TRY(upload_now(sc.mc.p, hs.data(), hs.size() * 8));
+    VCMI_TRY(upload_now(sc.mc.p + hs.size(), ht.data(), ht.size() * 8));
     dfeats = sc.mc.p;
     dnewtgt = sc.mc.p + hs.size();
   }
@@ -274,7 +274,7 @@ extern "C" int vcmi_parallel_dataset_dev(int64_t n, const double *const *src, co
   if (remove_silence)
     for (int64_t p = 0; p < n; ++p)
       VCMI_TRY(mc2e_device(sc, dfeats + src_off[p], D, S[p], alpha, fftlen, sc.e.p + meta[2 * n + p], nullptr));
-  VCMI_HIP(hipMemcpy(sc.meta.p, meta.data(), sizeof(int64_t) * 4 * n, hipMemcpyHostToDevice));
+  VCMI_TRY(upload_now(sc.meta.p, meta.data(), sizeof(int64_t) * 4 * n));
   hipLaunchKernelGGL(keep_index_kernel, dim3((unsigned)n), dim3(256), 0, nullptr, sc.e.p, sc.meta.p + 2 * n, sc.meta.p + 3 * n,
                      threshold, remove_silence, sc.idx.p, sc.cnt.p);
   VCMI_HIP(hipGetLastError());
@@ -286,7 +286,7 @@ extern "C" int vcmi_parallel_dataset_dev(int64_t n, const double *const *src, co
     oo += hcnt[p];
     if (counts) counts[p] = hcnt[p];
   }
-  VCMI_HIP(hipMemcpy(sc.meta.p + 4 * n, meta.data() + 4 * n, sizeof(int64_t) * n, hipMemcpyHostToDevice));
+  VCMI_TRY(upload_now(sc.meta.p + 4 * n, meta.data() + 4 * n, sizeof(int64_t) * n));
   // (3) joint features straight into the caller's device matrix
   hipLaunchKernelGGL(joint_features_kernel, dim3((unsigned)n, 8), dim3(256), 0, nullptr, dfeats, dnewtgt, sc.meta.p,
                      sc.meta.p + n, sc.meta.p + 2 * n, sc.idx.p, sc.cnt.p, sc.meta.p + 4 * n, D, ignore0th, add_delta, diff, dXY);

@@ -1096,9 +1096,9 @@ static int estep_device_run(const double *dX, int64_t N, int Dj, int M, const do
   VCMI_TRY(sc.G.reserve((size_t)ch * M));
   VCMI_TRY(sc.LSE.reserve((size_t)ch));
   VCMI_TRY(sc.part.reserve((size_t)maxseg * plen));
-  VCMI_HIP(hipMemcpyAsync(sc.mu.p, hmu.data(), hmu.size() * 8, hipMemcpyHostToDevice, st));
-  VCMI_HIP(hipMemcpyAsync(sc.iv.p, hiv.data(), hiv.size() * 8, hipMemcpyHostToDevice, st));
-  VCMI_HIP(hipMemcpyAsync(sc.cst.p, hc.data(), hc.size() * 8, hipMemcpyHostToDevice, st));
+  VCMI_TRY(staged_upload(sc.mu.p, hmu.data(), hmu.size() * 8, st));      // (through the pinned ring: hostpipe.hpp, upload_now)
+  VCMI_TRY(staged_upload(sc.iv.p, hiv.data(), hiv.size() * 8, st));      // (through the pinned ring: hostpipe.hpp, upload_now)
+  VCMI_TRY(staged_upload(sc.cst.p, hc.data(), hc.size() * 8, st));      // (through the pinned ring: hostpipe.hpp, upload_now)
   VCMI_HIP(hipStreamSynchronize(st));
   if (shmem > 64 * 1024)
     VCMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(estep_gamma_kernel),
@@ -1661,9 +1661,9 @@ static int estep_full_device(const double *dX, int64_t N, int Dj, int M, const d
     VCMI_TRY(sc.params.reserve((size_t)M * (1 + Dj + dd)));
     VCMI_TRY(sc.flag.reserve(1));
     double *dw = sc.params.p, *dmu = dw + M, *dsig = dmu + (size_t)M * Dj;
-    VCMI_HIP(hipMemcpyAsync(dw, w, sizeof(double) * M, hipMemcpyHostToDevice, st));
-    VCMI_HIP(hipMemcpyAsync(dmu, mu, sizeof(double) * M * Dj, hipMemcpyHostToDevice, st));
-    VCMI_HIP(hipMemcpyAsync(dsig, sigma, sizeof(double) * M * dd, hipMemcpyHostToDevice, st));
+    VCMI_TRY(staged_upload(dw, w, sizeof(double) * M, st));      // (through the pinned ring: hostpipe.hpp, upload_now)
+    VCMI_TRY(staged_upload(dmu, mu, sizeof(double) * M * Dj, st));      // (through the pinned ring: hostpipe.hpp, upload_now)
+    VCMI_TRY(staged_upload(dsig, sigma, sizeof(double) * M * dd, st));      // (through the pinned ring: hostpipe.hpp, upload_now)
     VCMI_HIP(hipMemsetAsync(sc.flag.p, 0, sizeof(int), st));
     VCMI_TRY(gmm_px_prepare_device(&sc.px, dw, dmu, dsig, Dj, M, sc.flag.p, st));
     VCMI_TRY(estep_full_core(sc.px, dX, N, Dj, M, dstats, st));
@@ -1860,9 +1860,9 @@ extern "C" int vcmi_gmm_em_create(int Dj, int M, const double *w, const double *
     delete h;
     return rc;
   }
-  hipError_t e = hipMemcpy(h->w(), w, sizeof(double) * M, hipMemcpyHostToDevice);
-  if (e == hipSuccess) e = hipMemcpy(h->mu(), mu, sizeof(double) * M * Dj, hipMemcpyHostToDevice);
-  if (e == hipSuccess) e = hipMemcpy(h->sigma(), sigma, sizeof(double) * M * dd, hipMemcpyHostToDevice);
+  hipError_t e = upload_now_hip(h->w(), w, sizeof(double) * M);
+  if (e == hipSuccess) e = upload_now_hip(h->mu(), mu, sizeof(double) * M * Dj);
+  if (e == hipSuccess) e = upload_now_hip(h->sigma(), sigma, sizeof(double) * M * dd);
   if (e == hipSuccess) e = hipMemset(h->flag.p, 0, sizeof(int));
   if (e != hipSuccess) {
     delete h;

@@ -2147,22 +2147,22 @@ static int prepare(vcmi_gmmmap *g, const double *w, const double *mu, const doub
     VCMI_TRY(g->U.reserve(hU.size()));
     VCMI_TRY(g->cz.reserve(hcz.size()));
     VCMI_TRY(g->lc.reserve(hlc.size()));
-    VCMI_HIP(hipMemcpy(g->U.p, hU.data(), hU.size() * 8, hipMemcpyHostToDevice));
-    VCMI_HIP(hipMemcpy(g->cz.p, hcz.data(), hcz.size() * 8, hipMemcpyHostToDevice));
-    VCMI_HIP(hipMemcpy(g->lc.p, hlc.data(), hlc.size() * 8, hipMemcpyHostToDevice));
+    VCMI_TRY(upload_now(g->U.p, hU.data(), hU.size() * 8));
+    VCMI_TRY(upload_now(g->cz.p, hcz.data(), hcz.size() * 8));
+    VCMI_TRY(upload_now(g->lc.p, hlc.data(), hlc.size() * 8));
   }
   if (!px_only) {
     VCMI_TRY(g->A.reserve(hA.size()));
     VCMI_TRY(g->b.reserve(hb.size()));
-    VCMI_HIP(hipMemcpy(g->A.p, hA.data(), hA.size() * 8, hipMemcpyHostToDevice));
-    VCMI_HIP(hipMemcpy(g->b.p, hb.data(), hb.size() * 8, hipMemcpyHostToDevice));
+    VCMI_TRY(upload_now(g->A.p, hA.data(), hA.size() * 8));
+    VCMI_TRY(upload_now(g->b.p, hb.data(), hb.size() * 8));
     if (!gmmmap_has_mfma(DP) && D > 16 && D <= 160) {      // convert_from_logdens_kernel reads A transposed
       std::vector<double> hAt(hA.size());
       for (int m = 0; m < M; ++m)
         for (int r = 0; r < DP; ++r)
           for (int k = 0; k < DP; ++k) hAt[pp * m + (size_t)k * DP + r] = hA[pp * m + (size_t)r * DP + k];
       VCMI_TRY(g->At.reserve(hAt.size()));
-      VCMI_HIP(hipMemcpy(g->At.p, hAt.data(), hAt.size() * 8, hipMemcpyHostToDevice));
+      VCMI_TRY(upload_now(g->At.p, hAt.data(), hAt.size() * 8));
     }
   }
 
@@ -2208,7 +2208,7 @@ static int prepare(vcmi_gmmmap *g, const double *w, const double *mu, const doub
     }
     DevBuf<double> &dst = uonly == 2 ? g->packedU2 : (uonly ? g->packedU : g->packed);
     VCMI_TRY(dst.reserve(pk.size()));
-    VCMI_HIP(hipMemcpy(dst.p, pk.data(), pk.size() * 8, hipMemcpyHostToDevice));
+    VCMI_TRY(upload_now(dst.p, pk.data(), pk.size() * 8));
   }
   // stages of the screen of shape 3 (gmmmap_screen.hpp) on the first rpm rows of every mixture's P_m: rpm = the row count
   // with the smallest estimated cost per 16-frame tile -- KS MFMAs screen 16 / rpm mixtures; a mixture the screen does not
@@ -2254,7 +2254,7 @@ static int prepare(vcmi_gmmmap *g, const double *w, const double *mu, const doub
         }
       }
     VCMI_TRY(g->packedQ.reserve(pq.size()));
-    VCMI_HIP(hipMemcpy(g->packedQ.p, pq.data(), pq.size() * 8, hipMemcpyHostToDevice));
+    VCMI_TRY(upload_now(g->packedQ.p, pq.data(), pq.size() * 8));
     // the same four rows split into bf16 hi + lo for the screen on the BF16 matrix pipe (gmmmap_screen.hpp, B16)
     if (rpm == 4 && screen16_has(DP)) {
       const int KS8 = std::min(KSQ, 8), NTL = KSQ - KS8, STG16 = screen16_stage_doubles(DP), nst16 = (M + 4 * NQ - 1) / (4 * NQ);
@@ -2299,7 +2299,7 @@ static int prepare(vcmi_gmmmap *g, const double *w, const double *mu, const doub
           }
         }
       VCMI_TRY(g->packedQ16.reserve(p16.size()));
-      VCMI_HIP(hipMemcpy(g->packedQ16.p, p16.data(), p16.size() * 8, hipMemcpyHostToDevice));
+      VCMI_TRY(upload_now(g->packedQ16.p, p16.data(), p16.size() * 8));
     }
   }
   // ... and of predict's screen (gmmmap_screen_argmax_kernel): always four rows per mixture, every tile-kernel dimension
@@ -2323,7 +2323,7 @@ static int prepare(vcmi_gmmmap *g, const double *w, const double *mu, const doub
         }
       }
     VCMI_TRY(g->packedQA.reserve(pq.size()));
-    VCMI_HIP(hipMemcpy(g->packedQA.p, pq.data(), pq.size() * 8, hipMemcpyHostToDevice));
+    VCMI_TRY(upload_now(g->packedQA.p, pq.data(), pq.size() * 8));
   }
   if (!g->h_mux.empty()) {     // operand of the frame grouping (gmmmap_group_key_kernel): [-2 mu^x | |mu^x|^2] over its first dimensions, fragment order
     const int KSK = std::min(DP / 4, kGroupKeyDims / 4), KS1 = KSK + 1, MT = (M + 15) / 16, DK = std::min(D, 4 * KSK);
@@ -2345,7 +2345,7 @@ static int prepare(vcmi_gmmmap *g, const double *w, const double *mu, const doub
           gf[((size_t)mt * KS1 + ks) * 64 + l] = v;
         }
     VCMI_TRY(g->gfrag.reserve(gf.size()));
-    VCMI_HIP(hipMemcpy(g->gfrag.p, gf.data(), gf.size() * 8, hipMemcpyHostToDevice));
+    VCMI_TRY(upload_now(g->gfrag.p, gf.data(), gf.size() * 8));
     // ... and for the BF16 matrix pipe (gmmmap_group_key16_kernel): -2 mu split into bf16 hi + lo, |mu|^2 as floats
     {
       std::vector<double> g16((size_t)MT * (kKey16TileBytes / 8), 0.0);
@@ -2371,7 +2371,7 @@ static int prepare(vcmi_gmmmap *g, const double *w, const double *mu, const doub
         }
       }
       VCMI_TRY(g->gfrag16.reserve(g16.size()));
-      VCMI_HIP(hipMemcpy(g->gfrag16.p, g16.data(), g16.size() * 8, hipMemcpyHostToDevice));
+      VCMI_TRY(upload_now(g->gfrag16.p, g16.data(), g16.size() * 8));
     }
   }
   return VCMI_OK;
@@ -2615,7 +2615,7 @@ int gmm_px_prepare_device(vcmi_gmmmap **inout, const double *d_w, const double *
           if (ks < tl.steps(t)) tab.push_back((t << 16) | ks);
       if ((int)tab.size() != tl.NSTEPS) return fail(VCMI_ERR_ARG, "internal: tiling table mismatch");
       VCMI_TRY(g->px_table.reserve(tab.size()));
-      VCMI_HIP(hipMemcpy(g->px_table.p, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice));
+      VCMI_TRY(upload_now(g->px_table.p, tab.data(), tab.size() * sizeof(int)));
       g->px_table_dp = DP;
     }
   }

@@ -344,6 +344,24 @@ struct Ring {
   hipEvent_t ev_up[K] = {}, ev_run[K] = {}, ev_down[K] = {}, ev_tmp = nullptr;
   char *pin_in[K] = {}, *pin_out[K] = {}, *dev_in[K] = {}, *dev_out[K] = {};
   size_t pin_in_cap = 0, pin_out_cap = 0, dev_in_cap = 0, dev_out_cap = 0;
+  // the partial first / last page of a registered array (copy_split): four pinned pages -- two for what goes up, two for what
+  // comes down and is copied into the caller's pages once the DMA is complete
+  char *edge = nullptr;
+  struct EdgeOut {
+    char *host;
+    const char *bounce;
+    size_t n;
+  } edge_out[2];
+  int n_edge_in = 0, n_edge_out = 0;
+  int edge_begin() {
+    if (!edge) VCMI_HIP(hipHostMalloc(reinterpret_cast<void **>(&edge), 4 * 4096, hipHostMallocPortable));
+    n_edge_in = n_edge_out = 0;
+    return VCMI_OK;
+  }
+  void edge_finish() {            // (behind the synchronisation of the stream that carried the downloads)
+    for (int i = 0; i < n_edge_out; ++i) memcpy(edge_out[i].host, edge_out[i].bounce, edge_out[i].n);
+    n_edge_out = 0;
+  }
 
   int init() {
     if (ready) return VCMI_OK;
@@ -434,17 +452,57 @@ void window_segments(const std::vector<HostPiece> &pieces, const std::vector<siz
   }
 }
 
-bool range_is_pinned(const void *p, size_t bytes);      // (below: caller-pinned memory)
+}  // namespace
+// (below: caller-pinned memory)  lo / hi: the part of the address space around [p, p + bytes) that the DMA engines reach -- the
+// whole pages inside an array registered with vcmi_host_register, everything for memory another runtime pinned
+bool range_is_pinned(const void *p, size_t bytes, uintptr_t *lo = nullptr, uintptr_t *hi = nullptr);
+
+// host <-> device copy of [h, h + bytes): the part inside [lo, hi) as one DMA on the pinned pages; what is left at either end
+// (less than a page each: the partial first and last page of a registered array are not pinned, see host_register) through
+// pinned bounce pages of the ring -- up: copied in here, then DMA'd; down: DMA'd into the bounce page and copied into the
+// caller's page by Ring::edge_finish once the stream is synchronised.  (Pageable hipMemcpyAsync calls for these few bytes made
+// the host wait for the stream in the middle of the pipeline: 13.2 ms per 10^6 frames instead of 7.4.)
+// One upload range and one download range per call (a head and a tail each); edge_begin() first.
+static int copy_split(Ring *r, char *d, char *h, size_t bytes, bool to_device, hipStream_t st, uintptr_t lo, uintptr_t hi) {
+  const uintptr_t a = (uintptr_t)h, b = a + bytes;
+  const uintptr_t m0 = std::min(std::max(lo, a), b), m1 = std::max(std::min(hi, b), m0);
+  auto edge = [&](uintptr_t x0, uintptr_t x1) -> int {
+    if (x1 <= x0) return VCMI_OK;
+    char *hp = h + (x0 - a), *dp = d + (x0 - a);
+    const size_t n = x1 - x0;
+    if (n > 4096 || (to_device ? r->n_edge_in : r->n_edge_out) >= 2) return fail(VCMI_ERR_ARG, "internal: edge copy of %zu bytes", n);
+    if (to_device) {
+      char *bn = r->edge + 4096 * (r->n_edge_in++);
+      memcpy(bn, hp, n);
+      VCMI_HIP(hipMemcpyAsync(dp, bn, n, hipMemcpyHostToDevice, st));
+    } else {
+      char *bn = r->edge + 4096 * (2 + r->n_edge_out);
+      VCMI_HIP(hipMemcpyAsync(bn, dp, n, hipMemcpyDeviceToHost, st));
+      r->edge_out[r->n_edge_out++] = Ring::EdgeOut{hp, bn, n};
+    }
+    return VCMI_OK;
+  };
+  VCMI_TRY(edge(a, m0));
+  if (m1 > m0) {
+    char *hp = h + (m0 - a), *dp = d + (m0 - a);
+    VCMI_HIP(hipMemcpyAsync(to_device ? (void *)dp : (void *)hp, to_device ? (const void *)hp : (const void *)dp, m1 - m0,
+                            to_device ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost, st));
+  }
+  return edge(m1, b);
+}
+namespace {
 
 int do_upload(Ring *r, char *dDst, const std::vector<HostPiece> *pieces, const char *hSrc, size_t bytes, hipStream_t consumer) {
   if (bytes == 0) return VCMI_OK;
-  if (!pieces && range_is_pinned(hSrc, bytes)) {
+  uintptr_t plo = 0, phi = 0;
+  if (!pieces && range_is_pinned(hSrc, bytes, &plo, &phi)) {
     // the caller pinned this array (vcmi_host_register): one DMA straight out of it.  The upload is complete on return -- the
     // staged path has copied the caller's data out of the array by then, and an entry point that only uploads (a resident
     // training matrix) must leave the same freedom to free or overwrite it.
     VCMI_HIP(hipEventRecord(r->ev_tmp, consumer));       // dDst may still be read by work the consumer enqueued earlier
     VCMI_HIP(hipStreamWaitEvent(r->up, r->ev_tmp, 0));
-    VCMI_HIP(hipMemcpyAsync(dDst, hSrc, bytes, hipMemcpyHostToDevice, r->up));
+    VCMI_TRY(r->edge_begin());
+    VCMI_TRY(copy_split(r, dDst, const_cast<char *>(hSrc), bytes, true, r->up, plo, phi));
     VCMI_HIP(hipStreamSynchronize(r->up));
     return VCMI_OK;
   }
@@ -483,11 +541,14 @@ int do_upload(Ring *r, char *dDst, const std::vector<HostPiece> *pieces, const c
 
 int do_download(Ring *r, const std::vector<HostPiece> *pieces, char *hDst, const char *dSrc, size_t bytes, hipStream_t producer) {
   if (bytes == 0) return VCMI_OK;
-  if (!pieces && range_is_pinned(hDst, bytes)) {        // a pinned destination: one DMA straight into it
+  uintptr_t plo = 0, phi = 0;
+  if (!pieces && range_is_pinned(hDst, bytes, &plo, &phi)) {        // a pinned destination: one DMA straight into it
     VCMI_HIP(hipEventRecord(r->ev_tmp, producer));
     VCMI_HIP(hipStreamWaitEvent(r->down, r->ev_tmp, 0));
-    VCMI_HIP(hipMemcpyAsync(hDst, dSrc, bytes, hipMemcpyDeviceToHost, r->down));
+    VCMI_TRY(r->edge_begin());
+    VCMI_TRY(copy_split(r, const_cast<char *>(dSrc), hDst, bytes, false, r->down, plo, phi));
     VCMI_HIP(hipStreamSynchronize(r->down));
+    r->edge_finish();
     return VCMI_OK;
   }
   const size_t chunk = std::min(bytes, kXferChunk);
@@ -544,14 +605,19 @@ namespace {
 struct PinnedRange {
   uintptr_t base;
   size_t bytes;
+  uintptr_t lo, hi;      // the whole pages inside [base, base + bytes) that are registered with the runtime; lo == hi: none
 };
 std::mutex g_pinned_mu;
 std::vector<PinnedRange> g_pinned;      // ranges registered through vcmi_host_register (few: linear scan)
+constexpr uintptr_t kPage = 4096;
+// Arrays whose whole pages make up less than this are recorded but not pinned: their transfers are latency-bound either way
+constexpr size_t kMinPinBytes = (size_t)1 << 20;
+}  // namespace
 
 // [p, p + bytes) lies in memory the DMA engines can address: a range registered here, or host memory another party pinned
 // (hipHostMalloc / hipHostRegister by the caller's runtime: torch's pin_memory, a Julia AMDGPU.jl pinned array) that the HIP
 // runtime knows.  VCMI_HOST_PINNED=0 (read once) switches the detection off (A/B: every call stages).
-bool range_is_pinned(const void *p, size_t bytes) {
+bool range_is_pinned(const void *p, size_t bytes, uintptr_t *lo, uintptr_t *hi) {
   static const bool enabled = [] {
     const char *e = getenv("VCMI_HOST_PINNED");
     return !(e && e[0] == '0');
@@ -561,7 +627,11 @@ bool range_is_pinned(const void *p, size_t bytes) {
   {
     std::lock_guard<std::mutex> lk(g_pinned_mu);
     for (const PinnedRange &r : g_pinned)
-      if (a >= r.base && a + bytes <= r.base + r.bytes) return true;
+      if (a >= r.base && a + bytes <= r.base + r.bytes) {
+        if (lo) *lo = r.lo;
+        if (hi) *hi = r.hi;
+        return r.hi > r.lo;              // (a small array: registered with this library, staged all the same)
+      }
   }
   // memory pinned by another party: worth two runtime look-ups only for transfers that are not small anyway (they stage)
   if (bytes < ((size_t)64 << 10)) return false;
@@ -581,10 +651,18 @@ bool range_is_pinned(const void *p, size_t bytes) {
     return false;
   }
   const uintptr_t off = (uintptr_t)at.devicePointer - (uintptr_t)base;
-  return off <= size && bytes <= size - off;
+  if (!(off <= size && bytes <= size - off)) return false;
+  if (lo) *lo = a;
+  if (hi) *hi = a + bytes;
+  return true;
 }
-}  // namespace
 
+// Only the WHOLE PAGES inside the array are registered with the runtime.  hipHostRegister pins (and hipHostUnregister unmaps)
+// every page the range touches; the first and the last page of an array on the heap also hold its neighbours, and after such a
+// page had been unmapped, later transfers of the runtime itself from pageable memory in that neighbourhood (its own in-place
+// pinning: a model upload of this library, torch's `.cuda()` of a numpy array) died with "Memory access fault by GPU" on a
+// page-aligned heap address -- about one run of the test suite in three (round 6; none in seven runs without the two tests that
+// registered 320-byte and 960 KB arrays).  The partial pages travel as pageable copies (copy_split).
 int host_register(void *p, size_t bytes) {
   if (!p || bytes == 0) return fail(VCMI_ERR_ARG, "vcmi_host_register: NULL pointer or zero length");
   // (one critical section over the overlap test, the registration and the table entry: two threads registering overlapping
@@ -593,13 +671,18 @@ int host_register(void *p, size_t bytes) {
   for (const PinnedRange &r : g_pinned)
     if ((uintptr_t)p < r.base + r.bytes && r.base < (uintptr_t)p + bytes)
       return fail(VCMI_ERR_ARG, "vcmi_host_register: the range overlaps one that is already registered");
-  const hipError_t e = hipHostRegister(p, bytes, hipHostRegisterPortable);
-  if (e != hipSuccess) {
-    (void)hipGetLastError();
-    return fail(e == hipErrorOutOfMemory ? VCMI_ERR_OOM : VCMI_ERR_HIP, "hipHostRegister of %zu bytes failed: %s", bytes,
-                hipGetErrorString(e));
+  const uintptr_t a = (uintptr_t)p;
+  uintptr_t lo = (a + kPage - 1) / kPage * kPage, hi = (a + bytes) / kPage * kPage;
+  if (hi <= lo || hi - lo < kMinPinBytes) lo = hi = 0;
+  if (hi > lo) {
+    const hipError_t e = hipHostRegister((void *)lo, hi - lo, hipHostRegisterPortable);
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      return fail(e == hipErrorOutOfMemory ? VCMI_ERR_OOM : VCMI_ERR_HIP, "hipHostRegister of %zu bytes failed: %s", (size_t)(hi - lo),
+                  hipGetErrorString(e));
+    }
   }
-  g_pinned.push_back(PinnedRange{(uintptr_t)p, bytes});
+  g_pinned.push_back(PinnedRange{a, bytes, lo, hi});
   return VCMI_OK;
 }
 
@@ -608,16 +691,28 @@ int host_unregister(void *p) {
   auto it = std::find_if(g_pinned.begin(), g_pinned.end(), [p](const PinnedRange &r) { return r.base == (uintptr_t)p; });
   if (it == g_pinned.end()) return fail(VCMI_ERR_ARG, "vcmi_host_unregister: %p was not registered with vcmi_host_register", p);
   // transfers of earlier calls are complete (every host-pointer entry point returns with its data delivered)
-  const hipError_t e = hipHostUnregister(p);
-  if (e != hipSuccess) {                // the pages are still locked: the entry stays, so that the range is still known as pinned
-    (void)hipGetLastError();
-    return fail(VCMI_ERR_HIP, "hipHostUnregister failed: %s", hipGetErrorString(e));
+  if (it->hi > it->lo) {
+    const hipError_t e = hipHostUnregister((void *)it->lo);
+    if (e != hipSuccess) {                // the pages are still locked: the entry stays, so that the range is still known as pinned
+      (void)hipGetLastError();
+      return fail(VCMI_ERR_HIP, "hipHostUnregister failed: %s", hipGetErrorString(e));
+    }
   }
   g_pinned.erase(it);
   return VCMI_OK;
 }
 
-int host_is_registered(const void *p, size_t bytes) { return range_is_pinned(p, bytes) ? 1 : 0; }
+// registered with vcmi_host_register (pinned or, for a small array, only recorded), or pinned by another runtime
+int host_is_registered(const void *p, size_t bytes) {
+  if (!p || bytes == 0) return 0;
+  {
+    std::lock_guard<std::mutex> lk(g_pinned_mu);
+    const uintptr_t a = (uintptr_t)p;
+    for (const PinnedRange &r : g_pinned)
+      if (a >= r.base && a + bytes <= r.base + r.bytes) return 1;
+  }
+  return range_is_pinned(p, bytes) ? 1 : 0;
+}
 
 int staged_upload(void *dDst, const void *hSrc, size_t bytes, hipStream_t consumer) {
   Ring *r = nullptr;
@@ -625,6 +720,13 @@ int staged_upload(void *dDst, const void *hSrc, size_t bytes, hipStream_t consum
   std::lock_guard<std::mutex> lk(r->mu);
   VCMI_TRY(r->init());
   return do_upload(r, (char *)dDst, nullptr, (const char *)hSrc, bytes, consumer);
+}
+
+int upload_now(void *dDst, const void *hSrc, size_t bytes) {
+  if (bytes == 0) return VCMI_OK;
+  VCMI_TRY(staged_upload(dDst, hSrc, bytes, nullptr));      // the null stream waits for the last chunk ...
+  VCMI_HIP(hipStreamSynchronize(nullptr));                  // ... and the caller for the null stream
+  return VCMI_OK;
 }
 
 int staged_upload_gather(void *dDst, const std::vector<HostPiece> &pieces, hipStream_t consumer) {
@@ -682,8 +784,9 @@ int staged_pipeline(const void *hIn, size_t in_unit, size_t in_stride, void *hOu
   }
   // A side whose array is PINNED (vcmi_host_register, or pinned by the caller's own runtime) and dense needs no staging copy:
   // the DMA engines read the caller's x / write the caller's y themselves.  The two sides are independent.
-  const bool in_direct = in_stride == in_unit && range_is_pinned(hIn, (size_t)units * in_unit);
-  const bool out_direct = out_stride == out_unit && range_is_pinned(hOut, (size_t)units * out_unit);
+  uintptr_t in_lo = 0, in_hi = 0, out_lo = 0, out_hi = 0;
+  const bool in_direct = in_stride == in_unit && range_is_pinned(hIn, (size_t)units * in_unit, &in_lo, &in_hi);
+  const bool out_direct = out_stride == out_unit && range_is_pinned(hOut, (size_t)units * out_unit, &out_lo, &out_hi);
   const size_t wide = std::max(in_unit, out_unit);
   static const size_t pipe_chunk = [] {          // A/B hook, read once: VCMI_HOST_CHUNK_MB (default: kPipeChunk)
     const char *e = getenv("VCMI_HOST_CHUNK_MB");
@@ -748,6 +851,7 @@ int staged_pipeline(const void *hIn, size_t in_unit, size_t in_stride, void *hOu
   VCMI_TRY(r->reserve(r->dev_in, r->dev_in_cap, (size_t)chunk * in_unit, false));
   VCMI_TRY(r->reserve(r->dev_out, r->dev_out_cap, (size_t)chunk * out_unit, false));
   VCMI_TRY(r->quiesce());
+  if (in_direct || out_direct) VCMI_TRY(r->edge_begin());
   // A large output array is usually fresh (`similar(X)`, numpy.empty): its first touch is ~80k page faults per 320 MB.
   // Ask for huge pages on the 2 MB-aligned interior before the workers touch it (a hint; ignored where unsupported).
   std::shared_ptr<Latch> prefault;     // joined before this function returns, on the error path too
@@ -798,7 +902,8 @@ int staged_pipeline(const void *hIn, size_t in_unit, size_t in_stride, void *hOu
           src = r->pin_in[s];
         }
         if (c >= K) VCMI_HIP(hipStreamWaitEvent(r->up, r->ev_run[s], 0));        // device slot: kernels of chunk c-K done
-        VCMI_HIP(hipMemcpyAsync(r->dev_in[s], src, (size_t)n * in_unit, hipMemcpyHostToDevice, r->up));
+        if (in_direct) VCMI_TRY(copy_split(r, r->dev_in[s], const_cast<char *>(src), (size_t)n * in_unit, true, r->up, in_lo, in_hi));
+        else VCMI_HIP(hipMemcpyAsync(r->dev_in[s], src, (size_t)n * in_unit, hipMemcpyHostToDevice, r->up));
         VCMI_HIP(hipEventRecord(r->ev_up[s], r->up));
         VCMI_HIP(hipStreamWaitEvent(r->run, r->ev_up[s], 0));
         if (c >= K) VCMI_HIP(hipStreamWaitEvent(r->run, r->ev_down[s], 0));      // output slot: download of chunk c-K done
@@ -806,13 +911,16 @@ int staged_pipeline(const void *hIn, size_t in_unit, size_t in_stride, void *hOu
         VCMI_HIP(hipEventRecord(r->ev_run[s], r->run));
         VCMI_HIP(hipStreamWaitEvent(r->down, r->ev_run[s], 0));
         // pin_out[s] was drained by the host LAG < K iterations ago
-        VCMI_HIP(hipMemcpyAsync(out_direct ? (char *)hOut + (size_t)first * out_stride : r->pin_out[s], r->dev_out[s],
-                                (size_t)n * out_unit, hipMemcpyDeviceToHost, r->down));
+        if (out_direct) VCMI_TRY(copy_split(r, r->dev_out[s], (char *)hOut + (size_t)first * out_stride, (size_t)n * out_unit, false, r->down, out_lo, out_hi));
+        else VCMI_HIP(hipMemcpyAsync(r->pin_out[s], r->dev_out[s], (size_t)n * out_unit, hipMemcpyDeviceToHost, r->down));
         VCMI_HIP(hipEventRecord(r->ev_down[s], r->down));
       }
       const int64_t j = c - LAG;
       if (out_direct) {
-        if (j == nch - 1) VCMI_HIP(hipStreamSynchronize(r->down));               // the caller's y is complete on return
+        if (j == nch - 1) {
+          VCMI_HIP(hipStreamSynchronize(r->down));               // the caller's y is complete on return
+          r->edge_finish();
+        }
         continue;
       }
       if (j >= 0 && j < nch) {

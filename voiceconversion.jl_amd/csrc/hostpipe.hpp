@@ -28,6 +28,15 @@ struct HostPiece {   // one contiguous host range of a gather (upload) or scatte
 // hSrc (pageable) -> dDst on the current device; returns once everything is enqueued; `consumer` (may be the null
 // stream) is made to wait for the last chunk.  The pieces of the gather variant land back to back at dDst.
 int staged_upload(void *dDst, const void *hSrc, size_t bytes, hipStream_t consumer);
+// A synchronous upload of model-sized data from ordinary (pageable) host memory THROUGH THE PINNED RING: complete on return, like
+// hipMemcpy -- but the runtime never pins the caller's pages in place.  (hipMemcpy from a pageable std::vector of a megabyte or
+// more locks the vector's pages for the DMA; in the full test suite -- after arrays had been registered, unregistered and freed
+// around the same heap addresses -- that DMA hit an unmapped page about once in three runs: "Memory access fault by GPU" inside
+// vcmi_gmmmap_create, round 6.)
+int upload_now(void *dDst, const void *hSrc, size_t bytes);
+inline hipError_t upload_now_hip(void *dDst, const void *hSrc, size_t bytes) {      // for call sites that chain hipError_t
+  return upload_now(dDst, hSrc, bytes) == VCMI_OK ? hipSuccess : hipErrorUnknown;
+}
 int staged_upload_gather(void *dDst, const std::vector<HostPiece> &pieces, hipStream_t consumer);
 // dSrc -> hDst (pageable); waits for `producer`'s work enqueued so far; returns when the data is in host memory.
 int staged_download(void *hDst, const void *dSrc, size_t bytes, hipStream_t producer);

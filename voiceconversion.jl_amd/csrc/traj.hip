@@ -1200,7 +1200,7 @@ static int traj_run(vcmi_traj *t, std::vector<TrajUtt> &utts, int64_t nframes, b
   VCMI_HIP(hipMemsetAsync(t->status.p, 0, sizeof(int), st));
   // longest utterances first
   std::stable_sort(utts.begin(), utts.end(), [](const TrajUtt &a, const TrajUtt &b) { return a.T > b.T; });
-  VCMI_HIP(hipMemcpy(t->uttbuf.p, utts.data(), sizeof(TrajUtt) * n, hipMemcpyHostToDevice));
+  VCMI_TRY(upload_now(t->uttbuf.p, utts.data(), sizeof(TrajUtt) * n));
   const size_t shmem = solve_lds_bytes(D);
   const TrajUtt *du = reinterpret_cast<const TrajUtt *>(t->uttbuf.p);
   if (g_mfma) {
@@ -1232,7 +1232,7 @@ static int traj_run(vcmi_traj *t, std::vector<TrajUtt> &utts, int64_t nframes, b
     VCMI_TRY(t->uttpad.reserve(sizeof(TrajUtt) * n));
     std::vector<TrajUtt> up(utts);
     for (auto &u : up) u.Y = t->ypad.p + (size_t)u.frame0 * Dp;
-    VCMI_HIP(hipMemcpy(t->uttpad.p, up.data(), sizeof(TrajUtt) * n, hipMemcpyHostToDevice));
+    VCMI_TRY(upload_now(t->uttpad.p, up.data(), sizeof(TrajUtt) * n));
     ws_stride_s = (int64_t)Tmax * (3 * Dp + 1) * Dp;
     VCMI_TRY(t->ws.reserve((size_t)grid * std::max(ws_stride, ws_stride_s)));
     hipLaunchKernelGGL(traj_pad_g_kernel, dim3((unsigned)std::min<int64_t>((nframes * 2 * Dp + 255) / 256, 4096)), dim3(256), 0, st,
@@ -1453,8 +1453,8 @@ static int traj_host_batch(vcmi_traj *t, int64_t n, const double *const *X, cons
           gr->t = r;
           VCMI_TRY(gr->muv.alloc(gvh->h_muv.size()));
           VCMI_TRY(gr->pv.alloc(gvh->h_pv.size()));
-          VCMI_HIP(hipMemcpy(gr->muv.p, gvh->h_muv.data(), gvh->h_muv.size() * 8, hipMemcpyHostToDevice));
-          VCMI_HIP(hipMemcpy(gr->pv.p, gvh->h_pv.data(), gvh->h_pv.size() * 8, hipMemcpyHostToDevice));
+          VCMI_TRY(upload_now(gr->muv.p, gvh->h_muv.data(), gvh->h_muv.size() * 8));
+          VCMI_TRY(upload_now(gr->pv.p, gvh->h_pv.data(), gvh->h_pv.size() * 8));
         }
         gv2.muv = gr->muv.p;
         gv2.pv = gr->pv.p;
@@ -1530,7 +1530,7 @@ extern "C" int vcmi_traj_create(vcmi_gmmmap *g, int64_t T, vcmi_traj **out) {
       for (int d = D; d < Dp; ++d) q[(size_t)d * Dp2 + d] = 1.0;              // padding: P = I, r = 0 -> y = 0, decoupled
     }
     int rcp = t->Qpad.alloc(Qp.size());
-    if (rcp == VCMI_OK && hipMemcpy(t->Qpad.p, Qp.data(), Qp.size() * 8, hipMemcpyHostToDevice) != hipSuccess) rcp = VCMI_ERR_HIP;
+    if (rcp == VCMI_OK && upload_now_hip(t->Qpad.p, Qp.data(), Qp.size() * 8) != hipSuccess) rcp = VCMI_ERR_HIP;
     if (rcp != VCMI_OK) {
       delete t;
       return rcp == VCMI_ERR_HIP ? fail(VCMI_ERR_HIP, "vcmi_traj_create: upload of the padded Q failed") : rcp;
@@ -1542,12 +1542,12 @@ extern "C" int vcmi_traj_create(vcmi_gmmmap *g, int64_t T, vcmi_traj **out) {
     delete t;
     return rc;
   }
-  hipError_t e = hipMemcpy(t->Q.p, Q.data(), Q.size() * 8, hipMemcpyHostToDevice);
-  if (e == hipSuccess) e = hipMemcpy(t->QT.p, QT.data(), QT.size() * 8, hipMemcpyHostToDevice);
-  if (e == hipSuccess) e = hipMemcpy(t->AT.p, AT.data(), AT.size() * 8, hipMemcpyHostToDevice);
-  if (e == hipSuccess) e = hipMemcpy(t->bvec.p, bv.data(), bv.size() * 8, hipMemcpyHostToDevice);
-  if (e == hipSuccess) e = hipMemcpy(t->Qfrag.p, Qf.data(), Qf.size() * 8, hipMemcpyHostToDevice);
-  if (e == hipSuccess) e = hipMemcpy(t->Afrag.p, Af.data(), Af.size() * 8, hipMemcpyHostToDevice);
+  hipError_t e = upload_now_hip(t->Q.p, Q.data(), Q.size() * 8);
+  if (e == hipSuccess) e = upload_now_hip(t->QT.p, QT.data(), QT.size() * 8);
+  if (e == hipSuccess) e = upload_now_hip(t->AT.p, AT.data(), AT.size() * 8);
+  if (e == hipSuccess) e = upload_now_hip(t->bvec.p, bv.data(), bv.size() * 8);
+  if (e == hipSuccess) e = upload_now_hip(t->Qfrag.p, Qf.data(), Qf.size() * 8);
+  if (e == hipSuccess) e = upload_now_hip(t->Afrag.p, Af.data(), Af.size() * 8);
   if (e != hipSuccess) {
     delete t;
     return fail(VCMI_ERR_HIP, "TrajectoryGMMMap: upload failed: %s", hipGetErrorString(e));
@@ -1681,8 +1681,8 @@ extern "C" int vcmi_trajgv_create(vcmi_traj *t, const double *muv, const double 
     delete h;
     return rc;
   }
-  hipError_t e = hipMemcpy(h->muv.p, muv, sizeof(double) * D, hipMemcpyHostToDevice);
-  if (e == hipSuccess) e = hipMemcpy(h->pv.p, Pj.data(), sizeof(double) * D * D, hipMemcpyHostToDevice);
+  hipError_t e = upload_now_hip(h->muv.p, muv, sizeof(double) * D);
+  if (e == hipSuccess) e = upload_now_hip(h->pv.p, Pj.data(), sizeof(double) * D * D);
   if (e != hipSuccess) {
     delete h;
     return fail(VCMI_ERR_HIP, "TrajectoryGVGMMMap: upload failed: %s", hipGetErrorString(e));
