@@ -26,6 +26,9 @@
 //     0.82 M cycles and the second in 1.16 M.  s_setprio by phase (high in the softmax + step A phase, low in step B's MFMA
 //     stream) evens them out (1.02 M / 1.06 M).
 // estep_fixture (M = 32, Dj = 80, 1.25e6 frames): 0.815 ms in estep_mfma_kernel -> 0.51 ms here (step: 0.89 -> 0.61 ms).
+// M <= 16 (the size bin/train_gmm.jl defaults to): one mixture tile, blocks of ONE frame tile, the two waves of a workgroup split
+// step A's contraction by k-steps (two planes of partial sums in LDS) -- 39.7 KB of LDS per workgroup with the x images packed
+// and 16-bit DMA offsets, four workgroups = eight waves per CU: 0.63 ms (estep_mfma_kernel) -> 0.39-0.41 ms per 1.25e6 frames.
 // The arithmetic of a frame is that of estep_mfma_kernel (same expanded form, same refinement rule, same table exp); the
 // partial statistics have the same row layout (row = workgroup x half) and go through estep_reduce_kernel.
 #pragma once
@@ -44,16 +47,29 @@ struct EstepSmallCfg {
   static_assert(MT == 1 || MT == 2, "one or two mixture tiles");
   static constexpr int KS = 2 * DJ / 4, NDT = 2 * DJ / 16;
   static constexpr int NW = 2 * MT;                              // waves per workgroup
-  static constexpr int FB = 32;                                  // frames per block: two frame tiles of 16
+  // frames per block.  MT = 2: two frame tiles of 16, a wave = (mixture tile, frame tile) in step A.  MT = 1: ONE frame tile,
+  // and the two waves split the contraction of step A by k-steps (partial sums in two planes of LDS, added by the softmax) --
+  // half the LDS per workgroup, so that four of them fit a CU and every SIMD has its two waves (with 32-frame blocks a CU
+  // held two workgroups of two waves: one wave per SIMD, 0.55 ms per 1.25e6 frames at M = 16)
+  static constexpr int FB = MT == 1 ? 16 : 32;
+  static constexpr bool SPLITK = MT == 1;
+  static constexpr int PLANES = SPLITK ? 2 : 1;
   static constexpr int RSX = (DJ + 2 + 13) / 32 * 32 + 18;       // as EstepCfg: 16-byte rows, conflict-free column reads
-  static constexpr int XBUF = (FB * RSX * 8 + 1023) / 1024 * 128;
-  static constexpr int LPF = 4 * MT;                             // softmax lanes per frame (four slots each)
-  // LDS row stride of l / gamma: 20 MT doubles -- the softmax's half-wave (32 / LPF frames x LPF consecutive doubles) lands on
-  // 64 distinct banks (MT = 2: rows 80 dwords apart -> 0, 16, 32, 48 mod 64; MT = 1: 40 dwords -> 0, 40, 16, 56, 32, 8, 48, 24)
-  static constexpr int RSG = 20 * MT;
-  static constexpr int WG_PER_CU = 2;
-  // [x 3][l / gamma FB x RSG][etab 64][thresholds 16 MT] doubles + [DMA source offsets: XBUF / 128 chunks x 64 lanes] ints
-  static constexpr size_t LDS_BYTES = ((size_t)3 * XBUF + (size_t)FB * RSG + 64 + 16 * MT) * sizeof(double) + (size_t)(XBUF / 128) * 64 * sizeof(unsigned);
+  static constexpr int NCHUNK = (FB * RSX * 8 + 1023) / 1024;    // 1 KB wave-instructions of the LDS-DMA per x image
+  // doubles between two x images.  MT = 1: exactly the image -- the last wave-instruction of an image is cut off behind it
+  // (kLastLanes) -- because there every byte counts: four workgroups per CU have 40 KB each
+  static constexpr int XBUF = SPLITK ? FB * RSX : NCHUNK * 128;
+  static constexpr int kLastLanes = SPLITK ? (FB * RSX * 8 - 1024 * (NCHUNK - 1)) / 16 : 64;
+  static constexpr int NV = 16 * MT * FB / (64 * NW);            // softmax values per lane: 4 (MT = 2) / 2 (MT = 1)
+  static constexpr int LPF = 16 * MT / NV;                       // softmax lanes per frame
+  static_assert(LPF == 8 && 64 / LPF * NW == FB, "one softmax pass per wave and block");
+  // LDS row stride of l / gamma (doubles): the softmax's half-wave (four frames x eight consecutive doubles) lands on 64
+  // distinct banks -- MT = 2: rows 80 dwords apart -> 0, 16, 32, 48 mod 64; MT = 1: 48 dwords -> 0, 48, 32, 16
+  static constexpr int RSG = MT == 2 ? 40 : 24;
+  static constexpr int WG_PER_CU = MT == 2 ? 2 : 4;
+  // [x 3][l / gamma PLANES x FB x RSG][etab 64][thresholds 16 MT] doubles + [DMA source offsets: NCHUNK x 64 lanes] shorts
+  static constexpr size_t LDS_BYTES = ((size_t)3 * XBUF + (size_t)PLANES * FB * RSG + 64 + 16 * MT) * sizeof(double) + (size_t)NCHUNK * 64 * sizeof(unsigned short);
+  static_assert(FB * 80 * 8 < 65536 && (XBUF * 8) % 16 == 0, "offsets fit 16 bits; images are 16-byte aligned");
   static_assert(LDS_BYTES * WG_PER_CU <= 160 * 1024, "LDS");
 };
 
@@ -112,14 +128,18 @@ estep_small_kernel(const double *__restrict__ X, int64_t N, int M, const double 
 #ifdef VCMI_ESTEP_PROF
   const unsigned long long tk0_ = __builtin_readcyclecounter(), rk0_ = __builtin_amdgcn_s_memrealtime();
 #endif
-  constexpr int KS = C::KS, NDT = C::NDT, FB = C::FB, RSX = C::RSX, RSG = C::RSG, XBUF = C::XBUF, NW = C::NW, LPF = C::LPF;
+  constexpr int KS = C::KS, NDT = C::NDT, FB = C::FB, RSX = C::RSX, RSG = C::RSG, XBUF = C::XBUF, NW = C::NW, LPF = C::LPF, NV = C::NV;
+  constexpr bool kSplitK = C::SPLITK;
+  constexpr int NS = KS / 2;                            // k-steps of x^2 (and of x) in a step A
+  constexpr int NSL = kSplitK ? NS / 2 : NS;            // ... of which a wave takes these (MFMA slots: one k-step of either chain each)
+  static_assert(!kSplitK || NS % 2 == 0, "k-steps");
   extern __shared__ double smem[];
   double *xbuf = smem;                     // [3][XBUF]: [FB][RSX] images
   double *lg = smem + 3 * XBUF;            // [FB][RSG]   l, then gamma
   double *red = lg;                        // [NW] scratch of the log-likelihood reduction (epilogue only)
-  double *etab = lg + FB * RSG;            // [64] 2^(j/64) for vc_exp_tab
+  double *etab = lg + C::PLANES * FB * RSG;  // [64] 2^(j/64) for vc_exp_tab
   double *tthr = etab + 64;                // [16 MT] refinement thresholds
-  unsigned *otab = reinterpret_cast<unsigned *>(tthr + 16 * MT);   // [NCHUNK][64] source offsets of the LDS-DMA (full blocks)
+  unsigned short *otab = reinterpret_cast<unsigned short *>(tthr + 16 * MT);   // [NCHUNK][64] source offsets of the LDS-DMA (full blocks)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // in a scalar register: per-wave addresses and branches are uniform
   const int lcol = lane & 15, lgrp = lane >> 4;
@@ -127,10 +147,15 @@ estep_small_kernel(const double *__restrict__ X, int64_t N, int M, const double 
   if (tid < 16 * MT) tthr[tid] = (tid < M) ? refc[2 * tid + 1] : -INFINITY;
   const int tile = wave % MT, half = wave / MT;
 
-  double wfrag[KS];
+  // this wave's weight fragments: slots [0, NSL) multiply x^2, [NSL, 2 NSL) multiply x (kSplitK: the k-steps half * NSL ... of either)
+  const int kofs = kSplitK ? half * NSL : 0;
+  double wfrag[2 * NSL];
 #pragma unroll
-  for (int ks = 0; ks < KS; ++ks) wfrag[ks] = Wpack[((size_t)tile * KS + ks) * 64 + lane];
-  const double cm = cinit[16 * tile + lcol];
+  for (int k = 0; k < NSL; ++k) {
+    wfrag[k] = Wpack[((size_t)tile * KS + kofs + k) * 64 + lane];
+    wfrag[NSL + k] = Wpack[((size_t)tile * KS + NS + kofs + k) * 64 + lane];
+  }
+  const double cm = (kSplitK && half) ? 0.0 : cinit[16 * tile + lcol];        // (kSplitK: the constant travels with the first partial sum)
   const d4 cin = {cm, cm, cm, cm};
   d4 sacc[NDT];
 #pragma unroll
@@ -139,7 +164,7 @@ estep_small_kernel(const double *__restrict__ X, int64_t N, int M, const double 
   int nprod = 0, nmfma = 0;
 
   const int64_t nblocks = (N + FB - 1) / FB;
-  constexpr int ROWB = RSX * 8, NCHUNK = XBUF / 128;
+  constexpr int ROWB = RSX * 8, NCHUNK = C::NCHUNK;
   // LDS-DMA of one block, 1 KB per wave-instruction (see estep_mfma_kernel).  The per-lane source offset of every chunk is the
   // same for all full blocks: it comes from a table in LDS (one ds_read per chunk instead of a dozen integer instructions --
   // every VALU instruction of this kernel is paid for in matrix-pipe time); only the call's last, partial block computes it.
@@ -148,19 +173,22 @@ estep_small_kernel(const double *__restrict__ X, int64_t N, int M, const double 
     const int rowc = row < last ? row : last;                    // (also the rows >= FB of the padding)
     return (col < dj * 8) ? (unsigned)(rowc * (dj * 8) + col) : 0u;
   };
-  for (int e = tid; e < NCHUNK * 64; e += 64 * NW) otab[e] = chunk_off(e >> 6, e & 63, FB - 1);
+  for (int e = tid; e < NCHUNK * 64; e += 64 * NW) otab[e] = (unsigned short)chunk_off(e >> 6, e & 63, FB - 1);
   auto stage = [&](int64_t f0, double *dst) {
     const char *base = reinterpret_cast<const char *>(X + f0 * dj);
     auto dma = [&](int q, unsigned off) {
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(base + off),
-                                       (__attribute__((address_space(3))) void *)(reinterpret_cast<char *>(dst) + 1024 * q), 16, 0, 0);
+      // (kLastLanes < 64: the images are packed, the lanes of the last chunk behind the image must not write -- what lies there
+      // is the next image, or l / gamma)
+      if (C::kLastLanes == 64 || q != NCHUNK - 1 || lane < C::kLastLanes)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(base + off),
+                                         (__attribute__((address_space(3))) void *)(reinterpret_cast<char *>(dst) + 1024 * q), 16, 0, 0);
     };
     if (N - f0 >= FB) {                                          // workgroup-uniform
       // (the table address is formed here, per block, from the opaque lane id: hoisted out of the loop the six addresses are
       // spilled, and a scratch reload's s_waitcnt vmcnt(0) also waits for the DMA issued just before it -- 950 cycles a chunk)
       int lane_t = lane;
       asm volatile("" : "+v"(lane_t));
-      const unsigned *ot = otab + lane_t;
+      const unsigned short *ot = otab + lane_t;
       unsigned off[(NCHUNK + NW - 1) / NW];
 #pragma unroll
       for (int i = 0; i < (NCHUNK + NW - 1) / NW; ++i) {
@@ -191,19 +219,21 @@ estep_small_kernel(const double *__restrict__ X, int64_t N, int M, const double 
   if (blk0 + bstride < nblocks) stage((blk0 + bstride) * FB, xbuf + XBUF);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  const int arow = (16 * half + lcol) * RSX + lgrp;            // step A: this lane's operand row / k offset in an x image
+  // step A: this lane's operand row / first k offset in an x image, its rows of l in LDS (kSplitK: the wave's plane)
+  const int arow = ((kSplitK ? 0 : 16 * half) + lcol) * RSX + lgrp + 4 * kofs;
+  double *const lgA = lg + (kSplitK ? half * FB * RSG : 16 * half * RSG) + lgrp * RSG + 16 * tile + lcol;
   if (blk0 < nblocks) {                                        // step A(0), on its own
     d4 acc = cin, acc2 = {0, 0, 0, 0};
-    nmfma += KS;
+    nmfma += 2 * NSL;
     const double *xr = xbuf + arow;
 #pragma unroll
-    for (int ks = 0; ks < KS / 2; ++ks) {
-      const double x = xr[4 * ks];
-      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x * x, wfrag[ks], acc, 0, 0, 0);
-      acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(x, wfrag[KS / 2 + ks], acc2, 0, 0, 0);
+    for (int k = 0; k < NSL; ++k) {
+      const double x = xr[4 * k];
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x * x, wfrag[k], acc, 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(x, wfrag[NSL + k], acc2, 0, 0, 0);
     }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) lg[(16 * half + 4 * r + lgrp) * RSG + 16 * tile + lcol] = acc[r] + acc2[r];
+    for (int r = 0; r < 4; ++r) lgA[4 * r * RSG] = acc[r] + acc2[r];
   }
   __syncthreads();
   int cur = 0;
@@ -215,7 +245,6 @@ estep_small_kernel(const double *__restrict__ X, int64_t N, int M, const double 
 #else
 #define VCMI_PT(i)
 #endif
-  constexpr int NS = KS / 2;                            // MFMA slots of a step A: one k-step of x^2 and one of x each
   for (int64_t blk = blk0; blk < nblocks; blk += bstride) {
 #ifdef VCMI_ESTEP_PROF
     unsigned long long tl_ = __builtin_readcyclecounter();
@@ -238,80 +267,89 @@ estep_small_kernel(const double *__restrict__ X, int64_t N, int M, const double 
       xq[0] = xr[0];
       xq[1] = xr[4];
       auto mfma_slot = [&](int k) {           // k-step k of both chains; the operand of slot k + 2 is requested
-        if (k + 2 < NS) xq[(k + 2) % 3] = xr[4 * (k + 2)];
+        if (k + 2 < NSL) xq[(k + 2) % 3] = xr[4 * (k + 2)];
         const double x = xq[k % 3];
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x * x, wfrag[k], acc, 0, 0, 0);
-        acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(x, wfrag[NS + k], acc2, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(x, wfrag[NSL + k], acc2, 0, 0, 0);
       };
       // softmax over the 16 MT slots of each frame: LPF lanes per frame, lane l owns the slots l + LPF i.  e^(v - u) by
       // vc_exp_tab's steps (fp64_exp.hpp), the four values of a lane side by side, one piece per MFMA slot.
       const int l = lane & (LPF - 1), f = (64 / LPF) * wave + lane / LPF;
       double *row = lg + f * RSG + l;
       constexpr double kRefine = 36.0;        // e^-36 = 2e-16: a mixture further below the maximum cannot change a sum
-      double v[4], tt[4], t[4], kf[4], r[4], pl[4], u = -INFINITY, s = 0.0, inv = 0.0;
-      int ki[4];
-      bool below[4], needl = false;
+      double v[NV], tt[NV], t[NV], kf[NV], r[NV], pl[NV], u = -INFINITY, s = 0.0, inv = 0.0;
+      int ki[NV];
+      bool below[NV], needl = false;
       const bool livef = (f0 + f < N);
       auto piece = [&](int p) {
         if (p == 0) {
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
+          for (int i = 0; i < NV; ++i) {
             v[i] = row[LPF * i];
+            if constexpr (kSplitK) t[i] = row[FB * RSG + LPF * i];      // the other wave's partial sum
             tt[i] = tthr[l + LPF * i];
           }
         } else if (p == 1) {
-          u = fmax(fmax(v[0], v[1]), fmax(v[2], v[3]));
+          if constexpr (kSplitK) {
 #pragma unroll
-          for (int i = 0; i < 4; ++i) below[i] = v[i] < tt[i];       // under the mixture's refinement threshold (-inf: never)
+            for (int i = 0; i < NV; ++i) v[i] += t[i];
+          }
+          u = v[0];
+#pragma unroll
+          for (int i = 1; i < NV; ++i) u = fmax(u, v[i]);
+#pragma unroll
+          for (int i = 0; i < NV; ++i) below[i] = v[i] < tt[i];       // under the mixture's refinement threshold (-inf: never)
         } else if (p == 2) {
           u = fmax(u, dpp_perm_f64<0xB1>(u));
         } else if (p == 3) {
           u = fmax(u, dpp_perm_f64<0x4E>(u));
         } else if (p == 4) {
-          if constexpr (LPF == 8) u = fmax(u, dpp_perm_f64<0x141>(u));
+          u = fmax(u, dpp_perm_f64<0x141>(u));
         } else if (p == 5) {
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
+          for (int i = 0; i < NV; ++i) {
             t[i] = fmax(v[i] - u, -1000.0);       // (also maps -inf: slots beyond M, zero weights)
             needl = needl || (below[i] && t[i] > -kRefine);
           }
         } else if (p == 6) {
 #pragma unroll
-          for (int i = 0; i < 4; ++i) kf[i] = rint(t[i] * 92.332482616893656877);
+          for (int i = 0; i < NV; ++i) kf[i] = rint(t[i] * 92.332482616893656877);
         } else if (p == 7) {
 #pragma unroll
-          for (int i = 0; i < 4; ++i) r[i] = fma(kf[i], -1.083042469326756e-02, t[i]);
+          for (int i = 0; i < NV; ++i) r[i] = fma(kf[i], -1.083042469326756e-02, t[i]);
         } else if (p == 8) {
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
+          for (int i = 0; i < NV; ++i) {
             r[i] = fma(kf[i], -2.9815858269852933e-12, r[i]);
             ki[i] = (int)kf[i];
             t[i] = etab[ki[i] & 63];
           }
         } else if (p == 9) {
 #pragma unroll
-          for (int i = 0; i < 4; ++i) pl[i] = vc_fma_sconst(8.333333333333333e-03, r[i], 4.1666666666666664e-02);
+          for (int i = 0; i < NV; ++i) pl[i] = vc_fma_sconst(8.333333333333333e-03, r[i], 4.1666666666666664e-02);
         } else if (p == 10) {
 #pragma unroll
-          for (int i = 0; i < 4; ++i) pl[i] = vc_fma_sconst(pl[i], r[i], 1.6666666666666666e-01);
+          for (int i = 0; i < NV; ++i) pl[i] = vc_fma_sconst(pl[i], r[i], 1.6666666666666666e-01);
         } else if (p == 11) {
 #pragma unroll
-          for (int i = 0; i < 4; ++i) pl[i] = fma(pl[i], r[i], 0.5);
+          for (int i = 0; i < NV; ++i) pl[i] = fma(pl[i], r[i], 0.5);
         } else if (p == 12) {
 #pragma unroll
-          for (int i = 0; i < 4; ++i) pl[i] = fma(pl[i], r[i], 1.0);
+          for (int i = 0; i < NV; ++i) pl[i] = fma(pl[i], r[i], 1.0);
         } else if (p == 13) {
 #pragma unroll
-          for (int i = 0; i < 4; ++i) pl[i] = fma(pl[i], r[i], 1.0);
+          for (int i = 0; i < NV; ++i) pl[i] = fma(pl[i], r[i], 1.0);
         } else if (p == 14) {
 #pragma unroll
-          for (int i = 0; i < 4; ++i) v[i] = ldexp(t[i] * pl[i], ki[i] >> 6);      // exactly 0 below -745
+          for (int i = 0; i < NV; ++i) v[i] = ldexp(t[i] * pl[i], ki[i] >> 6);      // exactly 0 below -745
         } else if (p == 15) {
-          s = (v[0] + v[1]) + (v[2] + v[3]);
+          s = v[0];
+#pragma unroll
+          for (int i = 1; i < NV; ++i) s += v[i];
           s += dpp_perm_f64<0xB1>(s);
         } else if (p == 16) {
           s += dpp_perm_f64<0x4E>(s);
-          if constexpr (LPF == 8) s += dpp_perm_f64<0x141>(s);
+          s += dpp_perm_f64<0x141>(s);
         } else {
           // 1 / s, s in [1, 32]: the hardware's estimate and two Newton steps (the division's scaling and fix-up cases cannot occur)
           const double sc = s > 0.0 ? s : 1.0;
@@ -323,9 +361,9 @@ estep_small_kernel(const double *__restrict__ X, int64_t N, int M, const double 
       };
       constexpr int NP = 18;
 #pragma unroll
-      for (int sl = 0; sl < NS; ++sl) {
+      for (int sl = 0; sl < NSL; ++sl) {
 #pragma unroll
-        for (int p = sl * NP / NS; p < (sl + 1) * NP / NS; ++p) piece(p);
+        for (int p = sl * NP / NSL; p < (sl + 1) * NP / NSL; ++p) piece(p);
         mfma_slot(sl);
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -339,13 +377,19 @@ estep_small_kernel(const double *__restrict__ X, int64_t N, int M, const double 
         ++nslow_;
 #endif
         const double *xf = xs + f * RSX;
-        double vv[4];
+        double vv[NV];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) vv[i] = row[LPF * i];
-        double uu = rowN_max<LPF>(fmax(fmax(vv[0], vv[1]), fmax(vv[2], vv[3])));
+        for (int i = 0; i < NV; ++i) vv[i] = row[LPF * i] + (kSplitK ? row[FB * RSG + LPF * i] : 0.0);
+        auto vmax = [&]() {
+          double m = vv[0];
+#pragma unroll
+          for (int i = 1; i < NV; ++i) m = fmax(m, vv[i]);
+          return rowN_max<LPF>(m);
+        };
+        double uu = vmax();
         const double thr = uu - kRefine;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NV; ++i) {
           const int m = l + LPF * i;
           if (needl && s > 1.0 && vv[i] > thr && vv[i] < tthr[m]) {
             const double *mp = refmu + (size_t)dj * m, *ip = refiv + (size_t)dj * m;
@@ -358,23 +402,23 @@ estep_small_kernel(const double *__restrict__ X, int64_t N, int M, const double 
             vv[i] = refc[2 * m] - 0.5 * q;
           }
         }
-        uu = rowN_max<LPF>(fmax(fmax(vv[0], vv[1]), fmax(vv[2], vv[3])));
+        uu = vmax();
         double ss = 0.0;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NV; ++i) {
           vv[i] = vc_exp_tab(vv[i] - uu, etab);
           ss += vv[i];
         }
         ss = rowN_sum<LPF>(ss);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = vv[i];
+        for (int i = 0; i < NV; ++i) v[i] = vv[i];
         u = uu;
         s = ss;
         inv = (livef && ss > 0.0) ? 1.0 / ss : 0.0;
       }
 #pragma unroll
-      for (int i = 0; i < 4; ++i) row[LPF * i] = v[i] * inv;
-      if (has_next) nmfma += KS;
+      for (int i = 0; i < NV; ++i) row[LPF * i] = v[i] * inv;
+      if (has_next) nmfma += 2 * NSL;
       // log-likelihood: sum of u + log s; the s of a lane's frames (in [1, 32]) are multiplied up, one log per sixteen blocks
       if (l == 0 && livef) {
         llacc += u;
@@ -437,7 +481,7 @@ estep_small_kernel(const double *__restrict__ X, int64_t N, int M, const double 
     // ---- S3: l of the next block into LDS (its responsibilities-to-be), the DMA of the block after it has landed ----
     if (has_next) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) lg[(16 * half + 4 * r + lgrp) * RSG + 16 * tile + lcol] = acc[r] + acc2[r];
+      for (int r = 0; r < 4; ++r) lgA[4 * r * RSG] = acc[r] + acc2[r];
     }
     VCMI_PT(4)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
