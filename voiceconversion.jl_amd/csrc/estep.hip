@@ -417,68 +417,80 @@ estep_mfma_kernel(const double *__restrict__ X, int64_t N, int M, const double *
         //      |mu| ~ 10 its terms reach 1e9 and l carries an absolute error of ~1e-7.  That is harmless while one mixture
         //      owns the frame (gamma = 1 whatever l is) and wrong when several compete: the responsibilities inherit the
         //      error.  So when more than one mixture is within kRefine of the frame's maximum, exactly those are
-        //      re-evaluated term by term, (x - mu)^2 / var summed over d, as the reference formula reads.
-        //      The kernel sits at the register cap: the re-evaluation works on the LDS copy of l with run-time loops
-        //      (nothing of v[] stays live across it) and the softmax then reloads its eight values. ----
-        {
-          constexpr double kRefine = 36.0;   // e^-36 = 2e-16: a mixture further below the maximum cannot change a sum
-          int nc = 0;
-#pragma unroll
-          for (int i = 0; i < C::MMAX / 16; ++i) nc += (v[i] > u - kRefine) ? 1 : 0;
-          nc = row16_sum(nc);
-          // PHASE 3 (one group of 128 of a larger model): a mixture that is alone near the top of ITS group may still compete
-          // with one of another group, which this launch cannot see -- so every value within kRefine of the group's maximum is
-          // made exact, the maximum itself included (a mixture within 36 nats of the frame's maximum over all groups is within
-          // 36 nats of its own group's maximum): cross-group competition then sees exact log-densities too
-          if (nc > (PHASE == 3 ? 0 : 1)) {
-            const double thr = u - kRefine;
-            const double *xf = xs + f * RSX;
-#pragma unroll 1
-            for (int i = 0; i < mtp; ++i) {
-              const double li = row[16 * i];
-              // ... unless the expanded form is provably good enough for this (frame, mixture): li >= the mixture's threshold
-              // (estep_prep_kernel: an error bound of 1e-10 from the value itself -- models with ordinary variances, the
-              // reference's trained ones among them, never take the loop below; the first version did for every competing
-              // pair: 3.8 ms instead of 1.3 per 1.25e6 frames that share their mixtures)
-              if (li > thr && li < tthr[lcol + 16 * i]) {
-                const int m = lcol + 16 * i;
-                const double *mp = refmu + (size_t)dj * m, *ip = refiv + (size_t)dj * m;
-                double q = 0.0;
-#pragma unroll 2
-                for (int d = 0; d < dj; ++d) {
-                  const double df = xf[d] - mp[d];
-                  q = fma(df * df, ip[d], q);
-                }
-                row[16 * i] = refc[2 * m] - 0.5 * q;
-              }
-            }
-            u = -INFINITY;
-#pragma unroll
-            for (int i = 0; i < C::MMAX / 16; ++i) {
-              v[i] = (!SHARE || i < mtp) ? row[16 * i] : -INFINITY;
-              u = fmax(u, v[i]);
-            }
-            u = row16_max(u);
-          }
-        }
+        //      re-evaluated term by term, (x - mu)^2 / var summed over d, as the reference formula reads --
+        //      unless the expanded form is provably good enough for the (frame, mixture): l at or above the mixture's threshold
+        //      (estep_prep_kernel: an error bound of 1e-10 from the value itself; models with ordinary variances, the
+        //      reference's trained ones among them, never re-evaluate anything).
+        //      Round 6: the TEST costs nothing extra on the way -- a compare on the exps' own operand and one against the
+        //      threshold per slot; "several compete" is read off the sum (s > 1: another mixture within ~36 nats) -- and the
+        //      re-evaluation, with a second softmax of the frame, sits behind one wave-uniform branch.  (Before, every frame
+        //      with competing mixtures -- every frame of real joint mel-cepstra -- walked its slots through LDS one by one to
+        //      find nothing: ~150 of a pass's ~400 VALU instructions, each paid for in matrix-pipe time.)
+        constexpr double kRefine = 36.0;     // e^-36 = 2e-16: a mixture further below the maximum cannot change a sum
+        bool needl = false;                  // one of this lane's slots is within kRefine of the maximum and below its threshold
         double s = 0.0;
 #pragma unroll
         for (int i = 0; i < C::MMAX / 16; ++i) {
+          const double dlt = v[i] - u;
+          if (!SHARE || i < mtp) needl = needl || (dlt > -kRefine && v[i] < tthr[lcol + 16 * i]);
 #if VCMI_ESTEP_EXP_SKIP
           // the 16 mixtures of slot group i are hopeless for all four frames of the pass (e^x = 0 below -745.2): no exp at all
-          if (__builtin_amdgcn_ballot_w64(v[i] - u > -745.2) == 0) {
+          if (__builtin_amdgcn_ballot_w64(dlt > -745.2) == 0) {
             v[i] = 0.0;
             continue;
           }
 #endif
-          v[i] = vc_exp_tab(v[i] - u, etab);   // 20 instructions against the 42 of exp(); -inf and < -745 give exactly 0
+          v[i] = vc_exp_tab(dlt, etab);   // 20 instructions against the 42 of exp(); -inf and < -745 give exactly 0
           s += v[i];
         }
         s = row16_sum(s);
+        // PHASE 3 (one group of 128 of a larger model): a mixture that is alone near the top of ITS group may still compete
+        // with one of another group, which this launch cannot see -- so every value within kRefine of the group's maximum is
+        // made exact, the maximum itself included (a mixture within 36 nats of the frame's maximum over all groups is within
+        // 36 nats of its own group's maximum): cross-group competition then sees exact log-densities too
+        const bool need = needl && (PHASE == 3 || s > 1.0);
+        if (__builtin_amdgcn_ballot_w64(need) != 0) {
+          const double thr = u - kRefine;
+          const double *xf = xs + f * RSX;
+#pragma unroll 1
+          for (int i = 0; i < mtp; ++i) {
+            const double li = row[16 * i];           // (still the log-densities: the responsibilities are stored below)
+            if (need && li > thr && li < tthr[lcol + 16 * i]) {
+              const int m = lcol + 16 * i;
+              const double *mp = refmu + (size_t)dj * m, *ip = refiv + (size_t)dj * m;
+              double q = 0.0;
+#pragma unroll 2
+              for (int d = 0; d < dj; ++d) {
+                const double df = xf[d] - mp[d];
+                q = fma(df * df, ip[d], q);
+              }
+              row[16 * i] = refc[2 * m] - 0.5 * q;
+            }
+          }
+          u = -INFINITY;
+#pragma unroll
+          for (int i = 0; i < C::MMAX / 16; ++i) {
+            v[i] = (!SHARE || i < mtp) ? row[16 * i] : -INFINITY;
+            u = fmax(u, v[i]);
+          }
+          u = row16_max(u);
+          s = 0.0;
+#pragma unroll
+          for (int i = 0; i < C::MMAX / 16; ++i) {
+            v[i] = vc_exp_tab(v[i] - u, etab);
+            s += v[i];
+          }
+          s = row16_sum(s);
+        }
         const bool livef = (f0 + f < N);
         // frames beyond N contribute gamma = 0; so does a slot group whose mixtures ALL have zero weight (every l = -inf:
         // u = -inf, s = 0 -- a 128-group of a padded model, M = 129 with w[129] = 0): gamma = 0 and log-sum-exp = -inf, not NaN
-        const double inv = (livef && s > 0.0) ? 1.0 / s : 0.0;
+        // 1 / s, s in [1, 128]: the hardware's estimate and two Newton steps (none of the division's scaling / fix-up cases can occur)
+        const double sc_ = s > 0.0 ? s : 1.0;
+        double rq_ = __builtin_amdgcn_rcp(sc_);
+        rq_ = fma(fma(-sc_, rq_, 1.0), rq_, rq_);
+        rq_ = fma(fma(-sc_, rq_, 1.0), rq_, rq_);
+        const double inv = (livef && s > 0.0) ? rq_ : 0.0;
 #pragma unroll
         for (int i = 0; i < C::MMAX / 16; ++i)
           if (!SHARE || i < mtp) row[16 * i] = v[i] * inv;

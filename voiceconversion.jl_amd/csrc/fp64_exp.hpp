@@ -94,15 +94,17 @@ __device__ __forceinline__ double vc_exp_tab(double x, const double *tab) {
 // row_half_mirror (i <-> 7 - i: joins the two quads of each half) and row_mirror (i <-> 15 - i: joins the halves).  Every
 // lane of the row ends with the same value (the partners add / compare the same two operands).  __shfl_xor compiles to
 // ds_bpermute_b32 pairs with an s_waitcnt each: four LDS round trips per reduction.
+// (The permutations used here -- quad_perm, row_half_mirror, row_mirror -- give every lane a source, so the destination's old
+// value never shows: mov_dpp with bound_ctrl instead of update_dpp(x, x, ...), whose tied operand costs a copy of x per 32-bit
+// half.  Round 6: next to FP64 MFMAs every VALU instruction is paid for in matrix-pipe time)
 template <int CTRL>
 __device__ __forceinline__ double dpp_row_f64(double x) {
-  int lo = __double2loint(x), hi = __double2hiint(x);
-  lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
-  hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
+  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(x), CTRL, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(x), CTRL, 0xF, 0xF, true);
   return __hiloint2double(hi, lo);
 }
 template <int CTRL>
-__device__ __forceinline__ int dpp_row_i32(int x) { return __builtin_amdgcn_update_dpp(x, x, CTRL, 0xF, 0xF, false); }
+__device__ __forceinline__ int dpp_row_i32(int x) { return __builtin_amdgcn_mov_dpp(x, CTRL, 0xF, 0xF, true); }
 __device__ __forceinline__ double row16_max(double x) {
   x = fmax(x, dpp_row_f64<0xB1>(x));
   x = fmax(x, dpp_row_f64<0x4E>(x));
