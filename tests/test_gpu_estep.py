@@ -311,17 +311,28 @@ def test_hard_assignment_path_all_frames_owned(vc, N, Dj, M, sep, zw):
     1e-9; repeat runs bit-identical; dj below the instantiated width, M not a multiple of 16, a mixture without weight."""
     from oracle import c_oracle as co
     w, mu, var, X = _separated_case(N + Dj + M, N, Dj, M, sep, zw)
-    a, o, soft = _both_paths(vc, X, w, mu, var)
+    # (one mixture tile, M <= 16: left to itself the library takes estep_small_kernel whatever the data -- it is as fast as this
+    # path there, and nothing has to be decided; the hard-assignment path is pinned for these cases)
+    a, o, soft = _both_paths(vc, X, w, mu, var, path=vc.ESTEP_HARD if M <= 16 else None)
     assert soft == 0, soft
     for p, q in zip(a[:3], o[:3]):
         assert relerr(p, q) < 1e-12, relerr(p, q)
     assert abs(a[3] - o[3]) < 1e-12 * abs(o[3])
-    b = vc.estep_diag(X.T, w, mu.T, var.T)
+    vc.estep_set_path(vc.ESTEP_HARD if M <= 16 else vc.ESTEP_AUTO)
+    try:
+        b = vc.estep_diag(X.T, w, mu.T, var.T)                # repeat runs of the path: bit-identical
+    finally:
+        vc.estep_set_path(vc.ESTEP_AUTO)
     assert all(np.array_equal(p, q) for p, q in zip(a[:3], b[:3])) and a[3] == b[3]
     r0, r1, r2, rl = co.estep_diag(X, w, mu, var)
     assert relerr(a[0], r0) < TOL and relerr(a[1], r1.T) < TOL and relerr(a[2], r2.T) < TOL
     assert abs(a[3] - rl) < TOL * abs(rl)
     assert abs(a[0].sum() - N) < 1e-6
+    if M <= 16:                                               # the library's own choice for one mixture tile: the FP64 kernel
+        from voiceconversion_jl_amd import _lib
+        c = vc.estep_diag(X.T, w, mu.T, var.T)
+        assert _lib.estep_last_soft() == -1
+        assert all(relerr(p, q) < 1e-12 for p, q in zip(a[:3], c[:3]))
     if zw is not None:
         assert a[0][zw] == 0.0 and not a[1][:, zw].any()
 

@@ -835,6 +835,10 @@ static int estep_mfma_launch(EstepScratch &sc, const double *dX, int64_t N, int 
     // identical inputs give identical bits whatever this thread (or any other) ran before.  vcmi_estep_set_path pins one.
     const int path = debug_flag(kDbgEstepNoHard) ? VCMI_ESTEP_SOFT : estep_path_choice();
     bool hard_on = N >= kHardMinFrames && N < ((int64_t)1 << 31) && M <= kHardMaxM && path != VCMI_ESTEP_SOFT;
+    // One mixture tile (M <= 16, the size bin/train_gmm.jl defaults to): estep_small_kernel takes 0.30 ms per 1.25e6 frames
+    // whatever the data, the hard-assignment path 0.42 where every frame has an owner -- nothing to decide, and the sample screen,
+    // the decision and the gated launches (0.09 ms) are not paid (vcmi_estep_set_path(VCMI_ESTEP_HARD) still takes that path)
+    if (path == VCMI_ESTEP_AUTO && M <= 16 && !debug_flag(kDbgEstepNoSmall)) hard_on = false;
     sc.last_hard = false;
     using CH = EstepHardCfg<DJ>;
     const int MT = (M + 15) / 16, MK = M + 1;
