@@ -872,7 +872,7 @@ static int estep_mfma_launch(EstepScratch &sc, const double *dX, int64_t N, int 
       if (path == VCMI_ESTEP_AUTO)       // the screen on a sample of the call's frames -> the control words
         hipLaunchKernelGGL(kk, dim3((unsigned)(nsample * kSamplePasses)), dim3(kHardKeyThreads), kshmem, st, sc.W16.p, M, dj, dX, N, (int *)nullptr,
                            sc.probe.p, nsample * kSamplePasses, cstride, (const int64_t *)nullptr, 1);
-      hipLaunchKernelGGL(estep_path_decide_kernel, dim3(1), dim3(64), 0, st, sc.probe.p, (int)(nsample * kSamplePasses), MK,
+      hipLaunchKernelGGL(estep_path_decide_kernel, dim3(1), dim3(kDecideThreads), 0, st, sc.probe.p, (int)(nsample * kSamplePasses), MK,
                          path == VCMI_ESTEP_AUTO ? -1 : 1, N, ctl);
       // The hard-assignment path proper: every kernel looks at ctl[kCtlHard] first.  (With the decision left to the device one of
       // the two chains -- these launches, or the one-kernel E-step of every frame -- returns at once, launch by launch, ~4.4 us

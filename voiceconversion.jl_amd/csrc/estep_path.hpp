@@ -21,10 +21,15 @@ enum { kCtlHard = 0, kCtlAllSoft = 1, kCtlNSoft = 2, kCtlLen = 4 };
 
 // decision from the sample's histograms (hist[c][k], k = M: no owner): hard iff at most a quarter of the sample has no owner.
 // force: -1 decide, 0 / 1 set.
-__global__ void estep_path_decide_kernel(const int *__restrict__ hist, int nsample, int MK, int force, int64_t N, int64_t *__restrict__ ctl) {
+// One workgroup of kDecideThreads (the histograms are nsample x MK ints -- 8 K at M = 128: 64 threads took 19 us over them,
+// one dependent load after the other; the sums are integers, so any order gives the same decision).
+constexpr int kDecideThreads = 1024;
+__global__ void __launch_bounds__(kDecideThreads)
+estep_path_decide_kernel(const int *__restrict__ hist, int nsample, int MK, int force, int64_t N, int64_t *__restrict__ ctl) {
+  __shared__ int part[2][kDecideThreads / 64];
   int soft = 0, all = 0;
   if (force < 0) {
-    for (int e = threadIdx.x; e < nsample * MK; e += 64) {
+    for (int e = threadIdx.x; e < nsample * MK; e += kDecideThreads) {
       const int v = hist[e];
       all += v;
       soft += (e % MK == MK - 1) ? v : 0;
@@ -34,8 +39,20 @@ __global__ void estep_path_decide_kernel(const int *__restrict__ hist, int nsamp
       soft += __shfl_xor(soft, sh);
       all += __shfl_xor(all, sh);
     }
+    if ((threadIdx.x & 63) == 0) {
+      part[0][threadIdx.x >> 6] = soft;
+      part[1][threadIdx.x >> 6] = all;
+    }
+    __syncthreads();
   }
   if (threadIdx.x == 0) {
+    if (force < 0) {
+      soft = all = 0;
+      for (int i = 0; i < kDecideThreads / 64; ++i) {
+        soft += part[0][i];
+        all += part[1][i];
+      }
+    }
     const bool hard = force < 0 ? (all > 0 && 4 * (int64_t)soft <= (int64_t)all) : force != 0;
     ctl[kCtlHard] = hard ? 1 : 0;
     ctl[kCtlAllSoft] = hard ? 0 : N;
