@@ -609,12 +609,16 @@ estep_mfma_kernel(const double *__restrict__ X, int64_t N, int M, const double *
     }
   }
   if constexpr (kGamma && PHASE != 3) {   // log-likelihood: fixed-order reduction inside the workgroup (thread 0: tile 0, sub 0)
+    // (butterflies within a wave, then the eight waves in order: a fixed order; thread 0 walking 512 LDS entries took 14 us at
+    // the end of every workgroup)
     llacc += log(sprod);
-    red[tid] = llacc;
+#pragma unroll
+    for (int sh = 1; sh < 64; sh <<= 1) llacc += __shfl_xor(llacc, sh);
+    if (lane == 0) red[wave] = llacc;
     __syncthreads();
     if (tid == 0) {
       double ll = 0.0;
-      for (int i = 0; i < 512; ++i) ll += red[i];
+      for (int i = 0; i < 8; ++i) ll += red[i];
       P[plen - 1] = ll;
     }
   }
