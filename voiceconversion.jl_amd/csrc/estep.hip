@@ -23,6 +23,7 @@
 #include "gmmmap_handle.hpp"
 #include "devgroup.hpp"
 #include "hostpipe.hpp"
+#define VCMI_DPP_NO_COPY 1           // (fp64_exp.hpp: lane permutations without the copy of the old value)
 #include "fp64_exp.hpp"
 #ifndef VCMI_ESTEP_EXP_SKIP
 #define VCMI_ESTEP_EXP_SKIP 1      // wave-uniform skip of the softmax exps of slot groups that are hopeless for the four frames of a pass (A/B: -0.9 %)

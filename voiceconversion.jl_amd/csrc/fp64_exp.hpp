@@ -95,16 +95,34 @@ __device__ __forceinline__ double vc_exp_tab(double x, const double *tab) {
 // lane of the row ends with the same value (the partners add / compare the same two operands).  __shfl_xor compiles to
 // ds_bpermute_b32 pairs with an s_waitcnt each: four LDS round trips per reduction.
 // (The permutations used here -- quad_perm, row_half_mirror, row_mirror -- give every lane a source, so the destination's old
-// value never shows: mov_dpp with bound_ctrl instead of update_dpp(x, x, ...), whose tied operand costs a copy of x per 32-bit
-// half.  Round 6: next to FP64 MFMAs every VALU instruction is paid for in matrix-pipe time)
+// value never shows.  VCMI_DPP_NO_COPY = 1: mov_dpp with bound_ctrl instead of update_dpp(x, x, ...), whose tied operand costs
+// a copy of x per 32-bit half -- the E-step kernels, where every VALU instruction next to the FP64 MFMAs is paid for in
+// matrix-pipe time, define it.  The conversion kernels keep the tied form they were tuned and profiled
+// with: their FP32 / integer permutations sit beside BF16 MFMAs, where nothing was to be gained (346-356 us per 10^6 frames for
+// the screened convert kernel with either form, box by box).)
+#ifndef VCMI_DPP_NO_COPY
+#define VCMI_DPP_NO_COPY 0
+#endif
 template <int CTRL>
 __device__ __forceinline__ double dpp_row_f64(double x) {
+#if VCMI_DPP_NO_COPY
   const int lo = __builtin_amdgcn_mov_dpp(__double2loint(x), CTRL, 0xF, 0xF, true);
   const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(x), CTRL, 0xF, 0xF, true);
+#else
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
+  hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
+#endif
   return __hiloint2double(hi, lo);
 }
 template <int CTRL>
-__device__ __forceinline__ int dpp_row_i32(int x) { return __builtin_amdgcn_mov_dpp(x, CTRL, 0xF, 0xF, true); }
+__device__ __forceinline__ int dpp_row_i32(int x) {
+#if VCMI_DPP_NO_COPY
+  return __builtin_amdgcn_mov_dpp(x, CTRL, 0xF, 0xF, true);
+#else
+  return __builtin_amdgcn_update_dpp(x, x, CTRL, 0xF, 0xF, false);
+#endif
+}
 __device__ __forceinline__ double row16_max(double x) {
   x = fmax(x, dpp_row_f64<0xB1>(x));
   x = fmax(x, dpp_row_f64<0x4E>(x));
