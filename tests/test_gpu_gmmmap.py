@@ -438,7 +438,7 @@ def test_utterance_sized_calls_one_tile_per_wave(vc, T):
     assert np.array_equal(Yh, got[0].cpu().numpy().T) or frame_relerr(Yh, got[0].cpu().numpy().T) < 1e-13
 
 
-@pytest.mark.parametrize("T", [1, 3000, 700_000])
+@pytest.mark.parametrize("T", [1, 3000, 40_000, 700_000])      # 320 B / 960 KB: recorded, not locked; 12.8 MB (heap) / 224 MB (mmap): whole pages locked
 def test_pinned_arrays_take_the_direct_path_and_change_nothing(vc, fixture_model, T):
     """vcmi_host_register (include/vcmi.h): a caller that keeps its arrays pins them once; the host-pointer calls then DMA
     straight from / into them.  Results equal the staged path's, for either side alone and for both (compared to rounding:
